@@ -1,0 +1,66 @@
+"""Parity-test configurations shared by oracle/make_golden.py and tests/.  TEST INFRASTRUCTURE ONLY.
+
+Each entry is a reduced-width instance of one architecture family of SURVEY.md section 8 (same layer
+types, strides, BN placement, skip wiring, mixing and loss options as the README recipes; smaller channel
+counts where the reference lets them be chosen).  The SST encoder/decoder have hard-coded widths
+(conv.py:323-426), so those two configs are full width and their large tensors are pinned by checksum.
+"""
+from oracle.detdata import det_uniform
+
+FULL_LIMIT = 4096      # tensors up to this many elements are stored in full, larger ones as checksums
+
+_L = dict(ae=10.0, s=45.0, t=0.001, pred=45.0)          # options.py:95-102 defaults
+
+CONFIGS = {
+    # Moving-MNIST recipe shape (options.py defaults), reduced widths
+    'dcgan_tiny': dict(architecture='dcgan', shape=[1, 64, 64], nt_cond=3, nt_pred=4, offset=3, B=3,
+                       code_size_s=6, code_size_t=5, enc_hidden_size=4, dec_hidden_size=4, res_hidden_size=8,
+                       n_blocks=1, mixing='concat', last_activation='sigmoid', skipco=False, lambdas=_L, salt=11),
+    # skip connections + multiplicative mixing + offset 0 (forecast-only supervision)
+    'dcgan_skip_mul': dict(architecture='dcgan', shape=[1, 64, 64], nt_cond=2, nt_pred=3, offset=0, B=2,
+                           code_size_s=6, code_size_t=6, enc_hidden_size=4, dec_hidden_size=4, res_hidden_size=8,
+                           n_blocks=2, mixing='mul', last_activation='sigmoid', skipco=True, lambdas=_L, salt=12),
+    # TaxiBJ recipe (README.md:82): vgg32, 2 channels, no last activation
+    'vgg32_tiny': dict(architecture='vgg', shape=[2, 32, 32], nt_cond=2, nt_pred=2, offset=2, B=3,
+                       code_size_s=6, code_size_t=5, enc_hidden_size=4, dec_hidden_size=4, res_hidden_size=8,
+                       n_blocks=1, mixing='concat', last_activation=None, skipco=False,
+                       lambdas=dict(ae=45.0, s=0.0001, t=0.001, pred=45.0), salt=13),
+    'vgg64_skip': dict(architecture='vgg', shape=[1, 64, 64], nt_cond=2, nt_pred=2, offset=2, B=2,
+                       code_size_s=5, code_size_t=4, enc_hidden_size=4, dec_hidden_size=4, res_hidden_size=8,
+                       n_blocks=1, mixing='concat', last_activation='sigmoid', skipco=True, lambdas=_L, salt=14),
+    # WaveEq recipe (README.md:90): mlp, mul mixing, 3 residual blocks, 4-layer decoder
+    'mlp_mul': dict(architecture='mlp', shape=[1, 8, 8], nt_cond=3, nt_pred=5, offset=3, B=5,
+                    code_size_s=8, code_size_t=8, enc_hidden_size=24, dec_hidden_size=24, dec_n_layers=4,
+                    res_hidden_size=16, n_blocks=3, mixing='mul', last_activation='sigmoid', skipco=False,
+                    lambdas=dict(ae=1.0, s=45.0, t=0.001, pred=45.0), salt=15),
+    # WaveEq-100 recipe (README.md:94): 2-D data shape [1, n_points], concat mixing
+    'mlp_concat_partial': dict(architecture='mlp', shape=[1, 10], nt_cond=2, nt_pred=3, offset=2, B=4,
+                               code_size_s=6, code_size_t=4, enc_hidden_size=20, dec_hidden_size=12,
+                               res_hidden_size=16, n_blocks=1, mixing='concat', last_activation='sigmoid',
+                               skipco=False, lambdas=_L, salt=16),
+    # --no_s (main.py:124-129): constant S, lamb_t forced to 0 (train.py:99-101)
+    'mlp_no_s': dict(architecture='mlp', shape=[1, 6, 6], nt_cond=2, nt_pred=3, offset=2, B=3, no_s=True,
+                     code_size_s=5, code_size_t=5, enc_hidden_size=16, dec_hidden_size=16, res_hidden_size=8,
+                     n_blocks=1, mixing='mul', last_activation='sigmoid', skipco=False, lambdas=_L, salt=17),
+    # SST recipe (README.md:86): conv integrator, skip decoder, offset 0, averaged t-loss
+    'sst_skip': dict(architecture='encoderSST', decoder_architecture='decoderSST', shape=[1, 64, 64], nt_cond=2,
+                     nt_pred=2, offset=0, B=2, code_size_s=12, code_size_t=8, enc_hidden_size=64,
+                     dec_hidden_size=64, res_hidden_size=16, n_blocks=2, mixing='concat', last_activation=None,
+                     skipco=True, average_tloss=True, data_range='normal',
+                     lambdas=dict(ae=1.0, s=100.0, t=5e-6, pred=45.0), salt=18),
+    'sst_noskip': dict(architecture='encoderSST', decoder_architecture='decoderSST', shape=[1, 64, 64], nt_cond=2,
+                       nt_pred=2, offset=0, B=2, code_size_s=10, code_size_t=6, enc_hidden_size=64,
+                       dec_hidden_size=64, res_hidden_size=8, n_blocks=1, mixing='concat', last_activation=None,
+                       skipco=False, average_tloss=True, data_range='normal',
+                       lambdas=dict(ae=1.0, s=100.0, t=5e-6, pred=45.0), salt=19),
+}
+
+
+def make_batch(cfg):
+    """(cond, target) of the dataset's shape: U[0,1) frames, or roughly z-scored (U-0.5)*3 for SST."""
+    B, shape = cfg['B'], list(cfg['shape'])
+    cond = det_uniform([B, cfg['nt_cond']] + shape, cfg['salt'] * 31 + 1)
+    target = det_uniform([B, cfg['nt_pred']] + shape, cfg['salt'] * 31 + 2)
+    if cfg.get('data_range') == 'normal':
+        cond, target = (cond - 0.5) * 3.0, (target - 0.5) * 3.0
+    return cond, target

@@ -1,0 +1,49 @@
+"""CPU: the oracle (oracle/cpu_ref.py) reproduces the vectors the REFERENCE produced (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+from oracle.detdata import det_fill
+from oracle.golden_configs import CONFIGS, make_batch
+from golden_util import load_golden, check_tensor
+
+TOL = 1e-5          # fp32 CPU vs fp32 CPU; bit-exact in the build container, slack for other BLAS builds
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_oracle_matches_reference_step(name):
+    cfg = CONFIGS[name]
+    gold = load_golden(name)
+    torch.manual_seed(0)
+    cond, target = make_batch(cfg)
+    net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=cfg.get('lr', 4e-4), betas=(0.9, 0.99))
+    lam = cfg['lambdas']
+    lamb_t = 0 if cfg.get('no_s') else lam['t']
+    total, terms, forecasts, t_codes = cpu_ref.training_losses(
+        cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], cfg.get('skipco', False), lam['ae'],
+        lam['s'], lamb_t, lam['pred'], average_tloss=bool(cfg.get('average_tloss')),
+        t_random=int(gold['t_random']))
+    assert abs(total.item() - float(gold['total'])) <= TOL * abs(float(gold['total']))
+    for k, v in terms.items():
+        assert abs(v.item() - float(gold['loss:' + k])) <= TOL * max(abs(float(gold['loss:' + k])), 1e-6), k
+    check_tensor(gold, 'forecasts', forecasts, TOL)
+    check_tensor(gold, 't_codes', t_codes, TOL)
+    opt.zero_grad()
+    total.backward()
+    for k, p in net.named_parameters():
+        check_tensor(gold, 'grad:' + k, p.grad, 2e-5)
+    opt.step()
+    for k, v in net.state_dict().items():
+        check_tensor(gold, 'after:' + k, v.float(), TOL)
+
+
+def test_t_random_comes_from_global_numpy_rng():
+    """train.py:72-75: the window end is np.random.randint(nt_cond, T [+1 if offset != 0])."""
+    cfg = CONFIGS['mlp_mul']
+    gold = load_golden('mlp_mul')
+    np.random.seed(cfg.get('np_seed', 1234))
+    hi = cfg['nt_cond'] + cfg['nt_pred'] + (0 if cfg['offset'] == 0 else 1)
+    assert int(np.random.randint(cfg['nt_cond'], hi)) == int(gold['t_random'])
