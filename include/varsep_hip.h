@@ -1,0 +1,123 @@
+/*
+ * varsep_hip.h -- C ABI of libvarsep_hip.so: the MI355X (gfx950) kernels behind the var_sep training
+ * hot path (encoders E_s/E_t -> residual latent integrator -> decoder D, forward and backward).
+ *
+ * The reference (JeremieDona/spatiotemporal_variable_separation) has no native layer: every numeric
+ * op on this path is a stock torch.nn call that lands in ATen.  The entry
+ * points below are therefore what a maintainer would bind in place of those ATen calls; each one
+ * cites the reference call site(s) it replaces (paths relative to /root/reference/var_sep).
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (torch); the library never allocates,
+ *     frees or keeps a pointer after the call returns; workspaces are passed in explicitly;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and is legal inside hipGraph stream capture (no allocation, no synchronisation);
+ *   - return value: VS_OK (0) or a negative VS_ERR_* code; nothing throws; vs_last_error() returns a
+ *     static description of the most recent failure on the calling thread;
+ *   - matrices are row-major; tensors are NCHW contiguous unless a leading dimension is given;
+ *   - dtype codes: VS_F32 = 0, VS_BF16 = 1.  "Compute type" selects the MFMA family: VS_F32 runs the
+ *     exact-fp32 v_mfma_f32_32x32x2_f32 path (parity mode, <=1e-3 vs the fp32 CPU oracle is met with
+ *     orders of magnitude to spare), VS_BF16 runs v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+ */
+#ifndef VARSEP_HIP_H
+#define VARSEP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_OK 0
+#define VS_ERR_ARG (-1)       /* bad argument (null pointer, negative size, unsupported enum) */
+#define VS_ERR_WORKSPACE (-2) /* workspace too small: call the matching *_workspace_bytes query */
+#define VS_ERR_LAUNCH (-3)    /* hipLaunchKernel failed; see vs_last_error() */
+#define VS_ERR_UNSUPPORTED (-4)
+
+#define VS_F32 0
+#define VS_BF16 1
+
+/* activation codes (networks/utils.py:50-72 activation_factory) */
+#define VS_ACT_NONE 0
+#define VS_ACT_RELU 1
+#define VS_ACT_LEAKY 2 /* LeakyReLU(0.2) */
+#define VS_ACT_SIGMOID 3
+#define VS_ACT_TANH 4
+#define VS_ACT_ELU 5
+
+/* operand layouts of vs_gemm: element (i, k) of an operand with leading dimension ld lives at
+ *   VS_LAYOUT_R : ptr[i * ld + k]   (reduction index k contiguous)
+ *   VS_LAYOUT_S : ptr[k * ld + i]   (output index i contiguous)                                    */
+#define VS_LAYOUT_R 0
+#define VS_LAYOUT_S 1
+
+const char* vs_version(void);
+const char* vs_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * vs_gemm: C[m, n] = epilogue( sum_k A(m, k) * B(n, k) ),  m < M, n < N, k < K.
+ *
+ * Replaces the dense contractions of the path:
+ *   nn.Linear forward            networks/mlp.py:40, networks/conv.py:124        A=x (R), B=W[out,in] (R)
+ *   nn.Linear input gradient     (autograd of the above)                          A=dy (R), B=W (S)
+ *   nn.Linear weight gradient    (autograd of the above)                          A=dy (S), B=x (S)
+ *   ConvTranspose2d k4 s1 p0 on a 1x1 map (conv.py:258,295) and Conv2d k4 valid on a 4x4 map
+ *   (conv.py:170), which are plain GEMMs over flattened weights.
+ *
+ * Epilogue, applied in this order to the fp32 accumulator v of element (m, n):
+ *   v *= alpha;  v += bias[n] (if bias);  v = act(v);
+ *   v *= act'(mask[m*ldmask+n]) (if mask: derivative of `mask_act` evaluated from its OUTPUT value --
+ *        1/0 for ReLU, 1/0.2 for LeakyReLU, y(1-y) for sigmoid, 1-y^2 for tanh; fuses the activation
+ *        backward of the previous layer into the input-gradient GEMM);
+ *   v += C_old[m, n] (if accumulate);  store as c_dtype.
+ *
+ * compute: VS_F32 (A, B stored fp32) or VS_BF16 (A, B stored bf16).  c_dtype / mask_dtype: VS_F32|VS_BF16.
+ * Any M, N, K >= 1 and any ld are accepted (unaligned shapes take a scalar load path).
+ * workspace: only used when the library chooses split-K (few output tiles, long K); query
+ * vs_gemm_workspace_bytes(M, N, K) for an upper bound.  May be NULL when that bound is 0.
+ */
+size_t vs_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+
+int vs_gemm(int compute, int64_t M, int64_t N, int64_t K,
+            const void* A, int64_t lda, int layout_a,
+            const void* B, int64_t ldb, int layout_b,
+            void* C, int64_t ldc, int c_dtype,
+            float alpha, const float* bias, int act,
+            const void* mask, int64_t ldmask, int mask_dtype, int mask_act,
+            int accumulate,
+            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise / reduction helpers around the GEMMs.
+ */
+
+/* dst[i] = (dst_dtype) src[i], i < n.  fp32 master weights -> bf16 shadow copies, input frames -> bf16. */
+int vs_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+/* Strided 2-D copy with conversion: dst[r*ldd + c] = src[r*lds + c], r < rows, c < cols.
+ * Used to cut the encoder's temporal window out of the [B, T, C*H*W] frame tensor without a
+ * host-side slice (train.py:76 full_data[:, t_random - nt_cond : t_random]); when `col_offset_dev`
+ * is non-NULL the source column offset is *col_offset_dev * col_offset_scale, read on the device, so
+ * a captured hipGraph stays valid when the random window moves.                                      */
+int vs_copy2d(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd,
+              int64_t rows, int64_t cols, const int32_t* col_offset_dev, int64_t col_offset_scale, void* stream);
+
+/* out[n] (+)= sum_m X[m*ldx + n]  (fp32 out).  Bias gradient of nn.Linear / conv (autograd of
+ * mlp.py:40).  `accumulate` = 0 overwrites.  Internally zeroes/accumulates with float atomics over row
+ * blocks, so results can differ in the last bits between runs (documented in DESIGN.md).            */
+int vs_colsum(const void* X, int x_dtype, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate,
+              void* stream);
+
+/* dz[i] = dy[i] * act'(y[i]) evaluated from the activation OUTPUT y (see vs_gemm mask semantics).
+ * Backward of the trailing activation of a chain (mlp_encdec.py:49 last_activation, conv.py:230).  */
+int vs_act_bwd(const void* dy, int dy_dtype, const void* y, int y_dtype, void* dz, int dz_dtype, int act,
+               int64_t n, void* stream);
+
+/* y[i] = act(x[i]) (out of place or in place).  networks/utils.py:50-72.                             */
+int vs_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, int act, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VARSEP_HIP_H */

@@ -1,0 +1,131 @@
+"""ctypes binding of libvarsep_hip.so (C ABI declared in include/varsep_hip.h).
+
+The library is built in-tree by `build_library()` (hipcc, --offload-arch=gfx950) and loaded lazily.  There is
+no CPU fallback: if the shared object is missing or a call fails, the product path raises.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_HERE, 'libvarsep_hip.so')
+SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_fused.hip']
+
+F32, BF16 = 0, 1
+ACT = {'none': 0, None: 0, 'identity': 0, 'relu': 1, 'leaky_relu': 2, 'sigmoid': 3, 'tanh': 4, 'elu': 5}
+LAYOUT_R, LAYOUT_S = 0, 1
+
+_lib = None
+
+
+class VarsepHipError(RuntimeError):
+    pass
+
+
+def _sources():
+    return [os.path.join(_CSRC, s) for s in SOURCES if os.path.exists(os.path.join(_CSRC, s))]
+
+
+def library_is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = _sources() + [os.path.join(_CSRC, 'vs_common.h'), os.path.join(_HERE, '..', 'include', 'varsep_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into libvarsep_hip.so (cross-compiles without a GPU)."""
+    if not force and not library_is_stale():
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objdir = os.path.join(_HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + '.o')
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
+                os.path.getmtime(src), os.path.getmtime(os.path.join(_CSRC, 'vs_common.h')),
+                os.path.getmtime(os.path.join(_HERE, '..', 'include', 'varsep_hip.h'))):
+            return obj
+        cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise VarsepHipError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
+        if verbose:
+            print('compiled', os.path.basename(src), file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, _sources()))
+    tmp = LIB_PATH + '.tmp'
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise VarsepHipError('link failed:\n' + r.stderr[-4000:])
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+_i64, _i32, _f32, _vp, _sz = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/varsep_hip.h
+SIGNATURES = {
+    'vs_version': (ctypes.c_char_p, []),
+    'vs_last_error': (ctypes.c_char_p, []),
+    'vs_gemm_workspace_bytes': (_sz, [_i64, _i64, _i64]),
+    'vs_gemm': (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _f32, _vp, _i32,
+                       _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    'vs_cast': (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
+    'vs_copy2d': (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp]),
+    'vs_colsum': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
+    'vs_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),
+    'vs_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _vp]),
+}
+
+
+def load_library():
+    """dlopen the in-tree library and attach argtypes; raises VarsepHipError when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VarsepHipError(
+            'libvarsep_hip.so is missing (%s). Build it with `python -c "import __graft_entry__ as g; g.build()"`; '
+            'there is no CPU fallback for the HIP path.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise VarsepHipError('%s failed (%d): %s' % (what, rc, load_library().vs_last_error().decode()))
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise VarsepHipError('unsupported tensor dtype %s' % t.dtype)
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise VarsepHipError('the HIP path needs tensors on an MI355X device (got a %s tensor); there is no CPU '
+                                 'fallback -- use oracle/cpu_ref.py in tests for CPU results' % t.device)

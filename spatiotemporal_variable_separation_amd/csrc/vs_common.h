@@ -1,0 +1,65 @@
+// Shared device/host helpers for libvarsep_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/varsep_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define VS_WAVE 64
+
+extern thread_local char vs_err_buf[256];
+int vs_fail(int code, const char* fmt, ...);
+
+#define VS_CHECK_ARG(cond, ...)                        \
+    do {                                               \
+        if (!(cond)) return vs_fail(VS_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define VS_CHECK_LAUNCH(what)                                                            \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- scalar load/store with dtype dispatch (dtype is wave-uniform) -------------------------------
+__device__ __forceinline__ float vs_ld(const void* p, int dtype, int64_t i) {
+    return dtype == VS_F32 ? ((const float*)p)[i] : (float)((const __bf16*)p)[i];
+}
+__device__ __forceinline__ void vs_st(void* p, int dtype, int64_t i, float v) {
+    if (dtype == VS_F32) ((float*)p)[i] = v;
+    else ((__bf16*)p)[i] = (__bf16)v;
+}
+
+// ---- activations (networks/utils.py:50-72) ---------------------------------------------------------
+__device__ __forceinline__ float vs_act(float v, int act) {
+    switch (act) {
+        case VS_ACT_RELU: return v > 0.f ? v : 0.f;
+        case VS_ACT_LEAKY: return v > 0.f ? v : 0.2f * v;
+        case VS_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case VS_ACT_TANH: return tanhf(v);
+        case VS_ACT_ELU: return v > 0.f ? v : (__expf(v) - 1.f);
+        default: return v;
+    }
+}
+// derivative of the activation expressed through its OUTPUT y (what the forward pass kept)
+__device__ __forceinline__ float vs_act_grad_from_out(float y, int act) {
+    switch (act) {
+        case VS_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case VS_ACT_LEAKY: return y > 0.f ? 1.f : 0.2f;
+        case VS_ACT_SIGMOID: return y * (1.f - y);
+        case VS_ACT_TANH: return 1.f - y * y;
+        case VS_ACT_ELU: return y > 0.f ? 1.f : (y + 1.f);
+        default: return 1.f;
+    }
+}
+
+static inline int64_t vs_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

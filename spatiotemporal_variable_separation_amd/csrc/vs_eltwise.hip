@@ -1,0 +1,134 @@
+// vs_eltwise.hip -- HBM-bound helpers around the GEMMs: casts, strided window copy, bias-gradient column
+// sums, activation forward/backward.  All are grid-stride kernels with 16-byte accesses on the contiguous
+// path (8 bf16 / 4 fp32 per lane), capped at 2048 workgroups of 256 threads (8 per CU on 256 CUs).
+#include <stdarg.h>
+#include "vs_common.h"
+
+thread_local char vs_err_buf[256] = "";
+
+int vs_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(vs_err_buf, sizeof(vs_err_buf), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* vs_last_error(void) { return vs_err_buf; }
+extern "C" const char* vs_version(void) { return "varsep_hip 0.1 (gfx950)"; }
+
+namespace {
+
+inline unsigned grid_for(int64_t work_items) {
+    int64_t b = vs_cdiv(work_items, 256);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// 4 consecutive elements per thread per iteration
+template <class F>
+__device__ __forceinline__ void map4(const void* x, int xd, void* y, int yd, int64_t n, F f) {
+    const int64_t n4 = n / 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float v[4];
+        if (xd == VS_F32) { f32x4 t = ((const f32x4*)x)[i]; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+        else { bf16x4 t = ((const bf16x4*)x)[i]; v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = f(v[j], i * 4 + j);
+        if (yd == VS_F32) { f32x4 t = {v[0], v[1], v[2], v[3]}; ((f32x4*)y)[i] = t; }
+        else { bf16x4 t = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; ((bf16x4*)y)[i] = t; }
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        vs_st(y, yd, i, f(vs_ld(x, xd, i), i));
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const void* src, int sd, void* dst, int dd, int64_t n) {
+    map4(src, sd, dst, dd, n, [](float v, int64_t) { return v; });
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const void* x, int xd, void* y, int yd, int act, int64_t n) {
+    map4(x, xd, y, yd, n, [act](float v, int64_t) { return vs_act(v, act); });
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const void* dy, int dyd, const void* y, int yd, void* dz, int dzd, int act,
+                                                      int64_t n) {
+    map4(dy, dyd, dz, dzd, n, [=](float g, int64_t i) { return g * vs_act_grad_from_out(vs_ld(y, yd, i), act); });
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const void* src, int sd, int64_t lds, void* dst, int dd, int64_t ldd,
+                                                     int64_t rows, int64_t cols, const int32_t* off_dev, int64_t off_scale) {
+    const int64_t off = off_dev ? (int64_t)(*off_dev) * off_scale : 0;
+    const int64_t total = rows * cols;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cols, c = idx % cols;
+        vs_st(dst, dd, r * ldd + c, vs_ld(src, sd, r * lds + off + c));
+    }
+}
+
+// column sums: block (bx, by) reduces rows [by*RB, by*RB+RB) of columns [bx*64, bx*64+64) and adds with one atomic per column
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_kernel(const void* X, int xd, int64_t ldx, int64_t M, int64_t N, float* out) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    int64_t r1 = r0 + CS_ROWS;
+    if (r1 > M) r1 = M;
+    float s = 0.f;
+    if (n < N)
+        for (int64_t r = r0 + g; r < r1; r += 4) s += vs_ld(X, xd, r * ldx + n);
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+
+}  // namespace
+
+extern "C" int vs_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
+    VS_CHECK_ARG(src && dst && n >= 0, "vs_cast: bad argument");
+    VS_CHECK_ARG((sd == VS_F32 || sd == VS_BF16) && (dd == VS_F32 || dd == VS_BF16), "vs_cast: bad dtype");
+    if (n == 0) return VS_OK;
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, sd, dst, dd, n);
+    VS_CHECK_LAUNCH("vs_cast");
+    return VS_OK;
+}
+
+extern "C" int vs_act_fwd(const void* x, int xd, void* y, int yd, int act, int64_t n, void* stream) {
+    VS_CHECK_ARG(x && y && n >= 0, "vs_act_fwd: bad argument");
+    if (n == 0) return VS_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, xd, y, yd, act, n);
+    VS_CHECK_LAUNCH("vs_act_fwd");
+    return VS_OK;
+}
+
+extern "C" int vs_act_bwd(const void* dy, int dyd, const void* y, int yd, void* dz, int dzd, int act, int64_t n, void* stream) {
+    VS_CHECK_ARG(dy && y && dz && n >= 0, "vs_act_bwd: bad argument");
+    if (n == 0) return VS_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, dyd, y, yd, dz, dzd, act, n);
+    VS_CHECK_LAUNCH("vs_act_bwd");
+    return VS_OK;
+}
+
+extern "C" int vs_copy2d(const void* src, int sd, int64_t lds, void* dst, int dd, int64_t ldd, int64_t rows, int64_t cols,
+                         const int32_t* col_offset_dev, int64_t col_offset_scale, void* stream) {
+    VS_CHECK_ARG(src && dst && rows >= 0 && cols >= 0, "vs_copy2d: bad argument");
+    if (rows * cols == 0) return VS_OK;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, src, sd, lds, dst, dd, ldd,
+                       rows, cols, col_offset_dev, col_offset_scale);
+    VS_CHECK_LAUNCH("vs_copy2d");
+    return VS_OK;
+}
+
+extern "C" int vs_colsum(const void* X, int xd, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate, void* stream) {
+    VS_CHECK_ARG(X && out && M > 0 && N > 0 && ldx >= N, "vs_colsum: bad argument");
+    if (!accumulate) {
+        if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return vs_fail(VS_ERR_LAUNCH, "vs_colsum: memset failed");
+    }
+    dim3 grid((unsigned)vs_cdiv(N, 64), (unsigned)vs_cdiv(M, CS_ROWS));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, xd, ldx, M, N, out);
+    VS_CHECK_LAUNCH("vs_colsum");
+    return VS_OK;
+}

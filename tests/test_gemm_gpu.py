@@ -1,0 +1,100 @@
+"""GPU parity of vs_gemm (through the C ABI) against an fp64 CPU contraction of the same operands.
+
+Tolerances: compute=f32 runs the exact-fp32 MFMA (k-ordered fmaf chain) -> 2e-6 relative L2;
+compute=bf16 multiplies bf16 operands exactly and accumulates in fp32 -> 2e-6 relative L2 against the fp64
+product of the bf16-rounded operands (the rounding of the INPUTS is the caller's choice, not the kernel's).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(128, 128, 64), (100, 70, 50), (7, 5, 3), (33, 200, 20), (300, 1200, 1200), (256, 1200, 4104),
+          (128, 96, 20480), (1000, 64, 257), (64, 4096, 1200)]
+
+
+def _operand(rows, K, layout, dtype, salt):
+    from oracle.detdata import det_uniform
+    x = (det_uniform((rows, K), salt) - 0.5) * 2.0
+    x = x.to(dtype)
+    dev = x.cuda()
+    return x.double(), (dev if layout == 0 else dev.t().contiguous())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('la,lb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_gemm_layouts(dtype, la, lb, shape):
+    from spatiotemporal_variable_separation_amd import ops
+    M, N, K = shape
+    a64, a = _operand(M, K, la, dtype, 3)
+    b64, b = _operand(N, K, lb, dtype, 5)
+    out = ops.gemm(a, la, b, lb, M, N, K)
+    torch.cuda.synchronize()
+    ref = a64 @ b64.t()
+    err = ((out.cpu().double() - ref).norm() / ref.norm()).item()
+    assert err < 2e-6, f'{dtype} layouts ({la},{lb}) shape {shape}: rel err {err:.3e}'
+
+
+def test_gemm_integer_exact_asymmetric():
+    """A = shifted identity-like, B asymmetric integers: any row/col swap or k permutation bug shows up exactly."""
+    from spatiotemporal_variable_separation_amd import ops
+    M, N, K = 96, 160, 72
+    a = torch.zeros(M, K)
+    for m in range(M):
+        a[m, (m * 5 + 1) % K] = 1.0
+        a[m, (m * 3) % K] += 2.0
+    b = (torch.arange(N).view(N, 1) * 3 + torch.arange(K).view(1, K) * 7) % 13 - 6.0
+    ref = a @ b.t()
+    for dtype in (torch.float32, torch.bfloat16):
+        for la in (0, 1):
+            for lb in (0, 1):
+                aa = a.to(dtype).cuda()
+                bb = b.to(dtype).cuda()
+                aa = aa if la == 0 else aa.t().contiguous()
+                bb = bb if lb == 0 else bb.t().contiguous()
+                out = ops.gemm(aa, la, bb, lb, M, N, K).cpu()
+                assert torch.equal(out, ref), f'{dtype} ({la},{lb}) max diff {(out - ref).abs().max()}'
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gemm_epilogue(dtype):
+    from spatiotemporal_variable_separation_amd import ops
+    from oracle.detdata import det_uniform
+    M, N, K = 200, 144, 88
+    a = ((det_uniform((M, K), 1) - 0.5)).to(dtype)
+    b = ((det_uniform((N, K), 2) - 0.5)).to(dtype)
+    bias = det_uniform((N,), 3) - 0.5
+    mask = (det_uniform((M, N), 4) - 0.3).to(dtype)
+    prev = det_uniform((M, N), 5)
+    z = 0.5 * (a.double() @ b.double().t()) + bias.double()
+    for act, fn in [('relu', torch.relu), ('leaky_relu', lambda t: torch.nn.functional.leaky_relu(t, 0.2)),
+                    ('sigmoid', torch.sigmoid), ('none', lambda t: t), ('tanh', torch.tanh)]:
+        out = ops.gemm(a.cuda(), 0, b.cuda(), 0, M, N, K, alpha=0.5, bias=bias.cuda(), act=act)
+        ref = fn(z)
+        assert ((out.cpu().double() - ref).norm() / ref.norm()).item() < 3e-6, act
+    # mask (ReLU / LeakyReLU derivative from the stored output) + accumulate + bf16 output
+    out = prev.clone().cuda()
+    ops.gemm(a.cuda(), 0, b.cuda(), 0, M, N, K, out=out, mask=mask.cuda(), mask_act='leaky_relu', accumulate=True)
+    md = mask.double()
+    ref = prev.double() + (a.double() @ b.double().t()) * torch.where(md > 0, 1.0, 0.2)
+    assert ((out.cpu().double() - ref).norm() / ref.norm()).item() < 3e-6
+    out16 = ops.gemm(a.cuda(), 0, b.cuda(), 0, M, N, K, out_dtype=torch.bfloat16, mask=mask.cuda(), mask_act='relu')
+    ref = (a.double() @ b.double().t()) * (md > 0)
+    assert ((out16.cpu().double() - ref).norm() / ref.norm()).item() < 4e-3     # one bf16 rounding of the output
+
+
+def test_colsum_cast_act():
+    from spatiotemporal_variable_separation_amd import ops
+    from oracle.detdata import det_uniform
+    x = det_uniform((777, 130), 9) - 0.5
+    for dt in (torch.float32, torch.bfloat16):
+        xd = x.to(dt)
+        s = ops.colsum(xd.cuda(), 777, 130).cpu()
+        assert torch.allclose(s, xd.float().sum(0), rtol=1e-5, atol=1e-4)
+    c = ops.cast(x.cuda(), torch.bfloat16).cpu()
+    assert torch.equal(c, x.to(torch.bfloat16))
+    y = ops.act_fwd(x.cuda(), 'sigmoid').cpu()
+    assert torch.allclose(y, torch.sigmoid(x), rtol=1e-6, atol=1e-6)
+    g = ops.act_bwd(x.cuda(), y.cuda(), 'sigmoid').cpu()
+    assert torch.allclose(g, x * y * (1 - y), rtol=1e-5, atol=1e-7)

@@ -1,0 +1,52 @@
+"""Micro-benchmark of vs_gemm on the WaveEq (config 2) shapes.  Usage: python tools/gemm_bench.py [bf16|f32]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spatiotemporal_variable_separation_amd import ops  # noqa: E402
+
+dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
+SHAPES = [  # (name, M, N, K, la, lb)
+    ('dec fwd 1200->4096', 3328, 4096, 1200, 0, 0),
+    ('dec fwd 1200->1200', 3328, 1200, 1200, 0, 0),
+    ('dec dgrad 4096->1200', 3328, 1200, 4096, 0, 1),
+    ('dec wgrad 4096x1200', 4096, 1200, 3328, 1, 1),
+    ('dec wgrad 1200x1200', 1200, 1200, 3328, 1, 1),
+    ('enc fwd 20480->1200', 256, 1200, 20480, 0, 0),
+    ('enc wgrad 1200x20480', 1200, 20480, 256, 1, 1),
+    ('square 4096', 4096, 4096, 4096, 0, 0),
+    ('square 4096 SS', 4096, 4096, 4096, 1, 1),
+]
+for name, M, N, K, la, lb in SHAPES:
+    a = (torch.rand((M, K) if la == 0 else (K, M), device='cuda') - 0.5).to(dt)
+    b = (torch.rand((N, K) if lb == 0 else (K, N), device='cuda') - 0.5).to(dt)
+    out = torch.empty((M, N), device='cuda', dtype=torch.float32)
+    for _ in range(3):
+        ops.gemm(a, la, b, lb, M, N, K, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 20
+    e0.record()
+    for _ in range(iters):
+        ops.gemm(a, la, b, lb, M, N, K, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    # torch (hipBLASLt) for orientation only
+    ta = a if la == 0 else a.t()
+    tb = b if lb == 0 else b.t()
+    for _ in range(3):
+        torch.matmul(ta, tb.t())
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        torch.matmul(ta, tb.t())
+    e1.record()
+    torch.cuda.synchronize()
+    ms_t = e0.elapsed_time(e1) / iters
+    fl = 2.0 * M * N * K
+    print(f'{name:24s} {str(dt)[6:]:9s} M={M:5d} N={N:5d} K={K:5d}  vs_gemm {ms * 1e3:8.1f} us {fl / ms / 1e9:8.1f} TF/s   '
+          f'[torch.matmul {ms_t * 1e3:8.1f} us {fl / ms_t / 1e9:8.1f} TF/s]')
