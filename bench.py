@@ -1,0 +1,196 @@
+"""Headline benchmark: training frames/s of the var_sep hot path on MI355X (contract in the task statement).
+
+    python bench.py --gpus N --steps K --warmup W [--config waveeq] [--precision bf16]
+
+One step = ae_loss + zero_order_loss + get_forecast + forecast MSE + t-regulariser, backward, gradient all-reduce
+(N > 1) and the Adam update, on one seeded synthetic batch per rank that is resident in HBM before timing starts.
+`value` = N * batch * nt_pred / step time (whole-job predicted frames per second).  Default workload = BASELINE.json
+configs[1] (WaveEq MLP, bf16), the configuration the metric is quoted on that fits one GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--config', default='waveeq')
+    p.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    p.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
+    p.add_argument('--no_cpu_baseline', action='store_true')
+    p.add_argument('--cpu_steps', type=int, default=None)
+    return p.parse_args()
+
+
+def dense_flops_and_bytes(net, cfg, esize):
+    """Algorithmic forward FLOPs / fused bytes per step (sum over Linear/conv calls of 2*MACs and
+    (|in|+|W|+|out|)*esize), measured with forward hooks on the product modules' parameter holders is not possible
+    (they are never called), so dense layers are counted analytically for the MLP family."""
+    B, n = cfg['batch'], cfg['nt_pred'] + cfg['offset']
+    calls = {'Es': 2 * B, 'Et': 2 * B, 'decoder': (n + 1) * B, 't_resnet': (n - 1) * B}
+    fl = by = 0.0
+    import torch.nn as nn
+    for name, rows in calls.items():
+        mod = getattr(net, name)
+        for m in mod.modules():
+            if isinstance(m, nn.Linear):
+                fl += 2.0 * rows * m.in_features * m.out_features
+                by += (rows * m.in_features + m.in_features * m.out_features + rows * m.out_features) * esize
+    return fl, by
+
+
+def cpu_baseline(cfg, steps):
+    """Time the CPU oracle (plain PyTorch fp32 restatement of the reference) on the host cores, same workload."""
+    from oracle import cpu_ref
+    from spatiotemporal_variable_separation_amd.data.synthetic import synthetic_batch
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    ocfg = dict(cfg)
+    net = cpu_ref.build_sep_net(ocfg)
+    net.train()
+    cond, target = synthetic_batch(cfg['data'], cfg['batch'], cfg['nt_cond'], cfg['nt_pred'], seed=1234)
+    lam = cfg['lambdas']
+    opt = torch.optim.Adam(net.parameters(), lr=4e-4, betas=(0.9, 0.99))
+
+    def step():
+        opt.zero_grad()
+        total, _, _, _ = cpu_ref.training_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'],
+                                                 cfg.get('skipco', False), lam['ae'], lam['s'], lam['t'], lam['pred'],
+                                                 average_tloss=bool(cfg.get('average_tloss')))
+        total.backward()
+        opt.step()
+    step()
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    dt = (time.time() - t0) / steps
+    return {'value': cfg['batch'] * cfg['nt_pred'] / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': f'{steps} full training steps of the same workload (batch {cfg["batch"]}, '
+            f'fp32, torch CPU, {torch.get_num_threads()} threads of {os.cpu_count()} logical CPUs), 1 warm-up',
+            'ms_per_step': dt * 1e3}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from spatiotemporal_variable_separation_amd import functional as VF, ops
+    from spatiotemporal_variable_separation_amd.configs import BASELINE_CONFIGS
+    from spatiotemporal_variable_separation_amd.data.synthetic import synthetic_batch
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.parallel import GradAllReducer, broadcast_module_state
+    from spatiotemporal_variable_separation_amd.train import compute_losses
+
+    cfg = dict(BASELINE_CONFIGS[args.config])
+    if args.batch:
+        cfg['batch'] = args.batch
+    torch.manual_seed(1234)
+    np.random.seed(1234)                     # same t_random sequence on every rank
+    net = build_sep_net(cfg).to(dev)
+    net.train()
+    if world > 1:
+        broadcast_module_state(net)
+    sync = GradAllReducer(net.parameters()) if world > 1 else None
+    opt = torch.optim.Adam(net.parameters(), lr=4e-4, betas=(0.9, 0.99), fused=True)
+    cond, target = synthetic_batch(cfg['data'], cfg['batch'], cfg['nt_cond'], cfg['nt_pred'], device=dev,
+                                   seed=1234 + rank)
+    lam = cfg['lambdas']
+    VF.set_precision(args.precision)
+
+    def step():
+        if sync is not None:
+            sync.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        total, _, _, _ = compute_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'],
+                                        cfg.get('skipco', False), lam['ae'], lam['s'], lam['t'], lam['pred'],
+                                        average_tloss=bool(cfg.get('average_tloss')))
+        total.backward()
+        if sync is not None:
+            sync.all_reduce()
+        opt.step()
+        return total
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ops.profile_reset(enable=True)           # HIP-event pairs around every vs_* launch of the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_collect()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    frames = world * cfg['batch'] * cfg['nt_pred']
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    # dominant kernel of the timed region (largest summed event time) and its roofline position
+    roof = None
+    if prof:
+        name, rec = max(prof.items(), key=lambda kv: kv[1]['ms'])
+        if rec['flops'] > 0:
+            peak = 2500.0 if args.precision == 'bf16' else 157.3
+            ach = rec['flops'] / (rec['ms'] * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 4), 'traffic': None, 'launches_per_step': rec['n'] / args.steps,
+                    'avg_launch_us': round(rec['ms'] * 1e3 / rec['n'], 2),
+                    'share_of_step': round(rec['ms'] / (ms * args.steps), 3)}
+        else:
+            ach = rec['bytes'] / (rec['ms'] * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'kernel': name, 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': round(ach / 8000.0, 4), 'traffic': None, 'launches_per_step': rec['n'] / args.steps,
+                    'avg_launch_us': round(rec['ms'] * 1e3 / rec['n'], 2),
+                    'share_of_step': round(rec['ms'] / (ms * args.steps), 3)}
+    out = {
+        'metric': 'training frames/sec (seq x nt_pred)', 'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': f'{args.config}: {cfg["architecture"]} enc/dec, batch {cfg["batch"]}/GPU, '
+                               f'nt_cond {cfg["nt_cond"]}, nt_pred {cfg["nt_pred"]}, offset {cfg["offset"]}',
+                   'global_batch': world * cfg['batch'], 'parallelism': f'dp{world}', 'optimizer': 'Adam (torch fused)',
+                   'final_loss': round(float(loss.item()), 5)},
+        'roofline': roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        steps = args.cpu_steps or (5 if args.config in ('waveeq', 'mnist_b16') else 2)
+        out['cpu_baseline'] = cpu_baseline(cfg, steps)
+        out['cpu_baseline']['value'] = round(out['cpu_baseline']['value'], 1)
+        out['cpu_baseline']['ms_per_step'] = round(out['cpu_baseline']['ms_per_step'], 1)
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

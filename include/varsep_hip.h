@@ -117,6 +117,47 @@ int vs_act_bwd(const void* dy, int dy_dtype, const void* y, int y_dtype, void* d
 /* y[i] = act(x[i]) (out of place or in place).  networks/utils.py:50-72.                             */
 int vs_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, int act, int64_t n, void* stream);
 
+/* dst[c*rows + r] = (dst_dtype) src[r*cols + c]: transposed (and converted) weight copies for the backward rollout. */
+int vs_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * vs_mlp_rollout_{fwd,bwd}: the residual latent integrator rolled over time in one persistent launch.
+ *
+ * Replaces the python loop of SeparableNetwork.get_forecast (networks/model.py:78-83) around
+ * MLPResnet.forward / MLPResBlock.forward (networks/resnet.py:22-50):
+ *     for t in 1..n-1:  for b in blocks:  r = W3_b relu(W2_b relu(W1_b x + b1_b) + b2_b) + b3_b ;  x = x + r
+ * Forward:
+ *   x0        [B, C] fp32         initial temporal code (E_t output)
+ *   weights   host array of 3*n_blocks device pointers {W1 [H,C], W2 [H,H], W3 [C,H]} per block, each PRE-PACKED by
+ *             vs_pack_rollout_weight in the compute type;  biases: host array of 3*n_blocks fp32 device pointers
+ *   t_codes   [B, n, C] fp32      every code of the rollout, t_codes[:, 0] = x0 (the layout get_forecast returns)
+ *   residuals [n-1, n_blocks, B, C] fp32 or NULL   (the `t_residuals` the reference returns)
+ *   xin_save [nb, n-1, B, C], h1_save / h2_save [nb, n-1, B, H]  compute type: inputs of the weight-gradient GEMMs
+ * Backward (through time):
+ *   grad_t_codes [B, n, C] fp32   gradient wrt every code;  weights_t: host array of 3*n_blocks device pointers
+ *             {W3^T [H,C], W2^T [H,H], W1^T [C,H]} per block, packed with vs_pack_rollout_weight(transpose = 1)
+ *   dx0 [B, C] fp32; dr_save [nb, n-1, B, C], dh2_save / dh1_save [nb, n-1, B, H] compute type.
+ *   Weight gradients are then vs_gemm(dh1_save[b] (S), xin_save[b] (S)) etc. with K = (n-1)*B, bias gradients
+ *   vs_colsum of the same buffers.
+ * One workgroup per 16 batch rows; no inter-workgroup communication; results are bitwise reproducible.
+ * Limits: n_blocks <= 8; LDS footprint (grows with H) must fit 160 KiB (H <= ~2048 in bf16).
+ */
+/* Pre-pack of one integrator weight for the rollout kernels: the logical matrix L[N][K] (L = src if transpose == 0,
+ * with src fp32 [N,K];  L = src^T if transpose == 1, with src fp32 [K,N]) is converted to the compute type and laid
+ * out in MFMA-fragment order, one contiguous 1 KiB piece per (16-column tile, k-step), zero padded, so that every
+ * wave-level weight load of the rollout is a single fully coalesced 1 KiB read.  dst must hold
+ * vs_rollout_packed_elems(compute, N, K) elements of the compute type.  Re-run after each optimizer step.          */
+size_t vs_rollout_packed_elems(int compute, int N, int K);
+int vs_pack_rollout_weight(int compute, const float* src, int transpose, int N, int K, void* dst, void* stream);
+
+int vs_mlp_rollout_fwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* x0,
+                       const void* const* weights, const float* const* biases, float* t_codes, float* residuals,
+                       void* xin_save, void* h1_save, void* h2_save, void* stream);
+
+int vs_mlp_rollout_bwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* grad_t_codes,
+                       const void* const* weights_t, const void* h1_save, const void* h2_save, float* dx0,
+                       void* dr_save, void* dh2_save, void* dh1_save, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,11 @@ SIGNATURES = {
     'vs_colsum': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     'vs_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     'vs_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _vp]),
+    'vs_transpose_cast': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    'vs_rollout_packed_elems': (_sz, [_i32, _i32, _i32]),
+    'vs_pack_rollout_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'vs_mlp_rollout_fwd': (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'vs_mlp_rollout_bwd': (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

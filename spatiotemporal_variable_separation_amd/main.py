@@ -1,0 +1,128 @@
+"""Training entry point: `python -m spatiotemporal_variable_separation_amd.main --xp_dir ... --data_dir ...`
+(reference: main.py:49-162, same flags; `--data_dir synthetic` selects seeded synthetic batches)."""
+import json
+import os
+
+import numpy as np
+import torch
+import torch.optim.lr_scheduler as lr_scheduler
+from torch import optim
+from torch.utils.data import DataLoader
+
+from . import functional as VF
+from .data.synthetic import SyntheticSequences, data_shape, LAST_ACTIVATION
+from .networks.factory import get_encoder, get_decoder, get_resnet
+from .networks.model import SeparableNetwork
+from .networks.utils import ConstantS
+from .options import parser
+from .parallel import GradAllReducer, broadcast_module_state
+from .train import train
+
+
+def load_dataset(args):
+    """Real datasets are loaded through the user's `var_sep.data` package when it is importable (they are host-side
+    code outside this package); `--data_dir synthetic` needs nothing."""
+    if args.data_dir == 'synthetic':
+        return SyntheticSequences(args.data, args.nt_cond, args.nt_pred, length=args.synthetic_len,
+                                  seed=args.seed or 1234, n_wave_points=args.n_wave_points)
+    try:
+        if args.data == 'mnist':
+            from var_sep.data.moving_mnist import MovingMNIST
+            return MovingMNIST.make_dataset(args.data_dir, 64, args.nt_cond, args.nt_cond + args.nt_pred, 4, True,
+                                            args.n_object, True)
+        if args.data == 'chairs':
+            from var_sep.data.chairs import Chairs
+            return Chairs(True, args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred)
+        if args.data == 'taxibj':
+            from var_sep.data.taxibj import TaxiBJ
+            return TaxiBJ.make_datasets(args.data_dir, len_closeness=args.nt_cond + args.nt_pred,
+                                        nt_cond=args.nt_cond)[0]
+        if args.data == 'sst':
+            from var_sep.data.sst import SST
+            return SST(args.data_dir, args.nt_cond, args.nt_pred, True, zones=args.zones)
+        if args.data == 'wave':
+            from var_sep.data.wave_eq import WaveEq
+            return WaveEq(args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred, True, args.downsample)
+        from var_sep.data.wave_eq import WaveEqPartial
+        return WaveEqPartial(args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred, True, args.downsample,
+                             args.n_wave_points)
+    except ImportError as e:
+        raise ImportError('dataset loaders are host-side code outside this package: put the reference\'s `var_sep` '
+                          'package on PYTHONPATH, or pass --data_dir synthetic (%s)' % e)
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    os.environ['OMP_NUM_THREADS'] = str(args.num_workers)
+
+    # one process per GPU; under torchrun LOCAL_RANK selects the device
+    rank, world = 0, 1
+    if args.ddp:
+        import torch.distributed as dist
+        dist.init_process_group('nccl')
+        rank, world = dist.get_rank(), dist.get_world_size()
+        args.device = int(os.environ.get('LOCAL_RANK', 0))
+    if args.device is None:
+        raise RuntimeError('the MI355X-native path has no CPU mode: pass --device N (or --ddp under torchrun)')
+    device = torch.device('cuda', args.device)
+    torch.cuda.set_device(device)
+
+    seed = np.random.randint(0, 10000) if args.seed is None else args.seed
+    torch.manual_seed(seed)
+    np.random.seed(seed)            # identical on every rank: one t_random per global step
+
+    if args.data == 'wave_partial':
+        assert args.architecture not in ['dcgan', 'vgg']
+    shape = data_shape(args.data, args.n_wave_points)
+    last_activation = LAST_ACTIVATION[args.data]
+    train_set = load_dataset(args)
+
+    if rank == 0:
+        os.makedirs(args.xp_dir, exist_ok=True)
+        with open(os.path.join(args.xp_dir, 'params.json'), 'w') as f:
+            json.dump(vars(args), f, indent=4, sort_keys=True)
+
+    def worker_init_fn(worker_id):
+        np.random.seed((torch.randint(100000, []).item() + worker_id))
+    sampler = None
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True, seed=seed)
+    train_loader = DataLoader(train_set, batch_size=args.batch_size, pin_memory=True, shuffle=sampler is None,
+                              sampler=sampler, num_workers=args.num_workers, worker_init_fn=worker_init_fn)
+
+    if not args.no_s:
+        Es = get_encoder(args.architecture, shape, args.code_size_s, args.enc_hidden_size, args.enc_n_layers,
+                         args.nt_cond, args.init_encoder, args.gain_encoder).to(device)
+    else:
+        assert not args.skipco
+        args.code_size_s = args.code_size_t
+        args.mixing = 'mul'
+        Es = ConstantS(return_value=1, code_size=args.code_size_s).to(device)
+    Et = get_encoder(args.architecture, shape, args.code_size_t, args.enc_hidden_size, args.enc_n_layers,
+                     args.nt_cond, args.init_encoder, args.gain_encoder).to(device)
+    decoder = get_decoder(args.architecture if args.decoder_architecture is None else args.decoder_architecture,
+                          shape, args.code_size_t, args.code_size_s, last_activation, args.dec_hidden_size,
+                          args.dec_n_layers, args.mixing, args.skipco, args.init_encoder, args.gain_encoder).to(device)
+    t_resnet = get_resnet(args.code_size_t, args.n_blocks, args.res_hidden_size, args.init_resnet, args.gain_resnet,
+                          args.architecture == 'encoderSST').to(device)
+    sep_net = SeparableNetwork(Es, Et, t_resnet, decoder, args.nt_cond, args.skipco)
+
+    grad_sync = None
+    if world > 1:
+        broadcast_module_state(sep_net)
+        grad_sync = GradAllReducer(sep_net.parameters())
+
+    optimizer = optim.Adam(sep_net.parameters(), lr=args.lr, betas=(args.beta1, args.beta2))
+    scheduler = lr_scheduler.MultiStepLR(optimizer, args.scheduler_milestones, gamma=args.scheduler_decay) \
+        if args.scheduler else None
+
+    VF.set_precision(args.precision or ('bf16' if args.torch_amp else 'fp32'))
+    train(args.xp_dir if rank == 0 else os.path.join(args.xp_dir, f'rank{rank}'), train_loader, device, sep_net,
+          optimizer, scheduler, args.apex_amp, args.torch_amp, args.epochs, args.lamb_ae, args.lamb_s, args.lamb_t,
+          args.lamb_pred, args.offset, args.nt_cond, args.nt_pred, args.no_s, args.skipco, args.chkpt_interval,
+          args.architecture == 'encoderSST', grad_sync=grad_sync, log_interval=args.log_interval)
+
+
+if __name__ == "__main__":
+    main()

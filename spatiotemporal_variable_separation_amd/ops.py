@@ -6,6 +6,46 @@ from ._lib import F32, BF16, ACT, LAYOUT_R, LAYOUT_S, check, dtype_code, stream_
 
 _ws_cache = {}
 
+# ---- optional per-launch timing with HIP events on the launch stream (bench.py: roofline of the dominant kernel) ----
+_PROF = {'on': False, 'events': []}
+_LNAME = {0: 'R', 1: 'S'}
+
+
+def profile_reset(enable=True):
+    _PROF['on'] = enable
+    _PROF['events'] = []
+
+
+def _pb():
+    if not _PROF['on']:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _pe(e0, name, flops=0.0, nbytes=0.0):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    _PROF['events'].append((name, e0, e1, flops, nbytes))
+
+
+def profile_collect():
+    """{kernel family: {'ms': summed event time, 'n': launches, 'flops': algorithmic FLOPs, 'bytes': algorithmic bytes}}"""
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1, fl, by in _PROF['events']:
+        r = out.setdefault(name, {'ms': 0.0, 'n': 0, 'flops': 0.0, 'bytes': 0.0})
+        r['ms'] += e0.elapsed_time(e1)
+        r['n'] += 1
+        r['flops'] += fl
+        r['bytes'] += by
+    _PROF['on'] = False
+    _PROF['events'] = []
+    return out
+
 
 def _workspace(nbytes, device):
     """One grow-only split-K workspace per device (allocated by torch, so legal inside graph capture after warm-up)."""
@@ -39,11 +79,14 @@ def gemm(a, layout_a, b, layout_b, M, N, K, out=None, out_dtype=torch.float32, a
     ws = _workspace(ws_bytes, a.device) if ws_bytes else None
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous()
+    e0 = _pb()
     check(lib.vs_gemm(compute, M, N, K, a.data_ptr(), lda, layout_a, b.data_ptr(), ldb, layout_b, out.data_ptr(),
                       out.stride(0), dtype_code(out), float(alpha), _ptr(bias), ACT[act], _ptr(mask),
                       mask.stride(0) if mask is not None else 0, dtype_code(mask) if mask is not None else 0,
                       ACT[mask_act], int(bool(accumulate)), _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()),
           'vs_gemm')
+    _pe(e0, 'vs_gemm<%s,%s%s>' % ('bf16' if compute == BF16 else 'f32', _LNAME[layout_a], _LNAME[layout_b]),
+        flops=2.0 * M * N * K, nbytes=float((M * K + N * K) * a.element_size() + M * N * out.element_size()))
     return out
 
 
@@ -92,3 +135,84 @@ def act_bwd(dy, y, act, out_dtype=None):
     check(_lib.load_library().vs_act_bwd(dy.data_ptr(), dtype_code(dy), y.data_ptr(), dtype_code(y), out.data_ptr(),
                                          dtype_code(out), ACT[act], dy.numel(), stream_ptr()), 'vs_act_bwd')
     return out
+
+
+def transpose_cast(src, dtype, out=None):
+    """out[c, r] = src[r, c] converted to `dtype` (2-D, contiguous)."""
+    require_cuda(src)
+    assert src.dim() == 2 and src.is_contiguous()
+    rows, cols = src.shape
+    if out is None:
+        out = torch.empty((cols, rows), dtype=dtype, device=src.device)
+    check(_lib.load_library().vs_transpose_cast(src.data_ptr(), dtype_code(src), out.data_ptr(), dtype_code(out), rows,
+                                                cols, stream_ptr()), 'vs_transpose_cast')
+    return out
+
+
+def _ptr_array(tensors):
+    import ctypes
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def pack_rollout_weight(w, dtype, transpose, out=None):
+    """fp32 master weight [rows, cols] -> packed MFMA-fragment order in `dtype` (logical L = w or w^T)."""
+    require_cuda(w)
+    assert w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32
+    N, K = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    lib = _lib.load_library()
+    code = BF16 if dtype == torch.bfloat16 else F32
+    n = lib.vs_rollout_packed_elems(code, N, K)
+    if out is None:
+        out = torch.empty((n,), dtype=dtype, device=w.device)
+    check(lib.vs_pack_rollout_weight(code, w.data_ptr(), int(bool(transpose)), N, K, out.data_ptr(), stream_ptr()),
+          'vs_pack_rollout_weight')
+    return out
+
+
+def mlp_rollout_fwd(x0, weights, biases, n_steps, H, want_residuals=True):
+    """weights: packed [W1,W2,W3]*n_blocks in the compute dtype; biases fp32.  Returns (t_codes, residuals, saves)."""
+    import ctypes
+    require_cuda(x0)
+    B, C = x0.shape
+    nb = len(weights) // 3
+    cdt, dev = weights[0].dtype, x0.device
+    t_codes = torch.empty((B, n_steps, C), dtype=torch.float32, device=dev)
+    steps = max(n_steps - 1, 0)
+    residuals = torch.empty((steps, nb, B, C), dtype=torch.float32, device=dev) if want_residuals else None
+    xin = torch.empty((nb, steps, B, C), dtype=cdt, device=dev)
+    h1 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
+    h2 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
+    wa, ba = _ptr_array(weights), _ptr_array(biases)
+    e0 = _pb()
+    check(_lib.load_library().vs_mlp_rollout_fwd(dtype_code(weights[0]), B, C, H, nb, n_steps, x0.data_ptr(),
+                                                 ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
+                                                 t_codes.data_ptr(), _ptr(residuals), xin.data_ptr(), h1.data_ptr(),
+                                                 h2.data_ptr(), stream_ptr()), 'vs_mlp_rollout_fwd')
+    fl = 2.0 * B * steps * nb * (2 * C * H + H * H)
+    _pe(e0, 'vs_mlp_rollout_fwd<%s>' % ('bf16' if cdt == torch.bfloat16 else 'f32'), flops=fl)
+    return t_codes, residuals, (xin, h1, h2)
+
+
+def mlp_rollout_bwd(grad_t_codes, weights_t, h1, h2, n_steps):
+    """weights_t: packed [W3^T, W2^T, W1^T]*n_blocks (compute dtype).  Returns (dx0, dr, dh2, dh1)."""
+    import ctypes
+    require_cuda(grad_t_codes)
+    B, n, C = grad_t_codes.shape
+    nb = len(weights_t) // 3
+    H = h1.shape[-1]
+    cdt, dev = weights_t[0].dtype, grad_t_codes.device
+    steps = max(n_steps - 1, 0)
+    dx0 = torch.empty((B, C), dtype=torch.float32, device=dev)
+    dr = torch.empty((nb, steps, B, C), dtype=cdt, device=dev)
+    dh2 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
+    dh1 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
+    wa = _ptr_array(weights_t)
+    e0 = _pb()
+    check(_lib.load_library().vs_mlp_rollout_bwd(dtype_code(weights_t[0]), B, C, H, nb, n_steps, grad_t_codes.data_ptr(),
+                                                 ctypes.cast(wa, ctypes.c_void_p), h1.data_ptr(), h2.data_ptr(),
+                                                 dx0.data_ptr(), dr.data_ptr(), dh2.data_ptr(), dh1.data_ptr(),
+                                                 stream_ptr()), 'vs_mlp_rollout_bwd')
+    fl = 2.0 * B * steps * nb * (2 * C * H + H * H)
+    _pe(e0, 'vs_mlp_rollout_bwd<%s>' % ('bf16' if cdt == torch.bfloat16 else 'f32'), flops=fl)
+    return dx0, dr, dh2, dh1

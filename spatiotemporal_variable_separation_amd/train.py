@@ -1,0 +1,113 @@
+"""Training loop and losses of the hot path (reference: train.py:38-175); same function names and arguments."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .utils.helper import save
+
+
+def zero_order_loss(s_code_old, s_code_new, skipco):
+    """Mean squared difference between the spatial codes of the first and last windows (train.py:38-42)."""
+    if skipco:
+        s_code_old = torch.cat([s_code_old[0].flatten()] + [x.flatten() for x in s_code_old[1]])
+        s_code_new = torch.cat([s_code_new[0].flatten()] + [x.flatten() for x in s_code_new[1]])
+    return (s_code_old - s_code_new).pow(2).mean()
+
+
+def ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=None):
+    """Auto-encoding loss (train.py:45-88).  Returns (loss, s_code_new, s_code_old).
+
+    `t_random` is drawn from the global NumPy RNG exactly like the reference unless given (additive argument)."""
+    full_data = torch.cat([cond, target], dim=1)
+    data_new = full_data[:, -nt_cond:]
+    data_old = full_data[:, :nt_cond]
+    s_code_old = sep_net.Es(data_old, return_skip=skipco)
+    s_code_new = sep_net.Es(data_new, return_skip=skipco)
+    if t_random is None:
+        if offset == 0:
+            t_random = np.random.randint(nt_cond, full_data.size(1))
+        else:
+            t_random = np.random.randint(nt_cond, full_data.size(1) + 1)
+    t_code_random = sep_net.Et(full_data[:, t_random - nt_cond:t_random])
+    if skipco:
+        reconstruction = sep_net.decoder(s_code_old[0], t_code_random, skip=s_code_old[1])
+    else:
+        reconstruction = sep_net.decoder(s_code_old, t_code_random)
+    supervision_data = full_data[:, t_random - offset]
+    loss = F.mse_loss(supervision_data, reconstruction, reduction='mean')
+    return loss, s_code_new, s_code_old
+
+
+def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb_ae, lamb_s, lamb_t, lamb_pred,
+                   average_tloss=False, t_random=None):
+    """The four loss terms and their weighted sum for one batch (train.py:117-149).
+
+    Returns (total, {'ae','zero','pred','t_reg'}, forecasts, t_codes)."""
+    assert offset == nt_cond or offset == 0
+    ae_loss_value, s_recent, s_old = ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=t_random)
+    spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
+    full_data = torch.cat([cond, target], dim=1)
+    forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_s_code=s_old)
+    forecast_offset = nt_cond if offset == 0 else 0
+    forecast_loss = F.mse_loss(forecasts, full_data[:, forecast_offset:])
+    if average_tloss:
+        t_reg = 0.5 * (t_codes[:, 0].pow(2).view(full_data.shape[0], -1)).mean()
+    else:
+        t_reg = 0.5 * torch.sum(t_codes[:, 0].pow(2), dim=1).mean()
+    total_loss = lamb_ae * ae_loss_value + lamb_s * spatial_ode_loss + lamb_pred * forecast_loss + lamb_t * t_reg
+    terms = {'ae': ae_loss_value, 'zero': spatial_ode_loss, 'pred': forecast_loss, 't_reg': t_reg}
+    return total_loss, terms, forecasts, t_codes
+
+
+def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_amp, use_torch_amp, epochs, lamb_ae,
+          lamb_s, lamb_t, lamb_pred, offset, nt_cond, nt_pred, no_s, skipco, chkpt_interval, average_tloss,
+          grad_sync=None, log_interval=None):
+    """Same 20 positional arguments as the reference's `train` (train.py:91-92).
+
+    Additive keyword arguments: `grad_sync` (a `parallel.GradAllReducer`, data-parallel gradient averaging over
+    RCCL) and `log_interval` (print losses / frames-per-second every N steps).  `use_apex_amp` is rejected (no
+    Apex on the MI355X path); `use_torch_amp` selects the bf16 compute mode, which needs no loss scaler.
+    """
+    import time
+    from . import functional as VF
+    if use_apex_amp:
+        raise ImportError('Apex is not part of the MI355X-native path; use --torch_amp (bf16 MFMA, fp32 master weights)')
+    if use_torch_amp:
+        VF.set_precision('bf16')
+    if no_s:
+        lamb_t = 0
+        print("No regularization on T as there is no S")
+    assert offset == nt_cond or offset == 0
+
+    step, t_last = 0, time.time()
+    try:
+        for epoch in range(epochs):
+            sep_net.train()
+            for cond, target in train_loader:
+                cond, target = cond.to(device, non_blocking=True), target.to(device, non_blocking=True)
+                if grad_sync is not None:
+                    grad_sync.zero_grad()            # gradients are views into flat all-reduce buckets
+                else:
+                    optimizer.zero_grad()
+                total_loss, terms, _, _ = compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco,
+                                                         lamb_ae, lamb_s, lamb_t, lamb_pred, average_tloss)
+                total_loss.backward()
+                if grad_sync is not None:
+                    grad_sync.all_reduce()
+                optimizer.step()
+                step += 1
+                if log_interval and step % log_interval == 0:
+                    torch.cuda.synchronize()
+                    dt = time.time() - t_last
+                    t_last = time.time()
+                    world = grad_sync.world_size if grad_sync is not None else 1
+                    fps = log_interval * cond.shape[0] * nt_pred * world / dt
+                    print(f'epoch {epoch} step {step}: total {total_loss.item():.5f} ' +
+                          ' '.join(f'{k} {v.item():.5f}' for k, v in terms.items()) + f' | {fps:.0f} frames/s')
+            if scheduler is not None:
+                scheduler.step()
+            if chkpt_interval is not None and (epoch + 1) % chkpt_interval == 0:
+                save(xp_dir, sep_net, epoch_number=epoch + 1)
+    except KeyboardInterrupt:
+        pass
+    save(xp_dir, sep_net)

@@ -1,0 +1,104 @@
+"""Shared driver for step-level parity: one training step on the HIP path vs the CPU oracle, same inputs."""
+import torch
+
+from oracle import cpu_ref
+from oracle.detdata import det_fill
+from oracle.golden_configs import make_batch
+from golden_util import rel_err
+
+
+def oracle_step(cfg, t_random):
+    cond, target = make_batch(cfg)
+    net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    net.train()
+    lam = cfg['lambdas']
+    lamb_t = 0 if cfg.get('no_s') else lam['t']
+    total, terms, forecasts, t_codes = cpu_ref.training_losses(
+        cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], cfg.get('skipco', False), lam['ae'],
+        lam['s'], lamb_t, lam['pred'], average_tloss=bool(cfg.get('average_tloss')), t_random=t_random)
+    total.backward()
+    return net, total, terms, forecasts, t_codes
+
+
+def hip_step(cfg, t_random, oracle_net, precision='fp32'):
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.train import compute_losses
+    cond, target = make_batch(cfg)
+    net = build_sep_net(cfg)
+    # identical parameters AND a check that the state-dict layout matches the reference-compatible oracle
+    sd = {k: v.clone() for k, v in oracle_net.state_dict().items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    net.train()
+    lam = cfg['lambdas']
+    lamb_t = 0 if cfg.get('no_s') else lam['t']
+    with VF.precision(precision):
+        total, terms, forecasts, t_codes = compute_losses(
+            cond.cuda(), target.cuda(), net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], cfg.get('skipco', False),
+            lam['ae'], lam['s'], lamb_t, lam['pred'], average_tloss=bool(cfg.get('average_tloss')), t_random=t_random)
+        total.backward()
+    torch.cuda.synchronize()
+    return net, total, terms, forecasts, t_codes
+
+
+def emulated_bf16_step(cfg, t_random):
+    """The fp32 oracle with the product's bf16 rounding points patched in (oracle/bf16_emu.py)."""
+    from oracle.bf16_emu import emulate_bf16
+    with emulate_bf16():
+        return oracle_step(cfg, t_random)
+
+
+def compare_step_bf16(cfg, t_random, tol=2e-3, sanity=0.6):
+    """bf16 mode: (1) must match the CPU emulation of its own rounding scheme to `tol` relative L2 (accumulation-order
+    noise only); (2) must stay within a loose `sanity` bound of the fp32 oracle (reported, the networks are tiny)."""
+    o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, 'bf16')
+    e_net, e_total, e_terms, e_fore, e_tc = emulated_bf16_step(cfg, t_random)
+    o_net, o_total, o_terms, o_fore, o_tc = oracle_step(cfg, t_random)
+
+    def errors(r_net, r_total, r_fore, r_tc):
+        rg = dict(r_net.named_parameters())
+        return {'forecasts': rel_err(h_fore.detach().cpu(), r_fore.detach()),
+                't_codes': rel_err(h_tc.detach().cpu(), r_tc.detach()),
+                'total': abs(h_total.item() - r_total.item()) / abs(r_total.item()),
+                'grad_worst': max(rel_err(p.grad.detach().cpu(), rg[k].grad) for k, p in h_net.named_parameters())}
+    vs_emu = errors(e_net, e_total, e_fore, e_tc)
+    vs_fp32 = errors(o_net, o_total, o_fore, o_tc)
+    for k, v in vs_emu.items():
+        assert v <= tol, f'{k}: HIP bf16 vs bf16-emulating oracle {v:.3e} > {tol:.1e}'
+    for k, v in vs_fp32.items():
+        assert v <= sanity, f'{k}: HIP bf16 vs fp32 oracle {v:.3e} > sanity bound {sanity}'
+    return vs_emu, vs_fp32
+
+
+def compare_step(cfg, t_random, precision, tol_out, tol_grad, fresh_oracle=None):
+    """Returns a dict of worst relative errors; asserts against the tolerances."""
+    o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])          # pristine weights for the HIP net
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision)
+    o_net, o_total, o_terms, o_fore, o_tc = oracle_step(cfg, t_random)
+    errs = {'forecasts': rel_err(h_fore.detach().cpu(), o_fore.detach()),
+            't_codes': rel_err(h_tc.detach().cpu(), o_tc.detach()),
+            'total': abs(h_total.item() - o_total.item()) / abs(o_total.item())}
+    for k in o_terms:
+        errs['loss:' + k] = abs(h_terms[k].item() - o_terms[k].item()) / max(abs(o_terms[k].item()), 1e-8)
+    for k in ('forecasts', 't_codes', 'total') + tuple('loss:' + k for k in o_terms):
+        assert errs[k] <= tol_out, f'{k}: {errs[k]:.3e} > {tol_out:.1e} ({precision})'
+    og = dict(o_net.named_parameters())
+    worst_g, worst_name = 0.0, None
+    for k, p in h_net.named_parameters():
+        assert p.grad is not None, f'no gradient for {k}'
+        e = rel_err(p.grad.detach().cpu(), og[k].grad)
+        if e > worst_g:
+            worst_g, worst_name = e, k
+    errs['grad_worst'] = worst_g
+    assert worst_g <= tol_grad, f'gradient {worst_name}: {worst_g:.3e} > {tol_grad:.1e} ({precision})'
+    # BN running statistics after the step (per-call updates)
+    osd = o_net.state_dict()
+    for k, v in h_net.state_dict().items():
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            e = rel_err(v.detach().cpu(), osd[k])
+            assert e <= tol_out, f'{k}: {e:.3e}'
+        if k.endswith('num_batches_tracked'):
+            assert int(v) == int(osd[k]), k
+    return errs

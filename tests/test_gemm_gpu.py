@@ -98,3 +98,50 @@ def test_colsum_cast_act():
     assert torch.allclose(y, torch.sigmoid(x), rtol=1e-6, atol=1e-6)
     g = ops.act_bwd(x.cuda(), y.cuda(), 'sigmoid').cpu()
     assert torch.allclose(g, x * y * (1 - y), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dims', [(5, 8, 16, 3, 6), (128, 32, 512, 3, 25), (37, 20, 512, 1, 15), (16, 4, 8, 1, 2), (3, 5, 8, 2, 1)])
+def test_fused_rollout_equals_stepwise(precision, dims):
+    """vs_mlp_rollout_{fwd,bwd} against the same recurrence run block by block through MLPChain (same kernels'
+    rounding points): codes, residuals, input gradient and every weight gradient."""
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.resnet import MLPResnet
+    from oracle.detdata import det_uniform
+    B, C, H, nb, n = dims
+    torch.manual_seed(0)
+    net = MLPResnet(C, nb, H).cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(0.5)
+    x0 = (det_uniform((B, C), 7) - 0.5).cuda()
+    g = (det_uniform((B, n, C), 8) - 0.5).cuda()
+    with VF.precision(precision):
+        xa = x0.clone().requires_grad_(True)
+        codes_f, res_f = net.rollout(xa, n)
+        (codes_f * g).sum().backward()
+        grads_f = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        dxa = xa.grad.clone()
+        net.zero_grad()
+        xb = x0.clone().requires_grad_(True)
+        x, codes, ress = xb, [xb], []
+        for t in range(1, n):
+            x, r = net(x)
+            codes.append(x)
+            ress.append(r)
+        codes_s = torch.stack(codes, dim=1)
+        (codes_s * g).sum().backward()
+    tol = 2e-5 if precision == 'fp32' else 2e-3
+
+    def rel(a, b):
+        return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+    assert rel(codes_f, codes_s) < tol
+    for t in range(n - 1):
+        for b in range(nb):
+            assert rel(res_f[t][b], ress[t][b]) < tol * 5
+    assert rel(dxa, xb.grad) < tol
+    for gf, p in zip(grads_f, net.parameters()):
+        if n == 1:
+            assert gf is None and p.grad is None          # no integrator step, no weight gradient
+            continue
+        assert rel(gf, p.grad) < tol * 5, (gf.shape,)
