@@ -133,6 +133,8 @@ int vs_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, 
  *   t_codes   [B, n, C] fp32      every code of the rollout, t_codes[:, 0] = x0 (the layout get_forecast returns)
  *   residuals [n-1, n_blocks, B, C] fp32 or NULL   (the `t_residuals` the reference returns)
  *   xin_save [nb, n-1, B, C], h1_save / h2_save [nb, n-1, B, H]  compute type: inputs of the weight-gradient GEMMs
+ *   m1_save / m2_save [nb, n-1, B, 32] uint32: ReLU sign bits of h1 / h2 (word j of a row holds columns j + 32 u in
+ *             bit u), so the backward kernel reads 2 words per thread and step instead of the activations
  * Backward (through time):
  *   grad_t_codes [B, n, C] fp32   gradient wrt every code;  weights_t: host array of 3*n_blocks device pointers
  *             {W3^T [H,C], W2^T [H,H], W1^T [C,H]} per block, packed with vs_pack_rollout_weight(transpose = 1)
@@ -152,10 +154,11 @@ int vs_pack_rollout_weight(int compute, const float* src, int transpose, int N, 
 
 int vs_mlp_rollout_fwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* x0,
                        const void* const* weights, const float* const* biases, float* t_codes, float* residuals,
-                       void* xin_save, void* h1_save, void* h2_save, void* stream);
+                       void* xin_save, void* h1_save, void* h2_save, uint32_t* m1_save, uint32_t* m2_save, void* stream);
 
 int vs_mlp_rollout_bwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* grad_t_codes,
-                       const void* const* weights_t, const void* h1_save, const void* h2_save, float* dx0,
+                       const void* const* weights_t, const void* h1_save, const void* h2_save,
+                       const uint32_t* m1_save, const uint32_t* m2_save, float* dx0,
                        void* dr_save, void* dh2_save, void* dh1_save, void* stream);
 
 #ifdef __cplusplus

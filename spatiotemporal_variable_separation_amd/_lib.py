@@ -89,8 +89,8 @@ SIGNATURES = {
     'vs_transpose_cast': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'vs_rollout_packed_elems': (_sz, [_i32, _i32, _i32]),
     'vs_pack_rollout_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
-    'vs_mlp_rollout_fwd': (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'vs_mlp_rollout_bwd': (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'vs_mlp_rollout_fwd': (_i32, [_i32] * 6 + [_vp] * 11),
+    'vs_mlp_rollout_bwd': (_i32, [_i32] * 6 + [_vp] * 11),
 }
 
 

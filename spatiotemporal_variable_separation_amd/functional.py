@@ -178,21 +178,21 @@ class MLPRollout(torch.autograd.Function):
             for l in range(3):
                 ws.append(packed_weight(params[6 * b + 2 * l], cdt, False))
                 bs.append(params[6 * b + 2 * l + 1].detach())
-        t_codes, residuals, (xin, h1, h2) = ops.mlp_rollout_fwd(x0.detach().float().contiguous(), ws, bs, n_steps, H)
+        t_codes, residuals, (xin, h1, h2, m1, m2) = ops.mlp_rollout_fwd(x0.detach().float().contiguous(), ws, bs, n_steps, H)
         ctx.cdt, ctx.nb, ctx.n_steps, ctx.params = cdt, nb, n_steps, params
-        ctx.save_for_backward(xin, h1, h2)
+        ctx.save_for_backward(xin, h1, h2, m1, m2)
         ctx.mark_non_differentiable(residuals)
         return t_codes, residuals
 
     @staticmethod
     def backward(ctx, g_codes, _g_res):
-        xin, h1, h2 = ctx.saved_tensors
+        xin, h1, h2, m1, m2 = ctx.saved_tensors
         cdt, nb, n_steps, params = ctx.cdt, ctx.nb, ctx.n_steps, ctx.params
         wts = []
         for b in range(nb):
             W1, W2, W3 = params[6 * b], params[6 * b + 2], params[6 * b + 4]
             wts += [packed_weight(W3, cdt, True), packed_weight(W2, cdt, True), packed_weight(W1, cdt, True)]
-        dx0, dr, dh2, dh1 = ops.mlp_rollout_bwd(g_codes.contiguous().float(), wts, h1, h2, n_steps)
+        dx0, dr, dh2, dh1 = ops.mlp_rollout_bwd(g_codes.contiguous().float(), wts, h1, h2, m1, m2, n_steps)
         B, C = dx0.shape
         H = h1.shape[-1]
         rows = (n_steps - 1) * B

@@ -183,18 +183,21 @@ def mlp_rollout_fwd(x0, weights, biases, n_steps, H, want_residuals=True):
     xin = torch.empty((nb, steps, B, C), dtype=cdt, device=dev)
     h1 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
     h2 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
+    m1 = torch.empty((nb, steps, B, 32), dtype=torch.int32, device=dev)
+    m2 = torch.empty((nb, steps, B, 32), dtype=torch.int32, device=dev)
     wa, ba = _ptr_array(weights), _ptr_array(biases)
     e0 = _pb()
     check(_lib.load_library().vs_mlp_rollout_fwd(dtype_code(weights[0]), B, C, H, nb, n_steps, x0.data_ptr(),
                                                  ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                                  t_codes.data_ptr(), _ptr(residuals), xin.data_ptr(), h1.data_ptr(),
-                                                 h2.data_ptr(), stream_ptr()), 'vs_mlp_rollout_fwd')
+                                                 h2.data_ptr(), m1.data_ptr(), m2.data_ptr(), stream_ptr()),
+          'vs_mlp_rollout_fwd')
     fl = 2.0 * B * steps * nb * (2 * C * H + H * H)
     _pe(e0, 'vs_mlp_rollout_fwd<%s>' % ('bf16' if cdt == torch.bfloat16 else 'f32'), flops=fl)
-    return t_codes, residuals, (xin, h1, h2)
+    return t_codes, residuals, (xin, h1, h2, m1, m2)
 
 
-def mlp_rollout_bwd(grad_t_codes, weights_t, h1, h2, n_steps):
+def mlp_rollout_bwd(grad_t_codes, weights_t, h1, h2, m1, m2, n_steps):
     """weights_t: packed [W3^T, W2^T, W1^T]*n_blocks (compute dtype).  Returns (dx0, dr, dh2, dh1)."""
     import ctypes
     require_cuda(grad_t_codes)
@@ -211,7 +214,7 @@ def mlp_rollout_bwd(grad_t_codes, weights_t, h1, h2, n_steps):
     e0 = _pb()
     check(_lib.load_library().vs_mlp_rollout_bwd(dtype_code(weights_t[0]), B, C, H, nb, n_steps, grad_t_codes.data_ptr(),
                                                  ctypes.cast(wa, ctypes.c_void_p), h1.data_ptr(), h2.data_ptr(),
-                                                 dx0.data_ptr(), dr.data_ptr(), dh2.data_ptr(), dh1.data_ptr(),
+                                                 m1.data_ptr(), m2.data_ptr(), dx0.data_ptr(), dr.data_ptr(), dh2.data_ptr(), dh1.data_ptr(),
                                                  stream_ptr()), 'vs_mlp_rollout_bwd')
     fl = 2.0 * B * steps * nb * (2 * C * H + H * H)
     _pe(e0, 'vs_mlp_rollout_bwd<%s>' % ('bf16' if cdt == torch.bfloat16 else 'f32'), flops=fl)

@@ -38,12 +38,67 @@ def ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=None):
     return loss, s_code_new, s_code_old
 
 
+def _mlp_family(sep_net):
+    from .networks.mlp_encdec import MLPEncoder, MLPDecoder
+    from .networks.resnet import MLPResnet
+    from .networks.utils import ConstantS
+    return (getattr(sep_net, 'fused', False) and not sep_net.skipco and isinstance(sep_net.Et, MLPEncoder)
+            and isinstance(sep_net.Es, (MLPEncoder, ConstantS)) and isinstance(sep_net.decoder, MLPDecoder)
+            and isinstance(sep_net.t_resnet, MLPResnet))
+
+
+def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset, lamb_ae, lamb_s, lamb_t, lamb_pred,
+                                average_tloss, t_random):
+    """Same arithmetic as the generic path below, with the calls that share weights batched along the row axis:
+    E_s on [first window; last window], E_t on [random window; conditioning window], D on [the auto-encoding row
+    block; every rollout step].  The MLP family has no BatchNorm, so stacking rows is exact; it halves the number of
+    weight-streaming GEMMs (E_s/E_t first layers are 98 MB of weights each) and leaves one gradient per parameter
+    (no accumulation passes)."""
+    from .networks.utils import ConstantS
+    full_data = torch.cat([cond, target], dim=1)
+    B, T = full_data.shape[0], full_data.shape[1]
+    flat = full_data.reshape(B, T, -1)
+    if t_random is None:
+        t_random = np.random.randint(nt_cond, T) if offset == 0 else np.random.randint(nt_cond, T + 1)
+
+    def window(end):
+        return flat[:, end - nt_cond:end].reshape(B, -1)
+
+    if isinstance(sep_net.Es, ConstantS):
+        s_old = sep_net.Es(full_data[:, :nt_cond])
+        s_new = sep_net.Es(full_data[:, -nt_cond:])
+    else:
+        s_both = sep_net.Es.mlp(torch.cat([window(nt_cond), window(T)], dim=0))
+        s_old, s_new = s_both[:B], s_both[B:]
+    t_both = sep_net.Et.mlp(torch.cat([window(t_random), window(nt_cond)], dim=0))
+    t_rand, t0 = t_both[:B], t_both[B:]
+
+    n = nt_pred + offset
+    t_codes, _ = sep_net.t_resnet.rollout(t0, n)
+    frames = sep_net.decoder.decode_sequence(s_old, torch.cat([t_rand.unsqueeze(1), t_codes], dim=1))   # [B, 1+n, ...]
+    reconstruction, forecasts = frames[:, 0], frames[:, 1:]
+
+    ae_loss_value = F.mse_loss(full_data[:, t_random - offset], reconstruction, reduction='mean')
+    spatial_ode_loss = (s_old - s_new).pow(2).mean()
+    forecast_loss = F.mse_loss(forecasts, full_data[:, (nt_cond if offset == 0 else 0):])
+    if average_tloss:
+        t_reg = 0.5 * (t_codes[:, 0].pow(2).view(B, -1)).mean()
+    else:
+        t_reg = 0.5 * torch.sum(t_codes[:, 0].pow(2), dim=1).mean()
+    total_loss = lamb_ae * ae_loss_value + lamb_s * spatial_ode_loss + lamb_pred * forecast_loss + lamb_t * t_reg
+    terms = {'ae': ae_loss_value, 'zero': spatial_ode_loss, 'pred': forecast_loss, 't_reg': t_reg}
+    return total_loss, terms, forecasts, t_codes
+
+
 def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb_ae, lamb_s, lamb_t, lamb_pred,
                    average_tloss=False, t_random=None):
     """The four loss terms and their weighted sum for one batch (train.py:117-149).
 
     Returns (total, {'ae','zero','pred','t_reg'}, forecasts, t_codes)."""
     assert offset == nt_cond or offset == 0
+    if cond.is_cuda and _mlp_family(sep_net):
+        return _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset, lamb_ae, lamb_s, lamb_t,
+                                           lamb_pred, average_tloss, t_random)
     ae_loss_value, s_recent, s_old = ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=t_random)
     spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
     full_data = torch.cat([cond, target], dim=1)

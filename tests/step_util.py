@@ -20,7 +20,7 @@ def oracle_step(cfg, t_random):
     return net, total, terms, forecasts, t_codes
 
 
-def hip_step(cfg, t_random, oracle_net, precision='fp32'):
+def hip_step(cfg, t_random, oracle_net, precision='fp32', fused=True):
     from spatiotemporal_variable_separation_amd import functional as VF
     from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
     from spatiotemporal_variable_separation_amd.train import compute_losses
@@ -31,6 +31,7 @@ def hip_step(cfg, t_random, oracle_net, precision='fp32'):
     net.load_state_dict(sd, strict=True)
     net = net.cuda()
     net.train()
+    net.fused = fused
     lam = cfg['lambdas']
     lamb_t = 0 if cfg.get('no_s') else lam['t']
     with VF.precision(precision):
@@ -72,10 +73,10 @@ def compare_step_bf16(cfg, t_random, tol=2e-3, sanity=0.6):
     return vs_emu, vs_fp32
 
 
-def compare_step(cfg, t_random, precision, tol_out, tol_grad, fresh_oracle=None):
+def compare_step(cfg, t_random, precision, tol_out, tol_grad, fused=True):
     """Returns a dict of worst relative errors; asserts against the tolerances."""
     o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])          # pristine weights for the HIP net
-    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision)
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision, fused=fused)
     o_net, o_total, o_terms, o_fore, o_tc = oracle_step(cfg, t_random)
     errs = {'forecasts': rel_err(h_fore.detach().cpu(), o_fore.detach()),
             't_codes': rel_err(h_tc.detach().cpu(), o_tc.detach()),

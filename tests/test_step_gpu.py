@@ -45,3 +45,11 @@ def test_step_bf16_within_stated_bound(name):
     vs_emu, vs_fp32 = compare_step_bf16(cfg, int(load_golden(name)['t_random']))
     print(name, 'vs bf16 emulation', {k: f'{v:.1e}' for k, v in vs_emu.items()}, 'vs fp32 oracle',
           {k: f'{v:.1e}' for k, v in vs_fp32.items()})
+
+
+@pytest.mark.parametrize('name', MLP_CONFIGS)
+def test_step_fp32_unfused_structure_matches_oracle(name):
+    """`sep_net.fused = False` keeps the reference's per-step launch structure (one decoder / integrator call per
+    frame, separate E_s/E_t calls); it must give the same numbers as the batched fast path."""
+    cfg = CONFIGS[name]
+    compare_step(cfg, int(load_golden(name)['t_random']), 'fp32', tol_out=1e-3, tol_grad=1e-3, fused=False)
