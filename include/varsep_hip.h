@@ -161,6 +161,65 @@ int vs_mlp_rollout_bwd(int compute, int B, int C, int H, int n_blocks, int n_ste
                        const uint32_t* m1_save, const uint32_t* m2_save, float* dx0,
                        void* dr_save, void* dh2_save, void* dh1_save, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Convolutions as im2col-free implicit GEMMs on NCHW tensors (csrc/vs_conv.hip).  x [B,Cin,H,W], stride/pad equal
+ * in both directions, dilation 1, groups 1 -- the only forms the reference uses.  Storage type of x / w / dy is the
+ * compute type; biases and weight gradients are fp32.
+ *
+ *   vs_conv2d_*            nn.Conv2d          w [Cout,Cin,kh,kw]   y [B,Cout,OH,OW], OH = (H + 2 pad - kh)/stride + 1
+ *                          conv.py:119-122 (k4 s2 p1), :147-165,300-317,326-343,362-382,402-417 and resnet.py:57-59
+ *                          (k3 s1 p1), :170 (k4 s1 p0)
+ *   vs_conv_transpose2d_*  nn.ConvTranspose2d w [Cin,Cout,kh,kw]   y [B,Cout,OH,OW], OH = (H - 1) stride - 2 pad + kh
+ *                          conv.py:258,295 (k4 s1 p0), :260-263 (k4 s2 p1), :318 (k3 s1 p1)
+ *   *_fwd   : y = conv(x, w) + bias (bias may be NULL)
+ *   *_dgrad : dx = gradient wrt x given dy (dy has the shape of y)
+ *   *_wgrad : dw (fp32, same shape as w) = gradient wrt w; uses split-K when the reduction B*OH*OW is long: pass a
+ *             workspace of vs_conv_wgrad_workspace_bytes(...) bytes (NULL = no split, slower but correct)
+ * In every call B, Cin, H, W, Cout describe the FORWARD op (x's shape and the weight's channel counts).
+ */
+size_t vs_conv_wgrad_workspace_bytes(int B, int Cin, int OH, int OW, int Cout, int kh, int kw);
+int vs_conv2d_fwd(int compute, const void* x, const void* w, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
+                  int Cout, int kh, int kw, int stride, int pad, void* stream);
+int vs_conv2d_dgrad(int compute, const void* dy, const void* w, void* dx, int dx_dtype, int B, int Cin, int H, int W, int Cout, int kh,
+                    int kw, int stride, int pad, void* stream);
+int vs_conv2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                    int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
+int vs_conv_transpose2d_fwd(int compute, const void* x, const void* w, const float* bias, void* y, int y_dtype, int B, int Cin, int H,
+                            int W, int Cout, int kh, int kw, int stride, int pad, void* stream);
+int vs_conv_transpose2d_dgrad(int compute, const void* dy, const void* w, void* dx, int dx_dtype, int B, int Cin, int H, int W, int Cout,
+                              int kh, int kw, int stride, int pad, void* stream);
+int vs_conv_transpose2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh,
+                              int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d + activation, pooling, upsampling (csrc/vs_norm.hip); x is NCHW [B,C,HW], dtypes VS_F32 | VS_BF16.
+ *
+ * vs_bn_stats   : per-call batch statistics of nn.BatchNorm2d in training mode (conv.py:41-60): mean[c], invstd[c] =
+ *                 1/sqrt(biased var + eps); when running_mean/var are non-NULL they are updated in place with
+ *                 `momentum` and the unbiased variance, exactly like ATen.
+ * vs_bn_act_fwd : y = act(gamma (x - mean) invstd + beta).  Eval mode: pass running_mean and 1/sqrt(running_var+eps).
+ * vs_bn_act_bwd : given dy = dL/dy, recomputes z = gamma xhat + beta, dz = dy act'(z), and returns dbeta = sum dz,
+ *                 dgamma = sum dz xhat and dx = gamma invstd (dz - dbeta/N - xhat dgamma/N)  (training != 0) or
+ *                 dx = gamma invstd dz (training == 0).
+ * vs_chan_sum   : out[c] = sum_{b,pix} x[b,c,pix]   (bias gradient of a convolution)
+ * vs_maxpool2_* : nn.MaxPool2d(2,2) (conv.py:151-169,330-335) on `planes` = B*C planes of H x W (even); backward
+ *                 routes dy to the first maximum in window scan order, like ATen.
+ * vs_upsample2_*: nn.Upsample(scale_factor=2, mode='nearest') (conv.py:296-314,371-377,406-413); H, W are the INPUT size.
+ */
+int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW, float* mean, float* invstd, float* running_mean,
+                float* running_var, float momentum, float eps, void* stream);
+int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, int act, int B, int C, int64_t HW, void* stream);
+int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, int act, int training, float* dgamma, float* dbeta, void* dx, int dx_dtype, int B, int C,
+                  int64_t HW, void* stream);
+int vs_chan_sum(const void* x, int x_dtype, int B, int C, int64_t HW, float* out, void* stream);
+int vs_maxpool2_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t planes, int H, int W, void* stream);
+int vs_maxpool2_bwd(const void* x, int x_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype, int64_t planes, int H, int W,
+                    void* stream);
+int vs_upsample2_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t planes, int H, int W, void* stream);
+int vs_upsample2_bwd(const void* dy, int dy_dtype, void* dx, int dx_dtype, int64_t planes, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

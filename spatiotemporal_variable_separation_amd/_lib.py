@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvarsep_hip.so')
-SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_fused.hip']
+SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip']
 
 F32, BF16 = 0, 1
 ACT = {'none': 0, None: 0, 'identity': 0, 'relu': 1, 'leaky_relu': 2, 'sigmoid': 3, 'tanh': 4, 'elu': 5}
@@ -35,7 +35,8 @@ def library_is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = _sources() + [os.path.join(_CSRC, 'vs_common.h'), os.path.join(_HERE, '..', 'include', 'varsep_hip.h')]
+    deps = _sources() + [os.path.join(_CSRC, 'vs_common.h'), os.path.join(_CSRC, 'vs_gemm_core.h'),
+                         os.path.join(_HERE, '..', 'include', 'varsep_hip.h')]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -52,6 +53,7 @@ def build_library(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src) + '.o')
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
                 os.path.getmtime(src), os.path.getmtime(os.path.join(_CSRC, 'vs_common.h')),
+                os.path.getmtime(os.path.join(_CSRC, 'vs_gemm_core.h')),
                 os.path.getmtime(os.path.join(_HERE, '..', 'include', 'varsep_hip.h'))):
             return obj
         cmd = [hipcc] + flags + ['-c', src, '-o', obj]
@@ -86,6 +88,21 @@ SIGNATURES = {
     'vs_colsum': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     'vs_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     'vs_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _vp]),
+    'vs_conv_wgrad_workspace_bytes': (_sz, [_i32] * 7),
+    'vs_conv2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
+    'vs_conv2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
+    'vs_conv2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
+    'vs_conv_transpose2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
+    'vs_conv_transpose2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
+    'vs_conv_transpose2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
+    'vs_bn_stats': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp]),
+    'vs_bn_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    'vs_bn_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    'vs_chan_sum': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    'vs_maxpool2_fwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
+    'vs_maxpool2_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
+    'vs_upsample2_fwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
+    'vs_upsample2_bwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
     'vs_transpose_cast': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'vs_rollout_packed_elems': (_sz, [_i32, _i32, _i32]),
     'vs_pack_rollout_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),

@@ -44,9 +44,9 @@ __device__ __forceinline__ float vs_act(float v, int act) {
     switch (act) {
         case VS_ACT_RELU: return v > 0.f ? v : 0.f;
         case VS_ACT_LEAKY: return v > 0.f ? v : 0.2f * v;
-        case VS_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case VS_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case VS_ACT_TANH: return tanhf(v);
-        case VS_ACT_ELU: return v > 0.f ? v : (__expf(v) - 1.f);
+        case VS_ACT_ELU: return v > 0.f ? v : (expf(v) - 1.f);
         default: return v;
     }
 }

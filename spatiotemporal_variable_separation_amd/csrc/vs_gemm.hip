@@ -19,279 +19,9 @@
 //   * few-tile/long-K problems (encoder first layer: M=128..256, K=20480) are split along K over
 //     gridDim.z into fp32 slabs and combined by a second kernel that also applies the epilogue, so the
 //     result is bitwise reproducible (no float atomics).
-#include "vs_common.h"
+#include "vs_gemm_core.h"
 
 namespace {
-
-enum { LR = VS_LAYOUT_R, LS = VS_LAYOUT_S };
-
-template <int CT> struct CTraits;
-template <> struct CTraits<VS_F32> { typedef float T; static constexpr int U = 4; static constexpr int KSTEP = 8; };
-template <> struct CTraits<VS_BF16> { typedef __bf16 T; static constexpr int U = 8; static constexpr int KSTEP = 16; };
-
-struct Epi {
-    void* C; int64_t ldc; int c_dtype;
-    float alpha; const float* bias; int act;
-    const void* mask; int64_t ldmask; int mask_dtype; int mask_act;
-    int accumulate;
-};
-
-__device__ __forceinline__ void epi_store(const Epi& e, int64_t m, int64_t n, float v) {
-    v *= e.alpha;
-    if (e.bias) v += e.bias[n];
-    v = vs_act(v, e.act);
-    if (e.mask) v *= vs_act_grad_from_out(vs_ld(e.mask, e.mask_dtype, m * e.ldmask + n), e.mask_act);
-    const int64_t idx = m * e.ldc + n;
-    if (e.accumulate) v += vs_ld(e.C, e.c_dtype, idx);
-    vs_st(e.C, e.c_dtype, idx, v);
-}
-
-// ---- dense operand: element (i,k) at p[i*ld+k] (R) or p[k*ld+i] (S); T = storage = compute type -------
-template <int CT, int LAYOUT>
-struct Dense {
-    typedef typename CTraits<CT>::T T;
-    static constexpr int U = CTraits<CT>::U;
-    static constexpr int layout = LAYOUT;
-    const T* p; int64_t ld; int64_t rows; int64_t K; int vec_ok;
-
-    // 16-byte unit: R -> elements (i, k..k+U-1);  S -> elements (i..i+U-1, k)
-    __device__ __forceinline__ u32x4 load(int64_t i, int64_t k) const {
-        u32x4 r = {0u, 0u, 0u, 0u};
-        if (LAYOUT == LR) {
-            if (i >= rows || k >= K) return r;
-            const T* q = p + i * ld + k;
-            if (vec_ok && k + U <= K) return *reinterpret_cast<const u32x4*>(q);
-            T tmp[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) tmp[j] = (k + j < K) ? q[j] : (T)0.f;
-            return *reinterpret_cast<u32x4*>(tmp);
-        } else {
-            if (k >= K || i >= rows) return r;
-            const T* q = p + k * ld + i;
-            if (vec_ok && i + U <= rows) return *reinterpret_cast<const u32x4*>(q);
-            T tmp[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) tmp[j] = (i + j < rows) ? q[j] : (T)0.f;
-            return *reinterpret_cast<u32x4*>(tmp);
-        }
-    }
-};
-
-// LDS geometry of one operand tile
-template <int CT, int LAYOUT, int ROWS, int BK>
-struct TileGeom {
-    static constexpr int U = CTraits<CT>::U;
-    // R: [ROWS][BK+U]   (pitch odd multiple of 16 B -> ds_read_b128 conflict free)
-    // S: [BK][ROWS+pad] (bf16: pad 32 -> the four k-rows of a tr_b16 read land in distinct 64-byte bank groups)
-    static constexpr int PITCH = LAYOUT == LR ? BK + U : (CT == VS_BF16 ? ROWS + 32 : ROWS + 4);
-    static constexpr int ELEMS = LAYOUT == LR ? ROWS * PITCH : BK * PITCH;
-    static constexpr int UNITS = ROWS * BK / U;          // 16-byte units per tile
-    static constexpr int PER_THREAD = UNITS / 256;
-    static_assert(UNITS % 256 == 0, "tile must split evenly over 256 threads");
-    // unit u -> (row offset, k offset) and LDS element offset
-    __device__ static __forceinline__ void map(int u, int& di, int& dk, int& lds_off) {
-        if (LAYOUT == LR) {
-            constexpr int CH = BK / U;
-            di = u / CH; dk = (u % CH) * U; lds_off = di * PITCH + dk;
-        } else {
-            constexpr int CH = ROWS / U;
-            dk = u / CH; di = (u % CH) * U; lds_off = dk * PITCH + di;
-        }
-    }
-};
-
-template <int CT, class Op, int ROWS, int BK>
-__device__ __forceinline__ void tile_fetch(const Op& op, int64_t i0, int64_t k0,
-                                           u32x4 (&regs)[TileGeom<CT, Op::layout, ROWS, BK>::PER_THREAD]) {
-    typedef TileGeom<CT, Op::layout, ROWS, BK> G;
-#pragma unroll
-    for (int it = 0; it < G::PER_THREAD; ++it) {
-        int di, dk, off;
-        G::map(threadIdx.x + it * 256, di, dk, off);
-        regs[it] = op.load(i0 + di, k0 + dk);
-    }
-}
-
-template <int CT, int LAYOUT, int ROWS, int BK>
-__device__ __forceinline__ void tile_commit(typename CTraits<CT>::T* lds,
-                                            const u32x4 (&regs)[TileGeom<CT, LAYOUT, ROWS, BK>::PER_THREAD]) {
-    typedef TileGeom<CT, LAYOUT, ROWS, BK> G;
-#pragma unroll
-    for (int it = 0; it < G::PER_THREAD; ++it) {
-        int di, dk, off;
-        G::map(threadIdx.x + it * 256, di, dk, off);
-        *reinterpret_cast<u32x4*>(lds + off) = regs[it];
-    }
-}
-
-// ---- fragment fetch: bf16, one 32-row block, one 16-deep k step -> bf16x8 (lane r=l&31, h=l>>5 holds k=8h..8h+7)
-template <int LAYOUT, int PITCH>
-__device__ __forceinline__ bf16x8 frag_bf16(const __bf16* tile, int row0, int kk, int lane) {
-    if (LAYOUT == LR) {
-        const int r = lane & 31, h = lane >> 5;
-        return *reinterpret_cast<const bf16x8*>(tile + (row0 + r) * PITCH + kk + 8 * h);
-    } else {
-        // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(row) block; lane 4q+p supplies the address of k-row q,
-        // rows 4p..4p+3; lane i receives row i of the four k-rows.  Two reads cover k = 8h..8h+3 and 8h+4..8h+7.
-        const int li = lane & 15, q = li >> 2, p = li & 3, cb = (lane >> 4) & 1, h = lane >> 5;
-        const __bf16* a = tile + (kk + 8 * h + q) * PITCH + row0 + 16 * cb + 4 * p;
-        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * PITCH));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-}
-
-// ---- fragment fetch: f32, one 32-row block, one 8-deep k group -> 4 floats; element j belongs to k = kk+4q+j
-template <int LAYOUT, int PITCH>
-__device__ __forceinline__ f32x4 frag_f32(const float* tile, int row0, int kk, int lane) {
-    const int r = lane & 31, q = lane >> 5;
-    if (LAYOUT == LR) {
-        return *reinterpret_cast<const f32x4*>(tile + (row0 + r) * PITCH + kk + 4 * q);
-    } else {
-        const float* a = tile + (kk + 4 * q) * PITCH + row0 + r;
-        f32x4 v;
-        v[0] = a[0]; v[1] = a[PITCH]; v[2] = a[2 * PITCH]; v[3] = a[3 * PITCH];
-        return v;
-    }
-}
-
-template <int CT, class OpA, class OpB, int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int64_t N, int64_t K,
-                                                   int k_tiles_per_split, Epi epi, float* slabs) {
-    typedef typename CTraits<CT>::T T;
-    typedef TileGeom<CT, OpA::layout, BM, BK> GA;
-    typedef TileGeom<CT, OpB::layout, BN, BK> GB;
-    constexpr int WM = BM / 2, WN = BN / 2;          // per-wave C block (waves 2x2)
-    constexpr int TM = WM / 32, TN = WN / 32;
-    static_assert(TM >= 1 && TN >= 1, "tile too small");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* sA = reinterpret_cast<T*>(smem);
-    T* sB = sA + GA::ELEMS;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-    const int64_t kt_total = (K + BK - 1) / BK;
-    const int64_t kt_begin = (int64_t)blockIdx.z * k_tiles_per_split;
-    int64_t kt_end = kt_begin + k_tiles_per_split;
-    if (kt_end > kt_total) kt_end = kt_total;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-    u32x4 ra[GA::PER_THREAD], rb[GB::PER_THREAD];
-    if (kt_begin < kt_end) {
-        tile_fetch<CT, OpA, BM, BK>(A, m0, kt_begin * BK, ra);
-        tile_fetch<CT, OpB, BN, BK>(B, n0, kt_begin * BK, rb);
-    }
-    for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
-        tile_commit<CT, OpA::layout, BM, BK>(sA, ra);
-        tile_commit<CT, OpB::layout, BN, BK>(sB, rb);
-        __syncthreads();
-        if (kt + 1 < kt_end) {       // prefetch next tile into registers; lands while the MFMAs below run
-            tile_fetch<CT, OpA, BM, BK>(A, m0, (kt + 1) * BK, ra);
-            tile_fetch<CT, OpB, BN, BK>(B, n0, (kt + 1) * BK, rb);
-        }
-        if constexpr (CT == VS_BF16) {
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 16) {
-                bf16x8 fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fa[i] = frag_bf16<OpA::layout, GA::PITCH>(reinterpret_cast<const __bf16*>(sA), wm + 32 * i, kk, lane);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[j] = frag_bf16<OpB::layout, GB::PITCH>(reinterpret_cast<const __bf16*>(sB), wn + 32 * j, kk, lane);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 8) {
-                f32x4 fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fa[i] = frag_f32<OpA::layout, GA::PITCH>(reinterpret_cast<const float*>(sA), wm + 32 * i, kk, lane);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[j] = frag_f32<OpB::layout, GB::PITCH>(reinterpret_cast<const float*>(sB), wn + 32 * j, kk, lane);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-
-    // C/D map of the 32x32 MFMA shape: column = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)
-    const int cj = lane & 31, rh = 4 * (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int64_t n = n0 + wn + 32 * j + cj;
-            if (n >= N) continue;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int64_t m = m0 + wm + 32 * i + (v & 3) + 8 * (v >> 2) + rh;
-                if (m >= M) continue;
-                if (slabs) slabs[((int64_t)blockIdx.z * M + m) * N + n] = acc[i][j][v];
-                else epi_store(epi, m, n, acc[i][j][v]);
-            }
-        }
-}
-
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int splits, int64_t M, int64_t N, Epi epi) {
-    const int64_t total = M * N;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += slabs[(int64_t)s * total + idx];      // fixed order: reproducible
-        epi_store(epi, idx / N, idx % N, v);
-    }
-}
-
-struct Plan { int bm, bn, splits; int64_t k_tiles_per_split; };
-
-template <int CT> constexpr int bk_of() { return CT == VS_BF16 ? 64 : 16; }
-
-Plan make_plan(int compute, int64_t M, int64_t N, int64_t K) {
-    const int bk = compute == VS_BF16 ? 64 : 16;
-    Plan p;
-    // tile: 128x128 when that still gives >= 2 tiles per CU-wave of work, else 64-wide variants
-    const int64_t t128 = vs_cdiv(M, 128) * vs_cdiv(N, 128);
-    if (t128 >= 512 || (M >= 1024 && N >= 1024 && t128 >= 192)) { p.bm = 128; p.bn = 128; }
-    else if (vs_cdiv(M, 128) * vs_cdiv(N, 64) >= 256 || M > 64) { p.bm = M > 64 ? 128 : 64; p.bn = 64; }
-    else { p.bm = 64; p.bn = 64; }
-    if (M <= 64) p.bm = 64;
-    if (N <= 64) p.bn = 64;
-    const int64_t tiles = vs_cdiv(M, p.bm) * vs_cdiv(N, p.bn);
-    const int64_t kt = vs_cdiv(K, bk);
-    int splits = 1;
-    if (tiles < 192 && kt >= 8) {
-        splits = (int)((512 + tiles - 1) / tiles);
-        const int64_t max_by_k = kt / 4;            // keep >= 4 K tiles per split
-        if (splits > max_by_k) splits = (int)max_by_k;
-        if (splits > 64) splits = 64;
-        if (splits < 1) splits = 1;
-    }
-    p.k_tiles_per_split = vs_cdiv(kt, splits);
-    p.splits = (int)vs_cdiv(kt, p.k_tiles_per_split);
-    return p;
-}
 
 template <int CT, int LA, int LB, int BM, int BN>
 int launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const Plan& plan,
@@ -354,7 +84,7 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
     VS_CHECK_ARG(lda >= (layout_a == LR ? K : M) && ldb >= (layout_b == LR ? K : N) && ldc >= N, "vs_gemm: leading dimension too small");
     VS_CHECK_ARG(!mask || ldmask >= N, "vs_gemm: ldmask too small");
     VS_CHECK_ARG(act >= VS_ACT_NONE && act <= VS_ACT_ELU, "vs_gemm: bad activation");
-    Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate};
+    Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate, 0, 0};
     Plan plan = make_plan(compute, M, N, K);
     float* slabs = nullptr;
     if (plan.splits > 1) {

@@ -1,0 +1,267 @@
+// vs_norm.hip -- the HBM-bound layers between the convolutions: BatchNorm2d (training statistics, fused affine +
+// activation, backward), per-channel sums (conv bias gradient), MaxPool2d(2,2), nearest Upsample(x2).
+//
+// Reference: conv.py:41-60 (conv -> BatchNorm2d -> activation blocks), MaxPool2d conv.py:151-169,330-335,
+// Upsample conv.py:296-314,371-377,406-413.  BatchNorm statistics are per CALL (training mode, eps 1e-5, momentum 0.1,
+// biased variance for normalisation, unbiased for the running estimate), exactly nn.BatchNorm2d.
+//
+// Kernel shapes: statistics/reductions use one 256-thread workgroup per channel (C = 64..512 workgroups; the batch*HW
+// extent of a channel is streamed with coalesced reads, reduced in registers -> LDS, no atomics -> reproducible);
+// element-wise passes are grid-stride with the channel recovered from the flat NCHW index.
+#include "vs_common.h"
+
+namespace {
+
+// per-channel reductions accumulate in fp64 (like ATen's CPU BatchNorm): they are HBM-bound, the adds are free, and the
+// statistics feed every element of the layer, so their rounding noise is amplified by deep BatchNorm stacks
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    // 256 threads = 4 waves of 64
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// derivative of the activation from its PRE-activation input z
+__device__ __forceinline__ float act_grad_from_pre(float z, int act) {
+    switch (act) {
+        case VS_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case VS_ACT_LEAKY: return z > 0.f ? 1.f : 0.2f;
+        case VS_ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-z)); return s * (1.f - s); }
+        case VS_ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
+        case VS_ACT_ELU: return z > 0.f ? 1.f : expf(z);
+        default: return 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, int B, int C, int64_t HW, float* mean, float* invstd,
+                                                       float* rmean, float* rvar, float momentum, float eps) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const int64_t n = (int64_t)B * HW;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int64_t b = i / HW, p = i - b * HW;
+        s += (double)vs_ld(x, xd, (b * C + c) * HW + p);
+    }
+    const double mu = block_sum(s, red) / (double)n;
+    double q = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int64_t b = i / HW, p = i - b * HW;
+        const double d = (double)vs_ld(x, xd, (b * C + c) * HW + p) - mu;
+        q += d * d;
+    }
+    const double ss = block_sum(q, red);
+    if (threadIdx.x == 0) {
+        const double var = ss / (double)n;
+        mean[c] = (float)mu;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rmean) {
+            const double unbiased = n > 1 ? ss / (double)(n - 1) : var;
+            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unbiased);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, void* y, int yd, const float* mean, const float* invstd,
+                                                         const float* gamma, const float* beta, int act, int C, int64_t HW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i / HW) % C);
+        const float xh = (vs_ld(x, xd, i) - mean[c]) * invstd[c];
+        vs_st(y, yd, i, vs_act(xh * gamma[c] + beta[c], act));
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int dyd, const void* x, int xd, const float* mean,
+                                                            const float* invstd, const float* gamma, const float* beta, int act, int B, int C,
+                                                            int64_t HW, float* sum_dz, float* sum_dz_xhat) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const int64_t n = (int64_t)B * HW;
+    const float mu = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int64_t b = i / HW, p = i - b * HW;
+        const int64_t idx = (b * C + c) * HW + p;
+        const float xh = (vs_ld(x, xd, idx) - mu) * is;
+        const float dz = vs_ld(dy, dyd, idx) * act_grad_from_pre(xh * g + bt, act);
+        s1 += (double)dz;
+        s2 += (double)dz * (double)xh;
+    }
+    const double t1 = block_sum(s1, red);
+    const double t2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { sum_dz[c] = (float)t1; sum_dz_xhat[c] = (float)t2; }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int dyd, const void* x, int xd, const float* mean,
+                                                           const float* invstd, const float* gamma, const float* beta, int act,
+                                                           const float* sum_dz, const float* sum_dz_xhat, void* dx, int dxd, int B, int C,
+                                                           int64_t HW, int64_t total, int training) {
+    const float inv_n = 1.f / (float)((int64_t)B * HW);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i / HW) % C);
+        const float xh = (vs_ld(x, xd, i) - mean[c]) * invstd[c];
+        const float dz = vs_ld(dy, dyd, i) * act_grad_from_pre(xh * gamma[c] + beta[c], act);
+        float v;
+        if (training) v = gamma[c] * invstd[c] * (dz - sum_dz[c] * inv_n - xh * sum_dz_xhat[c] * inv_n);
+        else v = gamma[c] * invstd[c] * dz;                 // eval mode: statistics are constants
+        vs_st(dx, dxd, i, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void chan_sum_kernel(const void* x, int xd, int B, int C, int64_t HW, float* out) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const int64_t n = (int64_t)B * HW;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int64_t b = i / HW, p = i - b * HW;
+        s += (double)vs_ld(x, xd, (b * C + c) * HW + p);
+    }
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) out[c] = (float)t;
+}
+
+// MaxPool2d(2,2): planes = B*C, input H x W (even), output H/2 x W/2
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void* x, int xd, void* y, int yd, int64_t planes, int H, int W) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total = planes * OH * OW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const int64_t pl = i / ((int64_t)OW * OH);
+        const int64_t base = (pl * H + 2 * oy) * W + 2 * ox;
+        const float a = vs_ld(x, xd, base), b = vs_ld(x, xd, base + 1), c = vs_ld(x, xd, base + W), d = vs_ld(x, xd, base + W + 1);
+        vs_st(y, yd, i, fmaxf(fmaxf(a, b), fmaxf(c, d)));
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* x, int xd, const void* dy, int dyd, void* dx, int dxd, int64_t planes,
+                                                          int H, int W) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total = planes * OH * OW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const int64_t pl = i / ((int64_t)OW * OH);
+        const int64_t base = (pl * H + 2 * oy) * W + 2 * ox;
+        const float v[4] = {vs_ld(x, xd, base), vs_ld(x, xd, base + 1), vs_ld(x, xd, base + W), vs_ld(x, xd, base + W + 1)};
+        int arg = 0;                                        // first maximum in window scan order, like ATen
+        float best = v[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (v[k] > best) { best = v[k]; arg = k; }
+        const float g = vs_ld(dy, dyd, i);
+        vs_st(dx, dxd, base, arg == 0 ? g : 0.f);
+        vs_st(dx, dxd, base + 1, arg == 1 ? g : 0.f);
+        vs_st(dx, dxd, base + W, arg == 2 ? g : 0.f);
+        vs_st(dx, dxd, base + W + 1, arg == 3 ? g : 0.f);
+    }
+}
+
+// nearest Upsample x2: planes x (H x W) -> planes x (2H x 2W)
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const void* x, int xd, void* y, int yd, int64_t planes, int H, int W) {
+    const int OH = 2 * H, OW = 2 * W;
+    const int64_t total = planes * OH * OW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const int64_t pl = i / ((int64_t)OW * OH);
+        vs_st(y, yd, i, vs_ld(x, xd, (pl * H + oy / 2) * W + ox / 2));
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const void* dy, int dyd, void* dx, int dxd, int64_t planes, int H, int W) {
+    const int OW = 2 * W;
+    const int64_t total = planes * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x0 = (int)(i % W), y0 = (int)((i / W) % H);
+        const int64_t pl = i / ((int64_t)W * H);
+        const int64_t base = (pl * 2 * H + 2 * y0) * OW + 2 * x0;
+        vs_st(dx, dxd, i, vs_ld(dy, dyd, base) + vs_ld(dy, dyd, base + 1) + vs_ld(dy, dyd, base + OW) + vs_ld(dy, dyd, base + OW + 1));
+    }
+}
+
+inline unsigned ew_grid(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW, float* mean, float* invstd, float* running_mean,
+                           float* running_var, float momentum, float eps, void* stream) {
+    VS_CHECK_ARG(x && mean && invstd && B > 0 && C > 0 && HW > 0, "vs_bn_stats: bad argument");
+    VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "vs_bn_stats: running_mean/var must come together");
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, x_dtype, B, C, HW, mean, invstd, running_mean,
+                       running_var, momentum, eps);
+    VS_CHECK_LAUNCH("vs_bn_stats");
+    return VS_OK;
+}
+
+extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, int act, int B, int C, int64_t HW, void* stream) {
+    VS_CHECK_ARG(x && y && mean && invstd && gamma && beta && B > 0 && C > 0 && HW > 0, "vs_bn_act_fwd: bad argument");
+    const int64_t total = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
+                       gamma, beta, act, C, HW, total);
+    VS_CHECK_LAUNCH("vs_bn_act_fwd");
+    return VS_OK;
+}
+
+extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int act, int training, float* dgamma, float* dbeta, void* dx,
+                             int dx_dtype, int B, int C, int64_t HW, void* stream) {
+    VS_CHECK_ARG(dy && x && mean && invstd && gamma && beta && dgamma && dbeta && dx && B > 0 && C > 0 && HW > 0, "vs_bn_act_bwd: bad argument");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd, gamma, beta,
+                       act, B, C, HW, dbeta, dgamma);
+    VS_CHECK_LAUNCH("vs_bn_act_bwd reduce");
+    const int64_t total = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd,
+                       gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B, C, HW, total, training);
+    VS_CHECK_LAUNCH("vs_bn_act_bwd apply");
+    return VS_OK;
+}
+
+extern "C" int vs_chan_sum(const void* x, int x_dtype, int B, int C, int64_t HW, float* out, void* stream) {
+    VS_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0, "vs_chan_sum: bad argument");
+    hipLaunchKernelGGL(chan_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, x_dtype, B, C, HW, out);
+    VS_CHECK_LAUNCH("vs_chan_sum");
+    return VS_OK;
+}
+
+extern "C" int vs_maxpool2_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t planes, int H, int W, void* stream) {
+    VS_CHECK_ARG(x && y && planes > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "vs_maxpool2_fwd: bad argument (H, W must be even)");
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(planes * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype,
+                       planes, H, W);
+    VS_CHECK_LAUNCH("vs_maxpool2_fwd");
+    return VS_OK;
+}
+
+extern "C" int vs_maxpool2_bwd(const void* x, int x_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype, int64_t planes, int H, int W,
+                               void* stream) {
+    VS_CHECK_ARG(x && dy && dx && planes > 0 && H % 2 == 0 && W % 2 == 0, "vs_maxpool2_bwd: bad argument");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(planes * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, x, x_dtype, dy, dy_dtype,
+                       dx, dx_dtype, planes, H, W);
+    VS_CHECK_LAUNCH("vs_maxpool2_bwd");
+    return VS_OK;
+}
+
+extern "C" int vs_upsample2_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t planes, int H, int W, void* stream) {
+    VS_CHECK_ARG(x && y && planes > 0 && H > 0 && W > 0, "vs_upsample2_fwd: bad argument");
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(ew_grid(planes * 4 * H * W)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, planes,
+                       H, W);
+    VS_CHECK_LAUNCH("vs_upsample2_fwd");
+    return VS_OK;
+}
+
+extern "C" int vs_upsample2_bwd(const void* dy, int dy_dtype, void* dx, int dx_dtype, int64_t planes, int H, int W, void* stream) {
+    VS_CHECK_ARG(dy && dx && planes > 0 && H > 0 && W > 0, "vs_upsample2_bwd: bad argument");
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(ew_grid(planes * H * W)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, dx, dx_dtype, planes,
+                       H, W);
+    VS_CHECK_LAUNCH("vs_upsample2_bwd");
+    return VS_OK;
+}

@@ -207,3 +207,99 @@ class MLPRollout(torch.autograd.Function):
                       ops.gemm(dh2b, S, h1b, S, H, H, rows), ops.colsum(dh2b, rows, H),
                       ops.gemm(drb, S, h2b, S, C, H, rows), ops.colsum(drb, rows, C)]
         return (dx0, None) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------ conv blocks
+class ConvBlock(torch.autograd.Function):
+    """conv / transposed conv -> [BatchNorm2d (per-call batch statistics)] -> [activation]  (conv.py:41-60).
+
+    cfg = (transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32).  Forward keeps the pre-BN conv
+    output z (compute dtype) and the batch statistics; backward recomputes the normalised value from z, so no
+    post-activation tensor has to be kept for BN blocks (save what OUR backward needs)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, rmean, rvar, cfg):
+        require_cuda(x)
+        transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32 = cfg
+        cdt = compute_dtype()
+        out_dt = torch.float32 if out_fp32 else cdt
+        xc = to_compute(x, cdt)
+        wc = shadow(w, cdt)
+        bias = b.detach() if b is not None else None
+        if has_bn:
+            z = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, cdt)
+            if training:
+                mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps)
+            else:
+                mean, invstd = rmean.detach().clone(), torch.rsqrt(rvar.detach() + eps)
+            y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt)
+            ctx.save_for_backward(xc, z, mean, invstd)
+        else:
+            y = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, out_dt)
+            if act not in ('none', None):
+                ops.act_fwd(y, act, out=y)
+            ctx.save_for_backward(xc, y)
+        ctx.cfg, ctx.cdt = cfg, cdt
+        ctx.w, ctx.b, ctx.gamma, ctx.beta = w, b, gamma, beta
+        ctx.x_dtype, ctx.x_needs_grad = x.dtype, x.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32 = ctx.cfg
+        cdt, w, b = ctx.cdt, ctx.w, ctx.b
+        dgamma = dbeta = None
+        if has_bn:
+            xc, z, mean, invstd = ctx.saved_tensors
+            dz, dgamma, dbeta = ops.bn_act_bwd(dy, z, mean, invstd, ctx.gamma.detach(), ctx.beta.detach(), act, training, cdt)
+        else:
+            xc, y = ctx.saved_tensors
+            dz = ops.act_bwd(dy, y, act, out_dtype=cdt) if act not in ('none', None) else to_compute(dy, cdt)
+        db = ops.chan_sum(dz) if b is not None and b.requires_grad else None
+        dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed) if w.requires_grad else None
+        dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype) if ctx.x_needs_grad else None
+        return dx, dw, db, dgamma, dbeta, None, None, None
+
+
+class MaxPool2(torch.autograd.Function):
+    """nn.MaxPool2d(2, 2) (conv.py:151-169, 330-335)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.maxpool2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool2_bwd(x, dy.to(x.dtype) if dy.dtype != x.dtype else dy)
+
+
+class Upsample2(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode='nearest') (conv.py:296-314, 371-377, 406-413)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.dt = x.dtype
+        return ops.upsample2_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample2_bwd(dy, ctx.dt)
+
+
+class Activation(torch.autograd.Function):
+    """Stand-alone activation (only where the reference applies one outside a conv block, e.g. conv.py:396 out_f)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        y = ops.act_fwd(x, act)
+        ctx.save_for_backward(y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.act_bwd(dy, y, ctx.act, out_dtype=y.dtype), None

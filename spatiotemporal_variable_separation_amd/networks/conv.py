@@ -1,0 +1,303 @@
+"""Convolutional encoders / decoders on the HIP conv blocks (reference: networks/conv.py:41-426).
+
+The module trees are the reference's (so `state_dict` keys match and `init_net`'s class-name dispatch works), but
+the containers are only parameter holders: `run_layers` walks them and issues one fused HIP block per
+conv -> [BatchNorm2d] -> [activation] group, plus pool / upsample / flatten+linear ops.
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as VF
+from .utils import activation_factory, activation_name
+
+_ACT_TYPES = (nn.ReLU, nn.LeakyReLU, nn.ELU, nn.Sigmoid, nn.Tanh)
+
+
+def make_conv_block(conv, activation, bn=True):
+    """conv -> [BatchNorm2d] -> [activation] as an nn.Sequential (conv.py:41-60)."""
+    modules = [conv]
+    if bn:
+        modules.append(nn.BatchNorm2d(conv.out_channels))
+    if activation != 'none':
+        modules.append(activation_factory(activation))
+    return nn.Sequential(*modules)
+
+
+def _flatten_modules(module, out):
+    if isinstance(module, (nn.Sequential, nn.ModuleList)):
+        for m in module:
+            _flatten_modules(m, out)
+    else:
+        out.append(module)
+    return out
+
+
+def run_layers(module, h, final_act='none', final_fp32=False):
+    """Execute a (nested) Sequential of reference layer objects on the HIP path.
+
+    `final_act` is an activation the caller applies right after the last layer (decoder `last_activation`); it is fused
+    into the last conv block when that block has no activation of its own.  `final_fp32` makes the last block write
+    fp32 (module outputs are fp32 in every precision mode)."""
+    layers = [m for m in _flatten_modules(module, []) if not isinstance(m, nn.Identity)]
+    # group: conv [bn] [act]
+    groups, i = [], 0
+    while i < len(layers):
+        m = layers[i]
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            bn = act = None
+            j = i + 1
+            if j < len(layers) and isinstance(layers[j], nn.BatchNorm2d):
+                bn = layers[j]
+                j += 1
+            if j < len(layers) and isinstance(layers[j], _ACT_TYPES):
+                act = layers[j]
+                j += 1
+            groups.append(('conv', m, bn, act))
+            i = j
+        else:
+            groups.append(('other', m, None, None))
+            i += 1
+    for gi, (kind, m, bn, act) in enumerate(groups):
+        last = gi == len(groups) - 1
+        if kind == 'conv':
+            act_name = activation_name(act) if act is not None else 'none'
+            extra = None
+            if last and final_act not in ('none', None):
+                if act_name == 'none':
+                    act_name = final_act
+                else:
+                    extra = final_act
+            assert m.kernel_size[0] == m.kernel_size[1] and m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1]
+            training = bn.training if bn is not None else False
+            if bn is not None and training:
+                bn.num_batches_tracked += 1            # per call, like nn.BatchNorm2d
+            cfg = (isinstance(m, nn.ConvTranspose2d), m.stride[0], m.padding[0], bn is not None, act_name, training,
+                   bn.momentum if bn is not None else 0.1, bn.eps if bn is not None else 1e-5,
+                   bool(final_fp32 and last and extra is None))
+            h = VF.ConvBlock.apply(h, m.weight, m.bias, bn.weight if bn is not None else None,
+                                   bn.bias if bn is not None else None, bn.running_mean if bn is not None else None,
+                                   bn.running_var if bn is not None else None, cfg)
+            if extra is not None:
+                h = VF.Activation.apply(h.float() if final_fp32 else h, extra)
+        elif isinstance(m, nn.MaxPool2d):
+            h = VF.MaxPool2.apply(h)
+        elif isinstance(m, nn.Upsample):
+            h = VF.Upsample2.apply(h)
+        elif isinstance(m, nn.Flatten):
+            h = h.reshape(h.shape[0], -1)
+        elif isinstance(m, nn.Linear):
+            h = VF.mlp_chain(h, [m], out_act=final_act if last else 'none')
+        else:
+            raise NotImplementedError(f'layer {type(m).__name__} has no HIP implementation')
+    if final_fp32 and h.dtype != torch.float32:
+        h = h.float()
+    return h
+
+
+def _fold_time(x):
+    """[B, nt, C, H, W] -> [B, nt*C, H, W] (conv.py:90): the temporal window becomes channels."""
+    return x.reshape(x.size(0), -1, x.size(3), x.size(4))
+
+
+class BaseEncoder(nn.Module):
+    """Encoder forward (conv.py:81-99): stages collect skips, `last_op` produces the flat code."""
+
+    def __init__(self, nh):
+        super().__init__()
+        self.nh = nh
+
+    def forward(self, x, return_skip=False):
+        h = _fold_time(x)
+        skips = []
+        for layer in self.conv:
+            h = run_layers(layer, h)
+            skips.append(h)
+        h = run_layers(self.last_op, h, final_fp32=True).view(-1, self.nh)
+        if return_skip:
+            return h, skips[::-1]
+        return h
+
+
+class DCGAN64Encoder(BaseEncoder):
+    """conv.py:102-124: four k4 s2 p1 convolutions (no BN on the first), then Flatten + Linear."""
+
+    def __init__(self, nc, nh, nf):
+        super().__init__(nh)
+        chans = [nc, nf, nf * 2, nf * 4, nf * 8]
+        self.conv = nn.ModuleList([
+            make_conv_block(nn.Conv2d(chans[i], chans[i + 1], 4, 2, 1), activation='leaky_relu', bn=(i > 0))
+            for i in range(4)])
+        self.last_op = nn.Sequential(nn.Flatten(), nn.Linear(nf * 8 * 4 * 4, nh))
+
+
+def _c3(cin, cout, activation='leaky_relu', bn=True):
+    return make_conv_block(nn.Conv2d(cin, cout, 3, 1, 1), activation=activation, bn=bn)
+
+
+def _pool():
+    return nn.MaxPool2d(kernel_size=2, stride=2, padding=0)
+
+
+def _up():
+    return nn.Upsample(scale_factor=2, mode='nearest')
+
+
+class VGG64Encoder(BaseEncoder):
+    """conv.py:127-171: VGG stages (2,2,3,3 convolutions) with 2x2 max-pooling, k4 valid conv + BN as last op."""
+
+    def __init__(self, nc, nh, nf, vgg32=False):
+        super().__init__(nh)
+        widths = [(nc, [nf, nf]), (nf, [nf * 2] * 2), (nf * 2, [nf * 4] * 3), (nf * 4, [nf * 8] * 3)]
+        stages = []
+        for si, (cin, couts) in enumerate(widths):
+            mods = [] if si == 0 else [_pool()]
+            for cout in couts:
+                mods.append(_c3(cin, cout))
+                cin = cout
+            stages.append(nn.Sequential(*mods))
+        self.conv = nn.ModuleList(stages)
+        self.last_op = nn.Sequential(_pool() if not vgg32 else nn.Identity(),
+                                     make_conv_block(nn.Conv2d(nf * 8, nh, 4, 1, 0), activation='none'))
+
+
+class BaseDecoder(nn.Module):
+    """Decoder forward (conv.py:207-230): mix codes, 1x1 -> 4x4 up-convolution, stages with optional skip concat."""
+
+    def __init__(self, ny, skip, last_activation, mixing):
+        super().__init__()
+        self.ny = ny
+        self.skip = skip
+        self.mixing = mixing
+        self.last_activation = activation_factory(last_activation)
+
+    def forward(self, z1, z2, skip=None):
+        assert skip is None and not self.skip or self.skip and skip is not None
+        z = torch.cat([z1, z2], dim=1) if self.mixing == 'concat' else z1 * z2
+        h = run_layers(self.first_upconv, z.view(*z.shape, 1, 1))
+        n_stage = len(self.conv)
+        for i, layer in enumerate(self.conv):
+            if skip is not None:
+                h = torch.cat([h, skip[i].to(h.dtype)], 1)
+            if i == n_stage - 1:
+                h = run_layers(layer, h, final_act=activation_name(self.last_activation), final_fp32=True)
+            else:
+                h = run_layers(layer, h)
+        return h
+
+
+class DCGAN64Decoder(BaseDecoder):
+    """conv.py:233-264."""
+
+    def __init__(self, nc, ny, nf, skip, last_activation, mixing):
+        super().__init__(ny, skip, last_activation, mixing)
+        coef = 2 if skip else 1
+        self.first_upconv = make_conv_block(nn.ConvTranspose2d(ny, nf * 8, 4, 1, 0), activation='leaky_relu')
+        self.conv = nn.ModuleList([
+            make_conv_block(nn.ConvTranspose2d(nf * 8 * coef, nf * 4, 4, 2, 1), activation='leaky_relu'),
+            make_conv_block(nn.ConvTranspose2d(nf * 4 * coef, nf * 2, 4, 2, 1), activation='leaky_relu'),
+            make_conv_block(nn.ConvTranspose2d(nf * 2 * coef, nf, 4, 2, 1), activation='leaky_relu'),
+            nn.ConvTranspose2d(nf * coef, nc, 4, 2, 1),
+        ])
+
+
+class VGG64Decoder(BaseDecoder):
+    """conv.py:267-320."""
+
+    def __init__(self, nc, ny, nf, skip, last_activation, mixing, vgg32=False):
+        super().__init__(ny, skip, last_activation, mixing)
+        coef = 2 if skip else 1
+        self.first_upconv = nn.Sequential(
+            make_conv_block(nn.ConvTranspose2d(ny, nf * 8, 4, 1, 0), activation='leaky_relu'),
+            _up() if not vgg32 else nn.Identity())
+        self.conv = nn.ModuleList([
+            nn.Sequential(_c3(nf * 8 * coef, nf * 8), _c3(nf * 8, nf * 8), _c3(nf * 8, nf * 4), _up()),
+            nn.Sequential(_c3(nf * 4 * coef, nf * 4), _c3(nf * 4, nf * 4), _c3(nf * 4, nf * 2), _up()),
+            nn.Sequential(_c3(nf * 2 * coef, nf * 2), _c3(nf * 2, nf), _up()),
+            nn.Sequential(_c3(nf * coef, nf), nn.ConvTranspose2d(nf, nc, 3, 1, 1)),
+        ])
+
+
+class EncoderSST(nn.Module):
+    """conv.py:323-356: spatial (16x16) code and three skips."""
+
+    def __init__(self, in_c, out_c):
+        super().__init__()
+        self.conv1 = nn.Sequential(_c3(in_c, 64), _c3(64, 64))
+        self.conv2 = nn.Sequential(_pool(), _c3(64, 128), _c3(128, 128))
+        self.conv3 = nn.Sequential(_pool(), _c3(128, 256), _c3(256, 256), _c3(256, 256))
+        self.conv4 = nn.Sequential(_c3(256, 512), _c3(512, out_c), _c3(out_c, out_c, activation='none', bn=False))
+
+    def forward(self, x, return_skip=False):
+        h1 = run_layers(self.conv1, _fold_time(x))
+        h2 = run_layers(self.conv2, h1)
+        h3 = run_layers(self.conv3, h2)
+        h4 = run_layers(self.conv4, h3, final_fp32=True)
+        if return_skip:
+            return h4, [h3, h2, h1]
+        return h4
+
+
+class DecoderSST_Skip(nn.Module):
+    """conv.py:359-396."""
+
+    def __init__(self, in_c, out_c, out_f):
+        super().__init__()
+        self.conv1 = nn.Sequential(_c3(in_c, 256), _c3(256, 256), _c3(256, 128))
+        self.conv2 = nn.Sequential(_c3(256 + 128, 128), _c3(128, 64), _c3(64, 64), _up())
+        self.conv3 = nn.Sequential(_c3(128 + 64, 128), _c3(128, 64), _c3(64, 64), _up())
+        self.conv4 = nn.Sequential(_c3(64 * 2, 64), _c3(64, 64), _c3(64, out_c))
+        self.out_f = activation_factory(out_f)
+
+    def forward(self, s_code, t_code, skip):
+        h3, h2, h1 = skip
+        out = run_layers(self.conv1, torch.cat([s_code, t_code], dim=1))
+        out = run_layers(self.conv2, torch.cat([h3.to(out.dtype), out], dim=1))
+        out = run_layers(self.conv3, torch.cat([h2.to(out.dtype), out], dim=1))
+        return run_layers(self.conv4, torch.cat([h1.to(out.dtype), out], dim=1), final_act=activation_name(self.out_f),
+                          final_fp32=True)
+
+
+class DecoderSST(nn.Module):
+    """conv.py:399-426."""
+
+    def __init__(self, in_c, out_c, out_f):
+        super().__init__()
+        self.conv1 = nn.Sequential(_c3(in_c, 256), _c3(256, 256), _c3(256, 128), _up())
+        self.conv2 = nn.Sequential(_c3(128, 128), _c3(128, 128), _c3(128, 64), _up())
+        self.conv3 = nn.Sequential(_c3(64, 64), _c3(64, out_c))
+        self.out_f = activation_factory(out_f)
+
+    def forward(self, s_code, t_code, skip=None):
+        x = run_layers(self.conv1, torch.cat([s_code, t_code], dim=1))
+        x = run_layers(self.conv2, x)
+        return run_layers(self.conv3, x, final_act=activation_name(self.out_f), final_fp32=True)
+
+
+class ConvResBlock(nn.Module):
+    """resnet.py:53-70."""
+
+    def __init__(self, in_c, out_c, nf=64):
+        super().__init__()
+        self.conv = nn.Sequential(_c3(in_c, nf), _c3(nf, nf), _c3(nf, out_c, activation='none'))
+        self.up = _c3(in_c, out_c, activation='none') if in_c != out_c else nn.Identity()
+
+    def forward(self, x):
+        residual = run_layers(self.conv, x, final_fp32=True)
+        skip = x if isinstance(self.up, nn.Identity) else run_layers(self.up, x, final_fp32=True)
+        return skip + residual, residual
+
+
+class ConvResnet(nn.Module):
+    """resnet.py:73-88: the conv integrator used with `--architecture encoderSST`."""
+
+    def __init__(self, in_c, n_blocks=1, nf=64):
+        super().__init__()
+        self.n_blocks = n_blocks
+        self.resblock_modules = nn.ModuleList([ConvResBlock(in_c, in_c, nf=nf) for _ in range(n_blocks)])
+
+    def forward(self, x, return_res=True):
+        residuals = []
+        for blk in self.resblock_modules:
+            x, residual = blk(x)
+            residuals.append(residual)
+        return (x, residuals) if return_res else x

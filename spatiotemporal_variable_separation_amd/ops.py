@@ -219,3 +219,161 @@ def mlp_rollout_bwd(grad_t_codes, weights_t, h1, h2, m1, m2, n_steps):
     fl = 2.0 * B * steps * nb * (2 * C * H + H * H)
     _pe(e0, 'vs_mlp_rollout_bwd<%s>' % ('bf16' if cdt == torch.bfloat16 else 'f32'), flops=fl)
     return dx0, dr, dh2, dh1
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+def _conv_out_hw(H, W, k, stride, pad, transposed):
+    if transposed:
+        return (H - 1) * stride - 2 * pad + k, (W - 1) * stride - 2 * pad + k
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype):
+    """x [B,Cin,H,W], w Conv2d [Cout,Cin,k,k] / ConvTranspose2d [Cin,Cout,k,k] in the same (compute) dtype."""
+    require_cuda(x, w, bias)
+    assert x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
+    B, Cin, H, W = x.shape
+    k = w.shape[2]
+    Cout = w.shape[1] if transposed else w.shape[0]
+    OH, OW = _conv_out_hw(H, W, k, stride, pad, transposed)
+    y = torch.empty((B, Cout, OH, OW), dtype=out_dtype, device=x.device)
+    lib = _lib.load_library()
+    fn = lib.vs_conv_transpose2d_fwd if transposed else lib.vs_conv2d_fwd
+    e0 = _pb()
+    check(fn(dtype_code(x), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W, Cout, k, k,
+             stride, pad, stream_ptr()), 'vs_conv_fwd')
+    _pe(e0, 'vs_conv%s_fwd<%s>' % ('T' if transposed else '', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
+        flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
+        nbytes=float(x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()))
+    return y
+
+
+def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype):
+    require_cuda(dy, w)
+    assert dy.is_contiguous() and w.is_contiguous() and dy.dtype == w.dtype
+    B, Cin, H, W = x_shape
+    k = w.shape[2]
+    Cout = w.shape[1] if transposed else w.shape[0]
+    dx = torch.empty((B, Cin, H, W), dtype=out_dtype, device=dy.device)
+    lib = _lib.load_library()
+    fn = lib.vs_conv_transpose2d_dgrad if transposed else lib.vs_conv2d_dgrad
+    e0 = _pb()
+    check(fn(dtype_code(dy), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dtype_code(dx), B, Cin, H, W, Cout, k, k, stride, pad,
+             stream_ptr()), 'vs_conv_dgrad')
+    OH, OW = dy.shape[2], dy.shape[3]
+    _pe(e0, 'vs_conv%s_dgrad<%s>' % ('T' if transposed else '', 'bf16' if dy.dtype == torch.bfloat16 else 'f32'),
+        flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
+        nbytes=float(dy.numel() * dy.element_size() + w.numel() * w.element_size() + dx.numel() * dx.element_size()))
+    return dx
+
+
+def conv_wgrad(dy, x, w_shape, stride, pad, transposed):
+    require_cuda(dy, x)
+    assert dy.is_contiguous() and x.is_contiguous() and dy.dtype == x.dtype
+    B, Cin, H, W = x.shape
+    k = w_shape[2]
+    Cout = w_shape[1] if transposed else w_shape[0]
+    OH, OW = dy.shape[2], dy.shape[3]
+    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    lib = _lib.load_library()
+    pix_h, pix_w = (H, W) if transposed else (OH, OW)
+    ws_bytes = lib.vs_conv_wgrad_workspace_bytes(B, Cin, pix_h, pix_w, Cout, k, k)
+    ws = _workspace(ws_bytes, x.device) if ws_bytes else None
+    fn = lib.vs_conv_transpose2d_wgrad if transposed else lib.vs_conv2d_wgrad
+    e0 = _pb()
+    check(fn(dtype_code(x), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, k, k, stride, pad, _ptr(ws),
+             ws.numel() if ws is not None else 0, stream_ptr()), 'vs_conv_wgrad')
+    _pe(e0, 'vs_conv%s_wgrad<%s>' % ('T' if transposed else '', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
+        flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
+        nbytes=float(dy.numel() * dy.element_size() + x.numel() * x.element_size() + dw.numel() * 4))
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------ norm / pool / upsample
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    require_cuda(x)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+    check(_lib.load_library().vs_bn_stats(x.data_ptr(), dtype_code(x), B, C, HW, mean.data_ptr(), invstd.data_ptr(),
+                                          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), stream_ptr()),
+          'vs_bn_stats')
+    return mean, invstd
+
+
+def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype):
+    require_cuda(x)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_bn_act_fwd(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), mean.data_ptr(),
+                                            invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], B, C, HW, stream_ptr()),
+          'vs_bn_act_fwd')
+    _pe(e0, 'vs_bn_act_fwd', nbytes=float(x.numel() * (x.element_size() + y.element_size())))
+    return y
+
+
+def bn_act_bwd(dy, x, mean, invstd, gamma, beta, act, training, out_dtype):
+    require_cuda(dy, x)
+    dy = dy.contiguous()
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
+    dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
+    dx = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_bn_act_bwd(dy.data_ptr(), dtype_code(dy), x.data_ptr(), dtype_code(x), mean.data_ptr(),
+                                            invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], int(bool(training)),
+                                            dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), dtype_code(dx), B, C, HW,
+                                            stream_ptr()), 'vs_bn_act_bwd')
+    _pe(e0, 'vs_bn_act_bwd', nbytes=float(x.numel() * (2 * x.element_size() + 2 * dy.element_size() + dx.element_size())))
+    return dx, dgamma, dbeta
+
+
+def chan_sum(x):
+    require_cuda(x)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+    check(_lib.load_library().vs_chan_sum(x.data_ptr(), dtype_code(x), B, C, HW, out.data_ptr(), stream_ptr()), 'vs_chan_sum')
+    return out
+
+
+def maxpool2_fwd(x):
+    require_cuda(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+    check(_lib.load_library().vs_maxpool2_fwd(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), B * C, H, W, stream_ptr()),
+          'vs_maxpool2_fwd')
+    return y
+
+
+def maxpool2_bwd(x, dy):
+    require_cuda(x, dy)
+    B, C, H, W = x.shape
+    dy = dy.contiguous()
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    check(_lib.load_library().vs_maxpool2_bwd(x.data_ptr(), dtype_code(x), dy.data_ptr(), dtype_code(dy), dx.data_ptr(),
+                                              dtype_code(dx), B * C, H, W, stream_ptr()), 'vs_maxpool2_bwd')
+    return dx
+
+
+def upsample2_fwd(x):
+    require_cuda(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+    check(_lib.load_library().vs_upsample2_fwd(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), B * C, H, W, stream_ptr()),
+          'vs_upsample2_fwd')
+    return y
+
+
+def upsample2_bwd(dy, out_dtype):
+    require_cuda(dy)
+    dy = dy.contiguous()
+    B, C, H2, W2 = dy.shape
+    dx = torch.empty((B, C, H2 // 2, W2 // 2), dtype=out_dtype, device=dy.device)
+    check(_lib.load_library().vs_upsample2_bwd(dy.data_ptr(), dtype_code(dy), dx.data_ptr(), dtype_code(dx), B * C, H2 // 2, W2 // 2,
+                                               stream_ptr()), 'vs_upsample2_bwd')
+    return dx

@@ -9,8 +9,8 @@ from .utils.helper import save
 def zero_order_loss(s_code_old, s_code_new, skipco):
     """Mean squared difference between the spatial codes of the first and last windows (train.py:38-42)."""
     if skipco:
-        s_code_old = torch.cat([s_code_old[0].flatten()] + [x.flatten() for x in s_code_old[1]])
-        s_code_new = torch.cat([s_code_new[0].flatten()] + [x.flatten() for x in s_code_new[1]])
+        s_code_old = torch.cat([s_code_old[0].flatten().float()] + [x.flatten().float() for x in s_code_old[1]])
+        s_code_new = torch.cat([s_code_new[0].flatten().float()] + [x.flatten().float() for x in s_code_new[1]])
     return (s_code_old - s_code_new).pow(2).mean()
 
 

@@ -1,0 +1,112 @@
+"""GPU parity of the convolution / BatchNorm / pooling kernels (through the C ABI) against torch CPU fp64 ops.
+
+fp32 compute: tolerance 1e-5 relative L2 (exact-fp32 MFMA; only the summation order differs from ATen).
+bf16 compute: operands are bf16-rounded first, then compared with the fp64 result on those rounded operands
+(tolerance 1e-5 on fp32 outputs): the kernel adds no error beyond the stated operand rounding.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (B, Cin, H, W, Cout, k, stride, pad, transposed)  -- every conv geometry the reference uses, at reduced widths
+GEOMS = [
+    (3, 5, 64, 64, 8, 4, 2, 1, False),      # DCGAN encoder layer 0 (conv.py:119)
+    (2, 16, 16, 16, 32, 4, 2, 1, False),    # DCGAN encoder mid layers
+    (3, 8, 32, 32, 8, 3, 1, 1, False),      # VGG / SST / ConvResBlock 3x3
+    (2, 12, 4, 4, 7, 4, 1, 0, False),       # VGG encoder last_op: 4x4 valid -> 1x1
+    (4, 11, 1, 1, 16, 4, 1, 0, True),       # decoder first_upconv: 1x1 -> 4x4 (conv.py:258,295)
+    (2, 16, 8, 8, 8, 4, 2, 1, True),        # DCGAN decoder k4 s2 p1
+    (3, 8, 32, 32, 1, 4, 2, 1, True),       # DCGAN decoder last layer (Cout = nc = 1)
+    (2, 6, 16, 16, 2, 3, 1, 1, True),       # VGG decoder last layer: ConvTranspose2d k3 s1 p1
+    (1, 130, 8, 8, 70, 3, 1, 1, False),     # odd channel counts (K and M tails)
+]
+
+
+def _rand(shape, salt, scale=1.0):
+    from oracle.detdata import det_uniform
+    return (det_uniform(shape, salt) - 0.5) * 2.0 * scale
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('geom', GEOMS)
+def test_conv_fwd_dgrad_wgrad(dtype, geom):
+    from spatiotemporal_variable_separation_amd import ops
+    B, Cin, H, W, Cout, k, s, p, tr = geom
+    x = _rand((B, Cin, H, W), 1).to(dtype)
+    wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    w = _rand(wshape, 2, 0.3).to(dtype)
+    bias = _rand((Cout,), 3)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    fn = F.conv_transpose2d if tr else F.conv2d
+    y64 = fn(x64, w64, bias.double(), stride=s, padding=p)
+    dy = _rand(tuple(y64.shape), 4).to(dtype)
+    y64.backward(dy.double())
+
+    def rel(a, b):
+        return ((a.cpu().double() - b).norm() / (b.norm() + 1e-30)).item()
+    y = ops.conv_fwd(x.cuda(), w.cuda(), bias.cuda(), s, p, tr, torch.float32)
+    assert tuple(y.shape) == tuple(y64.shape)
+    assert rel(y, y64.detach()) < 1e-5, f'fwd {geom} {dtype}'
+    dx = ops.conv_dgrad(dy.cuda(), w.cuda(), x.shape, s, p, tr, torch.float32)
+    assert rel(dx, x64.grad) < 1e-5, f'dgrad {geom} {dtype}'
+    dw = ops.conv_wgrad(dy.cuda(), x.cuda(), wshape, s, p, tr)
+    assert rel(dw, w64.grad) < 1e-5, f'wgrad {geom} {dtype}'
+
+
+@pytest.mark.parametrize('act', ['leaky_relu', 'relu', 'none', 'sigmoid'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_batchnorm_act_fwd_bwd(act, dtype):
+    from spatiotemporal_variable_separation_amd import ops
+    B, C, H, W = 5, 7, 12, 10
+    x = (_rand((B, C, H, W), 11) * 2 + 0.3).to(dtype)
+    gamma, beta = 1 + _rand((C,), 12, 0.3), _rand((C,), 13, 0.2)
+    dy = _rand((B, C, H, W), 14)
+    rm, rv = _rand((C,), 15, 0.1), 1 + _rand((C,), 16, 0.2)
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    acts = {'leaky_relu': lambda t: F.leaky_relu(t, 0.2), 'relu': torch.relu, 'none': lambda t: t, 'sigmoid': torch.sigmoid}
+    x64 = x.double().requires_grad_(True)
+    y64 = acts[act](bn(x64))
+    y64.backward(dy.double())
+    rmc, rvc = rm.clone().cuda(), rv.clone().cuda()
+    xc = x.cuda()
+    mean, invstd = ops.bn_stats(xc, rmc, rvc, 0.1, 1e-5)
+    y = ops.bn_act_fwd(xc, mean, invstd, gamma.cuda(), beta.cuda(), act, torch.float32)
+    dx, dg, db = ops.bn_act_bwd(dy.cuda(), xc, mean, invstd, gamma.cuda(), beta.cuda(), act, True, torch.float32)
+
+    def rel(a, b):
+        return ((a.cpu().double() - b).norm() / (b.norm() + 1e-30)).item()
+    assert rel(y, y64.detach()) < 2e-6
+    assert rel(rmc, bn.running_mean) < 2e-6 and rel(rvc, bn.running_var) < 2e-6
+    assert rel(dx, x64.grad) < 2e-5
+    assert rel(dg, bn.weight.grad) < 2e-5 and rel(db, bn.bias.grad) < 2e-5
+    # 16 sequential calls update the running statistics sequentially
+    for _ in range(15):
+        bn(x64.detach())
+        ops.bn_stats(xc, rmc, rvc, 0.1, 1e-5)
+    assert rel(rmc, bn.running_mean) < 1e-5 and rel(rvc, bn.running_var) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pool_upsample(dtype):
+    from spatiotemporal_variable_separation_amd import ops
+    x = _rand((3, 5, 8, 12), 21).to(dtype)
+    x64 = x.double().requires_grad_(True)
+    y64 = F.max_pool2d(x64, 2, 2)
+    dy = _rand(tuple(y64.shape), 22).to(dtype)
+    y64.backward(dy.double())
+    y = ops.maxpool2_fwd(x.cuda())
+    assert torch.equal(y.cpu().double(), y64.detach())
+    dx = ops.maxpool2_bwd(x.cuda(), dy.cuda())
+    assert torch.equal(dx.cpu().double(), x64.grad)
+    x64b = x.double().requires_grad_(True)
+    u64 = F.interpolate(x64b, scale_factor=2, mode='nearest')
+    du = _rand(tuple(u64.shape), 23)
+    u64.backward(du.double())
+    u = ops.upsample2_fwd(x.cuda())
+    assert torch.equal(u.cpu().double(), u64.detach())
+    dxu = ops.upsample2_bwd(du.cuda(), torch.float32)
+    assert ((dxu.cpu().double() - x64b.grad).norm() / x64b.grad.norm()).item() < 1e-6
