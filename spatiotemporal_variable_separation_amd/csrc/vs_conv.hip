@@ -171,8 +171,12 @@ int run(const OpA& a, const OpB& b, int64_t M, int64_t N, int64_t K, const Epi& 
     {                                                                                                                     \
         constexpr size_t smem = (TileGeom<CT, OpA::layout, BM_, BK>::ELEMS + TileGeom<CT, OpB::layout, BN_, BK>::ELEMS) * sizeof(T); \
         grid = dim3((unsigned)vs_cdiv(N, BN_), (unsigned)vs_cdiv(M, BM_), (unsigned)plan.splits);                         \
-        hipLaunchKernelGGL((gemm_kernel<CT, OpA, OpB, BM_, BN_, BK>), grid, block, smem, stream, a, b, M, N, K,           \
-                           (int)plan.k_tiles_per_split, epi, slabs);                                                      \
+        if (epi.nchw_hw > 0)                                                                                              \
+            hipLaunchKernelGGL((gemm_kernel<CT, OpA, OpB, BM_, BN_, BK, true>), grid, block, smem, stream, a, b, M, N, K, \
+                               (int)plan.k_tiles_per_split, epi, slabs);                                                  \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gemm_kernel<CT, OpA, OpB, BM_, BN_, BK, false>), grid, block, smem, stream, a, b, M, N, K,\
+                               (int)plan.k_tiles_per_split, epi, slabs);                                                  \
     }
     if (plan.bm == 128 && plan.bn == 128) VS_LAUNCH(128, 128)
     else if (plan.bm == 128) VS_LAUNCH(128, 64)

@@ -21,21 +21,31 @@ struct Epi {
     int64_t nchw_hw, nchw_c;
 };
 
+// row-major form: element (m, n) at C[m*ldc + n], bias per column
 __device__ __forceinline__ void epi_store(const Epi& e, int64_t m, int64_t n, float v) {
     v *= e.alpha;
-    int64_t idx;
-    if (e.nchw_hw > 0) {
-        if (e.bias) v += e.bias[m];
-        const int64_t b = n / e.nchw_hw;
-        idx = (b * e.nchw_c + m) * e.nchw_hw + (n - b * e.nchw_hw);
-    } else {
-        if (e.bias) v += e.bias[n];
-        idx = m * e.ldc + n;
-    }
+    if (e.bias) v += e.bias[n];
     v = vs_act(v, e.act);
-    if (e.mask) v *= vs_act_grad_from_out(vs_ld(e.mask, e.mask_dtype, e.nchw_hw > 0 ? idx : m * e.ldmask + n), e.mask_act);
+    if (e.mask) v *= vs_act_grad_from_out(vs_ld(e.mask, e.mask_dtype, m * e.ldmask + n), e.mask_act);
+    const int64_t idx = m * e.ldc + n;
     if (e.accumulate) v += vs_ld(e.C, e.c_dtype, idx);
     vs_st(e.C, e.c_dtype, idx, v);
+}
+
+// NCHW form: `col_base` = (n / hw) * C * hw + n % hw is computed once per column by the caller; bias per row (channel)
+__device__ __forceinline__ void epi_store_nchw(const Epi& e, int64_t m, int64_t col_base, float v) {
+    v *= e.alpha;
+    if (e.bias) v += e.bias[m];
+    v = vs_act(v, e.act);
+    const int64_t idx = col_base + m * e.nchw_hw;
+    if (e.mask) v *= vs_act_grad_from_out(vs_ld(e.mask, e.mask_dtype, idx), e.mask_act);
+    if (e.accumulate) v += vs_ld(e.C, e.c_dtype, idx);
+    vs_st(e.C, e.c_dtype, idx, v);
+}
+
+__device__ __forceinline__ int64_t nchw_col_base(const Epi& e, int64_t n) {
+    const int64_t b = n / e.nchw_hw;
+    return b * e.nchw_c * e.nchw_hw + (n - b * e.nchw_hw);
 }
 
 // ---- dense operand: element (i,k) at p[i*ld+k] (R) or p[k*ld+i] (S); T = storage = compute type -------
@@ -148,7 +158,7 @@ __device__ __forceinline__ f32x4 frag_f32(const float* tile, int row0, int kk, i
     }
 }
 
-template <int CT, class OpA, class OpB, int BM, int BN, int BK>
+template <int CT, class OpA, class OpB, int BM, int BN, int BK, bool NCHW = false>
 __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int64_t N, int64_t K,
                                                    int k_tiles_per_split, Epi epi, float* slabs) {
     typedef typename CTraits<CT>::T T;
@@ -237,11 +247,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
         for (int j = 0; j < TN; ++j) {
             const int64_t n = n0 + wn + 32 * j + cj;
             if (n >= N) continue;
+            int64_t col_base = 0;
+            if constexpr (NCHW) col_base = nchw_col_base(epi, n);
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int64_t m = m0 + wm + 32 * i + (v & 3) + 8 * (v >> 2) + rh;
                 if (m >= M) continue;
                 if (slabs) slabs[((int64_t)blockIdx.z * M + m) * N + n] = acc[i][j][v];
+                else if constexpr (NCHW) epi_store_nchw(epi, m, col_base, acc[i][j][v]);
                 else epi_store(epi, m, n, acc[i][j][v]);
             }
         }
@@ -252,7 +265,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < splits; ++s) v += slabs[(int64_t)s * total + idx];      // fixed order: reproducible
-        epi_store(epi, idx / N, idx % N, v);
+        const int64_t m = idx / N, n = idx - m * N;
+        if (epi.nchw_hw > 0) epi_store_nchw(epi, m, nchw_col_base(epi, n), v);
+        else epi_store(epi, m, n, v);
     }
 }
 

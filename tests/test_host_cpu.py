@@ -1,0 +1,96 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the CLI surface matches the reference,
+the product refuses to run without a GPU (no silent CPU fallback), module trees are state-dict compatible."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'varsep_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(vs_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from spatiotemporal_variable_separation_amd import _lib
+    _lib.build_library()
+    lib = _lib.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/varsep_hip.h but not exported'
+        assert name in _lib.SIGNATURES, f'{name} has no ctypes signature'
+    assert set(_lib.SIGNATURES) == set(declared)
+    assert lib.vs_version().decode().startswith('varsep_hip')
+    assert lib.vs_gemm_workspace_bytes(128, 1200, 20480) > 0        # host-side planning only, no GPU call
+    assert lib.vs_gemm_workspace_bytes(4096, 4096, 4096) == 0
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from spatiotemporal_variable_separation_amd import _lib
+    lib = _lib.load_library()
+    rc = lib.vs_gemm(0, -1, 4, 4, None, 4, 0, None, 4, 0, None, 4, 0, 1.0, None, 0, None, 0, 0, 0, 0, None, 0, None)
+    assert rc == -1 and b'vs_gemm' in lib.vs_last_error()
+
+
+def test_product_refuses_cpu_tensors():
+    from spatiotemporal_variable_separation_amd import _lib
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from oracle.golden_configs import CONFIGS, make_batch
+    for name in ('mlp_mul', 'dcgan_tiny'):
+        cfg = CONFIGS[name]
+        net = build_sep_net(cfg)
+        cond, _ = make_batch(cfg)
+        with pytest.raises(_lib.VarsepHipError, match='no CPU fallback'):
+            net.get_forecast(cond, 3)
+
+
+def test_state_dict_layout_matches_reference_compatible_oracle():
+    from oracle import cpu_ref
+    from oracle.golden_configs import CONFIGS
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    for name, cfg in CONFIGS.items():
+        a, b = build_sep_net(cfg).state_dict(), cpu_ref.build_sep_net(cfg).state_dict()
+        assert list(a.keys()) == list(b.keys()), name
+        for k in a:
+            assert a[k].shape == b[k].shape, (name, k)
+
+
+def test_cli_matches_reference_surface():
+    from spatiotemporal_variable_separation_amd.options import parser
+    # README recipes of the reference, including the `--gain_res` abbreviation of the SST recipe (README.md:86)
+    args = parser.parse_args('--xp_dir x --data_dir d --data sst --nt_cond 4 --nt_pred 6 --epochs 30 --code_size_t 64 '
+                             '--code_size_s 196 --gain_res 0.2 --offset 0 --gain_resnet 0.71 --architecture encoderSST '
+                             '--decoder_architecture decoderSST --lamb_ae 1 --lamb_s 100 --lamb_t 5e-6 --skipco '
+                             '--n_blocks 2'.split())
+    assert args.gain_resnet == 0.71 and args.skipco and args.n_blocks == 2 and args.offset == 0
+    d = parser.parse_args('--xp_dir x --data_dir d'.split())
+    assert (d.nt_cond, d.nt_pred, d.code_size_s, d.code_size_t, d.batch_size, d.lr, d.offset) == (5, 10, 128, 20, 128, 4e-4, 5)
+    assert (d.lamb_ae, d.lamb_s, d.lamb_t, d.lamb_pred, d.beta1, d.beta2) == (10, 45, 0.001, 45, 0.9, 0.99)
+    assert d.architecture == 'dcgan' and d.mixing == 'concat' and d.res_hidden_size == 512 and d.gain_resnet == 1.41
+    with pytest.raises(SystemExit):
+        parser.parse_args('--xp_dir x --data_dir d --torch_amp --apex_amp'.split())
+
+
+def test_factory_asserts_like_reference():
+    from spatiotemporal_variable_separation_amd.networks.factory import get_decoder, get_encoder
+    with pytest.raises(AssertionError):
+        get_decoder('mlp', [1, 8, 8], 4, 6, 'sigmoid', 8, 3, 'mul', False, 'normal', 0.02)      # mul needs equal codes
+    with pytest.raises(AssertionError):
+        get_decoder('mlp', [1, 8, 8], 4, 4, 'sigmoid', 8, 3, 'concat', True, 'normal', 0.02)    # skipco needs conv decoder
+    with pytest.raises(AssertionError):
+        get_encoder('dcgan', [1, 32, 32], 8, 4, 3, 2, 'normal', 0.02)                             # dcgan is 64x64 only
+
+
+def test_init_net_statistics():
+    from spatiotemporal_variable_separation_amd.networks.factory import get_resnet, get_encoder
+    torch.manual_seed(0)
+    r = get_resnet(8, 1, 64, 'orthogonal', 1.41)
+    w = r.blocks[0].mlp.module[0][0].weight             # [64, 8] orthogonal columns scaled by the gain
+    assert torch.allclose(w.t() @ w, 1.41 ** 2 * torch.eye(8), atol=1e-4)
+    e = get_encoder('mlp', [1, 8, 8], 4, 256, 3, 2, 'normal', 0.02)
+    assert abs(e.mlp.module[1][1].weight.std().item() - 0.02) < 2e-3 and e.mlp.module[1][1].bias.abs().max() == 0
