@@ -11,25 +11,37 @@ _PROF = {'on': False, 'events': []}
 _LNAME = {0: 'R', 1: 'S'}
 
 
-def profile_reset(enable=True):
+def profile_reset(enable=True, pool=0):
+    """Start (or stop) per-launch event timing.  `pool` events are created and recorded once up front so that the timed
+    region only re-records existing HIP events (creating thousands of events inside the region slows the host)."""
     _PROF['on'] = enable
     _PROF['events'] = []
+    _PROF['pool'] = []
+    if enable and pool:
+        for _ in range(pool):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            _PROF['pool'].append(e)
+        torch.cuda.synchronize()
+
+
+def _new_event():
+    pool = _PROF.get('pool')
+    e = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
 
 
 def _pb():
     if not _PROF['on']:
         return None
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    return e
+    return _new_event()
 
 
 def _pe(e0, name, flops=0.0, nbytes=0.0):
     if e0 is None:
         return
-    e1 = torch.cuda.Event(enable_timing=True)
-    e1.record()
-    _PROF['events'].append((name, e0, e1, flops, nbytes))
+    _PROF['events'].append((name, e0, _new_event(), flops, nbytes))
 
 
 def profile_collect():
