@@ -133,15 +133,20 @@ int vs_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, 
  *   t_codes   [B, n, C] fp32      every code of the rollout, t_codes[:, 0] = x0 (the layout get_forecast returns)
  *   residuals [n-1, n_blocks, B, C] fp32 or NULL   (the `t_residuals` the reference returns)
  *   xin_save [nb, n-1, B, C], h1_save / h2_save [nb, n-1, B, H]  compute type: inputs of the weight-gradient GEMMs
- *   m1_save / m2_save [nb, n-1, B, 32] uint32: ReLU sign bits of h1 / h2 (word j of a row holds columns j + 32 u in
- *             bit u), so the backward kernel reads 2 words per thread and step instead of the activations
+ *   m1_save / m2_save [nb, n-1, B, P, 32] uint32, P = vs_mlp_rollout_parts(...): ReLU sign bits of h1 / h2 (word
+ *             (q, j) of a row holds columns q*H/P + j + 32 u in bit u), so the backward kernel reads a few words per
+ *             thread and step instead of the activations
+ *   workspace: exchange area of vs_mlp_rollout_workspace_bytes(...) bytes (zeroed by the call).  When the hidden size
+ *             allows it the H x H layer of every 16-row slab is split over P workgroups (P CUs stream 1/P of the
+ *             weights each); they all-reduce one [16, C] partial per block-step through this area with epoch-tagged
+ *             8-byte granules (placement independent, bounded spins).  NULL / too small => P = 1 (no split).
  * Backward (through time):
  *   grad_t_codes [B, n, C] fp32   gradient wrt every code;  weights_t: host array of 3*n_blocks device pointers
  *             {W3^T [H,C], W2^T [H,H], W1^T [C,H]} per block, packed with vs_pack_rollout_weight(transpose = 1)
  *   dx0 [B, C] fp32; dr_save [nb, n-1, B, C], dh2_save / dh1_save [nb, n-1, B, H] compute type.
  *   Weight gradients are then vs_gemm(dh1_save[b] (S), xin_save[b] (S)) etc. with K = (n-1)*B, bias gradients
  *   vs_colsum of the same buffers.
- * One workgroup per 16 batch rows; no inter-workgroup communication; results are bitwise reproducible.
+ * P workgroups per 16 batch rows; partial sums are combined in a fixed order: results are bitwise reproducible.
  * Limits: n_blocks <= 8; LDS footprint (grows with H) must fit 160 KiB (H <= ~2048 in bf16).
  */
 /* Pre-pack of one integrator weight for the rollout kernels: the logical matrix L[N][K] (L = src if transpose == 0,
@@ -152,14 +157,17 @@ int vs_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, 
 size_t vs_rollout_packed_elems(int compute, int N, int K);
 int vs_pack_rollout_weight(int compute, const float* src, int transpose, int N, int K, void* dst, void* stream);
 
+int vs_mlp_rollout_parts(int compute, int B, int C, int H);
+size_t vs_mlp_rollout_workspace_bytes(int compute, int B, int C, int H);
 int vs_mlp_rollout_fwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* x0,
                        const void* const* weights, const float* const* biases, float* t_codes, float* residuals,
-                       void* xin_save, void* h1_save, void* h2_save, uint32_t* m1_save, uint32_t* m2_save, void* stream);
+                       void* xin_save, void* h1_save, void* h2_save, uint32_t* m1_save, uint32_t* m2_save, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 int vs_mlp_rollout_bwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* grad_t_codes,
                        const void* const* weights_t, const void* h1_save, const void* h2_save,
                        const uint32_t* m1_save, const uint32_t* m2_save, float* dx0,
-                       void* dr_save, void* dh2_save, void* dh1_save, void* stream);
+                       void* dr_save, void* dh2_save, void* dh1_save, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolutions as im2col-free implicit GEMMs on NCHW tensors (csrc/vs_conv.hip).  x [B,Cin,H,W], stride/pad equal

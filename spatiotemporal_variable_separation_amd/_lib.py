@@ -106,8 +106,10 @@ SIGNATURES = {
     'vs_transpose_cast': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'vs_rollout_packed_elems': (_sz, [_i32, _i32, _i32]),
     'vs_pack_rollout_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
-    'vs_mlp_rollout_fwd': (_i32, [_i32] * 6 + [_vp] * 11),
-    'vs_mlp_rollout_bwd': (_i32, [_i32] * 6 + [_vp] * 11),
+    'vs_mlp_rollout_parts': (_i32, [_i32] * 4),
+    'vs_mlp_rollout_workspace_bytes': (_sz, [_i32] * 4),
+    'vs_mlp_rollout_fwd': (_i32, [_i32] * 6 + [_vp] * 11 + [_sz, _vp]),
+    'vs_mlp_rollout_bwd': (_i32, [_i32] * 6 + [_vp] * 11 + [_sz, _vp]),
 }
 
 

@@ -161,6 +161,28 @@ def transpose_cast(src, dtype, out=None):
     return out
 
 
+_roll_ws = {}
+
+
+def _rollout_workspace(nbytes, device):
+    """Exchange area of the multi-workgroup rollout (one per device, grow-only; zeroed by every call of the library)."""
+    if not nbytes:
+        return None
+    buf = _roll_ws.get(device.index)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _roll_ws[device.index] = buf
+    return buf
+
+
+def rollout_exchange_error(device):
+    """Non-zero iff a bounded spin of the rollout exchange timed out since the last launch (debug aid; synchronises)."""
+    buf = _roll_ws.get(device.index)
+    if buf is None:
+        return 0
+    return int(buf[-16:-12].view(torch.int32).item())
+
+
 def _ptr_array(tensors):
     import ctypes
     arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
@@ -195,14 +217,19 @@ def mlp_rollout_fwd(x0, weights, biases, n_steps, H, want_residuals=True):
     xin = torch.empty((nb, steps, B, C), dtype=cdt, device=dev)
     h1 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
     h2 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
-    m1 = torch.empty((nb, steps, B, 32), dtype=torch.int32, device=dev)
-    m2 = torch.empty((nb, steps, B, 32), dtype=torch.int32, device=dev)
+    lib = _lib.load_library()
+    code = dtype_code(weights[0])
+    parts = lib.vs_mlp_rollout_parts(code, B, C, H)
+    m1 = torch.empty((nb, steps, B, parts, 32), dtype=torch.int32, device=dev)
+    m2 = torch.empty((nb, steps, B, parts, 32), dtype=torch.int32, device=dev)
+    xws = _rollout_workspace(lib.vs_mlp_rollout_workspace_bytes(code, B, C, H), dev)
     wa, ba = _ptr_array(weights), _ptr_array(biases)
     e0 = _pb()
     check(_lib.load_library().vs_mlp_rollout_fwd(dtype_code(weights[0]), B, C, H, nb, n_steps, x0.data_ptr(),
                                                  ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                                  t_codes.data_ptr(), _ptr(residuals), xin.data_ptr(), h1.data_ptr(),
-                                                 h2.data_ptr(), m1.data_ptr(), m2.data_ptr(), stream_ptr()),
+                                                 h2.data_ptr(), m1.data_ptr(), m2.data_ptr(), _ptr(xws),
+                                                 xws.numel() if xws is not None else 0, stream_ptr()),
           'vs_mlp_rollout_fwd')
     fl = 2.0 * B * steps * nb * (2 * C * H + H * H)
     _pe(e0, 'vs_mlp_rollout_fwd<%s>' % ('bf16' if cdt == torch.bfloat16 else 'f32'), flops=fl)
@@ -223,11 +250,14 @@ def mlp_rollout_bwd(grad_t_codes, weights_t, h1, h2, m1, m2, n_steps):
     dh2 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
     dh1 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
     wa = _ptr_array(weights_t)
+    lib = _lib.load_library()
+    xws = _rollout_workspace(lib.vs_mlp_rollout_workspace_bytes(dtype_code(weights_t[0]), B, C, H), dev)
     e0 = _pb()
     check(_lib.load_library().vs_mlp_rollout_bwd(dtype_code(weights_t[0]), B, C, H, nb, n_steps, grad_t_codes.data_ptr(),
                                                  ctypes.cast(wa, ctypes.c_void_p), h1.data_ptr(), h2.data_ptr(),
                                                  m1.data_ptr(), m2.data_ptr(), dx0.data_ptr(), dr.data_ptr(), dh2.data_ptr(), dh1.data_ptr(),
-                                                 stream_ptr()), 'vs_mlp_rollout_bwd')
+                                                 _ptr(xws), xws.numel() if xws is not None else 0, stream_ptr()),
+          'vs_mlp_rollout_bwd')
     fl = 2.0 * B * steps * nb * (2 * C * H + H * H)
     _pe(e0, 'vs_mlp_rollout_bwd<%s>' % ('bf16' if cdt == torch.bfloat16 else 'f32'), flops=fl)
     return dx0, dr, dh2, dh1
