@@ -109,6 +109,13 @@ int vs_copy2d(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dt
 int vs_colsum(const void* X, int x_dtype, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate,
               void* stream);
 
+/* Up to 12 column-sum jobs in ONE launch (all bias gradients of a Linear chain or of the integrator): job j adds the
+ * column sums of X[j] ([M[j], N[j]], leading dimension ldx[j]) into out[j][0..N[j]).  All arrays are HOST arrays of
+ * n_jobs entries.  When zero_base is non-NULL, zero_count floats starting there are cleared first (lay the outputs out in
+ * one flat buffer and clear it with this single memset).                                                               */
+int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const int64_t* ldx, const int64_t* M, const int64_t* N,
+                    float* const* out, float* zero_base, int64_t zero_count, void* stream);
+
 /* dz[i] = dy[i] * act'(y[i]) evaluated from the activation OUTPUT y (see vs_gemm mask semantics).
  * Backward of the trailing activation of a chain (mlp_encdec.py:49 last_activation, conv.py:230).  */
 int vs_act_bwd(const void* dy, int dy_dtype, const void* y, int y_dtype, void* dz, int dz_dtype, int act,

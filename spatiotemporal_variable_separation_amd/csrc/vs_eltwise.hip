@@ -84,7 +84,61 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* X, int xd, int6
     if (g == 0 && n < N) atomicAdd(out + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
+// several column-sum jobs in one launch (all bias gradients of a Linear chain): blockIdx.x walks the jobs' column blocks
+constexpr int CS_MAXJ = 12;
+struct ColsumJobs {
+    int nj;
+    const void* x[CS_MAXJ]; int dt[CS_MAXJ];
+    int64_t ld[CS_MAXJ], M[CS_MAXJ], N[CS_MAXJ];
+    float* out[CS_MAXJ];
+    int blk_off[CS_MAXJ + 1];
+};
+
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumJobs J) {
+    __shared__ float part[4][64];
+    int j = 0;
+    while (j + 1 < J.nj && (int)blockIdx.x >= J.blk_off[j + 1]) ++j;
+    const int64_t M = J.M[j], N = J.N[j], ldx = J.ld[j];
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    if (r0 >= M) return;
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t n = (int64_t)(blockIdx.x - J.blk_off[j]) * 64 + c;
+    int64_t r1 = r0 + CS_ROWS;
+    if (r1 > M) r1 = M;
+    const void* X = J.x[j];
+    const int xd = J.dt[j];
+    float s = 0.f;
+    if (n < N)
+        for (int64_t r = r0 + g; r < r1; r += 4) s += vs_ld(X, xd, r * ldx + n);
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) atomicAdd(J.out[j] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+
 }  // namespace
+
+extern "C" int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const int64_t* ldx, const int64_t* M, const int64_t* N,
+                               float* const* out, float* zero_base, int64_t zero_count, void* stream) {
+    VS_CHECK_ARG(n_jobs >= 1 && n_jobs <= CS_MAXJ && X && x_dtype && ldx && M && N && out, "vs_colsum_multi: bad argument (1..%d jobs)", CS_MAXJ);
+    ColsumJobs J;
+    J.nj = n_jobs;
+    int64_t max_m = 0;
+    J.blk_off[0] = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        VS_CHECK_ARG(X[j] && out[j] && M[j] > 0 && N[j] > 0 && ldx[j] >= N[j], "vs_colsum_multi: bad job %d", j);
+        J.x[j] = X[j]; J.dt[j] = x_dtype[j]; J.ld[j] = ldx[j]; J.M[j] = M[j]; J.N[j] = N[j]; J.out[j] = out[j];
+        J.blk_off[j + 1] = J.blk_off[j] + (int)vs_cdiv(N[j], 64);
+        if (M[j] > max_m) max_m = M[j];
+    }
+    if (zero_base && zero_count > 0) {
+        if (hipMemsetAsync(zero_base, 0, (size_t)zero_count * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return vs_fail(VS_ERR_LAUNCH, "vs_colsum_multi: memset failed");
+    }
+    dim3 grid((unsigned)J.blk_off[n_jobs], (unsigned)vs_cdiv(max_m, CS_ROWS));
+    hipLaunchKernelGGL(colsum_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, J);
+    VS_CHECK_LAUNCH("vs_colsum_multi");
+    return VS_OK;
+}
 
 extern "C" int vs_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
     VS_CHECK_ARG(src && dst && n >= 0, "vs_cast: bad argument");

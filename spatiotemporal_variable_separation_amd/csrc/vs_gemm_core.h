@@ -1,6 +1,8 @@
 // vs_gemm_core.h -- the LDS-tiled MFMA contraction kernel shared by vs_gemm.hip (dense operands) and vs_conv.hip
 // (implicit-GEMM convolution operands).  See vs_gemm.hip for the design notes.
 #pragma once
+#include <stdlib.h>
+#include <string.h>
 #include "vs_common.h"
 
 namespace {
@@ -278,13 +280,21 @@ template <int CT> constexpr int bk_of() { return CT == VS_BF16 ? 64 : 16; }
 Plan make_plan(int compute, int64_t M, int64_t N, int64_t K) {
     const int bk = compute == VS_BF16 ? 64 : 16;
     Plan p;
-    // tile: 128x128 when that still gives >= 2 tiles per CU-wave of work, else 64-wide variants
+    // Tile choice (measured on the config-2 shapes, tools/gemm_bench.py): the kernel keeps ~3 workgroups (12 waves) per CU
+    // busy; with fewer than ~4 tiles of 128x128 per CU most SIMDs hold a single wave that cannot overlap its LDS reads with
+    // MFMA and 128x64 wins (421 vs 312 TF/s at 3328x4096x1200); 64x64 wins when K is short (310 vs 172 TF/s at K = 256);
+    // few-tile problems go to split-K, where larger tiles mean fewer fp32 slabs.
     const int64_t t128 = vs_cdiv(M, 128) * vs_cdiv(N, 128);
-    if (t128 >= 512 || (M >= 1024 && N >= 1024 && t128 >= 192)) { p.bm = 128; p.bn = 128; }
-    else if (vs_cdiv(M, 128) * vs_cdiv(N, 64) >= 256 || M > 64) { p.bm = M > 64 ? 128 : 64; p.bn = 64; }
+    const int64_t t12864 = vs_cdiv(M, 128) * vs_cdiv(N, 64);
+    if (const char* f = getenv("VS_GEMM_TILE")) {                       // debugging aid: force a tile ("128x128", "128x64", "64x64")
+        p.bm = atoi(f); const char* x = strchr(f, 'x'); p.bn = x ? atoi(x + 1) : p.bm;
+    } else if (K <= 512 && t128 >= 256) { p.bm = 64; p.bn = 64; }      // short K: prologue/epilogue bound, many small tiles win
+    else if (t128 >= 1024) { p.bm = 128; p.bn = 128; }                 // >= 4 big tiles per CU: best LDS reuse
+    else if ((t12864 >= 160 || vs_cdiv(M, 64) * vs_cdiv(N, 64) < 256) && M > 64) { p.bm = 128; p.bn = 64; }
     else { p.bm = 64; p.bn = 64; }
     if (M <= 64) p.bm = 64;
     if (N <= 64) p.bn = 64;
+    if (p.bm == 64) p.bn = 64;
     const int64_t tiles = vs_cdiv(M, p.bm) * vs_cdiv(N, p.bn);
     const int64_t kt = vs_cdiv(K, bk);
     int splits = 1;

@@ -117,6 +117,7 @@ class MLPChain(torch.autograd.Function):
             dz = to_compute(dy, cdt)
         grads = [None] * (2 * L)
         dx = None
+        bias_jobs = []                       # (slot, dz): all bias gradients of the chain in one launch at the end
         for l in range(L - 1, -1, -1):
             W, b = params[2 * l], params[2 * l + 1]
             N, K = W.shape
@@ -124,13 +125,16 @@ class MLPChain(torch.autograd.Function):
             if W.requires_grad:
                 grads[2 * l] = ops.gemm(dz, S, h_in, S, N, K, M)                      # dW = dz^T h_in  (fp32)
             if b is not None and b.requires_grad:
-                grads[2 * l + 1] = ops.colsum(dz, M, N)
+                bias_jobs.append((2 * l + 1, dz))
             if l > 0:
                 masked = acts[l - 1] not in ('none', None)
                 dz = ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=cdt, mask=h_in if masked else None,
                               mask_act=acts[l - 1] if masked else 'none')
             elif ctx.x_needs_grad:
                 dx = ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=torch.float32)
+        if bias_jobs:
+            for (slot, _), db in zip(bias_jobs, ops.colsum_multi([dz_l for _, dz_l in bias_jobs])):
+                grads[slot] = db
         return (dx, None) + tuple(grads)
 
 
@@ -196,16 +200,17 @@ class MLPRollout(torch.autograd.Function):
         B, C = dx0.shape
         H = h1.shape[-1]
         rows = (n_steps - 1) * B
-        grads = []
+        if rows == 0:
+            return (dx0, None) + tuple(torch.zeros_like(p) for p in params)
+        grads, bias_jobs = [], []
         for b in range(nb):
-            if rows == 0:
-                grads += [torch.zeros_like(params[6 * b + i]) for i in range(6)]
-                continue
             dh1b, dh2b, drb = dh1[b].view(rows, H), dh2[b].view(rows, H), dr[b].view(rows, C)
             xb, h1b, h2b = xin[b].view(rows, C), h1[b].view(rows, H), h2[b].view(rows, H)
-            grads += [ops.gemm(dh1b, S, xb, S, H, C, rows), ops.colsum(dh1b, rows, H),
-                      ops.gemm(dh2b, S, h1b, S, H, H, rows), ops.colsum(dh2b, rows, H),
-                      ops.gemm(drb, S, h2b, S, C, H, rows), ops.colsum(drb, rows, C)]
+            grads += [ops.gemm(dh1b, S, xb, S, H, C, rows), None, ops.gemm(dh2b, S, h1b, S, H, H, rows), None,
+                      ops.gemm(drb, S, h2b, S, C, H, rows), None]
+            bias_jobs += [dh1b, dh2b, drb]
+        for i, db in enumerate(ops.colsum_multi(bias_jobs)):
+            grads[2 * i + 1] = db
         return (dx0, None) + tuple(grads)
 
 

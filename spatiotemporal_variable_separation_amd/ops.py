@@ -130,6 +130,32 @@ def colsum(x, M, N, out=None, accumulate=False):
     return out
 
 
+def colsum_multi(jobs):
+    """jobs: list of (x [M, N] 2-D tensor).  Returns one fp32 vector of column sums per job (views of one flat buffer),
+    computed by a single launch (+ one memset)."""
+    import ctypes
+    outs = []
+    for i in range(0, len(jobs), 12):
+        chunk = jobs[i:i + 12]
+        n = len(chunk)
+        require_cuda(*chunk)
+        total = sum(x.shape[1] for x in chunk)
+        flat = torch.empty((total,), dtype=torch.float32, device=chunk[0].device)
+        views, off = [], 0
+        for x in chunk:
+            views.append(flat[off:off + x.shape[1]])
+            off += x.shape[1]
+        VP, I32, I64 = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
+        e0 = _pb()
+        check(_lib.load_library().vs_colsum_multi(
+            n, VP(*[x.data_ptr() for x in chunk]), I32(*[dtype_code(x) for x in chunk]), I64(*[x.stride(0) for x in chunk]),
+            I64(*[x.shape[0] for x in chunk]), I64(*[x.shape[1] for x in chunk]), VP(*[v.data_ptr() for v in views]),
+            flat.data_ptr(), total, stream_ptr()), 'vs_colsum_multi')
+        _pe(e0, 'vs_colsum_multi', nbytes=float(sum(x.numel() * x.element_size() for x in chunk)))
+        outs += views
+    return outs
+
+
 def act_fwd(x, act, out=None, out_dtype=None):
     require_cuda(x)
     x = x.contiguous()
