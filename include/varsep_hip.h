@@ -188,18 +188,26 @@ int vs_mlp_rollout_bwd(int compute, int B, int C, int H, int n_blocks, int n_ste
  *                          conv.py:258,295 (k4 s1 p0), :260-263 (k4 s2 p1), :318 (k3 s1 p1)
  *   *_fwd   : y = conv(x, w) + bias (bias may be NULL)
  *   *_dgrad : dx = gradient wrt x given dy (dy has the shape of y)
+ *   The two TRANSPOSED-form contractions (vs_conv_transpose2d_fwd, vs_conv2d_dgrad) take `w_packed`, the weight
+ *   pre-packed by vs_conv_pack_weight (channel dims swapped, taps grouped per output-parity phase for stride 2,
+ *   converted to the compute type; refresh it after each optimizer step).  Supported there: stride 1 (any k, pad) and
+ *   stride 2 with k - 2*pad == 2 (the reference's k4 s2 p1), run as 4 dense parity phases.
  *   *_wgrad : dw (fp32, same shape as w) = gradient wrt w; uses split-K when the reduction B*OH*OW is long: pass a
  *             workspace of vs_conv_wgrad_workspace_bytes(...) bytes (NULL = no split, slower but correct)
  * In every call B, Cin, H, W, Cout describe the FORWARD op (x's shape and the weight's channel counts).
  */
 size_t vs_conv_wgrad_workspace_bytes(int B, int Cin, int OH, int OW, int Cout, int kh, int kw);
+/* w: fp32 master weight [D0][D1][kh][kw] (Conv2d: D0 = Cout, D1 = Cin; ConvTranspose2d: D0 = Cin, D1 = Cout);
+ * dst: vs_conv_packed_elems(...) elements of the compute type.                                                     */
+size_t vs_conv_packed_elems(int D0, int D1, int kh, int kw, int stride, int pad);
+int vs_conv_pack_weight(int compute, const float* w, int D0, int D1, int kh, int kw, int stride, int pad, void* dst, void* stream);
 int vs_conv2d_fwd(int compute, const void* x, const void* w, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
                   int Cout, int kh, int kw, int stride, int pad, void* stream);
-int vs_conv2d_dgrad(int compute, const void* dy, const void* w, void* dx, int dx_dtype, int B, int Cin, int H, int W, int Cout, int kh,
+int vs_conv2d_dgrad(int compute, const void* dy, const void* w_packed, void* dx, int dx_dtype, int B, int Cin, int H, int W, int Cout, int kh,
                     int kw, int stride, int pad, void* stream);
 int vs_conv2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                     int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
-int vs_conv_transpose2d_fwd(int compute, const void* x, const void* w, const float* bias, void* y, int y_dtype, int B, int Cin, int H,
+int vs_conv_transpose2d_fwd(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H,
                             int W, int Cout, int kh, int kw, int stride, int pad, void* stream);
 int vs_conv_transpose2d_dgrad(int compute, const void* dy, const void* w, void* dx, int dx_dtype, int B, int Cin, int H, int W, int Cout,
                               int kh, int kw, int stride, int pad, void* stream);

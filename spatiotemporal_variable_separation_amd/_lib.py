@@ -90,6 +90,8 @@ SIGNATURES = {
     'vs_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     'vs_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     'vs_conv_wgrad_workspace_bytes': (_sz, [_i32] * 7),
+    'vs_conv_packed_elems': (_sz, [_i32] * 6),
+    'vs_conv_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     'vs_conv2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
     'vs_conv2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
     'vs_conv2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),

@@ -1,19 +1,32 @@
 // vs_conv.hip -- Conv2d / ConvTranspose2d (forward, input gradient, weight gradient) as im2col-free implicit GEMMs
-// on the shared MFMA contraction kernel (vs_gemm_core.h).  Activations stay NCHW in HBM; no im2col buffer, no
-// layout change, no weight re-packing: the operand loaders below gather straight from the NCHW tensors / the
-// [Cout,Cin,kh,kw] (Conv2d) or [Cin,Cout,kh,kw] (ConvTranspose2d) weights into LDS tiles.
+// on the shared MFMA contraction kernel (vs_gemm_core.h).  Activations stay NCHW in HBM; there is no im2col buffer
+// and no activation re-layout: operand loaders gather straight from the NCHW tensors into LDS tiles.
 //
 // Orientation: output CHANNELS are the GEMM rows, output PIXELS (b, y, x) the GEMM columns, so that in the 32x32 MFMA
 // accumulator (column on the lane) consecutive lanes hold consecutive pixels of one channel: NCHW stores are
-// contiguous 128-byte runs per register, and the per-channel bias is a row constant.
+// contiguous runs per register, and the per-channel bias is a row constant.
 //
-//   op                    M        N            K            A (rows m, reduction k)        B (rows n, reduction k)
-//   conv   forward        Cout     B*OH*OW      Cin*kh*kw    W[m][k]              (dense)   x[b,c,oy*s-p+ky,ox*s-p+kx]   (im2col)
-//   conv   dgrad          Cin      B*H*W        Cout*kh*kw   W[co][m][ky,kx]      (WeightT) dy[b,co,(y+p-ky)/s,(x+p-kx)/s] (col2im)
-//   conv   wgrad          Cout     Cin*kh*kw    B*OH*OW      dy[b,m,pix]          (ChanRows) x gathered as im2col, pixel = reduction
-//   convT  forward        Cout     B*OH*OW      Cin*kh*kw    W[ci][m][ky,kx]      (WeightT) x[b,ci,(oy+p-ky)/s,(ox+p-kx)/s] (col2im)
-//   convT  dgrad          Cin      B*H*W        Cout*kh*kw   W[m][k]              (dense)   dy[b,co,y*s-p+ky,x*s-p+kx]   (im2col)
-//   convT  wgrad          Cin      Cout*kh*kw   B*H*W        x[b,m,pix]           (ChanRows) dy gathered as im2col, pixel = reduction
+// Every contraction is   out[m, pixel] = sum_{c, tap} Wd[m][(c, tap)] * src[b, c, gy*s + dy(tap), gx*s + dx(tap)]
+//   * the pixel operand is a TAP GATHER: for one (c, tap) a 16-byte LDS unit is 8 (bf16) / 4 (fp32) consecutive pixels
+//     of one image row, i.e. consecutive (s = 1) or every-other (s = 2) source elements -> one or two UNALIGNED 16-byte
+//     global loads (gfx950 runs in unaligned-access mode) instead of per-element loads; only units that touch the zero
+//     padding or straddle rows take the per-element path;
+//   * the weight operand is always a dense row-major matrix Wd[M][C*ntap]: the reference layout itself for Conv2d
+//     forward and ConvTranspose2d input-gradient, a pre-packed copy (vs_conv_pack_weight: channel dims swapped, taps
+//     selected per phase, converted to the compute type, refreshed once per optimizer step) for the others;
+//   * stride-2 transposed convolutions (ConvTranspose2d forward, Conv2d input-gradient, k4 s2 p1) are split into the
+//     4 output-parity PHASES: each phase is a dense 2x2-tap stride-1 contraction over the small grid that scatters to
+//     every other output pixel -- no multiplications by structural zeros (4x fewer MACs than the gather form);
+//   * weight gradients reduce over pixels: dy / x enter as channel-major rows (vector loads), the other tensor as a
+//     tap gather with the pixel on the reduction axis; long reductions use split-K.
+//
+//   op                    M      N (grid)          K              weights                  gathered tensor
+//   conv   forward        Cout   B*OH*OW           Cin*kh*kw      w (reference layout)     x,  s = stride
+//   conv   dgrad          Cin    B*H*W | phases    Cout*ntap      packed (swap)            dy, s = 1
+//   conv   wgrad          Cout   Cin*kh*kw         B*OH*OW        --                       x,  s = stride (pixel = reduction)
+//   convT  forward        Cout   B*OH*OW | phases  Cin*ntap       packed (swap)            x,  s = 1
+//   convT  dgrad          Cin    B*H*W             Cout*kh*kw     w (reference layout)     dy, s = stride
+//   convT  wgrad          Cin    Cout*kh*kw        B*H*W          --                       dy, s = stride (pixel = reduction)
 //
 // Reference call sites: every nn.Conv2d / nn.ConvTranspose2d of networks/conv.py:119-122,147-170,258-263,294-318,
 // 326-343,362-382,402-417 and networks/resnet.py:57-59, plus their autograd.
@@ -21,79 +34,84 @@
 
 namespace {
 
-struct Geo {
-    int B, C, H, W;       // the NCHW tensor the loader gathers from
-    int kh, kw, s, p;
-    int OH, OW;           // the pixel grid enumerated by the GEMM index (conv: output grid; col2im: the larger grid)
+constexpr int MAXTAP = 16;
+
+struct TapGeo {
+    int B, C, H, W;        // the NCHW tensor gathered from
+    int GH, GW;            // iteration grid (one GEMM column / reduction index per (b, gy, gx))
+    int s;                 // source coordinate = grid coordinate * s + tap offset
+    int ntap;
+    signed char dy[MAXTAP], dx[MAXTAP];
 };
 
+// src[b, c, gy*s + dy[t], gx*s + dx[t]] for U consecutive grid pixels starting at pix0 and one q = c * ntap + t
 template <int CT>
-struct GatherBase {
+struct TapGather {
     typedef typename CTraits<CT>::T T;
     static constexpr int U = CTraits<CT>::U;
-    const T* src; Geo g; int64_t npix, nq;
-};
+    const T* src; TapGeo g; int64_t npix, nq;
 
-// src[b, c, py*s - p + ky, px*s - p + kx] for U consecutive pixels starting at pix0 and one q = (c, ky, kx)
-template <int CT>
-struct Im2col : GatherBase<CT> {
-    typedef typename CTraits<CT>::T T;
-    static constexpr int U = CTraits<CT>::U;
-    __device__ __forceinline__ u32x4 unit(int64_t pix0, int64_t q) const {
-        T tmp[U];
+    // LEN consecutive grid pixels of ONE grid row, written to dst[0..LEN)
+    template <int LEN>
+    __device__ __forceinline__ void segment(T* dst, int b, int c, int gy, int gx0, int dyv, int dxv) const {
+        const int iy = gy * g.s + dyv;
 #pragma unroll
-        for (int j = 0; j < U; ++j) tmp[j] = (T)0.f;
-        const Geo& g = this->g;
-        if (q < this->nq && pix0 < this->npix) {
-            const int khw = g.kh * g.kw;
-            const int c = (int)(q / khw), kk = (int)(q % khw);
-            const int ky = kk / g.kw, kx = kk % g.kw;
-            const int ohw = g.OH * g.OW;
-            int b = (int)(pix0 / ohw);
-            const int rem = (int)(pix0 % ohw);
-            int py = rem / g.OW, px = rem % g.OW;
+        for (int j = 0; j < LEN; ++j) dst[j] = (T)0.f;
+        if (iy < 0 || iy >= g.H) return;
+        const T* row = src + (((int64_t)b * g.C + c) * g.H + iy) * g.W;
+        const int ix0 = gx0 * g.s + dxv, last = ix0 + (LEN - 1) * g.s;
+        if (ix0 >= 0 && last < g.W) {
+            struct __attribute__((packed, aligned(sizeof(T)))) Vec { T v[LEN]; };
+            if (g.s == 1) {
+                const Vec t = *reinterpret_cast<const Vec*>(row + ix0);          // one unaligned vector load
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                if (pix0 + j < this->npix) {
-                    const int iy = py * g.s - g.p + ky, ix = px * g.s - g.p + kx;
-                    if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
-                        tmp[j] = this->src[(((int64_t)b * g.C + c) * g.H + iy) * g.W + ix];
-                }
-                if (++px == g.OW) { px = 0; if (++py == g.OH) { py = 0; ++b; } }
+                for (int j = 0; j < LEN; ++j) dst[j] = t.v[j];
+            } else if (g.s == 2) {
+                // elements ix0, ix0+2, ...: first half from [ix0, ix0+LEN), second half from [ix0+LEN-1, ix0+2LEN-1)
+                const Vec t0 = *reinterpret_cast<const Vec*>(row + ix0);
+                const Vec t1 = *reinterpret_cast<const Vec*>(row + ix0 + LEN - 1);
+#pragma unroll
+                for (int j = 0; j < LEN / 2; ++j) { dst[j] = t0.v[2 * j]; dst[LEN / 2 + j] = t1.v[2 * j + 1]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < LEN; ++j) dst[j] = row[ix0 + j * g.s];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) {
+                const int ix = ix0 + j * g.s;
+                if (ix >= 0 && ix < g.W) dst[j] = row[ix];
             }
         }
-        return *reinterpret_cast<u32x4*>(tmp);
     }
-};
 
-// src[b, c, (py + p - ky)/s, (px + p - kx)/s] where divisible and in range (transposed-convolution gather)
-template <int CT>
-struct Col2im : GatherBase<CT> {
-    typedef typename CTraits<CT>::T T;
-    static constexpr int U = CTraits<CT>::U;
     __device__ __forceinline__ u32x4 unit(int64_t pix0, int64_t q) const {
         T tmp[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) tmp[j] = (T)0.f;
-        const Geo& g = this->g;
-        if (q < this->nq && pix0 < this->npix) {
-            const int khw = g.kh * g.kw;
-            const int c = (int)(q / khw), kk = (int)(q % khw);
-            const int ky = kk / g.kw, kx = kk % g.kw;
-            const int ohw = g.OH * g.OW;
-            int b = (int)(pix0 / ohw);
-            const int rem = (int)(pix0 % ohw);
-            int py = rem / g.OW, px = rem % g.OW;
+        if (q < nq && pix0 < npix) {
+            const int c = (int)(q / g.ntap), t = (int)(q - (int64_t)c * g.ntap);
+            const int dyv = g.dy[t], dxv = g.dx[t];
+            const int ghw = g.GH * g.GW;
+            int b = (int)(pix0 / ghw);
+            const int rem = (int)(pix0 - (int64_t)b * ghw);
+            int gy = rem / g.GW, gx = rem - gy * g.GW;
+            if ((g.GW % U) == 0 && pix0 + U <= npix) {
+                segment<U>(tmp, b, c, gy, gx, dyv, dxv);                         // whole unit inside one grid row
+            } else if (g.GW * 2 == U && gx == 0 && pix0 + U <= npix) {
+                segment<U / 2>(tmp, b, c, gy, 0, dyv, dxv);                      // 4-wide grids (bf16): two rows per unit
+                int gy2 = gy + 1, b2 = b;
+                if (gy2 == g.GH) { gy2 = 0; ++b2; }
+                segment<U / 2>(tmp + U / 2, b2, c, gy2, 0, dyv, dxv);
+            } else {
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                if (pix0 + j < this->npix) {
-                    const int ty = py + g.p - ky, tx = px + g.p - kx;
-                    if (ty >= 0 && tx >= 0 && (ty % g.s) == 0 && (tx % g.s) == 0) {
-                        const int iy = ty / g.s, ix = tx / g.s;
-                        if (iy < g.H && ix < g.W) tmp[j] = this->src[(((int64_t)b * g.C + c) * g.H + iy) * g.W + ix];
+                for (int j = 0; j < U; ++j) {
+                    if (pix0 + j < npix) {
+                        const int iy = gy * g.s + dyv, ix = gx * g.s + dxv;
+                        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) tmp[j] = src[(((int64_t)b * g.C + c) * g.H + iy) * g.W + ix];
                     }
+                    if (++gx == g.GW) { gx = 0; if (++gy == g.GH) { gy = 0; ++b; } }
                 }
-                if (++px == g.OW) { px = 0; if (++py == g.OH) { py = 0; ++b; } }
             }
         }
         return *reinterpret_cast<u32x4*>(tmp);
@@ -102,34 +120,11 @@ struct Col2im : GatherBase<CT> {
 
 // GEMM operand views of a gather: PIX_IS_ROW -> element(i = pixel, k = q), LDS layout S (unit along i);
 //                                 otherwise   -> element(i = q, k = pixel), LDS layout R (unit along k).
-template <int CT, class G, bool PIX_IS_ROW>
+template <int CT, bool PIX_IS_ROW>
 struct GatherOp {
     static constexpr int layout = PIX_IS_ROW ? LS : LR;
-    G gather;
+    TapGather<CT> gather;
     __device__ __forceinline__ u32x4 load(int64_t i, int64_t k) const { return PIX_IS_ROW ? gather.unit(i, k) : gather.unit(k, i); }
-};
-
-// element(m, k = (o, kk)) = w[(o * Mtot + m) * khw + kk]  (weight with the GEMM row as its SECOND dimension)
-template <int CT>
-struct WeightT {
-    typedef typename CTraits<CT>::T T;
-    static constexpr int U = CTraits<CT>::U;
-    static constexpr int layout = LR;
-    const T* w; int64_t Mtot, K; int khw;
-    __device__ __forceinline__ u32x4 load(int64_t m, int64_t k) const {
-        T tmp[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int64_t kq = k + j;
-            T v = (T)0.f;
-            if (m < Mtot && kq < K) {
-                const int64_t o = kq / khw;
-                v = w[(o * Mtot + m) * khw + (kq - o * khw)];
-            }
-            tmp[j] = v;
-        }
-        return *reinterpret_cast<u32x4*>(tmp);
-    }
 };
 
 // element(m = channel, k = pixel (b, pix)) = src[(b * C + m) * HW + pix]
@@ -192,12 +187,12 @@ int run(const OpA& a, const OpB& b, int64_t M, int64_t N, int64_t K, const Epi& 
     return VS_OK;
 }
 
-inline Epi nchw_epi(void* out, int out_dtype, const float* bias, int64_t hw, int64_t channels, int accumulate) {
-    Epi e{out, 0, out_dtype, 1.f, bias, VS_ACT_NONE, nullptr, 0, 0, VS_ACT_NONE, accumulate, hw, channels};
+inline Epi nchw_epi(void* out, int out_dtype, const float* bias, int64_t plane, int64_t channels) {
+    Epi e{out, 0, out_dtype, 1.f, bias, VS_ACT_NONE, nullptr, 0, 0, VS_ACT_NONE, 0, plane, channels, 0, 0, 0, 0, 0, 0, 0};
     return e;
 }
 inline Epi rowmajor_epi(void* out, int64_t ldc) {
-    Epi e{out, ldc, VS_F32, 1.f, nullptr, VS_ACT_NONE, nullptr, 0, 0, VS_ACT_NONE, 0, 0, 0};
+    Epi e{out, ldc, VS_F32, 1.f, nullptr, VS_ACT_NONE, nullptr, 0, 0, VS_ACT_NONE, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return e;
 }
 
@@ -206,51 +201,163 @@ int check_conv(const char* what, int compute, const void* a, const void* b, cons
     VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "%s: compute type %d", what, compute);
     VS_CHECK_ARG(a && b && c, "%s: null pointer", what);
     VS_CHECK_ARG(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "%s: bad geometry", what);
+    VS_CHECK_ARG(kh * kw <= MAXTAP, "%s: kernel %dx%d has more than %d taps", what, kh, kw, MAXTAP);
     return VS_OK;
 }
 
-// ---- the six contractions, templated on the compute type ------------------------------------------------------------
-// conv-like forward: y[b,co,oy,ox] = bias + sum x[b,ci,oy*s-p+ky,ox*s-p+kx] Wd[co][(ci,ky,kx)]   (Wd dense [Cout, Cin*khw])
+// Which (k, stride, pad) transposed geometries decompose into equal-size parity phases: every output pixel (s*i + py)
+// exists for i in [0, H): needs OH == s*H, i.e. kh - 2*pad == s.  (k4 s2 p1 yes; stride 1 is the single trivial phase.)
+inline bool phase_ok(int kh, int kw, int s, int p) { return s == 2 && kh - 2 * p == s && kw - 2 * p == s; }
+
+// taps of output parity (py, px) of a transposed convolution: ky with (py + p - ky) % s == 0, source offset (py+p-ky)/s
+inline int phase_taps(int kh, int kw, int s, int p, int py, int px, int* kidx, signed char* dy, signed char* dx) {
+    int n = 0;
+    for (int ky = 0; ky < kh; ++ky) {
+        if ((py + p - ky) % s != 0) continue;
+        for (int kx = 0; kx < kw; ++kx) {
+            if ((px + p - kx) % s != 0) continue;
+            kidx[n] = ky * kw + kx;
+            dy[n] = (signed char)((py + p - ky) / s);
+            dx[n] = (signed char)((px + p - kx) / s);
+            ++n;
+        }
+    }
+    return n;
+}
+
+// ---- forward-like contraction:  out[b, m, gy*S+oy, gx*S+ox] = bias[m] + sum Wd[m][(c,t)] src[b, c, gy*s+dy, gx*s+dx] ----
 template <int CT>
-int conv_like_fwd(const void* x, const void* wd, const float* bias, void* y, int y_dtype, int accumulate, int B, int Cin, int H, int W,
-                  int Cout, int kh, int kw, int s, int p, int OH, int OW, hipStream_t st, const char* what) {
+int gather_gemm(const void* src, const void* wd, const float* bias, void* out, int out_dtype, int M, const TapGeo& g, int OH, int OW, int scat,
+                int oy, int ox, hipStream_t st, const char* what) {
     typedef typename CTraits<CT>::T T;
-    const int64_t M = Cout, N = (int64_t)B * OH * OW, K = (int64_t)Cin * kh * kw;
+    const int64_t N = (int64_t)g.B * g.GH * g.GW, K = (int64_t)g.C * g.ntap;
     Dense<CT, LR> a{(const T*)wd, K, M, K, ((uintptr_t)wd % 16 == 0) && (K % CTraits<CT>::U == 0)};
-    GatherOp<CT, Im2col<CT>, true> b;
-    b.gather.src = (const T*)x; b.gather.g = Geo{B, Cin, H, W, kh, kw, s, p, OH, OW}; b.gather.npix = N; b.gather.nq = K;
-    return run<CT>(a, b, M, N, K, nchw_epi(y, y_dtype, bias, (int64_t)OH * OW, Cout, accumulate), nullptr, 0, st, what);
+    GatherOp<CT, true> b;
+    b.gather.src = (const T*)src; b.gather.g = g; b.gather.npix = N; b.gather.nq = K;
+    Epi e = nchw_epi(out, out_dtype, bias, (int64_t)OH * OW, M);
+    if (scat != 1 || g.GH != OH || g.GW != OW) {
+        e.g_w = g.GW; e.g_hw = g.GH * g.GW; e.o_w = OW; e.sy = scat; e.sx = scat; e.oy = oy; e.ox = ox;
+    }
+    return run<CT>(a, b, M, N, K, e, nullptr, 0, st, what);
 }
 
-// transposed-conv-like forward: y[b,co,oy,ox] = bias + sum x[b,ci,(oy+p-ky)/s,(ox+p-kx)/s] Wt[ci][co][ky,kx]
+inline void natural_taps(TapGeo& g, int kh, int kw, int pad, bool flipped) {
+    g.ntap = kh * kw;
+    for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx) {
+            g.dy[ky * kw + kx] = (signed char)(flipped ? pad - ky : ky - pad);
+            g.dx[ky * kw + kx] = (signed char)(flipped ? pad - kx : kx - pad);
+        }
+}
+
+// plain (strided) convolution form: Conv2d forward and ConvTranspose2d input gradient; weights in reference layout
 template <int CT>
-int convT_like_fwd(const void* x, const void* wt, const float* bias, void* y, int y_dtype, int accumulate, int B, int Cin, int H, int W,
-                   int Cout, int kh, int kw, int s, int p, int OH, int OW, hipStream_t st, const char* what) {
-    typedef typename CTraits<CT>::T T;
-    const int64_t M = Cout, N = (int64_t)B * OH * OW, K = (int64_t)Cin * kh * kw;
-    WeightT<CT> a{(const T*)wt, M, K, kh * kw};
-    GatherOp<CT, Col2im<CT>, true> b;
-    b.gather.src = (const T*)x; b.gather.g = Geo{B, Cin, H, W, kh, kw, s, p, OH, OW}; b.gather.npix = N; b.gather.nq = K;
-    return run<CT>(a, b, M, N, K, nchw_epi(y, y_dtype, bias, (int64_t)OH * OW, Cout, accumulate), nullptr, 0, st, what);
+int conv_form(const void* src, const void* w, const float* bias, void* out, int out_dtype, int B, int Csrc, int H, int W, int M, int kh, int kw,
+              int s, int p, int OH, int OW, hipStream_t st, const char* what) {
+    TapGeo g{B, Csrc, H, W, OH, OW, s, 0, {}, {}};
+    natural_taps(g, kh, kw, p, false);
+    return gather_gemm<CT>(src, w, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, st, what);
 }
 
-// weight gradient: dW[m][(c,ky,kx)] = sum_pix R[b,m,pix] * G[b,c,py*s-p+ky,px*s-p+kx]; R has Cr channels on the (PH,PW) pixel
+// transposed form: ConvTranspose2d forward and Conv2d input gradient; weights PACKED by vs_conv_pack_weight
+//   stride 1      : Wp[M][Csrc][kh*kw], taps flipped (offset p - k)
+//   stride 2 phase: Wp[phase][M][Csrc][ntap_phase]
+template <int CT>
+int transposed_form(const void* src, const void* wp, const float* bias, void* out, int out_dtype, int B, int Csrc, int H, int W, int M, int kh,
+                    int kw, int s, int p, int OH, int OW, hipStream_t st, const char* what) {
+    typedef typename CTraits<CT>::T T;
+    if (s == 1) {
+        TapGeo g{B, Csrc, H, W, OH, OW, 1, 0, {}, {}};
+        natural_taps(g, kh, kw, p, true);
+        return gather_gemm<CT>(src, wp, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, st, what);
+    }
+    if (!phase_ok(kh, kw, s, p)) return vs_fail(VS_ERR_UNSUPPORTED, "%s: transposed geometry k%d s%d p%d is not supported", what, kh, s, p);
+    const T* wph = (const T*)wp;
+    for (int py = 0; py < s; ++py)
+        for (int px = 0; px < s; ++px) {
+            TapGeo g{B, Csrc, H, W, H, W, 1, 0, {}, {}};
+            int kidx[MAXTAP];
+            g.ntap = phase_taps(kh, kw, s, p, py, px, kidx, g.dy, g.dx);
+            int rc = gather_gemm<CT>(src, wph, bias, out, out_dtype, M, g, OH, OW, s, py, px, st, what);
+            if (rc != VS_OK) return rc;
+            wph += (int64_t)M * Csrc * g.ntap;
+        }
+    return VS_OK;
+}
+
+// weight gradient: dW[m][(c,t)] = sum_pix R[b,m,pix] * G[b,c,py*s-p+ky,px*s-p+kx]; R has Cr channels on the (PH,PW) pixel
 // grid, G has Cg channels of size (GH,GW)
 template <int CT>
-int wgrad_like(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH, int PW, int Cg, int GH, int GW, int kh, int kw, int s,
-               int p, void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
+int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH, int PW, int Cg, int GH, int GW, int kh, int kw, int s, int p,
+               void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
     typedef typename CTraits<CT>::T T;
     const int64_t M = Cr, N = (int64_t)Cg * kh * kw, K = (int64_t)B * PH * PW;
     const int64_t hw = (int64_t)PH * PW;
     ChanRows<CT> a{(const T*)r, Cr, hw, K, ((uintptr_t)r % 16 == 0) && (hw % CTraits<CT>::U == 0)};
-    GatherOp<CT, Im2col<CT>, false> b;
-    b.gather.src = (const T*)gsrc; b.gather.g = Geo{B, Cg, GH, GW, kh, kw, s, p, PH, PW}; b.gather.npix = K; b.gather.nq = N;
+    GatherOp<CT, false> b;
+    TapGeo g{B, Cg, GH, GW, PH, PW, s, 0, {}, {}};
+    natural_taps(g, kh, kw, p, false);
+    b.gather.src = (const T*)gsrc; b.gather.g = g; b.gather.npix = K; b.gather.nq = N;
     return run<CT>(a, b, M, N, K, rowmajor_epi(dw, N), ws, ws_bytes, st, what);
+}
+
+// ---- weight pre-pack for the transposed form ---------------------------------------------------------------------------
+// src fp32 [D0][D1][kh*kw] (Conv2d: D0 = Cout, D1 = Cin; ConvTranspose2d: D0 = Cin, D1 = Cout).  The transposed form has
+// its GEMM rows on D1 and reduces over D0.  stride 1: dst[m][c][t] = src[c][m][t];  stride 2: for each phase,
+// dst[phase][m][c][j] = src[c][m][kidx_phase[j]].
+struct PackTable { int nphase; int ntap[4]; int kidx[4][MAXTAP]; };
+
+template <int CT>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, typename CTraits<CT>::T* dst, int D0, int D1, int khw, PackTable tb) {
+    int64_t base = 0;
+    for (int ph = 0; ph < tb.nphase; ++ph) {
+        const int nt = tb.ntap[ph];
+        const int64_t count = (int64_t)D1 * D0 * nt;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+            const int j = (int)(i % nt);
+            const int64_t mc = i / nt;
+            const int c = (int)(mc % D0), m = (int)(mc / D0);
+            dst[base + i] = (typename CTraits<CT>::T)src[((int64_t)c * D1 + m) * khw + tb.kidx[ph][j]];
+        }
+        base += count;
+    }
 }
 
 #define VS_DISPATCH(compute, fn, ...) ((compute) == VS_BF16 ? fn<VS_BF16>(__VA_ARGS__) : fn<VS_F32>(__VA_ARGS__))
 
 }  // namespace
+
+extern "C" size_t vs_conv_packed_elems(int D0, int D1, int kh, int kw, int stride, int pad) {
+    // stride 1: D0*D1*kh*kw; stride 2 phases: the phases partition the taps, so the total is the same
+    (void)stride; (void)pad;
+    return (size_t)D0 * D1 * kh * kw;
+}
+
+extern "C" int vs_conv_pack_weight(int compute, const float* w, int D0, int D1, int kh, int kw, int stride, int pad, void* dst, void* stream) {
+    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "vs_conv_pack_weight: compute type %d", compute);
+    VS_CHECK_ARG(w && dst && D0 > 0 && D1 > 0 && kh * kw <= MAXTAP && kh > 0 && kw > 0, "vs_conv_pack_weight: bad argument");
+    PackTable tb;
+    if (stride == 1) {
+        tb.nphase = 1; tb.ntap[0] = kh * kw;
+        for (int t = 0; t < kh * kw; ++t) tb.kidx[0][t] = t;
+    } else {
+        if (!phase_ok(kh, kw, stride, pad)) return vs_fail(VS_ERR_UNSUPPORTED, "vs_conv_pack_weight: k%d s%d p%d is not supported", kh, stride, pad);
+        tb.nphase = 4;
+        signed char dy[MAXTAP], dx[MAXTAP];
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) tb.ntap[py * 2 + px] = phase_taps(kh, kw, stride, pad, py, px, tb.kidx[py * 2 + px], dy, dx);
+    }
+    int64_t total = (int64_t)D0 * D1 * kh * kw;
+    int64_t blocks = (total / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    if (compute == VS_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<VS_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)dst, D0, D1, kh * kw, tb);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<VS_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)dst, D0, D1, kh * kw, tb);
+    VS_CHECK_LAUNCH("vs_conv_pack_weight");
+    return VS_OK;
+}
 
 extern "C" size_t vs_conv_wgrad_workspace_bytes(int B, int Cin, int OH, int OW, int Cout, int kh, int kw) {
     // upper bound over both weight-gradient orientations (conv: M=Cout,N=Cin*khw ; convT: M=Cin,N=Cout*khw)
@@ -266,17 +373,18 @@ extern "C" int vs_conv2d_fwd(int compute, const void* x, const void* w, const fl
     if (rc) return rc;
     const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
     VS_CHECK_ARG(OH > 0 && OW > 0, "vs_conv2d_fwd: empty output");
-    return VS_DISPATCH(compute, conv_like_fwd, x, w, bias, y, y_dtype, 0, B, Cin, H, W, Cout, kh, kw, stride, pad, OH, OW,
-                       (hipStream_t)stream, "vs_conv2d_fwd");
+    return VS_DISPATCH(compute, conv_form, x, w, bias, y, y_dtype, B, Cin, H, W, Cout, kh, kw, stride, pad, OH, OW, (hipStream_t)stream,
+                       "vs_conv2d_fwd");
 }
 
-extern "C" int vs_conv2d_dgrad(int compute, const void* dy, const void* w, void* dx, int dx_dtype, int B, int Cin, int H, int W, int Cout,
-                               int kh, int kw, int stride, int pad, void* stream) {
-    int rc = check_conv("vs_conv2d_dgrad", compute, dy, w, dx, B, Cin, H, W, Cout, kh, kw, stride, pad);
+extern "C" int vs_conv2d_dgrad(int compute, const void* dy, const void* w_packed, void* dx, int dx_dtype, int B, int Cin, int H, int W,
+                               int Cout, int kh, int kw, int stride, int pad, void* stream) {
+    int rc = check_conv("vs_conv2d_dgrad", compute, dy, w_packed, dx, B, Cin, H, W, Cout, kh, kw, stride, pad);
     if (rc) return rc;
     const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
-    // dx[b,ci,y,x] = sum dy[b,co,(y+p-ky)/s,(x+p-kx)/s] W[co][ci][ky,kx]: the transposed-conv gather with W read as [Cout][Cin][khw]
-    return VS_DISPATCH(compute, convT_like_fwd, dy, w, nullptr, dx, dx_dtype, 0, B, Cout, OH, OW, Cin, kh, kw, stride, pad, H, W,
+    // dx[b,ci,y,x] = sum dy[b,co,(y+p-ky)/s,(x+p-kx)/s] W[co][ci][ky,kx]: transposed form gathering from dy
+    VS_CHECK_ARG(stride == 1 || (OH * stride == H && OW * stride == W), "vs_conv2d_dgrad: stride-2 needs H == 2*OH");
+    return VS_DISPATCH(compute, transposed_form, dy, w_packed, nullptr, dx, dx_dtype, B, Cout, OH, OW, Cin, kh, kw, stride, pad, H, W,
                        (hipStream_t)stream, "vs_conv2d_dgrad");
 }
 
@@ -285,17 +393,17 @@ extern "C" int vs_conv2d_wgrad(int compute, const void* dy, const void* x, float
     int rc = check_conv("vs_conv2d_wgrad", compute, dy, x, dw, B, Cin, H, W, Cout, kh, kw, stride, pad);
     if (rc) return rc;
     const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
-    return VS_DISPATCH(compute, wgrad_like, dy, x, dw, B, Cout, OH, OW, Cin, H, W, kh, kw, stride, pad, workspace, workspace_bytes,
+    return VS_DISPATCH(compute, wgrad_form, dy, x, dw, B, Cout, OH, OW, Cin, H, W, kh, kw, stride, pad, workspace, workspace_bytes,
                        (hipStream_t)stream, "vs_conv2d_wgrad");
 }
 
-extern "C" int vs_conv_transpose2d_fwd(int compute, const void* x, const void* w, const float* bias, void* y, int y_dtype, int B, int Cin,
-                                       int H, int W, int Cout, int kh, int kw, int stride, int pad, void* stream) {
-    int rc = check_conv("vs_conv_transpose2d_fwd", compute, x, w, y, B, Cin, H, W, Cout, kh, kw, stride, pad);
+extern "C" int vs_conv_transpose2d_fwd(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B,
+                                       int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, void* stream) {
+    int rc = check_conv("vs_conv_transpose2d_fwd", compute, x, w_packed, y, B, Cin, H, W, Cout, kh, kw, stride, pad);
     if (rc) return rc;
     const int OH = (H - 1) * stride - 2 * pad + kh, OW = (W - 1) * stride - 2 * pad + kw;
     VS_CHECK_ARG(OH > 0 && OW > 0, "vs_conv_transpose2d_fwd: empty output");
-    return VS_DISPATCH(compute, convT_like_fwd, x, w, bias, y, y_dtype, 0, B, Cin, H, W, Cout, kh, kw, stride, pad, OH, OW,
+    return VS_DISPATCH(compute, transposed_form, x, w_packed, bias, y, y_dtype, B, Cin, H, W, Cout, kh, kw, stride, pad, OH, OW,
                        (hipStream_t)stream, "vs_conv_transpose2d_fwd");
 }
 
@@ -305,8 +413,8 @@ extern "C" int vs_conv_transpose2d_dgrad(int compute, const void* dy, const void
     if (rc) return rc;
     const int OH = (H - 1) * stride - 2 * pad + kh, OW = (W - 1) * stride - 2 * pad + kw;
     // dx[b,ci,y,x] = sum dy[b,co,y*s-p+ky,x*s-p+kx] W[ci][(co,ky,kx)]: a plain convolution of dy with W read as dense [Cin, Cout*khw]
-    return VS_DISPATCH(compute, conv_like_fwd, dy, w, nullptr, dx, dx_dtype, 0, B, Cout, OH, OW, Cin, kh, kw, stride, pad, H, W,
-                       (hipStream_t)stream, "vs_conv_transpose2d_dgrad");
+    return VS_DISPATCH(compute, conv_form, dy, w, nullptr, dx, dx_dtype, B, Cout, OH, OW, Cin, kh, kw, stride, pad, H, W, (hipStream_t)stream,
+                       "vs_conv_transpose2d_dgrad");
 }
 
 extern "C" int vs_conv_transpose2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout,
@@ -315,6 +423,6 @@ extern "C" int vs_conv_transpose2d_wgrad(int compute, const void* dy, const void
     if (rc) return rc;
     const int OH = (H - 1) * stride - 2 * pad + kh, OW = (W - 1) * stride - 2 * pad + kw;
     // dW[ci][(co,ky,kx)] = sum_pix x[b,ci,pix] dy[b,co,y*s-p+ky,x*s-p+kx]
-    return VS_DISPATCH(compute, wgrad_like, x, dy, dw, B, Cin, H, W, Cout, OH, OW, kh, kw, stride, pad, workspace, workspace_bytes,
+    return VS_DISPATCH(compute, wgrad_form, x, dy, dw, B, Cin, H, W, Cout, OH, OW, kh, kw, stride, pad, workspace, workspace_bytes,
                        (hipStream_t)stream, "vs_conv_transpose2d_wgrad");
 }

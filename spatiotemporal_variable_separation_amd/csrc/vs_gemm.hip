@@ -84,7 +84,7 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
     VS_CHECK_ARG(lda >= (layout_a == LR ? K : M) && ldb >= (layout_b == LR ? K : N) && ldc >= N, "vs_gemm: leading dimension too small");
     VS_CHECK_ARG(!mask || ldmask >= N, "vs_gemm: ldmask too small");
     VS_CHECK_ARG(act >= VS_ACT_NONE && act <= VS_ACT_ELU, "vs_gemm: bad activation");
-    Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate, 0, 0};
+    Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     Plan plan = make_plan(compute, M, N, K);
     float* slabs = nullptr;
     if (plan.splits > 1) {

@@ -21,6 +21,9 @@ struct Epi {
     // nchw_hw > 0: rows m are channels, columns n are pixels (b * hw + pix) of an NCHW tensor with `nchw_c` channels:
     // element (m, n) lives at ((n / hw) * nchw_c + m) * hw + n % hw and the bias is per ROW (channel).
     int64_t nchw_hw, nchw_c;
+    // optional sub-grid scatter (parity phases of a stride-2 transposed convolution): column n enumerates an iteration
+    // grid [B][g_hw / g_w][g_w] and lands on output pixel (gy*sy + oy, gx*sx + ox) of a plane with rows of o_w pixels
+    int g_w, g_hw, o_w, sy, sx, oy, ox;
 };
 
 // row-major form: element (m, n) at C[m*ldc + n], bias per column
@@ -46,8 +49,14 @@ __device__ __forceinline__ void epi_store_nchw(const Epi& e, int64_t m, int64_t 
 }
 
 __device__ __forceinline__ int64_t nchw_col_base(const Epi& e, int64_t n) {
-    const int64_t b = n / e.nchw_hw;
-    return b * e.nchw_c * e.nchw_hw + (n - b * e.nchw_hw);
+    if (e.g_hw == 0) {
+        const int64_t b = n / e.nchw_hw;
+        return b * e.nchw_c * e.nchw_hw + (n - b * e.nchw_hw);
+    }
+    const int64_t b = n / e.g_hw;
+    const int r = (int)(n - b * e.g_hw);
+    const int gy = r / e.g_w, gx = r - gy * e.g_w;
+    return b * e.nchw_c * e.nchw_hw + (int64_t)(gy * e.sy + e.oy) * e.o_w + gx * e.sx + e.ox;
 }
 
 // ---- dense operand: element (i,k) at p[i*ld+k] (R) or p[k*ld+i] (S); T = storage = compute type -------

@@ -215,6 +215,21 @@ class MLPRollout(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ conv blocks
+_packed_conv = {}
+
+
+def packed_conv_weight(p, dtype, stride, pad):
+    """Transposed-form pre-pack of a conv weight (ops.conv_pack_weight), cached per parameter version."""
+    key = (id(p), dtype, stride, pad)
+    ent = _packed_conv.get(key)
+    if ent is None or ent[0] != p._version or ent[2] is not p:
+        buf = ent[1] if ent is not None and ent[2] is p else None
+        buf = ops.conv_pack_weight(p.detach().contiguous(), dtype, stride, pad, out=buf)
+        _packed_conv[key] = (p._version, buf, p)
+        return buf
+    return ent[1]
+
+
 class ConvBlock(torch.autograd.Function):
     """conv / transposed conv -> [BatchNorm2d (per-call batch statistics)] -> [activation]  (conv.py:41-60).
 
@@ -230,9 +245,10 @@ class ConvBlock(torch.autograd.Function):
         out_dt = torch.float32 if out_fp32 else cdt
         xc = to_compute(x, cdt)
         wc = shadow(w, cdt)
+        wp = packed_conv_weight(w, cdt, stride, pad) if transposed else None
         bias = b.detach() if b is not None else None
         if has_bn:
-            z = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, cdt)
+            z = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, cdt, w_packed=wp)
             if training:
                 mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps)
             else:
@@ -240,7 +256,7 @@ class ConvBlock(torch.autograd.Function):
             y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt)
             ctx.save_for_backward(xc, z, mean, invstd)
         else:
-            y = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, out_dt)
+            y = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, out_dt, w_packed=wp)
             if act not in ('none', None):
                 ops.act_fwd(y, act, out=y)
             ctx.save_for_backward(xc, y)
@@ -262,7 +278,10 @@ class ConvBlock(torch.autograd.Function):
             dz = ops.act_bwd(dy, y, act, out_dtype=cdt) if act not in ('none', None) else to_compute(dy, cdt)
         db = ops.chan_sum(dz) if b is not None and b.requires_grad else None
         dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed) if w.requires_grad else None
-        dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype) if ctx.x_needs_grad else None
+        dx = None
+        if ctx.x_needs_grad:
+            wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
+            dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp)
         return dx, dw, db, dgamma, dbeta, None, None, None
 
 

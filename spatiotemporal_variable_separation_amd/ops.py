@@ -296,10 +296,30 @@ def _conv_out_hw(H, W, k, stride, pad, transposed):
     return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
 
 
-def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype):
-    """x [B,Cin,H,W], w Conv2d [Cout,Cin,k,k] / ConvTranspose2d [Cin,Cout,k,k] in the same (compute) dtype."""
+def conv_pack_weight(w_master, dtype, stride, pad, out=None):
+    """fp32 master weight [D0, D1, k, k] -> packed operand of the transposed-form contractions (compute dtype)."""
+    require_cuda(w_master)
+    assert w_master.dtype == torch.float32 and w_master.is_contiguous()
+    D0, D1, kh, kw = w_master.shape
+    lib = _lib.load_library()
+    if out is None:
+        out = torch.empty((lib.vs_conv_packed_elems(D0, D1, kh, kw, stride, pad),), dtype=dtype, device=w_master.device)
+    check(lib.vs_conv_pack_weight(BF16 if dtype == torch.bfloat16 else F32, w_master.data_ptr(), D0, D1, kh, kw, stride, pad,
+                                  out.data_ptr(), stream_ptr()), 'vs_conv_pack_weight')
+    return out
+
+
+def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
+    """x [B,Cin,H,W], w Conv2d [Cout,Cin,k,k] / ConvTranspose2d [Cin,Cout,k,k] in the same (compute) dtype.
+    The transposed form consumes `w_packed` (conv_pack_weight); it is built on the fly from `w` when not given."""
     require_cuda(x, w, bias)
     assert x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
+    if transposed:
+        if w_packed is None:
+            w_packed = conv_pack_weight(w.float().contiguous(), x.dtype, stride, pad)
+        w_arg = w_packed
+    else:
+        w_arg = w
     B, Cin, H, W = x.shape
     k = w.shape[2]
     Cout = w.shape[1] if transposed else w.shape[0]
@@ -308,7 +328,7 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype):
     lib = _lib.load_library()
     fn = lib.vs_conv_transpose2d_fwd if transposed else lib.vs_conv2d_fwd
     e0 = _pb()
-    check(fn(dtype_code(x), x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W, Cout, k, k,
+    check(fn(dtype_code(x), x.data_ptr(), w_arg.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W, Cout, k, k,
              stride, pad, stream_ptr()), 'vs_conv_fwd')
     _pe(e0, 'vs_conv%s_fwd<%s>' % ('T' if transposed else '', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
@@ -316,9 +336,15 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype):
     return y
 
 
-def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype):
+def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None):
     require_cuda(dy, w)
     assert dy.is_contiguous() and w.is_contiguous() and dy.dtype == w.dtype
+    if not transposed:
+        if w_packed is None:
+            w_packed = conv_pack_weight(w.float().contiguous(), dy.dtype, stride, pad)
+        w_arg = w_packed
+    else:
+        w_arg = w
     B, Cin, H, W = x_shape
     k = w.shape[2]
     Cout = w.shape[1] if transposed else w.shape[0]
@@ -326,7 +352,7 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype):
     lib = _lib.load_library()
     fn = lib.vs_conv_transpose2d_dgrad if transposed else lib.vs_conv2d_dgrad
     e0 = _pb()
-    check(fn(dtype_code(dy), dy.data_ptr(), w.data_ptr(), dx.data_ptr(), dtype_code(dx), B, Cin, H, W, Cout, k, k, stride, pad,
+    check(fn(dtype_code(dy), dy.data_ptr(), w_arg.data_ptr(), dx.data_ptr(), dtype_code(dx), B, Cin, H, W, Cout, k, k, stride, pad,
              stream_ptr()), 'vs_conv_dgrad')
     OH, OW = dy.shape[2], dy.shape[3]
     _pe(e0, 'vs_conv%s_dgrad<%s>' % ('T' if transposed else '', 'bf16' if dy.dtype == torch.bfloat16 else 'f32'),
