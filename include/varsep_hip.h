@@ -217,9 +217,14 @@ int vs_conv_transpose2d_wgrad(int compute, const void* dy, const void* x, float*
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d + activation, pooling, upsampling (csrc/vs_norm.hip); x is NCHW [B,C,HW], dtypes VS_F32 | VS_BF16.
  *
- * vs_bn_stats   : per-call batch statistics of nn.BatchNorm2d in training mode (conv.py:41-60): mean[c], invstd[c] =
- *                 1/sqrt(biased var + eps); when running_mean/var are non-NULL they are updated in place with
- *                 `momentum` and the unbiased variance, exactly like ATen.
+ * GROUPS: the batch of B samples is `groups` consecutive groups of B/groups samples and every group is normalised
+ *                 with its own statistics -- one group per reference CALL.  This is what lets the n+1 decoder calls of
+ *                 a training step (model.py:74-83) run as one batch over time with exactly the reference's per-call
+ *                 BatchNorm semantics.  mean / invstd / dgamma / dbeta are [groups, C] (sum dgamma/dbeta over groups).
+ * vs_bn_stats   : per-call batch statistics of nn.BatchNorm2d in training mode (conv.py:41-60): mean[g][c], invstd[g][c]
+ *                 = 1/sqrt(biased var + eps); when running_mean/var are non-NULL they are updated in place, group by
+ *                 group in call order, with `momentum` and the unbiased variance, exactly like `groups` sequential ATen
+ *                 calls (var_scratch: [groups, C] floats).
  * vs_bn_act_fwd : y = act(gamma (x - mean) invstd + beta).  Eval mode: pass running_mean and 1/sqrt(running_var+eps).
  * vs_bn_act_bwd : given dy = dL/dy, recomputes z = gamma xhat + beta, dz = dy act'(z), and returns dbeta = sum dz,
  *                 dgamma = sum dz xhat and dx = gamma invstd (dz - dbeta/N - xhat dgamma/N)  (training != 0) or
@@ -229,13 +234,13 @@ int vs_conv_transpose2d_wgrad(int compute, const void* dy, const void* x, float*
  *                 routes dy to the first maximum in window scan order, like ATen.
  * vs_upsample2_*: nn.Upsample(scale_factor=2, mode='nearest') (conv.py:296-314,371-377,406-413); H, W are the INPUT size.
  */
-int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW, float* mean, float* invstd, float* running_mean,
-                float* running_var, float momentum, float eps, void* stream);
+int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW, int groups, float* mean, float* invstd, float* var_scratch,
+                float* running_mean, float* running_var, float momentum, float eps, void* stream);
 int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
-                  const float* beta, int act, int B, int C, int64_t HW, void* stream);
+                  const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream);
 int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd, const float* gamma,
-                  const float* beta, int act, int training, float* dgamma, float* dbeta, void* dx, int dx_dtype, int B, int C,
-                  int64_t HW, void* stream);
+                  const float* beta, int act, int training, int groups, float* dgamma, float* dbeta, void* dx, int dx_dtype, int B,
+                  int C, int64_t HW, void* stream);
 int vs_chan_sum(const void* x, int x_dtype, int B, int C, int64_t HW, float* out, void* stream);
 int vs_maxpool2_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t planes, int H, int W, void* stream);
 int vs_maxpool2_bwd(const void* x, int x_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype, int64_t planes, int H, int W,

@@ -98,9 +98,9 @@ SIGNATURES = {
     'vs_conv_transpose2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
     'vs_conv_transpose2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
     'vs_conv_transpose2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
-    'vs_bn_stats': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _f32, _f32, _vp]),
-    'vs_bn_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
-    'vs_bn_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    'vs_bn_stats': (_i32, [_vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp]),
+    'vs_bn_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
+    'vs_bn_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     'vs_chan_sum': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     'vs_maxpool2_fwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
     'vs_maxpool2_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),

@@ -42,6 +42,28 @@ struct TapGeo {
     int s;                 // source coordinate = grid coordinate * s + tap offset
     int ntap;
     signed char dy[MAXTAP], dx[MAXTAP];
+    // index-math helpers filled by finish(): shifts when the grid is a power of two (-1 otherwise), multiply-high magic for / ntap
+    int gw_shift, ghw_shift;
+    unsigned ntap_magic;
+    void finish() {
+        gw_shift = ghw_shift = -1;
+        for (int k = 0; k < 31; ++k) {
+            if ((1 << k) == GW) gw_shift = k;
+            if ((1 << k) == GH * GW) ghw_shift = k;
+        }
+        ntap_magic = (unsigned)((0x100000000ull + ntap - 1) / ntap);      // floor(q / ntap) = umulhi(q, magic) for q < 2^16
+    }
+    __device__ __forceinline__ void split_q(int q, int& c, int& t) const {
+        c = (q < 65536) ? (int)__umulhi((unsigned)q, ntap_magic) : q / ntap;
+        t = q - c * ntap;
+    }
+    __device__ __forceinline__ void split_pix(int64_t pix, int& b, int& gy, int& gx) const {
+        int rem;
+        if (ghw_shift >= 0) { b = (int)(pix >> ghw_shift); rem = (int)(pix & ((1 << ghw_shift) - 1)); }
+        else { const int ghw = GH * GW; b = (int)(pix / ghw); rem = (int)(pix - (int64_t)b * ghw); }
+        if (gw_shift >= 0) { gy = rem >> gw_shift; gx = rem & ((1 << gw_shift) - 1); }
+        else { gy = rem / GW; gx = rem - gy * GW; }
+    }
 };
 
 // src[b, c, gy*s + dy[t], gx*s + dx[t]] for U consecutive grid pixels starting at pix0 and one q = c * ntap + t
@@ -85,33 +107,25 @@ struct TapGather {
         }
     }
 
-    __device__ __forceinline__ u32x4 unit(int64_t pix0, int64_t q) const {
+    // U consecutive grid pixels starting at (b, gy, gx) [= flat pix0] for channel c and tap offset (dyv, dxv)
+    __device__ __forceinline__ u32x4 unit_at(int64_t pix0, int b, int gy, int gx, int c, int dyv, int dxv) const {
         T tmp[U];
+        if ((g.GW % U) == 0 && pix0 + U <= npix) {
+            segment<U>(tmp, b, c, gy, gx, dyv, dxv);                             // whole unit inside one grid row
+        } else if (g.GW * 2 == U && gx == 0 && pix0 + U <= npix) {
+            segment<U / 2>(tmp, b, c, gy, 0, dyv, dxv);                          // 4-wide grids (bf16): two rows per unit
+            int gy2 = gy + 1, b2 = b;
+            if (gy2 == g.GH) { gy2 = 0; ++b2; }
+            segment<U / 2>(tmp + U / 2, b2, c, gy2, 0, dyv, dxv);
+        } else {
 #pragma unroll
-        for (int j = 0; j < U; ++j) tmp[j] = (T)0.f;
-        if (q < nq && pix0 < npix) {
-            const int c = (int)(q / g.ntap), t = (int)(q - (int64_t)c * g.ntap);
-            const int dyv = g.dy[t], dxv = g.dx[t];
-            const int ghw = g.GH * g.GW;
-            int b = (int)(pix0 / ghw);
-            const int rem = (int)(pix0 - (int64_t)b * ghw);
-            int gy = rem / g.GW, gx = rem - gy * g.GW;
-            if ((g.GW % U) == 0 && pix0 + U <= npix) {
-                segment<U>(tmp, b, c, gy, gx, dyv, dxv);                         // whole unit inside one grid row
-            } else if (g.GW * 2 == U && gx == 0 && pix0 + U <= npix) {
-                segment<U / 2>(tmp, b, c, gy, 0, dyv, dxv);                      // 4-wide grids (bf16): two rows per unit
-                int gy2 = gy + 1, b2 = b;
-                if (gy2 == g.GH) { gy2 = 0; ++b2; }
-                segment<U / 2>(tmp + U / 2, b2, c, gy2, 0, dyv, dxv);
-            } else {
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    if (pix0 + j < npix) {
-                        const int iy = gy * g.s + dyv, ix = gx * g.s + dxv;
-                        if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) tmp[j] = src[(((int64_t)b * g.C + c) * g.H + iy) * g.W + ix];
-                    }
-                    if (++gx == g.GW) { gx = 0; if (++gy == g.GH) { gy = 0; ++b; } }
+            for (int j = 0; j < U; ++j) {
+                tmp[j] = (T)0.f;
+                if (pix0 + j < npix) {
+                    const int iy = gy * g.s + dyv, ix = gx * g.s + dxv;
+                    if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) tmp[j] = src[(((int64_t)b * g.C + c) * g.H + iy) * g.W + ix];
                 }
+                if (++gx == g.GW) { gx = 0; if (++gy == g.GH) { gy = 0; ++b; } }
             }
         }
         return *reinterpret_cast<u32x4*>(tmp);
@@ -124,7 +138,38 @@ template <int CT, bool PIX_IS_ROW>
 struct GatherOp {
     static constexpr int layout = PIX_IS_ROW ? LS : LR;
     TapGather<CT> gather;
-    __device__ __forceinline__ u32x4 load(int64_t i, int64_t k) const { return PIX_IS_ROW ? gather.unit(i, k) : gather.unit(k, i); }
+    // the index i of a unit slot is fixed along K: decode it once (pixel -> (b, gy, gx), or q -> (channel, tap offsets))
+    struct State { int a, b, c; int ok; };
+    __device__ __forceinline__ State prepare(int64_t i) const {
+        State st = {0, 0, 0, 0};
+        if (PIX_IS_ROW) {
+            st.ok = i < gather.npix;
+            if (st.ok) gather.g.split_pix(i, st.a, st.b, st.c);                 // (b, gy, gx)
+        } else {
+            st.ok = i < gather.nq;
+            if (st.ok) {
+                int t;
+                gather.g.split_q((int)i, st.a, t);                              // (c, dy, dx)
+                st.b = gather.g.dy[t]; st.c = gather.g.dx[t];
+            }
+        }
+        return st;
+    }
+    __device__ __forceinline__ u32x4 load(const State& st, int64_t i, int64_t k) const {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        if (!st.ok) return z;
+        if (PIX_IS_ROW) {
+            if (k >= gather.nq) return z;
+            int c, t;
+            gather.g.split_q((int)k, c, t);
+            return gather.unit_at(i, st.a, st.b, st.c, c, gather.g.dy[t], gather.g.dx[t]);
+        } else {
+            if (k >= gather.npix) return z;
+            int b, gy, gx;
+            gather.g.split_pix(k, b, gy, gx);
+            return gather.unit_at(k, b, gy, gx, st.a, st.b, st.c);
+        }
+    }
 };
 
 // element(m = channel, k = pixel (b, pix)) = src[(b * C + m) * HW + pix]
@@ -133,11 +178,15 @@ struct ChanRows {
     typedef typename CTraits<CT>::T T;
     static constexpr int U = CTraits<CT>::U;
     static constexpr int layout = LR;
-    const T* src; int64_t C, HW, K; int vec_ok;
-    __device__ __forceinline__ u32x4 load(int64_t m, int64_t k) const {
+    const T* src; int64_t C, HW, K; int vec_ok; int hw_shift;
+    struct State { int ok; };
+    __device__ __forceinline__ State prepare(int64_t m) const { return State{m < C}; }
+    __device__ __forceinline__ u32x4 load(const State& st, int64_t m, int64_t k) const {
         u32x4 z = {0u, 0u, 0u, 0u};
-        if (m >= C || k >= K) return z;
-        int64_t b = k / HW, r = k - b * HW;
+        if (!st.ok || k >= K) return z;
+        int64_t b, r;
+        if (hw_shift >= 0) { b = k >> hw_shift; r = k & (((int64_t)1 << hw_shift) - 1); }
+        else { b = k / HW; r = k - b * HW; }
         if (vec_ok && r + U <= HW) return *reinterpret_cast<const u32x4*>(src + (b * C + m) * HW + r);
         T tmp[U];
 #pragma unroll
@@ -233,7 +282,7 @@ int gather_gemm(const void* src, const void* wd, const float* bias, void* out, i
     const int64_t N = (int64_t)g.B * g.GH * g.GW, K = (int64_t)g.C * g.ntap;
     Dense<CT, LR> a{(const T*)wd, K, M, K, ((uintptr_t)wd % 16 == 0) && (K % CTraits<CT>::U == 0)};
     GatherOp<CT, true> b;
-    b.gather.src = (const T*)src; b.gather.g = g; b.gather.npix = N; b.gather.nq = K;
+    b.gather.src = (const T*)src; b.gather.g = g; b.gather.g.finish(); b.gather.npix = N; b.gather.nq = K;
     Epi e = nchw_epi(out, out_dtype, bias, (int64_t)OH * OW, M);
     if (scat != 1 || g.GH != OH || g.GW != OW) {
         e.g_w = g.GW; e.g_hw = g.GH * g.GW; e.o_w = OW; e.sy = scat; e.sx = scat; e.oy = oy; e.ox = ox;
@@ -254,7 +303,7 @@ inline void natural_taps(TapGeo& g, int kh, int kw, int pad, bool flipped) {
 template <int CT>
 int conv_form(const void* src, const void* w, const float* bias, void* out, int out_dtype, int B, int Csrc, int H, int W, int M, int kh, int kw,
               int s, int p, int OH, int OW, hipStream_t st, const char* what) {
-    TapGeo g{B, Csrc, H, W, OH, OW, s, 0, {}, {}};
+    TapGeo g{B, Csrc, H, W, OH, OW, s, 0, {}, {}, 0, 0, 0};
     natural_taps(g, kh, kw, p, false);
     return gather_gemm<CT>(src, w, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, st, what);
 }
@@ -267,7 +316,7 @@ int transposed_form(const void* src, const void* wp, const float* bias, void* ou
                     int kw, int s, int p, int OH, int OW, hipStream_t st, const char* what) {
     typedef typename CTraits<CT>::T T;
     if (s == 1) {
-        TapGeo g{B, Csrc, H, W, OH, OW, 1, 0, {}, {}};
+        TapGeo g{B, Csrc, H, W, OH, OW, 1, 0, {}, {}, 0, 0, 0};
         natural_taps(g, kh, kw, p, true);
         return gather_gemm<CT>(src, wp, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, st, what);
     }
@@ -275,7 +324,7 @@ int transposed_form(const void* src, const void* wp, const float* bias, void* ou
     const T* wph = (const T*)wp;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {
-            TapGeo g{B, Csrc, H, W, H, W, 1, 0, {}, {}};
+            TapGeo g{B, Csrc, H, W, H, W, 1, 0, {}, {}, 0, 0, 0};
             int kidx[MAXTAP];
             g.ntap = phase_taps(kh, kw, s, p, py, px, kidx, g.dy, g.dx);
             int rc = gather_gemm<CT>(src, wph, bias, out, out_dtype, M, g, OH, OW, s, py, px, st, what);
@@ -293,11 +342,13 @@ int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH
     typedef typename CTraits<CT>::T T;
     const int64_t M = Cr, N = (int64_t)Cg * kh * kw, K = (int64_t)B * PH * PW;
     const int64_t hw = (int64_t)PH * PW;
-    ChanRows<CT> a{(const T*)r, Cr, hw, K, ((uintptr_t)r % 16 == 0) && (hw % CTraits<CT>::U == 0)};
+    int hw_shift = -1;
+    for (int k = 0; k < 31; ++k) if (((int64_t)1 << k) == hw) hw_shift = k;
+    ChanRows<CT> a{(const T*)r, Cr, hw, K, ((uintptr_t)r % 16 == 0) && (hw % CTraits<CT>::U == 0), hw_shift};
     GatherOp<CT, false> b;
-    TapGeo g{B, Cg, GH, GW, PH, PW, s, 0, {}, {}};
+    TapGeo g{B, Cg, GH, GW, PH, PW, s, 0, {}, {}, 0, 0, 0};
     natural_taps(g, kh, kw, p, false);
-    b.gather.src = (const T*)gsrc; b.gather.g = g; b.gather.npix = K; b.gather.nq = N;
+    b.gather.src = (const T*)gsrc; b.gather.g = g; b.gather.g.finish(); b.gather.npix = K; b.gather.nq = N;
     return run<CT>(a, b, M, N, K, rowmajor_epi(dw, N), ws, ws_bytes, st, what);
 }
 

@@ -67,21 +67,28 @@ struct Dense {
     static constexpr int layout = LAYOUT;
     const T* p; int64_t ld; int64_t rows; int64_t K; int vec_ok;
 
+    // Per-thread, per-unit-slot state that does not change along K (the row a unit belongs to is fixed for the whole K loop)
+    struct State { const T* base; int ok; };
+    __device__ __forceinline__ State prepare(int64_t i) const {
+        State st;
+        if (LAYOUT == LR) { st.ok = i < rows; st.base = p + i * ld; }
+        else { st.ok = i < rows ? (i + U <= rows ? 2 : 1) : 0; st.base = p + i; }
+        return st;
+    }
     // 16-byte unit: R -> elements (i, k..k+U-1);  S -> elements (i..i+U-1, k)
-    __device__ __forceinline__ u32x4 load(int64_t i, int64_t k) const {
+    __device__ __forceinline__ u32x4 load(const State& st, int64_t i, int64_t k) const {
         u32x4 r = {0u, 0u, 0u, 0u};
+        if (!st.ok || k >= K) return r;
         if (LAYOUT == LR) {
-            if (i >= rows || k >= K) return r;
-            const T* q = p + i * ld + k;
+            const T* q = st.base + k;
             if (vec_ok && k + U <= K) return *reinterpret_cast<const u32x4*>(q);
             T tmp[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) tmp[j] = (k + j < K) ? q[j] : (T)0.f;
             return *reinterpret_cast<u32x4*>(tmp);
         } else {
-            if (k >= K || i >= rows) return r;
-            const T* q = p + k * ld + i;
-            if (vec_ok && i + U <= rows) return *reinterpret_cast<const u32x4*>(q);
+            const T* q = st.base + k * ld;
+            if (vec_ok && st.ok == 2) return *reinterpret_cast<const u32x4*>(q);
             T tmp[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) tmp[j] = (i + j < rows) ? q[j] : (T)0.f;
@@ -114,14 +121,25 @@ struct TileGeom {
 };
 
 template <int CT, class Op, int ROWS, int BK>
-__device__ __forceinline__ void tile_fetch(const Op& op, int64_t i0, int64_t k0,
-                                           u32x4 (&regs)[TileGeom<CT, Op::layout, ROWS, BK>::PER_THREAD]) {
+__device__ __forceinline__ void tile_prepare(const Op& op, int64_t i0, typename Op::State (&st)[TileGeom<CT, Op::layout, ROWS, BK>::PER_THREAD]) {
     typedef TileGeom<CT, Op::layout, ROWS, BK> G;
 #pragma unroll
     for (int it = 0; it < G::PER_THREAD; ++it) {
         int di, dk, off;
         G::map(threadIdx.x + it * 256, di, dk, off);
-        regs[it] = op.load(i0 + di, k0 + dk);
+        st[it] = op.prepare(i0 + di);
+    }
+}
+
+template <int CT, class Op, int ROWS, int BK>
+__device__ __forceinline__ void tile_fetch(const Op& op, const typename Op::State (&st)[TileGeom<CT, Op::layout, ROWS, BK>::PER_THREAD], int64_t i0,
+                                           int64_t k0, u32x4 (&regs)[TileGeom<CT, Op::layout, ROWS, BK>::PER_THREAD]) {
+    typedef TileGeom<CT, Op::layout, ROWS, BK> G;
+#pragma unroll
+    for (int it = 0; it < G::PER_THREAD; ++it) {
+        int di, dk, off;
+        G::map(threadIdx.x + it * 256, di, dk, off);
+        regs[it] = op.load(st[it], i0 + di, k0 + dk);
     }
 }
 
@@ -200,17 +218,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
     u32x4 ra[GA::PER_THREAD], rb[GB::PER_THREAD];
+    typename OpA::State sta[GA::PER_THREAD];
+    typename OpB::State stb[GB::PER_THREAD];
+    tile_prepare<CT, OpA, BM, BK>(A, m0, sta);
+    tile_prepare<CT, OpB, BN, BK>(B, n0, stb);
     if (kt_begin < kt_end) {
-        tile_fetch<CT, OpA, BM, BK>(A, m0, kt_begin * BK, ra);
-        tile_fetch<CT, OpB, BN, BK>(B, n0, kt_begin * BK, rb);
+        tile_fetch<CT, OpA, BM, BK>(A, sta, m0, kt_begin * BK, ra);
+        tile_fetch<CT, OpB, BN, BK>(B, stb, n0, kt_begin * BK, rb);
     }
     for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
         tile_commit<CT, OpA::layout, BM, BK>(sA, ra);
         tile_commit<CT, OpB::layout, BN, BK>(sB, rb);
         __syncthreads();
         if (kt + 1 < kt_end) {       // prefetch next tile into registers; lands while the MFMAs below run
-            tile_fetch<CT, OpA, BM, BK>(A, m0, (kt + 1) * BK, ra);
-            tile_fetch<CT, OpB, BN, BK>(B, n0, (kt + 1) * BK, rb);
+            tile_fetch<CT, OpA, BM, BK>(A, sta, m0, (kt + 1) * BK, ra);
+            tile_fetch<CT, OpB, BN, BK>(B, stb, n0, (kt + 1) * BK, rb);
         }
         if constexpr (CT == VS_BF16) {
 #pragma unroll
@@ -229,6 +251,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         } else {
+            // parity mode: two-level summation.  Each K tile (16 products) is accumulated in a fresh MFMA chain and then
+            // added to the running total, so the rounding error grows like sqrt(16) + sqrt(K/16) instead of sqrt(K) of a
+            // single k-ordered fmaf chain (K reaches 4608 in the 512-channel 3x3 convolutions) -- comparable to the
+            // blocked accumulation of CPU BLAS/oneDNN that the oracle runs on.
+            f32x16 part[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) part[i][j][v] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 8) {
                 f32x4 fa[TM], fb[TN];
@@ -244,8 +277,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                            part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], part[i][j], 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += part[i][j];
         }
         __syncthreads();
     }

@@ -37,56 +37,75 @@ __device__ __forceinline__ float act_grad_from_pre(float z, int act) {
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, int B, int C, int64_t HW, float* mean, float* invstd,
-                                                       float* rmean, float* rvar, float momentum, float eps) {
+// Statistics per (group, channel): the batch is G consecutive groups of Bg samples, each group normalised on its own --
+// one reference CALL per group (the decoder is invoked once per frame with per-call statistics; batching
+// the calls over time is exact when every call keeps its own mean/variance and the running estimates are folded in
+// call order, which bn_running_kernel does).
+__global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, int Bg, int C, int64_t HW, float* mean, float* invstd,
+                                                       float* ubvar, float eps) {
     __shared__ double red[4];
-    const int c = blockIdx.x;
-    const int64_t n = (int64_t)B * HW;
+    const int c = blockIdx.x, g = blockIdx.y;
+    const int64_t n = (int64_t)Bg * HW;
+    const int64_t b0 = (int64_t)g * Bg;
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const int64_t b = i / HW, p = i - b * HW;
-        s += (double)vs_ld(x, xd, (b * C + c) * HW + p);
+        s += (double)vs_ld(x, xd, ((b0 + b) * C + c) * HW + p);
     }
     const double mu = block_sum(s, red) / (double)n;
     double q = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const int64_t b = i / HW, p = i - b * HW;
-        const double d = (double)vs_ld(x, xd, (b * C + c) * HW + p) - mu;
+        const double d = (double)vs_ld(x, xd, ((b0 + b) * C + c) * HW + p) - mu;
         q += d * d;
     }
     const double ss = block_sum(q, red);
     if (threadIdx.x == 0) {
         const double var = ss / (double)n;
-        mean[c] = (float)mu;
-        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (rmean) {
-            const double unbiased = n > 1 ? ss / (double)(n - 1) : var;
-            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * mu);
-            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unbiased);
-        }
+        mean[g * C + c] = (float)mu;
+        invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (ubvar) ubvar[g * C + c] = (float)(n > 1 ? ss / (double)(n - 1) : var);
     }
 }
 
+__global__ __launch_bounds__(256) void bn_running_kernel(const float* mean, const float* ubvar, int G, int C, float* rmean, float* rvar,
+                                                         float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double rm = rmean[c], rv = rvar[c];
+    for (int g = 0; g < G; ++g) {                       // sequential, in call order
+        rm = (1.0 - momentum) * rm + momentum * (double)mean[g * C + c];
+        rm = (double)(float)rm;                         // the reference rounds to fp32 after every call
+        rv = (1.0 - momentum) * rv + momentum * (double)ubvar[g * C + c];
+        rv = (double)(float)rv;
+    }
+    rmean[c] = (float)rm;
+    rvar[c] = (float)rv;
+}
+
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, void* y, int yd, const float* mean, const float* invstd,
-                                                         const float* gamma, const float* beta, int act, int C, int64_t HW, int64_t total) {
+                                                         const float* gamma, const float* beta, int act, int C, int64_t HW, int64_t total,
+                                                         int64_t group_elems) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)((i / HW) % C);
-        const float xh = (vs_ld(x, xd, i) - mean[c]) * invstd[c];
+        const int gc = (int)(i / group_elems) * C + c;
+        const float xh = (vs_ld(x, xd, i) - mean[gc]) * invstd[gc];
         vs_st(y, yd, i, vs_act(xh * gamma[c] + beta[c], act));
     }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int dyd, const void* x, int xd, const float* mean,
-                                                            const float* invstd, const float* gamma, const float* beta, int act, int B, int C,
+                                                            const float* invstd, const float* gamma, const float* beta, int act, int Bg, int C,
                                                             int64_t HW, float* sum_dz, float* sum_dz_xhat) {
     __shared__ double red[4];
-    const int c = blockIdx.x;
-    const int64_t n = (int64_t)B * HW;
-    const float mu = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    const int c = blockIdx.x, grp = blockIdx.y;
+    const int64_t n = (int64_t)Bg * HW;
+    const int64_t b0 = (int64_t)grp * Bg;
+    const float mu = mean[grp * C + c], is = invstd[grp * C + c], g = gamma[c], bt = beta[c];
     double s1 = 0.0, s2 = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const int64_t b = i / HW, p = i - b * HW;
-        const int64_t idx = (b * C + c) * HW + p;
+        const int64_t idx = ((b0 + b) * C + c) * HW + p;
         const float xh = (vs_ld(x, xd, idx) - mu) * is;
         const float dz = vs_ld(dy, dyd, idx) * act_grad_from_pre(xh * g + bt, act);
         s1 += (double)dz;
@@ -94,36 +113,44 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int 
     }
     const double t1 = block_sum(s1, red);
     const double t2 = block_sum(s2, red);
-    if (threadIdx.x == 0) { sum_dz[c] = (float)t1; sum_dz_xhat[c] = (float)t2; }
+    if (threadIdx.x == 0) { sum_dz[grp * C + c] = (float)t1; sum_dz_xhat[grp * C + c] = (float)t2; }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int dyd, const void* x, int xd, const float* mean,
                                                            const float* invstd, const float* gamma, const float* beta, int act,
-                                                           const float* sum_dz, const float* sum_dz_xhat, void* dx, int dxd, int B, int C,
+                                                           const float* sum_dz, const float* sum_dz_xhat, void* dx, int dxd, int Bg, int C,
                                                            int64_t HW, int64_t total, int training) {
-    const float inv_n = 1.f / (float)((int64_t)B * HW);
+    const float inv_n = 1.f / (float)((int64_t)Bg * HW);
+    const int64_t group_elems = (int64_t)Bg * C * HW;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)((i / HW) % C);
-        const float xh = (vs_ld(x, xd, i) - mean[c]) * invstd[c];
+        const int gc = (int)(i / group_elems) * C + c;
+        const float xh = (vs_ld(x, xd, i) - mean[gc]) * invstd[gc];
         const float dz = vs_ld(dy, dyd, i) * act_grad_from_pre(xh * gamma[c] + beta[c], act);
         float v;
-        if (training) v = gamma[c] * invstd[c] * (dz - sum_dz[c] * inv_n - xh * sum_dz_xhat[c] * inv_n);
-        else v = gamma[c] * invstd[c] * dz;                 // eval mode: statistics are constants
+        if (training) v = gamma[c] * invstd[gc] * (dz - sum_dz[gc] * inv_n - xh * sum_dz_xhat[gc] * inv_n);
+        else v = gamma[c] * invstd[gc] * dz;                // eval mode: statistics are constants
         vs_st(dx, dxd, i, v);
     }
 }
 
+// per-channel sum; blockIdx.y splits the (batch x pixel) extent so that few-channel tensors (the 1-channel frames of the
+// last decoder layer) still fill the chip; partial sums meet in one float atomic per workgroup
 __global__ __launch_bounds__(256) void chan_sum_kernel(const void* x, int xd, int B, int C, int64_t HW, float* out) {
     __shared__ double red[4];
     const int c = blockIdx.x;
     const int64_t n = (int64_t)B * HW;
+    const int64_t per = (n + gridDim.y - 1) / gridDim.y;
+    const int64_t i0 = (int64_t)blockIdx.y * per;
+    int64_t i1 = i0 + per;
+    if (i1 > n) i1 = n;
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
         const int64_t b = i / HW, p = i - b * HW;
         s += (double)vs_ld(x, xd, (b * C + c) * HW + p);
     }
     const double t = block_sum(s, red);
-    if (threadIdx.x == 0) out[c] = (float)t;
+    if (threadIdx.x == 0) atomicAdd(out + c, (float)t);
 }
 
 // MaxPool2d(2,2): planes = B*C, input H x W (even), output H/2 x W/2
@@ -192,43 +219,55 @@ inline unsigned ew_grid(int64_t total) {
 
 }  // namespace
 
-extern "C" int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW, float* mean, float* invstd, float* running_mean,
-                           float* running_var, float momentum, float eps, void* stream) {
-    VS_CHECK_ARG(x && mean && invstd && B > 0 && C > 0 && HW > 0, "vs_bn_stats: bad argument");
+extern "C" int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW, int groups, float* mean, float* invstd, float* var_scratch,
+                           float* running_mean, float* running_var, float momentum, float eps, void* stream) {
+    VS_CHECK_ARG(x && mean && invstd && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_stats: bad argument");
     VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "vs_bn_stats: running_mean/var must come together");
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, x_dtype, B, C, HW, mean, invstd, running_mean,
-                       running_var, momentum, eps);
+    VS_CHECK_ARG(!running_mean || var_scratch, "vs_bn_stats: var_scratch [groups*C] is needed to update running statistics");
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups), dim3(256), 0, (hipStream_t)stream, x, x_dtype, B / groups, C, HW, mean, invstd,
+                       running_mean ? var_scratch : nullptr, eps);
     VS_CHECK_LAUNCH("vs_bn_stats");
+    if (running_mean) {
+        hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, var_scratch, groups, C, running_mean,
+                           running_var, momentum);
+        VS_CHECK_LAUNCH("vs_bn_stats running update");
+    }
     return VS_OK;
 }
 
 extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
-                             const float* beta, int act, int B, int C, int64_t HW, void* stream) {
-    VS_CHECK_ARG(x && y && mean && invstd && gamma && beta && B > 0 && C > 0 && HW > 0, "vs_bn_act_fwd: bad argument");
+                             const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream) {
+    VS_CHECK_ARG(x && y && mean && invstd && gamma && beta && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_act_fwd: bad argument");
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
-                       gamma, beta, act, C, HW, total);
+                       gamma, beta, act, C, HW, total, (int64_t)(B / groups) * C * HW);
     VS_CHECK_LAUNCH("vs_bn_act_fwd");
     return VS_OK;
 }
 
 extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd,
-                             const float* gamma, const float* beta, int act, int training, float* dgamma, float* dbeta, void* dx,
+                             const float* gamma, const float* beta, int act, int training, int groups, float* dgamma, float* dbeta, void* dx,
                              int dx_dtype, int B, int C, int64_t HW, void* stream) {
-    VS_CHECK_ARG(dy && x && mean && invstd && gamma && beta && dgamma && dbeta && dx && B > 0 && C > 0 && HW > 0, "vs_bn_act_bwd: bad argument");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd, gamma, beta,
-                       act, B, C, HW, dbeta, dgamma);
+    VS_CHECK_ARG(dy && x && mean && invstd && gamma && beta && dgamma && dbeta && dx && B > 0 && C > 0 && HW > 0 && groups >= 1 &&
+                     B % groups == 0, "vs_bn_act_bwd: bad argument");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd, gamma,
+                       beta, act, B / groups, C, HW, dbeta, dgamma);
     VS_CHECK_LAUNCH("vs_bn_act_bwd reduce");
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd,
-                       gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B, C, HW, total, training);
+                       gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, HW, total, training);
     VS_CHECK_LAUNCH("vs_bn_act_bwd apply");
     return VS_OK;
 }
 
 extern "C" int vs_chan_sum(const void* x, int x_dtype, int B, int C, int64_t HW, float* out, void* stream) {
     VS_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0, "vs_chan_sum: bad argument");
-    hipLaunchKernelGGL(chan_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, x_dtype, B, C, HW, out);
+    if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_chan_sum: memset failed");
+    int64_t chunks = ((int64_t)B * HW + 32767) / 32768;
+    const int64_t want = (1024 + C - 1) / C;                     // aim at ~1024 workgroups in total
+    if (chunks > want) chunks = want;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(chan_sum_kernel, dim3(C, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, x_dtype, B, C, HW, out);
     VS_CHECK_LAUNCH("vs_chan_sum");
     return VS_OK;
 }

@@ -233,14 +233,15 @@ def packed_conv_weight(p, dtype, stride, pad):
 class ConvBlock(torch.autograd.Function):
     """conv / transposed conv -> [BatchNorm2d (per-call batch statistics)] -> [activation]  (conv.py:41-60).
 
-    cfg = (transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32).  Forward keeps the pre-BN conv
+    cfg = (transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32, groups); `groups` > 1 means the
+    batch is that many reference calls stacked along dim 0, each normalised with its own statistics.  Forward keeps the pre-BN conv
     output z (compute dtype) and the batch statistics; backward recomputes the normalised value from z, so no
     post-activation tensor has to be kept for BN blocks (save what OUR backward needs)."""
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, rmean, rvar, cfg):
         require_cuda(x)
-        transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32 = cfg
+        transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32, groups = cfg
         cdt = compute_dtype()
         out_dt = torch.float32 if out_fp32 else cdt
         xc = to_compute(x, cdt)
@@ -250,10 +251,11 @@ class ConvBlock(torch.autograd.Function):
         if has_bn:
             z = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, cdt, w_packed=wp)
             if training:
-                mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps)
+                mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
             else:
-                mean, invstd = rmean.detach().clone(), torch.rsqrt(rvar.detach() + eps)
-            y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt)
+                mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
+                invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
+            y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
             ctx.save_for_backward(xc, z, mean, invstd)
         else:
             y = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, out_dt, w_packed=wp)
@@ -267,16 +269,21 @@ class ConvBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32 = ctx.cfg
+        transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32, groups = ctx.cfg
         cdt, w, b = ctx.cdt, ctx.w, ctx.b
         dgamma = dbeta = None
         if has_bn:
             xc, z, mean, invstd = ctx.saved_tensors
-            dz, dgamma, dbeta = ops.bn_act_bwd(dy, z, mean, invstd, ctx.gamma.detach(), ctx.beta.detach(), act, training, cdt)
+            dz, dgamma, dbeta = ops.bn_act_bwd(dy, z, mean, invstd, ctx.gamma.detach(), ctx.beta.detach(), act, training, cdt,
+                                               groups=groups)
         else:
             xc, y = ctx.saved_tensors
             dz = ops.act_bwd(dy, y, act, out_dtype=cdt) if act not in ('none', None) else to_compute(dy, cdt)
-        db = ops.chan_sum(dz) if b is not None and b.requires_grad else None
+        db = None
+        if b is not None and b.requires_grad:
+            # a conv bias in front of a training-mode BatchNorm has an exactly-zero gradient (the batch mean removes it);
+            # the reference returns fp32 summation noise there, we return the exact value without a reduction pass
+            db = torch.zeros_like(b) if (has_bn and training) else ops.chan_sum(dz)
         dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed) if w.requires_grad else None
         dx = None
         if ctx.x_needs_grad:

@@ -32,15 +32,17 @@ def _flatten_modules(module, out):
     return out
 
 
-def run_layers(module, h, final_act='none', final_fp32=False):
+def run_layers(module, h, final_act='none', final_fp32=False, groups=1):
     """Execute a (nested) Sequential of reference layer objects on the HIP path.
 
     `final_act` is an activation the caller applies right after the last layer (decoder `last_activation`); it is fused
     into the last conv block when that block has no activation of its own.  `final_fp32` makes the last block write
-    fp32 (module outputs are fp32 in every precision mode)."""
+    fp32 (module outputs are fp32 in every precision mode).  `groups` > 1: dim 0 of `h` holds that many reference CALLS
+    stacked (e.g. the decoder calls of all rollout steps); every BatchNorm then keeps per-call statistics and updates
+    its running estimates call by call, so the batched execution is the reference's arithmetic."""
     layers = [m for m in _flatten_modules(module, []) if not isinstance(m, nn.Identity)]
     # group: conv [bn] [act]
-    groups, i = [], 0
+    blocks, i = [], 0
     while i < len(layers):
         m = layers[i]
         if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
@@ -52,13 +54,13 @@ def run_layers(module, h, final_act='none', final_fp32=False):
             if j < len(layers) and isinstance(layers[j], _ACT_TYPES):
                 act = layers[j]
                 j += 1
-            groups.append(('conv', m, bn, act))
+            blocks.append(('conv', m, bn, act))
             i = j
         else:
-            groups.append(('other', m, None, None))
+            blocks.append(('other', m, None, None))
             i += 1
-    for gi, (kind, m, bn, act) in enumerate(groups):
-        last = gi == len(groups) - 1
+    for gi, (kind, m, bn, act) in enumerate(blocks):
+        last = gi == len(blocks) - 1
         if kind == 'conv':
             act_name = activation_name(act) if act is not None else 'none'
             extra = None
@@ -70,10 +72,10 @@ def run_layers(module, h, final_act='none', final_fp32=False):
             assert m.kernel_size[0] == m.kernel_size[1] and m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1]
             training = bn.training if bn is not None else False
             if bn is not None and training:
-                bn.num_batches_tracked += 1            # per call, like nn.BatchNorm2d
+                bn.num_batches_tracked += groups       # per call, like nn.BatchNorm2d
             cfg = (isinstance(m, nn.ConvTranspose2d), m.stride[0], m.padding[0], bn is not None, act_name, training,
                    bn.momentum if bn is not None else 0.1, bn.eps if bn is not None else 1e-5,
-                   bool(final_fp32 and last and extra is None))
+                   bool(final_fp32 and last and extra is None), groups)
             h = VF.ConvBlock.apply(h, m.weight, m.bias, bn.weight if bn is not None else None,
                                    bn.bias if bn is not None else None, bn.running_mean if bn is not None else None,
                                    bn.running_var if bn is not None else None, cfg)
@@ -170,19 +172,31 @@ class BaseDecoder(nn.Module):
         self.mixing = mixing
         self.last_activation = activation_factory(last_activation)
 
-    def forward(self, z1, z2, skip=None):
+    def forward(self, z1, z2, skip=None, groups=1):
         assert skip is None and not self.skip or self.skip and skip is not None
         z = torch.cat([z1, z2], dim=1) if self.mixing == 'concat' else z1 * z2
-        h = run_layers(self.first_upconv, z.view(*z.shape, 1, 1))
+        h = run_layers(self.first_upconv, z.view(*z.shape, 1, 1), groups=groups)
         n_stage = len(self.conv)
         for i, layer in enumerate(self.conv):
             if skip is not None:
                 h = torch.cat([h, skip[i].to(h.dtype)], 1)
             if i == n_stage - 1:
-                h = run_layers(layer, h, final_act=activation_name(self.last_activation), final_fp32=True)
+                h = run_layers(layer, h, final_act=activation_name(self.last_activation), final_fp32=True, groups=groups)
             else:
-                h = run_layers(layer, h)
+                h = run_layers(layer, h, groups=groups)
         return h
+
+    def decode_sequence(self, z1, t_codes, skip=None):
+        """All n decoder calls of a rollout (model.py:74-83) as ONE batch of n*B samples ordered [step][sample]; every
+        BatchNorm keeps per-step statistics (`groups = n`), so this is the reference's arithmetic with n x larger GEMMs.
+
+        z1 [B, Cs], t_codes [B, n, Ct] -> frames [B, n, C, H, W] (a transposed view of the [n, B, ...] result)."""
+        B, n = t_codes.shape[0], t_codes.shape[1]
+        z2 = t_codes.transpose(0, 1).reshape(n * B, -1)
+        z1e = z1.repeat(n, 1)
+        skips = None if skip is None else [s.repeat(n, 1, 1, 1) for s in skip]
+        out = self.forward(z1e, z2, skip=skips, groups=n)
+        return out.view(n, B, *out.shape[1:]).transpose(0, 1)
 
 
 class DCGAN64Decoder(BaseDecoder):
@@ -237,6 +251,16 @@ class EncoderSST(nn.Module):
         return h4
 
 
+def _decode_sequence_spatial(dec, s_code, t_codes, skip):
+    """decode_sequence for the SST decoders: s_code [B, Cs, h, w], t_codes [B, n, Ct, h, w] -> [B, n, C, H, W]."""
+    B, n = t_codes.shape[0], t_codes.shape[1]
+    z2 = t_codes.transpose(0, 1).reshape(n * B, *t_codes.shape[2:])
+    z1e = s_code.repeat(n, 1, 1, 1)
+    skips = None if skip is None else [s.repeat(n, 1, 1, 1) for s in skip]
+    out = dec.forward(z1e, z2, skips, groups=n)
+    return out.view(n, B, *out.shape[1:]).transpose(0, 1)
+
+
 class DecoderSST_Skip(nn.Module):
     """conv.py:359-396."""
 
@@ -248,13 +272,16 @@ class DecoderSST_Skip(nn.Module):
         self.conv4 = nn.Sequential(_c3(64 * 2, 64), _c3(64, 64), _c3(64, out_c))
         self.out_f = activation_factory(out_f)
 
-    def forward(self, s_code, t_code, skip):
+    def forward(self, s_code, t_code, skip, groups=1):
         h3, h2, h1 = skip
-        out = run_layers(self.conv1, torch.cat([s_code, t_code], dim=1))
-        out = run_layers(self.conv2, torch.cat([h3.to(out.dtype), out], dim=1))
-        out = run_layers(self.conv3, torch.cat([h2.to(out.dtype), out], dim=1))
+        out = run_layers(self.conv1, torch.cat([s_code, t_code], dim=1), groups=groups)
+        out = run_layers(self.conv2, torch.cat([h3.to(out.dtype), out], dim=1), groups=groups)
+        out = run_layers(self.conv3, torch.cat([h2.to(out.dtype), out], dim=1), groups=groups)
         return run_layers(self.conv4, torch.cat([h1.to(out.dtype), out], dim=1), final_act=activation_name(self.out_f),
-                          final_fp32=True)
+                          final_fp32=True, groups=groups)
+
+    def decode_sequence(self, s_code, t_codes, skip):
+        return _decode_sequence_spatial(self, s_code, t_codes, skip)
 
 
 class DecoderSST(nn.Module):
@@ -267,10 +294,13 @@ class DecoderSST(nn.Module):
         self.conv3 = nn.Sequential(_c3(64, 64), _c3(64, out_c))
         self.out_f = activation_factory(out_f)
 
-    def forward(self, s_code, t_code, skip=None):
-        x = run_layers(self.conv1, torch.cat([s_code, t_code], dim=1))
-        x = run_layers(self.conv2, x)
-        return run_layers(self.conv3, x, final_act=activation_name(self.out_f), final_fp32=True)
+    def forward(self, s_code, t_code, skip=None, groups=1):
+        x = run_layers(self.conv1, torch.cat([s_code, t_code], dim=1), groups=groups)
+        x = run_layers(self.conv2, x, groups=groups)
+        return run_layers(self.conv3, x, final_act=activation_name(self.out_f), final_fp32=True, groups=groups)
+
+    def decode_sequence(self, s_code, t_codes, skip=None):
+        return _decode_sequence_spatial(self, s_code, t_codes, skip)
 
 
 class ConvResBlock(nn.Module):

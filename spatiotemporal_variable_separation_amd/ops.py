@@ -384,46 +384,51 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed):
 
 
 # ------------------------------------------------------------------------------------------------ norm / pool / upsample
-def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, groups=1):
+    """Per-(group, channel) batch statistics; returns (mean [groups, C], invstd [groups, C])."""
     require_cuda(x)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
-    mean = torch.empty((C,), dtype=torch.float32, device=x.device)
-    invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
-    check(_lib.load_library().vs_bn_stats(x.data_ptr(), dtype_code(x), B, C, HW, mean.data_ptr(), invstd.data_ptr(),
-                                          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), stream_ptr()),
-          'vs_bn_stats')
+    mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((groups, C), dtype=torch.float32, device=x.device) if running_mean is not None else None
+    check(_lib.load_library().vs_bn_stats(x.data_ptr(), dtype_code(x), B, C, HW, groups, mean.data_ptr(), invstd.data_ptr(),
+                                          _ptr(scratch), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+                                          stream_ptr()), 'vs_bn_stats')
     return mean, invstd
 
 
-def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype):
+def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype, groups=1):
     require_cuda(x)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     e0 = _pb()
     check(_lib.load_library().vs_bn_act_fwd(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), mean.data_ptr(),
-                                            invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], B, C, HW, stream_ptr()),
-          'vs_bn_act_fwd')
+                                            invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], B, C, HW, groups,
+                                            stream_ptr()), 'vs_bn_act_fwd')
     _pe(e0, 'vs_bn_act_fwd', nbytes=float(x.numel() * (x.element_size() + y.element_size())))
     return y
 
 
-def bn_act_bwd(dy, x, mean, invstd, gamma, beta, act, training, out_dtype):
+def bn_act_bwd(dy, x, mean, invstd, gamma, beta, act, training, out_dtype, groups=1):
+    """Returns (dx, dgamma [C], dbeta [C]) -- per-group sums are reduced over the groups here."""
     require_cuda(dy, x)
     dy = dy.contiguous()
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
-    dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
-    dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
+    dgamma = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+    dbeta = torch.empty((groups, C), dtype=torch.float32, device=x.device)
     dx = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     e0 = _pb()
     check(_lib.load_library().vs_bn_act_bwd(dy.data_ptr(), dtype_code(dy), x.data_ptr(), dtype_code(x), mean.data_ptr(),
                                             invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], int(bool(training)),
-                                            dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), dtype_code(dx), B, C, HW,
+                                            groups, dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), dtype_code(dx), B, C, HW,
                                             stream_ptr()), 'vs_bn_act_bwd')
     _pe(e0, 'vs_bn_act_bwd', nbytes=float(x.numel() * (2 * x.element_size() + 2 * dy.element_size() + dx.element_size())))
-    return dx, dgamma, dbeta
+    if groups == 1:
+        return dx, dgamma[0], dbeta[0]
+    return dx, dgamma.sum(0), dbeta.sum(0)
 
 
 def chan_sum(x):

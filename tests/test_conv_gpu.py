@@ -110,3 +110,31 @@ def test_pool_upsample(dtype):
     assert torch.equal(u.cpu().double(), u64.detach())
     dxu = ops.upsample2_bwd(du.cuda(), torch.float32)
     assert ((dxu.cpu().double() - x64b.grad).norm() / x64b.grad.norm()).item() < 1e-6
+
+
+def test_grouped_batchnorm_equals_sequential_calls():
+    """groups = G on a stacked batch == G separate BatchNorm calls (statistics, outputs, gradients, running stats)."""
+    from spatiotemporal_variable_separation_amd import ops
+    G, Bg, C, H, W = 3, 4, 6, 8, 8
+    x = (_rand((G * Bg, C, H, W), 31) * 1.5 + 0.2)
+    dy = _rand((G * Bg, C, H, W), 32)
+    gamma, beta = 1 + _rand((C,), 33, 0.3), _rand((C,), 34, 0.2)
+    rm0, rv0 = _rand((C,), 35, 0.1), 1 + _rand((C,), 36, 0.2)
+    xc, dyc = x.cuda(), dy.cuda()
+    rm_g, rv_g = rm0.clone().cuda(), rv0.clone().cuda()
+    mean, invstd = ops.bn_stats(xc, rm_g, rv_g, 0.1, 1e-5, groups=G)
+    y = ops.bn_act_fwd(xc, mean, invstd, gamma.cuda(), beta.cuda(), 'leaky_relu', torch.float32, groups=G)
+    dx, dg, db = ops.bn_act_bwd(dyc, xc, mean, invstd, gamma.cuda(), beta.cuda(), 'leaky_relu', True, torch.float32, groups=G)
+    rm_s, rv_s = rm0.clone().cuda(), rv0.clone().cuda()
+    dg_s, db_s = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    for g in range(G):
+        sl = slice(g * Bg, (g + 1) * Bg)
+        xs = xc[sl].contiguous()
+        m1, i1 = ops.bn_stats(xs, rm_s, rv_s, 0.1, 1e-5)
+        y1 = ops.bn_act_fwd(xs, m1, i1, gamma.cuda(), beta.cuda(), 'leaky_relu', torch.float32)
+        dx1, dg1, db1 = ops.bn_act_bwd(dyc[sl].contiguous(), xs, m1, i1, gamma.cuda(), beta.cuda(), 'leaky_relu', True, torch.float32)
+        assert torch.equal(y[sl], y1) and torch.equal(dx[sl], dx1)
+        dg_s += dg1
+        db_s += db1
+    assert torch.equal(rm_g, rm_s) and torch.equal(rv_g, rv_s)
+    assert torch.allclose(dg, dg_s, rtol=1e-6, atol=1e-6) and torch.allclose(db, db_s, rtol=1e-6, atol=1e-6)

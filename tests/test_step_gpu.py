@@ -47,7 +47,7 @@ def test_step_bf16_within_stated_bound(name):
           {k: f'{v:.1e}' for k, v in vs_fp32.items()})
 
 
-@pytest.mark.parametrize('name', MLP_CONFIGS)
+@pytest.mark.parametrize('name', MLP_CONFIGS + ['dcgan_tiny', 'vgg32_tiny', 'sst_skip'])
 def test_step_fp32_unfused_structure_matches_oracle(name):
     """`sep_net.fused = False` keeps the reference's per-step launch structure (one decoder / integrator call per
     frame, separate E_s/E_t calls); it must give the same numbers as the batched fast path."""
