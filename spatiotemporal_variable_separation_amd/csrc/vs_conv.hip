@@ -41,11 +41,19 @@ struct TapGeo {
     int GH, GW;            // iteration grid (one GEMM column / reduction index per (b, gy, gx))
     int s;                 // source coordinate = grid coordinate * s + tap offset
     int ntap;
-    signed char dy[MAXTAP], dx[MAXTAP];
+    signed char dy[MAXTAP], dx[MAXTAP];   // host-side tap list; the device reads the nibble-packed copies below
     // index-math helpers filled by finish(): shifts when the grid is a power of two (-1 otherwise), multiply-high magic for / ntap
     int gw_shift, ghw_shift;
     unsigned ntap_magic;
+    unsigned long long dy_tab, dx_tab;    // tap t -> ((tab >> 4t) & 15) - 8   (offsets are within [-8, 7]); two scalars, no indexing
+    __device__ __forceinline__ int tap_dy(int t) const { return (int)((dy_tab >> (4 * t)) & 15ull) - 8; }
+    __device__ __forceinline__ int tap_dx(int t) const { return (int)((dx_tab >> (4 * t)) & 15ull) - 8; }
     void finish() {
+        dy_tab = dx_tab = 0;
+        for (int t = 0; t < ntap; ++t) {
+            dy_tab |= (unsigned long long)((dy[t] + 8) & 15) << (4 * t);
+            dx_tab |= (unsigned long long)((dx[t] + 8) & 15) << (4 * t);
+        }
         gw_shift = ghw_shift = -1;
         for (int k = 0; k < 31; ++k) {
             if ((1 << k) == GW) gw_shift = k;
@@ -97,6 +105,22 @@ struct TapGather {
             } else {
 #pragma unroll
                 for (int j = 0; j < LEN; ++j) dst[j] = row[ix0 + j * g.s];
+            }
+        } else if (g.s == 1 && g.W >= LEN && ix0 >= -2 && last <= g.W + 1) {
+            // border unit of a stride-1 gather (zero padding on one side): ONE vector load of the nearest in-range window,
+            // then a register shift -- small feature maps (4..16 pixels per row) are almost all border units
+            struct __attribute__((packed, aligned(sizeof(T)))) Vec { T v[LEN]; };
+            const int base = ix0 < 0 ? 0 : g.W - LEN;
+            const Vec t = *reinterpret_cast<const Vec*>(row + base);
+            const int sh = ix0 - base;                                           // -2, -1 (left border) or +1, +2 (right border)
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) {
+                T v = (T)0.f;
+                if (sh == -1) { if (j >= 1) v = t.v[j - 1]; }
+                else if (sh == 1) { if (j + 1 < LEN) v = t.v[j + 1]; }
+                else if (sh == -2) { if (j >= 2) v = t.v[j - 2]; }
+                else if (sh == 2) { if (j + 2 < LEN) v = t.v[j + 2]; }
+                dst[j] = v;
             }
         } else {
 #pragma unroll
@@ -150,7 +174,7 @@ struct GatherOp {
             if (st.ok) {
                 int t;
                 gather.g.split_q((int)i, st.a, t);                              // (c, dy, dx)
-                st.b = gather.g.dy[t]; st.c = gather.g.dx[t];
+                st.b = gather.g.tap_dy(t); st.c = gather.g.tap_dx(t);
             }
         }
         return st;
@@ -162,7 +186,7 @@ struct GatherOp {
             if (k >= gather.nq) return z;
             int c, t;
             gather.g.split_q((int)k, c, t);
-            return gather.unit_at(i, st.a, st.b, st.c, c, gather.g.dy[t], gather.g.dx[t]);
+            return gather.unit_at(i, st.a, st.b, st.c, c, gather.g.tap_dy(t), gather.g.tap_dx(t));
         } else {
             if (k >= gather.npix) return z;
             int b, gy, gx;
@@ -303,7 +327,7 @@ inline void natural_taps(TapGeo& g, int kh, int kw, int pad, bool flipped) {
 template <int CT>
 int conv_form(const void* src, const void* w, const float* bias, void* out, int out_dtype, int B, int Csrc, int H, int W, int M, int kh, int kw,
               int s, int p, int OH, int OW, hipStream_t st, const char* what) {
-    TapGeo g{B, Csrc, H, W, OH, OW, s, 0, {}, {}, 0, 0, 0};
+    TapGeo g{B, Csrc, H, W, OH, OW, s, 0, {}, {}, 0, 0, 0, 0, 0};
     natural_taps(g, kh, kw, p, false);
     return gather_gemm<CT>(src, w, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, st, what);
 }
@@ -316,7 +340,7 @@ int transposed_form(const void* src, const void* wp, const float* bias, void* ou
                     int kw, int s, int p, int OH, int OW, hipStream_t st, const char* what) {
     typedef typename CTraits<CT>::T T;
     if (s == 1) {
-        TapGeo g{B, Csrc, H, W, OH, OW, 1, 0, {}, {}, 0, 0, 0};
+        TapGeo g{B, Csrc, H, W, OH, OW, 1, 0, {}, {}, 0, 0, 0, 0, 0};
         natural_taps(g, kh, kw, p, true);
         return gather_gemm<CT>(src, wp, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, st, what);
     }
@@ -324,7 +348,7 @@ int transposed_form(const void* src, const void* wp, const float* bias, void* ou
     const T* wph = (const T*)wp;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {
-            TapGeo g{B, Csrc, H, W, H, W, 1, 0, {}, {}, 0, 0, 0};
+            TapGeo g{B, Csrc, H, W, H, W, 1, 0, {}, {}, 0, 0, 0, 0, 0};
             int kidx[MAXTAP];
             g.ntap = phase_taps(kh, kw, s, p, py, px, kidx, g.dy, g.dx);
             int rc = gather_gemm<CT>(src, wph, bias, out, out_dtype, M, g, OH, OW, s, py, px, st, what);
@@ -346,7 +370,7 @@ int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH
     for (int k = 0; k < 31; ++k) if (((int64_t)1 << k) == hw) hw_shift = k;
     ChanRows<CT> a{(const T*)r, Cr, hw, K, ((uintptr_t)r % 16 == 0) && (hw % CTraits<CT>::U == 0), hw_shift};
     GatherOp<CT, false> b;
-    TapGeo g{B, Cg, GH, GW, PH, PW, s, 0, {}, {}, 0, 0, 0};
+    TapGeo g{B, Cg, GH, GW, PH, PW, s, 0, {}, {}, 0, 0, 0, 0, 0};
     natural_taps(g, kh, kw, p, false);
     b.gather.src = (const T*)gsrc; b.gather.g = g; b.gather.g.finish(); b.gather.npix = K; b.gather.nq = N;
     return run<CT>(a, b, M, N, K, rowmajor_epi(dw, N), ws, ws_bytes, st, what);

@@ -31,3 +31,19 @@ def load_yaml(path):
 def load_json(path):
     with open(path, 'r') as f:
         return DotDict(json.load(f))
+
+
+def load_model(xp_dir, sep_net, epoch_number=None, map_location='cpu'):
+    """Load the four checkpoint files written by `save` -- or by the REFERENCE's `save` (utils/helper.py:22-33, whole-module
+    pickles of `var_sep.networks.*` classes; unpickling those needs the reference package importable) -- into `sep_net`.
+
+    Only `state_dict()`s cross over: keys and shapes are identical by construction, so reference-trained weights run on
+    the HIP path unchanged.  torch >= 2.6 defaults to weights_only=True, which rejects
+    whole-module pickles; they are loaded with weights_only=False like the reference's test/utils.py:10-13 intends."""
+    append = f'_{epoch_number}' if epoch_number is not None else ''
+    for stem, module in (('ov_Et', sep_net.Et), ('ov_Es', sep_net.Es), ('decoder', sep_net.decoder),
+                         ('t_resnet', sep_net.t_resnet)):
+        obj = torch.load(os.path.join(xp_dir, f'{stem}{append}.pt'), map_location=map_location, weights_only=False)
+        state = obj.state_dict() if hasattr(obj, 'state_dict') else obj
+        module.load_state_dict(state, strict=True)
+    return sep_net

@@ -1,0 +1,68 @@
+"""GPU: eval-mode `get_forecast` (BatchNorm on running statistics, no_grad, long horizon, content swap via init_s_code) --
+the inference usage of the reference's evaluation scripts (test/wave/test.py:41-48, test/mnist/test.py:120-131) -- and the
+checkpoint round trip (utils/helper.py:22-33)."""
+import pytest
+import torch
+
+from oracle import cpu_ref
+from oracle.detdata import det_fill
+from oracle.golden_configs import CONFIGS, make_batch
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(name):
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    cfg = CONFIGS[name]
+    o_net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt']).eval()
+    h_net = build_sep_net(cfg)
+    h_net.load_state_dict(o_net.state_dict(), strict=True)
+    return cfg, o_net, h_net.cuda().eval()
+
+
+@pytest.mark.parametrize('name', ['mlp_mul', 'dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'sst_skip'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_eval_forecast_matches_oracle(name, fused):
+    cfg, o_net, h_net = _pair(name)
+    h_net.fused = fused
+    cond, _ = make_batch(cfg)
+    horizon = 12
+    with torch.no_grad():
+        o_fore, o_codes, o_s, _ = o_net.get_forecast(cond, horizon)
+        h_fore, h_codes, h_s, _ = h_net.get_forecast(cond.cuda(), horizon)
+    assert tuple(h_fore.shape) == tuple(o_fore.shape) and tuple(h_codes.shape) == tuple(o_codes.shape)
+    assert rel_err(h_fore.cpu(), o_fore) < 1e-3, name
+    assert rel_err(h_codes.cpu(), o_codes) < 1e-3, name
+    # eval mode must not touch the running statistics
+    osd = o_net.state_dict()
+    for k, v in h_net.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            assert torch.equal(v.cpu(), osd[k]), k
+
+
+def test_content_swap_with_init_s_code():
+    """Disentanglement usage (test/mnist/test_disentanglement.py): S from one sequence, T from another."""
+    cfg, o_net, h_net = _pair('dcgan_tiny')
+    cond, _ = make_batch(cfg)
+    other = cond.flip(0)
+    with torch.no_grad():
+        o_s = o_net.Es(other)
+        o_fore = o_net.get_forecast(cond, 5, init_s_code=o_s)[0]
+        h_s = h_net.Es(other.cuda())
+        h_fore = h_net.get_forecast(cond.cuda(), 5, init_s_code=h_s)[0]
+    assert rel_err(h_fore.cpu(), o_fore) < 1e-3
+
+
+def test_checkpoint_round_trip(tmp_path):
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.utils.helper import save, load_model
+    cfg, o_net, h_net = _pair('dcgan_tiny')
+    save(str(tmp_path), h_net, epoch_number=3)
+    for stem in ('ov_Et_3.pt', 'ov_Es_3.pt', 'decoder_3.pt', 't_resnet_3.pt'):
+        assert (tmp_path / stem).exists()
+    fresh = build_sep_net(cfg)
+    load_model(str(tmp_path), fresh, epoch_number=3)
+    a, b = fresh.state_dict(), o_net.state_dict()
+    for k in b:
+        assert torch.equal(a[k].cpu(), b[k]), k
