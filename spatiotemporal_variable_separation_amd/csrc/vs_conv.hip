@@ -160,21 +160,36 @@ struct TapGather {
 //                                 otherwise   -> element(i = q, k = pixel), LDS layout R (unit along k).
 template <int CT, bool PIX_IS_ROW>
 struct GatherOp {
+    typedef typename CTraits<CT>::T T;
+    static constexpr int U = CTraits<CT>::U;
     static constexpr int layout = PIX_IS_ROW ? LS : LR;
     TapGather<CT> gather;
-    // the index i of a unit slot is fixed along K: decode it once (pixel -> (b, gy, gx), or q -> (channel, tap offsets))
-    struct State { int a, b, c; int ok; };
+    // The index i of a unit slot is fixed along K: decode it once.
+    //   PIX_IS_ROW : (a,b,c) = (b, gy, gx), `base` = element offset of source pixel (b, channel 0, gy*s, gx*s), and
+    //                `interior` has bit t set when tap t reads U in-range pixels of one row (single vector load, no checks)
+    //   otherwise  : (a,b,c) = (channel, dy, dx) of the fixed q
+    struct State { int a, b, c; int ok; int64_t base; unsigned interior; };
     __device__ __forceinline__ State prepare(int64_t i) const {
-        State st = {0, 0, 0, 0};
+        State st = {0, 0, 0, 0, 0, 0u};
+        const TapGeo& g = gather.g;
         if (PIX_IS_ROW) {
             st.ok = i < gather.npix;
-            if (st.ok) gather.g.split_pix(i, st.a, st.b, st.c);                 // (b, gy, gx)
+            if (st.ok) {
+                g.split_pix(i, st.a, st.b, st.c);                                // (b, gy, gx)
+                st.base = (((int64_t)st.a * g.C) * g.H + (int64_t)st.b * g.s) * g.W + (int64_t)st.c * g.s;
+                if ((g.GW % U) == 0 && i + U <= gather.npix && g.s <= 2) {
+                    for (int t = 0; t < g.ntap; ++t) {
+                        const int iy = st.b * g.s + g.tap_dy(t), ix0 = st.c * g.s + g.tap_dx(t);
+                        if (iy >= 0 && iy < g.H && ix0 >= 0 && ix0 + (U - 1) * g.s < g.W) st.interior |= 1u << t;
+                    }
+                }
+            }
         } else {
             st.ok = i < gather.nq;
             if (st.ok) {
                 int t;
-                gather.g.split_q((int)i, st.a, t);                              // (c, dy, dx)
-                st.b = gather.g.tap_dy(t); st.c = gather.g.tap_dx(t);
+                g.split_q((int)i, st.a, t);                                      // (c, dy, dx)
+                st.b = g.tap_dy(t); st.c = g.tap_dx(t);
             }
         }
         return st;
@@ -182,15 +197,28 @@ struct GatherOp {
     __device__ __forceinline__ u32x4 load(const State& st, int64_t i, int64_t k) const {
         u32x4 z = {0u, 0u, 0u, 0u};
         if (!st.ok) return z;
+        const TapGeo& g = gather.g;
         if (PIX_IS_ROW) {
             if (k >= gather.nq) return z;
             int c, t;
-            gather.g.split_q((int)k, c, t);
-            return gather.unit_at(i, st.a, st.b, st.c, c, gather.g.tap_dy(t), gather.g.tap_dx(t));
+            g.split_q((int)k, c, t);
+            const int dyv = g.tap_dy(t), dxv = g.tap_dx(t);
+            if ((st.interior >> t) & 1u) {                                       // fast path: no bounds logic at all
+                const T* p = gather.src + st.base + ((int64_t)c * g.H + dyv) * g.W + dxv;
+                struct __attribute__((packed, aligned(sizeof(T)))) Vec { T v[U]; };
+                if (g.s == 1) return *reinterpret_cast<const u32x4*>(reinterpret_cast<const Vec*>(p));
+                const Vec t0 = *reinterpret_cast<const Vec*>(p);
+                const Vec t1 = *reinterpret_cast<const Vec*>(p + U - 1);
+                T tmp[U];
+#pragma unroll
+                for (int j = 0; j < U / 2; ++j) { tmp[j] = t0.v[2 * j]; tmp[U / 2 + j] = t1.v[2 * j + 1]; }
+                return *reinterpret_cast<u32x4*>(tmp);
+            }
+            return gather.unit_at(i, st.a, st.b, st.c, c, dyv, dxv);
         } else {
             if (k >= gather.npix) return z;
             int b, gy, gx;
-            gather.g.split_pix(k, b, gy, gx);
+            g.split_pix(k, b, gy, gx);
             return gather.unit_at(k, b, gy, gx, st.a, st.b, st.c);
         }
     }
@@ -228,6 +256,7 @@ int run(const OpA& a, const OpB& b, int64_t M, int64_t N, int64_t K, const Epi& 
     typedef typename CTraits<CT>::T T;
     constexpr int BK = CT == VS_BF16 ? 64 : 16;
     Plan plan = make_plan(CT, M, N, K);
+    if (plan.bm == 128 && plan.bn == 128) plan.bn = 64;      // gather operands are register hungry: 128x128 drops to 2 waves/SIMD
     float* slabs = nullptr;
     if (plan.splits > 1) {
         const size_t need = (size_t)plan.splits * (size_t)M * (size_t)N * sizeof(float);
@@ -298,6 +327,51 @@ inline int phase_taps(int kh, int kw, int s, int p, int py, int px, int* kidx, s
     return n;
 }
 
+// ---- tiny-M path (Cout = 1..4: the image-producing last decoder layer): one thread per 16-byte pixel unit, all K in
+// registers-free streaming fashion.  HBM/L2 bound (the MFMA tile would waste 60/64 rows); weights are wave-uniform loads.
+template <int CT, int MR>
+__global__ __launch_bounds__(256) void gather_rowdot_kernel(Dense<CT, LR> A, GatherOp<CT, true> B, int M, int64_t N, int K, Epi epi) {
+    typedef typename CTraits<CT>::T T;
+    constexpr int U = CTraits<CT>::U;
+    const int64_t units = (N + U - 1) / U;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+        const int64_t pix0 = u * U;
+        const typename GatherOp<CT, true>::State st = B.prepare(pix0);
+        float acc[MR][U];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int j = 0; j < U; ++j) acc[m][j] = 0.f;
+        for (int q0 = 0; q0 < K; q0 += 8) {                          // 8 independent gathers in flight per thread
+            u32x4 raw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = B.load(st, pix0, q0 + e);          // q >= K returns zeros
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const T* v = reinterpret_cast<const T*>(&raw[e]);
+                const int q = q0 + e < K ? q0 + e : K - 1;
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    if (m < M) {
+                        const float w = (float)A.p[(int64_t)m * A.ld + q];
+#pragma unroll
+                        for (int j = 0; j < U; ++j) acc[m][j] += w * (float)v[j];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int64_t n = pix0 + j;
+            if (n >= N) break;
+            const int64_t cb = nchw_col_base(epi, n);
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+                if (m < M) epi_store_nchw(epi, m, cb, acc[m][j]);
+        }
+    }
+}
+
 // ---- forward-like contraction:  out[b, m, gy*S+oy, gx*S+ox] = bias[m] + sum Wd[m][(c,t)] src[b, c, gy*s+dy, gx*s+dx] ----
 template <int CT>
 int gather_gemm(const void* src, const void* wd, const float* bias, void* out, int out_dtype, int M, const TapGeo& g, int OH, int OW, int scat,
@@ -310,6 +384,13 @@ int gather_gemm(const void* src, const void* wd, const float* bias, void* out, i
     Epi e = nchw_epi(out, out_dtype, bias, (int64_t)OH * OW, M);
     if (scat != 1 || g.GH != OH || g.GW != OW) {
         e.g_w = g.GW; e.g_hw = g.GH * g.GW; e.o_w = OW; e.sy = scat; e.sx = scat; e.oy = oy; e.ox = ox;
+    }
+    if (M <= 4 && K <= 65536) {
+        int64_t blocks = vs_cdiv(vs_cdiv(N, CTraits<CT>::U), 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL((gather_rowdot_kernel<CT, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, b, M, N, (int)K, e);
+        VS_CHECK_LAUNCH(what);
+        return VS_OK;
     }
     return run<CT>(a, b, M, N, K, e, nullptr, 0, st, what);
 }

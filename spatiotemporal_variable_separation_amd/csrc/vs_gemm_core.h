@@ -350,6 +350,14 @@ Plan make_plan(int compute, int64_t M, int64_t N, int64_t K) {
         if (splits > max_by_k) splits = (int)max_by_k;
         if (splits > 64) splits = 64;
         if (splits < 1) splits = 1;
+    } else if (tiles < 1024 && kt >= 128) {
+        // long reductions over few tiles (convolution weight gradients: K = batch x pixels up to ~10^6): one workgroup per CU
+        // walking thousands of K tiles is latency bound; aim at ~1024 workgroups, >= 32 K tiles each
+        splits = (int)((1024 + tiles - 1) / tiles);
+        const int64_t max_by_k = kt / 32;
+        if (splits > max_by_k) splits = (int)max_by_k;
+        if (splits > 64) splits = 64;
+        if (splits < 1) splits = 1;
     }
     p.k_tiles_per_split = vs_cdiv(kt, splits);
     p.splits = (int)vs_cdiv(kt, p.k_tiles_per_split);

@@ -41,26 +41,67 @@ __device__ __forceinline__ float act_grad_from_pre(float z, int act) {
 // one reference CALL per group (the decoder is invoked once per frame with per-call statistics; batching
 // the calls over time is exact when every call keeps its own mean/variance and the running estimates are folded in
 // call order, which bn_running_kernel does).
+// 8 (bf16) / 4 (fp32) consecutive elements of one (sample, channel) plane per 16-byte load
+__device__ __forceinline__ int ld_vec(const void* x, int xd, int64_t idx, float (&v)[8]) {
+    if (xd == VS_F32) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>((const float*)x + idx);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        return 4;
+    }
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>((const __bf16*)x + idx);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+    return 8;
+}
+__device__ __forceinline__ void st_vec(void* y, int yd, int64_t idx, const float (&v)[8], int n) {
+    if (yd == VS_F32) {
+        for (int o = 0; o < n; o += 4) {
+            f32x4 t = {v[o], v[o + 1], v[o + 2], v[o + 3]};
+            *reinterpret_cast<f32x4*>((float*)y + idx + o) = t;
+        }
+    } else if (n == 8) {
+        bf16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (__bf16)v[j];
+        *reinterpret_cast<bf16x8*>((__bf16*)y + idx) = t;
+    } else {
+        bf16x4 t = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *reinterpret_cast<bf16x4*>((__bf16*)y + idx) = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, int Bg, int C, int64_t HW, float* mean, float* invstd,
-                                                       float* ubvar, float eps) {
+                                                       float* ubvar, float eps, int vec) {
     __shared__ double red[4];
     const int c = blockIdx.x, g = blockIdx.y;
     const int64_t n = (int64_t)Bg * HW;
     const int64_t b0 = (int64_t)g * Bg;
-    double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
-        const int64_t b = i / HW, p = i - b * HW;
-        s += (double)vs_ld(x, xd, ((b0 + b) * C + c) * HW + p);
+    // single pass, fp64 sum and sum of squares: exact enough (53-bit accumulation of fp32/bf16 data) and half the HBM traffic
+    double s = 0.0, q = 0.0;
+    if (vec) {
+        const int w = xd == VS_F32 ? 4 : 8;
+        const int64_t per = HW / w;                                  // vectors per plane
+        for (int64_t i = threadIdx.x; i < (int64_t)Bg * per; i += 256) {
+            const int64_t b = i / per, p = (i - b * per) * w;
+            float v[8];
+            const int cnt = ld_vec(x, xd, ((b0 + b) * C + c) * HW + p, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < cnt) { s += (double)v[j]; q += (double)v[j] * (double)v[j]; }
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            const int64_t b = i / HW, p = i - b * HW;
+            const double v = (double)vs_ld(x, xd, ((b0 + b) * C + c) * HW + p);
+            s += v; q += v * v;
+        }
     }
-    const double mu = block_sum(s, red) / (double)n;
-    double q = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
-        const int64_t b = i / HW, p = i - b * HW;
-        const double d = (double)vs_ld(x, xd, ((b0 + b) * C + c) * HW + p) - mu;
-        q += d * d;
-    }
-    const double ss = block_sum(q, red);
+    const double ts = block_sum(s, red);
+    const double tq = block_sum(q, red);
     if (threadIdx.x == 0) {
+        const double mu = ts / (double)n;
+        double ss = tq - ts * mu;                                    // sum (x - mu)^2
+        if (ss < 0.0) ss = 0.0;
         const double var = ss / (double)n;
         mean[g * C + c] = (float)mu;
         invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -85,7 +126,24 @@ __global__ __launch_bounds__(256) void bn_running_kernel(const float* mean, cons
 
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, void* y, int yd, const float* mean, const float* invstd,
                                                          const float* gamma, const float* beta, int act, int C, int64_t HW, int64_t total,
-                                                         int64_t group_elems) {
+                                                         int64_t group_elems, int vec) {
+    if (vec) {                                                       // 16-byte chunks never straddle a (sample, channel) plane
+        const int w = xd == VS_F32 ? 4 : 8;
+        const int64_t nv = total / w;
+        for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += (int64_t)gridDim.x * 256) {
+            const int64_t i = iv * w;
+            const int c = (int)((i / HW) % C);
+            const int gc = (int)(i / group_elems) * C + c;
+            const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
+            float v[8];
+            const int cnt = ld_vec(x, xd, i, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < cnt) v[j] = vs_act((v[j] - mu) * is * g + bt, act);
+            st_vec(y, yd, i, v, cnt);
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)((i / HW) % C);
         const int gc = (int)(i / group_elems) * C + c;
@@ -96,13 +154,30 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, 
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int dyd, const void* x, int xd, const float* mean,
                                                             const float* invstd, const float* gamma, const float* beta, int act, int Bg, int C,
-                                                            int64_t HW, float* sum_dz, float* sum_dz_xhat) {
+                                                            int64_t HW, float* sum_dz, float* sum_dz_xhat, int vec) {
     __shared__ double red[4];
     const int c = blockIdx.x, grp = blockIdx.y;
     const int64_t n = (int64_t)Bg * HW;
     const int64_t b0 = (int64_t)grp * Bg;
     const float mu = mean[grp * C + c], is = invstd[grp * C + c], g = gamma[c], bt = beta[c];
     double s1 = 0.0, s2 = 0.0;
+    if (vec) {
+        const int w = (xd == VS_F32 || dyd == VS_F32) ? 4 : 8;
+        const int64_t per = HW / w;
+        for (int64_t i = threadIdx.x; i < (int64_t)Bg * per; i += 256) {
+            const int64_t b = i / per, p = (i - b * per) * w;
+            const int64_t idx = ((b0 + b) * C + c) * HW + p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < w) {
+                    const float xh = (vs_ld(x, xd, idx + j) - mu) * is;
+                    const float dz = vs_ld(dy, dyd, idx + j) * act_grad_from_pre(xh * g + bt, act);
+                    s1 += (double)dz;
+                    s2 += (double)dz * (double)xh;
+                }
+            }
+        }
+    } else
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const int64_t b = i / HW, p = i - b * HW;
         const int64_t idx = ((b0 + b) * C + c) * HW + p;
@@ -119,9 +194,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int dyd, const void* x, int xd, const float* mean,
                                                            const float* invstd, const float* gamma, const float* beta, int act,
                                                            const float* sum_dz, const float* sum_dz_xhat, void* dx, int dxd, int Bg, int C,
-                                                           int64_t HW, int64_t total, int training) {
+                                                           int64_t HW, int64_t total, int training, int vec) {
     const float inv_n = 1.f / (float)((int64_t)Bg * HW);
     const int64_t group_elems = (int64_t)Bg * C * HW;
+    if (vec) {
+        const int w = 4;                                             // 4 consecutive elements of one plane per thread
+        const int64_t nv = total / w;
+        for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += (int64_t)gridDim.x * 256) {
+            const int64_t i = iv * w;
+            const int c = (int)((i / HW) % C);
+            const int gc = (int)(i / group_elems) * C + c;
+            const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
+            const float k1 = sum_dz[gc] * inv_n, k2 = sum_dz_xhat[gc] * inv_n;
+#pragma unroll
+            for (int j = 0; j < w; ++j) {
+                const float xh = (vs_ld(x, xd, i + j) - mu) * is;
+                const float dz = vs_ld(dy, dyd, i + j) * act_grad_from_pre(xh * g + bt, act);
+                vs_st(dx, dxd, i + j, training ? g * is * (dz - k1 - xh * k2) : g * is * dz);
+            }
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)((i / HW) % C);
         const int gc = (int)(i / group_elems) * C + c;
@@ -224,8 +317,9 @@ extern "C" int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW,
     VS_CHECK_ARG(x && mean && invstd && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_stats: bad argument");
     VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "vs_bn_stats: running_mean/var must come together");
     VS_CHECK_ARG(!running_mean || var_scratch, "vs_bn_stats: var_scratch [groups*C] is needed to update running statistics");
+    const int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups), dim3(256), 0, (hipStream_t)stream, x, x_dtype, B / groups, C, HW, mean, invstd,
-                       running_mean ? var_scratch : nullptr, eps);
+                       running_mean ? var_scratch : nullptr, eps, vec);
     VS_CHECK_LAUNCH("vs_bn_stats");
     if (running_mean) {
         hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, var_scratch, groups, C, running_mean,
@@ -239,8 +333,9 @@ extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, c
                              const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream) {
     VS_CHECK_ARG(x && y && mean && invstd && gamma && beta && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_act_fwd: bad argument");
     const int64_t total = (int64_t)B * C * HW;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
-                       gamma, beta, act, C, HW, total, (int64_t)(B / groups) * C * HW);
+    const int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
+                       gamma, beta, act, C, HW, total, (int64_t)(B / groups) * C * HW, vec);
     VS_CHECK_LAUNCH("vs_bn_act_fwd");
     return VS_OK;
 }
@@ -250,12 +345,13 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
                              int dx_dtype, int B, int C, int64_t HW, void* stream) {
     VS_CHECK_ARG(dy && x && mean && invstd && gamma && beta && dgamma && dbeta && dx && B > 0 && C > 0 && HW > 0 && groups >= 1 &&
                      B % groups == 0, "vs_bn_act_bwd: bad argument");
+    const int vec = (HW % 8 == 0);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd, gamma,
-                       beta, act, B / groups, C, HW, dbeta, dgamma);
+                       beta, act, B / groups, C, HW, dbeta, dgamma, vec);
     VS_CHECK_LAUNCH("vs_bn_act_bwd reduce");
     const int64_t total = (int64_t)B * C * HW;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd,
-                       gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, HW, total, training);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd,
+                       gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, HW, total, training, vec);
     VS_CHECK_LAUNCH("vs_bn_act_bwd apply");
     return VS_OK;
 }
