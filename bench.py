@@ -179,11 +179,20 @@ def main():
         else:
             ach = rec['bytes'] / (rec['ms'] * 1e-3) / 1e9
             base.update({'bound': 'hbm', 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(ach / 8000.0, 4)})
+        if name in traffic:
+            base['traffic'] = round(traffic[name]['bytes_per_launch'])
+            base['traffic_source'] = 'profiles/r01_waveeq_bf16_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)'
         if 'rollout' in name:
             base['note'] = ('sequential recurrence: (n-1)*n_blocks*3 dependent 16-row GEMMs per slab, bound by per-CU L2 '
                             'weight streaming and barrier latency, not by MFMA rate (SURVEY.md H3)')
         return base
     sampled = len([i for i in range(args.steps) if i % 4 == 3 or args.steps < 8])
+    # HBM-side traffic per launch from the committed rocprofv3 --pmc passes (collected separately: PMC passes cannot
+    # run inside the timed region); only attached for the default workload they were measured on
+    traffic = {}
+    tpath = os.path.join(ROOT, 'profiles', 'r01_waveeq_bf16_traffic.json')
+    if args.config == 'waveeq' and args.precision == 'bf16' and cfg['batch'] == 128 and os.path.exists(tpath):
+        traffic = json.load(open(tpath))
     roof, others = None, []
     if prof:
         ranked = sorted(prof.items(), key=lambda kv: -kv[1]['ms'])
