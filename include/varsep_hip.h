@@ -116,6 +116,17 @@ int vs_colsum(const void* X, int x_dtype, int64_t ldx, int64_t M, int64_t N, flo
 int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const int64_t* ldx, const int64_t* M, const int64_t* N,
                     float* const* out, float* zero_base, int64_t zero_count, void* stream);
 
+/* Fused frame losses (train.py:85-86 ae_loss MSE and train.py:139 forecast MSE in one pass over the decoded frames).
+ * frames [B, G, D] fp32: per sample the auto-encoding reconstruction (g = 0) followed by the G-1 forecasts; full [B, T, D]
+ * fp32: every observed frame; idx [G] int32 ON THE DEVICE: frame g is compared with full[:, idx[g]].
+ *   fwd: sums[0] = sum of squared errors of frame 0, sums[1] = of frames 1..G-1 (float atomics: last-bit nondeterminism).
+ *   bwd: dframes[b, g, :] = coef[g == 0 ? 0 : 1] * (frames - target); coef [2] on the device = 2/N_k times the upstream
+ *        gradient of loss k, so no host synchronisation is needed.  D must make rows 16-byte aligned for speed.          */
+int vs_frames_sse_fwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D, float* sums,
+                      void* stream);
+int vs_frames_sse_bwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D, const float* coef,
+                      float* dframes, void* stream);
+
 /* dz[i] = dy[i] * act'(y[i]) evaluated from the activation OUTPUT y (see vs_gemm mask semantics).
  * Backward of the trailing activation of a chain (mlp_encdec.py:49 last_activation, conv.py:230).  */
 int vs_act_bwd(const void* dy, int dy_dtype, const void* y, int y_dtype, void* dz, int dz_dtype, int act,

@@ -87,6 +87,8 @@ SIGNATURES = {
     'vs_copy2d': (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp]),
     'vs_colsum': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     'vs_colsum_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'vs_frames_sse_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp]),
+    'vs_frames_sse_bwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp]),
     'vs_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     'vs_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     'vs_conv_wgrad_workspace_bytes': (_sz, [_i32] * 7),

@@ -115,7 +115,84 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumJobs J) {
     if (g == 0 && n < N) atomicAdd(J.out[j] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
 }
 
+// ---- fused frame losses: sum of squared errors of every decoded frame against its target frame ------------------------------
+// frames [B, G, D] fp32 (G frames per sample: the auto-encoding reconstruction followed by the n forecasts), full [B, T, D]
+// fp32 (all observed frames), idx[g] = index of the frame of `full` that frame g is compared with (device array, so the
+// random auto-encoding target can change without re-recording a graph).  sums[0] = SSE of frame 0 (ae_loss, train.py:85-86),
+// sums[1] = SSE of frames 1.. (forecast loss, train.py:139).
+__global__ __launch_bounds__(256) void frames_sse_kernel(const float* frames, const float* full, const int* idx, int64_t rows, int G, int T,
+                                                         int64_t D, float* sums) {
+    __shared__ float red[2][4];
+    float s0 = 0.f, s1 = 0.f;                      // frame 0 / frames 1..
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {       // each workgroup walks many (sample, frame) rows:
+        const int g = (int)(r % G);                                 // two atomics per workgroup, not per row
+        const int64_t b = r / G;
+        const float* f = frames + r * D;
+        const float* t = full + (b * T + idx[g]) * D;
+        float s = 0.f;
+        for (int64_t i = (int64_t)threadIdx.x * 4; i + 3 < D; i += 1024) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(f + i), c = *reinterpret_cast<const f32x4*>(t + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = a[j] - c[j]; s += d * d; }
+        }
+        if (threadIdx.x == 0)
+            for (int64_t i = D & ~(int64_t)3; i < D; ++i) { const float d = f[i] - t[i]; s += d * d; }
+        if (g == 0) s0 += s; else s1 += s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o, 64); s1 += __shfl_down(s1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(sums + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// dframes[b,g,:] = coef[g == 0 ? 0 : 1] * (frames[b,g,:] - full[b,idx[g],:]);  coef on the device (2/N times the upstream gradient)
+__global__ __launch_bounds__(256) void frames_sse_bwd_kernel(const float* frames, const float* full, const int* idx, int G, int T, int64_t D,
+                                                             const float* coef, float* dframes) {
+    const int g = blockIdx.y % G;
+    const int64_t b = blockIdx.y / G;
+    const float k = coef[g == 0 ? 0 : 1];
+    const float* f = frames + (b * G + g) * D;
+    const float* t = full + (b * T + idx[g]) * D;
+    float* o = dframes + (b * G + g) * D;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < D; i += (int64_t)gridDim.x * 1024) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(f + i), c = *reinterpret_cast<const f32x4*>(t + i);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = k * (a[j] - c[j]);
+        *reinterpret_cast<f32x4*>(o + i) = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = D & ~(int64_t)3; i < D; ++i) o[i] = k * (f[i] - t[i]);
+}
+
 }  // namespace
+
+extern "C" int vs_frames_sse_fwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D, float* sums,
+                                 void* stream) {
+    VS_CHECK_ARG(frames && full && idx && sums && B > 0 && G > 0 && T > 0 && D > 0, "vs_frames_sse_fwd: bad argument");
+    if (hipMemsetAsync(sums, 0, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_frames_sse_fwd: memset failed");
+    int64_t wgs = B * G;
+    if (wgs > 1024) wgs = 1024;
+    hipLaunchKernelGGL(frames_sse_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, frames, full, idx, B * G, G, T, D, sums);
+    VS_CHECK_LAUNCH("vs_frames_sse_fwd");
+    return VS_OK;
+}
+
+extern "C" int vs_frames_sse_bwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D, const float* coef,
+                                 float* dframes, void* stream) {
+    VS_CHECK_ARG(frames && full && idx && coef && dframes && B > 0 && G > 0 && T > 0 && D > 0, "vs_frames_sse_bwd: bad argument");
+    unsigned gx = (unsigned)((D / 4 + 255) / 256);
+    if (gx > 8) gx = 8;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(frames_sse_bwd_kernel, dim3(gx, (unsigned)(B * G)), dim3(256), 0, (hipStream_t)stream, frames, full, idx, G, T, D, coef,
+                       dframes);
+    VS_CHECK_LAUNCH("vs_frames_sse_bwd");
+    return VS_OK;
+}
 
 extern "C" int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const int64_t* ldx, const int64_t* M, const int64_t* N,
                                float* const* out, float* zero_base, int64_t zero_count, void* stream) {

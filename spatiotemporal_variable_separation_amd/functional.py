@@ -334,3 +334,28 @@ class Activation(torch.autograd.Function):
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         return ops.act_bwd(dy, y, ctx.act, out_dtype=y.dtype), None
+
+
+# ------------------------------------------------------------------------------------------------ fused frame losses
+class FrameLosses(torch.autograd.Function):
+    """(ae_mse, forecast_mse) of a [B, 1+n, D] stack of decoded frames against the frames `full[:, idx[g]]` in one pass.
+
+    Reference: train.py:85-86 (F.mse_loss of the reconstruction) and train.py:139 (F.mse_loss of the forecasts); both are
+    plain means of squared errors, so they are two partial sums of the same kernel.  Backward writes
+    d frames = 2/N_k * upstream_k * (frames - target) directly (no slicing / concatenation gradients to materialise)."""
+
+    @staticmethod
+    def forward(ctx, frames, full, idx):
+        B, G, D = frames.shape
+        sums = ops.frames_sse_fwd(frames, full, idx)
+        ctx.save_for_backward(frames, full, idx)
+        scale = torch.tensor([1.0 / (B * D), 1.0 / (B * max(G - 1, 1) * D)], dtype=torch.float32, device=frames.device)
+        ctx.scale = scale
+        out = sums * scale
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_ae, g_pred):
+        frames, full, idx = ctx.saved_tensors
+        coef = torch.stack([g_ae, g_pred]).float() * (2.0 * ctx.scale)
+        return ops.frames_sse_bwd(frames, full, idx, coef.contiguous()), None, None

@@ -476,3 +476,28 @@ def upsample2_bwd(dy, out_dtype):
     check(_lib.load_library().vs_upsample2_bwd(dy.data_ptr(), dtype_code(dy), dx.data_ptr(), dtype_code(dx), B * C, H2 // 2, W2 // 2,
                                                stream_ptr()), 'vs_upsample2_bwd')
     return dx
+
+
+# ------------------------------------------------------------------------------------------------ fused frame losses
+def frames_sse_fwd(frames, full, idx):
+    """frames [B, G, D] fp32, full [B, T, D] fp32, idx [G] int32 (device) -> sums [2] (frame 0; frames 1..)."""
+    require_cuda(frames, full, idx)
+    assert frames.is_contiguous() and full.is_contiguous() and frames.dtype == torch.float32 and full.dtype == torch.float32
+    B, G, D = frames.shape
+    sums = torch.empty((2,), dtype=torch.float32, device=frames.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_frames_sse_fwd(frames.data_ptr(), full.data_ptr(), idx.data_ptr(), B, G, full.shape[1], D,
+                                                sums.data_ptr(), stream_ptr()), 'vs_frames_sse_fwd')
+    _pe(e0, 'vs_frames_sse_fwd', nbytes=float(2 * frames.numel() * 4))
+    return sums
+
+
+def frames_sse_bwd(frames, full, idx, coef):
+    require_cuda(frames, full, idx, coef)
+    B, G, D = frames.shape
+    out = torch.empty_like(frames)
+    e0 = _pb()
+    check(_lib.load_library().vs_frames_sse_bwd(frames.data_ptr(), full.data_ptr(), idx.data_ptr(), B, G, full.shape[1], D,
+                                                coef.data_ptr(), out.data_ptr(), stream_ptr()), 'vs_frames_sse_bwd')
+    _pe(e0, 'vs_frames_sse_bwd', nbytes=float(3 * frames.numel() * 4))
+    return out

@@ -38,6 +38,22 @@ def ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=None):
     return loss, s_code_new, s_code_old
 
 
+_frame_index_cache = {}
+
+
+def _frame_index(ae_frame, first_forecast, n, device, n_frames):
+    """Device-resident [ae target frame, forecast target frames...] index vector.  One table holding the row for every
+    possible auto-encoding frame is built once; picking a row is a view, so the training step never does a host-to-device
+    copy (which would synchronise the stream) when the random window moves."""
+    key = (first_forecast, n, n_frames, str(device))
+    table = _frame_index_cache.get(key)
+    if table is None:
+        rows = [[a] + list(range(first_forecast, first_forecast + n)) for a in range(n_frames)]
+        table = torch.tensor(rows, dtype=torch.int32, device=device)
+        _frame_index_cache[key] = table
+    return table[ae_frame]
+
+
 def _mlp_family(sep_net):
     from .networks.mlp_encdec import MLPEncoder, MLPDecoder
     from .networks.resnet import MLPResnet
@@ -55,6 +71,7 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     weight-streaming GEMMs (E_s/E_t first layers are 98 MB of weights each) and leaves one gradient per parameter
     (no accumulation passes)."""
     from .networks.utils import ConstantS
+    from . import functional as VF
     full_data = torch.cat([cond, target], dim=1)
     B, T = full_data.shape[0], full_data.shape[1]
     flat = full_data.reshape(B, T, -1)
@@ -76,11 +93,13 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     n = nt_pred + offset
     t_codes, _ = sep_net.t_resnet.rollout(t0, n)
     frames = sep_net.decoder.decode_sequence(s_old, torch.cat([t_rand.unsqueeze(1), t_codes], dim=1))   # [B, 1+n, ...]
-    reconstruction, forecasts = frames[:, 0], frames[:, 1:]
+    forecasts = frames[:, 1:]
 
-    ae_loss_value = F.mse_loss(full_data[:, t_random - offset], reconstruction, reduction='mean')
+    # both frame losses in one fused pass: frame 0 vs full[:, t_random - offset], frame g vs full[:, fo + g - 1]
+    fo = nt_cond if offset == 0 else 0
+    idx = _frame_index(int(t_random) - offset, fo, n, frames.device, T)
+    ae_loss_value, forecast_loss = VF.FrameLosses.apply(frames.reshape(B, 1 + n, -1), flat.contiguous(), idx)
     spatial_ode_loss = (s_old - s_new).pow(2).mean()
-    forecast_loss = F.mse_loss(forecasts, full_data[:, (nt_cond if offset == 0 else 0):])
     if average_tloss:
         t_reg = 0.5 * (t_codes[:, 0].pow(2).view(B, -1)).mean()
     else:
