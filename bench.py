@@ -29,6 +29,7 @@ def parse():
     p.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     p.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
     p.add_argument('--no_cpu_baseline', action='store_true')
+    p.add_argument('--no_graph', action='store_true', help='issue every kernel from Python instead of replaying a hipGraph')
     p.add_argument('--cpu_steps', type=int, default=None)
     return p.parse_args()
 
@@ -117,7 +118,9 @@ def main():
     if world > 1:
         broadcast_module_state(net)
     sync = GradAllReducer(net.parameters()) if world > 1 else None
-    opt = torch.optim.Adam(net.parameters(), lr=4e-4, betas=(0.9, 0.99), fused=True)
+    from spatiotemporal_variable_separation_amd.train import GraphedStep, _mlp_family
+    use_graph = (not args.no_graph) and world == 1 and _mlp_family(net)
+    opt = torch.optim.Adam(net.parameters(), lr=4e-4, betas=(0.9, 0.99), fused=True, capturable=use_graph)
     cond, target = synthetic_batch(cfg['data'], cfg['batch'], cfg['nt_cond'], cfg['nt_pred'], device=dev,
                                    seed=1234 + rank)
     lam = cfg['lambdas']
@@ -204,7 +207,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': f'{args.config}: {cfg["architecture"]} enc/dec, batch {cfg["batch"]}/GPU, '
                                f'nt_cond {cfg["nt_cond"]}, nt_pred {cfg["nt_pred"]}, offset {cfg["offset"]}',
-                   'global_batch': world * cfg['batch'], 'parallelism': f'dp{world}', 'optimizer': 'Adam (torch fused)',
+                   'global_batch': world * cfg['batch'], 'parallelism': f'dp{world}', 'optimizer': 'Adam (torch fused)', 'launch': 'hipGraph replay' if use_graph else 'eager',
                    'final_loss': round(float(loss.item()), 5)},
         'roofline': roof, 'roofline_others': others,
     }

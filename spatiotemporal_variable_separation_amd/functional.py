@@ -349,13 +349,11 @@ class FrameLosses(torch.autograd.Function):
         B, G, D = frames.shape
         sums = ops.frames_sse_fwd(frames, full, idx)
         ctx.save_for_backward(frames, full, idx)
-        scale = torch.tensor([1.0 / (B * D), 1.0 / (B * max(G - 1, 1) * D)], dtype=torch.float32, device=frames.device)
-        ctx.scale = scale
-        out = sums * scale
-        return out[0], out[1]
+        ctx.scale = (1.0 / (B * D), 1.0 / (B * max(G - 1, 1) * D))      # python floats: nothing is copied from the host
+        return sums[0] * ctx.scale[0], sums[1] * ctx.scale[1]
 
     @staticmethod
     def backward(ctx, g_ae, g_pred):
         frames, full, idx = ctx.saved_tensors
-        coef = torch.stack([g_ae, g_pred]).float() * (2.0 * ctx.scale)
-        return ops.frames_sse_bwd(frames, full, idx, coef.contiguous()), None, None
+        coef = torch.stack([g_ae.float() * (2.0 * ctx.scale[0]), g_pred.float() * (2.0 * ctx.scale[1])])
+        return ops.frames_sse_bwd(frames, full, idx, coef), None, None

@@ -113,7 +113,7 @@ def main(argv=None):
         broadcast_module_state(sep_net)
         grad_sync = GradAllReducer(sep_net.parameters())
 
-    optimizer = optim.Adam(sep_net.parameters(), lr=args.lr, betas=(args.beta1, args.beta2))
+    optimizer = optim.Adam(sep_net.parameters(), lr=args.lr, betas=(args.beta1, args.beta2), capturable=bool(args.hip_graph))
     scheduler = lr_scheduler.MultiStepLR(optimizer, args.scheduler_milestones, gamma=args.scheduler_decay) \
         if args.scheduler else None
 
@@ -121,7 +121,7 @@ def main(argv=None):
     train(args.xp_dir if rank == 0 else os.path.join(args.xp_dir, f'rank{rank}'), train_loader, device, sep_net,
           optimizer, scheduler, args.apex_amp, args.torch_amp, args.epochs, args.lamb_ae, args.lamb_s, args.lamb_t,
           args.lamb_pred, args.offset, args.nt_cond, args.nt_pred, args.no_s, args.skipco, args.chkpt_interval,
-          args.architecture == 'encoderSST', grad_sync=grad_sync, log_interval=args.log_interval)
+          args.architecture == 'encoderSST', grad_sync=grad_sync, log_interval=args.log_interval, hip_graph=args.hip_graph)
 
 
 if __name__ == "__main__":

@@ -51,7 +51,7 @@ def _frame_index(ae_frame, first_forecast, n, device, n_frames):
         rows = [[a] + list(range(first_forecast, first_forecast + n)) for a in range(n_frames)]
         table = torch.tensor(rows, dtype=torch.int32, device=device)
         _frame_index_cache[key] = table
-    return table[ae_frame]
+    return table if ae_frame is None else table[ae_frame]
 
 
 def _mlp_family(sep_net):
@@ -69,12 +69,18 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     E_s on [first window; last window], E_t on [random window; conditioning window], D on [the auto-encoding row
     block; every rollout step].  The MLP family has no BatchNorm, so stacking rows is exact; it halves the number of
     weight-streaming GEMMs (E_s/E_t first layers are 98 MB of weights each) and leaves one gradient per parameter
-    (no accumulation passes)."""
+    (no accumulation passes).
+
+    `t_random` may be a python int (drawn on the host like the reference) or an int32 CUDA tensor of one element: in that
+    case every use of it happens on the device (window gather with a device-side offset, target lookup by index_select),
+    so the whole step can be recorded once into a hipGraph and replayed while the random window moves."""
     from .networks.utils import ConstantS
-    from . import functional as VF
+    from . import functional as VF, ops
     full_data = torch.cat([cond, target], dim=1)
     B, T = full_data.shape[0], full_data.shape[1]
     flat = full_data.reshape(B, T, -1)
+    D = flat.shape[2]
+    on_device = isinstance(t_random, torch.Tensor)
     if t_random is None:
         t_random = np.random.randint(nt_cond, T) if offset == 0 else np.random.randint(nt_cond, T + 1)
 
@@ -87,7 +93,15 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     else:
         s_both = sep_net.Es.mlp(torch.cat([window(nt_cond), window(T)], dim=0))
         s_old, s_new = s_both[:B], s_both[B:]
-    t_both = sep_net.Et.mlp(torch.cat([window(t_random), window(nt_cond)], dim=0))
+    if on_device:
+        # rows [0, B): full[:, t - nt_cond : t] cut out by a kernel that reads t on the device; rows [B, 2B): the conditioning window
+        x_et = torch.empty((2 * B, nt_cond * D), dtype=VF.compute_dtype(), device=flat.device)
+        ops.copy2d(flat, B, nt_cond * D, T * D, x_et, nt_cond * D, col_offset_dev=t_random, col_offset_scale=D,
+                   src_elem_offset=-nt_cond * D)
+        ops.copy2d(flat, B, nt_cond * D, T * D, x_et[B:], nt_cond * D)
+    else:
+        x_et = torch.cat([window(t_random), window(nt_cond)], dim=0)
+    t_both = sep_net.Et.mlp(x_et)
     t_rand, t0 = t_both[:B], t_both[B:]
 
     n = nt_pred + offset
@@ -97,7 +111,10 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
 
     # both frame losses in one fused pass: frame 0 vs full[:, t_random - offset], frame g vs full[:, fo + g - 1]
     fo = nt_cond if offset == 0 else 0
-    idx = _frame_index(int(t_random) - offset, fo, n, frames.device, T)
+    if on_device:
+        idx = torch.index_select(_frame_index(None, fo, n, frames.device, T + 1), 0, (t_random - offset).long()).view(-1)
+    else:
+        idx = _frame_index(int(t_random) - offset, fo, n, frames.device, T + 1)
     ae_loss_value, forecast_loss = VF.FrameLosses.apply(frames.reshape(B, 1 + n, -1), flat.contiguous(), idx)
     spatial_ode_loss = (s_old - s_new).pow(2).mean()
     if average_tloss:
@@ -107,6 +124,60 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     total_loss = lamb_ae * ae_loss_value + lamb_s * spatial_ode_loss + lamb_pred * forecast_loss + lamb_t * t_reg
     terms = {'ae': ae_loss_value, 'zero': spatial_ode_loss, 'pred': forecast_loss, 't_reg': t_reg}
     return total_loss, terms, forecasts, t_codes
+
+
+class GraphedStep:
+    """One whole optimisation step (losses, backward, Adam) of an MLP-family model recorded into a hipGraph and replayed.
+
+    The step launches ~110 kernels of 2-800 us; issued one by one from Python the host needs ~3.9 ms per step, more than the
+    GPU needs to execute them, so the eager loop is host-bound.  Stream capture (torch.cuda.CUDAGraph = hipGraph on ROCm)
+    records the kernels the C-ABI library launches on the capture stream together with torch's own; the only per-step host
+    inputs -- the batch and the random window end `t_random` (train.py:72-75) -- enter through static device buffers, and
+    every use of `t_random` inside the step is device-side.  Requires Adam(capturable=True)."""
+
+    def __init__(self, sep_net, optimizer, cond, target, nt_cond, nt_pred, offset, lambdas, average_tloss=False, warmup=3):
+        assert cond.is_cuda and _mlp_family(sep_net), 'GraphedStep supports the MLP family on a GPU'
+        self.net, self.opt = sep_net, optimizer
+        self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
+        self.cond, self.target = cond.clone(), target.clone()
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=cond.device)
+        self.t_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.T = cond.shape[1] + target.shape[1]
+        self.nt_cond, self.offset = nt_cond, offset
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._draw()
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        self._draw()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+
+    def _draw(self):
+        hi = self.T if self.offset == 0 else self.T + 1
+        self.t_host[0] = int(np.random.randint(self.nt_cond, hi))
+        self.t_dev.copy_(self.t_host, non_blocking=True)
+
+    def _body(self):
+        nt_cond, nt_pred, offset, l_ae, l_s, l_t, l_pred, avg = self.args
+        self.opt.zero_grad(set_to_none=True)
+        total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
+                                                     l_pred, avg, self.t_dev)
+        total.backward()
+        self.opt.step()
+        return total.detach()
+
+    def step(self, cond=None, target=None):
+        """Replay one optimisation step; new batches are copied into the static input buffers first."""
+        if cond is not None:
+            self.cond.copy_(cond, non_blocking=True)
+            self.target.copy_(target, non_blocking=True)
+        self._draw()
+        self.graph.replay()
+        return self.loss
 
 
 def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb_ae, lamb_s, lamb_t, lamb_pred,
@@ -135,11 +206,12 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
 
 def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_amp, use_torch_amp, epochs, lamb_ae,
           lamb_s, lamb_t, lamb_pred, offset, nt_cond, nt_pred, no_s, skipco, chkpt_interval, average_tloss,
-          grad_sync=None, log_interval=None):
+          grad_sync=None, log_interval=None, hip_graph=False):
     """Same 20 positional arguments as the reference's `train` (train.py:91-92).
 
     Additive keyword arguments: `grad_sync` (a `parallel.GradAllReducer`, data-parallel gradient averaging over
-    RCCL) and `log_interval` (print losses / frames-per-second every N steps).  `use_apex_amp` is rejected (no
+    RCCL), `log_interval` (print losses / frames-per-second every N steps) and `hip_graph` (MLP family, single GPU: record
+    the whole step once into a hipGraph -- `GraphedStep` -- and replay it; the optimizer must be Adam(capturable=True)).  `use_apex_amp` is rejected (no
     Apex on the MI355X path); `use_torch_amp` selects the bf16 compute mode, which needs no loss scaler.
     """
     import time
@@ -154,11 +226,25 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
     assert offset == nt_cond or offset == 0
 
     step, t_last = 0, time.time()
+    graphed = None
     try:
         for epoch in range(epochs):
             sep_net.train()
             for cond, target in train_loader:
                 cond, target = cond.to(device, non_blocking=True), target.to(device, non_blocking=True)
+                if hip_graph and grad_sync is None and _mlp_family(sep_net):
+                    if graphed is None:
+                        graphed = GraphedStep(sep_net, optimizer, cond, target, nt_cond, nt_pred, offset,
+                                              (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss)
+                    if cond.shape == graphed.cond.shape:
+                        total_loss = graphed.step(cond, target)
+                        step += 1
+                        if log_interval and step % log_interval == 0:
+                            torch.cuda.synchronize()
+                            dt, t_last = time.time() - t_last, time.time()
+                            print(f'epoch {epoch} step {step}: total {total_loss.item():.5f} | '
+                                  f'{log_interval * cond.shape[0] * nt_pred / dt:.0f} frames/s (hipGraph)')
+                        continue                     # a ragged last batch falls through to the eager path below
                 if grad_sync is not None:
                     grad_sync.zero_grad()            # gradients are views into flat all-reduce buckets
                 else:

@@ -53,3 +53,52 @@ def test_step_fp32_unfused_structure_matches_oracle(name):
     frame, separate E_s/E_t calls); it must give the same numbers as the batched fast path."""
     cfg = CONFIGS[name]
     compare_step(cfg, int(load_golden(name)['t_random']), 'fp32', tol_out=1e-3, tol_grad=1e-3, fused=False)
+
+
+def test_graphed_step_equals_eager_steps():
+    """train.GraphedStep (whole step recorded into a hipGraph, device-side t_random) == the eager loop, step for step."""
+    import numpy as np
+    import torch
+    from oracle import cpu_ref
+    from oracle.detdata import det_fill
+    from oracle.golden_configs import make_batch
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.train import GraphedStep, compute_losses
+    cfg = CONFIGS['mlp_mul']
+    lam = cfg['lambdas']
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    o_net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+
+    def fresh():
+        net = build_sep_net(cfg)
+        net.load_state_dict(o_net.state_dict())
+        return net.cuda().train()
+    with VF.precision('fp32'):
+        # eager reference with the same NumPy stream: 3 warm-up steps, one draw consumed by the capture (stream capture
+        # records kernels without executing them, so it is not an optimisation step), then 4 replayed steps
+        net_e = fresh()
+        opt_e = torch.optim.Adam(net_e.parameters(), lr=1e-3)
+        np.random.seed(7)
+        losses_e = []
+        hi = cfg['nt_cond'] + cfg['nt_pred'] + (0 if cfg['offset'] == 0 else 1)
+        for it in range(7):
+            if it == 3:
+                np.random.randint(cfg['nt_cond'], hi)
+            opt_e.zero_grad()
+            total = compute_losses(cond, target, net_e, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], False, lam['ae'], lam['s'],
+                                   lam['t'], lam['pred'])[0]
+            total.backward()
+            opt_e.step()
+            losses_e.append(total.item())
+        net_g = fresh()
+        opt_g = torch.optim.Adam(net_g.parameters(), lr=1e-3, capturable=True)
+        np.random.seed(7)
+        g = GraphedStep(net_g, opt_g, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'],
+                        (lam['ae'], lam['s'], lam['t'], lam['pred']), warmup=3)
+        losses_g = [g.step().item() for _ in range(4)]
+    torch.cuda.synchronize()
+    assert np.allclose(losses_g, losses_e[3:], rtol=2e-4), (losses_g, losses_e)
+    for (k, a), (_, b) in zip(net_g.state_dict().items(), net_e.state_dict().items()):
+        assert torch.allclose(a, b, rtol=2e-3, atol=2e-5), k
