@@ -40,6 +40,56 @@ def compute_dtype():
     return torch.float32 if _STATE['precision'] == 'fp32' else torch.bfloat16
 
 
+# ------------------------------------------------------------------------------------------------ side streams
+# Two kinds of work are off the critical path of a training step and run on side HIP streams when enabled:
+#   * weight/bias gradients (every wgrad GEMM, column sum): only the optimizer consumes them, so they are launched on
+#     a dedicated stream behind an event and joined by `join_side_streams()` right before the optimizer step;
+#   * the latent rollout (a 32-workgroup persistent kernel that leaves 7/8 of the chip idle): its forward overlaps the
+#     E_s encoder, its backward overlaps the decoder/encoder weight gradients.
+# Only valid when every parameter receives ONE gradient per step (the batched MLP-family step) and without hook-driven
+# gradient all-reduce; `train._compute_losses_mlp_batched` / `GraphedStep` switch it on, everything else leaves it off.
+_SIDE = {'on': False, 'wgrad': None, 'rollout': None}
+
+
+def enable_side_streams(flag):
+    _SIDE['on'] = bool(flag)
+
+
+def side_streams_enabled():
+    return _SIDE['on']
+
+
+def _side_stream(name):
+    if _SIDE[name] is None:
+        _SIDE[name] = torch.cuda.Stream()
+    return _SIDE[name]
+
+
+def run_deferred(fn, *inputs):
+    """Run `fn()` (weight-gradient launches) on the wgrad stream behind everything queued so far on the current stream."""
+    if not _SIDE['on']:
+        return fn()
+    main, ws = torch.cuda.current_stream(), _side_stream('wgrad')
+    ws.wait_stream(main)
+    for t in inputs:
+        t.record_stream(ws)
+    with torch.cuda.stream(ws):
+        out = fn()
+    outs = out if isinstance(out, (list, tuple)) else [out]
+    for t in outs:
+        if isinstance(t, torch.Tensor):
+            t.record_stream(main)
+    return out
+
+
+def join_side_streams():
+    """Make the current stream wait for all deferred gradient work (call before the optimizer step)."""
+    if _SIDE['wgrad'] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE['wgrad'])
+    if _SIDE['rollout'] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE['rollout'])
+
+
 # ------------------------------------------------------------------------------------------------ weight shadows
 _shadow = {}
 
@@ -122,8 +172,8 @@ class MLPChain(torch.autograd.Function):
             W, b = params[2 * l], params[2 * l + 1]
             N, K = W.shape
             h_in = saved[l]
-            if W.requires_grad:
-                grads[2 * l] = ops.gemm(dz, S, h_in, S, N, K, M)                      # dW = dz^T h_in  (fp32)
+            if W.requires_grad:               # dW = dz^T h_in (fp32); off the critical path -> wgrad stream when enabled
+                grads[2 * l] = run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K: ops.gemm(dz, S, h_in, S, N, K, M), dz, h_in)
             if b is not None and b.requires_grad:
                 bias_jobs.append((2 * l + 1, dz))
             if l > 0:
@@ -133,7 +183,8 @@ class MLPChain(torch.autograd.Function):
             elif ctx.x_needs_grad:
                 dx = ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=torch.float32)
         if bias_jobs:
-            for (slot, _), db in zip(bias_jobs, ops.colsum_multi([dz_l for _, dz_l in bias_jobs])):
+            dzs = [dz_l for _, dz_l in bias_jobs]
+            for (slot, _), db in zip(bias_jobs, run_deferred(lambda: ops.colsum_multi(dzs), *dzs)):
                 grads[slot] = db
         return (dx, None) + tuple(grads)
 
@@ -202,15 +253,19 @@ class MLPRollout(torch.autograd.Function):
         rows = (n_steps - 1) * B
         if rows == 0:
             return (dx0, None) + tuple(torch.zeros_like(p) for p in params)
-        grads, bias_jobs = [], []
-        for b in range(nb):
-            dh1b, dh2b, drb = dh1[b].view(rows, H), dh2[b].view(rows, H), dr[b].view(rows, C)
-            xb, h1b, h2b = xin[b].view(rows, C), h1[b].view(rows, H), h2[b].view(rows, H)
-            grads += [ops.gemm(dh1b, S, xb, S, H, C, rows), None, ops.gemm(dh2b, S, h1b, S, H, H, rows), None,
-                      ops.gemm(drb, S, h2b, S, C, H, rows), None]
-            bias_jobs += [dh1b, dh2b, drb]
-        for i, db in enumerate(ops.colsum_multi(bias_jobs)):
-            grads[2 * i + 1] = db
+
+        def weight_grads():
+            grads, bias_jobs = [], []
+            for b in range(nb):
+                dh1b, dh2b, drb = dh1[b].view(rows, H), dh2[b].view(rows, H), dr[b].view(rows, C)
+                xb, h1b, h2b = xin[b].view(rows, C), h1[b].view(rows, H), h2[b].view(rows, H)
+                grads += [ops.gemm(dh1b, S, xb, S, H, C, rows), None, ops.gemm(dh2b, S, h1b, S, H, H, rows), None,
+                          ops.gemm(drb, S, h2b, S, C, H, rows), None]
+                bias_jobs += [dh1b, dh2b, drb]
+            for i, db in enumerate(ops.colsum_multi(bias_jobs)):
+                grads[2 * i + 1] = db
+            return grads
+        grads = run_deferred(weight_grads, dr, dh2, dh1, xin, h1, h2)
         return (dx0, None) + tuple(grads)
 
 

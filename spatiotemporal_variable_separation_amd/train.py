@@ -87,12 +87,12 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     def window(end):
         return flat[:, end - nt_cond:end].reshape(B, -1)
 
-    if isinstance(sep_net.Es, ConstantS):
-        s_old = sep_net.Es(full_data[:, :nt_cond])
-        s_new = sep_net.Es(full_data[:, -nt_cond:])
-    else:
+    def spatial_codes():
+        if isinstance(sep_net.Es, ConstantS):
+            return sep_net.Es(full_data[:, :nt_cond]), sep_net.Es(full_data[:, -nt_cond:])
         s_both = sep_net.Es.mlp(torch.cat([window(nt_cond), window(T)], dim=0))
-        s_old, s_new = s_both[:B], s_both[B:]
+        return s_both[:B], s_both[B:]
+
     if on_device:
         # rows [0, B): full[:, t - nt_cond : t] cut out by a kernel that reads t on the device; rows [B, 2B): the conditioning window
         x_et = torch.empty((2 * B, nt_cond * D), dtype=VF.compute_dtype(), device=flat.device)
@@ -105,7 +105,20 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     t_rand, t0 = t_both[:B], t_both[B:]
 
     n = nt_pred + offset
-    t_codes, _ = sep_net.t_resnet.rollout(t0, n)
+    if VF.side_streams_enabled():
+        # the rollout (32 workgroups) runs on its own stream while E_s uses the rest of the chip; autograd replays the same
+        # stream assignment in backward, where the rollout overlaps the encoder/decoder weight gradients
+        main, side = torch.cuda.current_stream(), VF._side_stream('rollout')
+        side.wait_stream(main)
+        t0.record_stream(side)
+        with torch.cuda.stream(side):
+            t_codes, _ = sep_net.t_resnet.rollout(t0, n)
+        s_old, s_new = spatial_codes()
+        main.wait_stream(side)
+        t_codes.record_stream(main)
+    else:
+        s_old, s_new = spatial_codes()
+        t_codes, _ = sep_net.t_resnet.rollout(t0, n)
     frames = sep_net.decoder.decode_sequence(s_old, torch.cat([t_rand.unsqueeze(1), t_codes], dim=1))   # [B, 1+n, ...]
     forecasts = frames[:, 1:]
 
@@ -135,8 +148,10 @@ class GraphedStep:
     inputs -- the batch and the random window end `t_random` (train.py:72-75) -- enter through static device buffers, and
     every use of `t_random` inside the step is device-side.  Requires Adam(capturable=True)."""
 
-    def __init__(self, sep_net, optimizer, cond, target, nt_cond, nt_pred, offset, lambdas, average_tloss=False, warmup=3):
+    def __init__(self, sep_net, optimizer, cond, target, nt_cond, nt_pred, offset, lambdas, average_tloss=False, warmup=3,
+                 side_streams=True):
         assert cond.is_cuda and _mlp_family(sep_net), 'GraphedStep supports the MLP family on a GPU'
+        self.side_streams = side_streams
         self.net, self.opt = sep_net, optimizer
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
         self.cond, self.target = cond.clone(), target.clone()
@@ -163,10 +178,16 @@ class GraphedStep:
 
     def _body(self):
         nt_cond, nt_pred, offset, l_ae, l_s, l_t, l_pred, avg = self.args
+        from . import functional as VF
         self.opt.zero_grad(set_to_none=True)
-        total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
-                                                     l_pred, avg, self.t_dev)
-        total.backward()
+        VF.enable_side_streams(self.side_streams)
+        try:
+            total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
+                                                         l_pred, avg, self.t_dev)
+            total.backward()
+            VF.join_side_streams()
+        finally:
+            VF.enable_side_streams(False)
         self.opt.step()
         return total.detach()
 
