@@ -92,14 +92,24 @@ def cpu_baseline(cfg, steps):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the result JSON): libraries that print banners to the C-level stdout (RCCL prints its
+    # version block there at communicator creation) are diverted to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    # VARSEP_BENCH_FORCE_DIST=1 runs the data-parallel code path (process group, flat buckets, RCCL all-reduce per step)
+    # at world size 1, so the N>1 path can be exercised on a one-GPU box
+    ddp = world > 1 or os.environ.get('VARSEP_BENCH_FORCE_DIST') == '1'
+    if ddp:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', device_id=dev, rank=rank, world_size=world)
 
     from spatiotemporal_variable_separation_amd import functional as VF, ops
     from spatiotemporal_variable_separation_amd.configs import BASELINE_CONFIGS
@@ -115,11 +125,11 @@ def main():
     np.random.seed(1234)                     # same t_random sequence on every rank
     net = build_sep_net(cfg).to(dev)
     net.train()
-    if world > 1:
+    if ddp:
         broadcast_module_state(net)
-    sync = GradAllReducer(net.parameters()) if world > 1 else None
+    sync = GradAllReducer(net.parameters(), force=(world == 1)) if ddp else None
     from spatiotemporal_variable_separation_amd.train import GraphedStep, _mlp_family
-    use_graph = (not args.no_graph) and world == 1 and _mlp_family(net)
+    use_graph = (not args.no_graph) and _mlp_family(net)
     opt = torch.optim.Adam(net.parameters(), lr=4e-4, betas=(0.9, 0.99), fused=True, capturable=use_graph)
     cond, target = synthetic_batch(cfg['data'], cfg['batch'], cfg['nt_cond'], cfg['nt_pred'], device=dev,
                                    seed=1234 + rank)
@@ -141,33 +151,58 @@ def main():
         return total
 
     def barrier():
-        if world > 1:
+        if ddp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    graphed = None
+    if use_graph:
+        # the timed region replays the recorded step (train.GraphedStep: the same kernels, launched by hipGraphLaunch instead
+        # of ~110 Python-issued launches); with N > 1 ranks: graph(losses + backward) -> bucket all-reduces -> graph(Adam)
+        graphed = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'],
+                              (lam['ae'], lam['s'], lam['t'], lam['pred']), bool(cfg.get('average_tloss')),
+                              warmup=max(1, min(args.warmup, 3)), grad_sync=sync)
+        timed_step = graphed.step
+    else:
+        timed_step = step
     for _ in range(args.warmup):
-        step()
+        timed_step()
     # HIP-event pairs around every vs_* launch of the timed region (events pre-created: ~2 x launches/step x steps)
     events_on = os.environ.get('VARSEP_BENCH_NO_EVENTS') is None
-    ops.profile_reset(enable=events_on, pool=256 * (args.steps // 4 + 8))
+    n_inst = 4                               # instrumented eager steps after a graph-replay timed region
+    ops.profile_reset(enable=events_on and graphed is None, pool=256 * (args.steps // 4 + 8 + n_inst))
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ops._PROF['on'] = events_on and (i % 4 == 3 or args.steps < 8)     # sample every 4th step: keeps host overhead low
-        loss = step()
-    ops._PROF['on'] = events_on
+    if graphed is not None:
+        for i in range(args.steps):
+            loss = graphed.step()
+    else:
+        for i in range(args.steps):
+            ops._PROF['on'] = events_on and (i % 4 == 3 or args.steps < 8)     # sample every 4th step: keeps host overhead low
+            loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    sampled = len([i for i in range(args.steps) if i % 4 == 3 or args.steps < 8])
+    inst_ms = None
+    if graphed is not None and events_on:
+        # per-kernel durations cannot be taken inside a graph replay (events are not recordable there): the same step is
+        # run eagerly a few times afterwards with an event pair around every vs_* launch
+        torch.cuda.synchronize()
+        step()
+        ops.profile_reset(enable=True, pool=256 * (n_inst + 2))
+        for i in range(n_inst):
+            step()
+        torch.cuda.synchronize()
+        sampled = n_inst
     prof = ops.profile_collect()
-    if world > 1:
+    if ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     ms = dt / args.steps * 1e3
     frames = world * cfg['batch'] * cfg['nt_pred']
     if rank != 0:
-        if world > 1:
-            torch.distributed.destroy_process_group()
+        torch.distributed.destroy_process_group()
         return
 
     # roofline position of every instrumented kernel family of the timed region, largest summed event time first;
@@ -189,7 +224,6 @@ def main():
             base['note'] = ('sequential recurrence: (n-1)*n_blocks*3 dependent 16-row GEMMs per slab, bound by per-CU L2 '
                             'weight streaming and barrier latency, not by MFMA rate (SURVEY.md H3)')
         return base
-    sampled = len([i for i in range(args.steps) if i % 4 == 3 or args.steps < 8])
     # HBM-side traffic per launch from the committed rocprofv3 --pmc passes (collected separately: PMC passes cannot
     # run inside the timed region); only attached for the default workload they were measured on
     traffic = {}
@@ -207,7 +241,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': f'{args.config}: {cfg["architecture"]} enc/dec, batch {cfg["batch"]}/GPU, '
                                f'nt_cond {cfg["nt_cond"]}, nt_pred {cfg["nt_pred"]}, offset {cfg["offset"]}',
-                   'global_batch': world * cfg['batch'], 'parallelism': f'dp{world}', 'optimizer': 'Adam (torch fused)', 'launch': 'hipGraph replay' if use_graph else 'eager',
+                   'global_batch': world * cfg['batch'], 'parallelism': f'dp{world}', 'optimizer': 'Adam (torch fused)', 'launch': ('hipGraph replay (per-kernel roofline timings from eager instrumented steps after the timed region)' if use_graph else 'eager'),
                    'final_loss': round(float(loss.item()), 5)},
         'roofline': roof, 'roofline_others': others,
     }
@@ -216,8 +250,8 @@ def main():
         out['cpu_baseline'] = cpu_baseline(cfg, steps)
         out['cpu_baseline']['value'] = round(out['cpu_baseline']['value'], 1)
         out['cpu_baseline']['ms_per_step'] = round(out['cpu_baseline']['ms_per_step'], 1)
-    print(json.dumps(out))
-    if world > 1:
+    os.write(result_fd, (json.dumps(out) + '\n').encode())
+    if ddp:
         torch.distributed.destroy_process_group()
 
 

@@ -30,6 +30,22 @@ int vs_fail(int code, const char* fmt, ...);
         if (e_ != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
     } while (0)
 
+// ---- zero fill as a kernel ----------------------------------------------------------------------------------------
+// hipMemsetAsync recorded into a hipGraph (stream capture) does not reliably re-execute in order on ROCm 7.0: replays of a
+// single-stream capture left accumulator buffers un-zeroed.  A fill kernel is an ordinary kernel node.  `bytes` must be a
+// multiple of 4 and `ptr` 4-byte aligned (every caller zeroes fp32 / 8-byte granule areas).
+static __global__ void vs_zero_kernel(uint32_t* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+static inline hipError_t vs_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(vs_zero_kernel, dim3(blocks), dim3(256), 0, stream, (uint32_t*)ptr, n);
+    return hipGetLastError();
+}
+
 // ---- scalar load/store with dtype dispatch (dtype is wave-uniform) -------------------------------
 __device__ __forceinline__ float vs_ld(const void* p, int dtype, int64_t i) {
     return dtype == VS_F32 ? ((const float*)p)[i] : (float)((const __bf16*)p)[i];

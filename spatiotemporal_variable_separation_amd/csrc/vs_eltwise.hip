@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void frames_sse_bwd_kernel(const float* frames
 extern "C" int vs_frames_sse_fwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D, float* sums,
                                  void* stream) {
     VS_CHECK_ARG(frames && full && idx && sums && B > 0 && G > 0 && T > 0 && D > 0, "vs_frames_sse_fwd: bad argument");
-    if (hipMemsetAsync(sums, 0, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_frames_sse_fwd: memset failed");
+    if (vs_zero_async(sums, 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_frames_sse_fwd: memset failed");
     int64_t wgs = B * G;
     if (wgs > 1024) wgs = 1024;
     hipLaunchKernelGGL(frames_sse_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, frames, full, idx, B * G, G, T, D, sums);
@@ -208,7 +208,7 @@ extern "C" int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dt
         if (M[j] > max_m) max_m = M[j];
     }
     if (zero_base && zero_count > 0) {
-        if (hipMemsetAsync(zero_base, 0, (size_t)zero_count * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        if (vs_zero_async(zero_base, (size_t)zero_count * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return vs_fail(VS_ERR_LAUNCH, "vs_colsum_multi: memset failed");
     }
     dim3 grid((unsigned)J.blk_off[n_jobs], (unsigned)vs_cdiv(max_m, CS_ROWS));
@@ -255,7 +255,7 @@ extern "C" int vs_copy2d(const void* src, int sd, int64_t lds, void* dst, int dd
 extern "C" int vs_colsum(const void* X, int xd, int64_t ldx, int64_t M, int64_t N, float* out, int accumulate, void* stream) {
     VS_CHECK_ARG(X && out && M > 0 && N > 0 && ldx >= N, "vs_colsum: bad argument");
     if (!accumulate) {
-        if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        if (vs_zero_async(out, (size_t)N * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return vs_fail(VS_ERR_LAUNCH, "vs_colsum: memset failed");
     }
     dim3 grid((unsigned)vs_cdiv(N, 64), (unsigned)vs_cdiv(M, CS_ROWS));

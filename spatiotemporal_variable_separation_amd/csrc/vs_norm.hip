@@ -358,7 +358,7 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
 
 extern "C" int vs_chan_sum(const void* x, int x_dtype, int B, int C, int64_t HW, float* out, void* stream) {
     VS_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0, "vs_chan_sum: bad argument");
-    if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_chan_sum: memset failed");
+    if (vs_zero_async(out, (size_t)C * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_chan_sum: memset failed");
     int64_t chunks = ((int64_t)B * HW + 32767) / 32768;
     const int64_t want = (1024 + C - 1) / C;                     // aim at ~1024 workgroups in total
     if (chunks > want) chunks = want;

@@ -290,7 +290,7 @@ __host__ __device__ inline int ksplit_for(int ntiles, int nsteps) {
 // dependence on placement.  Every workgroup sums the P partials in part order, so all P hold bitwise identical
 // results.  Double buffering is sufficient: a workgroup can only publish epoch e+2 (same buffer as e) after it has
 // finished epoch e+1, which needs every peer's e+1 granules, which each peer publishes only after reading epoch e.
-// The area is zeroed by a hipMemsetAsync before every launch (epochs restart at 1).  Spins are bounded: on a timeout
+// The area is zeroed by a fill kernel before every launch (epochs restart at 1).  Spins are bounded: on a timeout
 // the error word is set and the kernel runs on (wrong result, no hang).
 typedef unsigned long long u64;
 
@@ -613,7 +613,7 @@ int launch_roll(bool fwd, const RollParams& p, hipStream_t stream) {
     const int nslabs = (p.B + 15) / 16;
     if (p.P > 1) {
         const size_t xbytes = (size_t)2 * nslabs * p.P * 16 * Cf * sizeof(u64);
-        if (hipMemsetAsync(p.xbuf, 0, xbytes + 16, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: memset failed");
+        if (vs_zero_async(p.xbuf, xbytes + 16, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: memset failed");
     }
     dim3 grid((unsigned)(nslabs * p.P));
     if (fwd) hipLaunchKernelGGL(rollout_fwd_kernel<CT>, grid, dim3(NT), smem, stream, p);

@@ -84,6 +84,8 @@ def run_deferred(fn, *inputs):
 
 def join_side_streams():
     """Make the current stream wait for all deferred gradient work (call before the optimizer step)."""
+    if not _SIDE['on']:
+        return          # nothing was deferred; waiting on a stream outside the running capture would break the capture
     if _SIDE['wgrad'] is not None:
         torch.cuda.current_stream().wait_stream(_SIDE['wgrad'])
     if _SIDE['rollout'] is not None:

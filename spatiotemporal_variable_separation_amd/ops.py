@@ -5,6 +5,7 @@ from . import _lib
 from ._lib import F32, BF16, ACT, LAYOUT_R, LAYOUT_S, check, dtype_code, stream_ptr, require_cuda
 
 _ws_cache = {}
+_retired = []
 
 # ---- optional per-launch timing with HIP events on the launch stream (bench.py: roofline of the dominant kernel) ----
 _PROF = {'on': False, 'events': []}
@@ -60,11 +61,14 @@ def profile_collect():
 
 
 def _workspace(nbytes, device):
-    """One grow-only split-K workspace per device (allocated by torch, so legal inside graph capture after warm-up)."""
-    key = device.index
+    """One grow-only split-K workspace per (device, stream): launches on different streams may overlap, and a workspace is only
+    ordered by the stream it is used on (allocated by torch, so legal inside graph capture after warm-up)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _retired.append(buf)      # a recorded hipGraph may hold its address: outgrown workspaces are never freed
+        buf = torch.empty(max(nbytes, 2 * buf.numel() if buf is not None else 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 
@@ -196,6 +200,8 @@ def _rollout_workspace(nbytes, device):
         return None
     buf = _roll_ws.get(device.index)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _retired.append(buf)
         buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         _roll_ws[device.index] = buf
     return buf

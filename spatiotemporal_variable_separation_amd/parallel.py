@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, overlap=True):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, overlap=True, force=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -23,9 +23,10 @@ class GradAllReducer:
         self.buckets = []            # (flat, [params])
         self._pending = {}
         self._handles = []
+        self._force = force             # run the collectives even at world size 1 (exercises the RCCL path on one GPU)
         self._build(bucket_bytes)
         self._comm_stream = None
-        self._overlap = overlap and self.world_size > 1
+        self._overlap = overlap and (self.world_size > 1 or force)
         if self._overlap:
             self._install_hooks()
 
@@ -90,17 +91,38 @@ class GradAllReducer:
     def _reduce(self, flat):
         if self.backend == 'nccl':
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        elif flat.is_cuda:
+            # gloo with device buckets (tests: several ranks sharing one GPU): staged through host memory
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            flat.copy_(host.div_(self.world_size))
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             flat.div_(self.world_size)
 
     def all_reduce(self):
         """Average gradients over ranks; returns when the current stream may consume them."""
-        if self.world_size == 1:
+        if self.world_size == 1 and not self._force:
             return
         for bi in range(len(self.buckets)):
             if self._pending.get(bi, len(self.buckets[bi][1])) is not None:      # not launched by a hook
                 self._launch(bi)
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    # ---- graph-replay mode: the backward pass is a recorded hipGraph, so no hooks fire -----------------------------
+    def zero_buffers(self):
+        """Zero the flat buckets without arming the hooks (capturable: one memset per bucket)."""
+        for flat, _ in self.buckets:
+            flat.zero_()
+        self._pending = {}
+
+    def reduce_all(self):
+        """All-reduce every bucket now (comm stream ordered after the current stream) and make the current stream wait."""
+        if self.world_size == 1 and not self._force:
+            return
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 
@@ -112,5 +134,11 @@ def broadcast_module_state(module, src=0, process_group=None):
     """Make every replica start from rank `src`'s parameters and buffers (BN running statistics included)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
         return
+    staged = dist.get_backend(process_group) != 'nccl'
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=process_group)
+        if staged and t.is_cuda:
+            host = t.data.cpu()
+            dist.broadcast(host, src=src, group=process_group)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t.data, src=src, group=process_group)

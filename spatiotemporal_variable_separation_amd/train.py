@@ -1,4 +1,6 @@
 """Training loop and losses of the hot path (reference: train.py:38-175); same function names and arguments."""
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -149,14 +151,15 @@ class GraphedStep:
     every use of `t_random` inside the step is device-side.  Requires Adam(capturable=True)."""
 
     def __init__(self, sep_net, optimizer, cond, target, nt_cond, nt_pred, offset, lambdas, average_tloss=False, warmup=3,
-                 side_streams=True):
+                 side_streams=True, grad_sync=None):
         assert cond.is_cuda and _mlp_family(sep_net), 'GraphedStep supports the MLP family on a GPU'
-        self.side_streams = side_streams
-        self.net, self.opt = sep_net, optimizer
+        # deferred weight gradients require that nothing reads a gradient before join_side_streams(): not the case when they
+        # are accumulated into the reducer's (pre-existing) flat buckets
+        self.side_streams = side_streams and grad_sync is None and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
+        self.net, self.opt, self.sync = sep_net, optimizer, grad_sync
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
         self.cond, self.target = cond.clone(), target.clone()
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=cond.device)
-        self.t_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.T = cond.shape[1] + target.shape[1]
         self.nt_cond, self.offset = nt_cond, offset
         side = torch.cuda.Stream()
@@ -164,22 +167,45 @@ class GraphedStep:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._draw()
-                self._body()
+                self._fwd_bwd()
+                self._reduce()
+                self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
         self._draw()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._body()
+        self.graph_opt = None
+        if grad_sync is None:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._fwd_bwd()
+                self.opt.step()
+        else:
+            # data parallel: losses + backward into the reducer's flat gradient buckets in one graph, the bucket
+            # all-reduces issued eagerly in between (4 RCCL calls at WaveEq size; no collective inside a capture), Adam in
+            # a second graph
+            with torch.cuda.graph(self.graph):
+                self.loss = self._fwd_bwd()
+            self._reduce()
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt):
+                self.opt.step()
 
     def _draw(self):
         hi = self.T if self.offset == 0 else self.T + 1
-        self.t_host[0] = int(np.random.randint(self.nt_cond, hi))
-        self.t_dev.copy_(self.t_host, non_blocking=True)
+        # a fill kernel carries the value as a launch argument: no staging buffer the host could overwrite while an earlier
+        # step's copy is still queued behind a 3 ms replay
+        self.t_dev.fill_(int(np.random.randint(self.nt_cond, hi)))
 
-    def _body(self):
+    def _reduce(self):
+        if self.sync is not None:
+            self.sync.reduce_all()
+
+    def _fwd_bwd(self):
         nt_cond, nt_pred, offset, l_ae, l_s, l_t, l_pred, avg = self.args
         from . import functional as VF
-        self.opt.zero_grad(set_to_none=True)
+        if self.sync is not None:
+            self.sync.zero_buffers()
+        else:
+            self.opt.zero_grad(set_to_none=True)
         VF.enable_side_streams(self.side_streams)
         try:
             total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
@@ -188,7 +214,6 @@ class GraphedStep:
             VF.join_side_streams()
         finally:
             VF.enable_side_streams(False)
-        self.opt.step()
         return total.detach()
 
     def step(self, cond=None, target=None):
@@ -198,6 +223,9 @@ class GraphedStep:
             self.target.copy_(target, non_blocking=True)
         self._draw()
         self.graph.replay()
+        if self.graph_opt is not None:
+            self._reduce()
+            self.graph_opt.replay()
         return self.loss
 
 
@@ -231,7 +259,7 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
     """Same 20 positional arguments as the reference's `train` (train.py:91-92).
 
     Additive keyword arguments: `grad_sync` (a `parallel.GradAllReducer`, data-parallel gradient averaging over
-    RCCL), `log_interval` (print losses / frames-per-second every N steps) and `hip_graph` (MLP family, single GPU: record
+    RCCL), `log_interval` (print losses / frames-per-second every N steps) and `hip_graph` (MLP family: record
     the whole step once into a hipGraph -- `GraphedStep` -- and replay it; the optimizer must be Adam(capturable=True)).  `use_apex_amp` is rejected (no
     Apex on the MI355X path); `use_torch_amp` selects the bf16 compute mode, which needs no loss scaler.
     """
@@ -253,18 +281,19 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
             sep_net.train()
             for cond, target in train_loader:
                 cond, target = cond.to(device, non_blocking=True), target.to(device, non_blocking=True)
-                if hip_graph and grad_sync is None and _mlp_family(sep_net):
+                if hip_graph and _mlp_family(sep_net):
                     if graphed is None:
                         graphed = GraphedStep(sep_net, optimizer, cond, target, nt_cond, nt_pred, offset,
-                                              (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss)
+                                              (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss, grad_sync=grad_sync)
                     if cond.shape == graphed.cond.shape:
                         total_loss = graphed.step(cond, target)
                         step += 1
                         if log_interval and step % log_interval == 0:
                             torch.cuda.synchronize()
                             dt, t_last = time.time() - t_last, time.time()
+                            world = grad_sync.world_size if grad_sync is not None else 1
                             print(f'epoch {epoch} step {step}: total {total_loss.item():.5f} | '
-                                  f'{log_interval * cond.shape[0] * nt_pred / dt:.0f} frames/s (hipGraph)')
+                                  f'{world * log_interval * cond.shape[0] * nt_pred / dt:.0f} frames/s (hipGraph)')
                         continue                     # a ragged last batch falls through to the eager path below
                 if grad_sync is not None:
                     grad_sync.zero_grad()            # gradients are views into flat all-reduce buckets

@@ -55,8 +55,11 @@ def test_step_fp32_unfused_structure_matches_oracle(name):
     compare_step(cfg, int(load_golden(name)['t_random']), 'fp32', tol_out=1e-3, tol_grad=1e-3, fused=False)
 
 
-def test_graphed_step_equals_eager_steps():
-    """train.GraphedStep (whole step recorded into a hipGraph, device-side t_random) == the eager loop, step for step."""
+@pytest.mark.parametrize('side_streams', [True, False])
+def test_graphed_step_equals_eager_steps(side_streams):
+    """train.GraphedStep (whole step recorded into a hipGraph, device-side t_random) == the eager loop, step for step, as a
+    multi-stream capture and as a single-stream one (regression: memset nodes of a single-stream capture were not replayed in
+    order on ROCm 7.0 and left the bias-gradient accumulators dirty; the library now zero-fills with a kernel)."""
     import numpy as np
     import torch
     from oracle import cpu_ref
@@ -96,7 +99,7 @@ def test_graphed_step_equals_eager_steps():
         opt_g = torch.optim.Adam(net_g.parameters(), lr=1e-3, capturable=True)
         np.random.seed(7)
         g = GraphedStep(net_g, opt_g, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'],
-                        (lam['ae'], lam['s'], lam['t'], lam['pred']), warmup=3)
+                        (lam['ae'], lam['s'], lam['t'], lam['pred']), warmup=3, side_streams=side_streams)
         losses_g = [g.step().item() for _ in range(4)]
     torch.cuda.synchronize()
     assert np.allclose(losses_g, losses_e[3:], rtol=2e-4), (losses_g, losses_e)
