@@ -151,10 +151,14 @@ int vs_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, 
  *   t_codes   [B, n, C] fp32      every code of the rollout, t_codes[:, 0] = x0 (the layout get_forecast returns)
  *   residuals [n-1, n_blocks, B, C] fp32 or NULL   (the `t_residuals` the reference returns)
  *   xin_save [nb, n-1, B, C], h1_save / h2_save [nb, n-1, B, H]  compute type: inputs of the weight-gradient GEMMs
- *   m1_save / m2_save [nb, n-1, B, P, 32] uint32, P = vs_mlp_rollout_parts(...): ReLU sign bits of h1 / h2 (word
- *             (q, j) of a row holds columns q*H/P + j + 32 u in bit u), so the backward kernel reads a few words per
- *             thread and step instead of the activations
- *   workspace: exchange area of vs_mlp_rollout_workspace_bytes(...) bytes (zeroed by the call).  When the hidden size
+ *   m1_save / m2_save [nb, n-1, Bp, P, 32] uint32, Bp = B rounded up to 16, P = vs_mlp_rollout_parts(...): ReLU sign
+ *             bits of h1 / h2, opaque to the caller (written by _fwd, read by _bwd of the same sizes), so the backward
+ *             kernel reads a few words per step instead of the activations
+ *   workspace: exchange area of vs_mlp_rollout_workspace_bytes(...) bytes (zeroed by the call; its last 16 bytes hold a
+ *             timeout flag).  bf16, C <= 32, H in {128, 256, 512}, ceil(B/16) * n_blocks * H/64 <= 224: weight-stationary
+ *             pipelined form -- one workgroup per (16-row slab, block, 64-column part) keeps its weight fragments in
+ *             registers for the whole rollout and hands [16, C] partials to the workgroups of the next block through
+ *             the exchange area.  Otherwise the slab form:  When the hidden size
  *             allows it the H x H layer of every 16-row slab is split over P workgroups (P CUs stream 1/P of the
  *             weights each); they all-reduce one [16, C] partial per block-step through this area with epoch-tagged
  *             8-byte granules (placement independent, bounded spins).  NULL / too small => P = 1 (no split).

@@ -47,7 +47,7 @@ def build_library(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objdir = os.path.join(_HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
-    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + os.environ.get('VARSEP_HIPCC_FLAGS', '').split()
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + '.o')

@@ -22,6 +22,7 @@
 // Backward-through-time runs the same structure in reverse with transposed weight copies, producing dr/dh2/dh1
 // for every (block, step); the weight gradients are then three large vs_gemm calls per block (K = (n-1)*B).
 #include "vs_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -43,7 +44,8 @@ struct RollParams {
     unsigned* m2_save;           // same for h2  (both [nb, n-1, B, P, 32]: one word per part)
     int P;                       // workgroups per slab (hidden dimension split)
     unsigned long long* xbuf;    // exchange area [2][nslabs][P][16*Cf] of {epoch, value} granules
-    unsigned* xerr;              // timeout flag
+    unsigned* xerr;              // timeout flag (last 16 bytes of the workspace)
+    size_t xtotal;               // workspace bytes (zero-filled before every launch)
     // backward
     const float* g;              // [B, n, C] gradient wrt every t_code
     float* dx0;                  // [B, C]
@@ -336,7 +338,9 @@ struct Lds {
     int Cf, Ck, Hk, NpH, NpC;
 };
 
-__host__ __device__ inline size_t lds_layout(int C, int H, int nb, int esize, int KS, int U, int* Cf, int* Ck, int* Hk, int* NpH, int* NpC,
+__host__ __device__ inline int ksplit_for(int ntiles, int nsteps);
+
+__host__ __device__ inline size_t lds_layout(int C, int H, int nb, int P, int esize, int KS, int U, int* Cf, int* Ck, int* Hk, int* NpH, int* NpC,
                                              size_t* off_c, size_t* off_h1, size_t* off_h2, size_t* off_bias, size_t* off_part) {
     *Cf = round_up(C, 4);
     *Ck = round_up(C, KS) + U;            // + one 16-byte unit: conflict-free ds_read_b128
@@ -349,18 +353,24 @@ __host__ __device__ inline size_t lds_layout(int C, int H, int nb, int esize, in
     off = (off + 15) & ~(size_t)15; *off_h2 = off; off += (size_t)16 * (*Hk) * esize;
     off = (off + 15) & ~(size_t)15; *off_bias = off; off += (size_t)nb * (2 * H + C) * 4;
     off = (off + 15) & ~(size_t)15; *off_part = off;
-    // partials: worst case over the layer shapes used (full-H output unsplit; C output with ksplit 8)
-    const size_t pH = (size_t)16 * 8 * (*NpH) * 4 / ((H + 15) / 16 >= NW ? 8 : 1);
-    const size_t pC = (size_t)16 * 8 * (*NpC) * 4;
-    off += pH > pC ? pH : pC;
+    // partials: ksplit slabs of [16][Np] for each of the three layer shapes a workgroup runs (same set in both directions)
+    const int Hs = H / P;
+    const int tilesH = (H + 15) / 16, tilesC = (C + 15) / 16, tilesS = (Hs + 15) / 16;
+    const int stepsC = (C + KS - 1) / KS, stepsH = (H + KS - 1) / KS, stepsS = (Hs + KS - 1) / KS;
+    const size_t p1 = (size_t)ksplit_for(tilesH, stepsC) * 16 * (*NpH) * 4;
+    const size_t p2 = (size_t)ksplit_for(P > 1 ? tilesS : tilesH, stepsH) * 16 * (*NpH) * 4;
+    const size_t p3 = (size_t)ksplit_for(tilesC, P > 1 ? stepsS : stepsH) * 16 * (*NpC) * 4;
+    size_t pm = p1 > p2 ? p1 : p2;
+    if (p3 > pm) pm = p3;
+    off += pm;
     return off;
 }
 
 template <int CT>
-__device__ __forceinline__ Lds carve(char* smem, int C, int H, int nb) {
+__device__ __forceinline__ Lds carve(char* smem, int C, int H, int nb, int P) {
     Lds L;
     size_t oc, o1, o2, ob, op;
-    lds_layout(C, H, nb, (int)sizeof(typename RT<CT>::T), RT<CT>::KS, RT<CT>::U, &L.Cf, &L.Ck, &L.Hk, &L.NpH, &L.NpC, &oc, &o1, &o2, &ob, &op);
+    lds_layout(C, H, nb, P, (int)sizeof(typename RT<CT>::T), RT<CT>::KS, RT<CT>::U, &L.Cf, &L.Ck, &L.Hk, &L.NpH, &L.NpC, &oc, &o1, &o2, &ob, &op);
     L.xs = reinterpret_cast<float*>(smem);
     L.a_c = smem + oc; L.a_h1 = smem + o1; L.a_h2 = smem + o2;
     L.bias = reinterpret_cast<float*>(smem + ob);
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(NT) void rollout_fwd_kernel(RollParams p) {
     typedef typename RT<CT>::T T;
     constexpr int KS = RT<CT>::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Lds L = carve<CT>(smem, p.C, p.H, p.nb);
+    const Lds L = carve<CT>(smem, p.C, p.H, p.nb, p.P);
     T* a_c = (T*)L.a_c; T* a_h1 = (T*)L.a_h1; T* a_h2 = (T*)L.a_h2;
     const int B = p.B, C = p.C, H = p.H, n = p.n, nb = p.nb, P = p.P;
     const int nslabs = (B + 15) / 16;
@@ -419,6 +429,7 @@ __global__ __launch_bounds__(NT) void rollout_fwd_kernel(RollParams p) {
             const T* W1 = (const T*)p.W[3 * b]; const T* W2 = (const T*)p.W[3 * b + 1]; const T* W3 = (const T*)p.W[3 * b + 2];
             const float* b1 = L.bias + b * (2 * H + C); const float* b2 = b1 + H; const float* b3 = b2 + H;
             const int64_t sbase = ((int64_t)b * (n - 1) + (t - 1)) * B + row0;     // row index into the [nb][n-1][B][.] saves
+            const int64_t mbase = ((int64_t)b * (n - 1) + (t - 1)) * (nslabs * 16) + row0;   // sign-bit arrays have rows padded to 16
             StagedSmall<CT> S1, S3;
             StagedStream<CT> S2;
             S1.issue(W1, A1);
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(NT) void rollout_fwd_kernel(RollParams p) {
                         if (vrow) ((T*)p.h1_save)[(sbase + er) * H + c] = hv;
                     }
                 }
-                if (vrow) p.m1_save[((sbase + er) * P + part) * 32 + ec] = bits;
+                if (vrow) p.m1_save[((mbase + er) * P + part) * 32 + ec] = bits;
             }
             __syncthreads();
             S2.run(a_h1, W2, L.part, A2);                                           // h2: own column slice (weight stream / P)
@@ -461,7 +472,7 @@ __global__ __launch_bounds__(NT) void rollout_fwd_kernel(RollParams p) {
                     a_h2[er * L.Hk + c_lo + cl] = hv;
                     if (vrow) ((T*)p.h2_save)[(sbase + er) * H + c_lo + cl] = hv;
                 }
-                if (vrow) p.m2_save[((sbase + er) * P + part) * 32 + ec] = bits;
+                if (vrow) p.m2_save[((mbase + er) * P + part) * 32 + ec] = bits;
             }
             __syncthreads();
             S3.run(a_h2, W3, L.part, A3);                                           // partial residual over the own K slice
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(NT) void rollout_bwd_kernel(RollParams p) {
     typedef typename RT<CT>::T T;
     constexpr int KS = RT<CT>::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Lds L = carve<CT>(smem, p.C, p.H, p.nb);
+    const Lds L = carve<CT>(smem, p.C, p.H, p.nb, p.P);
     T* a_c = (T*)L.a_c; T* a_h1 = (T*)L.a_h1; T* a_h2 = (T*)L.a_h2;
     const int B = p.B, C = p.C, H = p.H, n = p.n, nb = p.nb, P = p.P;
     const int nslabs = (B + 15) / 16;
@@ -518,11 +529,12 @@ __global__ __launch_bounds__(NT) void rollout_bwd_kernel(RollParams p) {
         for (int b = nb - 1; b >= 0; --b) {
             const T* W3T = (const T*)p.W[3 * b]; const T* W2T = (const T*)p.W[3 * b + 1]; const T* W1T = (const T*)p.W[3 * b + 2];
             const int64_t sbase = ((int64_t)b * (n - 1) + (t - 1)) * B + row0;
+            const int64_t mbase = ((int64_t)b * (n - 1) + (t - 1)) * (nslabs * 16) + row0;
             // sign bits: h2 for ALL columns (word q of part q), h1 for the own slice; issued before the GEMMs that hide them
             unsigned w2[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) w2[q] = (vrow && q < P) ? p.m2_save[((sbase + er) * P + q) * 32 + ec] : 0u;
-            const unsigned w1 = vrow ? p.m1_save[((sbase + er) * P + part) * 32 + ec] : 0u;
+            for (int q = 0; q < 8; ++q) w2[q] = (vrow && q < P) ? p.m2_save[((mbase + er) * P + q) * 32 + ec] : 0u;
+            const unsigned w1 = vrow ? p.m1_save[((mbase + er) * P + part) * 32 + ec] : 0u;
             StagedSmall<CT> S3, S1;
             StagedStream<CT> S2;
             S3.issue(W3T, A3);
@@ -582,6 +594,384 @@ __global__ __launch_bounds__(NT) void rollout_bwd_kernel(RollParams p) {
             if (vrow) p.dx0[(int64_t)(row0 + er) * C + c] = L.xs[er * L.Cf + c] + p.g[((int64_t)(row0 + er) * n) * C + c];
 }
 
+// =====================================================================================================================
+// Weight-stationary pipelined form (bf16, C <= 32, H in {128, 256, 512}).
+//
+// The slab-per-workgroup form above re-streams every block's weights from L2 at every time step and pays ~7 barriers and
+// LDS round trips per block-step (7.7 us fwd / 10.7 us bwd at WaveEq size) although the MFMA work of a block-step is a
+// few hundred cycles.  Here every (slab, block, part) triple gets its OWN workgroup whose weight fragments are loaded
+// into registers ONCE (H = 512: 104 VGPRs per lane) and never move again: a block-step is then three short MFMA bursts
+// out of registers, three barriers, and one hop of the granule exchange to the workgroups of the next block.  The
+// workgroups of one slab form a ring of nb groups x P parts; group b sleeps while the other blocks work (the chip has
+// 256 CUs and the recurrence can use at most nslabs * P of them at a time anyway).
+//
+//   part p of block b owns hidden columns [64 p, 64 p + 64):  P = H / 64, 4 waves, wave w owns the 16-column tile w of it
+//   layer a (code -> hidden, N = H, K = C): computed in full by every part (K is one k-step), wave w: tiles w, w+4, ...
+//   layer b (hidden -> hidden slice, N = 64, K = H): wave w: tile 4p + w, KH k-steps, two accumulators
+//   layer c (hidden slice -> code, N = C, K = 64): waves 0/1: code tile w, two chained k-steps -> partial [16, 32]
+//   exchange: epoch e = block-step index + 1; slots [2][nslabs][P + 1][16 x 32] granules {epoch, fp32}: P partials plus the
+//   block input x (published by part 0 as soon as it is known).  The consumer (every part of the next block) computes
+//   x_out = x_in + ((p_0 + ... + p_{P-1}) + b3) in that fixed order: all parts hold bitwise identical codes.
+//   Double buffering is sufficient for the same reason as above (a group publishes e + 2 only after receiving all of e + 1,
+//   whose producers had finished reading e).
+// Backward-through-time is the same skeleton with the transposed weights, ReLU masks instead of bias + ReLU and the
+// block-steps walked in reverse.  Sign bits are stored one bit per hidden column, row-major (16-bit unit per 16-column tile).
+namespace wsr {
+
+constexpr int WT = 256;
+constexpr int XP = 40;            // LDS row pitch of the code operand (32 + 8: conflict-free ds_read_b128)
+constexpr int SP = 72;            // LDS row pitch of the hidden-slice operand (64 + 8)
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef const __attribute__((address_space(4))) u64* const_u64_ptr;      // read-only for this kernel: scalar loads
+
+__device__ __forceinline__ u64 gload(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gstore(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// LDS-only workgroup barrier: __syncthreads() also drains the vector-memory counter (its release fence waits for every
+// outstanding global store -- the activation saves and the exchange granules -- to be acknowledged by L2); the barriers of a
+// block-step only order LDS traffic, so they wait for the LDS counter alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
+}
+// two fp32 -> one dword of two bf16 (round to nearest even, hardware convert)
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return *reinterpret_cast<unsigned*>(&v);
+}
+// ReLU on two packed bf16: as signed 16-bit integers negative floats are negative, so max(x, 0) clears them
+__device__ __forceinline__ unsigned pk_relu(unsigned v) {
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(v));
+    return r;
+}
+// x where the lane's bit of `mask` is set, else 0 (mask = a stored v_cmp result of the forward pass: one bit per lane)
+__device__ __forceinline__ float keep_if(float x, u64 mask) {
+    float r;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+    return r;
+}
+
+#ifdef VS_WS_TIMING
+#define WS_STAMP(k) do { if (dbg && slab == 0 && part == 0 && tid == 0) dbg[((int64_t)q * 8 + (k))] = wall_clock64(); } while (0)
+#else
+#define WS_STAMP(k) do { } while (0)
+#endif
+
+// Transposed chain: every layer is computed as (weights) x (activations)^T, so an MFMA result -- lane (c, g) holds 4
+// consecutive FEATURES 4g..4g+3 of batch row c -- is, after the bf16 convert, already the B-operand fragment of the next
+// layer (8 k-values per lane = the results of two feature tiles; the k order inside a k-step is a fixed permutation that the
+// next layer's weight fragments are loaded with).  Layer a -> layer b therefore never touches LDS: wave w computes the
+// feature tiles T = 4 j + w of layer a and contracts exactly those features in layer b (K split over the 4 waves, all 64
+// output features of the part); the four K-partials meet in LDS (16 KB, one barrier), wave w finishes output tile w.
+template <int KH, bool FWD>
+__global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_pitch /* words per row of m1/m2 */, long long* dbg) {
+    typedef __bf16 T;
+    constexpr int H = 32 * KH, P = KH / 2, NJ = KH / 2, NKB = NJ / 2 > 0 ? NJ / 2 : 1;
+    static_assert(NJ % 2 == 0, "two layer-a tiles form one k-step of layer b");
+    __shared__ __attribute__((aligned(16))) T xa[16 * XP];
+    __shared__ __attribute__((aligned(16))) T ah2[16 * SP];
+    __shared__ __attribute__((aligned(16))) float bias_a[H];
+    __shared__ __attribute__((aligned(16))) f32x4 pb[4 * 4 * 64];          // layer b K-partials: [wave][output tile][lane]
+
+    const int B = p.B, C = p.C, n = p.n, nb = p.nb;
+    const int nslabs = (B + 15) / 16, Bp = nslabs * 16;
+    int id = blockIdx.x;
+    const int slab = id % nslabs; id /= nslabs;
+    const int part = id % P;
+    const int blk = id / P;
+    const int pos = FWD ? blk : nb - 1 - blk;                 // position of this block inside a time step, in execution order
+    const int row0 = slab * 16;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (told to the compiler: scalar mask loads)
+    const int er = tid >> 5, ec = tid & 31;                   // exchange mapping: elements (er, ec) and (er + 8, ec)
+    const int own = 4 * part + w;                             // the 16-feature tile of the hidden dimension this wave finishes / saves
+    const bool vrow = row0 + c < B;                           // MFMA results: lane (c, g) belongs to batch row c
+
+    // ---- weights: loaded once, resident in registers for the whole rollout ------------------------------------------
+    const T* Wa = (const T*)p.W[3 * blk];
+    const T* Wb = (const T*)p.W[3 * blk + 1];
+    const T* Wc = (const T*)p.W[3 * blk + 2];
+    u32x4 wa[NJ], wa_own, wb[4][NKB], wc[2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wa[j] = *reinterpret_cast<const u32x4*>(Wa + ((int64_t)(4 * j + w) * 64 + lane) * 8);
+    wa_own = *reinterpret_cast<const u32x4*>(Wa + ((int64_t)own * 64 + lane) * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < NKB; ++jj) {
+            // k-step jj of this wave = layer-a tiles 4 (2 jj) + w and 4 (2 jj + 1) + w: lane (c, g) contracts the features
+            // 16 (8 jj + w) + 4 g + {0..3} and the same + 64.  In the standard pack they sit in k-step 4 jj + w / 2 (resp. + 2),
+            // lane group 2 (w & 1) + g / 2, 8-byte half g & 1.
+            const T* piece = Wb + (((int64_t)(4 * part + i) * KH + 4 * jj + (w >> 1)) * 64 + 16 * (2 * (w & 1) + (g >> 1)) + c) * 8 + (g & 1) * 4;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(piece);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(piece + 2 * 64 * 8);
+            wb[i][jj] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+    }
+    const bool code_tile = (w & 1) * 16 < C;                  // C <= 16: the packed code layer has one column tile, the other is zero
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        wc[s] = u32x4{0u, 0u, 0u, 0u};
+        if (code_tile) wc[s] = *reinterpret_cast<const u32x4*>(Wc + (((int64_t)(w & 1) * KH + 2 * part + s) * 64 + lane) * 8);
+    }
+    f32x4 bias_b = {0.f, 0.f, 0.f, 0.f};
+    float bc = 0.f;
+    if (FWD) {
+        for (int i = tid; i < H; i += WT) bias_a[i] = p.bias[3 * blk][i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_b[r] = p.bias[3 * blk + 1][16 * own + 4 * g + r];
+        const int prev = (blk + nb - 1) % nb;                  // the block whose output this workgroup consumes
+        bc = ec < C ? p.bias[3 * prev + 2][ec] : 0.f;
+    }
+    __syncthreads();
+
+    u64* const xbase = p.xbuf;
+    auto slot = [&](unsigned epoch, int who) -> u64* {
+        return xbase + ((((int64_t)(epoch & 1u) * nslabs + slab) * (P + 1) + who) << 9);
+    };
+
+    const int iters = (n - 1) + (pos == 0 ? 1 : 0);            // position 0 also receives the very last output
+    for (int it = 0; it < iters; ++it) {
+        const int q = it * nb + pos;                            // block-step index in execution order
+        const bool extra = it == n - 1;
+        const int t = FWD ? it + 1 : n - 1 - it;                // time step of this block-step
+        const int64_t sbase = ((int64_t)blk * (n - 1) + (t - 1)) * B + row0;
+        // sign bits of this (block, step, slab): lane masks (v_cmp results: bit 16 g + c <-> feature 4 g + r of the tile, batch
+        // row c), 4 x 8 bytes per tile; the tile T = 4 j + w is stored at index 8 w + j so that a wave reads one contiguous run
+        const int64_t mofs = (((int64_t)blk * (n - 1) + (t - 1)) * Bp + row0) * mask_pitch;
+        const int mown = (NJ * w + part) * 4;                   // u64 index of this wave's own tile (T = 4 part + w)
+        WS_STAMP(0);
+
+        // ---- 1. receive the block input (fwd: code x, bwd: running gradient) --------------------------------------
+        float xv[2];
+        if (q == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = er + 8 * i;
+                float v = 0.f;
+                if (row0 + r < B && ec < C)
+                    v = FWD ? p.x0[(int64_t)(row0 + r) * C + ec] : p.g[((int64_t)(row0 + r) * n + (n - 1)) * C + ec];
+                xv[i] = v;
+            }
+        } else {
+            const unsigned epoch = (unsigned)q;
+            u64 v[2][P + 1];
+            unsigned spins = 0;
+            // cheap wait on ONE granule of the last-published kind (a partial), then fetch everything and verify
+            while ((unsigned)(gload(slot(epoch, P - 1) + er * 32 + ec) >> 32) != epoch) {
+                if (++spins > SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int s = 0; s <= P; ++s) {
+                    v[0][s] = gload(slot(epoch, s) + er * 32 + ec);
+                    v[1][s] = gload(slot(epoch, s) + (er + 8) * 32 + ec);
+                }
+#pragma unroll
+                for (int s = 0; s <= P; ++s) ok = ok && (unsigned)(v[0][s] >> 32) == epoch && (unsigned)(v[1][s] >> 32) == epoch;
+                if (ok) break;
+                if (++spins > SPIN_LIMIT) { atomicOr(p.xerr, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = er + 8 * i;
+                float res = __uint_as_float((unsigned)v[i][0]);
+#pragma unroll
+                for (int s = 1; s < P; ++s) res += __uint_as_float((unsigned)v[i][s]);
+                if (FWD) res += bc;
+                float x = __uint_as_float((unsigned)v[i][P]) + res;
+                const bool valid = row0 + r < B && ec < C;
+                if (FWD) {
+                    if (p.residuals && part == 0 && valid) p.residuals[((int64_t)(q - 1) * B + row0 + r) * C + ec] = res;
+                } else if (pos == 0 && valid) {
+                    x += p.g[((int64_t)(row0 + r) * n + t) * C + ec];      // entering time step t: add its upstream gradient
+                }
+                xv[i] = x;
+            }
+        }
+        WS_STAMP(1);
+        if (extra) {
+            if (part == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = er + 8 * i;
+                    if (row0 + r < B && ec < C) {
+                        if (FWD) p.t_codes[((int64_t)(row0 + r) * n + it) * C + ec] = xv[i];
+                        else p.dx0[(int64_t)(row0 + r) * C + ec] = xv[i];
+                    }
+                }
+            }
+            break;
+        }
+        const unsigned epoch_out = (unsigned)q + 1u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xa[(er + 8 * i) * XP + ec] = (T)xv[i];
+        WS_STAMP(2);
+        lds_barrier();
+        WS_STAMP(3);
+        // everything below the barrier that is not on the critical path of the ring: block-input saves, the code output
+        if (part == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = er + 8 * i;
+                gstore(slot(epoch_out, P) + r * 32 + ec, ((u64)epoch_out << 32) | (u64)__float_as_uint(xv[i]));
+                if (row0 + r < B && ec < C) {
+                    if (FWD) {
+                        ((T*)p.xin_save)[(sbase + r) * C + ec] = (T)xv[i];
+                        if (pos == 0) p.t_codes[((int64_t)(row0 + r) * n + it) * C + ec] = xv[i];   // input of block 0 = code of time it
+                    } else {
+                        ((T*)p.dr_save)[(sbase + r) * C + ec] = (T)xv[i];
+                    }
+                }
+            }
+        }
+
+        // ---- 2. layer a (code -> the features this wave contracts in layer b), results stay in registers ---------------
+        const u32x4 xb = *reinterpret_cast<const u32x4*>(xa + c * XP + g * 8);
+        const_u64_ptr mask_a = nullptr, mask_b = nullptr;
+        if (!FWD) {
+            mask_a = (const_u64_ptr)(uintptr_t)(p.m2_save + mofs);        // ReLU mask of h2: gates dh2 (layer a of the backward chain)
+            mask_b = (const_u64_ptr)(uintptr_t)(p.m1_save + mofs);        // ReLU mask of h1: gates dh1 (layer b)
+        }
+        f32x4 aa[NJ], ao = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            aa[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (FWD) aa[j] = *reinterpret_cast<const f32x4*>(bias_a + 16 * (4 * j + w) + 4 * g);
+        }
+        if (FWD) ao = *reinterpret_cast<const f32x4*>(bias_a + 16 * own + 4 * g);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) aa[j] = mma(wa[j], xb, aa[j]);
+        ao = mma(wa_own, xb, ao);           // this wave's own tile once more, for the activation save (and the sign bits)
+        u32x4 hf[NKB];
+#pragma unroll
+        for (int jj = 0; jj < NKB; ++jj) {
+            f32x4 a0 = aa[2 * jj], a1 = aa[2 * jj + 1];
+            if (FWD) {
+                hf[jj] = u32x4{pk_relu(pk_bf16(a0[0], a0[1])), pk_relu(pk_bf16(a0[2], a0[3])), pk_relu(pk_bf16(a1[0], a1[1])),
+                               pk_relu(pk_bf16(a1[2], a1[3]))};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a0[r] = keep_if(a0[r], mask_a[(NJ * w + 2 * jj) * 4 + r]);
+                    a1[r] = keep_if(a1[r], mask_a[(NJ * w + 2 * jj + 1) * 4 + r]);
+                }
+                hf[jj] = u32x4{pk_bf16(a0[0], a0[1]), pk_bf16(a0[2], a0[3]), pk_bf16(a1[0], a1[1]), pk_bf16(a1[2], a1[3])};
+            }
+        }
+
+        // ---- 3. layer b: K-partial over this wave's features, all 64 output features of the part ----------------------------
+        {
+            f32x4 bb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < NKB; ++jj) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bb[i] = mma(wb[i][jj], hf[jj], bb[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pb[(w * 4 + i) * 64 + lane] = bb[i];
+        }
+        {   // own tile of layer a: save (4 consecutive features of row c = 8 bytes) + sign bits
+            u32x2 pk;
+            if (FWD) {
+                u64 bal[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bal[r] = __ballot(ao[r] > 0.f);
+                pk = u32x2{pk_relu(pk_bf16(ao[0], ao[1])), pk_relu(pk_bf16(ao[2], ao[3]))};
+                if (lane == 0) {
+                    u64* mdst = reinterpret_cast<u64*>(p.m1_save + mofs) + mown;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mdst[r] = bal[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ao[r] = keep_if(ao[r], mask_a[mown + r]);
+                pk = u32x2{pk_bf16(ao[0], ao[1]), pk_bf16(ao[2], ao[3])};
+            }
+            if (vrow) {
+                T* dst = (FWD ? (T*)p.h1_save : (T*)p.dh2_save) + (sbase + c) * H + 16 * own + 4 * g;
+                *reinterpret_cast<u32x2*>(dst) = pk;
+            }
+        }
+        WS_STAMP(4);
+        lds_barrier();
+        {   // finish output tile w of the part: fixed-order sum of the four K-partials
+            f32x4 sum = pb[(0 * 4 + w) * 64 + lane];
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) {
+                const f32x4 o = pb[(ww * 4 + w) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] += o[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] += bias_b[r];
+            u32x2 pk;
+            if (FWD) {
+                u64 bal[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bal[r] = __ballot(sum[r] > 0.f);
+                pk = u32x2{pk_relu(pk_bf16(sum[0], sum[1])), pk_relu(pk_bf16(sum[2], sum[3]))};
+                if (lane == 0) {
+                    u64* mdst = reinterpret_cast<u64*>(p.m2_save + mofs) + mown;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mdst[r] = bal[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] = keep_if(sum[r], mask_b[mown + r]);
+                pk = u32x2{pk_bf16(sum[0], sum[1]), pk_bf16(sum[2], sum[3])};
+            }
+            *reinterpret_cast<u32x2*>(ah2 + c * SP + 16 * w + 4 * g) = pk;
+            if (vrow) {
+                T* dst = (FWD ? (T*)p.h2_save : (T*)p.dh1_save) + (sbase + c) * H + 16 * own + 4 * g;
+                *reinterpret_cast<u32x2*>(dst) = pk;
+            }
+        }
+        WS_STAMP(5);
+        lds_barrier();
+        WS_STAMP(6);
+
+        // ---- 4. layer c: [16, own 64] x [64, C]: partial of the block output, published to the next block ---------------
+        if (w < 2) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const T* arow = ah2 + c * SP + g * 8;
+            acc = mma(*reinterpret_cast<const u32x4*>(arow), wc[0], acc);
+            acc = mma(*reinterpret_cast<const u32x4*>(arow + 32), wc[1], acc);
+            u64* dst = slot(epoch_out, part) + 16 * w + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gstore(dst + (4 * g + r) * 32, ((u64)epoch_out << 32) | (u64)__float_as_uint(acc[r]));
+        }
+        WS_STAMP(7);
+        // the next block-step of this workgroup overwrites xa / ah2 / pb only after its receive, i.e. after the other blocks of
+        // the ring (or, for n_blocks == 1, its own peers) consumed this output: the LDS reads above are long finished
+    }
+}
+
+// usable when the register-resident fragments and the one-workgroup-per-(slab, block, part) grid fit
+inline bool usable(int compute, int B, int C, int H, int nb) {
+    if (compute != VS_BF16 || C > 32 || (H != 128 && H != 256 && H != 512)) return false;
+    const int nslabs = (B + 15) / 16, P = H / 64;
+    if ((int64_t)nslabs * nb * P > 224) return false;            // all workgroups must be co-resident (256 CUs)
+    const char* e = getenv("VS_ROLLOUT_WS");
+    return !(e && e[0] == '0');
+}
+
+inline size_t exchange_bytes(int B, int H) {
+    const int nslabs = (B + 15) / 16, P = H / 64;
+    return (size_t)2 * nslabs * (P + 1) * 512 * sizeof(u64);
+}
+
+}  // namespace wsr
+
 int pick_parts(int compute, int B, int C, int H) {
     // split the hidden dimension over P workgroups per slab when slices stay MFMA/k-step aligned and LDS-friendly
     const int KS = compute == VS_BF16 ? 32 : 16;
@@ -598,11 +988,52 @@ int pick_parts(int compute, int B, int C, int H) {
     return P;
 }
 
+int launch_ws(bool fwd, const RollParams& p, int mask_pitch, size_t workspace_bytes, hipStream_t stream) {
+    if (vs_zero_async(p.xbuf, workspace_bytes, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: zero fill failed");
+    const int nslabs = (p.B + 15) / 16, P = p.H / 64;
+    dim3 grid((unsigned)(nslabs * p.nb * P)), block(wsr::WT);
+    long long* dbg = nullptr;
+#ifdef VS_WS_TIMING
+    static long long* dbg_buf = nullptr;
+    const int Q = (p.n - 1) * p.nb;
+    if (!dbg_buf && hipMalloc(&dbg_buf, 8 * 8 * 4096) != hipSuccess) dbg_buf = nullptr;
+    dbg = Q <= 4096 ? dbg_buf : nullptr;
+#endif
+#define VS_WS_LAUNCH(KH)                                                                                              \
+    do {                                                                                                              \
+        if (fwd) hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, true>), grid, block, 0, stream, p, mask_pitch, dbg);  \
+        else hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, false>), grid, block, 0, stream, p, mask_pitch, dbg);     \
+    } while (0)
+    if (p.H == 512) VS_WS_LAUNCH(16);
+    else if (p.H == 256) VS_WS_LAUNCH(8);
+    else VS_WS_LAUNCH(4);
+#undef VS_WS_LAUNCH
+    VS_CHECK_LAUNCH("vs_mlp_rollout (weight-stationary)");
+#ifdef VS_WS_TIMING
+    if (dbg) {          // debug build only: phase timestamps of (slab 0, part 0) of every block, 10 ns ticks
+        if (hipStreamSynchronize(stream) != hipSuccess) return VS_OK;
+        static long long h[8 * 4096];
+        if (hipMemcpy(h, dbg, sizeof(long long) * 8 * Q, hipMemcpyDeviceToHost) != hipSuccess) return VS_OK;
+        double sum[8] = {0}, hop = 0;
+        int cnt = 0;
+        for (int q = 2; q < Q - 1; ++q) {
+            for (int k = 1; k < 8; ++k) sum[k] += (double)(h[q * 8 + k] - h[q * 8 + k - 1]);
+            hop += (double)(h[(q + 1) * 8 + 1] - h[q * 8 + 7]);
+            ++cnt;
+        }
+        fprintf(stderr, "[ws %s] ticks of 10 ns per block-step: wait %.1f | post-recv %.1f | barrier %.1f | layer a %.1f | layer b %.1f | barrier %.1f | "
+                "layer c + publish %.1f | hop publish->received %.1f | total %.1f (%d block-steps)\n", fwd ? "fwd" : "bwd", sum[1] / cnt, sum[2] / cnt,
+                sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[7] / cnt, hop / cnt, (double)(h[(Q - 1) * 8 + 7] - h[0]) / (Q - 1), Q);
+    }
+#endif
+    return VS_OK;
+}
+
 template <int CT>
 int launch_roll(bool fwd, const RollParams& p, hipStream_t stream) {
     int Cf, Ck, Hk, NpH, NpC;
     size_t oc, o1, o2, ob, op;
-    const size_t smem = lds_layout(p.C, p.H, p.nb, (int)sizeof(typename RT<CT>::T), RT<CT>::KS, RT<CT>::U, &Cf, &Ck, &Hk, &NpH, &NpC, &oc, &o1,
+    const size_t smem = lds_layout(p.C, p.H, p.nb, p.P, (int)sizeof(typename RT<CT>::T), RT<CT>::KS, RT<CT>::U, &Cf, &Ck, &Hk, &NpH, &NpC, &oc, &o1,
                                    &o2, &ob, &op);
     if (smem > 160 * 1024) return vs_fail(VS_ERR_UNSUPPORTED, "vs_mlp_rollout: C=%d H=%d needs %zu B of LDS (> 160 KiB)", p.C, p.H, smem);
     const void* kfn = fwd ? (const void*)rollout_fwd_kernel<CT> : (const void*)rollout_bwd_kernel<CT>;
@@ -612,8 +1043,7 @@ int launch_roll(bool fwd, const RollParams& p, hipStream_t stream) {
     }
     const int nslabs = (p.B + 15) / 16;
     if (p.P > 1) {
-        const size_t xbytes = (size_t)2 * nslabs * p.P * 16 * Cf * sizeof(u64);
-        if (vs_zero_async(p.xbuf, xbytes + 16, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: memset failed");
+        if (vs_zero_async(p.xbuf, p.xtotal, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: zero fill failed");
     }
     dim3 grid((unsigned)(nslabs * p.P));
     if (fwd) hipLaunchKernelGGL(rollout_fwd_kernel<CT>, grid, dim3(NT), smem, stream, p);
@@ -635,8 +1065,20 @@ int setup_exchange(RollParams& p, int compute, void* workspace, size_t workspace
     const size_t need = (size_t)2 * nslabs * p.P * 16 * Cf * sizeof(u64) + 16;
     if (p.P > 1 && (!workspace || workspace_bytes < need)) p.P = 1;         // no exchange area: run unsplit
     p.xbuf = (u64*)workspace;
-    p.xerr = p.P > 1 ? (unsigned*)((char*)workspace + need - 16) : nullptr;
+    p.xtotal = workspace_bytes & ~(size_t)15;
+    p.xerr = p.P > 1 ? (unsigned*)((char*)workspace + p.xtotal - 16) : nullptr;
     return VS_OK;
+}
+
+// weight-stationary form: same decision in both directions (the sign-bit layout differs from the slab form)
+bool setup_ws(RollParams& p, int compute, void* workspace, size_t workspace_bytes, int* mask_pitch) {
+    if (!wsr::usable(compute, p.B, p.C, p.H, p.nb) || p.n < 2) return false;
+    if (!workspace || workspace_bytes < wsr::exchange_bytes(p.B, p.H) + 16) return false;
+    p.xbuf = (u64*)workspace;
+    p.xtotal = workspace_bytes & ~(size_t)15;
+    p.xerr = (unsigned*)((char*)workspace + p.xtotal - 16);
+    *mask_pitch = pick_parts(compute, p.B, p.C, p.H) * 32;
+    return true;
 }
 
 }  // namespace
@@ -645,8 +1087,12 @@ extern "C" int vs_mlp_rollout_parts(int compute, int B, int C, int H) { return p
 
 extern "C" size_t vs_mlp_rollout_workspace_bytes(int compute, int B, int C, int H) {
     const int P = pick_parts(compute, B, C, H);
-    if (P <= 1) return 0;
-    return (size_t)2 * ((B + 15) / 16) * P * 16 * round_up(C, 4) * sizeof(u64) + 16;
+    size_t need = P > 1 ? (size_t)2 * ((B + 15) / 16) * P * 16 * round_up(C, 4) * sizeof(u64) + 16 : 0;
+    if (compute == VS_BF16 && C <= 32 && (H == 128 || H == 256 || H == 512)) {       // weight-stationary form (any n_blocks)
+        const size_t ws = wsr::exchange_bytes(B, H) + 16;
+        if (ws > need) need = ws;
+    }
+    return need;
 }
 
 extern "C" int vs_mlp_rollout_fwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* x0,
@@ -662,6 +1108,8 @@ extern "C" int vs_mlp_rollout_fwd(int compute, int B, int C, int H, int n_blocks
     for (int i = 0; i < 3 * n_blocks; ++i) { p.W[i] = weights[i]; p.bias[i] = biases[i]; }
     p.x0 = x0; p.t_codes = t_codes; p.residuals = residuals;
     p.xin_save = xin_save; p.h1_save = h1_save; p.h2_save = h2_save; p.m1_save = m1_save; p.m2_save = m2_save;
+    int mask_pitch = 0;
+    if (setup_ws(p, compute, workspace, workspace_bytes, &mask_pitch)) return launch_ws(true, p, mask_pitch, p.xtotal, (hipStream_t)stream);
     setup_exchange(p, compute, workspace, workspace_bytes);
     return compute == VS_BF16 ? launch_roll<VS_BF16>(true, p, (hipStream_t)stream) : launch_roll<VS_F32>(true, p, (hipStream_t)stream);
 }
@@ -681,6 +1129,8 @@ extern "C" int vs_mlp_rollout_bwd(int compute, int B, int C, int H, int n_blocks
     p.h1_save = const_cast<void*>(h1_save); p.h2_save = const_cast<void*>(h2_save);
     p.m1_save = const_cast<uint32_t*>(m1_save); p.m2_save = const_cast<uint32_t*>(m2_save);
     p.dr_save = dr_save; p.dh2_save = dh2_save; p.dh1_save = dh1_save;
+    int mask_pitch = 0;
+    if (setup_ws(p, compute, workspace, workspace_bytes, &mask_pitch)) return launch_ws(false, p, mask_pitch, p.xtotal, (hipStream_t)stream);
     setup_exchange(p, compute, workspace, workspace_bytes);
     return compute == VS_BF16 ? launch_roll<VS_BF16>(false, p, (hipStream_t)stream) : launch_roll<VS_F32>(false, p, (hipStream_t)stream);
 }

@@ -252,8 +252,9 @@ def mlp_rollout_fwd(x0, weights, biases, n_steps, H, want_residuals=True):
     lib = _lib.load_library()
     code = dtype_code(weights[0])
     parts = lib.vs_mlp_rollout_parts(code, B, C, H)
-    m1 = torch.empty((nb, steps, B, parts, 32), dtype=torch.int32, device=dev)
-    m2 = torch.empty((nb, steps, B, parts, 32), dtype=torch.int32, device=dev)
+    Bp = (B + 15) // 16 * 16                 # sign-bit arrays: rows padded to whole 16-row slabs
+    m1 = torch.empty((nb, steps, Bp, parts, 32), dtype=torch.int32, device=dev)
+    m2 = torch.empty((nb, steps, Bp, parts, 32), dtype=torch.int32, device=dev)
     xws = _rollout_workspace(lib.vs_mlp_rollout_workspace_bytes(code, B, C, H), dev)
     wa, ba = _ptr_array(weights), _ptr_array(biases)
     e0 = _pb()
