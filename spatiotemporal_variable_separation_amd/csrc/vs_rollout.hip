@@ -622,12 +622,50 @@ constexpr int WT = 256;
 constexpr int XP = 40;            // LDS row pitch of the code operand (32 + 8: conflict-free ds_read_b128)
 constexpr int SP = 72;            // LDS row pitch of the hidden-slice operand (64 + 8)
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+#ifndef WS_NAP
+#define WS_NAP 8                  // s_sleep units (64 clocks) between seeing the producer's input and polling its partials
+#endif
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-typedef const __attribute__((address_space(4))) u64* const_u64_ptr;      // read-only for this kernel: scalar loads
 
 __device__ __forceinline__ u64 gload(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void gstore(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Two adjacent granules per load.  A relaxed agent-scope 8-byte atomic load is `global_load_dwordx2 ... sc1`; the exchange is
+// bound by the per-CU load issue rate, and a 16-byte `global_load_dwordx4 ... sc1` moves two granules per lane and issue slot
+// (each 8-byte half is still read untorn -- every granule carries its own tag, both are checked).  All loads of a round are
+// issued back to back inside one asm statement, which also waits for them (the compiler cannot track asm-issued loads).
+template <int N> struct GranulePairs;
+template <> struct GranulePairs<3> {
+    static __device__ __forceinline__ void load(u32x4* v, const u64* const* a) {
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2])
+                     : "memory");
+    }
+};
+template <> struct GranulePairs<5> {
+    static __device__ __forceinline__ void load(u32x4* v, const u64* const* a) {
+        asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\tglobal_load_dwordx4 %2, %7, off sc1\n\t"
+                     "global_load_dwordx4 %3, %8, off sc1\n\tglobal_load_dwordx4 %4, %9, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4])
+                     : "memory");
+    }
+};
+template <> struct GranulePairs<9> {
+    static __device__ __forceinline__ void load(u32x4* v, const u64* const* a) {
+        asm volatile("global_load_dwordx4 %0, %9, off sc1\n\tglobal_load_dwordx4 %1, %10, off sc1\n\tglobal_load_dwordx4 %2, %11, off sc1\n\t"
+                     "global_load_dwordx4 %3, %12, off sc1\n\tglobal_load_dwordx4 %4, %13, off sc1\n\tglobal_load_dwordx4 %5, %14, off sc1\n\t"
+                     "global_load_dwordx4 %6, %15, off sc1\n\tglobal_load_dwordx4 %7, %16, off sc1\n\tglobal_load_dwordx4 %8, %17, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8])
+                     : "memory");
+    }
+};
 // LDS-only workgroup barrier: __syncthreads() also drains the vector-memory counter (its release fence waits for every
 // outstanding global store -- the activation saves and the exchange granules -- to be acknowledged by L2); the barriers of a
 // block-step only order LDS traffic, so they wait for the LDS counter alone.
@@ -648,11 +686,14 @@ __device__ __forceinline__ unsigned pk_relu(unsigned v) {
     asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(v));
     return r;
 }
-// x where the lane's bit of `mask` is set, else 0 (mask = a stored v_cmp result of the forward pass: one bit per lane)
-__device__ __forceinline__ float keep_if(float x, u64 mask) {
-    float r;
-    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
-    return r;
+// x where the lane's bit of a stored v_cmp result is set, else 0.  `half` is the 32-bit half of the 64-lane mask that holds
+// this lane's bit, `sh` = 31 - (lane & 31) moves that bit to the sign position.
+__device__ __forceinline__ float keep_if(float x, unsigned half, int sh) { return (int)(half << sh) < 0 ? x : 0.f; }
+// sign bits of one 16-feature tile: words [0..3] = low halves of the four v_cmp masks (r = 0..3), [4..7] = high halves, so a
+// lane fetches its four bits with one 16-byte load
+__device__ __forceinline__ void store_tile_masks(unsigned* dst, const u64* bal) {
+    *reinterpret_cast<u32x4*>(dst) = u32x4{(unsigned)bal[0], (unsigned)bal[1], (unsigned)bal[2], (unsigned)bal[3]};
+    *reinterpret_cast<u32x4*>(dst + 4) = u32x4{(unsigned)(bal[0] >> 32), (unsigned)(bal[1] >> 32), (unsigned)(bal[2] >> 32), (unsigned)(bal[3] >> 32)};
 }
 
 #ifdef VS_WS_TIMING
@@ -687,7 +728,8 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
     const int row0 = slab * 16;
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (told to the compiler: scalar mask loads)
-    const int er = tid >> 5, ec = tid & 31;                   // exchange mapping: elements (er, ec) and (er + 8, ec)
+    const int er = tid >> 4, ec = 2 * (tid & 15);             // exchange mapping: the adjacent elements (er, ec) and (er, ec + 1)
+    const bool erow = row0 + er < B;
     const int own = 4 * part + w;                             // the 16-feature tile of the hidden dimension this wave finishes / saves
     const bool vrow = row0 + c < B;                           // MFMA results: lane (c, g) belongs to batch row c
 
@@ -719,13 +761,14 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
         if (code_tile) wc[s] = *reinterpret_cast<const u32x4*>(Wc + (((int64_t)(w & 1) * KH + 2 * part + s) * 64 + lane) * 8);
     }
     f32x4 bias_b = {0.f, 0.f, 0.f, 0.f};
-    float bc = 0.f;
+    float bc[2] = {0.f, 0.f};
     if (FWD) {
         for (int i = tid; i < H; i += WT) bias_a[i] = p.bias[3 * blk][i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias_b[r] = p.bias[3 * blk + 1][16 * own + 4 * g + r];
         const int prev = (blk + nb - 1) % nb;                  // the block whose output this workgroup consumes
-        bc = ec < C ? p.bias[3 * prev + 2][ec] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bc[i] = ec + i < C ? p.bias[3 * prev + 2][ec + i] : 0.f;
     }
     __syncthreads();
 
@@ -741,9 +784,19 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
         const int t = FWD ? it + 1 : n - 1 - it;                // time step of this block-step
         const int64_t sbase = ((int64_t)blk * (n - 1) + (t - 1)) * B + row0;
         // sign bits of this (block, step, slab): lane masks (v_cmp results: bit 16 g + c <-> feature 4 g + r of the tile, batch
-        // row c), 4 x 8 bytes per tile; the tile T = 4 j + w is stored at index 8 w + j so that a wave reads one contiguous run
+        // row c), 32 bytes per tile (store_tile_masks); the tile T = 4 j + w is stored at index NJ w + j: a wave reads one contiguous run
         const int64_t mofs = (((int64_t)blk * (n - 1) + (t - 1)) * Bp + row0) * mask_pitch;
-        const int mown = (NJ * w + part) * 4;                   // u64 index of this wave's own tile (T = 4 part + w)
+        const int mown = (NJ * w + part) * 8;                   // word index of this wave's own tile (T = 4 part + w)
+        // bwd: this lane's sign bits of the block-step do not depend on the recurrence: fetched before the wait
+        u32x4 mk_a[NJ], mk_ao = {0u, 0u, 0u, 0u}, mk_b = {0u, 0u, 0u, 0u};
+        const int msh = 31 - (lane & 31);
+        if (!FWD && !extra) {
+            const unsigned* m2w = p.m2_save + mofs + 4 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) mk_a[j] = *reinterpret_cast<const u32x4*>(m2w + (NJ * w + j) * 8);
+            mk_ao = *reinterpret_cast<const u32x4*>(m2w + mown);
+            mk_b = *reinterpret_cast<const u32x4*>(p.m1_save + mofs + 4 * (lane >> 5) + mown);
+        }
         WS_STAMP(0);
 
         // ---- 1. receive the block input (fwd: code x, bwd: running gradient) --------------------------------------
@@ -751,47 +804,45 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
         if (q == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int r = er + 8 * i;
                 float v = 0.f;
-                if (row0 + r < B && ec < C)
-                    v = FWD ? p.x0[(int64_t)(row0 + r) * C + ec] : p.g[((int64_t)(row0 + r) * n + (n - 1)) * C + ec];
+                if (erow && ec + i < C) v = FWD ? p.x0[(int64_t)(row0 + er) * C + ec + i] : p.g[((int64_t)(row0 + er) * n + (n - 1)) * C + ec + i];
                 xv[i] = v;
             }
         } else {
             const unsigned epoch = (unsigned)q;
-            u64 v[2][P + 1];
             unsigned spins = 0;
-            // cheap wait on ONE granule of the last-published kind (a partial), then fetch everything and verify
-            while ((unsigned)(gload(slot(epoch, P - 1) + er * 32 + ec) >> 32) != epoch) {
+            // Phase 1: cheap wait (one 8-byte load per thread and round) for the producer's block INPUT, which part 0 publishes a
+            // whole block-step of compute before the partials.  Phase 2: the partials are now ~1 us away -- after a fixed nap
+            // every round fetches all granules, so the round that finds them complete IS the fetch.
+            while ((unsigned)(gload(slot(epoch, P) + er * 32 + ec) >> 32) != epoch) {
                 if (++spins > SPIN_LIMIT) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            __builtin_amdgcn_s_sleep(WS_NAP);
+            u32x4 v[P + 1];
+            const u64* addr[P + 1];
+#pragma unroll
+            for (int s = 0; s <= P; ++s) addr[s] = slot(epoch, s) + er * 32 + ec;
             for (;;) {
+                GranulePairs<P + 1>::load(v, addr);
                 bool ok = true;
 #pragma unroll
-                for (int s = 0; s <= P; ++s) {
-                    v[0][s] = gload(slot(epoch, s) + er * 32 + ec);
-                    v[1][s] = gload(slot(epoch, s) + (er + 8) * 32 + ec);
-                }
-#pragma unroll
-                for (int s = 0; s <= P; ++s) ok = ok && (unsigned)(v[0][s] >> 32) == epoch && (unsigned)(v[1][s] >> 32) == epoch;
+                for (int s = 0; s <= P; ++s) ok = ok && v[s][1] == epoch && v[s][3] == epoch;
                 if (ok) break;
                 if (++spins > SPIN_LIMIT) { atomicOr(p.xerr, 1u); break; }
-                __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int r = er + 8 * i;
-                float res = __uint_as_float((unsigned)v[i][0]);
+                float res = __uint_as_float(v[0][2 * i]);
 #pragma unroll
-                for (int s = 1; s < P; ++s) res += __uint_as_float((unsigned)v[i][s]);
-                if (FWD) res += bc;
-                float x = __uint_as_float((unsigned)v[i][P]) + res;
-                const bool valid = row0 + r < B && ec < C;
+                for (int s = 1; s < P; ++s) res += __uint_as_float(v[s][2 * i]);
+                if (FWD) res += bc[i];
+                float x = __uint_as_float(v[P][2 * i]) + res;
+                const bool valid = erow && ec + i < C;
                 if (FWD) {
-                    if (p.residuals && part == 0 && valid) p.residuals[((int64_t)(q - 1) * B + row0 + r) * C + ec] = res;
+                    if (p.residuals && part == 0 && valid) p.residuals[((int64_t)(q - 1) * B + row0 + er) * C + ec + i] = res;
                 } else if (pos == 0 && valid) {
-                    x += p.g[((int64_t)(row0 + r) * n + t) * C + ec];      // entering time step t: add its upstream gradient
+                    x += p.g[((int64_t)(row0 + er) * n + t) * C + ec + i];      // entering time step t: add its upstream gradient
                 }
                 xv[i] = x;
             }
@@ -801,18 +852,16 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
             if (part == 0) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int r = er + 8 * i;
-                    if (row0 + r < B && ec < C) {
-                        if (FWD) p.t_codes[((int64_t)(row0 + r) * n + it) * C + ec] = xv[i];
-                        else p.dx0[(int64_t)(row0 + r) * C + ec] = xv[i];
+                    if (erow && ec + i < C) {
+                        if (FWD) p.t_codes[((int64_t)(row0 + er) * n + it) * C + ec + i] = xv[i];
+                        else p.dx0[(int64_t)(row0 + er) * C + ec + i] = xv[i];
                     }
                 }
             }
             break;
         }
         const unsigned epoch_out = (unsigned)q + 1u;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) xa[(er + 8 * i) * XP + ec] = (T)xv[i];
+        *reinterpret_cast<unsigned*>(xa + er * XP + ec) = pk_bf16(xv[0], xv[1]);
         WS_STAMP(2);
         lds_barrier();
         WS_STAMP(3);
@@ -820,14 +869,13 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
         if (part == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int r = er + 8 * i;
-                gstore(slot(epoch_out, P) + r * 32 + ec, ((u64)epoch_out << 32) | (u64)__float_as_uint(xv[i]));
-                if (row0 + r < B && ec < C) {
+                gstore(slot(epoch_out, P) + er * 32 + ec + i, ((u64)epoch_out << 32) | (u64)__float_as_uint(xv[i]));
+                if (erow && ec + i < C) {
                     if (FWD) {
-                        ((T*)p.xin_save)[(sbase + r) * C + ec] = (T)xv[i];
-                        if (pos == 0) p.t_codes[((int64_t)(row0 + r) * n + it) * C + ec] = xv[i];   // input of block 0 = code of time it
+                        ((T*)p.xin_save)[(sbase + er) * C + ec + i] = (T)xv[i];
+                        if (pos == 0) p.t_codes[((int64_t)(row0 + er) * n + it) * C + ec + i] = xv[i];   // input of block 0 = code of time it
                     } else {
-                        ((T*)p.dr_save)[(sbase + r) * C + ec] = (T)xv[i];
+                        ((T*)p.dr_save)[(sbase + er) * C + ec + i] = (T)xv[i];
                     }
                 }
             }
@@ -835,11 +883,6 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
 
         // ---- 2. layer a (code -> the features this wave contracts in layer b), results stay in registers ---------------
         const u32x4 xb = *reinterpret_cast<const u32x4*>(xa + c * XP + g * 8);
-        const_u64_ptr mask_a = nullptr, mask_b = nullptr;
-        if (!FWD) {
-            mask_a = (const_u64_ptr)(uintptr_t)(p.m2_save + mofs);        // ReLU mask of h2: gates dh2 (layer a of the backward chain)
-            mask_b = (const_u64_ptr)(uintptr_t)(p.m1_save + mofs);        // ReLU mask of h1: gates dh1 (layer b)
-        }
         f32x4 aa[NJ], ao = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -860,8 +903,8 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    a0[r] = keep_if(a0[r], mask_a[(NJ * w + 2 * jj) * 4 + r]);
-                    a1[r] = keep_if(a1[r], mask_a[(NJ * w + 2 * jj + 1) * 4 + r]);
+                    a0[r] = keep_if(a0[r], mk_a[2 * jj][r], msh);          // ReLU mask of h2 gates dh2
+                    a1[r] = keep_if(a1[r], mk_a[2 * jj + 1][r], msh);
                 }
                 hf[jj] = u32x4{pk_bf16(a0[0], a0[1]), pk_bf16(a0[2], a0[3]), pk_bf16(a1[0], a1[1]), pk_bf16(a1[2], a1[3])};
             }
@@ -887,14 +930,10 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bal[r] = __ballot(ao[r] > 0.f);
                 pk = u32x2{pk_relu(pk_bf16(ao[0], ao[1])), pk_relu(pk_bf16(ao[2], ao[3]))};
-                if (lane == 0) {
-                    u64* mdst = reinterpret_cast<u64*>(p.m1_save + mofs) + mown;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mdst[r] = bal[r];
-                }
+                if (lane == 0) store_tile_masks(p.m1_save + mofs + mown, bal);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ao[r] = keep_if(ao[r], mask_a[mown + r]);
+                for (int r = 0; r < 4; ++r) ao[r] = keep_if(ao[r], mk_ao[r], msh);
                 pk = u32x2{pk_bf16(ao[0], ao[1]), pk_bf16(ao[2], ao[3])};
             }
             if (vrow) {
@@ -920,14 +959,10 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bal[r] = __ballot(sum[r] > 0.f);
                 pk = u32x2{pk_relu(pk_bf16(sum[0], sum[1])), pk_relu(pk_bf16(sum[2], sum[3]))};
-                if (lane == 0) {
-                    u64* mdst = reinterpret_cast<u64*>(p.m2_save + mofs) + mown;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mdst[r] = bal[r];
-                }
+                if (lane == 0) store_tile_masks(p.m2_save + mofs + mown, bal);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sum[r] = keep_if(sum[r], mask_b[mown + r]);
+                for (int r = 0; r < 4; ++r) sum[r] = keep_if(sum[r], mk_b[r], msh);            // ReLU mask of h1 gates dh1
                 pk = u32x2{pk_bf16(sum[0], sum[1]), pk_bf16(sum[2], sum[3])};
             }
             *reinterpret_cast<u32x2*>(ah2 + c * SP + 16 * w + 4 * g) = pk;
