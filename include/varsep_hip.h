@@ -116,6 +116,20 @@ int vs_colsum(const void* X, int x_dtype, int64_t ldx, int64_t M, int64_t N, flo
 int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const int64_t* ldx, const int64_t* M, const int64_t* N,
                     float* const* out, float* zero_base, int64_t zero_count, void* stream);
 
+/* Adam update of up to 64 fp32 tensors in one launch (reference: train.py:156-158 `optimizer.step()` on
+ * torch.optim.Adam(lr, betas): weight_decay 0, amsgrad off; same operation order as torch's single-tensor path:
+ *   m += (1-b1)(g-m); v = b2 v + (1-b2) g g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = step[0] + 1).
+ * `step` is an int32 ON THE DEVICE (capturable into a hipGraph); it is NOT modified here -- several vs_adam_multi calls
+ * of one optimizer step (more than 64 tensors) share it, then vs_adam_step_increment bumps it once.
+ * skipped (host array or NULL): optimizer steps a tensor sat out without gradient -- torch counts steps per parameter, so
+ * its t is step[0] + 1 - skipped[i].
+ * shadow_bf16 (array or NULL, entries may be NULL): bf16 copy of the updated parameter written in the same pass (the
+ * operand copy the bf16 forward pass reads).  Every tensor 16-byte aligned, contiguous.                                  */
+int vs_adam_multi(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step, double lr, double beta1,
+                  double beta2, double eps, void* stream);
+int vs_adam_step_increment(int32_t* step, void* stream);
+
 /* Fused frame losses (train.py:85-86 ae_loss MSE and train.py:139 forecast MSE in one pass over the decoded frames).
  * frames [B, G, D] fp32: per sample the auto-encoding reconstruction (g = 0) followed by the G-1 forecasts; full [B, T, D]
  * fp32: every observed frame; idx [G] int32 ON THE DEVICE: frame g is compared with full[:, idx[g]].

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvarsep_hip.so')
-SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip']
+SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip']
 
 F32, BF16 = 0, 1
 ACT = {'none': 0, None: 0, 'identity': 0, 'relu': 1, 'leaky_relu': 2, 'sigmoid': 3, 'tanh': 4, 'elu': 5}
@@ -87,6 +87,9 @@ SIGNATURES = {
     'vs_copy2d': (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp]),
     'vs_colsum': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     'vs_colsum_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    'vs_adam_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                             ctypes.c_double, _vp]),
+    'vs_adam_step_increment': (_i32, [_vp, _vp]),
     'vs_frames_sse_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp]),
     'vs_frames_sse_bwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp]),
     'vs_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),

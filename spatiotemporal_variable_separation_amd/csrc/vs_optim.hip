@@ -1,0 +1,126 @@
+// vs_optim.hip -- the Adam update of the training loop (reference: train.py:156-158 `optimizer.step()` with
+// torch.optim.Adam(lr, betas), weight_decay = 0, amsgrad = False) for every parameter of the model in ONE launch.
+//
+// HBM-bound by construction: per parameter 16 B read (p, g, m, v) + 12 B written (p, m, v), optionally + 2 B for the bf16
+// operand copy the next forward pass reads.  One launch walks a table of up to 64 tensors in 16 KiB chunks (a chunk never
+// straddles two tensors), 16-byte vector accesses, every workgroup fully used whatever the mix of tensor sizes (the WaveEq
+// model has two 24.6 M-element matrices next to 32-element biases).  The step count lives on the device, so the launch is
+// recordable into a hipGraph.
+#include "vs_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int AD_MAXJ = 64;
+constexpr int AD_CHUNK = 4096;          // elements per workgroup iteration
+
+struct AdamJobs {
+    float* p[AD_MAXJ];
+    const float* g[AD_MAXJ];
+    float* m[AD_MAXJ];
+    float* v[AD_MAXJ];
+    __bf16* shadow[AD_MAXJ];            // optional bf16 copy of the updated parameter
+    long long n[AD_MAXJ];
+    int skipped[AD_MAXJ];               // optimizer steps this tensor sat out (no gradient): its own step count lags the group's
+    int chunk_off[AD_MAXJ + 1];         // prefix sum of chunk counts
+    int nj;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* __restrict__ step, double lr_d, double beta1_d, double beta2_d,
+                                                         float eps) {
+    // hyper-parameters arrive in double like the Python floats torch works with: 1 - beta and beta^t are formed in double
+    const float lr = (float)lr_d, beta2 = (float)beta2_d;
+    // bias corrections from the device-side step count (the count is incremented by a separate 1-thread launch AFTER this one,
+    // so every workgroup of this launch reads the same value)
+    const int t_group = step[0] + 1;
+    const float w1 = (float)(1.0 - beta1_d), w2 = (float)(1.0 - beta2_d);
+    const int total = J.chunk_off[J.nj];
+    for (int ch = blockIdx.x; ch < total; ch += gridDim.x) {
+        int j = 0;                                            // uniform per workgroup: scalar search over <= 64 entries
+        while (J.chunk_off[j + 1] <= ch) ++j;
+        const double t = (double)(t_group - J.skipped[j]);
+        const float bc1 = (float)(1.0 - pow(beta1_d, t));
+        const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2_d, t));
+        const float step_size = lr / bc1;
+        const long long base = (long long)(ch - J.chunk_off[j]) * AD_CHUNK;
+        const long long n = J.n[j];
+        float* __restrict__ P = J.p[j];
+        const float* __restrict__ G = J.g[j];
+        float* __restrict__ M = J.m[j];
+        float* __restrict__ V = J.v[j];
+        __bf16* __restrict__ S = J.shadow[j];
+#pragma unroll
+        for (int u = 0; u < AD_CHUNK / 1024; ++u) {
+            const long long i = base + (long long)u * 1024 + threadIdx.x * 4;
+            if (i + 3 < n) {
+                f32x4 p = *reinterpret_cast<const f32x4*>(P + i), g = *reinterpret_cast<const f32x4*>(G + i);
+                f32x4 m = *reinterpret_cast<const f32x4*>(M + i), v = *reinterpret_cast<const f32x4*>(V + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m[e] = m[e] + w1 * (g[e] - m[e]);                       // exp_avg.lerp_(grad, 1 - beta1)
+                    v[e] = v[e] * beta2 + (w2 * g[e]) * g[e];              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+                    const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
+                    p[e] = p[e] - step_size * (m[e] / denom);              // param.addcdiv_(exp_avg, denom, -step_size)
+                }
+                *reinterpret_cast<f32x4*>(P + i) = p;
+                *reinterpret_cast<f32x4*>(M + i) = m;
+                *reinterpret_cast<f32x4*>(V + i) = v;
+                if (S) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    bf16x4 s = {(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
+                    *reinterpret_cast<bf16x4*>(S + i) = s;
+                }
+            } else {
+                for (long long k = i; k < n && k < i + 4; ++k) {
+                    const float g = G[k];
+                    const float m = M[k] + w1 * (g - M[k]);
+                    const float v = V[k] * beta2 + (w2 * g) * g;
+                    const float denom = sqrtf(v) / bc2_sqrt + eps;
+                    const float p = P[k] - step_size * (m / denom);
+                    P[k] = p; M[k] = m; V[k] = v;
+                    if (S) S[k] = (__bf16)p;
+                }
+            }
+        }
+    }
+}
+
+__global__ void step_increment_kernel(int* step) { step[0] += 1; }
+
+}  // namespace
+
+extern "C" int vs_adam_multi(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                             void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step, double lr, double beta1, double beta2, double eps,
+                             void* stream) {
+    VS_CHECK_ARG(n_tensors >= 1 && n_tensors <= AD_MAXJ && params && grads && exp_avg && exp_avg_sq && numel && step,
+                 "vs_adam_multi: bad argument (1..%d tensors)", AD_MAXJ);
+    VS_CHECK_ARG(lr > 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps > 0.0, "vs_adam_multi: bad hyper-parameter");
+    AdamJobs J;
+    J.nj = n_tensors;
+    J.chunk_off[0] = 0;
+    for (int j = 0; j < n_tensors; ++j) {
+        VS_CHECK_ARG(params[j] && grads[j] && exp_avg[j] && exp_avg_sq[j] && numel[j] > 0, "vs_adam_multi: bad tensor %d", j);
+        VS_CHECK_ARG(((uintptr_t)params[j] | (uintptr_t)grads[j] | (uintptr_t)exp_avg[j] | (uintptr_t)exp_avg_sq[j]) % 16 == 0,
+                     "vs_adam_multi: tensor %d is not 16-byte aligned", j);
+        J.p[j] = params[j]; J.g[j] = grads[j]; J.m[j] = exp_avg[j]; J.v[j] = exp_avg_sq[j];
+        J.shadow[j] = shadow_bf16 ? (__bf16*)shadow_bf16[j] : nullptr;
+        VS_CHECK_ARG(!J.shadow[j] || (uintptr_t)J.shadow[j] % 8 == 0, "vs_adam_multi: shadow %d is not 8-byte aligned", j);
+        J.n[j] = numel[j];
+        J.skipped[j] = skipped ? skipped[j] : 0;
+        const int64_t chunks = (numel[j] + AD_CHUNK - 1) / AD_CHUNK;
+        VS_CHECK_ARG(J.chunk_off[j] + chunks < (1ll << 30), "vs_adam_multi: too many elements");
+        J.chunk_off[j + 1] = J.chunk_off[j] + (int)chunks;
+    }
+    int blocks = J.chunk_off[n_tensors];
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J, step, lr, beta1, beta2, (float)eps);
+    VS_CHECK_LAUNCH("vs_adam_multi");
+    return VS_OK;
+}
+
+extern "C" int vs_adam_step_increment(int32_t* step, void* stream) {
+    VS_CHECK_ARG(step, "vs_adam_step_increment: null pointer");
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    VS_CHECK_LAUNCH("vs_adam_step_increment");
+    return VS_OK;
+}

@@ -110,6 +110,22 @@ def shadow(p, dtype):
     return ent[1]
 
 
+def shadow_buffer_for_update(p):
+    """The live bf16 operand copy of `p`, if one exists: the optimizer kernel rewrites it in the pass that updates `p`."""
+    ent = _shadow.get(id(p))
+    if ent is not None and ent[2] is p and ent[1].shape == p.shape and ent[1].dtype == torch.bfloat16 and ent[1].is_contiguous():
+        return ent[1]
+    return None
+
+
+def shadows_written(params):
+    """Called after an optimizer kernel refreshed the shadows of `params` in place: mark them current."""
+    for p in params:
+        ent = _shadow.get(id(p))
+        if ent is not None and ent[2] is p:
+            _shadow[id(p)] = (p._version, ent[1], p)
+
+
 def refresh_shadows(params, dtype=torch.bfloat16):
     """Re-cast every shadow in place (same storage) -- the form used inside a captured hipGraph step."""
     for p in params:

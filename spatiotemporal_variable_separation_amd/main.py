@@ -113,7 +113,9 @@ def main(argv=None):
         broadcast_module_state(sep_net)
         grad_sync = GradAllReducer(sep_net.parameters())
 
-    optimizer = optim.Adam(sep_net.parameters(), lr=args.lr, betas=(args.beta1, args.beta2), capturable=bool(args.hip_graph))
+    # same constructor call as the reference (main.py:133); the update runs as one multi-tensor HIP launch (optim.py)
+    from .optim import Adam
+    optimizer = Adam(sep_net.parameters(), lr=args.lr, betas=(args.beta1, args.beta2))
     scheduler = lr_scheduler.MultiStepLR(optimizer, args.scheduler_milestones, gamma=args.scheduler_decay) \
         if args.scheduler else None
 

@@ -1,0 +1,121 @@
+"""Adam on the HIP path (reference: main.py:133 `optim.Adam(sep_net.parameters(), lr, betas)` + train.py:156-158).
+
+`Adam` is a `torch.optim.Optimizer` (same constructor arguments, `state_dict()` layout: per-parameter `step`, `exp_avg`,
+`exp_avg_sq`), whose `step()` updates every parameter of a group with ONE `vs_adam_multi` launch per 64 tensors instead
+of torch's per-dtype/per-device multi-tensor kernels: the update is HBM-bound (28 bytes per parameter) and the launch
+walks the tensors in 16 KiB chunks so that the two 24.6 M-element encoder matrices and the 32-element biases of the
+WaveEq model keep every CU streaming.  The step count lives on the device, so `step()` can be recorded into a hipGraph
+(train.GraphedStep) without `capturable=True` plumbing.  Only what the reference uses is supported: no weight decay, no
+amsgrad, no maximize; fp32 CUDA parameters (anything else raises: there is no CPU fallback on the product path)."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import VarsepHipError
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, capturable=True, fused=None):
+        if weight_decay != 0 or amsgrad:
+            raise ValueError('the MI355X Adam implements what the reference uses: weight_decay=0, amsgrad=False')
+        if not 0.0 < lr or not 0.0 < eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError('invalid Adam hyper-parameters')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._tables = {}
+
+    # ---- state -------------------------------------------------------------------------------------------------
+    def _init_group(self, gi, group):
+        """Device step counter per group + (exp_avg, exp_avg_sq) per parameter, created on first use."""
+        for p in group['params']:
+            st = self.state[p]
+            if len(st) == 0:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise VarsepHipError('HIP Adam needs contiguous fp32 CUDA parameters (no CPU fallback)')
+                st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)        # torch's capturable layout
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if 'step_dev' not in group:
+            ps = group['params']
+            steps = [int(self.state[p]['step'].item()) for p in ps]
+            start = max(steps) if steps else 0
+            for p, t in zip(ps, steps):
+                self.state[p]['skipped'] = start - t
+            group['step_dev'] = torch.full((1,), start, dtype=torch.int32, device=ps[0].device)
+
+    def _table(self, gi, plist, shadows):
+        """ctypes pointer tables of one chunk of <= 64 tensors; rebuilt only when a pointer changes (a new .grad tensor after
+        zero_grad(set_to_none=True) in the eager loop; stable inside a recorded graph and with flat gradient buckets)."""
+        key = (gi, id(plist[0]), len(plist))
+        ptrs = tuple((p.data_ptr(), p.grad.data_ptr(), 0 if s is None else s.data_ptr(), self.state[p].get('skipped', 0))
+                     for p, s in zip(plist, shadows))
+        ent = self._tables.get(key)
+        if ent is not None and ent[0] == ptrs:
+            return ent[1]
+        n = len(plist)
+        VP, I64, I32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+        tab = (VP(*[p.data_ptr() for p in plist]), VP(*[p.grad.data_ptr() for p in plist]),
+               VP(*[self.state[p]['exp_avg'].data_ptr() for p in plist]), VP(*[self.state[p]['exp_avg_sq'].data_ptr() for p in plist]),
+               VP(*[None if s is None else s.data_ptr() for s in shadows]), I64(*[p.numel() for p in plist]),
+               I32(*[self.state[p].get('skipped', 0) for p in plist]))
+        self._tables[key] = (ptrs, tab)
+        return tab
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        from . import functional as VF
+        lib = _lib.load_library()
+        for gi, group in enumerate(self.param_groups):
+            self._init_group(gi, group)
+            live = [p for p in group['params'] if p.grad is not None]
+            for p in group['params']:
+                if p.grad is None:                   # torch counts steps per parameter: this one falls one behind the group
+                    self.state[p]['skipped'] = self.state[p].get('skipped', 0) + 1
+            if not live:
+                group['step_dev'] += 1
+                continue
+            for p in live:
+                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or not p.grad.is_cuda:
+                    raise VarsepHipError('HIP Adam needs contiguous fp32 CUDA gradients')
+            stream = torch.cuda.current_stream(live[0].device).cuda_stream
+            lr, (b1, b2), eps = group['lr'], group['betas'], group['eps']
+            for i in range(0, len(live), 64):
+                chunk = live[i:i + 64]
+                shadows = [VF.shadow_buffer_for_update(p) for p in chunk]
+                tab = self._table(gi, chunk, shadows)
+                rc = lib.vs_adam_multi(len(chunk), ctypes.cast(tab[0], ctypes.c_void_p), ctypes.cast(tab[1], ctypes.c_void_p),
+                                       ctypes.cast(tab[2], ctypes.c_void_p), ctypes.cast(tab[3], ctypes.c_void_p),
+                                       ctypes.cast(tab[4], ctypes.c_void_p), ctypes.cast(tab[5], ctypes.c_void_p),
+                                       ctypes.cast(tab[6], ctypes.c_void_p), group['step_dev'].data_ptr(), lr, b1, b2, eps, stream)
+                _lib.check(rc, 'vs_adam_multi')
+            _lib.check(lib.vs_adam_step_increment(group['step_dev'].data_ptr(), stream), 'vs_adam_step_increment')
+            for p in live:
+                # the kernel wrote through raw pointers: tell autograd / the operand caches that the parameter changed
+                torch.autograd.graph.increment_version(p)
+            VF.shadows_written(live)
+        return loss
+
+    def state_dict(self):
+        # keep the per-parameter `step` entries (torch layout) in sync with the device counter before serialising
+        for group in self.param_groups:
+            if 'step_dev' in group:
+                t = float(group['step_dev'].item())
+                for p in group['params']:
+                    if p in self.state and 'step' in self.state[p]:
+                        self.state[p]['step'].fill_(t - self.state[p].get('skipped', 0))
+        sd = super().state_dict()
+        for g in sd['param_groups']:
+            g.pop('step_dev', None)
+        for st in sd['state'].values():
+            st.pop('skipped', None)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            group.pop('step_dev', None)              # re-created from the loaded per-parameter step on the next step()
+        self._tables = {}

@@ -148,7 +148,8 @@ class GraphedStep:
     GPU needs to execute them, so the eager loop is host-bound.  Stream capture (torch.cuda.CUDAGraph = hipGraph on ROCm)
     records the kernels the C-ABI library launches on the capture stream together with torch's own; the only per-step host
     inputs -- the batch and the random window end `t_random` (train.py:72-75) -- enter through static device buffers, and
-    every use of `t_random` inside the step is device-side.  Requires Adam(capturable=True)."""
+    every use of `t_random` inside the step is device-side.  The optimizer is optim.Adam (HIP, always recordable) or
+    torch.optim.Adam(capturable=True); a learning-rate change by a scheduler triggers a re-recording."""
 
     def __init__(self, sep_net, optimizer, cond, target, nt_cond, nt_pred, offset, lambdas, average_tloss=False, warmup=3,
                  side_streams=True, grad_sync=None):
@@ -156,6 +157,7 @@ class GraphedStep:
         # deferred weight gradients require that nothing reads a gradient before join_side_streams(): not the case when they
         # are accumulated into the reducer's (pre-existing) flat buckets
         self.side_streams = side_streams and grad_sync is None and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
+        check_optimizer(optimizer)
         self.net, self.opt, self.sync = sep_net, optimizer, grad_sync
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
         self.cond, self.target = cond.clone(), target.clone()
@@ -171,6 +173,11 @@ class GraphedStep:
                 self._reduce()
                 self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
+        self._capture()
+
+    def _capture(self):
+        grad_sync = self.sync
+        self._lrs = [g['lr'] for g in self.opt.param_groups]
         self._draw()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
@@ -221,12 +228,22 @@ class GraphedStep:
         if cond is not None:
             self.cond.copy_(cond, non_blocking=True)
             self.target.copy_(target, non_blocking=True)
+        if [g['lr'] for g in self.opt.param_groups] != self._lrs:
+            self._capture()                          # a scheduler moved the learning rate: it is a launch argument of the recording
         self._draw()
         self.graph.replay()
         if self.graph_opt is not None:
             self._reduce()
             self.graph_opt.replay()
         return self.loss
+
+
+def check_optimizer(optimizer):
+    """torch's fused=True optimizers update parameters without bumping their version counters, which is what the bf16 operand
+    copies and the pre-packed weights are keyed on: training would silently continue on stale weights.  Refuse them."""
+    if getattr(optimizer, 'defaults', {}).get('fused'):
+        raise ValueError('torch optimizers with fused=True do not invalidate the bf16 operand copies / weight pre-packs of the HIP '
+                         'path; use spatiotemporal_variable_separation_amd.optim.Adam (one HIP launch) or a non-fused optimizer')
 
 
 def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb_ae, lamb_s, lamb_t, lamb_pred,
@@ -265,6 +282,7 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
     """
     import time
     from . import functional as VF
+    check_optimizer(optimizer)
     if use_apex_amp:
         raise ImportError('Apex is not part of the MI355X-native path; use --torch_amp (bf16 MFMA, fp32 master weights)')
     if use_torch_amp:

@@ -1,0 +1,115 @@
+"""HIP multi-tensor Adam (vs_adam_multi) against torch.optim.Adam, the optimizer the reference constructs (main.py:133)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(1200, 777), (32,), (5, 3, 4, 4), (4096 * 3 + 5,), (1,), (64, 64)]
+    return [torch.nn.Parameter((torch.rand(s, generator=g) - 0.5).cuda()) for s in shapes]
+
+
+@pytest.mark.parametrize('lr,betas', [(4e-4, (0.9, 0.99)), (1e-3, (0.5, 0.999))])
+def test_adam_matches_torch(lr, betas):
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    pa, pb = _params(0), _params(0)
+    oa = Adam(pa, lr=lr, betas=betas)
+    ob = torch.optim.Adam(pb, lr=lr, betas=betas)
+    g = torch.Generator().manual_seed(1)
+    for step in range(5):
+        for a, b in zip(pa, pb):
+            gr = (torch.rand(a.shape, generator=g) - 0.5).cuda() * (10.0 ** (step - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        if step == 3:
+            pa[1].grad = None                      # a parameter without gradient is skipped, like torch does
+            pb[1].grad = None
+        v0 = pa[0]._version
+        oa.step()
+        ob.step()
+        assert pa[0]._version > v0                 # operand caches keyed on the version counter see the update
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (step, a.shape, (a - b).abs().max().item())
+    sa, sb = oa.state_dict(), ob.state_dict()
+    for k in sb['state']:
+        for name in ('exp_avg', 'exp_avg_sq'):
+            assert torch.allclose(sa["state"][k][name], sb["state"][k][name], rtol=1e-5, atol=1e-6)
+    assert float(sa['state'][0]['step']) == 5.0
+
+
+def test_adam_writes_bf16_shadow_and_is_graph_capturable():
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    p = _params(3)[:2]
+    sh = VF.shadow(p[0], torch.bfloat16)                     # creates the cached operand copy
+    opt = Adam(p, lr=1e-2, betas=(0.9, 0.99))
+    for q in p:
+        q.grad = torch.ones_like(q)
+    opt.step()                                                # warm-up (allocates state) outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        opt.step()
+    ref = [q.detach().clone() for q in p]
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(ref[0], p[0])
+    assert VF.shadow(p[0], torch.bfloat16).data_ptr() == sh.data_ptr()
+    assert torch.equal(sh, p[0].detach().to(torch.bfloat16))  # refreshed in the same pass, no separate cast
+    # 1 eager + 3 replayed steps == 4 torch steps
+    q = _params(3)[:2]
+    ob = torch.optim.Adam(q, lr=1e-2, betas=(0.9, 0.99))
+    for _ in range(4):
+        for t in q:
+            t.grad = torch.ones_like(t)
+        ob.step()
+    for a, b in zip(p, q):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+
+
+def test_adam_rejects_cpu_parameters():
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd._lib import VarsepHipError
+    p = [torch.nn.Parameter(torch.zeros(4))]
+    p[0].grad = torch.ones(4)
+    with pytest.raises(VarsepHipError):
+        Adam(p).step()
+
+
+def test_bf16_training_follows_the_fp32_master_weights():
+    """Regression: the bf16 operand copies must track the optimizer.  HIP Adam (writes them in its own pass) and torch's
+    non-fused Adam (bumps the version counters) give the same loss trajectory; torch's fused Adam is refused."""
+    import numpy as np
+    from oracle.detdata import det_fill
+    from oracle.golden_configs import CONFIGS, make_batch
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.train import check_optimizer, compute_losses
+    cfg = CONFIGS['mlp_mul']
+    lam = cfg['lambdas']
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+
+    def run(make):
+        net = det_fill(build_sep_net(cfg), salt=cfg['salt']).cuda().train()
+        opt = make(net.parameters())
+        np.random.seed(3)
+        out = []
+        with VF.precision('bf16'):
+            for _ in range(8):
+                opt.zero_grad(set_to_none=True)
+                total = compute_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], False, lam['ae'], lam['s'],
+                                       lam['t'], lam['pred'])[0]
+                total.backward()
+                opt.step()
+                out.append(total.item())
+        return out
+    hip = run(lambda ps: Adam(ps, lr=2e-3, betas=(0.9, 0.99)))
+    ref = run(lambda ps: torch.optim.Adam(ps, lr=2e-3, betas=(0.9, 0.99)))
+    assert hip[-1] < 0.9 * hip[0]                              # it trains
+    assert np.allclose(hip, ref, rtol=2e-2), (hip, ref)
+    with pytest.raises(ValueError):
+        check_optimizer(torch.optim.Adam([torch.nn.Parameter(torch.zeros(4, device='cuda'))], fused=True))
