@@ -116,6 +116,20 @@ int vs_colsum(const void* X, int x_dtype, int64_t ldx, int64_t M, int64_t N, flo
 int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const int64_t* ldx, const int64_t* M, const int64_t* N,
                     float* const* out, float* zero_base, int64_t zero_count, void* stream);
 
+/* All four training losses and their weighted sum in one pass (train.py:117-149, MLP-family layout):
+ *   total = l_ae mse(frames[:,0], full[:,idx[0]]) + l_s mean((s_old-s_new)^2) + l_pred mse(frames[:,1:], full[:,idx[1:]])
+ *           + l_t t_reg,   t_reg = 0.5 mean_b sum_c t0^2 (average_tloss: 0.5 mean_{b,c} t0^2);  lambdas = {l_ae, l_s, l_t, l_pred}
+ *   (host).  n_s = number of spatial-code elements (0: no spatial term, s_old/s_new may be NULL).
+ *   fwd: out [10] floats on the device: [4] total, [5] ae, [6] zero-order, [7] pred, [8] t_reg ([0..3], [9] scratch).
+ *   bwd: grad_total = upstream gradient of `total` (1 float ON THE DEVICE); writes dframes [B,G,D], ds_old, ds_new [n_s], dt0.  */
+int vs_train_losses_fwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D,
+                        const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
+                        int average_tloss, const float* lambdas, float* out, void* stream);
+int vs_train_losses_bwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D,
+                        const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
+                        int average_tloss, const float* lambdas, const float* grad_total, float* dframes, float* ds_old,
+                        float* ds_new, float* dt0, void* stream);
+
 /* Adam update of up to 64 fp32 tensors in one launch (reference: train.py:156-158 `optimizer.step()` on
  * torch.optim.Adam(lr, betas): weight_decay 0, amsgrad off; same operation order as torch's single-tensor path:
  *   m += (1-b1)(g-m); v = b2 v + (1-b2) g g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = step[0] + 1).
@@ -124,7 +138,7 @@ int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const 
  * skipped (host array or NULL): optimizer steps a tensor sat out without gradient -- torch counts steps per parameter, so
  * its t is step[0] + 1 - skipped[i].
  * shadow_bf16 (array or NULL, entries may be NULL): bf16 copy of the updated parameter written in the same pass (the
- * operand copy the bf16 forward pass reads).  Every tensor 16-byte aligned, contiguous.                                  */
+ * operand copy the bf16 forward pass reads).  Tensors contiguous; 16-byte aligned ones take the vector path.                                  */
 int vs_adam_multi(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                   void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step, double lr, double beta1,
                   double beta2, double eps, void* stream);
@@ -192,6 +206,9 @@ int vs_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, 
  * vs_rollout_packed_elems(compute, N, K) elements of the compute type.  Re-run after each optimizer step.          */
 size_t vs_rollout_packed_elems(int compute, int N, int K);
 int vs_pack_rollout_weight(int compute, const float* src, int transpose, int N, int K, void* dst, void* stream);
+/* The same for several weights in one launch (<= 48 jobs): src[i] fp32 [rows, cols], logical L = src or src^T [N[i], K[i]]. */
+int vs_pack_rollout_weights(int compute, int n_jobs, const float* const* src, const int* transpose, const int* N, const int* K,
+                            void* const* dst, void* stream);
 
 int vs_mlp_rollout_parts(int compute, int B, int C, int H);
 size_t vs_mlp_rollout_workspace_bytes(int compute, int B, int C, int H);

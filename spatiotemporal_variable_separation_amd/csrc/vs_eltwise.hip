@@ -171,6 +171,157 @@ __global__ __launch_bounds__(256) void frames_sse_bwd_kernel(const float* frames
 
 }  // namespace
 
+// ---- all four training losses in one pass (train.py:117-149) -------------------------------------------------------------
+//   total = l_ae * mse(frame 0) + l_s * mean((s_old - s_new)^2) + l_pred * mse(frames 1..) + l_t * t_reg
+//   t_reg = 0.5 * mean_b sum_c t0^2   (average_tloss: 0.5 * mean_{b,c} t0^2)
+// Composed from torch ops this tail is ~30 launches of 2-5 us forward and as many backward -- 12 % of a WaveEq step that is
+// otherwise MFMA/HBM work.  Forward: one zero fill + ONE kernel (frame rows walked by all workgroups, the two small code terms
+// by workgroup 0, the last workgroup to finish assembles the scalars); backward: ONE kernel writing every gradient.
+namespace {
+struct LossArgs {
+    const float* frames; const float* full; const int* idx;
+    int64_t rows, D; int G, T;
+    const float* s_old; const float* s_new; int64_t n_s;      // spatial codes (n_s = 0: no spatial term)
+    const float* t0; int64_t Bt, Ct;                           // initial temporal code [Bt, Ct]
+    float l_ae, l_s, l_pred, l_t;
+    float inv_ae, inv_pred, inv_s, inv_t;                      // 1/N of each mean
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// out: [0..3] raw sums (SSE frame 0, SSE frames 1.., sum (s_old - s_new)^2, sum t0^2), [4] total, [5] ae, [6] zero, [7] pred,
+//      [8] t_reg, [9] ticket (int)
+__global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float* out) {
+    __shared__ float red[4];
+    __shared__ int last;
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
+        const int g = (int)(r % a.G);
+        const int64_t b = r / a.G;
+        const float* f = a.frames + r * a.D;
+        const float* t = a.full + (b * a.T + a.idx[g]) * a.D;
+        float s = 0.f;
+        for (int64_t i = (int64_t)threadIdx.x * 4; i + 3 < a.D; i += 1024) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(f + i), y = *reinterpret_cast<const f32x4*>(t + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = x[j] - y[j]; s += d * d; }
+        }
+        if (threadIdx.x == 0)
+            for (int64_t i = a.D & ~(int64_t)3; i < a.D; ++i) { const float d = f[i] - t[i]; s += d * d; }
+        if (g == 0) s0 += s; else s1 += s;
+    }
+    s0 = block_sum_256(s0, red);
+    s1 = block_sum_256(s1, red);
+    if (threadIdx.x == 0) { atomicAdd(out, s0); atomicAdd(out + 1, s1); }
+    if (blockIdx.x == 0) {                                     // the two code terms are tiny: one workgroup, fixed order
+        float ss = 0.f, st = 0.f;
+        for (int64_t i = threadIdx.x; i < a.n_s; i += 256) { const float d = a.s_old[i] - a.s_new[i]; ss += d * d; }
+        for (int64_t i = threadIdx.x; i < a.Bt * a.Ct; i += 256) { const float v = a.t0[i]; st += v * v; }
+        ss = block_sum_256(ss, red);
+        st = block_sum_256(st, red);
+        if (threadIdx.x == 0) { atomicAdd(out + 2, ss); atomicAdd(out + 3, st); }
+    }
+    // the workgroup that takes the last ticket sees every contribution (release by each, acquire by the last)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int t = atomicAdd(reinterpret_cast<int*>(out + 9), 1);
+        last = (t == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const float sse0 = atomicAdd(out, 0.f), sse1 = atomicAdd(out + 1, 0.f), ssd = atomicAdd(out + 2, 0.f), sst = atomicAdd(out + 3, 0.f);
+        const float ae = sse0 * a.inv_ae, pred = sse1 * a.inv_pred, zero = ssd * a.inv_s, treg = 0.5f * sst * a.inv_t;
+        out[5] = ae; out[6] = zero; out[7] = pred; out[8] = treg;
+        out[4] = a.l_ae * ae + a.l_s * zero + a.l_pred * pred + a.l_t * treg;      // same association as train.py:146-149
+    }
+}
+
+// gradients of `total` times the upstream scalar *g: dframes, ds_old (= -ds_new), dt0
+__global__ __launch_bounds__(256) void train_losses_bwd_kernel(LossArgs a, const float* g, float* dframes, float* ds_old, float* ds_new, float* dt0) {
+    const float up = g[0];
+    if (blockIdx.y == (unsigned)a.rows) {                       // one extra grid row: the code gradients
+        const float cs = up * a.l_s * 2.f * a.inv_s, ct = up * a.l_t * a.inv_t;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_s; i += (int64_t)gridDim.x * 256) {
+            const float d = cs * (a.s_old[i] - a.s_new[i]);
+            ds_old[i] = d; ds_new[i] = -d;
+        }
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.Bt * a.Ct; i += (int64_t)gridDim.x * 256) dt0[i] = ct * a.t0[i];
+        return;
+    }
+    const int gidx = blockIdx.y % a.G;
+    const int64_t b = blockIdx.y / a.G;
+    const float k = gidx == 0 ? up * a.l_ae * 2.f * a.inv_ae : up * a.l_pred * 2.f * a.inv_pred;
+    const float* f = a.frames + (b * a.G + gidx) * a.D;
+    const float* t = a.full + (b * a.T + a.idx[gidx]) * a.D;
+    float* o = dframes + (b * a.G + gidx) * a.D;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < a.D; i += (int64_t)gridDim.x * 1024) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(f + i), y = *reinterpret_cast<const f32x4*>(t + i);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = k * (x[j] - y[j]);
+        *reinterpret_cast<f32x4*>(o + i) = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = a.D & ~(int64_t)3; i < a.D; ++i) o[i] = k * (f[i] - t[i]);
+}
+
+int fill_loss_args(LossArgs& a, const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D, const float* s_old,
+                   const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct, int average_tloss, const float* lambdas) {
+    VS_CHECK_ARG(frames && full && idx && t0 && lambdas && B > 0 && G >= 1 && T > 0 && D > 0 && Bt > 0 && Ct > 0 && n_s >= 0,
+                 "vs_train_losses: bad argument");
+    VS_CHECK_ARG(n_s == 0 || (s_old && s_new), "vs_train_losses: spatial codes missing");
+    a.frames = frames; a.full = full; a.idx = idx; a.rows = B * G; a.D = D; a.G = G; a.T = T;
+    a.s_old = s_old; a.s_new = s_new; a.n_s = n_s; a.t0 = t0; a.Bt = Bt; a.Ct = Ct;
+    a.l_ae = lambdas[0]; a.l_s = lambdas[1]; a.l_t = lambdas[2]; a.l_pred = lambdas[3];
+    a.inv_ae = (float)(1.0 / ((double)B * D));
+    a.inv_pred = (float)(1.0 / ((double)B * (G > 1 ? G - 1 : 1) * D));
+    a.inv_s = n_s > 0 ? (float)(1.0 / (double)n_s) : 0.f;
+    a.inv_t = (float)(1.0 / (average_tloss ? (double)Bt * Ct : (double)Bt));
+    return VS_OK;
+}
+}  // namespace
+
+extern "C" int vs_train_losses_fwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D,
+                                   const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
+                                   int average_tloss, const float* lambdas, float* out, void* stream) {
+    LossArgs a;
+    int rc = fill_loss_args(a, frames, full, idx, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss, lambdas);
+    if (rc != VS_OK) return rc;
+    VS_CHECK_ARG(out, "vs_train_losses_fwd: null output");
+    if (vs_zero_async(out, 10 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_train_losses_fwd: zero fill failed");
+    int64_t wgs = B * G;
+    if (wgs > 1024) wgs = 1024;
+    hipLaunchKernelGGL(train_losses_fwd_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, out);
+    VS_CHECK_LAUNCH("vs_train_losses_fwd");
+    return VS_OK;
+}
+
+extern "C" int vs_train_losses_bwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D,
+                                   const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
+                                   int average_tloss, const float* lambdas, const float* grad_total, float* dframes, float* ds_old,
+                                   float* ds_new, float* dt0, void* stream) {
+    LossArgs a;
+    int rc = fill_loss_args(a, frames, full, idx, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss, lambdas);
+    if (rc != VS_OK) return rc;
+    VS_CHECK_ARG(grad_total && dframes && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_bwd: null pointer");
+    unsigned gx = (unsigned)((D / 4 + 255) / 256);
+    if (gx > 8) gx = 8;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(train_losses_bwd_kernel, dim3(gx, (unsigned)(B * G + 1)), dim3(256), 0, (hipStream_t)stream, a, grad_total, dframes, ds_old,
+                       ds_new, dt0);
+    VS_CHECK_LAUNCH("vs_train_losses_bwd");
+    return VS_OK;
+}
+
 extern "C" int vs_frames_sse_fwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D, float* sums,
                                  void* stream) {
     VS_CHECK_ARG(frames && full && idx && sums && B > 0 && G > 0 && T > 0 && D > 0, "vs_frames_sse_fwd: bad argument");

@@ -21,6 +21,7 @@ struct AdamJobs {
     float* v[AD_MAXJ];
     __bf16* shadow[AD_MAXJ];            // optional bf16 copy of the updated parameter
     long long n[AD_MAXJ];
+    int aligned[AD_MAXJ];               // all four pointers 16-byte aligned (and the shadow 8-byte): vector path
     int skipped[AD_MAXJ];               // optimizer steps this tensor sat out (no gradient): its own step count lags the group's
     int chunk_off[AD_MAXJ + 1];         // prefix sum of chunk counts
     int nj;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
 #pragma unroll
         for (int u = 0; u < AD_CHUNK / 1024; ++u) {
             const long long i = base + (long long)u * 1024 + threadIdx.x * 4;
-            if (i + 3 < n) {
+            if (i + 3 < n && J.aligned[j]) {
                 f32x4 p = *reinterpret_cast<const f32x4*>(P + i), g = *reinterpret_cast<const f32x4*>(G + i);
                 f32x4 m = *reinterpret_cast<const f32x4*>(M + i), v = *reinterpret_cast<const f32x4*>(V + i);
 #pragma unroll
@@ -100,11 +101,12 @@ extern "C" int vs_adam_multi(int n_tensors, float* const* params, const float* c
     J.chunk_off[0] = 0;
     for (int j = 0; j < n_tensors; ++j) {
         VS_CHECK_ARG(params[j] && grads[j] && exp_avg[j] && exp_avg_sq[j] && numel[j] > 0, "vs_adam_multi: bad tensor %d", j);
-        VS_CHECK_ARG(((uintptr_t)params[j] | (uintptr_t)grads[j] | (uintptr_t)exp_avg[j] | (uintptr_t)exp_avg_sq[j]) % 16 == 0,
-                     "vs_adam_multi: tensor %d is not 16-byte aligned", j);
+        VS_CHECK_ARG(((uintptr_t)params[j] | (uintptr_t)grads[j] | (uintptr_t)exp_avg[j] | (uintptr_t)exp_avg_sq[j]) % 4 == 0,
+                     "vs_adam_multi: tensor %d is not 4-byte aligned", j);
         J.p[j] = params[j]; J.g[j] = grads[j]; J.m[j] = exp_avg[j]; J.v[j] = exp_avg_sq[j];
         J.shadow[j] = shadow_bf16 ? (__bf16*)shadow_bf16[j] : nullptr;
-        VS_CHECK_ARG(!J.shadow[j] || (uintptr_t)J.shadow[j] % 8 == 0, "vs_adam_multi: shadow %d is not 8-byte aligned", j);
+        J.aligned[j] = ((uintptr_t)params[j] | (uintptr_t)grads[j] | (uintptr_t)exp_avg[j] | (uintptr_t)exp_avg_sq[j]) % 16 == 0 &&
+                       (!J.shadow[j] || (uintptr_t)J.shadow[j] % 8 == 0);
         J.n[j] = numel[j];
         J.skipped[j] = skipped ? skipped[j] : 0;
         const int64_t chunks = (numel[j] + AD_CHUNK - 1) / AD_CHUNK;

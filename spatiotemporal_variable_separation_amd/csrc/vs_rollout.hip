@@ -1225,6 +1225,67 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* src, int transpo
 }
 }  // namespace
 
+// Several weights in one launch (the integrator has 3 x n_blocks matrices, each needed as L and L^T): one workgroup-stride
+// loop over the concatenated 16-byte units of all jobs.
+namespace {
+constexpr int PK_MAXJ = 48;
+struct PackJobs {
+    const float* src[PK_MAXJ];
+    void* dst[PK_MAXJ];
+    int N[PK_MAXJ], K[PK_MAXJ], transpose[PK_MAXJ];
+    long long unit_off[PK_MAXJ + 1];
+    int nj;
+};
+template <int CT>
+__global__ __launch_bounds__(256) void pack_multi_kernel(PackJobs J) {
+    typedef typename RT<CT>::T T;
+    constexpr int KS = RT<CT>::KS, U = RT<CT>::U;
+    const long long total = J.unit_off[J.nj];
+    for (long long gu = (long long)blockIdx.x * 256 + threadIdx.x; gu < total; gu += (long long)gridDim.x * 256) {
+        int j = 0;
+        while (J.unit_off[j + 1] <= gu) ++j;
+        const long long u = gu - J.unit_off[j];
+        const int N = J.N[j], K = J.K[j], transpose = J.transpose[j];
+        const float* src = J.src[j];
+        const int ksteps = (K + KS - 1) / KS;
+        const int lane = (int)(u & 63);
+        const long long piece = u >> 6;
+        const int s = (int)(piece % ksteps), nt = (int)(piece / ksteps);
+        const int n = nt * 16 + (lane & 15), k0 = s * KS + (lane >> 4) * U;
+        T tmp[U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const int k = k0 + e;
+            float v = 0.f;
+            if (n < N && k < K) v = transpose ? src[(int64_t)k * N + n] : src[(int64_t)n * K + k];
+            tmp[e] = (T)v;
+        }
+        *reinterpret_cast<u32x4*>((T*)J.dst[j] + u * U) = *reinterpret_cast<u32x4*>(tmp);
+    }
+}
+}  // namespace
+
+extern "C" int vs_pack_rollout_weights(int compute, int n_jobs, const float* const* src, const int* transpose, const int* N, const int* K,
+                                       void* const* dst, void* stream) {
+    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "vs_pack_rollout_weights: compute type %d", compute);
+    VS_CHECK_ARG(n_jobs >= 1 && n_jobs <= PK_MAXJ && src && transpose && N && K && dst, "vs_pack_rollout_weights: bad argument (1..%d jobs)", PK_MAXJ);
+    const int KS = compute == VS_BF16 ? 32 : 16;
+    PackJobs J;
+    J.nj = n_jobs;
+    J.unit_off[0] = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        VS_CHECK_ARG(src[j] && dst[j] && N[j] > 0 && K[j] > 0, "vs_pack_rollout_weights: bad job %d", j);
+        J.src[j] = src[j]; J.dst[j] = dst[j]; J.N[j] = N[j]; J.K[j] = K[j]; J.transpose[j] = transpose[j];
+        J.unit_off[j + 1] = J.unit_off[j] + (long long)((N[j] + 15) / 16) * ((K[j] + KS - 1) / KS) * 64;
+    }
+    long long blocks = (J.unit_off[n_jobs] + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (compute == VS_BF16) hipLaunchKernelGGL(pack_multi_kernel<VS_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
+    else hipLaunchKernelGGL(pack_multi_kernel<VS_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
+    VS_CHECK_LAUNCH("vs_pack_rollout_weights");
+    return VS_OK;
+}
+
 extern "C" size_t vs_rollout_packed_elems(int compute, int N, int K) {
     const int KS = compute == VS_BF16 ? 32 : 16;
     return (size_t)((N + 15) / 16) * 16 * (size_t)((K + KS - 1) / KS) * KS;

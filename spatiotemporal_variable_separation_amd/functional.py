@@ -232,6 +232,20 @@ def packed_weight(p, dtype, transpose):
     return ent[1]
 
 
+def prepack_weights(requests, dtype):
+    """Bring several rollout pre-packs up to date with ONE launch: requests = [(parameter, transpose)]."""
+    stale = []
+    for p, tr in requests:
+        key = (id(p), bool(tr), dtype)
+        ent = _packed.get(key)
+        if ent is None or ent[0] != p._version or ent[2] is not p:
+            stale.append((key, p, tr, ent[1] if ent is not None and ent[2] is p else None))
+    if stale:
+        bufs = ops.pack_rollout_weights([(p.detach().contiguous(), tr, buf) for _, p, tr, buf in stale], dtype)
+        for (key, p, _, _), buf in zip(stale, bufs):
+            _packed[key] = (p._version, buf, p)
+
+
 class MLPRollout(torch.autograd.Function):
     """All n-1 integrator steps x n_blocks residual MLP blocks in one persistent kernel per direction.
 
@@ -247,6 +261,9 @@ class MLPRollout(torch.autograd.Function):
         nb = len(params) // 6
         H = params[0].shape[0]
         ws, bs = [], []
+        if torch.is_grad_enabled() or any(p.requires_grad for p in params):
+            # forward and transposed (backward) packs of every block in one launch
+            prepack_weights([(params[6 * b + 2 * l], tr) for b in range(nb) for l in range(3) for tr in (False, True)], cdt)
         for b in range(nb):
             for l in range(3):
                 ws.append(packed_weight(params[6 * b + 2 * l], cdt, False))
@@ -407,6 +424,30 @@ class Activation(torch.autograd.Function):
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         return ops.act_bwd(dy, y, ctx.act, out_dtype=y.dtype), None
+
+
+# ------------------------------------------------------------------------------------------------ all training losses
+class TrainLosses(torch.autograd.Function):
+    """total = l_ae*ae + l_s*zero + l_pred*pred + l_t*t_reg and the four terms (train.py:117-149) from the decoded frame stack
+    [B, 1+n, D], the spatial codes of the first/last window and the initial temporal code: one kernel forward, one backward
+    (ops.train_losses_*), instead of ~30 elementwise / reduction launches each way.  Returns (total, ae, zero, pred, t_reg); only
+    `total` is differentiable, the terms are for logging."""
+
+    @staticmethod
+    def forward(ctx, frames, full, idx, s_old, s_new, t0, lambdas, average_tloss):
+        out = ops.train_losses_fwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss)
+        ctx.save_for_backward(frames, full, idx, s_old, s_new, t0)
+        ctx.lambdas, ctx.average = tuple(float(v) for v in lambdas), bool(average_tloss)
+        total, ae, zero, pred, treg = out[4], out[5], out[6], out[7], out[8]
+        ctx.mark_non_differentiable(ae, zero, pred, treg)
+        return total, ae, zero, pred, treg
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        frames, full, idx, s_old, s_new, t0 = ctx.saved_tensors
+        dframes, ds_old, ds_new, dt0 = ops.train_losses_bwd(frames, full, idx, s_old, s_new, t0, ctx.lambdas, ctx.average,
+                                                            g_total.float().contiguous())
+        return dframes, None, None, ds_old, ds_new, dt0, None, None
 
 
 # ------------------------------------------------------------------------------------------------ fused frame losses

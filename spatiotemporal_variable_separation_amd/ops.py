@@ -236,6 +236,30 @@ def pack_rollout_weight(w, dtype, transpose, out=None):
     return out
 
 
+def pack_rollout_weights(jobs, dtype):
+    """jobs: list of (fp32 weight [rows, cols], transpose, out buffer or None).  One launch; returns the packed buffers."""
+    import ctypes
+    lib = _lib.load_library()
+    code = BF16 if dtype == torch.bfloat16 else F32
+    outs = []
+    for i in range(0, len(jobs), 48):
+        chunk = jobs[i:i + 48]
+        n = len(chunk)
+        Ns, Ks, bufs = [], [], []
+        for w, tr, out in chunk:
+            require_cuda(w)
+            assert w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32
+            N, K = (w.shape[1], w.shape[0]) if tr else (w.shape[0], w.shape[1])
+            if out is None:
+                out = torch.empty((lib.vs_rollout_packed_elems(code, N, K),), dtype=dtype, device=w.device)
+            Ns.append(N); Ks.append(K); bufs.append(out)
+        VP, I32 = ctypes.c_void_p * n, ctypes.c_int * n
+        check(lib.vs_pack_rollout_weights(code, n, VP(*[w.data_ptr() for w, _, _ in chunk]), I32(*[int(bool(tr)) for _, tr, _ in chunk]),
+                                          I32(*Ns), I32(*Ks), VP(*[b.data_ptr() for b in bufs]), stream_ptr()), 'vs_pack_rollout_weights')
+        outs += bufs
+    return outs
+
+
 def mlp_rollout_fwd(x0, weights, biases, n_steps, H, want_residuals=True):
     """weights: packed [W1,W2,W3]*n_blocks in the compute dtype; biases fp32.  Returns (t_codes, residuals, saves)."""
     import ctypes
@@ -497,6 +521,46 @@ def frames_sse_fwd(frames, full, idx):
                                                 sums.data_ptr(), stream_ptr()), 'vs_frames_sse_fwd')
     _pe(e0, 'vs_frames_sse_fwd', nbytes=float(2 * frames.numel() * 4))
     return sums
+
+
+def _loss_args(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss):
+    import ctypes
+    require_cuda(frames, full, idx, t0)
+    assert frames.is_contiguous() and full.is_contiguous() and t0.is_contiguous()
+    assert frames.dtype == torch.float32 and full.dtype == torch.float32 and t0.dtype == torch.float32
+    B, G, D = frames.shape
+    n_s = 0 if s_old is None else s_old.numel()
+    if n_s:
+        require_cuda(s_old, s_new)
+        assert s_old.is_contiguous() and s_new.is_contiguous() and s_old.dtype == torch.float32 and s_new.dtype == torch.float32
+    lam = (ctypes.c_float * 4)(*[float(v) for v in lambdas])
+    return (frames.data_ptr(), full.data_ptr(), idx.data_ptr(), B, G, full.shape[1], D, _ptr(s_old) if n_s else None,
+            _ptr(s_new) if n_s else None, n_s, t0.data_ptr(), t0.shape[0], t0.numel() // t0.shape[0], int(bool(average_tloss)),
+            ctypes.cast(lam, ctypes.c_void_p)), lam
+
+
+def train_losses_fwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss):
+    """-> out [10] device floats: [4] total, [5] ae, [6] zero-order, [7] pred, [8] t_reg.  lambdas = (ae, s, t, pred)."""
+    args, keep = _loss_args(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss)
+    out = torch.empty((10,), dtype=torch.float32, device=frames.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_train_losses_fwd(*args, out.data_ptr(), stream_ptr()), 'vs_train_losses_fwd')
+    _pe(e0, 'vs_train_losses_fwd', nbytes=float(2 * frames.numel() * 4))
+    return out
+
+
+def train_losses_bwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss, grad_total):
+    args, keep = _loss_args(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss)
+    require_cuda(grad_total)
+    dframes = torch.empty_like(frames)
+    ds_old = torch.empty_like(s_old) if s_old is not None else None
+    ds_new = torch.empty_like(s_new) if s_new is not None else None
+    dt0 = torch.empty_like(t0)
+    e0 = _pb()
+    check(_lib.load_library().vs_train_losses_bwd(*args, grad_total.data_ptr(), dframes.data_ptr(), _ptr(ds_old), _ptr(ds_new),
+                                                  dt0.data_ptr(), stream_ptr()), 'vs_train_losses_bwd')
+    _pe(e0, 'vs_train_losses_bwd', nbytes=float(3 * frames.numel() * 4))
+    return dframes, ds_old, ds_new, dt0
 
 
 def frames_sse_bwd(frames, full, idx, coef):

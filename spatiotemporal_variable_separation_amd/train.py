@@ -130,13 +130,12 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
         idx = torch.index_select(_frame_index(None, fo, n, frames.device, T + 1), 0, (t_random - offset).long()).view(-1)
     else:
         idx = _frame_index(int(t_random) - offset, fo, n, frames.device, T + 1)
-    ae_loss_value, forecast_loss = VF.FrameLosses.apply(frames.reshape(B, 1 + n, -1), flat.contiguous(), idx)
-    spatial_ode_loss = (s_old - s_new).pow(2).mean()
-    if average_tloss:
-        t_reg = 0.5 * (t_codes[:, 0].pow(2).view(B, -1)).mean()
-    else:
-        t_reg = 0.5 * torch.sum(t_codes[:, 0].pow(2), dim=1).mean()
-    total_loss = lamb_ae * ae_loss_value + lamb_s * spatial_ode_loss + lamb_pred * forecast_loss + lamb_t * t_reg
+    # t_codes[:, 0] IS t0 (the rollout copies its input there), so the regulariser reads the encoder output directly
+    no_s = isinstance(sep_net.Es, ConstantS)
+    total_loss, ae_loss_value, spatial_ode_loss, forecast_loss, t_reg = VF.TrainLosses.apply(
+        frames.reshape(B, 1 + n, -1), flat.contiguous(), idx, None if no_s else s_old.reshape(B, -1).float().contiguous(),
+        None if no_s else s_new.reshape(B, -1).float().contiguous(), t0.reshape(B, -1).float().contiguous(),
+        (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss)
     terms = {'ae': ae_loss_value, 'zero': spatial_ode_loss, 'pred': forecast_loss, 't_reg': t_reg}
     return total_loss, terms, forecasts, t_codes
 

@@ -38,6 +38,29 @@ def test_adam_matches_torch(lr, betas):
     assert float(sa['state'][0]['step']) == 5.0
 
 
+def test_adam_accepts_views_into_flat_gradient_buckets():
+    """Gradients as views at odd element offsets of one flat buffer (parallel.GradAllReducer): the misaligned ones take the
+    scalar path of the kernel."""
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    pa, pb = _params(2), _params(2)
+    flat = torch.zeros(sum(p.numel() for p in pa) + 3, device='cuda')
+    off = 3
+    for p in pa:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    oa, ob = Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    g = torch.Generator().manual_seed(4)
+    for _ in range(3):
+        for a, b in zip(pa, pb):
+            gr = (torch.rand(a.shape, generator=g) - 0.5).cuda()
+            a.grad.copy_(gr)
+            b.grad = gr.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+
+
 def test_adam_writes_bf16_shadow_and_is_graph_capturable():
     from spatiotemporal_variable_separation_amd import functional as VF
     from spatiotemporal_variable_separation_amd.optim import Adam
