@@ -208,13 +208,23 @@ __global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float
         const float* f = a.frames + r * a.D;
         const float* t = a.full + (b * a.T + a.idx[g]) * a.D;
         float s = 0.f;
-        for (int64_t i = (int64_t)threadIdx.x * 4; i + 3 < a.D; i += 1024) {
+        int64_t i = (int64_t)threadIdx.x * 4;
+        for (; i + 3 * 1024 + 3 < a.D; i += 4096) {            // four 16-byte loads of each stream in flight per thread
+            f32x4 x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { x[u] = *reinterpret_cast<const f32x4*>(f + i + u * 1024); y[u] = *reinterpret_cast<const f32x4*>(t + i + u * 1024); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = x[u][j] - y[u][j]; s += d * d; }
+        }
+        for (; i + 3 < a.D; i += 1024) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(f + i), y = *reinterpret_cast<const f32x4*>(t + i);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float d = x[j] - y[j]; s += d * d; }
         }
         if (threadIdx.x == 0)
-            for (int64_t i = a.D & ~(int64_t)3; i < a.D; ++i) { const float d = f[i] - t[i]; s += d * d; }
+            for (int64_t k = a.D & ~(int64_t)3; k < a.D; ++k) { const float d = f[k] - t[k]; s += d * d; }
         if (g == 0) s0 += s; else s1 += s;
     }
     s0 = block_sum_256(s0, red);
@@ -299,7 +309,7 @@ extern "C" int vs_train_losses_fwd(const float* frames, const float* full, const
     VS_CHECK_ARG(out, "vs_train_losses_fwd: null output");
     if (vs_zero_async(out, 10 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_train_losses_fwd: zero fill failed");
     int64_t wgs = B * G;
-    if (wgs > 1024) wgs = 1024;
+    if (wgs > 2048) wgs = 2048;
     hipLaunchKernelGGL(train_losses_fwd_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, out);
     VS_CHECK_LAUNCH("vs_train_losses_fwd");
     return VS_OK;

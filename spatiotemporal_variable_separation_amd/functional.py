@@ -436,6 +436,7 @@ class TrainLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, frames, full, idx, s_old, s_new, t0, lambdas, average_tloss):
         out = ops.train_losses_fwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss)
+        ctx.set_materialize_grads(False)             # no zero tensors for the (unused) gradients of the four logging terms
         ctx.save_for_backward(frames, full, idx, s_old, s_new, t0)
         ctx.lambdas, ctx.average = tuple(float(v) for v in lambdas), bool(average_tloss)
         total, ae, zero, pred, treg = out[4], out[5], out[6], out[7], out[8]
@@ -445,6 +446,8 @@ class TrainLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, *_unused):
         frames, full, idx, s_old, s_new, t0 = ctx.saved_tensors
+        if g_total is None:
+            return (None,) * 8
         dframes, ds_old, ds_new, dt0 = ops.train_losses_bwd(frames, full, idx, s_old, s_new, t0, ctx.lambdas, ctx.average,
                                                             g_total.float().contiguous())
         return dframes, None, None, ds_old, ds_new, dt0, None, None

@@ -66,7 +66,7 @@ def _mlp_family(sep_net):
 
 
 def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset, lamb_ae, lamb_s, lamb_t, lamb_pred,
-                                average_tloss, t_random):
+                                average_tloss, t_random, full_data=None):
     """Same arithmetic as the generic path below, with the calls that share weights batched along the row axis:
     E_s on [first window; last window], E_t on [random window; conditioning window], D on [the auto-encoding row
     block; every rollout step].  The MLP family has no BatchNorm, so stacking rows is exact; it halves the number of
@@ -78,7 +78,8 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     so the whole step can be recorded once into a hipGraph and replayed while the random window moves."""
     from .networks.utils import ConstantS
     from . import functional as VF, ops
-    full_data = torch.cat([cond, target], dim=1)
+    if full_data is None:                            # GraphedStep keeps cond/target as views of one [B, T, ...] buffer already
+        full_data = torch.cat([cond, target], dim=1)
     B, T = full_data.shape[0], full_data.shape[1]
     flat = full_data.reshape(B, T, -1)
     D = flat.shape[2]
@@ -159,7 +160,9 @@ class GraphedStep:
         check_optimizer(optimizer)
         self.net, self.opt, self.sync = sep_net, optimizer, grad_sync
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
-        self.cond, self.target = cond.clone(), target.clone()
+        # static inputs of the recording: one [B, T, ...] buffer, cond / target are views of it (no concatenation per step)
+        self.full = torch.cat([cond, target], dim=1).contiguous()
+        self.cond, self.target = self.full[:, :cond.shape[1]], self.full[:, cond.shape[1]:]
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=cond.device)
         self.T = cond.shape[1] + target.shape[1]
         self.nt_cond, self.offset = nt_cond, offset
@@ -215,7 +218,7 @@ class GraphedStep:
         VF.enable_side_streams(self.side_streams)
         try:
             total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
-                                                         l_pred, avg, self.t_dev)
+                                                         l_pred, avg, self.t_dev, full_data=self.full)
             total.backward()
             VF.join_side_streams()
         finally:
