@@ -94,25 +94,70 @@ struct ColsumJobs {
     int blk_off[CS_MAXJ + 1];
 };
 
+// A workgroup reduces CS_ROWS rows of a 256-column block: 32 lanes x 8 consecutive columns (one 16-byte load per row for bf16,
+// two for fp32), 8 row groups, 4 rows in flight per thread; the 8 row groups meet in LDS, one atomic per column.
+constexpr int CSM_COLS = 256;
 __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumJobs J) {
-    __shared__ float part[4][64];
+    __shared__ float part[8][CSM_COLS + 8];
     int j = 0;
     while (j + 1 < J.nj && (int)blockIdx.x >= J.blk_off[j + 1]) ++j;
     const int64_t M = J.M[j], N = J.N[j], ldx = J.ld[j];
     const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
     if (r0 >= M) return;
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int64_t n = (int64_t)(blockIdx.x - J.blk_off[j]) * 64 + c;
+    const int c8 = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t n = (int64_t)(blockIdx.x - J.blk_off[j]) * CSM_COLS + 8 * c8;
     int64_t r1 = r0 + CS_ROWS;
     if (r1 > M) r1 = M;
     const void* X = J.x[j];
     const int xd = J.dt[j];
-    float s = 0.f;
-    if (n < N)
-        for (int64_t r = r0 + g; r < r1; r += 4) s += vs_ld(X, xd, r * ldx + n);
-    part[g][c] = s;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const bool vec = n + 8 <= N && ldx % 8 == 0 && (uintptr_t)X % 16 == 0;
+    if (vec && xd == VS_BF16) {
+        const __bf16* p = (const __bf16*)X + n;
+        int64_t r = r0 + g;
+        for (; r + 24 < r1; r += 32) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(p + (r + 8 * u) * ldx);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const __bf16* h = reinterpret_cast<const __bf16*>(&v[u]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)h[e];
+            }
+        }
+        for (; r < r1; r += 8) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(p + r * ldx);
+            const __bf16* h = reinterpret_cast<const __bf16*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)h[e];
+        }
+    } else if (vec && xd == VS_F32) {
+        const float* p = (const float*)X + n;
+        for (int64_t r = r0 + g; r < r1; r += 8) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p + r * ldx), b = *reinterpret_cast<const f32x4*>(p + r * ldx + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += a[e]; s[4 + e] += b[e]; }
+        }
+    } else if (n < N) {
+        for (int64_t r = r0 + g; r < r1; r += 8)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (n + e < N) s[e] += vs_ld(X, xd, r * ldx + n + e);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[g][8 * c8 + e] = s[e];
     __syncthreads();
-    if (g == 0 && n < N) atomicAdd(J.out[j] + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+    const int col = threadIdx.x;
+    const int64_t nc = (int64_t)(blockIdx.x - J.blk_off[j]) * CSM_COLS + col;
+    if (nc < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][col];
+        atomicAdd(J.out[j] + nc, t);
+    }
 }
 
 // ---- fused frame losses: sum of squared errors of every decoded frame against its target frame ------------------------------
@@ -175,8 +220,8 @@ __global__ __launch_bounds__(256) void frames_sse_bwd_kernel(const float* frames
 //   total = l_ae * mse(frame 0) + l_s * mean((s_old - s_new)^2) + l_pred * mse(frames 1..) + l_t * t_reg
 //   t_reg = 0.5 * mean_b sum_c t0^2   (average_tloss: 0.5 * mean_{b,c} t0^2)
 // Composed from torch ops this tail is ~30 launches of 2-5 us forward and as many backward -- 12 % of a WaveEq step that is
-// otherwise MFMA/HBM work.  Forward: one zero fill + ONE kernel (frame rows walked by all workgroups, the two small code terms
-// by workgroup 0, the last workgroup to finish assembles the scalars); backward: ONE kernel writing every gradient.
+// otherwise MFMA/HBM work.  Forward: a zero fill, ONE pass (frame rows walked by all workgroups, the two small code terms by
+// workgroup 0) and a 1-thread launch assembling the scalars; backward: ONE kernel writing every gradient.
 namespace {
 struct LossArgs {
     const float* frames; const float* full; const int* idx;
@@ -197,10 +242,9 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 // out: [0..3] raw sums (SSE frame 0, SSE frames 1.., sum (s_old - s_new)^2, sum t0^2), [4] total, [5] ae, [6] zero, [7] pred,
-//      [8] t_reg, [9] ticket (int)
+//      [8] t_reg
 __global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float* out) {
     __shared__ float red[4];
-    __shared__ int last;
     float s0 = 0.f, s1 = 0.f;
     for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
         const int g = (int)(r % a.G);
@@ -238,21 +282,14 @@ __global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float
         st = block_sum_256(st, red);
         if (threadIdx.x == 0) { atomicAdd(out + 2, ss); atomicAdd(out + 3, st); }
     }
-    // the workgroup that takes the last ticket sees every contribution (release by each, acquire by the last)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const int t = atomicAdd(reinterpret_cast<int*>(out + 9), 1);
-        last = (t == (int)gridDim.x - 1);
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
-        const float sse0 = atomicAdd(out, 0.f), sse1 = atomicAdd(out + 1, 0.f), ssd = atomicAdd(out + 2, 0.f), sst = atomicAdd(out + 3, 0.f);
-        const float ae = sse0 * a.inv_ae, pred = sse1 * a.inv_pred, zero = ssd * a.inv_s, treg = 0.5f * sst * a.inv_t;
-        out[5] = ae; out[6] = zero; out[7] = pred; out[8] = treg;
-        out[4] = a.l_ae * ae + a.l_s * zero + a.l_pred * pred + a.l_t * treg;      // same association as train.py:146-149
-    }
+}
+
+// A device-scope release fence per workgroup (the "last ticket assembles" pattern) costs more than this whole kernel on
+// gfx950 (each fence writes back the XCD's L2: +45 us at 1024 workgroups), so the scalars are assembled by a 1-thread launch.
+__global__ void train_losses_finalize_kernel(LossArgs a, float* out) {
+    const float ae = out[0] * a.inv_ae, pred = out[1] * a.inv_pred, zero = out[2] * a.inv_s, treg = 0.5f * out[3] * a.inv_t;
+    out[5] = ae; out[6] = zero; out[7] = pred; out[8] = treg;
+    out[4] = a.l_ae * ae + a.l_s * zero + a.l_pred * pred + a.l_t * treg;          // same association as train.py:146-149
 }
 
 // gradients of `total` times the upstream scalar *g: dframes, ds_old (= -ds_new), dt0
@@ -309,8 +346,9 @@ extern "C" int vs_train_losses_fwd(const float* frames, const float* full, const
     VS_CHECK_ARG(out, "vs_train_losses_fwd: null output");
     if (vs_zero_async(out, 10 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_train_losses_fwd: zero fill failed");
     int64_t wgs = B * G;
-    if (wgs > 2048) wgs = 2048;
+    if (wgs > 1024) wgs = 1024;
     hipLaunchKernelGGL(train_losses_fwd_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, out);
+    hipLaunchKernelGGL(train_losses_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, out);
     VS_CHECK_LAUNCH("vs_train_losses_fwd");
     return VS_OK;
 }
@@ -365,7 +403,7 @@ extern "C" int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dt
     for (int j = 0; j < n_jobs; ++j) {
         VS_CHECK_ARG(X[j] && out[j] && M[j] > 0 && N[j] > 0 && ldx[j] >= N[j], "vs_colsum_multi: bad job %d", j);
         J.x[j] = X[j]; J.dt[j] = x_dtype[j]; J.ld[j] = ldx[j]; J.M[j] = M[j]; J.N[j] = N[j]; J.out[j] = out[j];
-        J.blk_off[j + 1] = J.blk_off[j] + (int)vs_cdiv(N[j], 64);
+        J.blk_off[j + 1] = J.blk_off[j] + (int)vs_cdiv(N[j], CSM_COLS);
         if (M[j] > max_m) max_m = M[j];
     }
     if (zero_base && zero_count > 0) {

@@ -148,3 +148,22 @@ def test_fused_rollout_equals_stepwise(precision, dims):
             assert gf is None and p.grad is None          # no integrator step, no weight gradient
             continue
         assert rel(gf, p.grad) < tol * 5, (gf.shape,)
+
+
+def test_colsum_multi_shapes_and_dtypes():
+    """All bias gradients of a chain in one launch: vector path (8-column units), ragged columns, odd row counts, views."""
+    from spatiotemporal_variable_separation_amd import ops
+    from oracle.detdata import det_uniform
+    jobs, refs = [], []
+    for i, (m, n, dt) in enumerate([(3328, 1200, torch.bfloat16), (257, 4096, torch.bfloat16), (300, 33, torch.float32),
+                                    (1000, 520, torch.float32), (5, 7, torch.bfloat16), (777, 264, torch.bfloat16)]):
+        x = (det_uniform((m, n), 20 + i) - 0.5).to(dt).cuda()
+        jobs.append(x)
+        refs.append(x.double().sum(0))
+    wide = (det_uniform((64, 512), 31) - 0.5).to(torch.bfloat16).cuda()
+    jobs.append(wide[:, 8:136])                                   # a column window of a wider matrix (ld > N)
+    refs.append(wide[:, 8:136].double().sum(0))
+    outs = ops.colsum_multi(jobs)
+    for o, r, x in zip(outs, refs, jobs):
+        assert o.shape == r.shape
+        assert torch.allclose(o.double(), r, rtol=1e-5, atol=1e-3 * x.shape[0] ** 0.5 * 1e-2), (x.shape, (o.double() - r).abs().max().item())
