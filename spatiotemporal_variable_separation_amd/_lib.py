@@ -90,6 +90,9 @@ SIGNATURES = {
     'vs_adam_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                              ctypes.c_double, _vp]),
     'vs_adam_step_increment': (_i32, [_vp, _vp]),
+    'vs_gemm_batched_workspace_bytes': (_sz, [_i32, _i64, _i64, _i64]),
+    'vs_gemm_batched': (_i32, [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _f32, _i32,
+                               _vp, _sz, _vp]),
     'vs_train_losses_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     'vs_train_losses_bwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp]),

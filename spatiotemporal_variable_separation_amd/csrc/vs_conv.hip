@@ -160,6 +160,7 @@ struct TapGather {
 //                                 otherwise   -> element(i = q, k = pixel), LDS layout R (unit along k).
 template <int CT, bool PIX_IS_ROW>
 struct GatherOp {
+    __device__ __forceinline__ void shift(int64_t) {}
     typedef typename CTraits<CT>::T T;
     static constexpr int U = CTraits<CT>::U;
     static constexpr int layout = PIX_IS_ROW ? LS : LR;
@@ -227,6 +228,7 @@ struct GatherOp {
 // element(m = channel, k = pixel (b, pix)) = src[(b * C + m) * HW + pix]
 template <int CT>
 struct ChanRows {
+    __device__ __forceinline__ void shift(int64_t) {}
     typedef typename CTraits<CT>::T T;
     static constexpr int U = CTraits<CT>::U;
     static constexpr int layout = LR;

@@ -32,7 +32,8 @@ int launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, in
     Dense<CT, LA> a{(const T*)A, lda, M, K, ((uintptr_t)A % 16 == 0) && (lda % U == 0)};
     Dense<CT, LB> b{(const T*)B, ldb, N, K, ((uintptr_t)B % 16 == 0) && (ldb % U == 0)};
     constexpr size_t smem = (TileGeom<CT, LA, BM, BK>::ELEMS + TileGeom<CT, LB, BN, BK>::ELEMS) * sizeof(T);
-    dim3 grid((unsigned)vs_cdiv(N, BN), (unsigned)vs_cdiv(M, BM), (unsigned)plan.splits);
+    const int batch = epi.splits_per_batch > 0 ? plan.batch : 1;
+    dim3 grid((unsigned)vs_cdiv(N, BN), (unsigned)vs_cdiv(M, BM), (unsigned)(plan.splits * batch));
     hipLaunchKernelGGL((gemm_kernel<CT, Dense<CT, LA>, Dense<CT, LB>, BM, BN, BK>), grid, dim3(256), smem, stream, a, b, M, N,
                        K, (int)plan.k_tiles_per_split, epi, slabs);
     VS_CHECK_LAUNCH("vs_gemm");
@@ -57,6 +58,57 @@ int launch_layout(int la, int lb, const void* A, int64_t lda, const void* B, int
 }
 
 }  // namespace
+
+extern "C" size_t vs_gemm_batched_workspace_bytes(int batch, int64_t M, int64_t N, int64_t K) {
+    if (batch <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
+    size_t worst = 0;
+    for (int c = 0; c < 2; ++c) {
+        Plan p = make_plan(c, M, N, K, batch);
+        if (p.splits > 1) {
+            size_t b = (size_t)batch * p.splits * (size_t)M * (size_t)N * sizeof(float);
+            if (b > worst) worst = b;
+        }
+    }
+    return worst;
+}
+
+// `batch` independent problems of one shape in one launch (the weight gradients of the integrator's blocks: the same three
+// small GEMMs per block, each too small to fill the chip): problem i uses A + i*stride_a, B + i*stride_b, C + i*stride_c.
+extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, int64_t stride_a,
+                               int layout_a, const void* B, int64_t ldb, int64_t stride_b, int layout_b, void* C, int64_t ldc,
+                               int64_t stride_c, int c_dtype, float alpha, int accumulate, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "vs_gemm_batched: compute type %d", compute);
+    VS_CHECK_ARG(batch >= 1 && batch <= 1024 && M > 0 && N > 0 && K > 0, "vs_gemm_batched: bad sizes");
+    VS_CHECK_ARG(A && B && C, "vs_gemm_batched: null operand");
+    VS_CHECK_ARG((layout_a == LR || layout_a == LS) && (layout_b == LR || layout_b == LS), "vs_gemm_batched: bad layout");
+    VS_CHECK_ARG(c_dtype == VS_F32 || c_dtype == VS_BF16, "vs_gemm_batched: bad c_dtype");
+    VS_CHECK_ARG(lda >= (layout_a == LR ? K : M) && ldb >= (layout_b == LR ? K : N) && ldc >= N, "vs_gemm_batched: leading dimension too small");
+    const int esz = compute == VS_BF16 ? 2 : 4;
+    VS_CHECK_ARG((stride_a * esz) % 16 == 0 && (stride_b * esz) % 16 == 0, "vs_gemm_batched: operand strides must keep 16-byte alignment");
+    Plan plan = make_plan(compute, M, N, K, batch);
+    plan.batch = batch;
+    Epi epi{C, ldc, c_dtype, alpha, nullptr, VS_ACT_NONE, nullptr, 0, 0, 0, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0, plan.splits, stride_a, stride_b, stride_c};
+    float* slabs = nullptr;
+    if (plan.splits > 1) {
+        const size_t need = (size_t)batch * plan.splits * (size_t)M * (size_t)N * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return vs_fail(VS_ERR_WORKSPACE, "vs_gemm_batched: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
+        slabs = (float*)workspace;
+    }
+    int rc = compute == VS_BF16
+                 ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
+                 : launch_layout<VS_F32>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
+    if (rc != VS_OK) return rc;
+    if (slabs) {
+        int64_t blocks = vs_cdiv(M * N, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, stream, slabs, plan.splits, M, N, epi);
+        VS_CHECK_LAUNCH("vs_gemm_batched split-K reduce");
+    }
+    return VS_OK;
+}
 
 extern "C" size_t vs_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

@@ -24,7 +24,16 @@ struct Epi {
     // optional sub-grid scatter (parity phases of a stride-2 transposed convolution): column n enumerates an iteration
     // grid [B][g_hw / g_w][g_w] and lands on output pixel (gy*sy + oy, gx*sx + ox) of a plane with rows of o_w pixels
     int g_w, g_hw, o_w, sy, sx, oy, ox;
+    // batched dense GEMM (vs_gemm_batched): gridDim.z = batch * splits; operand / output element strides between problems
+    int splits_per_batch;
+    int64_t batch_a, batch_b, batch_c;
 };
+
+__device__ __forceinline__ Epi epi_for_batch(const Epi& e, int64_t batch) {
+    Epi r = e;
+    if (batch) r.C = (char*)e.C + batch * e.batch_c * (e.c_dtype == VS_F32 ? 4 : 2);
+    return r;
+}
 
 // row-major form: element (m, n) at C[m*ldc + n], bias per column
 __device__ __forceinline__ void epi_store(const Epi& e, int64_t m, int64_t n, float v) {
@@ -66,6 +75,7 @@ struct Dense {
     static constexpr int U = CTraits<CT>::U;
     static constexpr int layout = LAYOUT;
     const T* p; int64_t ld; int64_t rows; int64_t K; int vec_ok;
+    __device__ __forceinline__ void shift(int64_t elems) { p += elems; }       // batched GEMM: move to this problem's operand
 
     // Per-thread, per-unit-slot state that does not change along K (the row a unit belongs to is fixed for the whole K loop)
     struct State { const T* base; int ok; };
@@ -189,7 +199,15 @@ __device__ __forceinline__ f32x4 frag_f32(const float* tile, int row0, int kk, i
 
 template <int CT, class OpA, class OpB, int BM, int BN, int BK, bool NCHW = false>
 __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int64_t N, int64_t K,
-                                                   int k_tiles_per_split, Epi epi, float* slabs) {
+                                                   int k_tiles_per_split, Epi epi_in, float* slabs) {
+    int zsplit = blockIdx.z;
+    if (epi_in.splits_per_batch > 0) {                  // batched: z = batch * splits + split
+        const int batch = blockIdx.z / epi_in.splits_per_batch;
+        zsplit = blockIdx.z - batch * epi_in.splits_per_batch;
+        A.shift(batch * epi_in.batch_a);
+        B.shift(batch * epi_in.batch_b);
+    }
+    const Epi epi = epi_for_batch(epi_in, epi_in.splits_per_batch > 0 ? blockIdx.z / epi_in.splits_per_batch : 0);
     typedef typename CTraits<CT>::T T;
     typedef TileGeom<CT, OpA::layout, BM, BK> GA;
     typedef TileGeom<CT, OpB::layout, BN, BK> GB;
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
     const int64_t kt_total = (K + BK - 1) / BK;
-    const int64_t kt_begin = (int64_t)blockIdx.z * k_tiles_per_split;
+    const int64_t kt_begin = (int64_t)zsplit * k_tiles_per_split;
     int64_t kt_end = kt_begin + k_tiles_per_split;
     if (kt_end > kt_total) kt_end = kt_total;
 
@@ -308,8 +326,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
         }
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int splits, int64_t M, int64_t N, Epi epi) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int splits, int64_t M, int64_t N, Epi epi_in) {
     const int64_t total = M * N;
+    slabs += (int64_t)blockIdx.y * splits * total;      // blockIdx.y = problem of a batched GEMM (0 otherwise)
+    const Epi epi = epi_for_batch(epi_in, blockIdx.y);
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < splits; ++s) v += slabs[(int64_t)s * total + idx];      // fixed order: reproducible
@@ -319,11 +339,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
     }
 }
 
-struct Plan { int bm, bn, splits; int64_t k_tiles_per_split; };
+struct Plan { int bm, bn, splits; int64_t k_tiles_per_split; int batch = 1; };
 
 template <int CT> constexpr int bk_of() { return CT == VS_BF16 ? 64 : 16; }
 
-Plan make_plan(int compute, int64_t M, int64_t N, int64_t K) {
+Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1) {
     const int bk = compute == VS_BF16 ? 64 : 16;
     Plan p;
     // Tile choice (measured on the config-2 shapes, tools/gemm_bench.py): the kernel keeps ~3 workgroups (12 waves) per CU
@@ -341,7 +361,7 @@ Plan make_plan(int compute, int64_t M, int64_t N, int64_t K) {
     if (M <= 64) p.bm = 64;
     if (N <= 64) p.bn = 64;
     if (p.bm == 64) p.bn = 64;
-    const int64_t tiles = vs_cdiv(M, p.bm) * vs_cdiv(N, p.bn);
+    const int64_t tiles = vs_cdiv(M, p.bm) * vs_cdiv(N, p.bn) * batch;
     const int64_t kt = vs_cdiv(K, bk);
     int splits = 1;
     if (tiles < 192 && kt >= 8) {

@@ -290,13 +290,14 @@ class MLPRollout(torch.autograd.Function):
             return (dx0, None) + tuple(torch.zeros_like(p) for p in params)
 
         def weight_grads():
+            # the three weight gradients of ALL blocks: one batched launch per layer (the saves are [block][step*B][feature])
+            dW1 = ops.gemm_batched(dh1.view(nb, rows, H), S, xin.view(nb, rows, C), S, H, C, rows)
+            dW2 = ops.gemm_batched(dh2.view(nb, rows, H), S, h1.view(nb, rows, H), S, H, H, rows)
+            dW3 = ops.gemm_batched(dr.view(nb, rows, C), S, h2.view(nb, rows, H), S, C, H, rows)
             grads, bias_jobs = [], []
             for b in range(nb):
-                dh1b, dh2b, drb = dh1[b].view(rows, H), dh2[b].view(rows, H), dr[b].view(rows, C)
-                xb, h1b, h2b = xin[b].view(rows, C), h1[b].view(rows, H), h2[b].view(rows, H)
-                grads += [ops.gemm(dh1b, S, xb, S, H, C, rows), None, ops.gemm(dh2b, S, h1b, S, H, H, rows), None,
-                          ops.gemm(drb, S, h2b, S, C, H, rows), None]
-                bias_jobs += [dh1b, dh2b, drb]
+                grads += [dW1[b], None, dW2[b], None, dW3[b], None]
+                bias_jobs += [dh1[b].view(rows, H), dh2[b].view(rows, H), dr[b].view(rows, C)]
             for i, db in enumerate(ops.colsum_multi(bias_jobs)):
                 grads[2 * i + 1] = db
             return grads

@@ -106,6 +106,27 @@ def gemm(a, layout_a, b, layout_b, M, N, K, out=None, out_dtype=torch.float32, a
     return out
 
 
+def gemm_batched(a, layout_a, b, layout_b, M, N, K, out_dtype=torch.float32):
+    """a [batch, ., .], b [batch, ., .] contiguous 3-D tensors of one dtype: out[i] = A_i B_i^T for every i in ONE launch."""
+    require_cuda(a, b)
+    lib = _lib.load_library()
+    if a.dtype != b.dtype:
+        raise _lib.VarsepHipError('gemm operands must share a dtype (%s vs %s)' % (a.dtype, b.dtype))
+    assert a.dim() == 3 and b.dim() == 3 and a.is_contiguous() and b.is_contiguous() and a.shape[0] == b.shape[0]
+    batch = a.shape[0]
+    compute = dtype_code(a)
+    out = torch.empty((batch, M, N), dtype=out_dtype, device=a.device)
+    ws_bytes = lib.vs_gemm_batched_workspace_bytes(batch, M, N, K)
+    ws = _workspace(ws_bytes, a.device) if ws_bytes else None
+    e0 = _pb()
+    check(lib.vs_gemm_batched(compute, batch, M, N, K, a.data_ptr(), a.stride(1), a.stride(0), layout_a, b.data_ptr(), b.stride(1),
+                              b.stride(0), layout_b, out.data_ptr(), N, M * N, dtype_code(out), 1.0, 0, _ptr(ws),
+                              ws.numel() if ws is not None else 0, stream_ptr()), 'vs_gemm_batched')
+    _pe(e0, 'vs_gemm<%s,%s%s>' % ('bf16' if compute == BF16 else 'f32', _LNAME[layout_a], _LNAME[layout_b]),
+        flops=2.0 * batch * M * N * K, nbytes=float(batch * ((M * K + N * K) * a.element_size() + M * N * out.element_size())))
+    return out
+
+
 def cast(src, dtype, out=None):
     require_cuda(src)
     src = src.contiguous()

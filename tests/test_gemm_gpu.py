@@ -167,3 +167,22 @@ def test_colsum_multi_shapes_and_dtypes():
     for o, r, x in zip(outs, refs, jobs):
         assert o.shape == r.shape
         assert torch.allclose(o.double(), r, rtol=1e-5, atol=1e-3 * x.shape[0] ** 0.5 * 1e-2), (x.shape, (o.double() - r).abs().max().item())
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dims', [(3, 512, 32, 3072, 1, 1), (3, 512, 512, 3072, 1, 1), (2, 32, 512, 96, 1, 1), (4, 100, 72, 264, 0, 0),
+                                  (5, 64, 40, 128, 0, 1)])
+def test_gemm_batched_equals_loop(dt, dims):
+    """vs_gemm_batched == a loop of vs_gemm over the problems (same kernel, same split-K plan per problem class)."""
+    from spatiotemporal_variable_separation_amd import ops
+    from oracle.detdata import det_uniform
+    batch, M, N, K, la, lb = dims
+    a = (det_uniform((batch, M, K) if la == 0 else (batch, K, M), 41) - 0.5).to(dt).cuda()
+    b = (det_uniform((batch, N, K) if lb == 0 else (batch, K, N), 42) - 0.5).to(dt).cuda()
+    out = ops.gemm_batched(a, la, b, lb, M, N, K)
+    for i in range(batch):
+        ai = a[i].float() if la == 0 else a[i].float().t()
+        bi = b[i].float() if lb == 0 else b[i].float().t()
+        ref = ai.double() @ bi.double().t()
+        tol = 1e-5 if dt == torch.float32 else 1e-5         # inputs are exactly representable: only accumulation order differs
+        assert torch.allclose(out[i].double(), ref, rtol=1e-4, atol=tol * K ** 0.5), (i, (out[i].double() - ref).abs().max().item())
