@@ -132,6 +132,8 @@ def main():
     use_graph = (not args.no_graph) and _mlp_family(net)
     from spatiotemporal_variable_separation_amd.optim import Adam
     opt = Adam(net.parameters(), lr=4e-4, betas=(0.9, 0.99))
+    from spatiotemporal_variable_separation_amd.train import enable_update_in_backward
+    enable_update_in_backward(opt, net, sync)
     cond, target = synthetic_batch(cfg['data'], cfg['batch'], cfg['nt_cond'], cfg['nt_pred'], device=dev,
                                    seed=1234 + rank)
     lam = cfg['lambdas']

@@ -78,7 +78,7 @@ const char* vs_last_error(void);
  * vs_gemm_workspace_bytes(M, N, K) for an upper bound.  May be NULL when that bound is 0.
  */
 /* `batch` independent GEMMs of one shape in one launch: problem i reads A + i*stride_a, B + i*stride_b (elements of the compute
- * type, multiples of 16 bytes) and writes C + i*stride_c (elements of c_dtype); no bias / activation / mask.  Used for the weight
+ * type; multiples of 16 bytes keep the vector loads) and writes C + i*stride_c (elements of c_dtype); no bias / activation / mask.  Used for the weight
  * gradients of the integrator's residual blocks (reference: resnet.py:22-50, three Linear layers per block).              */
 size_t vs_gemm_batched_workspace_bytes(int batch, int64_t M, int64_t N, int64_t K);
 int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, int64_t stride_a, int layout_a,

@@ -29,8 +29,9 @@ int launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, in
     typedef typename CTraits<CT>::T T;
     constexpr int BK = bk_of<CT>();
     constexpr int U = CTraits<CT>::U;
-    Dense<CT, LA> a{(const T*)A, lda, M, K, ((uintptr_t)A % 16 == 0) && (lda % U == 0)};
-    Dense<CT, LB> b{(const T*)B, ldb, N, K, ((uintptr_t)B % 16 == 0) && (ldb % U == 0)};
+    // 16-byte vector loads need every problem of a batch to start 16-byte aligned too
+    Dense<CT, LA> a{(const T*)A, lda, M, K, ((uintptr_t)A % 16 == 0) && (lda % U == 0) && (epi.batch_a % U == 0)};
+    Dense<CT, LB> b{(const T*)B, ldb, N, K, ((uintptr_t)B % 16 == 0) && (ldb % U == 0) && (epi.batch_b % U == 0)};
     constexpr size_t smem = (TileGeom<CT, LA, BM, BK>::ELEMS + TileGeom<CT, LB, BN, BK>::ELEMS) * sizeof(T);
     const int batch = epi.splits_per_batch > 0 ? plan.batch : 1;
     dim3 grid((unsigned)vs_cdiv(N, BN), (unsigned)vs_cdiv(M, BM), (unsigned)(plan.splits * batch));
@@ -85,8 +86,6 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
     VS_CHECK_ARG((layout_a == LR || layout_a == LS) && (layout_b == LR || layout_b == LS), "vs_gemm_batched: bad layout");
     VS_CHECK_ARG(c_dtype == VS_F32 || c_dtype == VS_BF16, "vs_gemm_batched: bad c_dtype");
     VS_CHECK_ARG(lda >= (layout_a == LR ? K : M) && ldb >= (layout_b == LR ? K : N) && ldc >= N, "vs_gemm_batched: leading dimension too small");
-    const int esz = compute == VS_BF16 ? 2 : 4;
-    VS_CHECK_ARG((stride_a * esz) % 16 == 0 && (stride_b * esz) % 16 == 0, "vs_gemm_batched: operand strides must keep 16-byte alignment");
     Plan plan = make_plan(compute, M, N, K, batch);
     plan.batch = batch;
     Epi epi{C, ldc, c_dtype, alpha, nullptr, VS_ACT_NONE, nullptr, 0, 0, 0, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0, plan.splits, stride_a, stride_b, stride_c};

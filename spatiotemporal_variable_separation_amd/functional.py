@@ -82,6 +82,11 @@ def run_deferred(fn, *inputs):
     return out
 
 
+def side_streams_in_use():
+    """Streams that deferred gradient work of the current step may still be running on."""
+    return [s for s in (_SIDE['wgrad'], _SIDE['rollout']) if s is not None] if _SIDE['on'] else []
+
+
 def join_side_streams():
     """Make the current stream wait for all deferred gradient work (call before the optimizer step)."""
     if not _SIDE['on']:

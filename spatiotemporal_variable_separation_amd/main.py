@@ -116,6 +116,8 @@ def main(argv=None):
     # same constructor call as the reference (main.py:133); the update runs as one multi-tensor HIP launch (optim.py)
     from .optim import Adam
     optimizer = Adam(sep_net.parameters(), lr=args.lr, betas=(args.beta1, args.beta2))
+    from .train import enable_update_in_backward
+    enable_update_in_backward(optimizer, sep_net, grad_sync)
     scheduler = lr_scheduler.MultiStepLR(optimizer, args.scheduler_milestones, gamma=args.scheduler_decay) \
         if args.scheduler else None
 

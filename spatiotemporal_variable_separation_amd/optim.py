@@ -23,6 +23,44 @@ class Adam(torch.optim.Optimizer):
             raise ValueError('invalid Adam hyper-parameters')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tables = {}
+        self._buckets, self._bucket_of, self._left, self._launched, self._stream = [], {}, [], set(), None
+
+    # ---- update-in-backward ------------------------------------------------------------------------------------------
+    def overlap_with_backward(self, buckets):
+        """The update is HBM-bound and the tail of backward (the encoders' small GEMMs) is not: let each bucket of parameters
+        (e.g. one per network: decoder, integrator, E_s, E_t) be updated on a side stream as soon as ITS gradients are final,
+        while backward continues.  `step()` then only handles what is left and joins.  Contract: exactly one backward pass per
+        `step()` (as in the reference loop), every parameter in one param group, no gradient hooks that modify gradients after
+        accumulation (so: not together with the data-parallel reducer)."""
+        assert len(self.param_groups) == 1, 'overlap_with_backward: one param group'
+        self._buckets = [[p for p in b if p.requires_grad] for b in buckets]
+        self._buckets = [b for b in self._buckets if b]
+        self._bucket_of = {id(p): i for i, b in enumerate(self._buckets) for p in b}
+        self._left = [len(b) for b in self._buckets]
+        self._launched = set()
+        for b in self._buckets:
+            for p in b:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _on_grad(self, p):
+        bi = self._bucket_of.get(id(p))
+        if bi is None or bi in self._launched:
+            return
+        self._left[bi] -= 1
+        if self._left[bi] > 0:
+            return
+        group = self.param_groups[0]
+        self._init_group(0, group)
+        from . import functional as VF
+        main = torch.cuda.current_stream(p.device)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=p.device)
+        self._stream.wait_stream(main)
+        for s in VF.side_streams_in_use():             # deferred weight gradients are produced on their own stream
+            self._stream.wait_stream(s)
+        with torch.cuda.stream(self._stream):
+            self._update(0, group, self._buckets[bi])
+        self._launched.add(bi)
 
     # ---- state -------------------------------------------------------------------------------------------------
     def _init_group(self, gi, group):
@@ -67,37 +105,50 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        from . import functional as VF
         lib = _lib.load_library()
         for gi, group in enumerate(self.param_groups):
             self._init_group(gi, group)
-            live = [p for p in group['params'] if p.grad is not None]
+            done = set()
+            if gi == 0 and self._launched:          # buckets already updated from the backward hooks
+                for bi in self._launched:
+                    done.update(id(p) for p in self._buckets[bi])
+            live = [p for p in group['params'] if p.grad is not None and id(p) not in done]
             for p in group['params']:
                 if p.grad is None:                   # torch counts steps per parameter: this one falls one behind the group
                     self.state[p]['skipped'] = self.state[p].get('skipped', 0) + 1
-            if not live:
-                group['step_dev'] += 1
-                continue
-            for p in live:
-                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or not p.grad.is_cuda:
-                    raise VarsepHipError('HIP Adam needs contiguous fp32 CUDA gradients')
-            stream = torch.cuda.current_stream(live[0].device).cuda_stream
-            lr, (b1, b2), eps = group['lr'], group['betas'], group['eps']
-            for i in range(0, len(live), 64):
-                chunk = live[i:i + 64]
-                shadows = [VF.shadow_buffer_for_update(p) for p in chunk]
-                tab = self._table(gi, chunk, shadows)
-                rc = lib.vs_adam_multi(len(chunk), ctypes.cast(tab[0], ctypes.c_void_p), ctypes.cast(tab[1], ctypes.c_void_p),
-                                       ctypes.cast(tab[2], ctypes.c_void_p), ctypes.cast(tab[3], ctypes.c_void_p),
-                                       ctypes.cast(tab[4], ctypes.c_void_p), ctypes.cast(tab[5], ctypes.c_void_p),
-                                       ctypes.cast(tab[6], ctypes.c_void_p), group['step_dev'].data_ptr(), lr, b1, b2, eps, stream)
-                _lib.check(rc, 'vs_adam_multi')
-            _lib.check(lib.vs_adam_step_increment(group['step_dev'].data_ptr(), stream), 'vs_adam_step_increment')
-            for p in live:
-                # the kernel wrote through raw pointers: tell autograd / the operand caches that the parameter changed
-                torch.autograd.graph.increment_version(p)
-            VF.shadows_written(live)
+            if live:
+                self._update(gi, group, live)
+            main = torch.cuda.current_stream(group['params'][0].device)
+            if gi == 0 and self._launched:
+                main.wait_stream(self._stream)
+            _lib.check(lib.vs_adam_step_increment(group['step_dev'].data_ptr(), main.cuda_stream), 'vs_adam_step_increment')
+        if self._buckets:
+            self._left = [len(b) for b in self._buckets]
+            self._launched = set()
         return loss
+
+    def _update(self, gi, group, live):
+        """One vs_adam_multi launch per 64 tensors of `live` on the current stream (the step counter is not touched)."""
+        from . import functional as VF
+        lib = _lib.load_library()
+        for p in live:
+            if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or not p.grad.is_cuda:
+                raise VarsepHipError('HIP Adam needs contiguous fp32 CUDA gradients')
+        stream = torch.cuda.current_stream(live[0].device).cuda_stream
+        lr, (b1, b2), eps = group['lr'], group['betas'], group['eps']
+        for i in range(0, len(live), 64):
+            chunk = live[i:i + 64]
+            shadows = [VF.shadow_buffer_for_update(p) for p in chunk]
+            tab = self._table(gi, chunk, shadows)
+            rc = lib.vs_adam_multi(len(chunk), ctypes.cast(tab[0], ctypes.c_void_p), ctypes.cast(tab[1], ctypes.c_void_p),
+                                   ctypes.cast(tab[2], ctypes.c_void_p), ctypes.cast(tab[3], ctypes.c_void_p),
+                                   ctypes.cast(tab[4], ctypes.c_void_p), ctypes.cast(tab[5], ctypes.c_void_p),
+                                   ctypes.cast(tab[6], ctypes.c_void_p), group['step_dev'].data_ptr(), lr, b1, b2, eps, stream)
+            _lib.check(rc, 'vs_adam_multi')
+        for p in live:
+            # the kernel wrote through raw pointers: tell autograd / the operand caches that the parameter changed
+            torch.autograd.graph.increment_version(p)
+        VF.shadows_written(live)
 
     def state_dict(self):
         # keep the per-parameter `step` entries (torch layout) in sync with the device counter before serialising

@@ -159,6 +159,7 @@ class GraphedStep:
         self.side_streams = side_streams and grad_sync is None and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
         check_optimizer(optimizer)
         self.net, self.opt, self.sync = sep_net, optimizer, grad_sync
+        enable_update_in_backward(optimizer, sep_net, grad_sync)
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
         # static inputs of the recording: one [B, T, ...] buffer, cond / target are views of it (no concatenation per step)
         self.full = torch.cat([cond, target], dim=1).contiguous()
@@ -238,6 +239,24 @@ class GraphedStep:
             self._reduce()
             self.graph_opt.replay()
         return self.loss
+
+
+def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False):
+    """With the HIP Adam and no gradient all-reduce: update decoder + integrator + E_s on a side stream as soon as the last
+    of their gradients is final, i.e. while backward is still in E_t (optim.Adam.overlap_with_backward).  One bucket on
+    purpose: the update streams HBM at >5 TB/s and, launched earlier, would run beside the integrator's backward kernel,
+    whose inter-workgroup exchange is latency-bound on the same memory fabric (measured: 204 -> 275 us)."""
+    # Opt-in (VARSEP_ADAM_OVERLAP=1): on the WaveEq step it is a wash (1.898 vs 1.891 ms) -- the update and E_t's backward
+    # (98 MB of fp32 weight gradient per encoder) compete for the same HBM bandwidth, both just run slower side by side.
+    from .optim import Adam as HipAdam
+    if not force and os.environ.get('VARSEP_ADAM_OVERLAP') != '1':
+        return
+    if isinstance(optimizer, HipAdam) and grad_sync is None and not optimizer._buckets and len(optimizer.param_groups) == 1:
+        owned = {id(p) for p in optimizer.param_groups[0]['params']}
+        early = [p for m in (sep_net.decoder, sep_net.t_resnet, sep_net.Es) for p in m.parameters() if id(p) in owned]
+        buckets = [early, [p for p in sep_net.Et.parameters() if id(p) in owned]]
+        if sum(len(b) for b in buckets) == len(owned):
+            optimizer.overlap_with_backward(buckets)
 
 
 def check_optimizer(optimizer):

@@ -136,3 +136,47 @@ def test_bf16_training_follows_the_fp32_master_weights():
     assert np.allclose(hip, ref, rtol=2e-2), (hip, ref)
     with pytest.raises(ValueError):
         check_optimizer(torch.optim.Adam([torch.nn.Parameter(torch.zeros(4, device='cuda'))], fused=True))
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_update_in_backward_equals_plain_step(graph):
+    """optim.Adam.overlap_with_backward (each network updated on a side stream as soon as its gradients are final) changes
+    the schedule, not the arithmetic: same parameters as the plain step() after several steps, eager and as a recorded graph."""
+    import numpy as np
+    from oracle.detdata import det_fill
+    from oracle.golden_configs import CONFIGS, make_batch
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.train import GraphedStep, compute_losses, enable_update_in_backward
+    cfg = CONFIGS['mlp_mul']
+    lam = cfg['lambdas']
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+
+    def run(overlap):
+        net = det_fill(build_sep_net(cfg), salt=cfg['salt']).cuda().train()
+        opt = Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.99))
+        if overlap:
+            enable_update_in_backward(opt, net, force=True)
+            assert opt._buckets
+        else:
+            opt._buckets = [[]]                      # keeps GraphedStep from switching the overlap on
+        np.random.seed(11)
+        if graph:
+            g = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], (lam['ae'], lam['s'], lam['t'], lam['pred']),
+                            warmup=2)
+            for _ in range(4):
+                g.step()
+        else:
+            for _ in range(5):
+                opt.zero_grad(set_to_none=True)
+                compute_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], False, lam['ae'], lam['s'], lam['t'],
+                               lam['pred'])[0].backward()
+                opt.step()
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in net.state_dict().items()}, float(opt.state_dict()['state'][0]['step'])
+    a, sa = run(True)
+    b, sb = run(False)
+    assert sa == sb
+    for k in a:
+        assert torch.allclose(a[k], b[k], rtol=2e-4, atol=2e-6), k

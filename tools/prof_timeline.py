@@ -2,7 +2,7 @@
 
     python tools/prof_timeline.py <kernel_trace.csv> [step index]
 
-The step is delimited by two consecutive launches of the optimizer kernel; overlapping kernels show a negative gap."""
+The step is delimited by two consecutive launches of the optimizer's step-count kernel; overlapping kernels show a negative gap."""
 import csv
 import sys
 
@@ -11,7 +11,7 @@ def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     which = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(rows) if 'adam_multi' in r['Kernel_Name']]
+    idx = [i for i, r in enumerate(rows) if 'step_increment' in r['Kernel_Name']]
     a, b = idx[which], idx[which + 1]
     t0 = int(rows[a]['End_Timestamp'])
     prev_end, tot, busy_until, idle = t0, 0, t0, 0
