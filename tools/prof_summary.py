@@ -3,19 +3,19 @@
     python tools/prof_summary.py <kernel_stats.csv> [divisor-kernel-substring]
 
 The number of executed steps is taken from the call count of a kernel that runs exactly once per step (default: the
-forward rollout kernel), so warm-up, graph capture and the instrumented eager steps are all accounted for."""
+optimizer's step-count kernel), so warm-up, graph capture and the instrumented eager steps are all accounted for."""
 import csv
 import sys
 
 
 def main():
     path = sys.argv[1]
-    key = sys.argv[2] if len(sys.argv) > 2 else 'rollout'
+    key = sys.argv[2] if len(sys.argv) > 2 else 'step_increment'
     rows = list(csv.DictReader(open(path)))
     name_k = 'Name' if 'Name' in rows[0] else 'KernelName'
     def calls(r): return int(r.get('Calls') or r.get('Count'))
     def total_ns(r): return float(r.get('TotalDurationNs') or r.get('TotalDuration(ns)') or r['TotalDuration'])
-    fw = [r for r in rows if key in r[name_k] and ('Lb1E' in r[name_k] or 'true' in r[name_k] or 'fwd' in r[name_k])]
+    fw = [r for r in rows if key in r[name_k]]
     steps = calls(fw[0]) if fw else 1
     tot = sum(total_ns(r) for r in rows)
     print(f'steps executed: {steps}; total kernel time per step: {tot / steps / 1e3:.1f} us\n')
