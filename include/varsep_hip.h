@@ -250,21 +250,26 @@ int vs_mlp_rollout_bwd(int compute, int B, int C, int H, int n_blocks, int n_ste
  *             workspace of vs_conv_wgrad_workspace_bytes(...) bytes (NULL = no split, slower but correct)
  * In every call B, Cin, H, W, Cout describe the FORWARD op (x's shape and the weight's channel counts).
  */
+/* Workspace for every conv entry point below (forward, input gradient, weight gradient of Conv2d(Cin, Cout, k, stride, pad) on
+ * [B, Cin, H, W] and of the ConvTranspose2d with the same numbers).  With a workspace of this size, contractions with >= 64
+ * output channels run as "gather once into a transient column matrix, then dense MFMA GEMM" (2-3x faster than gathering
+ * inside the MFMA loop); with workspace = NULL (or too small) they gather inside the loop.  The result is the same either way. */
+size_t vs_conv_workspace_bytes(int compute, int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad);
 size_t vs_conv_wgrad_workspace_bytes(int B, int Cin, int OH, int OW, int Cout, int kh, int kw);
 /* w: fp32 master weight [D0][D1][kh][kw] (Conv2d: D0 = Cout, D1 = Cin; ConvTranspose2d: D0 = Cin, D1 = Cout);
  * dst: vs_conv_packed_elems(...) elements of the compute type.                                                     */
 size_t vs_conv_packed_elems(int D0, int D1, int kh, int kw, int stride, int pad);
 int vs_conv_pack_weight(int compute, const float* w, int D0, int D1, int kh, int kw, int stride, int pad, void* dst, void* stream);
 int vs_conv2d_fwd(int compute, const void* x, const void* w, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
-                  int Cout, int kh, int kw, int stride, int pad, void* stream);
+                  int Cout, int kh, int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
 int vs_conv2d_dgrad(int compute, const void* dy, const void* w_packed, void* dx, int dx_dtype, int B, int Cin, int H, int W, int Cout, int kh,
-                    int kw, int stride, int pad, void* stream);
+                    int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
 int vs_conv2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                     int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
 int vs_conv_transpose2d_fwd(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H,
-                            int W, int Cout, int kh, int kw, int stride, int pad, void* stream);
+                            int W, int Cout, int kh, int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
 int vs_conv_transpose2d_dgrad(int compute, const void* dy, const void* w, void* dx, int dx_dtype, int B, int Cin, int H, int W, int Cout,
-                              int kh, int kw, int stride, int pad, void* stream);
+                              int kh, int kw, int stride, int pad, void* workspace, size_t workspace_bytes, int cols_from_wgrad, void* stream);
 int vs_conv_transpose2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh,
                               int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
 

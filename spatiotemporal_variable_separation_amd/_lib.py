@@ -104,11 +104,12 @@ SIGNATURES = {
     'vs_conv_wgrad_workspace_bytes': (_sz, [_i32] * 7),
     'vs_conv_packed_elems': (_sz, [_i32] * 6),
     'vs_conv_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    'vs_conv2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
-    'vs_conv2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
+    'vs_conv_workspace_bytes': (_sz, [_i32] * 10),
+    'vs_conv2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _vp]),
+    'vs_conv2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _vp]),
     'vs_conv2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
-    'vs_conv_transpose2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
-    'vs_conv_transpose2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp]),
+    'vs_conv_transpose2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _vp]),
+    'vs_conv_transpose2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _i32, _vp]),
     'vs_conv_transpose2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
     'vs_bn_stats': (_i32, [_vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp]),
     'vs_bn_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),

@@ -374,10 +374,113 @@ __global__ __launch_bounds__(256) void gather_rowdot_kernel(Dense<CT, LR> A, Gat
     }
 }
 
+// ---- materialised gather ("im2col" into a transient column matrix) -------------------------------------------------------------
+// cols[q][pix] = src[b, c, gy*s + dy(t), gx*s + dx(t)]  (q = c * ntap + t, pixels contiguous, row pitch ld = npix rounded up to U).
+// The implicit form above pays the gather's index math and border handling inside the MFMA loop (50-75 TFLOP/s); for
+// contractions with >= 64 output channels it is cheaper to run the gather ONCE as a streaming kernel (HBM-bound: 2 bytes written
+// and later read per (q, pixel)) and to contract with the dense operand loaders (350-430 TFLOP/s).  The matrix lives in the
+// caller's workspace and is dead after the call.
+template <int CT>
+__global__ __launch_bounds__(256) void im2col_kernel(TapGather<CT> gth, typename CTraits<CT>::T* cols, int64_t ld, int64_t units_per_q) {
+    constexpr int U = CTraits<CT>::U;
+    const int q = blockIdx.y;
+    int c, t;
+    gth.g.split_q(q, c, t);
+    const int dyv = gth.g.tap_dy(t), dxv = gth.g.tap_dx(t);
+    typename CTraits<CT>::T* row = cols + (int64_t)q * ld;
+    for (int64_t pu = (int64_t)blockIdx.x * 256 + threadIdx.x; pu < units_per_q; pu += (int64_t)gridDim.x * 256) {
+        const int64_t pix0 = pu * U;
+        int b, gy, gx;
+        gth.g.split_pix(pix0, b, gy, gx);
+        *reinterpret_cast<u32x4*>(row + pix0) = gth.unit_at(pix0, b, gy, gx, c, dyv, dxv);
+    }
+}
+
+// Stride-1, same-size grids with taps inside the 3x3 neighbourhood (the parity phases of the stride-2 transposed convolutions,
+// 3x3 pad-1 convolutions), bf16, rows a multiple of 8 pixels: one thread owns (channel c, 8-pixel unit) and produces the units
+// of ALL taps from at most three source rows, each fetched once as (left neighbour, aligned 16-byte unit, right neighbour) --
+// nine independent loads, no per-tap address math, shifts by v_alignbyte.  The generic kernel above spends one dependent,
+// branchy gather per (tap, unit) and reaches ~1 TB/s of column-matrix writes; this form is bound by the writes.
+__global__ __launch_bounds__(256) void im2col_s1_bf16_kernel(TapGather<VS_BF16> gth, __bf16* cols, int64_t ld, int64_t units_per_c) {
+    const TapGeo& g = gth.g;
+    const int c = blockIdx.y, ntap = g.ntap, W = g.W, H = g.H;
+    for (int64_t pu = (int64_t)blockIdx.x * 256 + threadIdx.x; pu < units_per_c; pu += (int64_t)gridDim.x * 256) {
+        const int64_t pix0 = pu * 8;
+        int b, gy, gx;
+        g.split_pix(pix0, b, gy, gx);
+        const __bf16* plane = gth.src + ((int64_t)b * g.C + c) * H * W;
+        u32x4 u[3];
+        unsigned l[3], r[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {                                   // source rows gy - 1, gy, gy + 1
+            const int iy = gy + d - 1;
+            const bool ok = iy >= 0 && iy < H;
+            const __bf16* row = plane + (int64_t)(ok ? iy : gy) * W + gx;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(row);
+            const unsigned short lv = *reinterpret_cast<const unsigned short*>(row + (gx > 0 ? -1 : 0));
+            const unsigned short rv = *reinterpret_cast<const unsigned short*>(row + (gx + 8 < W ? 8 : 7));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[d][j] = ok ? v[j] : 0u;
+            l[d] = (ok && gx > 0) ? (unsigned)lv : 0u;
+            r[d] = (ok && gx + 8 < W) ? (unsigned)rv : 0u;
+        }
+        for (int t = 0; t < ntap; ++t) {
+            const int dyv = g.tap_dy(t), dxv = g.tap_dx(t);
+            const u32x4 uu = dyv < 0 ? u[0] : (dyv == 0 ? u[1] : u[2]);
+            const unsigned ll = dyv < 0 ? l[0] : (dyv == 0 ? l[1] : l[2]);
+            const unsigned rr = dyv < 0 ? r[0] : (dyv == 0 ? r[1] : r[2]);
+            u32x4 o;
+            if (dxv == 0) {
+                o = uu;
+            } else if (dxv < 0) {                                       // [l, u0 .. u6]
+                o[0] = (uu[0] << 16) | ll;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) o[j] = __builtin_amdgcn_alignbyte(uu[j], uu[j - 1], 2);
+            } else {                                                    // [u1 .. u7, r]
+#pragma unroll
+                for (int j = 0; j < 3; ++j) o[j] = __builtin_amdgcn_alignbyte(uu[j + 1], uu[j], 2);
+                o[3] = (uu[3] >> 16) | (rr << 16);
+            }
+            *reinterpret_cast<u32x4*>(cols + ((int64_t)c * ntap + t) * ld + pix0) = o;
+        }
+    }
+}
+
+inline bool s1_fast_ok(const TapGeo& g, int64_t npix, const void* src) {
+    if (g.s != 1 || g.GH != g.H || g.GW != g.W || g.W % 8 != 0 || npix % 8 != 0 || (uintptr_t)src % 16 != 0) return false;
+    for (int t = 0; t < g.ntap; ++t)
+        if (g.dy[t] < -1 || g.dy[t] > 1 || g.dx[t] < -1 || g.dx[t] > 1) return false;
+    return true;
+}
+
+template <int CT>
+inline int64_t cols_pitch(int64_t npix) { return (npix + CTraits<CT>::U - 1) / CTraits<CT>::U * CTraits<CT>::U; }
+
+// when the column matrix pays: enough output channels that the contraction dominates the extra HBM pass
+inline bool cols_worthwhile(int64_t M, int64_t npix, int64_t nq) { return M >= 64 && npix * nq >= (1 << 20) && nq <= 65535; }
+
+template <int CT>
+int materialise(const TapGather<CT>& gth, void* ws, hipStream_t st, const char* what) {
+    constexpr int U = CTraits<CT>::U;
+    const int64_t ld = cols_pitch<CT>(gth.npix), units = ld / U;
+    int64_t bx = (units + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    if constexpr (CT == VS_BF16) {
+        if (s1_fast_ok(gth.g, gth.npix, gth.src)) {
+            hipLaunchKernelGGL(im2col_s1_bf16_kernel, dim3((unsigned)bx, (unsigned)gth.g.C), dim3(256), 0, st, gth, (__bf16*)ws, ld, units);
+            VS_CHECK_LAUNCH(what);
+            return VS_OK;
+        }
+    }
+    hipLaunchKernelGGL(im2col_kernel<CT>, dim3((unsigned)bx, (unsigned)gth.nq), dim3(256), 0, st, gth, (typename CTraits<CT>::T*)ws, ld, units);
+    VS_CHECK_LAUNCH(what);
+    return VS_OK;
+}
+
 // ---- forward-like contraction:  out[b, m, gy*S+oy, gx*S+ox] = bias[m] + sum Wd[m][(c,t)] src[b, c, gy*s+dy, gx*s+dx] ----
 template <int CT>
 int gather_gemm(const void* src, const void* wd, const float* bias, void* out, int out_dtype, int M, const TapGeo& g, int OH, int OW, int scat,
-                int oy, int ox, hipStream_t st, const char* what) {
+                int oy, int ox, void* ws, size_t ws_bytes, hipStream_t st, const char* what, bool cols_ready = false) {
     typedef typename CTraits<CT>::T T;
     const int64_t N = (int64_t)g.B * g.GH * g.GW, K = (int64_t)g.C * g.ntap;
     Dense<CT, LR> a{(const T*)wd, K, M, K, ((uintptr_t)wd % 16 == 0) && (K % CTraits<CT>::U == 0)};
@@ -394,6 +497,16 @@ int gather_gemm(const void* src, const void* wd, const float* bias, void* out, i
         VS_CHECK_LAUNCH(what);
         return VS_OK;
     }
+    const size_t cols_bytes = (size_t)K * cols_pitch<CT>(N) * sizeof(T);
+    if (ws && ws_bytes >= cols_bytes && cols_worthwhile(M, N, K)) {
+        if (!cols_ready) {
+            int rc = materialise<CT>(b.gather, ws, st, what);
+            if (rc != VS_OK) return rc;
+        }
+        const int64_t ld = cols_pitch<CT>(N);
+        Dense<CT, LS> bd{(const T*)ws, ld, N, K, 1};               // element (pixel n, k = q) at cols[q * ld + n]
+        return run<CT>(a, bd, M, N, K, e, (char*)ws + cols_bytes, ws_bytes - cols_bytes, st, what);
+    }
     return run<CT>(a, b, M, N, K, e, nullptr, 0, st, what);
 }
 
@@ -409,10 +522,10 @@ inline void natural_taps(TapGeo& g, int kh, int kw, int pad, bool flipped) {
 // plain (strided) convolution form: Conv2d forward and ConvTranspose2d input gradient; weights in reference layout
 template <int CT>
 int conv_form(const void* src, const void* w, const float* bias, void* out, int out_dtype, int B, int Csrc, int H, int W, int M, int kh, int kw,
-              int s, int p, int OH, int OW, hipStream_t st, const char* what) {
+              int s, int p, int OH, int OW, void* ws, size_t ws_bytes, hipStream_t st, const char* what, bool cols_ready = false) {
     TapGeo g{B, Csrc, H, W, OH, OW, s, 0, {}, {}, 0, 0, 0, 0, 0};
     natural_taps(g, kh, kw, p, false);
-    return gather_gemm<CT>(src, w, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, st, what);
+    return gather_gemm<CT>(src, w, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, ws, ws_bytes, st, what, cols_ready);
 }
 
 // transposed form: ConvTranspose2d forward and Conv2d input gradient; weights PACKED by vs_conv_pack_weight
@@ -420,12 +533,12 @@ int conv_form(const void* src, const void* w, const float* bias, void* out, int 
 //   stride 2 phase: Wp[phase][M][Csrc][ntap_phase]
 template <int CT>
 int transposed_form(const void* src, const void* wp, const float* bias, void* out, int out_dtype, int B, int Csrc, int H, int W, int M, int kh,
-                    int kw, int s, int p, int OH, int OW, hipStream_t st, const char* what) {
+                    int kw, int s, int p, int OH, int OW, void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
     typedef typename CTraits<CT>::T T;
     if (s == 1) {
         TapGeo g{B, Csrc, H, W, OH, OW, 1, 0, {}, {}, 0, 0, 0, 0, 0};
         natural_taps(g, kh, kw, p, true);
-        return gather_gemm<CT>(src, wp, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, st, what);
+        return gather_gemm<CT>(src, wp, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, ws, ws_bytes, st, what);
     }
     if (!phase_ok(kh, kw, s, p)) return vs_fail(VS_ERR_UNSUPPORTED, "%s: transposed geometry k%d s%d p%d is not supported", what, kh, s, p);
     const T* wph = (const T*)wp;
@@ -434,11 +547,19 @@ int transposed_form(const void* src, const void* wp, const float* bias, void* ou
             TapGeo g{B, Csrc, H, W, H, W, 1, 0, {}, {}, 0, 0, 0, 0, 0};
             int kidx[MAXTAP];
             g.ntap = phase_taps(kh, kw, s, p, py, px, kidx, g.dy, g.dx);
-            int rc = gather_gemm<CT>(src, wph, bias, out, out_dtype, M, g, OH, OW, s, py, px, st, what);
+            int rc = gather_gemm<CT>(src, wph, bias, out, out_dtype, M, g, OH, OW, s, py, px, ws, ws_bytes, st, what);
             if (rc != VS_OK) return rc;
             wph += (int64_t)M * Csrc * g.ntap;
         }
     return VS_OK;
+}
+
+// does wgrad_form(M, N = channels * taps, K = pixels) materialise its column matrix into this workspace?  (also asked by the
+// ConvTranspose2d input gradient, which can reuse that very matrix)
+template <int CT>
+inline bool wgrad_uses_cols(int64_t M, int64_t N, int64_t K, const void* ws, size_t ws_bytes) {
+    const size_t cols_bytes = (size_t)N * cols_pitch<CT>(K) * sizeof(typename CTraits<CT>::T);
+    return ws && ws_bytes >= cols_bytes + vs_gemm_workspace_bytes(M, N, K) && cols_worthwhile(M, K, N);
 }
 
 // weight gradient: dW[m][(c,t)] = sum_pix R[b,m,pix] * G[b,c,py*s-p+ky,px*s-p+kx]; R has Cr channels on the (PH,PW) pixel
@@ -456,6 +577,14 @@ int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH
     TapGeo g{B, Cg, GH, GW, PH, PW, s, 0, {}, {}, 0, 0, 0, 0, 0};
     natural_taps(g, kh, kw, p, false);
     b.gather.src = (const T*)gsrc; b.gather.g = g; b.gather.g.finish(); b.gather.npix = K; b.gather.nq = N;
+    const size_t cols_bytes = (size_t)N * cols_pitch<CT>(K) * sizeof(T);
+    if (wgrad_uses_cols<CT>(M, N, K, ws, ws_bytes)) {
+        int rc = materialise<CT>(b.gather, ws, st, what);
+        if (rc != VS_OK) return rc;
+        const int64_t ld = cols_pitch<CT>(K);
+        Dense<CT, LR> bd{(const T*)ws, ld, N, K, 1};               // element (q, k = pixel) at cols[q * ld + k]
+        return run<CT>(a, bd, M, N, K, rowmajor_epi(dw, N), (char*)ws + cols_bytes, ws_bytes - cols_bytes, st, what);
+    }
     return run<CT>(a, b, M, N, K, rowmajor_epi(dw, N), ws, ws_bytes, st, what);
 }
 
@@ -525,25 +654,50 @@ extern "C" size_t vs_conv_wgrad_workspace_bytes(int B, int Cin, int OH, int OW, 
     return a > b ? a : b;
 }
 
+extern "C" size_t vs_conv_workspace_bytes(int compute, int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad) {
+    // covers forward, input gradient and weight gradient of Conv2d(Cin, Cout) on [B, Cin, H, W] AND of the ConvTranspose2d with the
+    // same numbers: the largest column matrix any of them materialises + the split-K slabs of the contraction behind it
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
+    const int64_t e = compute == VS_BF16 ? 2 : 4, U = 16 / e;
+    const int64_t OHc = (H + 2 * pad - kh) / stride + 1, OWc = (W + 2 * pad - kw) / stride + 1;       // Conv2d output
+    const int64_t OHt = (int64_t)(H - 1) * stride - 2 * pad + kh, OWt = (int64_t)(W - 1) * stride - 2 * pad + kw;   // ConvTranspose2d output
+    const int64_t khw = (int64_t)kh * kw;
+    const int64_t tt = (stride == 2 && phase_ok(kh, kw, stride, pad)) ? khw / 4 : khw;      // taps per launch of the transposed forms
+    auto cols = [&](int64_t npix, int64_t nq) { return (size_t)(nq * ((npix + U - 1) / U * U) * e); };
+    size_t worst = 0;
+    auto take = [&](size_t c, int64_t M, int64_t N, int64_t K) { const size_t t = c + vs_gemm_workspace_bytes(M, N, K); if (t > worst) worst = t; };
+    if (OHc > 0 && OWc > 0) {
+        take(cols(B * OHc * OWc, Cin * khw), Cout, B * OHc * OWc, Cin * khw);                         // conv forward
+        take(cols(B * OHc * OWc, Cout * tt), Cin, (int64_t)B * H * W, Cout * tt);                     // conv dgrad (per phase when stride 2)
+        take(cols(B * OHc * OWc, Cin * khw), Cout, Cin * khw, B * OHc * OWc);                         // conv wgrad
+    }
+    if (OHt > 0 && OWt > 0) {
+        take(cols((int64_t)B * H * W, Cin * tt), Cout, B * OHt * OWt, Cin * tt);                      // convT forward (per phase when stride 2)
+        take(cols((int64_t)B * H * W, Cout * khw), Cin, (int64_t)B * H * W, Cout * khw);              // convT dgrad
+        take(cols((int64_t)B * H * W, Cout * khw), Cin, Cout * khw, (int64_t)B * H * W);              // convT wgrad
+    }
+    return worst;
+}
+
 extern "C" int vs_conv2d_fwd(int compute, const void* x, const void* w, const float* bias, void* y, int y_dtype, int B, int Cin, int H,
-                             int W, int Cout, int kh, int kw, int stride, int pad, void* stream) {
+                             int W, int Cout, int kh, int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_conv("vs_conv2d_fwd", compute, x, w, y, B, Cin, H, W, Cout, kh, kw, stride, pad);
     if (rc) return rc;
     const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
     VS_CHECK_ARG(OH > 0 && OW > 0, "vs_conv2d_fwd: empty output");
-    return VS_DISPATCH(compute, conv_form, x, w, bias, y, y_dtype, B, Cin, H, W, Cout, kh, kw, stride, pad, OH, OW, (hipStream_t)stream,
-                       "vs_conv2d_fwd");
+    return VS_DISPATCH(compute, conv_form, x, w, bias, y, y_dtype, B, Cin, H, W, Cout, kh, kw, stride, pad, OH, OW, workspace, workspace_bytes,
+                       (hipStream_t)stream, "vs_conv2d_fwd");
 }
 
 extern "C" int vs_conv2d_dgrad(int compute, const void* dy, const void* w_packed, void* dx, int dx_dtype, int B, int Cin, int H, int W,
-                               int Cout, int kh, int kw, int stride, int pad, void* stream) {
+                               int Cout, int kh, int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_conv("vs_conv2d_dgrad", compute, dy, w_packed, dx, B, Cin, H, W, Cout, kh, kw, stride, pad);
     if (rc) return rc;
     const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
     // dx[b,ci,y,x] = sum dy[b,co,(y+p-ky)/s,(x+p-kx)/s] W[co][ci][ky,kx]: transposed form gathering from dy
     VS_CHECK_ARG(stride == 1 || (OH * stride == H && OW * stride == W), "vs_conv2d_dgrad: stride-2 needs H == 2*OH");
     return VS_DISPATCH(compute, transposed_form, dy, w_packed, nullptr, dx, dx_dtype, B, Cout, OH, OW, Cin, kh, kw, stride, pad, H, W,
-                       (hipStream_t)stream, "vs_conv2d_dgrad");
+                       workspace, workspace_bytes, (hipStream_t)stream, "vs_conv2d_dgrad");
 }
 
 extern "C" int vs_conv2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh, int kw,
@@ -556,23 +710,33 @@ extern "C" int vs_conv2d_wgrad(int compute, const void* dy, const void* x, float
 }
 
 extern "C" int vs_conv_transpose2d_fwd(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B,
-                                       int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, void* stream) {
+                                       int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
     int rc = check_conv("vs_conv_transpose2d_fwd", compute, x, w_packed, y, B, Cin, H, W, Cout, kh, kw, stride, pad);
     if (rc) return rc;
     const int OH = (H - 1) * stride - 2 * pad + kh, OW = (W - 1) * stride - 2 * pad + kw;
     VS_CHECK_ARG(OH > 0 && OW > 0, "vs_conv_transpose2d_fwd: empty output");
     return VS_DISPATCH(compute, transposed_form, x, w_packed, bias, y, y_dtype, B, Cin, H, W, Cout, kh, kw, stride, pad, OH, OW,
-                       (hipStream_t)stream, "vs_conv_transpose2d_fwd");
+                       workspace, workspace_bytes, (hipStream_t)stream, "vs_conv_transpose2d_fwd");
 }
 
 extern "C" int vs_conv_transpose2d_dgrad(int compute, const void* dy, const void* w, void* dx, int dx_dtype, int B, int Cin, int H, int W,
-                                         int Cout, int kh, int kw, int stride, int pad, void* stream) {
+                                         int Cout, int kh, int kw, int stride, int pad, void* workspace, size_t workspace_bytes,
+                                         int cols_from_wgrad, void* stream) {
     int rc = check_conv("vs_conv_transpose2d_dgrad", compute, dy, w, dx, B, Cin, H, W, Cout, kh, kw, stride, pad);
     if (rc) return rc;
     const int OH = (H - 1) * stride - 2 * pad + kh, OW = (W - 1) * stride - 2 * pad + kw;
     // dx[b,ci,y,x] = sum dy[b,co,y*s-p+ky,x*s-p+kx] W[ci][(co,ky,kx)]: a plain convolution of dy with W read as dense [Cin, Cout*khw]
-    return VS_DISPATCH(compute, conv_form, dy, w, nullptr, dx, dx_dtype, B, Cout, OH, OW, Cin, kh, kw, stride, pad, H, W, (hipStream_t)stream,
-                       "vs_conv_transpose2d_dgrad");
+    // the weight gradient gathers dy through the same taps onto the same pixel grid: when it ran just before on this stream with
+    // this workspace (and did materialise), its column matrix is still there
+    bool ready = false;
+    if (cols_from_wgrad) {
+        const int64_t Mw = Cin, Nw = (int64_t)Cout * kh * kw, Kw = (int64_t)B * H * W;
+        ready = compute == VS_BF16 ? wgrad_uses_cols<VS_BF16>(Mw, Nw, Kw, workspace, workspace_bytes)
+                                   : wgrad_uses_cols<VS_F32>(Mw, Nw, Kw, workspace, workspace_bytes);
+    }
+    return VS_DISPATCH(compute, conv_form, dy, w, nullptr, dx, dx_dtype, B, Cout, OH, OW, Cin, kh, kw, stride, pad, H, W, workspace,
+                       workspace_bytes, (hipStream_t)stream, "vs_conv_transpose2d_dgrad", ready);
 }
 
 extern "C" int vs_conv_transpose2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout,

@@ -384,7 +384,8 @@ class ConvBlock(torch.autograd.Function):
         dx = None
         if ctx.x_needs_grad:
             wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
-            dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp)
+            dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
+                                cols_from_wgrad=transposed and dw is not None)
         return dx, dw, db, dgamma, dbeta, None, None, None
 
 

@@ -361,6 +361,15 @@ def conv_pack_weight(w_master, dtype, stride, pad, out=None):
     return out
 
 
+def _conv_workspace(x_dtype_code, B, Cin, H, W, Cout, k, stride, pad, device):
+    """Transient column-matrix + split-K workspace of a convolution (VS_CONV_COLS=0: none -> gather inside the MFMA loop)."""
+    import os
+    if os.environ.get('VS_CONV_COLS') == '0':
+        return None
+    nbytes = _lib.load_library().vs_conv_workspace_bytes(x_dtype_code, B, Cin, H, W, Cout, k, k, stride, pad)
+    return _workspace(nbytes, device) if nbytes else None
+
+
 def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     """x [B,Cin,H,W], w Conv2d [Cout,Cin,k,k] / ConvTranspose2d [Cin,Cout,k,k] in the same (compute) dtype.
     The transposed form consumes `w_packed` (conv_pack_weight); it is built on the fly from `w` when not given."""
@@ -379,16 +388,19 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     y = torch.empty((B, Cout, OH, OW), dtype=out_dtype, device=x.device)
     lib = _lib.load_library()
     fn = lib.vs_conv_transpose2d_fwd if transposed else lib.vs_conv2d_fwd
+    ws = _conv_workspace(dtype_code(x), B, Cin, H, W, Cout, k, stride, pad, x.device)
     e0 = _pb()
     check(fn(dtype_code(x), x.data_ptr(), w_arg.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W, Cout, k, k,
-             stride, pad, stream_ptr()), 'vs_conv_fwd')
+             stride, pad, _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()), 'vs_conv_fwd')
     _pe(e0, 'vs_conv%s_fwd<%s>' % ('T' if transposed else '', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
         nbytes=float(x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()))
     return y
 
 
-def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None):
+def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None, cols_from_wgrad=False):
+    """cols_from_wgrad (ConvTranspose2d only): conv_wgrad of the same dy / geometry ran just before on this stream, reuse its column
+    matrix instead of gathering dy a second time."""
     require_cuda(dy, w)
     assert dy.is_contiguous() and w.is_contiguous() and dy.dtype == w.dtype
     if not transposed:
@@ -403,9 +415,11 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     dx = torch.empty((B, Cin, H, W), dtype=out_dtype, device=dy.device)
     lib = _lib.load_library()
     fn = lib.vs_conv_transpose2d_dgrad if transposed else lib.vs_conv2d_dgrad
+    ws = _conv_workspace(dtype_code(dy), B, Cin, H, W, Cout, k, stride, pad, dy.device)
     e0 = _pb()
+    extra = (int(bool(cols_from_wgrad)),) if transposed else ()
     check(fn(dtype_code(dy), dy.data_ptr(), w_arg.data_ptr(), dx.data_ptr(), dtype_code(dx), B, Cin, H, W, Cout, k, k, stride, pad,
-             stream_ptr()), 'vs_conv_dgrad')
+             _ptr(ws), ws.numel() if ws is not None else 0, *extra, stream_ptr()), 'vs_conv_dgrad')
     OH, OW = dy.shape[2], dy.shape[3]
     _pe(e0, 'vs_conv%s_dgrad<%s>' % ('T' if transposed else '', 'bf16' if dy.dtype == torch.bfloat16 else 'f32'),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
@@ -423,8 +437,10 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed):
     dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     lib = _lib.load_library()
     pix_h, pix_w = (H, W) if transposed else (OH, OW)
-    ws_bytes = lib.vs_conv_wgrad_workspace_bytes(B, Cin, pix_h, pix_w, Cout, k, k)
-    ws = _workspace(ws_bytes, x.device) if ws_bytes else None
+    ws = _conv_workspace(dtype_code(x), B, Cin, H, W, Cout, k, stride, pad, x.device)
+    if ws is None:
+        ws_bytes = lib.vs_conv_wgrad_workspace_bytes(B, Cin, pix_h, pix_w, Cout, k, k)
+        ws = _workspace(ws_bytes, x.device) if ws_bytes else None
     fn = lib.vs_conv_transpose2d_wgrad if transposed else lib.vs_conv2d_wgrad
     e0 = _pb()
     check(fn(dtype_code(x), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, k, k, stride, pad, _ptr(ws),
