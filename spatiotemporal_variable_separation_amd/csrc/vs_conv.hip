@@ -446,6 +446,60 @@ __global__ __launch_bounds__(256) void im2col_s1_bf16_kernel(TapGather<VS_BF16> 
     }
 }
 
+// Stride-2 4x4 pad-1 gathers (Conv2d k4 s2 p1 forward / weight gradient, ConvTranspose2d k4 s2 p1 input / weight gradient), bf16,
+// output-grid rows a multiple of 8 pixels: one thread owns (channel c, 8 grid pixels of row gy) and produces the units of all
+// 16 taps from the four source rows 2 gy - 1 .. 2 gy + 2, each fetched once as (left neighbour, two aligned 16-byte units,
+// right neighbour) -- 16 independent loads.  Source column of grid pixel j under tap kx is 2 (gx + j) - 1 + kx: the even /
+// odd halves of the 16-element window, shifted by one element for kx = 0 and kx = 3.
+__global__ __launch_bounds__(256) void im2col_k4s2_bf16_kernel(TapGather<VS_BF16> gth, __bf16* cols, int64_t ld, int64_t units_per_c) {
+    const TapGeo& g = gth.g;
+    const int c = blockIdx.y, W = g.W, H = g.H;
+    for (int64_t pu = (int64_t)blockIdx.x * 256 + threadIdx.x; pu < units_per_c; pu += (int64_t)gridDim.x * 256) {
+        const int64_t pix0 = pu * 8;
+        int b, gy, gx;
+        g.split_pix(pix0, b, gy, gx);
+        const __bf16* plane = gth.src + ((int64_t)b * g.C + c) * H * W;
+        const int x0 = 2 * gx;                                            // window = source columns x0 - 1 .. x0 + 16
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int iy = 2 * gy - 1 + ky;
+            const bool ok = iy >= 0 && iy < H;
+            const __bf16* row = plane + (int64_t)(ok ? iy : 0) * W + x0;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(row), bq = *reinterpret_cast<const u32x4*>(row + 8);
+            const unsigned short lv = *reinterpret_cast<const unsigned short*>(row + (x0 > 0 ? -1 : 0));
+            const unsigned short rv = *reinterpret_cast<const unsigned short*>(row + (x0 + 16 < W ? 16 : 15));
+            unsigned w[8];                                                // dword i = (r[2i], r[2i+1])
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w[j] = ok ? a[j] : 0u; w[4 + j] = ok ? bq[j] : 0u; }
+            const unsigned L = (ok && x0 > 0) ? (unsigned)lv : 0u, R = (ok && x0 + 16 < W) ? (unsigned)rv : 0u;
+            u32x4 ev, od, evs, ods;                                       // evens r0,r2,..,r14 | odds r1,..,r15 | r2,..,r14,R | L,r1,..,r13
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ev[j] = (w[2 * j] & 0xffffu) | (w[2 * j + 1] << 16);
+                od[j] = (w[2 * j] >> 16) | (w[2 * j + 1] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) evs[j] = __builtin_amdgcn_alignbyte(ev[j + 1], ev[j], 2);
+            evs[3] = (ev[3] >> 16) | (R << 16);
+            ods[0] = (od[0] << 16) | L;
+#pragma unroll
+            for (int j = 1; j < 4; ++j) ods[j] = __builtin_amdgcn_alignbyte(od[j], od[j - 1], 2);
+            __bf16* dst = cols + ((int64_t)c * 16 + ky * 4) * ld + pix0;          // tap t = ky * 4 + kx  (natural_taps order)
+            *reinterpret_cast<u32x4*>(dst) = ods;                                  // kx = 0: columns 2 j - 1
+            *reinterpret_cast<u32x4*>(dst + ld) = ev;                              // kx = 1: columns 2 j
+            *reinterpret_cast<u32x4*>(dst + 2 * ld) = od;                          // kx = 2: columns 2 j + 1
+            *reinterpret_cast<u32x4*>(dst + 3 * ld) = evs;                         // kx = 3: columns 2 j + 2
+        }
+    }
+}
+
+inline bool k4s2_fast_ok(const TapGeo& g, int64_t npix, const void* src) {
+    if (g.s != 2 || g.ntap != 16 || g.H != 2 * g.GH || g.W != 2 * g.GW || g.GW % 8 != 0 || npix % 8 != 0 || (uintptr_t)src % 16 != 0) return false;
+    for (int t = 0; t < 16; ++t)
+        if (g.dy[t] != t / 4 - 1 || g.dx[t] != t % 4 - 1) return false;              // natural (unflipped) k4 p1 taps
+    return true;
+}
+
 inline bool s1_fast_ok(const TapGeo& g, int64_t npix, const void* src) {
     if (g.s != 1 || g.GH != g.H || g.GW != g.W || g.W % 8 != 0 || npix % 8 != 0 || (uintptr_t)src % 16 != 0) return false;
     for (int t = 0; t < g.ntap; ++t)
@@ -468,6 +522,11 @@ int materialise(const TapGather<CT>& gth, void* ws, hipStream_t st, const char* 
     if constexpr (CT == VS_BF16) {
         if (s1_fast_ok(gth.g, gth.npix, gth.src)) {
             hipLaunchKernelGGL(im2col_s1_bf16_kernel, dim3((unsigned)bx, (unsigned)gth.g.C), dim3(256), 0, st, gth, (__bf16*)ws, ld, units);
+            VS_CHECK_LAUNCH(what);
+            return VS_OK;
+        }
+        if (k4s2_fast_ok(gth.g, gth.npix, gth.src)) {
+            hipLaunchKernelGGL(im2col_k4s2_bf16_kernel, dim3((unsigned)bx, (unsigned)gth.g.C), dim3(256), 0, st, gth, (__bf16*)ws, ld, units);
             VS_CHECK_LAUNCH(what);
             return VS_OK;
         }

@@ -21,6 +21,13 @@ GEOMS = [
     (3, 8, 32, 32, 1, 4, 2, 1, True),       # DCGAN decoder last layer (Cout = nc = 1)
     (2, 6, 16, 16, 2, 3, 1, 1, True),       # VGG decoder last layer: ConvTranspose2d k3 s1 p1
     (1, 130, 8, 8, 70, 3, 1, 1, False),     # odd channel counts (K and M tails)
+    # >= 64 output channels and >= 2^20 (pixel, tap-channel) pairs: the "gather once into a column matrix + dense GEMM" path
+    (16, 64, 32, 32, 64, 4, 2, 1, False),   # k4 s2 gather kernel (fwd, wgrad), stride-1 phase kernel at 16x16 (dgrad)
+    (16, 64, 16, 16, 64, 4, 2, 1, True),    # phases at 16x16 (fwd), k4 s2 gather of dy + reuse by dgrad
+    (32, 128, 8, 8, 64, 4, 2, 1, True),     # 8-pixel rows: every unit is a full row (no neighbours)
+    (128, 128, 4, 4, 64, 4, 2, 1, True),    # 4x4 maps: generic gather kernel (two rows per 16-byte unit)
+    (2, 64, 32, 32, 96, 3, 1, 1, False),    # 3x3 pad 1 (VGG / SST widths): stride-1 kernel with all nine taps
+    (2, 72, 24, 24, 64, 3, 1, 1, True),     # ConvTranspose2d k3 s1 p1, flipped taps, rows of 24 pixels
 ]
 
 
@@ -53,6 +60,18 @@ def test_conv_fwd_dgrad_wgrad(dtype, geom):
     assert rel(dx, x64.grad) < 1e-5, f'dgrad {geom} {dtype}'
     dw = ops.conv_wgrad(dy.cuda(), x.cuda(), wshape, s, p, tr)
     assert rel(dw, w64.grad) < 1e-5, f'wgrad {geom} {dtype}'
+    if tr:
+        # the order functional.ConvBlock.backward uses: weight gradient, then the input gradient reusing its column matrix
+        dx2 = ops.conv_dgrad(dy.cuda(), w.cuda(), x.shape, s, p, tr, torch.float32, cols_from_wgrad=True)
+        assert rel(dx2, x64.grad) < 1e-5, f'dgrad after wgrad {geom} {dtype}'
+    # with and without the transient column matrix: same contraction, same operands -> same numbers up to summation order
+    import os
+    os.environ['VS_CONV_COLS'] = '0'
+    try:
+        y0 = ops.conv_fwd(x.cuda(), w.cuda(), bias.cuda(), s, p, tr, torch.float32)
+    finally:
+        del os.environ['VS_CONV_COLS']
+    assert rel(y0, y64.detach()) < 1e-5
 
 
 @pytest.mark.parametrize('act', ['leaky_relu', 'relu', 'none', 'sigmoid'])
