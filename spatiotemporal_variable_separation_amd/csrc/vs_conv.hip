@@ -31,6 +31,7 @@
 // Reference call sites: every nn.Conv2d / nn.ConvTranspose2d of networks/conv.py:119-122,147-170,258-263,294-318,
 // 326-343,362-382,402-417 and networks/resnet.py:57-59, plus their autograd.
 #include "vs_gemm_core.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -569,6 +570,92 @@ int gather_gemm(const void* src, const void* wd, const float* bias, void* out, i
     return run<CT>(a, b, M, N, K, e, nullptr, 0, st, what);
 }
 
+// ---- ConvTranspose2d k4 s2 p1 with 1..4 output channels (the image-producing last decoder layer), all four parity phases in ONE
+// pass: a thread owns (sample, source row y, 8 source pixels) and walks the input channels; per channel it fetches the rows
+// y-1, y, y+1 once (left neighbour, 16-byte unit, right neighbour) and accumulates the 2 x 2 output parities of its 8 pixels,
+// i.e. two output rows of 16 consecutive pixels.  The four per-phase launches of the row-dot kernel read the input four times
+// (0.7 TB/s effective); here it is read once and the kernel is bound by that read.
+// Packed weights (vs_conv_pack_weight, stride 2): Wp[phase = 2 py + px][m][c][j], j = the phase's taps in (ky, kx) ascending order.
+template <int CT, int MR>
+__global__ __launch_bounds__(256) void convt_k4s2_small_kernel(const typename CTraits<CT>::T* x, const typename CTraits<CT>::T* wp, const float* bias,
+                                                               void* out, int od, int B, int C, int H, int W, int M) {
+    typedef typename CTraits<CT>::T T;
+    const int upr = W / 8;                                              // 8-pixel units per source row
+    const int64_t units = (int64_t)B * H * upr;
+    // phase taps: py = 0 -> (ky, dy) = (1, 0), (3, -1);  py = 1 -> (0, 1), (2, 0)   (same for x); j = 2 * jy + jx
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+        const int ux = (int)(u % upr);
+        const int64_t by = u / upr;
+        const int y = (int)(by % H), b = (int)(by / H), x0 = ux * 8;
+        float acc[MR][2][2][8];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[m][py][px][i] = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const T* plane = x + ((int64_t)b * C + c) * H * W;
+            float xs[3][10];                                            // rows y-1, y, y+1; columns x0-1 .. x0+8
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int iy = y + d - 1;
+                const bool ok = iy >= 0 && iy < H;
+                const T* row = plane + (int64_t)(ok ? iy : y) * W + x0;
+                T v[8];
+                if constexpr (CT == VS_BF16) {
+                    *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(row);
+                } else {
+                    *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(row);
+                    *reinterpret_cast<u32x4*>(v + 4) = *reinterpret_cast<const u32x4*>(row + 4);
+                }
+                const T lv = row[x0 > 0 ? -1 : 0], rv = row[x0 + 8 < W ? 8 : 7];
+                xs[d][0] = (ok && x0 > 0) ? (float)lv : 0.f;
+                xs[d][9] = (ok && x0 + 8 < W) ? (float)rv : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xs[d][1 + i] = ok ? (float)v[i] : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                if (m >= M) break;
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        const T* wq = wp + (((int64_t)(2 * py + px) * M + m) * C + c) * 4;
+#pragma unroll
+                        for (int jy = 0; jy < 2; ++jy)
+#pragma unroll
+                            for (int jx = 0; jx < 2; ++jx) {
+                                const float wv = (float)wq[2 * jy + jx];
+                                const int dy = py == 0 ? (jy == 0 ? 0 : -1) : (jy == 0 ? 1 : 0);
+                                const int dx = px == 0 ? (jx == 0 ? 0 : -1) : (jx == 0 ? 1 : 0);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) acc[m][py][px][i] += wv * xs[dy + 1][i + dx + 1];
+                            }
+                    }
+            }
+        }
+        const int OW = 2 * W;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m >= M) break;
+            const float bv = bias ? bias[m] : 0.f;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int64_t o = (((int64_t)b * M + m) * (2 * H) + 2 * y + py) * OW + 2 * x0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    vs_st(out, od, o + 2 * i, acc[m][py][0][i] + bv);
+                    vs_st(out, od, o + 2 * i + 1, acc[m][py][1][i] + bv);
+                }
+            }
+        }
+    }
+}
+
 inline void natural_taps(TapGeo& g, int kh, int kw, int pad, bool flipped) {
     g.ntap = kh * kw;
     for (int ky = 0; ky < kh; ++ky)
@@ -600,6 +687,15 @@ int transposed_form(const void* src, const void* wp, const float* bias, void* ou
         return gather_gemm<CT>(src, wp, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, ws, ws_bytes, st, what);
     }
     if (!phase_ok(kh, kw, s, p)) return vs_fail(VS_ERR_UNSUPPORTED, "%s: transposed geometry k%d s%d p%d is not supported", what, kh, s, p);
+    if (kh == 4 && kw == 4 && p == 1 && M <= 2 && W % 8 == 0 && (uintptr_t)src % 16 == 0 && getenv("VS_CONVT_SMALL") == nullptr) {
+        const int64_t units = (int64_t)B * H * (W / 8);
+        int64_t blocks = (units + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL((convt_k4s2_small_kernel<CT, 2>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)src, (const T*)wp, bias, out, out_dtype,
+                           B, Csrc, H, W, M);
+        VS_CHECK_LAUNCH(what);
+        return VS_OK;
+    }
     const T* wph = (const T*)wp;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {
