@@ -248,10 +248,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
         tile_commit<CT, OpA::layout, BM, BK>(sA, ra);
         tile_commit<CT, OpB::layout, BN, BK>(sB, rb);
         __syncthreads();
+#ifndef VS_DIAG_NO_GLOBAL
         if (kt + 1 < kt_end) {       // prefetch next tile into registers; lands while the MFMAs below run
             tile_fetch<CT, OpA, BM, BK>(A, sta, m0, (kt + 1) * BK, ra);
             tile_fetch<CT, OpB, BN, BK>(B, stb, n0, (kt + 1) * BK, rb);
         }
+#endif
         if constexpr (CT == VS_BF16) {
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 16) {
@@ -265,8 +267,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j) {
+#ifdef VS_DIAG_NO_MFMA
+                        acc[i][j][0] += (float)fa[i][0] + (float)fb[j][0];          // keeps the LDS reads alive, no matrix work
+#else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#endif
+                    }
             }
         } else {
             // parity mode: two-level summation.  Each K tile (16 products) is accumulated in a fresh MFMA chain and then
