@@ -512,7 +512,10 @@ template <int CT>
 inline int64_t cols_pitch(int64_t npix) { return (npix + CTraits<CT>::U - 1) / CTraits<CT>::U * CTraits<CT>::U; }
 
 // when the column matrix pays: enough output channels that the contraction dominates the extra HBM pass
-inline bool cols_worthwhile(int64_t M, int64_t npix, int64_t nq) { return M >= 64 && npix * nq >= (1 << 20) && nq <= 65535; }
+inline bool cols_worthwhile(int64_t M, int64_t npix, int64_t nq) {
+    if (getenv("VS_CONV_COLS_FORCE")) return M > 4 && nq <= 65535;      // test aid: the column-matrix form at any size
+    return M >= 64 && npix * nq >= (1 << 20) && nq <= 65535;
+}
 
 template <int CT>
 int materialise(const TapGather<CT>& gth, void* ws, hipStream_t st, const char* what) {

@@ -64,6 +64,55 @@ def emulated_bf16_step(cfg, t_random):
         return oracle_step(cfg, t_random)
 
 
+def emulated_product_step(cfg, t_random):
+    """bf16 mode of the conv families: the product's module tree and host logic on the CPU with every functional entry point
+    replaced by its bf16-rounding torch emulation (oracle/bf16_emu.py, second half)."""
+    from oracle.bf16_emu import emulate_product_bf16
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.train import compute_losses
+    cond, target = make_batch(cfg)
+    o_net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    lam = cfg['lambdas']
+    lamb_t = 0 if cfg.get('no_s') else lam['t']
+    with emulate_product_bf16():
+        net = build_sep_net(cfg)
+        net.load_state_dict({k: v.clone() for k, v in o_net.state_dict().items()}, strict=True)
+        net.train()
+        total, terms, forecasts, t_codes = compute_losses(
+            cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], cfg.get('skipco', False), lam['ae'], lam['s'], lamb_t,
+            lam['pred'], average_tloss=bool(cfg.get('average_tloss')), t_random=t_random)
+        total.backward()
+    return net, total, terms, forecasts, t_codes
+
+
+def compare_step_bf16_conv(cfg, t_random, tol_out=2e-3, tol_grad=5e-2):
+    """HIP bf16 step of a conv family against the emulation above: same rounding points, so outputs / losses agree to
+    accumulation-order noise and one-ulp bf16 flips (tol_out); gradients go through ill-conditioned per-call BatchNorm stacks at
+    batch 2-3 (see compare_step), so they get the wider tol_grad -- still 10x tighter than anything bf16 vs fp32 could give."""
+    o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, 'bf16')
+    e_net, e_total, e_terms, e_fore, e_tc = emulated_product_step(cfg, t_random)
+    errs = {'forecasts': rel_err(h_fore.detach().cpu().float(), e_fore.detach().float()),
+            't_codes': rel_err(h_tc.detach().cpu().float(), e_tc.detach().float()),
+            'total': abs(h_total.item() - e_total.item()) / abs(e_total.item())}
+    for k, v in errs.items():
+        assert v <= tol_out, f'{k}: HIP bf16 vs bf16-emulating product-on-CPU {v:.3e} > {tol_out:.1e}'
+    eg = dict(e_net.named_parameters())
+    floor = grad_floor(e_net)
+    worst = 0.0
+    for k, p in h_net.named_parameters():
+        e = grad_err(p.grad.detach().cpu(), eg[k].grad, floor)
+        worst = max(worst, e)
+        assert e <= tol_grad, f'gradient {k}: HIP bf16 vs emulation {e:.3e} > {tol_grad:.1e}'
+    errs['grad_worst'] = worst
+    # BatchNorm running statistics after the step
+    esd = e_net.state_dict()
+    for k, v in h_net.state_dict().items():
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            assert rel_err(v.detach().cpu(), esd[k]) <= tol_out, k
+    return errs
+
+
 def compare_step_bf16(cfg, t_random, tol=2e-3, sanity=0.6, emulate=True):
     """bf16 mode: (1) MLP family: must match the CPU emulation of its own rounding scheme to `tol` relative L2
     (accumulation-order noise only); (2) every family: outputs within 5e-2 and gradients within a loose `sanity` bound

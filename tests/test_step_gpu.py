@@ -47,6 +47,103 @@ def test_step_bf16_within_stated_bound(name):
           {k: f'{v:.1e}' for k, v in vs_fp32.items()})
 
 
+@pytest.mark.parametrize('name', CONV_CONFIGS)
+def test_step_bf16_conv_matches_bf16_emulation(name):
+    """bf16 mode of the conv families against the product-on-CPU emulation with the kernels' rounding points
+    (oracle/bf16_emu.py): outputs, losses, BatchNorm running statistics and gradients of one whole training step.
+    The DCGAN stacks agree to 1e-4; in the deeper VGG / SST stacks ONE stored value that lands on the other side of a bf16
+    rounding boundary (fp32 accumulation order differs between MFMA and the CPU convolution) is amplified by the per-call
+    BatchNorm over 2-3 samples to 1e-2 -- the same drift two HIP runs with different summation orders show
+    (tools/bf16_noise.py) -- so the whole-step bound is loose there and the sharp statement is the stage-wise test below."""
+    from step_util import compare_step_bf16_conv
+    cfg = CONFIGS[name]
+    tight = name.startswith('dcgan')
+    errs = compare_step_bf16_conv(cfg, int(load_golden(name)['t_random']), tol_out=2e-3 if tight else 8e-2,
+                                  tol_grad=5e-2 if tight else float('inf'))
+    print(name, {k: f'{v:.1e}' for k, v in errs.items()})
+
+
+@pytest.mark.parametrize('name', CONV_CONFIGS)
+def test_conv_stages_bf16_match_emulation_elementwise(name):
+    """Every conv -> [BatchNorm] -> [activation] block (and pool / flatten+linear unit) of both encoders, fed the SAME bf16 input
+    on the HIP path and in the emulation: the stored outputs are equal element by element except for isolated one-ulp
+    differences (<= 0.5 % of the elements, each a few bf16 ulps of the output range at most), and the block's input / parameter gradients for a fixed
+    upstream gradient agree to 2 %.  (Block by block because BatchNorm couples a whole channel: one flipped element shifts the
+    statistics of the NEXT block and with them hundreds of values by an ulp -- chaos, not arithmetic.)"""
+    import torch
+    from oracle import cpu_ref
+    from oracle.bf16_emu import emulate_product_bf16
+    from oracle.detdata import det_fill, det_uniform
+    from oracle.golden_configs import make_batch
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.conv import run_layers
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    cfg = CONFIGS[name]
+    cond, _ = make_batch(cfg)
+    o = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    netg, nete = build_sep_net(cfg), build_sep_net(cfg)
+    netg.load_state_dict(o.state_dict())
+    nete.load_state_dict(o.state_dict())
+    netg, nete = netg.cuda().train(), nete.train()
+    x = cond[:, :cfg['nt_cond']].reshape(cond.shape[0], -1, *cond.shape[-2:])
+    checked = 0
+    import torch.nn as nn
+
+    def units(m):
+        kids = list(m.children())
+        if isinstance(m, nn.Sequential) and any(isinstance(k, nn.Sequential) for k in kids):
+            return [u for k in kids for u in units(k)]               # a stage of blocks (and pools): one unit per block
+        return [m]
+
+    def stages(enc):
+        if hasattr(enc, 'conv'):
+            return list(enc.conv) + [enc.last_op]
+        return [getattr(enc, n) for n in ('conv1', 'conv2', 'conv3', 'conv4')]
+    for enc_g, enc_e in ((netg.Et, nete.Et), (netg.Es, nete.Es)):
+        if not (hasattr(enc_g, 'conv') or hasattr(enc_g, 'conv1')):
+            continue
+        stages_g = [u for st in stages(enc_g) for u in units(st)]
+        stages_e = [u for st in stages(enc_e) for u in units(st)]
+        h = x.to(torch.bfloat16)
+        for i, (lg, le) in enumerate(zip(stages_g, stages_e)):
+            last = i == len(stages_g) - 1
+            hg_in = h.cuda().requires_grad_(True)
+            he_in = h.clone().requires_grad_(True)
+            with VF.precision('bf16'):
+                yg = run_layers(lg, hg_in, final_fp32=last)
+            with emulate_product_bf16():
+                ye = run_layers(le, he_in, final_fp32=last)
+            a, b = yg.detach().cpu().float(), ye.detach().float()
+            diff = (a - b).abs()
+            n_bad = int((diff > 0).sum())
+            if yg.dtype == torch.bfloat16:
+                # isolated elements only: the conv output z is stored in bf16 BEFORE BatchNorm, so where the MFMA and the CPU
+                # convolution round a z to different neighbours the block output moves by ulp(z) * gamma * invstd -- a few ulps of
+                # the largest outputs at most
+                assert n_bad <= max(3, a.numel() // 200), f'{name} unit {i}: {n_bad} of {a.numel()} stored values differ'
+                assert diff.max().item() <= 2.0 ** -5 * b.abs().max().item(), f'{name} unit {i}: {diff.max().item():.3e}'
+            else:
+                # fp32 results (module outputs): accumulation-order noise; behind a BatchNorm over 2-3 samples one flipped z moves
+                # the code by ~1e-2
+                assert ((a - b).norm() / b.norm().clamp_min(1e-20)).item() < 5e-2, f'{name} unit {i}'
+            dy = ((det_uniform(tuple(ye.shape), 50 + i) - 0.5)).to(ye.dtype)
+            yg.backward(dy.cuda())
+            ye.backward(dy)
+            gi = ((hg_in.grad.cpu().float() - he_in.grad.float()).norm() / he_in.grad.float().norm().clamp_min(1e-20)).item()
+            assert gi < 2e-2, f'{name} unit {i}: input gradient {gi:.2e}'
+            for (k, pg), (_, pe) in zip(lg.named_parameters(), le.named_parameters()):
+                if pe.grad is None:
+                    continue
+                scale = max(pe.grad.norm().item(), 1e-4 * max(q.grad.norm().item() for q in le.parameters() if q.grad is not None))
+                e = ((pg.grad.cpu() - pe.grad).norm() / scale).item()
+                assert e < 2e-2, f'{name} unit {i} {k}: parameter gradient {e:.2e}'
+                pg.grad = None
+                pe.grad = None
+            h = yg.detach().cpu()                                            # the HIP output feeds BOTH next stages
+            checked += 1
+    assert checked > 0
+
+
 @pytest.mark.parametrize('name', MLP_CONFIGS + ['dcgan_tiny', 'vgg32_tiny', 'sst_skip'])
 def test_step_fp32_unfused_structure_matches_oracle(name):
     """`sep_net.fused = False` keeps the reference's per-step launch structure (one decoder / integrator call per
