@@ -127,7 +127,9 @@ def main():
     net.train()
     if ddp:
         broadcast_module_state(net)
-    sync = GradAllReducer(net.parameters(), force=(world == 1)) if ddp else None
+    # bf16 mode: gradients travel as bf16 (VARSEP_GRAD_COMM=fp32 keeps fp32 on the wire); reported in config.grad_allreduce
+    comm_bf16 = args.precision == 'bf16' and os.environ.get('VARSEP_GRAD_COMM', 'bf16') == 'bf16'
+    sync = GradAllReducer(net.parameters(), force=(world == 1), comm_dtype=torch.bfloat16 if comm_bf16 else torch.float32) if ddp else None
     from spatiotemporal_variable_separation_amd.train import GraphedStep, _mlp_family
     use_graph = (not args.no_graph) and _mlp_family(net)
     from spatiotemporal_variable_separation_amd.optim import Adam
@@ -244,7 +246,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': f'{args.config}: {cfg["architecture"]} enc/dec, batch {cfg["batch"]}/GPU, '
                                f'nt_cond {cfg["nt_cond"]}, nt_pred {cfg["nt_pred"]}, offset {cfg["offset"]}',
-                   'global_batch': world * cfg['batch'], 'parallelism': f'dp{world}', 'optimizer': 'Adam (vs_adam_multi, one HIP launch)', 'launch': ('hipGraph replay (per-kernel roofline timings from eager instrumented steps after the timed region)' if use_graph else 'eager'),
+                   'global_batch': world * cfg['batch'], 'parallelism': f'dp{world}',
+                   'grad_allreduce': ('none (1 rank)' if not ddp else ('bf16 buckets over RCCL' if comm_bf16 else 'fp32 buckets over RCCL')), 'optimizer': 'Adam (vs_adam_multi, one HIP launch)', 'launch': ('hipGraph replay (per-kernel roofline timings from eager instrumented steps after the timed region)' if use_graph else 'eager'),
                    'final_loss': round(float(loss.item()), 5)},
         'roofline': roof, 'roofline_others': others,
     }

@@ -102,6 +102,9 @@ def _build():
     g.add_argument('--seed', type=int, default=None, help='Seed (the reference draws an unsaved random seed).')
     g.add_argument('--ddp', action='store_true',
                    help='Batch-sharded data parallelism: launch with torchrun, one process per GPU, RCCL all-reduce.')
+    g.add_argument('--grad_comm', default='fp32', choices=['fp32', 'bf16'],
+                   help='Wire format of the gradient all-reduce with --ddp (bf16 halves the xGMI bytes; fp32 keeps N replicas '
+                        'bit-compatible with the single-process step).')
     g.add_argument('--hip_graph', action='store_true',
                    help='MLP architectures on one GPU: record the whole training step into a hipGraph and replay it.')
     g.add_argument('--log_interval', type=int, default=None, help='Print losses and frames/s every N steps.')

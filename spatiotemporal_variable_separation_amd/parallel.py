@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, overlap=True, force=False):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, overlap=True, force=False, comm_dtype=torch.float32):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -24,6 +24,12 @@ class GradAllReducer:
         self._pending = {}
         self._handles = []
         self._force = force             # run the collectives even at world size 1 (exercises the RCCL path on one GPU)
+        # comm_dtype=torch.bfloat16: the bucket is rounded to bf16 for the wire (half the xGMI bytes: the all-reduce of the WaveEq
+        # model's 243 MB of fp32 gradients is as long as the whole compute step) and averaged in bf16 -- the usual gradient
+        # compression of bf16 training; fp32 (default) keeps the N-replica step equal to the single-process step.
+        assert comm_dtype in (torch.float32, torch.bfloat16)
+        self.comm_dtype = comm_dtype
+        self._wire = {}
         self._build(bucket_bytes)
         self._comm_stream = None
         self._overlap = overlap and (self.world_size > 1 or force)
@@ -89,6 +95,19 @@ class GradAllReducer:
         self._pending[bi] = None
 
     def _reduce(self, flat):
+        if self.comm_dtype != torch.float32:
+            wire = self._wire.get(flat.data_ptr())
+            if wire is None:
+                wire = self._wire[flat.data_ptr()] = torch.empty_like(flat, dtype=self.comm_dtype)
+            wire.copy_(flat)                                   # fp32 -> bf16 (round to nearest even)
+            if self.backend == 'nccl':
+                dist.all_reduce(wire, op=dist.ReduceOp.AVG, group=self.group)
+            else:                                              # gloo (tests): no bf16 reduction there -- sum the bf16 values in fp32
+                host = wire.float().cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                wire.copy_((host / self.world_size).to(self.comm_dtype))
+            flat.copy_(wire)
+            return
         if self.backend == 'nccl':
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
         elif flat.is_cuda:

@@ -63,7 +63,7 @@ def _run(net, cond, target, cfg, sync, graph, steps):
     return losses
 
 
-def _worker(rank, world, port, backend, graph, out_dir):
+def _worker(rank, world, port, backend, graph, out_dir, comm='fp32'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -76,7 +76,8 @@ def _worker(rank, world, port, backend, graph, out_dir):
     shard = slice(rank * per, rank * per + per)
     net = _build(cfg, cfg['salt'] + rank)                      # ranks start different, rank 0's state wins
     broadcast_module_state(net)
-    sync = GradAllReducer(net.parameters(), bucket_bytes=16 << 10, force=(world == 1))
+    sync = GradAllReducer(net.parameters(), bucket_bytes=16 << 10, force=(world == 1),
+                          comm_dtype=torch.bfloat16 if comm == 'bf16' else torch.float32)
     _run(net, cond[shard].cuda().contiguous(), target[shard].cuda().contiguous(), cfg, sync, graph, 3)
     torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
@@ -109,3 +110,15 @@ def test_rccl_world1_graphed_step_equals_plain_graph(tmp_path):
     for k, v in ref.items():
         # not bit-equal: bias gradients are float-atomic column sums (last-bit run-to-run noise that Adam amplifies)
         assert torch.allclose(r0[k], v, rtol=2e-4, atol=2e-6), f'{k}: RCCL world-1 reducer changed the step'
+
+
+def test_two_ranks_bf16_gradient_wire_format(tmp_path):
+    """comm_dtype=bf16: the replicas stay bit-identical to each other and close to the fp32-wire step (gradients rounded to bf16
+    for the exchange: 4e-3 relative, which Adam turns into parameter differences of the order of lr * 1e-2)."""
+    mp.spawn(_worker, args=(2, _free_port(), 'gloo', False, str(tmp_path), 'bf16'), nprocs=2, join=True)
+    ref = _single(False)
+    r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
+    for k, v in ref.items():
+        assert torch.equal(r0[k], r1[k]), f'replicas diverged at {k}'
+        assert torch.allclose(r0[k], v, rtol=5e-2, atol=2e-4), f'{k}: bf16-wire DDP step far from the single-process step'
