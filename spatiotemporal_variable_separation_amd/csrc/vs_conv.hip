@@ -901,11 +901,13 @@ extern "C" size_t vs_conv_workspace_bytes(int compute, int B, int Cin, int H, in
     auto take = [&](size_t c, int64_t M, int64_t N, int64_t K) { const size_t t = c + vs_gemm_workspace_bytes(M, N, K); if (t > worst) worst = t; };
     if (OHc > 0 && OWc > 0) {
         take(cols(B * OHc * OWc, Cin * khw), Cout, B * OHc * OWc, Cin * khw);                         // conv forward
-        take(cols(B * OHc * OWc, Cout * tt), Cin, (int64_t)B * H * W, Cout * tt);                     // conv dgrad (per phase when stride 2)
+        if (stride == 2) take(cols(B * OHc * OWc, Cout * tt), Cin, B * OHc * OWc, Cout * tt);        // conv dgrad: per phase on dy's grid
+        else take(cols((int64_t)B * H * W, Cout * khw), Cin, (int64_t)B * H * W, Cout * khw);         //   stride 1: on dx's grid
         take(cols(B * OHc * OWc, Cin * khw), Cout, Cin * khw, B * OHc * OWc);                         // conv wgrad
     }
     if (OHt > 0 && OWt > 0) {
-        take(cols((int64_t)B * H * W, Cin * tt), Cout, B * OHt * OWt, Cin * tt);                      // convT forward (per phase when stride 2)
+        if (stride == 2) take(cols((int64_t)B * H * W, Cin * tt), Cout, (int64_t)B * H * W, Cin * tt); // convT forward: per phase on x's grid
+        else take(cols(B * OHt * OWt, Cin * khw), Cout, B * OHt * OWt, Cin * khw);                     //   stride 1: on the output grid
         take(cols((int64_t)B * H * W, Cout * khw), Cin, (int64_t)B * H * W, Cout * khw);              // convT dgrad
         take(cols((int64_t)B * H * W, Cout * khw), Cin, Cout * khw, (int64_t)B * H * W);              // convT wgrad
     }

@@ -28,6 +28,8 @@ GEOMS = [
     (128, 128, 4, 4, 64, 4, 2, 1, True),    # 4x4 maps: generic gather kernel (two rows per 16-byte unit)
     (2, 64, 32, 32, 96, 3, 1, 1, False),    # 3x3 pad 1 (VGG / SST widths): stride-1 kernel with all nine taps
     (2, 72, 24, 24, 64, 3, 1, 1, True),     # ConvTranspose2d k3 s1 p1, flipped taps, rows of 24 pixels
+    (64, 148, 1, 1, 512, 4, 1, 0, True),    # decoder first_upconv at full width: 1x1 -> 4x4 through the column matrix
+    (64, 128, 4, 4, 64, 4, 1, 0, False),    # VGG encoder last_op at width: its input gradient gathers dy on the 4x4 grid
 ]
 
 
