@@ -645,7 +645,7 @@ int gather_gemm(const void* src, const void* wd, const float* bias, void* out, i
         Dense<CT, LS> bd{(const T*)ws, ld, N, K, 1};               // element (pixel n, k = q) at cols[q * ld + n]
         return run<CT>(a, bd, M, N, K, e, (char*)ws + cols_bytes, ws_bytes - cols_bytes, st, what);
     }
-    return run<CT>(a, b, M, N, K, e, nullptr, 0, st, what);
+    return run<CT>(a, b, M, N, K, e, ws, ws_bytes, st, what);     // implicit gather; the workspace (if any) serves split-K
 }
 
 // ---- ConvTranspose2d k4 s2 p1 with 1..4 output channels (the image-producing last decoder layer), all four parity phases in ONE
