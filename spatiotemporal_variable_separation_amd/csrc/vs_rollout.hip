@@ -995,7 +995,14 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
 inline bool usable(int compute, int B, int C, int H, int nb) {
     if (compute != VS_BF16 || C > 32 || (H != 128 && H != 256 && H != 512)) return false;
     const int nslabs = (B + 15) / 16, P = H / 64;
-    if ((int64_t)nslabs * nb * P > 224) return false;            // all workgroups must be co-resident (256 CUs)
+    // all workgroups must be co-resident (they wait for each other): one per CU, with headroom for whatever else is running
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus = n;
+    }
+    if ((int64_t)nslabs * nb * P > (int64_t)cus - cus / 8) return false;      // MI355X: 256 CUs -> at most 224 workgroups
     const char* e = getenv("VS_ROLLOUT_WS");
     return !(e && e[0] == '0');
 }
