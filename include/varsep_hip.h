@@ -124,16 +124,29 @@ int vs_colsum(const void* X, int x_dtype, int64_t ldx, int64_t M, int64_t N, flo
 int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const int64_t* ldx, const int64_t* M, const int64_t* N,
                     float* const* out, float* zero_base, int64_t zero_count, void* stream);
 
+/* Decoder input of the auto-encoding pair and of every rollout step in one launch (mlp_encdec.py:43-48 mixing applied at
+ * model.py:74-83): z [B, 1+n, Cz] = mix(s [B, Cs], [t_rand [B, Ct] ; t_codes [B, n, Ct]]), mixing 0 = concat (Cz = Cs + Ct),
+ * 1 = mul (Cz = Cs = Ct); out fp32, out_bf16 (may be NULL) the same values rounded for the decoder's first bf16 GEMM.
+ * bwd: dz [B, 1+n, Cz] fp32 -> ds [B, Cs] (summed over the frames), dt_rand [B, Ct], dt_codes [B, n, Ct].                   */
+int vs_mix_codes_fwd(const float* s, const float* t_rand, const float* t_codes, int64_t B, int n, int Cs, int Ct, int mixing, float* out,
+                     void* out_bf16, void* stream);
+int vs_mix_codes_bwd(const float* dz, const float* s, const float* t_rand, const float* t_codes, int64_t B, int n, int Cs, int Ct,
+                     int mixing, float* ds, float* dt_rand, float* dt_codes, void* stream);
+
 /* All four training losses and their weighted sum in one pass (train.py:117-149, MLP-family layout):
  *   total = l_ae mse(frames[:,0], full[:,idx[0]]) + l_s mean((s_old-s_new)^2) + l_pred mse(frames[:,1:], full[:,idx[1:]])
  *           + l_t t_reg,   t_reg = 0.5 mean_b sum_c t0^2 (average_tloss: 0.5 mean_{b,c} t0^2);  lambdas = {l_ae, l_s, l_t, l_pred}
- *   (host).  n_s = number of spatial-code elements (0: no spatial term, s_old/s_new may be NULL).
+ *   (host).  n_s = number of spatial-code elements (0: no spatial term, s_old/s_new may be NULL).  Target frames: idx [G] on the
+ *   device, or idx = NULL and frame 0 <-> full[:, t_random_dev[0] - ae_shift], frame g <-> full[:, first_forecast + g - 1] (the
+ *   random window end of train.py:72-75 read on the device: no index tensor to build per step).
  *   fwd: out [10] floats on the device: [4] total, [5] ae, [6] zero-order, [7] pred, [8] t_reg ([0..3], [9] scratch).
  *   bwd: grad_total = upstream gradient of `total` (1 float ON THE DEVICE); writes dframes [B,G,D], ds_old, ds_new [n_s], dt0.  */
-int vs_train_losses_fwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D,
+int vs_train_losses_fwd(const float* frames, const float* full, const int32_t* idx, const int32_t* t_random_dev, int ae_shift,
+                        int first_forecast, int64_t B, int G, int T, int64_t D,
                         const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
                         int average_tloss, const float* lambdas, float* out, void* stream);
-int vs_train_losses_bwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D,
+int vs_train_losses_bwd(const float* frames, const float* full, const int32_t* idx, const int32_t* t_random_dev, int ae_shift,
+                        int first_forecast, int64_t B, int G, int T, int64_t D,
                         const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
                         int average_tloss, const float* lambdas, const float* grad_total, float* dframes, float* ds_old,
                         float* ds_new, float* dt0, void* stream);

@@ -225,12 +225,18 @@ __global__ __launch_bounds__(256) void frames_sse_bwd_kernel(const float* frames
 namespace {
 struct LossArgs {
     const float* frames; const float* full; const int* idx;
+    const int* t_dev; int ae_shift, first_forecast;           // idx == NULL: frame 0 <-> full[:, t_dev[0] - ae_shift], frame g <-> first_forecast + g - 1
     int64_t rows, D; int G, T;
     const float* s_old; const float* s_new; int64_t n_s;      // spatial codes (n_s = 0: no spatial term)
     const float* t0; int64_t Bt, Ct;                           // initial temporal code [Bt, Ct]
     float l_ae, l_s, l_pred, l_t;
     float inv_ae, inv_pred, inv_s, inv_t;                      // 1/N of each mean
 };
+
+__device__ __forceinline__ int loss_target_frame(const LossArgs& a, int g) {
+    if (a.idx) return a.idx[g];
+    return g == 0 ? a.t_dev[0] - a.ae_shift : a.first_forecast + g - 1;
+}
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
 #pragma unroll
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float
         const int g = (int)(r % a.G);
         const int64_t b = r / a.G;
         const float* f = a.frames + r * a.D;
-        const float* t = a.full + (b * a.T + a.idx[g]) * a.D;
+        const float* t = a.full + (b * a.T + loss_target_frame(a, g)) * a.D;
         float s = 0.f;
         int64_t i = (int64_t)threadIdx.x * 4;
         for (; i + 3 * 1024 + 3 < a.D; i += 4096) {            // four 16-byte loads of each stream in flight per thread
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256) void train_losses_bwd_kernel(LossArgs a, const
     const int64_t b = blockIdx.y / a.G;
     const float k = gidx == 0 ? up * a.l_ae * 2.f * a.inv_ae : up * a.l_pred * 2.f * a.inv_pred;
     const float* f = a.frames + (b * a.G + gidx) * a.D;
-    const float* t = a.full + (b * a.T + a.idx[gidx]) * a.D;
+    const float* t = a.full + (b * a.T + loss_target_frame(a, gidx)) * a.D;
     float* o = dframes + (b * a.G + gidx) * a.D;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < a.D; i += (int64_t)gridDim.x * 1024) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(f + i), y = *reinterpret_cast<const f32x4*>(t + i);
@@ -321,9 +327,11 @@ __global__ __launch_bounds__(256) void train_losses_bwd_kernel(LossArgs a, const
         for (int64_t i = a.D & ~(int64_t)3; i < a.D; ++i) o[i] = k * (f[i] - t[i]);
 }
 
-int fill_loss_args(LossArgs& a, const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D, const float* s_old,
-                   const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct, int average_tloss, const float* lambdas) {
-    VS_CHECK_ARG(frames && full && idx && t0 && lambdas && B > 0 && G >= 1 && T > 0 && D > 0 && Bt > 0 && Ct > 0 && n_s >= 0,
+int fill_loss_args(LossArgs& a, const float* frames, const float* full, const int32_t* idx, const int32_t* t_dev, int ae_shift, int first_forecast,
+                   int64_t B, int G, int T, int64_t D, const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
+                   int average_tloss, const float* lambdas) {
+    a.t_dev = t_dev; a.ae_shift = ae_shift; a.first_forecast = first_forecast;
+    VS_CHECK_ARG(frames && full && (idx || t_dev) && t0 && lambdas && B > 0 && G >= 1 && T > 0 && D > 0 && Bt > 0 && Ct > 0 && n_s >= 0,
                  "vs_train_losses: bad argument");
     VS_CHECK_ARG(n_s == 0 || (s_old && s_new), "vs_train_losses: spatial codes missing");
     a.frames = frames; a.full = full; a.idx = idx; a.rows = B * G; a.D = D; a.G = G; a.T = T;
@@ -337,11 +345,13 @@ int fill_loss_args(LossArgs& a, const float* frames, const float* full, const in
 }
 }  // namespace
 
-extern "C" int vs_train_losses_fwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D,
+extern "C" int vs_train_losses_fwd(const float* frames, const float* full, const int32_t* idx, const int32_t* t_random_dev, int ae_shift,
+                                   int first_forecast, int64_t B, int G, int T, int64_t D,
                                    const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
                                    int average_tloss, const float* lambdas, float* out, void* stream) {
     LossArgs a;
-    int rc = fill_loss_args(a, frames, full, idx, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss, lambdas);
+    int rc = fill_loss_args(a, frames, full, idx, t_random_dev, ae_shift, first_forecast, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss,
+                            lambdas);
     if (rc != VS_OK) return rc;
     VS_CHECK_ARG(out, "vs_train_losses_fwd: null output");
     if (vs_zero_async(out, 10 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_train_losses_fwd: zero fill failed");
@@ -353,12 +363,14 @@ extern "C" int vs_train_losses_fwd(const float* frames, const float* full, const
     return VS_OK;
 }
 
-extern "C" int vs_train_losses_bwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D,
+extern "C" int vs_train_losses_bwd(const float* frames, const float* full, const int32_t* idx, const int32_t* t_random_dev, int ae_shift,
+                                   int first_forecast, int64_t B, int G, int T, int64_t D,
                                    const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
                                    int average_tloss, const float* lambdas, const float* grad_total, float* dframes, float* ds_old,
                                    float* ds_new, float* dt0, void* stream) {
     LossArgs a;
-    int rc = fill_loss_args(a, frames, full, idx, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss, lambdas);
+    int rc = fill_loss_args(a, frames, full, idx, t_random_dev, ae_shift, first_forecast, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss,
+                            lambdas);
     if (rc != VS_OK) return rc;
     VS_CHECK_ARG(grad_total && dframes && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_bwd: null pointer");
     unsigned gx = (unsigned)((D / 4 + 255) / 256);
@@ -367,6 +379,88 @@ extern "C" int vs_train_losses_bwd(const float* frames, const float* full, const
     hipLaunchKernelGGL(train_losses_bwd_kernel, dim3(gx, (unsigned)(B * G + 1)), dim3(256), 0, (hipStream_t)stream, a, grad_total, dframes, ds_old,
                        ds_new, dt0);
     VS_CHECK_LAUNCH("vs_train_losses_bwd");
+    return VS_OK;
+}
+
+// ---- decoder input of a whole rollout: z[b, g, :] = mix(s[b, :], t[b, g, :]) with t = [t_rand ; t_codes] -----------------------
+// Reference: mlp_encdec.py:43-48 (`torch.cat([z1, z2], dim=1)` or `z1 * z2`) applied to the auto-encoding pair and to every
+// rollout step (model.py:74-83).  From torch ops this is expand + cat + mul + cast forward and mul, mul, sum-over-frames, slice
+// and cat gradients backward (~14 launches between the decoder and the integrator); here one launch each way.
+namespace {
+// mixing 0: concat (Cz = Cs + Ct), 1: mul (Cz = Cs = Ct)
+__global__ __launch_bounds__(256) void mix_codes_fwd_kernel(const float* s, const float* t_rand, const float* t_codes, int64_t B, int n, int Cs,
+                                                            int Ct, int mixing, float* out, __bf16* out_lp) {
+    const int G = n + 1, Cz = mixing ? Cs : Cs + Ct;
+    const int64_t total = B * G * Cz;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cz);
+        const int64_t row = i / Cz;
+        const int g = (int)(row % G);
+        const int64_t b = row / G;
+        float v;
+        if (mixing) {
+            const float tv = g == 0 ? t_rand[b * Ct + c] : t_codes[(b * n + g - 1) * Ct + c];
+            v = s[b * Cs + c] * tv;
+        } else if (c < Cs) {
+            v = s[b * Cs + c];
+        } else {
+            v = g == 0 ? t_rand[b * Ct + c - Cs] : t_codes[(b * n + g - 1) * Ct + c - Cs];
+        }
+        out[i] = v;
+        if (out_lp) out_lp[i] = (__bf16)v;
+    }
+}
+
+// one workgroup per sample: thread c walks the G frames of column c (ds needs the sum over the frames, in frame order)
+__global__ __launch_bounds__(256) void mix_codes_bwd_kernel(const float* dz, const float* s, const float* t_rand, const float* t_codes, int64_t B,
+                                                            int n, int Cs, int Ct, int mixing, float* ds, float* dt_rand, float* dt_codes) {
+    const int G = n + 1, Cz = mixing ? Cs : Cs + Ct;
+    const int64_t b = blockIdx.x;
+    for (int c = threadIdx.x; c < Cz; c += 256) {
+        const float* dzp = dz + (b * G) * Cz + c;
+        if (mixing) {
+            const float sv = s[b * Cs + c];
+            float acc = 0.f;
+            for (int g = 0; g < G; ++g) {
+                const float d = dzp[(int64_t)g * Cz];
+                const float tv = g == 0 ? t_rand[b * Ct + c] : t_codes[(b * n + g - 1) * Ct + c];
+                acc += d * tv;
+                if (g == 0) dt_rand[b * Ct + c] = d * sv; else dt_codes[(b * n + g - 1) * Ct + c] = d * sv;
+            }
+            ds[b * Cs + c] = acc;
+        } else if (c < Cs) {
+            float acc = 0.f;
+            for (int g = 0; g < G; ++g) acc += dzp[(int64_t)g * Cz];
+            ds[b * Cs + c] = acc;
+        } else {
+            for (int g = 0; g < G; ++g) {
+                const float d = dzp[(int64_t)g * Cz];
+                if (g == 0) dt_rand[b * Ct + c - Cs] = d; else dt_codes[(b * n + g - 1) * Ct + c - Cs] = d;
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int vs_mix_codes_fwd(const float* s, const float* t_rand, const float* t_codes, int64_t B, int n, int Cs, int Ct, int mixing, float* out,
+                                void* out_bf16, void* stream) {
+    VS_CHECK_ARG(s && t_rand && (t_codes || n == 0) && out && B > 0 && n >= 0 && Cs > 0 && Ct > 0, "vs_mix_codes_fwd: bad argument");
+    VS_CHECK_ARG((mixing == 0 || mixing == 1) && (mixing == 0 || Cs == Ct), "vs_mix_codes_fwd: mixing 1 (mul) needs Cs == Ct");
+    const int64_t total = B * (n + 1) * (mixing ? Cs : Cs + Ct);
+    hipLaunchKernelGGL(mix_codes_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, t_rand, t_codes, B, n, Cs, Ct, mixing, out,
+                       (__bf16*)out_bf16);
+    VS_CHECK_LAUNCH("vs_mix_codes_fwd");
+    return VS_OK;
+}
+
+extern "C" int vs_mix_codes_bwd(const float* dz, const float* s, const float* t_rand, const float* t_codes, int64_t B, int n, int Cs, int Ct,
+                                int mixing, float* ds, float* dt_rand, float* dt_codes, void* stream) {
+    VS_CHECK_ARG(dz && s && t_rand && (t_codes || n == 0) && ds && dt_rand && (dt_codes || n == 0) && B > 0 && n >= 0 && Cs > 0 && Ct > 0,
+                 "vs_mix_codes_bwd: bad argument");
+    VS_CHECK_ARG((mixing == 0 || mixing == 1) && (mixing == 0 || Cs == Ct), "vs_mix_codes_bwd: mixing 1 (mul) needs Cs == Ct");
+    hipLaunchKernelGGL(mix_codes_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dz, s, t_rand, t_codes, B, n, Cs, Ct, mixing, ds,
+                       dt_rand, dt_codes);
+    VS_CHECK_LAUNCH("vs_mix_codes_bwd");
     return VS_OK;
 }
 

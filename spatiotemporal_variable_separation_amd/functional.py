@@ -158,12 +158,13 @@ class MLPChain(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, acts, *params):
+    def forward(ctx, x, x_lowp, acts, *params):
         require_cuda(x)
         cdt = compute_dtype()
         n_layers = len(params) // 2
         M = x.shape[0]
-        h = to_compute(x, cdt)
+        # x_lowp: the same rows already in the compute dtype (MixCodes writes them while it builds x), saves the cast pass
+        h = x_lowp if x_lowp is not None and x_lowp.dtype == cdt else to_compute(x, cdt)
         saved = [h]
         for l in range(n_layers):
             W, b = params[2 * l], params[2 * l + 1]
@@ -209,16 +210,16 @@ class MLPChain(torch.autograd.Function):
             dzs = [dz_l for _, dz_l in bias_jobs]
             for (slot, _), db in zip(bias_jobs, run_deferred(lambda: ops.colsum_multi(dzs), *dzs)):
                 grads[slot] = db
-        return (dx, None) + tuple(grads)
+        return (dx, None, None) + tuple(grads)
 
 
-def mlp_chain(x, linears, hidden_act='relu', out_act='none'):
+def mlp_chain(x, linears, hidden_act='relu', out_act='none', x_lowp=None):
     """Run a stack of nn.Linear parameter holders as one fused chain."""
     acts = [hidden_act] * (len(linears) - 1) + [out_act]
     params = []
     for lin in linears:
         params += [lin.weight, lin.bias]
-    return MLPChain.apply(x, tuple(acts), *params)
+    return MLPChain.apply(x, x_lowp, tuple(acts), *params)
 
 
 # ------------------------------------------------------------------------------------------------ fused rollout
@@ -442,7 +443,13 @@ class TrainLosses(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, frames, full, idx, s_old, s_new, t0, lambdas, average_tloss):
-        out = ops.train_losses_fwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss)
+        # idx: int32 [1+n] target frames on the device, or (t_random int32 [1] on the device, ae_shift, first_forecast): frame 0
+        # <-> full[:, t_random - ae_shift], frame g <-> full[:, first_forecast + g - 1], resolved inside the kernels
+        ctx.window = None
+        if isinstance(idx, tuple):
+            ctx.window, idx = (int(idx[1]), int(idx[2])), idx[0]
+        idx_arg = idx if ctx.window is None else (idx,) + ctx.window
+        out = ops.train_losses_fwd(frames, full, idx_arg, s_old, s_new, t0, lambdas, average_tloss)
         ctx.set_materialize_grads(False)             # no zero tensors for the (unused) gradients of the four logging terms
         ctx.save_for_backward(frames, full, idx, s_old, s_new, t0)
         ctx.lambdas, ctx.average = tuple(float(v) for v in lambdas), bool(average_tloss)
@@ -455,9 +462,35 @@ class TrainLosses(torch.autograd.Function):
         frames, full, idx, s_old, s_new, t0 = ctx.saved_tensors
         if g_total is None:
             return (None,) * 8
-        dframes, ds_old, ds_new, dt0 = ops.train_losses_bwd(frames, full, idx, s_old, s_new, t0, ctx.lambdas, ctx.average,
+        idx_arg = idx if ctx.window is None else (idx,) + ctx.window
+        dframes, ds_old, ds_new, dt0 = ops.train_losses_bwd(frames, full, idx_arg, s_old, s_new, t0, ctx.lambdas, ctx.average,
                                                             g_total.float().contiguous())
         return dframes, None, None, ds_old, ds_new, dt0, None, None
+
+
+# ------------------------------------------------------------------------------------------------ decoder input of a rollout
+class MixCodes(torch.autograd.Function):
+    """z[b, g] = mix(s[b], [t_rand ; t_codes][b, g]) for the auto-encoding pair (g = 0) and every rollout step: the decoder
+    input of model.py:74-83 with the mixing of mlp_encdec.py:43-48, one launch forward (instead of expand, cat, mul, cast)
+    and one backward (instead of the mul / sum-over-frames / slice / cat gradients).  Returns (z fp32, z in the compute
+    dtype or None); the second output is not differentiable and feeds mlp_chain(x_lowp=...)."""
+
+    @staticmethod
+    def forward(ctx, s, t_rand, t_codes, mixing):
+        cdt = compute_dtype()
+        z, z_lowp = ops.mix_codes_fwd(s, t_rand, t_codes, mixing, lowp=cdt == torch.bfloat16)
+        ctx.save_for_backward(s, t_rand, t_codes)
+        ctx.mixing = mixing
+        if z_lowp is None:
+            return z, None
+        ctx.mark_non_differentiable(z_lowp)
+        return z, z_lowp
+
+    @staticmethod
+    def backward(ctx, dz, _unused=None):
+        s, t_rand, t_codes = ctx.saved_tensors
+        ds, dt_rand, dt_codes = ops.mix_codes_bwd(dz.float().contiguous(), s, t_rand, t_codes, ctx.mixing)
+        return ds, dt_rand, dt_codes, None
 
 
 # ------------------------------------------------------------------------------------------------ fused frame losses

@@ -562,7 +562,16 @@ def frames_sse_fwd(frames, full, idx):
 
 def _loss_args(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss):
     import ctypes
-    require_cuda(frames, full, idx, t0)
+    if isinstance(idx, tuple):                       # (t_random int32 [1] on the device, ae_shift, first_forecast)
+        t_dev, ae_shift, first_forecast = idx
+        assert t_dev.dtype == torch.int32 and t_dev.numel() == 1
+        require_cuda(t_dev)
+        idx_args = (None, t_dev.data_ptr(), int(ae_shift), int(first_forecast))
+    else:
+        require_cuda(idx)
+        assert idx.dtype == torch.int32 and idx.is_contiguous()
+        idx_args = (idx.data_ptr(), None, 0, 0)
+    require_cuda(frames, full, t0)
     assert frames.is_contiguous() and full.is_contiguous() and t0.is_contiguous()
     assert frames.dtype == torch.float32 and full.dtype == torch.float32 and t0.dtype == torch.float32
     B, G, D = frames.shape
@@ -571,7 +580,7 @@ def _loss_args(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss):
         require_cuda(s_old, s_new)
         assert s_old.is_contiguous() and s_new.is_contiguous() and s_old.dtype == torch.float32 and s_new.dtype == torch.float32
     lam = (ctypes.c_float * 4)(*[float(v) for v in lambdas])
-    return (frames.data_ptr(), full.data_ptr(), idx.data_ptr(), B, G, full.shape[1], D, _ptr(s_old) if n_s else None,
+    return (frames.data_ptr(), full.data_ptr()) + idx_args + (B, G, full.shape[1], D, _ptr(s_old) if n_s else None,
             _ptr(s_new) if n_s else None, n_s, t0.data_ptr(), t0.shape[0], t0.numel() // t0.shape[0], int(bool(average_tloss)),
             ctypes.cast(lam, ctypes.c_void_p)), lam
 
@@ -598,6 +607,41 @@ def train_losses_bwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss
                                                   dt0.data_ptr(), stream_ptr()), 'vs_train_losses_bwd')
     _pe(e0, 'vs_train_losses_bwd', nbytes=float(3 * frames.numel() * 4))
     return dframes, ds_old, ds_new, dt0
+
+
+_MIXING = {'concat': 0, 'mul': 1}
+
+
+def mix_codes_fwd(s, t_rand, t_codes, mixing, lowp=False):
+    """-> (z [B, 1+n, Cz] fp32, the same in bf16 or None); mixing 'concat' | 'mul' (mlp_encdec.py:43-48)."""
+    require_cuda(s, t_rand, t_codes)
+    assert s.dtype == t_rand.dtype == t_codes.dtype == torch.float32
+    assert s.is_contiguous() and t_rand.is_contiguous() and t_codes.is_contiguous()
+    B, Cs = s.shape
+    n, Ct = t_codes.shape[1], t_codes.shape[2]
+    assert t_rand.shape == (B, Ct) and t_codes.shape[0] == B
+    Cz = Cs if mixing == 'mul' else Cs + Ct
+    z = torch.empty((B, n + 1, Cz), dtype=torch.float32, device=s.device)
+    z_lowp = torch.empty((B, n + 1, Cz), dtype=torch.bfloat16, device=s.device) if lowp else None
+    e0 = _pb()
+    check(_lib.load_library().vs_mix_codes_fwd(s.data_ptr(), t_rand.data_ptr(), t_codes.data_ptr(), B, n, Cs, Ct, _MIXING[mixing],
+                                               z.data_ptr(), _ptr(z_lowp), stream_ptr()), 'vs_mix_codes_fwd')
+    _pe(e0, 'vs_mix_codes_fwd', nbytes=float(z.numel() * 8))
+    return z, z_lowp
+
+
+def mix_codes_bwd(dz, s, t_rand, t_codes, mixing):
+    require_cuda(dz, s, t_rand, t_codes)
+    assert dz.dtype == torch.float32 and dz.is_contiguous()
+    B, Cs = s.shape
+    n, Ct = t_codes.shape[1], t_codes.shape[2]
+    ds, dt_rand, dt_codes = torch.empty_like(s), torch.empty_like(t_rand), torch.empty_like(t_codes)
+    e0 = _pb()
+    check(_lib.load_library().vs_mix_codes_bwd(dz.data_ptr(), s.data_ptr(), t_rand.data_ptr(), t_codes.data_ptr(), B, n, Cs, Ct,
+                                               _MIXING[mixing], ds.data_ptr(), dt_rand.data_ptr(), dt_codes.data_ptr(), stream_ptr()),
+          'vs_mix_codes_bwd')
+    _pe(e0, 'vs_mix_codes_bwd', nbytes=float(dz.numel() * 8))
+    return ds, dt_rand, dt_codes
 
 
 def frames_sse_bwd(frames, full, idx, coef):

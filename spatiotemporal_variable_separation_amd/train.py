@@ -74,7 +74,7 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     (no accumulation passes).
 
     `t_random` may be a python int (drawn on the host like the reference) or an int32 CUDA tensor of one element: in that
-    case every use of it happens on the device (window gather with a device-side offset, target lookup by index_select),
+    case every use of it happens on the device (window gather with a device-side offset, target frame picked inside the loss kernels),
     so the whole step can be recorded once into a hipGraph and replayed while the random window moves."""
     from .networks.utils import ConstantS
     from . import functional as VF, ops
@@ -122,13 +122,13 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     else:
         s_old, s_new = spatial_codes()
         t_codes, _ = sep_net.t_resnet.rollout(t0, n)
-    frames = sep_net.decoder.decode_sequence(s_old, torch.cat([t_rand.unsqueeze(1), t_codes], dim=1))   # [B, 1+n, ...]
+    frames = sep_net.decoder.decode_rollout(s_old, t_rand, t_codes)                                       # [B, 1+n, ...]
     forecasts = frames[:, 1:]
 
     # both frame losses in one fused pass: frame 0 vs full[:, t_random - offset], frame g vs full[:, fo + g - 1]
     fo = nt_cond if offset == 0 else 0
     if on_device:
-        idx = torch.index_select(_frame_index(None, fo, n, frames.device, T + 1), 0, (t_random - offset).long()).view(-1)
+        idx = (t_random, offset, fo)                 # resolved inside the loss kernels: no index tensor to build per step
     else:
         idx = _frame_index(int(t_random) - offset, fo, n, frames.device, T + 1)
     # t_codes[:, 0] IS t0 (the rollout copies its input there), so the regulariser reads the encoder output directly

@@ -1,0 +1,62 @@
+"""Direct checks of the fused step kernels around the decoder: vs_mix_codes_* (decoder input of a rollout) and the
+device-side target-frame selection of vs_train_losses_* (train.py:72-88, 117-149; mlp_encdec.py:43-48)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mix_ref(s, t_rand, t_codes, mixing):
+    t_all = torch.cat([t_rand.unsqueeze(1), t_codes], dim=1)
+    se = s.unsqueeze(1).expand(-1, t_all.shape[1], -1)
+    return torch.cat([se, t_all], dim=2) if mixing == 'concat' else se * t_all
+
+
+@pytest.mark.parametrize('mixing,B,n,Cs,Ct', [('concat', 128, 10, 32, 32), ('mul', 128, 10, 32, 32), ('concat', 5, 3, 7, 20),
+                                               ('mul', 3, 1, 300, 300), ('concat', 2, 0, 4, 4)])
+def test_mix_codes_matches_torch(mixing, B, n, Cs, Ct):
+    from spatiotemporal_variable_separation_amd import functional as VF, ops
+    g = torch.Generator().manual_seed(B * 100 + n)
+    s, t_rand, t_codes = torch.randn(B, Cs, generator=g), torch.randn(B, Ct, generator=g), torch.randn(B, n, Ct, generator=g)
+    dz = torch.randn(B, n + 1, Cs if mixing == 'mul' else Cs + Ct, generator=g)
+    leaves = [x.clone().requires_grad_(True) for x in (s, t_rand, t_codes)]
+    ref = _mix_ref(*leaves, mixing)
+    ref.backward(dz)
+
+    dev = [x.cuda().requires_grad_(True) for x in (s, t_rand, t_codes)]
+    with VF.precision('bf16'):
+        z, z_lowp = VF.MixCodes.apply(*dev, mixing)
+    assert torch.equal(z.cpu(), ref.detach())                       # one product or a copy per element: exact
+    assert z_lowp.dtype == torch.bfloat16 and torch.equal(z_lowp.cpu(), ref.detach().bfloat16())
+    z.backward(dz.cuda())
+    for got, want in zip(dev, leaves):
+        torch.testing.assert_close(got.grad.cpu(), want.grad, rtol=1e-5, atol=1e-6)    # ds: sum over the frames, fp32 order
+    with VF.precision('fp32'):
+        z32, none = VF.MixCodes.apply(*[x.detach() for x in dev], mixing)
+    assert none is None and torch.equal(z32, z)
+    with pytest.raises(Exception):
+        ops.mix_codes_fwd(s.cuda(), t_rand.cuda(), t_codes.cuda(), 'sum')
+
+
+@pytest.mark.parametrize('offset', [0, 1])
+def test_train_losses_device_window_equals_index_vector(offset):
+    from spatiotemporal_variable_separation_amd import ops
+    B, T, D, nt_cond, n = 6, 9, 515, 3, 5 + offset
+    G = 1 + n
+    g = torch.Generator().manual_seed(7 + offset)
+    frames = torch.randn(B, G, D, generator=g).cuda()
+    full = torch.randn(B, T + 1, D, generator=g).cuda()
+    s_old, s_new, t0 = (torch.randn(B, 19, generator=g).cuda() for _ in range(3))
+    fo = nt_cond if offset == 0 else 0
+    lambdas = (10.0, 45.0, 0.001, 45.0)
+    gt = torch.tensor(1.0).cuda()
+    for t in (nt_cond, T - 1, T if offset else T - 2):
+        idx = torch.tensor([t - offset] + list(range(fo, fo + n)), dtype=torch.int32).cuda()
+        t_dev = torch.tensor([t], dtype=torch.int32).cuda()
+        a = ops.train_losses_fwd(frames, full, idx, s_old, s_new, t0, lambdas, False)
+        b = ops.train_losses_fwd(frames, full, (t_dev, offset, fo), s_old, s_new, t0, lambdas, False)
+        torch.testing.assert_close(a[4:9], b[4:9], rtol=1e-5, atol=1e-6)     # partial sums meet in float atomics: order varies
+        ga = ops.train_losses_bwd(frames, full, idx, s_old, s_new, t0, lambdas, False, gt)
+        gb = ops.train_losses_bwd(frames, full, (t_dev, offset, fo), s_old, s_new, t0, lambdas, False, gt)
+        for x, y in zip(ga, gb):
+            assert torch.equal(x, y)
