@@ -94,7 +94,7 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
         if isinstance(sep_net.Es, ConstantS):
             return sep_net.Es(full_data[:, :nt_cond]), sep_net.Es(full_data[:, -nt_cond:])
         s_both = sep_net.Es.mlp(torch.cat([window(nt_cond), window(T)], dim=0))
-        return s_both[:B], s_both[B:]
+        return s_both.view(2, B, -1).unbind(0)       # unbind: its gradient is ONE stack kernel (two slices: fill+copy each, then add)
 
     if on_device:
         # rows [0, B): full[:, t - nt_cond : t] cut out by a kernel that reads t on the device; rows [B, 2B): the conditioning window
@@ -105,7 +105,7 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     else:
         x_et = torch.cat([window(t_random), window(nt_cond)], dim=0)
     t_both = sep_net.Et.mlp(x_et)
-    t_rand, t0 = t_both[:B], t_both[B:]
+    t_rand, t0 = t_both.view(2, B, -1).unbind(0)
 
     n = nt_pred + offset
     if VF.side_streams_enabled():
@@ -159,6 +159,7 @@ class GraphedStep:
         self.side_streams = side_streams and grad_sync is None and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
         check_optimizer(optimizer)
         self.net, self.opt, self.sync = sep_net, optimizer, grad_sync
+        self._one = torch.ones((), dtype=torch.float32, device=cond.device)
         enable_update_in_backward(optimizer, sep_net, grad_sync)
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
         # static inputs of the recording: one [B, T, ...] buffer, cond / target are views of it (no concatenation per step)
@@ -220,7 +221,7 @@ class GraphedStep:
         try:
             total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
                                                          l_pred, avg, self.t_dev, full_data=self.full)
-            total.backward()
+            total.backward(self._one)                # a resident 1.0: no ones_like fill per step
             VF.join_side_streams()
         finally:
             VF.enable_side_streams(False)
