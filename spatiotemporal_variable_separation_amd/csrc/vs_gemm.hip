@@ -20,6 +20,7 @@
 //     gridDim.z into fp32 slabs and combined by a second kernel that also applies the epilogue, so the
 //     result is bitwise reproducible (no float atomics).
 #include "vs_gemm_core.h"
+#include "vs_gemm_glds.h"
 
 namespace {
 
@@ -41,9 +42,34 @@ int launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, in
     return VS_OK;
 }
 
+template <int LA, int LB>
+int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const Plan& plan, const Epi& epi,
+                float* slabs, hipStream_t stream) {
+    const int batch = epi.splits_per_batch > 0 ? plan.batch : 1;
+    dim3 grid((unsigned)vs_cdiv(N, 128), (unsigned)vs_cdiv(M, 128), (unsigned)(plan.splits * batch));
+    hipLaunchKernelGGL((gemm_glds_kernel<LA, LB, false>), grid, dim3(256), 32768, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, M, N, K,
+                       (int)plan.k_tiles_per_split, epi, slabs);
+    VS_CHECK_LAUNCH("vs_gemm (LDS-DMA tile)");
+    return VS_OK;
+}
+
 template <int CT, int LA, int LB>
 int launch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const Plan& plan,
                 const Epi& epi, float* slabs, hipStream_t stream) {
+    if constexpr (CT == VS_BF16 && LA == LR && LB == LR) {
+        // LDS-DMA staged tile (vs_gemm_glds.h).  Measured on MI355X (tools/gemm_bench.py): 479 vs 433 TF/s on the decoder's
+        // 2688x4096x1200 forward GEMM, 609 vs 588 at 4096^3; the S-operand forms are NOT faster than the register-staged
+        // 128x64 tile yet (266 / 348 vs 417 / 405 TF/s), so only R x R takes this path.  VS_GEMM_GLDS=0 disables, =2 forces all layouts.
+        static const int glds_mode = getenv("VS_GEMM_GLDS") ? atoi(getenv("VS_GEMM_GLDS")) : 1;
+        if (plan.bm == 128 && plan.bn == 128 && glds_mode && glds_operand_ok(A, lda, LA, M, K, epi.batch_a) &&
+            glds_operand_ok(B, ldb, LB, N, K, epi.batch_b))
+            return launch_glds<LA, LB>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
+    } else if constexpr (CT == VS_BF16) {
+        static const int glds_mode = getenv("VS_GEMM_GLDS") ? atoi(getenv("VS_GEMM_GLDS")) : 1;
+        if (plan.bm == 128 && plan.bn == 128 && glds_mode == 2 && glds_operand_ok(A, lda, LA, M, K, epi.batch_a) &&
+            glds_operand_ok(B, ldb, LB, N, K, epi.batch_b))
+            return launch_glds<LA, LB>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
+    }
     if (plan.bm == 128 && plan.bn == 128) return launch<CT, LA, LB, 128, 128>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     if (plan.bm == 128 && plan.bn == 64) return launch<CT, LA, LB, 128, 64>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     return launch<CT, LA, LB, 64, 64>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
@@ -136,7 +162,8 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
     VS_CHECK_ARG(!mask || ldmask >= N, "vs_gemm: ldmask too small");
     VS_CHECK_ARG(act >= VS_ACT_NONE && act <= VS_ACT_ELU, "vs_gemm: bad activation");
     Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    Plan plan = make_plan(compute, M, N, K);
+    const bool rr_dma = layout_a == LR && layout_b == LR && glds_operand_ok(A, lda, LR, M, K, 0) && glds_operand_ok(B, ldb, LR, N, K, 0);
+    Plan plan = make_plan(compute, M, N, K, 1, rr_dma);
     float* slabs = nullptr;
     if (plan.splits > 1) {
         const size_t need = (size_t)plan.splits * (size_t)M * (size_t)N * sizeof(float);
