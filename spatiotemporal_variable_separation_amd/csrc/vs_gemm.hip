@@ -47,8 +47,14 @@ int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t 
                 float* slabs, hipStream_t stream) {
     const int batch = epi.splits_per_batch > 0 ? plan.batch : 1;
     dim3 grid((unsigned)vs_cdiv(N, 128), (unsigned)vs_cdiv(M, 128), (unsigned)(plan.splits * batch));
-    hipLaunchKernelGGL((gemm_glds_kernel<LA, LB, false>), grid, dim3(256), 32768, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, M, N, K,
-                       (int)plan.k_tiles_per_split, epi, slabs);
+    static const int forced = getenv("VS_GEMM_GLDS_STAGES") ? atoi(getenv("VS_GEMM_GLDS_STAGES")) : 0;
+    const int stages = forced ? forced : ((int64_t)grid.x * grid.y * grid.z >= 1024 ? 2 : 1);
+    if (stages == 2)
+        hipLaunchKernelGGL((gemm_glds_kernel<LA, LB, false, 2>), grid, dim3(256), 65536, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, M, N,
+                           K, (int)plan.k_tiles_per_split, epi, slabs);
+    else
+        hipLaunchKernelGGL((gemm_glds_kernel<LA, LB, false, 1>), grid, dim3(256), 32768, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, M, N,
+                           K, (int)plan.k_tiles_per_split, epi, slabs);
     VS_CHECK_LAUNCH("vs_gemm (LDS-DMA tile)");
     return VS_OK;
 }

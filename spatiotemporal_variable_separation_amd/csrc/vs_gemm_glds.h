@@ -14,6 +14,9 @@
 // Pieces outside the matrix (row tail, K tail) are fetched from a 16-byte block of zeros instead: the per-lane source
 // address is the only thing LDS-DMA lets a lane choose.  Requirements (checked by the launcher, else the register-staged
 // kernel runs): 16-byte aligned base, leading dimension % 8 == 0, contiguous extent % 8 == 0 (K for R, rows for S).
+// STAGES = 1: one LDS buffer, two barriers per K tile, 3 workgroups per CU overlap each other (best when the tiles of a
+// problem fit one round of 768 slots); STAGES = 2: two buffers, prefetch across the barrier, 2 workgroups per CU (best
+// for >= 1024 tiles: 711 vs 588 TF/s at 4096^3).
 #pragma once
 #include "vs_gemm_core.h"
 
@@ -81,7 +84,7 @@ __device__ __forceinline__ bf16x8 glds_frag(const __bf16* tile, int row0, int kk
     }
 }
 
-template <int LA, int LB, bool NCHW>
+template <int LA, int LB, bool NCHW, int STAGES = 1>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const __bf16* Ap, int64_t lda, const __bf16* Bp, int64_t ldb, int64_t M, int64_t N,
                                                         int64_t K, int k_tiles_per_split, Epi epi_in, float* slabs) {
     int zsplit = blockIdx.z;
@@ -118,24 +121,60 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const __bf16* Ap, int64_
     ga.prepare(Ap, lda, M, m0, kt_begin * 64);
     gb.prepare(Bp, ldb, N, n0, kt_begin * 64);
 
-    for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
-        ga.stage(sA, kt * 64, K);
-        gb.stage(sB, kt * 64, K);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 64; kk += 16) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = glds_frag<LA>(reinterpret_cast<const __bf16*>(sA), wm + 32 * i, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = glds_frag<LB>(reinterpret_cast<const __bf16*>(sB), wn + 32 * j, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    // fragments of k-step s+1 are requested before the MFMAs of k-step s are issued (two register sets, static names): with
+    // one or two waves per SIMD nothing else hides the ds_read latency
+    auto compute = [&](const char* tA, const char* tB) {
+        const __bf16* pa = reinterpret_cast<const __bf16*>(tA);
+        const __bf16* pb = reinterpret_cast<const __bf16*>(tB);
+        bf16x8 a0[2], b0[2], a1[2], b1[2];
+#define VS_GLDS_LOAD(fa, fb, kk)                                               \
+        fa[0] = glds_frag<LA>(pa, wm, kk, lane); fa[1] = glds_frag<LA>(pa, wm + 32, kk, lane); \
+        fb[0] = glds_frag<LB>(pb, wn, kk, lane); fb[1] = glds_frag<LB>(pb, wn + 32, kk, lane);
+#define VS_GLDS_MFMA(fa, fb)                                                   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[0][0], 0, 0, 0); \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[0][1], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[1][0], 0, 0, 0); \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[1][1], 0, 0, 0);
+        VS_GLDS_LOAD(a0, b0, 0)
+        VS_GLDS_LOAD(a1, b1, 16)
+        VS_GLDS_MFMA(a0, b0)
+        VS_GLDS_LOAD(a0, b0, 32)
+        VS_GLDS_MFMA(a1, b1)
+        VS_GLDS_LOAD(a1, b1, 48)
+        VS_GLDS_MFMA(a0, b0)
+        VS_GLDS_MFMA(a1, b1)
+#undef VS_GLDS_LOAD
+#undef VS_GLDS_MFMA
+    };
+    if constexpr (STAGES == 1) {
+        for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
+            ga.stage(sA, kt * 64, K);
+            gb.stage(sB, kt * 64, K);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(sA, sB);
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+        // two LDS buffers: the DMA of K tile t+1 stays in flight across the barrier while tile t is multiplied; one barrier per
+        // K tile; tile t+1 goes into the buffer tile t-1 was read from, which the barrier has just released.  (A deeper ring
+        // -- 4 buffers, counted vmcnt(16) -- was measured SLOWER: 128 KiB of LDS leaves one wave per SIMD and the
+        // ds_read -> MFMA chain of a single wave is then the bottleneck: 483 vs 711 TF/s at 4096^3.)
+        if (kt_begin < kt_end) {
+            ga.stage(smem, kt_begin * 64, K);
+            gb.stage(smem + 16384, kt_begin * 64, K);
+        }
+        int cur = 0;
+        for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // tile kt landed for every wave; every wave is done reading tile kt-1
+            if (kt + 1 < kt_end) {
+                ga.stage(smem + (cur ^ 1) * 32768, (kt + 1) * 64, K);
+                gb.stage(smem + (cur ^ 1) * 32768 + 16384, (kt + 1) * 64, K);
+            }
+            compute(smem + cur * 32768, smem + cur * 32768 + 16384);
+            cur ^= 1;
+        }
     }
 
     const int cj = lane & 31, rh = 4 * (lane >> 5);

@@ -186,3 +186,54 @@ def test_gemm_batched_equals_loop(dt, dims):
         ref = ai.double() @ bi.double().t()
         tol = 1e-5 if dt == torch.float32 else 1e-5         # inputs are exactly representable: only accumulation order differs
         assert torch.allclose(out[i].double(), ref, rtol=1e-4, atol=tol * K ** 0.5), (i, (out[i].double() - ref).abs().max().item())
+
+
+# ---- LDS-DMA staged 128x128 tile (vs_gemm_glds.h) -------------------------------------------------------------------------
+# R x R bf16 problems with >= 512 tiles of 128x128 take it by default (one LDS buffer below 1024 tiles, two from there on);
+# row tails, K tails (K % 64 != 0) and the bias/activation epilogue included
+@pytest.mark.parametrize('shape', [(2688, 4096, 1200), (2690, 4100, 1208), (4096, 4096, 520), (4100, 4096, 72)])
+def test_gemm_lds_dma_tile_default_path(shape):
+    from spatiotemporal_variable_separation_amd import ops
+    M, N, K = shape
+    a64, a = _operand(M, K, 0, torch.bfloat16, 11)
+    b64, b = _operand(N, K, 0, torch.bfloat16, 13)
+    bias = torch.linspace(-1, 1, N)
+    out = ops.gemm(a, 0, b, 0, M, N, K, bias=bias.cuda(), act='relu')
+    ref = torch.relu(a64 @ b64.t() + bias.double())
+    err = ((out.cpu().double() - ref).norm() / ref.norm()).item()
+    assert err < 2e-6, f'shape {shape}: rel err {err:.3e}'
+
+
+_FORCED_TILE_SCRIPT = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from spatiotemporal_variable_separation_amd import ops
+from oracle.detdata import det_uniform
+worst = 0.0
+for (M, N, K) in [(256, 384, 256), (300, 200, 200), (1200, 1208, 2688), (128, 136, 72), (264, 4096, 1200)]:
+    for la in (0, 1):
+        for lb in (0, 1):
+            a = ((det_uniform((M, K), 3) - 0.5) * 2).bfloat16()
+            b = ((det_uniform((N, K), 5) - 0.5) * 2).bfloat16()
+            ad = a.cuda() if la == 0 else a.cuda().t().contiguous()
+            bd = b.cuda() if lb == 0 else b.cuda().t().contiguous()
+            out = ops.gemm(ad, la, bd, lb, M, N, K)
+            ref = a.double() @ b.double().t()
+            worst = max(worst, ((out.cpu().double() - ref).norm() / ref.norm()).item())
+print('WORST %.3e' % worst)
+'''
+
+
+@pytest.mark.parametrize('stages', ['1', '2'])
+def test_gemm_lds_dma_tile_all_layouts_forced(stages):
+    """Every operand layout through the LDS-DMA tile (S operands use the permuted [k][rows] image and transposing reads); the
+    switches are read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VS_GEMM_GLDS='2', VS_GEMM_TILE='128x128', VS_GEMM_GLDS_STAGES=stages)
+    r = subprocess.run([sys.executable, '-c', _FORCED_TILE_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float(r.stdout.strip().split('WORST')[-1])
+    assert worst < 2e-6, r.stdout
