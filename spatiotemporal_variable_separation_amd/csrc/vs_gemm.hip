@@ -63,9 +63,11 @@ template <int CT, int LA, int LB>
 int launch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const Plan& plan,
                 const Epi& epi, float* slabs, hipStream_t stream) {
     if constexpr (CT == VS_BF16 && LA == LR && LB == LR) {
-        // LDS-DMA staged tile (vs_gemm_glds.h).  Measured on MI355X (tools/gemm_bench.py): 479 vs 433 TF/s on the decoder's
-        // 2688x4096x1200 forward GEMM, 609 vs 588 at 4096^3; the S-operand forms are NOT faster than the register-staged
-        // 128x64 tile yet (266 / 348 vs 417 / 405 TF/s), so only R x R takes this path.  VS_GEMM_GLDS=0 disables, =2 forces all layouts.
+        // LDS-DMA staged tile (vs_gemm_glds.h) wherever the plan picks 128x128 (>= 1024 tiles).  Measured on MI355X
+        // (tools/gemm_bench.py): 732 vs 588 TF/s at 4096^3 with two LDS buffers; with S operands it is not faster than the
+        // register-staged tile yet (598 vs 593), so only R x R takes this path.  At 512-1023 tiles (the decoder's
+        // 3328x4096x1200: 832 tiles on 768 / 512 resident slots) 128x64 register staging stays ahead: 75 vs 89-98 us.
+        // VS_GEMM_GLDS=0 disables, =2 forces all layouts.
         static const int glds_mode = getenv("VS_GEMM_GLDS") ? atoi(getenv("VS_GEMM_GLDS")) : 1;
         if (plan.bm == 128 && plan.bn == 128 && glds_mode && glds_operand_ok(A, lda, LA, M, K, epi.batch_a) &&
             glds_operand_ok(B, ldb, LB, N, K, epi.batch_b))
@@ -168,8 +170,7 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
     VS_CHECK_ARG(!mask || ldmask >= N, "vs_gemm: ldmask too small");
     VS_CHECK_ARG(act >= VS_ACT_NONE && act <= VS_ACT_ELU, "vs_gemm: bad activation");
     Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bool rr_dma = layout_a == LR && layout_b == LR && glds_operand_ok(A, lda, LR, M, K, 0) && glds_operand_ok(B, ldb, LR, N, K, 0);
-    Plan plan = make_plan(compute, M, N, K, 1, rr_dma);
+    Plan plan = make_plan(compute, M, N, K);
     float* slabs = nullptr;
     if (plan.splits > 1) {
         const size_t need = (size_t)plan.splits * (size_t)M * (size_t)N * sizeof(float);

@@ -350,7 +350,7 @@ struct Plan { int bm, bn, splits; int64_t k_tiles_per_split; int batch = 1; };
 
 template <int CT> constexpr int bk_of() { return CT == VS_BF16 ? 64 : 16; }
 
-Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1, bool rr = false) {
+Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1) {
     const int bk = compute == VS_BF16 ? 64 : 16;
     Plan p;
     // Tile choice (measured on the config-2 shapes, tools/gemm_bench.py): the kernel keeps ~3 workgroups (12 waves) per CU
@@ -363,7 +363,6 @@ Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1, 
         p.bm = atoi(f); const char* x = strchr(f, 'x'); p.bn = x ? atoi(x + 1) : p.bm;
     } else if (K <= 512 && t128 >= 256) { p.bm = 64; p.bn = 64; }      // short K: prologue/epilogue bound, many small tiles win
     else if (t128 >= 1024) { p.bm = 128; p.bn = 128; }                 // >= 4 big tiles per CU: best LDS reuse
-    else if (rr && compute == VS_BF16 && t128 >= 512 && K % 8 == 0) { p.bm = 128; p.bn = 128; }   // LDS-DMA tile (R x R operands)
     else if ((t12864 >= 160 || vs_cdiv(M, 64) * vs_cdiv(N, 64) < 256) && M > 64) { p.bm = 128; p.bn = 64; }
     else { p.bm = 64; p.bn = 64; }
     if (M <= 64) p.bm = 64;

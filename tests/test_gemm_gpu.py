@@ -189,9 +189,9 @@ def test_gemm_batched_equals_loop(dt, dims):
 
 
 # ---- LDS-DMA staged 128x128 tile (vs_gemm_glds.h) -------------------------------------------------------------------------
-# R x R bf16 problems with >= 512 tiles of 128x128 take it by default (one LDS buffer below 1024 tiles, two from there on);
-# row tails, K tails (K % 64 != 0) and the bias/activation epilogue included
-@pytest.mark.parametrize('shape', [(2688, 4096, 1200), (2690, 4100, 1208), (4096, 4096, 520), (4100, 4096, 72)])
+# R x R bf16 problems with >= 1024 tiles of 128x128 take it by default (two LDS buffers); row tails, K tails (K % 64 != 0)
+# and the bias/activation epilogue included
+@pytest.mark.parametrize('shape', [(4096, 4096, 520), (4100, 4100, 72), (8192, 2048, 1208)])
 def test_gemm_lds_dma_tile_default_path(shape):
     from spatiotemporal_variable_separation_amd import ops
     M, N, K = shape

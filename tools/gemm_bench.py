@@ -9,21 +9,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatiotemporal_variable_separation_amd import ops  # noqa: E402
 
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
-SHAPES = [  # (name, M, N, K, la, lb) -- every GEMM of one WaveEq training step (B=128: encoder rows 256, decoder rows 2688)
-    ('dec fwd 1200->4096', 2688, 4096, 1200, 0, 0),
-    ('dec fwd 1200->1200 x2', 2688, 1200, 1200, 0, 0),
-    ('dec fwd 32->1200', 2688, 1200, 32, 0, 0),
+SHAPES = [  # (name, M, N, K, la, lb) -- every GEMM of one WaveEq training step (B=128: encoder rows 256, decoder rows 3328)
+    ('dec fwd 1200->4096', 3328, 4096, 1200, 0, 0),
+    ('dec fwd 1200->1200 x2', 3328, 1200, 1200, 0, 0),
+    ('dec fwd 32->1200', 3328, 1200, 32, 0, 0),
     ('enc fwd 20480->1200 x2', 256, 1200, 20480, 0, 0),
     ('enc fwd 1200->1200 x2', 256, 1200, 1200, 0, 0),
     ('enc fwd 1200->32 x2', 256, 32, 1200, 0, 0),
-    ('dec dgrad 4096->1200', 2688, 1200, 4096, 0, 1),
-    ('dec dgrad 1200->1200 x2', 2688, 1200, 1200, 0, 1),
-    ('dec dgrad 1200->32', 2688, 32, 1200, 0, 1),
+    ('dec dgrad 4096->1200', 3328, 1200, 4096, 0, 1),
+    ('dec dgrad 1200->1200 x2', 3328, 1200, 1200, 0, 1),
+    ('dec dgrad 1200->32', 3328, 32, 1200, 0, 1),
     ('enc dgrad 32->1200 x2', 256, 1200, 32, 0, 1),
     ('enc dgrad 1200->1200 x2', 256, 1200, 1200, 0, 1),
-    ('dec wgrad 4096x1200', 4096, 1200, 2688, 1, 1),
-    ('dec wgrad 1200x1200 x2', 1200, 1200, 2688, 1, 1),
-    ('dec wgrad 1200x32', 1200, 32, 2688, 1, 1),
+    ('dec wgrad 4096x1200', 4096, 1200, 3328, 1, 1),
+    ('dec wgrad 1200x1200 x2', 1200, 1200, 3328, 1, 1),
+    ('dec wgrad 1200x32', 1200, 32, 3328, 1, 1),
     ('enc wgrad 1200x20480 x2', 1200, 20480, 256, 1, 1),
     ('enc wgrad 1200x1200 x2', 1200, 1200, 256, 1, 1),
     ('enc wgrad 32x1200 x2', 32, 1200, 256, 1, 1),
