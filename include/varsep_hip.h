@@ -149,7 +149,7 @@ int vs_train_losses_bwd(const float* frames, const float* full, const int32_t* i
                         int first_forecast, int64_t B, int G, int T, int64_t D,
                         const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
                         int average_tloss, const float* lambdas, const float* grad_total, float* dframes, float* ds_old,
-                        float* ds_new, float* dt0, void* stream);
+                        float* ds_new, float* dt0, int frames_act, void* dz, int dz_dtype, void* stream);
 
 /* Adam update of up to 64 fp32 tensors in one launch (reference: train.py:156-158 `optimizer.step()` on
  * torch.optim.Adam(lr, betas): weight_decay 0, amsgrad off; same operation order as torch's single-tensor path:

@@ -299,7 +299,10 @@ __global__ void train_losses_finalize_kernel(LossArgs a, float* out) {
 }
 
 // gradients of `total` times the upstream scalar *g: dframes, ds_old (= -ds_new), dt0
-__global__ __launch_bounds__(256) void train_losses_bwd_kernel(LossArgs a, const float* g, float* dframes, float* ds_old, float* ds_new, float* dt0) {
+// dz != NULL: the frames are the output y of an activation (the decoder's last one) and the kernel writes the gradient of its
+// INPUT, k * (y - target) * act'(y), in dz's dtype -- what ops.act_bwd would compute from dframes in a second pass
+__global__ __launch_bounds__(256) void train_losses_bwd_kernel(LossArgs a, const float* g, float* dframes, float* ds_old, float* ds_new, float* dt0,
+                                                               int act, void* dz, int dz_dtype) {
     const float up = g[0];
     if (blockIdx.y == (unsigned)a.rows) {                       // one extra grid row: the code gradients
         const float cs = up * a.l_s * 2.f * a.inv_s, ct = up * a.l_t * a.inv_t;
@@ -315,7 +318,27 @@ __global__ __launch_bounds__(256) void train_losses_bwd_kernel(LossArgs a, const
     const float k = gidx == 0 ? up * a.l_ae * 2.f * a.inv_ae : up * a.l_pred * 2.f * a.inv_pred;
     const float* f = a.frames + (b * a.G + gidx) * a.D;
     const float* t = a.full + (b * a.T + loss_target_frame(a, gidx)) * a.D;
-    float* o = dframes + (b * a.G + gidx) * a.D;
+    const int64_t row0 = (b * a.G + gidx) * a.D;
+    if (dz) {
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < a.D; i += (int64_t)gridDim.x * 1024) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(f + i), y = *reinterpret_cast<const f32x4*>(t + i);
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (k * (x[j] - y[j])) * vs_act_grad_from_out(x[j], act);
+            if (dz_dtype == VS_F32) {
+                *reinterpret_cast<f32x4*>((float*)dz + row0 + i) = f32x4{r[0], r[1], r[2], r[3]};
+            } else {
+                bf16x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (__bf16)r[j];
+                *reinterpret_cast<bf16x4*>((__bf16*)dz + row0 + i) = w;            // D % 4 tail handled below; row0 % 4 == 0 is checked by the host
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int64_t i = a.D & ~(int64_t)3; i < a.D; ++i) vs_st(dz, dz_dtype, row0 + i, (k * (f[i] - t[i])) * vs_act_grad_from_out(f[i], act));
+        return;
+    }
+    float* o = dframes + row0;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i + 3 < a.D; i += (int64_t)gridDim.x * 1024) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(f + i), y = *reinterpret_cast<const f32x4*>(t + i);
         f32x4 r;
@@ -367,17 +390,19 @@ extern "C" int vs_train_losses_bwd(const float* frames, const float* full, const
                                    int first_forecast, int64_t B, int G, int T, int64_t D,
                                    const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
                                    int average_tloss, const float* lambdas, const float* grad_total, float* dframes, float* ds_old,
-                                   float* ds_new, float* dt0, void* stream) {
+                                   float* ds_new, float* dt0, int frames_act, void* dz, int dz_dtype, void* stream) {
     LossArgs a;
     int rc = fill_loss_args(a, frames, full, idx, t_random_dev, ae_shift, first_forecast, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss,
                             lambdas);
     if (rc != VS_OK) return rc;
-    VS_CHECK_ARG(grad_total && dframes && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_bwd: null pointer");
+    VS_CHECK_ARG(grad_total && (dframes || dz) && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_bwd: null pointer");
+    VS_CHECK_ARG(!dz || ((dz_dtype == VS_F32 || dz_dtype == VS_BF16) && frames_act >= VS_ACT_NONE && frames_act <= VS_ACT_ELU && D % 4 == 0),
+                 "vs_train_losses_bwd: dz needs a valid dtype / activation and D %% 4 == 0");
     unsigned gx = (unsigned)((D / 4 + 255) / 256);
     if (gx > 8) gx = 8;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(train_losses_bwd_kernel, dim3(gx, (unsigned)(B * G + 1)), dim3(256), 0, (hipStream_t)stream, a, grad_total, dframes, ds_old,
-                       ds_new, dt0);
+                       ds_new, dt0, frames_act, dz, dz_dtype);
     VS_CHECK_LAUNCH("vs_train_losses_bwd");
     return VS_OK;
 }

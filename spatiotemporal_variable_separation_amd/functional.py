@@ -149,6 +149,32 @@ def to_compute(x, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ Linear chains
+class GradHandoff:
+    """Side channel from the Function that consumes a chain's output to the chain's backward.
+
+    When the consumer is the fused loss (TrainLosses), d loss / d output is `k * (y - target)` and the chain's first backward
+    step multiplies it by act'(y): the loss kernel can write that product directly in the compute dtype (one pass, no fp32
+    gradient of the frame stack in HBM).  Autograd still wants an fp32 gradient for the output, so the consumer returns a
+    zero placeholder (a 0-stride view of one resident zero, no kernel) and leaves the real tensor here; if other consumers
+    add gradients of their own, the chain sees a non-placeholder `dy` and adds its activation gradient on top."""
+    __slots__ = ('act', 'cdt', 'dz')
+    _zero = {}
+
+    def __init__(self):
+        self.act, self.cdt, self.dz = None, None, None
+
+    @classmethod
+    def placeholder(cls, like):
+        z = cls._zero.get(like.device)
+        if z is None:
+            z = cls._zero[like.device] = torch.zeros((), dtype=torch.float32, device=like.device)
+        return z.expand(like.shape)
+
+    @staticmethod
+    def is_placeholder(t):
+        return all(st == 0 for st in t.stride()) and t.numel() > 1
+
+
 class MLPChain(torch.autograd.Function):
     """y = act_L(W_L ... act_1(W_1 x + b_1) ... + b_L) with every bias/activation fused into the GEMM epilogues.
 
@@ -158,7 +184,7 @@ class MLPChain(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, x_lowp, acts, *params):
+    def forward(ctx, x, x_lowp, acts, handoff, *params):
         require_cuda(x)
         cdt = compute_dtype()
         n_layers = len(params) // 2
@@ -174,6 +200,9 @@ class MLPChain(torch.autograd.Function):
                          out_dtype=torch.float32 if last else cdt)
             saved.append(h)
         ctx.acts, ctx.cdt, ctx.n_layers = acts, cdt, n_layers
+        ctx.handoff = handoff
+        if handoff is not None:
+            handoff.act, handoff.cdt, handoff.dz = acts[n_layers - 1], cdt, None
         ctx.x_needs_grad = x.requires_grad
         ctx.params = params
         ctx.save_for_backward(*saved)
@@ -184,11 +213,19 @@ class MLPChain(torch.autograd.Function):
         saved = ctx.saved_tensors
         acts, cdt, L, params = ctx.acts, ctx.cdt, ctx.n_layers, ctx.params
         M = dy.shape[0]
-        dy = dy.contiguous()
-        if acts[L - 1] not in ('none', None):
-            dz = ops.act_bwd(dy, saved[L], acts[L - 1], out_dtype=cdt)
+        handed = None
+        if ctx.handoff is not None and ctx.handoff.dz is not None:
+            handed, ctx.handoff.dz = ctx.handoff.dz.view(M, -1), None
+        if handed is not None and GradHandoff.is_placeholder(dy):
+            dz = handed                                  # the consumer already applied act'(y) and the cast
         else:
-            dz = to_compute(dy, cdt)
+            dy = dy.contiguous()
+            if acts[L - 1] not in ('none', None):
+                dz = ops.act_bwd(dy, saved[L], acts[L - 1], out_dtype=cdt)
+            else:
+                dz = to_compute(dy, cdt)
+            if handed is not None:
+                dz = dz + handed
         grads = [None] * (2 * L)
         dx = None
         bias_jobs = []                       # (slot, dz): all bias gradients of the chain in one launch at the end
@@ -210,16 +247,16 @@ class MLPChain(torch.autograd.Function):
             dzs = [dz_l for _, dz_l in bias_jobs]
             for (slot, _), db in zip(bias_jobs, run_deferred(lambda: ops.colsum_multi(dzs), *dzs)):
                 grads[slot] = db
-        return (dx, None, None) + tuple(grads)
+        return (dx, None, None, None) + tuple(grads)
 
 
-def mlp_chain(x, linears, hidden_act='relu', out_act='none', x_lowp=None):
+def mlp_chain(x, linears, hidden_act='relu', out_act='none', x_lowp=None, handoff=None):
     """Run a stack of nn.Linear parameter holders as one fused chain."""
     acts = [hidden_act] * (len(linears) - 1) + [out_act]
     params = []
     for lin in linears:
         params += [lin.weight, lin.bias]
-    return MLPChain.apply(x, x_lowp, tuple(acts), *params)
+    return MLPChain.apply(x, x_lowp, tuple(acts), handoff, *params)
 
 
 # ------------------------------------------------------------------------------------------------ fused rollout
@@ -442,7 +479,8 @@ class TrainLosses(torch.autograd.Function):
     `total` is differentiable, the terms are for logging."""
 
     @staticmethod
-    def forward(ctx, frames, full, idx, s_old, s_new, t0, lambdas, average_tloss):
+    def forward(ctx, frames, full, idx, s_old, s_new, t0, lambdas, average_tloss, handoff=None):
+        ctx.handoff = handoff
         # idx: int32 [1+n] target frames on the device, or (t_random int32 [1] on the device, ae_shift, first_forecast): frame 0
         # <-> full[:, t_random - ae_shift], frame g <-> full[:, first_forecast + g - 1], resolved inside the kernels
         ctx.window = None
@@ -461,11 +499,18 @@ class TrainLosses(torch.autograd.Function):
     def backward(ctx, g_total, *_unused):
         frames, full, idx, s_old, s_new, t0 = ctx.saved_tensors
         if g_total is None:
-            return (None,) * 8
+            return (None,) * 9
         idx_arg = idx if ctx.window is None else (idx,) + ctx.window
-        dframes, ds_old, ds_new, dt0 = ops.train_losses_bwd(frames, full, idx_arg, s_old, s_new, t0, ctx.lambdas, ctx.average,
-                                                            g_total.float().contiguous())
-        return dframes, None, None, ds_old, ds_new, dt0, None, None
+        h = ctx.handoff
+        if h is not None and h.act not in ('none', None) and frames.shape[-1] % 4 == 0:
+            # the frames are the outputs of the producing chain's last activation: write d/d(pre-activation) for it directly
+            h.dz, ds_old, ds_new, dt0 = ops.train_losses_bwd(frames, full, idx_arg, s_old, s_new, t0, ctx.lambdas, ctx.average,
+                                                             g_total.float().contiguous(), frames_act=h.act, dz_dtype=h.cdt)
+            dframes = GradHandoff.placeholder(frames)
+        else:
+            dframes, ds_old, ds_new, dt0 = ops.train_losses_bwd(frames, full, idx_arg, s_old, s_new, t0, ctx.lambdas, ctx.average,
+                                                                g_total.float().contiguous())
+        return dframes, None, None, ds_old, ds_new, dt0, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ decoder input of a rollout

@@ -40,15 +40,16 @@ class MLPDecoder(nn.Module):
         x = self.mlp(z.reshape(B * n, -1), out_act=activation_name(self.last_activation))
         return x.view([B, n] + self.output_shape)
 
-    def decode_rollout(self, z1, t_first, t_codes):
+    def decode_rollout(self, z1, t_first, t_codes, handoff=None):
         """decode_sequence(z1, cat([t_first[:, None], t_codes], 1)) with the decoder input built by one kernel
         (VF.MixCodes): the auto-encoding pair (train.py:85) and the forecasts of every rollout step (model.py:74-83).
 
-        z1 [B, Cs], t_first [B, Ct], t_codes [B, n, Ct] -> frames [B, 1+n, *output_shape]."""
+        z1 [B, Cs], t_first [B, Ct], t_codes [B, n, Ct] -> frames [B, 1+n, *output_shape].  `handoff`: a VF.GradHandoff the
+        consumer of the frames (the fused loss) may fill with the gradient of the last pre-activation."""
         from .. import functional as VF
         B, n = t_codes.shape[0], t_codes.shape[1]
         z, z_lowp = VF.MixCodes.apply(z1.float().contiguous(), t_first.float().contiguous(), t_codes.float().contiguous(), self.mixing)
         x = VF.mlp_chain(z.reshape(B * (n + 1), -1), self.mlp.linears(), hidden_act=self.mlp.activation,
                          out_act=activation_name(self.last_activation),
-                         x_lowp=None if z_lowp is None else z_lowp.reshape(B * (n + 1), -1))
+                         x_lowp=None if z_lowp is None else z_lowp.reshape(B * (n + 1), -1), handoff=handoff)
         return x.view([B, n + 1] + self.output_shape)

@@ -595,17 +595,22 @@ def train_losses_fwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss
     return out
 
 
-def train_losses_bwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss, grad_total):
+def train_losses_bwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss, grad_total, frames_act=None, dz_dtype=None):
+    """-> (dframes, ds_old, ds_new, dt0).  With `frames_act` (the activation whose outputs `frames` are) the first result is instead
+    the gradient of that activation's input, dframes * act'(frames), in `dz_dtype`."""
     args, keep = _loss_args(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss)
     require_cuda(grad_total)
-    dframes = torch.empty_like(frames)
+    fused = frames_act is not None
+    dframes = torch.empty(frames.shape, dtype=dz_dtype if fused else torch.float32, device=frames.device)
     ds_old = torch.empty_like(s_old) if s_old is not None else None
     ds_new = torch.empty_like(s_new) if s_new is not None else None
     dt0 = torch.empty_like(t0)
     e0 = _pb()
-    check(_lib.load_library().vs_train_losses_bwd(*args, grad_total.data_ptr(), dframes.data_ptr(), _ptr(ds_old), _ptr(ds_new),
-                                                  dt0.data_ptr(), stream_ptr()), 'vs_train_losses_bwd')
-    _pe(e0, 'vs_train_losses_bwd', nbytes=float(3 * frames.numel() * 4))
+    check(_lib.load_library().vs_train_losses_bwd(*args, grad_total.data_ptr(), None if fused else dframes.data_ptr(), _ptr(ds_old),
+                                                  _ptr(ds_new), dt0.data_ptr(), ACT[frames_act] if fused else 0,
+                                                  dframes.data_ptr() if fused else None, dtype_code(dframes) if fused else 0, stream_ptr()),
+          'vs_train_losses_bwd')
+    _pe(e0, 'vs_train_losses_bwd', nbytes=float(2 * frames.numel() * 4 + dframes.numel() * dframes.element_size()))
     return dframes, ds_old, ds_new, dt0
 
 

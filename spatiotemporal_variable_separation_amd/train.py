@@ -122,7 +122,8 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     else:
         s_old, s_new = spatial_codes()
         t_codes, _ = sep_net.t_resnet.rollout(t0, n)
-    frames = sep_net.decoder.decode_rollout(s_old, t_rand, t_codes)                                       # [B, 1+n, ...]
+    handoff = VF.GradHandoff() if os.environ.get('VARSEP_LOSS_HANDOFF', '1') == '1' else None
+    frames = sep_net.decoder.decode_rollout(s_old, t_rand, t_codes, handoff=handoff)                      # [B, 1+n, ...]
     forecasts = frames[:, 1:]
 
     # both frame losses in one fused pass: frame 0 vs full[:, t_random - offset], frame g vs full[:, fo + g - 1]
@@ -136,7 +137,7 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     total_loss, ae_loss_value, spatial_ode_loss, forecast_loss, t_reg = VF.TrainLosses.apply(
         frames.reshape(B, 1 + n, -1), flat.contiguous(), idx, None if no_s else s_old.reshape(B, -1).float().contiguous(),
         None if no_s else s_new.reshape(B, -1).float().contiguous(), t0.reshape(B, -1).float().contiguous(),
-        (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss)
+        (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss, handoff)
     terms = {'ae': ae_loss_value, 'zero': spatial_ode_loss, 'pred': forecast_loss, 't_reg': t_reg}
     return total_loss, terms, forecasts, t_codes
 

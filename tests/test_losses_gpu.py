@@ -60,3 +60,40 @@ def test_train_losses_device_window_equals_index_vector(offset):
         gb = ops.train_losses_bwd(frames, full, (t_dev, offset, fo), s_old, s_new, t0, lambdas, False, gt)
         for x, y in zip(ga, gb):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('extra_consumer', [False, True])
+def test_loss_gradient_handoff_equals_two_pass_backward(precision, extra_consumer):
+    """The fused loss writes the decoder chain's last pre-activation gradient itself (functional.GradHandoff); the result must be
+    the one of the two-pass backward (fp32 frame gradient, then act_bwd), also when the frames feed a second consumer."""
+    import torch.nn as nn
+    from spatiotemporal_variable_separation_amd import functional as VF
+    B, G, D, T = 4, 3, 64, 6
+    torch.manual_seed(3)
+    lin = [nn.Linear(8, 16).cuda(), nn.Linear(16, D).cuda()]
+    x = torch.randn(B * G, 8).cuda()
+    full = torch.rand(B, T, D).cuda()
+    s_old, s_new, t0 = (torch.randn(B, 5).cuda() for _ in range(3))
+    idx = torch.tensor([2, 3, 4], dtype=torch.int32).cuda()
+
+    def run(handoff):
+        for l in lin:
+            l.zero_grad()
+        with VF.precision(precision):
+            y = VF.mlp_chain(x, lin, out_act='sigmoid', handoff=handoff)
+            total = VF.TrainLosses.apply(y.view(B, G, D), full, idx, s_old, s_new, t0, (10.0, 1.0, 0.1, 5.0), False, handoff)[0]
+            if extra_consumer:
+                total = total + (y * y).sum() * 0.01
+            total.backward()
+        return [p.grad.clone() for l in lin for p in l.parameters()]
+
+    want = run(None)
+    h = VF.GradHandoff()
+    got = run(h)
+    assert h.act == 'sigmoid' and h.dz is None          # filled by the loss, consumed by the chain
+    for a, b in zip(got, want):
+        if extra_consumer:
+            torch.testing.assert_close(a, b, rtol=2e-2 if precision == 'bf16' else 1e-5, atol=1e-4 if precision == 'bf16' else 1e-7)
+        else:
+            assert torch.equal(a, b)                     # same arithmetic, same rounding point
