@@ -9,9 +9,9 @@ import sys
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    which = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     idx = [i for i, r in enumerate(rows) if 'step_increment' in r['Kernel_Name']]
+    which = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2          # default: a step from the middle of the run
     a, b = idx[which], idx[which + 1]
     t0 = int(rows[a]['End_Timestamp'])
     prev_end, tot, busy_until, idle = t0, 0, t0, 0
