@@ -30,6 +30,7 @@
 //
 // Reference call sites: every nn.Conv2d / nn.ConvTranspose2d of networks/conv.py:119-122,147-170,258-263,294-318,
 // 326-343,362-382,402-417 and networks/resnet.py:57-59, plus their autograd.
+#include <type_traits>
 #include "vs_gemm_core.h"
 #include <stdlib.h>
 
@@ -259,7 +260,9 @@ int run(const OpA& a, const OpB& b, int64_t M, int64_t N, int64_t K, const Epi& 
     typedef typename CTraits<CT>::T T;
     constexpr int BK = CT == VS_BF16 ? 64 : 16;
     Plan plan = make_plan(CT, M, N, K);
-    if (plan.bm == 128 && plan.bn == 128) plan.bn = 64;      // gather operands are register hungry: 128x128 drops to 2 waves/SIMD
+    constexpr bool both_dense = std::is_same<OpA, Dense<CT, OpA::layout>>::value && std::is_same<OpB, Dense<CT, OpB::layout>>::value;
+    if (!both_dense && plan.bm == 128 && plan.bn == 128) plan.bn = 64;   // gather operands are register hungry: 128x128 drops to 2 waves/SIMD
+    if ((!both_dense || CT != VS_BF16) && plan.bm == 64 && plan.bn == 128) plan.bn = 64;
     float* slabs = nullptr;
     if (plan.splits > 1) {
         const size_t need = (size_t)plan.splits * (size_t)M * (size_t)N * sizeof(float);
@@ -280,6 +283,7 @@ int run(const OpA& a, const OpB& b, int64_t M, int64_t N, int64_t K, const Epi& 
     }
     if (plan.bm == 128 && plan.bn == 128) VS_LAUNCH(128, 128)
     else if (plan.bm == 128) VS_LAUNCH(128, 64)
+    else if (plan.bn == 128) { if constexpr (both_dense && CT == VS_BF16) VS_LAUNCH(64, 128) }
     else VS_LAUNCH(64, 64)
 #undef VS_LAUNCH
     VS_CHECK_LAUNCH(what);

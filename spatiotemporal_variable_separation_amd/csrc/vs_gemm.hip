@@ -80,6 +80,8 @@ int launch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t 
     }
     if (plan.bm == 128 && plan.bn == 128) return launch<CT, LA, LB, 128, 128>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     if (plan.bm == 128 && plan.bn == 64) return launch<CT, LA, LB, 128, 64>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
+    if constexpr (CT == VS_BF16)
+        if (plan.bm == 64 && plan.bn == 128) return launch<CT, LA, LB, 64, 128>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     return launch<CT, LA, LB, 64, 64>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
 }
 

@@ -368,6 +368,9 @@ Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1) 
     if (M <= 64) p.bm = 64;
     if (N <= 64) p.bn = 64;
     if (p.bm == 64) p.bn = 64;
+    // <= 64 output rows x very many columns (64-channel convolution layers over a whole batch of pixels): a 64x128 tile gives
+    // every wave two accumulators per A fragment (1.5 LDS fragment reads per MFMA instead of 2)
+    if (compute == VS_BF16 && !getenv("VS_GEMM_TILE") && M <= 64 && M > 32 && vs_cdiv(N, 128) >= 1024 && K >= 128) { p.bm = 64; p.bn = 128; }
     const int64_t tiles = vs_cdiv(M, p.bm) * vs_cdiv(N, p.bn) * batch;
     const int64_t kt = vs_cdiv(K, bk);
     int splits = 1;

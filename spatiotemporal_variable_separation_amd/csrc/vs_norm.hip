@@ -70,6 +70,19 @@ __device__ __forceinline__ void st_vec(void* y, int yd, int64_t idx, const float
     }
 }
 
+// channel c and (group, channel) slot of the flat NCHW element index i; 32-bit divisions whenever the tensor has < 2^31
+// elements (three 64-bit divisions per 16-byte vector cost as much as the payload arithmetic)
+__device__ __forceinline__ void chan_of(int64_t i, int64_t HW, int C, int64_t group_elems, bool small, int& c, int& gc) {
+    if (small) {
+        const uint32_t u = (uint32_t)i;
+        c = (int)((u / (uint32_t)HW) % (uint32_t)C);
+        gc = (int)(u / (uint32_t)group_elems) * C + c;
+    } else {
+        c = (int)((i / HW) % C);
+        gc = (int)(i / group_elems) * C + c;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, int Bg, int C, int64_t HW, float* mean, float* invstd,
                                                        float* ubvar, float eps, int vec) {
     __shared__ double red[4];
@@ -81,8 +94,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, in
     if (vec) {
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t per = HW / w;                                  // vectors per plane
-        for (int64_t i = threadIdx.x; i < (int64_t)Bg * per; i += 256) {
-            const int64_t b = i / per, p = (i - b * per) * w;
+        const uint32_t per32 = (uint32_t)per, nvec = (uint32_t)Bg * per32;           // < 2^31: a channel of one call group
+        for (uint32_t i = threadIdx.x; i < nvec; i += 256) {
+            const uint32_t b = i / per32, p = (i - b * per32) * w;
             float v[8];
             const int cnt = ld_vec(x, xd, ((b0 + b) * C + c) * HW + p, v);
 #pragma unroll
@@ -130,10 +144,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, 
     if (vec) {                                                       // 16-byte chunks never straddle a (sample, channel) plane
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t nv = total / w;
+        const bool small = total < (int64_t)1 << 31;
         for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += (int64_t)gridDim.x * 256) {
             const int64_t i = iv * w;
-            const int c = (int)((i / HW) % C);
-            const int gc = (int)(i / group_elems) * C + c;
+            int c, gc;
+            chan_of(i, HW, C, group_elems, small, c, gc);
             const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
             float v[8];
             const int cnt = ld_vec(x, xd, i, v);
@@ -161,7 +176,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int 
     const int64_t b0 = (int64_t)grp * Bg;
     const float mu = mean[grp * C + c], is = invstd[grp * C + c], g = gamma[c], bt = beta[c];
     double s1 = 0.0, s2 = 0.0;
-    if (vec) {
+    if (vec && xd == dyd) {
+        // one 16-byte load per tensor and thread (8 bf16 / 4 fp32 of one plane); fp32 partial sums over the vector, fp64 across
+        const int w = xd == VS_F32 ? 4 : 8;
+        const int64_t per = HW / w;
+        const uint32_t per32 = (uint32_t)per, nvec = (uint32_t)Bg * per32;
+        for (uint32_t i = threadIdx.x; i < nvec; i += 256) {
+            const uint32_t b = i / per32, p = (i - b * per32) * w;
+            const int64_t idx = ((b0 + b) * C + c) * HW + p;
+            float xv[8], gv[8];
+            const int cnt = ld_vec(x, xd, idx, xv);
+            ld_vec(dy, dyd, idx, gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < cnt) {
+                    const float xh = (xv[j] - mu) * is;
+                    const float dz = gv[j] * act_grad_from_pre(xh * g + bt, act);
+                    s1 += (double)dz;
+                    s2 += (double)dz * (double)xh;
+                }
+            }
+        }
+    } else if (vec) {
         const int w = (xd == VS_F32 || dyd == VS_F32) ? 4 : 8;
         const int64_t per = HW / w;
         for (int64_t i = threadIdx.x; i < (int64_t)Bg * per; i += 256) {
@@ -197,6 +233,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int d
                                                            int64_t HW, int64_t total, int training, int vec) {
     const float inv_n = 1.f / (float)((int64_t)Bg * HW);
     const int64_t group_elems = (int64_t)Bg * C * HW;
+    if (vec && xd == dyd) {                                          // 16-byte loads of both tensors, one 16-byte (or 2 x 16) store
+        const int w = xd == VS_F32 ? 4 : 8;
+        const int64_t nv = total / w;
+        const bool small = total < (int64_t)1 << 31;
+        for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += (int64_t)gridDim.x * 256) {
+            const int64_t i = iv * w;
+            int c, gc;
+            chan_of(i, HW, C, group_elems, small, c, gc);
+            const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
+            const float k1 = sum_dz[gc] * inv_n, k2 = sum_dz_xhat[gc] * inv_n;
+            float xv[8], gv[8];
+            const int cnt = ld_vec(x, xd, i, xv);
+            ld_vec(dy, dyd, i, gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < cnt) {
+                    const float xh = (xv[j] - mu) * is;
+                    const float dz = gv[j] * act_grad_from_pre(xh * g + bt, act);
+                    xv[j] = training ? g * is * (dz - k1 - xh * k2) : g * is * dz;
+                }
+            }
+            st_vec(dx, dxd, i, xv, cnt);
+        }
+        return;
+    }
     if (vec) {
         const int w = 4;                                             // 4 consecutive elements of one plane per thread
         const int64_t nv = total / w;
