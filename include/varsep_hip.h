@@ -124,6 +124,15 @@ int vs_colsum(const void* X, int x_dtype, int64_t ldx, int64_t M, int64_t N, flo
 int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const int64_t* ldx, const int64_t* M, const int64_t* N,
                     float* const* out, float* zero_base, int64_t zero_count, void* stream);
 
+/* Batch assembly from a simulation set resident in HBM (reference: data/wave_eq.py:67-72 `WaveEq.__getitem__` and :86-90
+ * `WaveEqPartial.__getitem__`, for a whole batch of sampler indices): data [n_seq, nt, frame_elems] fp32; item b =
+ * item_idx[b] selects sequence item / windows_per_seq and first frame item % windows_per_seq; out [batch, seq_len, frame_elems]
+ * (or [batch, seq_len, n_pixels] when pixel_idx != NULL picks n_pixels fixed positions of every frame) in out_dtype.
+ * Item indices outside [0, n_seq * windows_per_seq) are the caller's error (the sampler draws from that range).          */
+int vs_gather_windows(const float* data, int64_t n_seq, int64_t nt, int64_t frame_elems, const int32_t* item_idx, int batch,
+                      int windows_per_seq, int seq_len, const int32_t* pixel_idx, int n_pixels, void* out, int out_dtype,
+                      void* stream);
+
 /* Decoder input of the auto-encoding pair and of every rollout step in one launch (mlp_encdec.py:43-48 mixing applied at
  * model.py:74-83): z [B, 1+n, Cz] = mix(s [B, Cs], [t_rand [B, Ct] ; t_codes [B, n, Ct]]), mixing 0 = concat (Cz = Cs + Ct),
  * 1 = mul (Cz = Cs = Ct); out fp32, out_bf16 (may be NULL) the same values rounded for the decoder's first bf16 GEMM.

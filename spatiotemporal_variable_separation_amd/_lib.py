@@ -96,6 +96,7 @@ SIGNATURES = {
     'vs_train_losses_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     'vs_train_losses_bwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _i32, _vp, _i32, _vp]),
+    'vs_gather_windows': (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     'vs_mix_codes_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     'vs_mix_codes_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     'vs_pack_rollout_weights': (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -407,6 +407,55 @@ extern "C" int vs_train_losses_bwd(const float* frames, const float* full, const
     return VS_OK;
 }
 
+// ---- batch assembly from an HBM-resident simulation set -------------------------------------------------------------------------
+// Reference: data/wave_eq.py:67-72 (`WaveEq.__getitem__`: item idx -> sequence idx / per, first frame idx % per, window of
+// seq_len frames) and :86-90 (`WaveEqPartial`: the same window restricted to n_pixels fixed pixels), applied to a whole batch
+// of item indices.  At the step rates of this path (WaveEq: 128 x 25 frames per 1.8 ms = 29 GB/s of fp32 frames) a host
+// DataLoader cannot feed the GPU; the whole normalised set stays in HBM and a batch is one gather launch driven by the
+// sampler's indices.
+namespace {
+__global__ __launch_bounds__(256) void gather_windows_kernel(const float* data, int64_t nt, int64_t frame, const int32_t* item, int per,
+                                                             int seq_len, const int32_t* pix, int n_pix, void* out, int od) {
+    const int b = blockIdx.y;
+    const int idx = item[b];
+    const int64_t seq = idx / per, first = idx - seq * per;
+    const float* src = data + (seq * nt + first) * frame;            // seq_len consecutive frames
+    const int64_t width = pix ? n_pix : frame;
+    const int64_t total = (int64_t)seq_len * width;
+    const int64_t obase = (int64_t)b * total;
+    if (!pix && (frame & 3) == 0) {                                  // whole frames: a contiguous run of seq_len * frame floats
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+            if (od == VS_F32) *reinterpret_cast<f32x4*>((float*)out + obase + i) = v;
+            else { bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; *reinterpret_cast<bf16x4*>((__bf16*)out + obase + i) = w; }
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / width, p = i - t * width;
+        vs_st(out, od, obase + i, src[t * frame + (pix ? pix[p] : p)]);
+    }
+}
+}  // namespace
+
+extern "C" int vs_gather_windows(const float* data, int64_t n_seq, int64_t nt, int64_t frame_elems, const int32_t* item_idx, int batch,
+                                 int windows_per_seq, int seq_len, const int32_t* pixel_idx, int n_pixels, void* out, int out_dtype,
+                                 void* stream) {
+    VS_CHECK_ARG(data && item_idx && out && n_seq > 0 && nt > 0 && frame_elems > 0 && batch > 0 && windows_per_seq > 0 && seq_len > 0 &&
+                     seq_len <= nt, "vs_gather_windows: bad argument");
+    VS_CHECK_ARG(windows_per_seq + seq_len - 1 <= nt, "vs_gather_windows: a window would run past the end of its sequence");
+    VS_CHECK_ARG(!pixel_idx || n_pixels > 0, "vs_gather_windows: pixel table without a count");
+    VS_CHECK_ARG(out_dtype == VS_F32 || out_dtype == VS_BF16, "vs_gather_windows: bad out_dtype");
+    const int64_t total = (int64_t)seq_len * (pixel_idx ? n_pixels : frame_elems);
+    int64_t gx = (total / 4 + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gather_windows_kernel, dim3((unsigned)gx, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, data, nt, frame_elems,
+                       item_idx, windows_per_seq, seq_len, pixel_idx, n_pixels, out, out_dtype);
+    VS_CHECK_LAUNCH("vs_gather_windows");
+    return VS_OK;
+}
+
 // ---- decoder input of a whole rollout: z[b, g, :] = mix(s[b, :], t[b, g, :]) with t = [t_rand ; t_codes] -----------------------
 // Reference: mlp_encdec.py:43-48 (`torch.cat([z1, z2], dim=1)` or `z1 * z2`) applied to the auto-encoding pair and to every
 // rollout step (model.py:74-83).  From torch ops this is expand + cat + mul + cast forward and mul, mul, sum-over-frames, slice

@@ -19,12 +19,19 @@ from .parallel import GradAllReducer, broadcast_module_state
 from .train import train
 
 
-def load_dataset(args):
-    """Real datasets are loaded through the user's `var_sep.data` package when it is importable (they are host-side
-    code outside this package); `--data_dir synthetic` needs nothing."""
+def load_dataset(args, device=None):
+    """`--data_dir synthetic` needs nothing.  The WaveEq sets (main.py:91-102 of the reference) are this package's own HBM-resident
+    datasets (data/wave_eq.py: batches gathered on the device).  The other real datasets are loaded through the user's
+    `var_sep.data` package when it is importable (host-side code outside this package)."""
     if args.data_dir == 'synthetic':
         return SyntheticSequences(args.data, args.nt_cond, args.nt_pred, length=args.synthetic_len,
                                   seed=args.seed or 1234, n_wave_points=args.n_wave_points)
+    if args.data in ('wave', 'wave_partial') and device is not None and torch.device(device).type == 'cuda':
+        from .data.wave_eq import WaveEq, WaveEqPartial
+        if args.data == 'wave':
+            return WaveEq(args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred, True, args.downsample, device=device)
+        return WaveEqPartial(args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred, True, args.downsample, args.n_wave_points,
+                             device=device)
     try:
         if args.data == 'mnist':
             from var_sep.data.moving_mnist import MovingMNIST
@@ -75,7 +82,9 @@ def main(argv=None):
         assert args.architecture not in ['dcgan', 'vgg']
     shape = data_shape(args.data, args.n_wave_points)
     last_activation = LAST_ACTIVATION[args.data]
-    train_set = load_dataset(args)
+    train_set = load_dataset(args, device)
+    if args.data == 'wave' and getattr(train_set, 'device_resident', False):
+        shape = [1] + list(train_set.frame_shape)      # the reference hard-codes 64x64 (main.py:95); follow the files instead
 
     if rank == 0:
         os.makedirs(args.xp_dir, exist_ok=True)
@@ -88,8 +97,12 @@ def main(argv=None):
     if world > 1:
         from torch.utils.data.distributed import DistributedSampler
         sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True, seed=seed)
-    train_loader = DataLoader(train_set, batch_size=args.batch_size, pin_memory=True, shuffle=sampler is None,
-                              sampler=sampler, num_workers=args.num_workers, worker_init_fn=worker_init_fn)
+    if getattr(train_set, 'device_resident', False):
+        from .data.wave_eq import DeviceBatchLoader                # same sampler stream as the DataLoader below, one gather launch per batch
+        train_loader = DeviceBatchLoader(train_set, args.batch_size, shuffle=sampler is None, sampler=sampler)
+    else:
+        train_loader = DataLoader(train_set, batch_size=args.batch_size, pin_memory=True, shuffle=sampler is None,
+                                  sampler=sampler, num_workers=args.num_workers, worker_init_fn=worker_init_fn)
 
     if not args.no_s:
         Es = get_encoder(args.architecture, shape, args.code_size_s, args.enc_hidden_size, args.enc_n_layers,

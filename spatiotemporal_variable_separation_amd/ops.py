@@ -614,6 +614,25 @@ def train_losses_bwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss
     return dframes, ds_old, ds_new, dt0
 
 
+def gather_windows(data, item_idx, windows_per_seq, seq_len, pixel_idx=None, out_dtype=torch.float32):
+    """data [n_seq, nt, frame] fp32 on the device, item_idx int32 [B] -> [B, seq_len, frame (or len(pixel_idx))]."""
+    require_cuda(data, item_idx, pixel_idx)
+    assert data.dtype == torch.float32 and data.is_contiguous() and data.dim() == 3
+    assert item_idx.dtype == torch.int32 and item_idx.is_contiguous()
+    n_seq, nt, frame = data.shape
+    B = item_idx.numel()
+    n_pix = 0
+    if pixel_idx is not None:
+        assert pixel_idx.dtype == torch.int32 and pixel_idx.is_contiguous()
+        n_pix = pixel_idx.numel()
+    out = torch.empty((B, seq_len, n_pix if pixel_idx is not None else frame), dtype=out_dtype, device=data.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_gather_windows(data.data_ptr(), n_seq, nt, frame, item_idx.data_ptr(), B, int(windows_per_seq), int(seq_len),
+                                                _ptr(pixel_idx), n_pix, out.data_ptr(), dtype_code(out), stream_ptr()), 'vs_gather_windows')
+    _pe(e0, 'vs_gather_windows', nbytes=float(out.numel() * (4 + out.element_size())))
+    return out
+
+
 _MIXING = {'concat': 0, 'mul': 1}
 
 
