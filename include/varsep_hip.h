@@ -295,6 +295,13 @@ int vs_conv_transpose2d_dgrad(int compute, const void* dy, const void* w, void* 
 int vs_conv_transpose2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh,
                               int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
 
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) on `planes` = B*C planes of H x W (reference: conv.py:517, the ResNet18
+ * stem of the chairs encoder); output (H + 2 - 3) / 2 + 1 per side.  Backward gathers over the overlapping windows (arg-max =
+ * first maximum in window order, as ATen), no atomics.                                                                  */
+int vs_maxpool3s2_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t planes, int H, int W, void* stream);
+int vs_maxpool3s2_bwd(const void* x, int x_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype, int64_t planes, int H, int W,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d + activation, pooling, upsampling (csrc/vs_norm.hip); x is NCHW [B,C,HW], dtypes VS_F32 | VS_BF16.
  *

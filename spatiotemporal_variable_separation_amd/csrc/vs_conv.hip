@@ -36,7 +36,7 @@
 
 namespace {
 
-constexpr int MAXTAP = 16;
+constexpr int MAXTAP = 32;       // 5x5 kernels (the chairs ResNet18 stem, conv.py:514) have 25 taps
 
 struct TapGeo {
     int B, C, H, W;        // the NCHW tensor gathered from
@@ -47,14 +47,15 @@ struct TapGeo {
     // index-math helpers filled by finish(): shifts when the grid is a power of two (-1 otherwise), multiply-high magic for / ntap
     int gw_shift, ghw_shift;
     unsigned ntap_magic;
-    unsigned long long dy_tab, dx_tab;    // tap t -> ((tab >> 4t) & 15) - 8   (offsets are within [-8, 7]); two scalars, no indexing
-    __device__ __forceinline__ int tap_dy(int t) const { return (int)((dy_tab >> (4 * t)) & 15ull) - 8; }
-    __device__ __forceinline__ int tap_dx(int t) const { return (int)((dx_tab >> (4 * t)) & 15ull) - 8; }
+    // tap t -> ((tab[t / 16] >> 4 (t % 16)) & 15) - 8   (offsets are within [-8, 7]); four scalars, 16 taps per 64-bit word
+    unsigned long long dy_tab[2], dx_tab[2];
+    __device__ __forceinline__ int tap_dy(int t) const { return (int)(((t < 16 ? dy_tab[0] : dy_tab[1]) >> (4 * (t & 15))) & 15ull) - 8; }
+    __device__ __forceinline__ int tap_dx(int t) const { return (int)(((t < 16 ? dx_tab[0] : dx_tab[1]) >> (4 * (t & 15))) & 15ull) - 8; }
     void finish() {
-        dy_tab = dx_tab = 0;
+        dy_tab[0] = dy_tab[1] = dx_tab[0] = dx_tab[1] = 0;
         for (int t = 0; t < ntap; ++t) {
-            dy_tab |= (unsigned long long)((dy[t] + 8) & 15) << (4 * t);
-            dx_tab |= (unsigned long long)((dx[t] + 8) & 15) << (4 * t);
+            dy_tab[t >> 4] |= (unsigned long long)((dy[t] + 8) & 15) << (4 * (t & 15));
+            dx_tab[t >> 4] |= (unsigned long long)((dx[t] + 8) & 15) << (4 * (t & 15));
         }
         gw_shift = ghw_shift = -1;
         for (int k = 0; k < 31; ++k) {
@@ -64,6 +65,7 @@ struct TapGeo {
         ntap_magic = (unsigned)((0x100000000ull + ntap - 1) / ntap);      // floor(q / ntap) = umulhi(q, magic) for q < 2^16
     }
     __device__ __forceinline__ void split_q(int q, int& c, int& t) const {
+        if (ntap == 1) { c = q; t = 0; return; }                        // the magic for 1 would be 2^32: does not fit 32 bits
         c = (q < 65536) ? (int)__umulhi((unsigned)q, ntap_magic) : q / ntap;
         t = q - c * ntap;
     }
@@ -316,7 +318,10 @@ int check_conv(const char* what, int compute, const void* a, const void* b, cons
 
 // Which (k, stride, pad) transposed geometries decompose into equal-size parity phases: every output pixel (s*i + py)
 // exists for i in [0, H): needs OH == s*H, i.e. kh - 2*pad == s.  (k4 s2 p1 yes; stride 1 is the single trivial phase.)
-inline bool phase_ok(int kh, int kw, int s, int p) { return s == 2 && kh - 2 * p == s && kw - 2 * p == s; }
+// stride-2 transposed forms are run as 4 output-parity phases; tap offsets (py + p - ky) / 2 must fit the [-8, 7] tap tables
+inline bool phase_ok(int kh, int kw, int s, int p) { return s == 2 && kh <= 9 && kw <= 9 && p <= 8 && kh * kw <= MAXTAP; }
+// the geometry the original phase kernels were written for: every phase covers the whole source grid (out = 2 x in)
+inline bool phase_uniform(int kh, int kw, int s, int p) { return s == 2 && kh - 2 * p == s && kw - 2 * p == s; }
 
 // taps of output parity (py, px) of a transposed convolution: ky with (py + p - ky) % s == 0, source offset (py+p-ky)/s
 inline int phase_taps(int kh, int kw, int s, int p, int py, int px, int* kidx, signed char* dy, signed char* dx) {
@@ -756,6 +761,16 @@ int conv_form(const void* src, const void* w, const float* bias, void* out, int 
     return gather_gemm<CT>(src, w, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, ws, ws_bytes, st, what, cols_ready);
 }
 
+// out[plane, gy * s + oy, gx * s + ox] = 0 over a phase grid (a phase of a strided input gradient that no tap reaches)
+__global__ __launch_bounds__(256) void zero_phase_kernel(void* out, int od, int64_t planes, int GH, int GW, int OH, int OW, int s, int oy, int ox) {
+    const int64_t total = planes * GH * GW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int gx = (int)(i % GW), gy = (int)((i / GW) % GH);
+        const int64_t plane = i / ((int64_t)GW * GH);
+        vs_st(out, od, (plane * OH + gy * s + oy) * OW + gx * s + ox, 0.f);
+    }
+}
+
 // transposed form: ConvTranspose2d forward and Conv2d input gradient; weights PACKED by vs_conv_pack_weight
 //   stride 1      : Wp[M][Csrc][kh*kw], taps flipped (offset p - k)
 //   stride 2 phase: Wp[phase][M][Csrc][ntap_phase]
@@ -769,7 +784,8 @@ int transposed_form(const void* src, const void* wp, const float* bias, void* ou
         return gather_gemm<CT>(src, wp, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, ws, ws_bytes, st, what);
     }
     if (!phase_ok(kh, kw, s, p)) return vs_fail(VS_ERR_UNSUPPORTED, "%s: transposed geometry k%d s%d p%d is not supported", what, kh, s, p);
-    if (kh == 4 && kw == 4 && p == 1 && M <= 2 && W % 8 == 0 && (uintptr_t)src % 16 == 0 && getenv("VS_CONVT_SMALL") == nullptr) {
+    if (kh == 4 && kw == 4 && p == 1 && M <= 2 && W % 8 == 0 && OH == 2 * H && OW == 2 * W && (uintptr_t)src % 16 == 0 &&
+        getenv("VS_CONVT_SMALL") == nullptr) {
         const int64_t units = (int64_t)B * H * (W / 8);
         int64_t blocks = (units + 255) / 256;
         if (blocks > 16384) blocks = 16384;
@@ -778,12 +794,27 @@ int transposed_form(const void* src, const void* wp, const float* bias, void* ou
         VS_CHECK_LAUNCH(what);
         return VS_OK;
     }
+    // Output pixel (2 gy + py, 2 gx + px) of phase (py, px) reads source pixels (gy + dy_t, gx + dx_t): the phase grid is the set
+    // of output pixels of that parity, ceil((OH - py) / 2) x ceil((OW - px) / 2) -- the whole source grid when out = 2 x in
+    // (k4 s2 p1), smaller and phase-dependent for the input gradients of k3 s2 p1 / k1 s2 p0 convolutions on odd sizes
+    // (conv.py:440, 531 of the reference's ResNet18).  A phase without taps (k1: only even pixels receive anything) is zeros.
     const T* wph = (const T*)wp;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {
-            TapGeo g{B, Csrc, H, W, H, W, 1, 0, {}, {}, 0, 0, 0, 0, 0};
+            const int GH = (OH - py + s - 1) / s, GW = (OW - px + s - 1) / s;
+            TapGeo g{B, Csrc, H, W, GH, GW, 1, 0, {}, {}, 0, 0, 0, 0, 0};
             int kidx[MAXTAP];
             g.ntap = phase_taps(kh, kw, s, p, py, px, kidx, g.dy, g.dx);
+            if (GH <= 0 || GW <= 0) { wph += (int64_t)M * Csrc * g.ntap; continue; }
+            if (g.ntap == 0) {
+                if (bias) return vs_fail(VS_ERR_UNSUPPORTED, "%s: a tap-free phase with a bias is not supported (k%d s%d p%d)", what, kh, s, p);
+                const int64_t total = (int64_t)B * M * GH * GW;
+                int64_t blocks = (total + 255) / 256;
+                if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL(zero_phase_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, out_dtype, (int64_t)B * M, GH, GW, OH, OW, s, py, px);
+                VS_CHECK_LAUNCH(what);
+                continue;
+            }
             int rc = gather_gemm<CT>(src, wph, bias, out, out_dtype, M, g, OH, OW, s, py, px, ws, ws_bytes, st, what);
             if (rc != VS_OK) return rc;
             wph += (int64_t)M * Csrc * g.ntap;
@@ -899,7 +930,7 @@ extern "C" size_t vs_conv_workspace_bytes(int compute, int B, int Cin, int H, in
     const int64_t OHc = (H + 2 * pad - kh) / stride + 1, OWc = (W + 2 * pad - kw) / stride + 1;       // Conv2d output
     const int64_t OHt = (int64_t)(H - 1) * stride - 2 * pad + kh, OWt = (int64_t)(W - 1) * stride - 2 * pad + kw;   // ConvTranspose2d output
     const int64_t khw = (int64_t)kh * kw;
-    const int64_t tt = (stride == 2 && phase_ok(kh, kw, stride, pad)) ? khw / 4 : khw;      // taps per launch of the transposed forms
+    const int64_t tt = (stride == 2 && phase_ok(kh, kw, stride, pad)) ? (int64_t)((kh + 1) / 2) * ((kw + 1) / 2) : khw;   // most taps of a phase
     auto cols = [&](int64_t npix, int64_t nq) { return (size_t)(nq * ((npix + U - 1) / U * U) * e); };
     size_t worst = 0;
     auto take = [&](size_t c, int64_t M, int64_t N, int64_t K) { const size_t t = c + vs_gemm_workspace_bytes(M, N, K); if (t > worst) worst = t; };
@@ -934,7 +965,6 @@ extern "C" int vs_conv2d_dgrad(int compute, const void* dy, const void* w_packed
     if (rc) return rc;
     const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
     // dx[b,ci,y,x] = sum dy[b,co,(y+p-ky)/s,(x+p-kx)/s] W[co][ci][ky,kx]: transposed form gathering from dy
-    VS_CHECK_ARG(stride == 1 || (OH * stride == H && OW * stride == W), "vs_conv2d_dgrad: stride-2 needs H == 2*OH");
     return VS_DISPATCH(compute, transposed_form, dy, w_packed, nullptr, dx, dx_dtype, B, Cout, OH, OW, Cin, kh, kw, stride, pad, H, W,
                        workspace, workspace_bytes, (hipStream_t)stream, "vs_conv2d_dgrad");
 }

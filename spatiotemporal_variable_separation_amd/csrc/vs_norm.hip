@@ -343,6 +343,53 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const void* x, int xd,
 }
 
 // nearest Upsample x2: planes x (H x W) -> planes x (2H x 2W)
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (the chairs ResNet18 stem, conv.py:517): windows overlap, so backward is a
+// gather -- every input pixel visits the (at most four) windows that contain it, recomputes each window's arg-max (first
+// maximum in row-major window order, like ATen) and adds that window's gradient when it is the winner: no atomics
+__device__ __forceinline__ int pool3_argmax(const void* x, int xd, int64_t plane_base, int H, int W, int oy, int ox, float& best) {
+    const int y0 = oy * 2 - 1 < 0 ? 0 : oy * 2 - 1, x0 = ox * 2 - 1 < 0 ? 0 : ox * 2 - 1;
+    const int y1 = oy * 2 + 2 > H ? H : oy * 2 + 2, x1 = ox * 2 + 2 > W ? W : ox * 2 + 2;
+    int arg = y0 * W + x0;                                           // ATen: max_pool2d starts from the first in-range position
+    best = -INFINITY;
+    for (int iy = y0; iy < y1; ++iy)
+        for (int ix = x0; ix < x1; ++ix) {
+            const float v = vs_ld(x, xd, plane_base + (int64_t)iy * W + ix);
+            if (v > best || v != v) { best = v; arg = iy * W + ix; }  // a NaN always takes over, as in ATen
+        }
+    return arg;
+}
+
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const void* x, int xd, void* y, int yd, int64_t planes, int H, int W, int OH, int OW) {
+    const int64_t total = planes * OH * OW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const int64_t plane = i / ((int64_t)OW * OH);
+        float best;
+        pool3_argmax(x, xd, plane * H * W, H, W, oy, ox, best);
+        vs_st(y, yd, i, best);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const void* x, int xd, const void* dy, int dyd, void* dx, int dxd, int64_t planes, int H,
+                                                             int W, int OH, int OW) {
+    const int64_t total = planes * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ix = (int)(i % W), iy = (int)((i / W) % H);
+        const int64_t plane = i / ((int64_t)W * H);
+        float acc = 0.f;
+        // windows (oy, ox) with 2 oy - 1 <= iy <= 2 oy + 1
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy < 0 || oy >= OH) continue;
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox < 0 || ox >= OW) continue;
+                float best;
+                if (pool3_argmax(x, xd, plane * H * W, H, W, oy, ox, best) == iy * W + ix) acc += vs_ld(dy, dyd, (plane * OH + oy) * OW + ox);
+            }
+        }
+        vs_st(dx, dxd, i, acc);
+    }
+}
+
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const void* x, int xd, void* y, int yd, int64_t planes, int H, int W) {
     const int OH = 2 * H, OW = 2 * W;
     const int64_t total = planes * OH * OW;
@@ -443,6 +490,25 @@ extern "C" int vs_maxpool2_bwd(const void* x, int x_dtype, const void* dy, int d
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(planes * (H / 2) * (W / 2))), dim3(256), 0, (hipStream_t)stream, x, x_dtype, dy, dy_dtype,
                        dx, dx_dtype, planes, H, W);
     VS_CHECK_LAUNCH("vs_maxpool2_bwd");
+    return VS_OK;
+}
+
+extern "C" int vs_maxpool3s2_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t planes, int H, int W, void* stream) {
+    VS_CHECK_ARG(x && y && planes > 0 && H > 0 && W > 0, "vs_maxpool3s2_fwd: bad argument");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(ew_grid(planes * OH * OW)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, planes, H,
+                       W, OH, OW);
+    VS_CHECK_LAUNCH("vs_maxpool3s2_fwd");
+    return VS_OK;
+}
+
+extern "C" int vs_maxpool3s2_bwd(const void* x, int x_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype, int64_t planes, int H, int W,
+                                 void* stream) {
+    VS_CHECK_ARG(x && dy && dx && planes > 0 && H > 0 && W > 0, "vs_maxpool3s2_bwd: bad argument");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(ew_grid(planes * H * W)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, dy, dy_dtype, dx,
+                       dx_dtype, planes, H, W, OH, OW);
+    VS_CHECK_LAUNCH("vs_maxpool3s2_bwd");
     return VS_OK;
 }
 

@@ -442,6 +442,21 @@ class MaxPool2(torch.autograd.Function):
         return ops.maxpool2_bwd(x, dy.to(x.dtype) if dy.dtype != x.dtype else dy)
 
 
+class MaxPool3s2(torch.autograd.Function):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (conv.py:517, ResNet18 stem)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.maxpool3s2_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool3s2_bwd(x, dy.to(x.dtype) if dy.dtype != x.dtype else dy)
+
+
 class Upsample2(torch.autograd.Function):
     """nn.Upsample(scale_factor=2, mode='nearest') (conv.py:296-314, 371-377, 406-413)."""
 

@@ -527,6 +527,26 @@ def maxpool2_bwd(x, dy):
     return dx
 
 
+def maxpool3s2_fwd(x):
+    """nn.MaxPool2d(3, 2, 1) on [B, C, H, W]."""
+    require_cuda(x)
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device)
+    check(_lib.load_library().vs_maxpool3s2_fwd(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), B * C, H, W, stream_ptr()),
+          'vs_maxpool3s2_fwd')
+    return y
+
+
+def maxpool3s2_bwd(x, dy):
+    require_cuda(x, dy)
+    B, C, H, W = x.shape
+    dy = dy.contiguous()
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    check(_lib.load_library().vs_maxpool3s2_bwd(x.data_ptr(), dtype_code(x), dy.data_ptr(), dtype_code(dy), dx.data_ptr(),
+                                                dtype_code(dx), B * C, H, W, stream_ptr()), 'vs_maxpool3s2_bwd')
+    return dx
+
+
 def upsample2_fwd(x):
     require_cuda(x)
     B, C, H, W = x.shape

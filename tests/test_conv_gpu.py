@@ -30,6 +30,15 @@ GEOMS = [
     (2, 72, 24, 24, 64, 3, 1, 1, True),     # ConvTranspose2d k3 s1 p1, flipped taps, rows of 24 pixels
     (64, 148, 1, 1, 512, 4, 1, 0, True),    # decoder first_upconv at full width: 1x1 -> 4x4 through the column matrix
     (64, 128, 4, 4, 64, 4, 1, 0, False),    # VGG encoder last_op at width: its input gradient gathers dy on the 4x4 grid
+    # chairs ResNet18 encoder (conv.py:433-564): 25-tap stem, odd sizes, stride-2 3x3 and 1x1 convs whose input gradients
+    # run as four parity phases of DIFFERENT extents (one of them without taps for the 1x1 kernel)
+    (2, 15, 64, 64, 16, 5, 2, 3, False),    # stem: k5 s2 p3, 64 -> 33
+    (3, 8, 17, 17, 12, 3, 2, 1, False),     # layer2.0.conv1: k3 s2 p1, 17 -> 9
+    (3, 8, 17, 17, 12, 1, 2, 0, False),     # layer2.0.downsample.0: k1 s2 p0, 17 -> 9
+    (2, 16, 9, 9, 24, 3, 2, 1, False),      # 9 -> 5
+    (2, 16, 5, 5, 24, 1, 2, 0, False),      # 5 -> 3
+    (4, 24, 3, 3, 10, 3, 1, 0, False),      # conv_out: 3x3 valid -> 1x1
+    (4, 64, 33, 33, 64, 3, 2, 1, False),    # 33 -> 17 with 64 channels: the column-matrix path on odd sizes
 ]
 
 
@@ -159,3 +168,21 @@ def test_grouped_batchnorm_equals_sequential_calls():
         db_s += db1
     assert torch.equal(rm_g, rm_s) and torch.equal(rv_g, rv_s)
     assert torch.allclose(dg, dg_s, rtol=1e-6, atol=1e-6) and torch.allclose(db, db_s, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 5, 33, 33), (3, 4, 8, 8), (1, 3, 5, 7), (2, 2, 1, 1)])
+def test_maxpool3s2_matches_torch(dtype, shape):
+    """nn.MaxPool2d(3, 2, 1) (ResNet18 stem): overlapping windows, gradient routed to the first maximum; ties included."""
+    from spatiotemporal_variable_separation_amd import functional as VF
+    x = (_rand(shape, 21) * 4).round() / 4                      # quarter steps: plenty of exact ties inside the windows
+    x = x.to(dtype)
+    xr = x.double().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = _rand(tuple(yr.shape), 22).to(dtype)
+    yr.backward(dy.double())
+    xd = x.cuda().requires_grad_(True)
+    y = VF.MaxPool3s2.apply(xd)
+    assert tuple(y.shape) == tuple(yr.shape) and torch.equal(y.cpu().double(), yr.detach())
+    y.backward(dy.cuda())
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-2 if dtype == torch.bfloat16 else 1e-6)
