@@ -361,8 +361,64 @@ def init_net(net, init_type='normal', init_gain=0.02):
     net.apply(visit)
 
 
+class BasicBlock(nn.Module):
+    """conv.py:440-468."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        residual = x if self.downsample is None else self.downsample(x)
+        out = out + residual
+        return self.relu(out)
+
+
+class ResNet18(nn.Module):
+    """conv.py:509-564: the chairs encoder.  `bn_out` exists but is never applied (conv.py:526, 559)."""
+
+    def __init__(self, pose_dim, nc=3, out_f=None):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(nc, 64, kernel_size=5, stride=2, padding=3)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, 2)
+        self.layer2 = self._make_layer(128, 2, stride=2)
+        self.layer3 = self._make_layer(256, 2, stride=2)
+        self.layer4 = self._make_layer(512, 2, stride=2)
+        self.conv_out = nn.Conv2d(512, pose_dim, kernel_size=3)
+        self.bn_out = nn.BatchNorm2d(pose_dim)
+        self.out_function = act(out_f)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride), nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x, return_skip=False):
+        x = x.view(x.size(0), -1, x.size(3), x.size(4))
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.out_function(self.conv_out(x))
+        return x.view(len(x), -1)
+
+
 def get_encoder(nn_type, shape, output_size, hidden_size, n_layers, nt_cond, init_type, init_gain):
-    """factory.py:25-44 (the chairs-only `resnet` encoder is outside SURVEY section 8)."""
+    """factory.py:25-44."""
     nc, dim = shape[0], shape[-1]
     if nn_type == 'dcgan':
         assert dim == 64
@@ -372,6 +428,8 @@ def get_encoder(nn_type, shape, output_size, hidden_size, n_layers, nt_cond, ini
         enc = VGG64Encoder(nc * nt_cond, output_size, hidden_size, vgg32=dim == 32)
     elif nn_type == 'encoderSST':
         enc = EncoderSST(nc * nt_cond, output_size)
+    elif nn_type == 'resnet':
+        enc = ResNet18(output_size, nc * nt_cond)
     elif nn_type == 'mlp':
         enc = MLPEncoder(int(nt_cond * np.prod(np.array(shape))), hidden_size, output_size, n_layers)
     else:

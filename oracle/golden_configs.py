@@ -53,6 +53,12 @@ CONFIGS = {
                        dec_hidden_size=64, res_hidden_size=8, n_blocks=1, mixing='concat', last_activation=None,
                        skipco=False, average_tloss=True, data_range='normal',
                        lambdas=dict(ae=1.0, s=100.0, t=5e-6, pred=45.0), salt=19),
+    # chairs recipe (README.md:78): ResNet18 encoders (fixed widths 64..512, conv.py:509-564) + DCGAN decoder, 3-channel frames;
+    # ~22 M encoder parameters, pinned by checksum
+    'chairs_resnet': dict(architecture='resnet', decoder_architecture='dcgan', shape=[3, 64, 64], nt_cond=2, nt_pred=2, offset=2, B=2,
+                          code_size_s=6, code_size_t=5, enc_hidden_size=4, dec_hidden_size=4, res_hidden_size=8, n_blocks=1,
+                          mixing='concat', last_activation='sigmoid', skipco=False, lambdas=dict(ae=1.0, s=1.0, t=0.001, pred=45.0),
+                          salt=19),
 }
 
 

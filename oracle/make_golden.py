@@ -123,7 +123,7 @@ def run_config(name, cfg, mods):
     t_random = int(np.random.randint(cfg['nt_cond'], hi))
     opt_b.zero_grad()
     total.backward()
-    grads = {k: p.grad.clone() for k, p in net_b.named_parameters()}
+    grads = {k: p.grad.clone() for k, p in net_b.named_parameters() if p.grad is not None}    # ResNet18.bn_out is never used
     opt_b.step()
     sa, sb = net_a.state_dict(), net_b.state_dict()
     for k in sa:
@@ -145,6 +145,9 @@ def run_config(name, cfg, mods):
     o_total.backward()
     worst = 0.0
     for k, p in net_o.named_parameters():
+        if k not in grads:
+            assert p.grad is None, k
+            continue
         g = grads[k]
         worst = max(worst, ((p.grad - g).abs().max() / (g.abs().max() + 1e-30)).item())
     opt_o.step()

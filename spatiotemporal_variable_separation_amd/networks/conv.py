@@ -331,3 +331,69 @@ class ConvResnet(nn.Module):
             x, residual = blk(x)
             residuals.append(residual)
         return (x, residuals) if return_res else x
+
+
+# ------------------------------------------------------------------------------------------------ chairs: ResNet18 encoder
+class BasicBlock(nn.Module):
+    """conv.py:440-468: conv3x3(stride) + BN + ReLU, conv3x3 + BN, [1x1 stride-s conv + BN on the shortcut], add, ReLU.
+    The attribute names are the reference's (`conv1 bn1 conv2 bn2 downsample`) so that state dicts interchange."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = run_layers(nn.Sequential(self.conv1, self.bn1, self.relu), x)
+        out = run_layers(nn.Sequential(self.conv2, self.bn2), out)
+        residual = run_layers(self.downsample, x) if self.downsample is not None else x
+        if residual.dtype != out.dtype:
+            residual = residual.to(out.dtype)
+        return VF.Activation.apply(out + residual, 'relu')
+
+
+class ResNet18(nn.Module):
+    """conv.py:509-564 (after DrNet): k5 s2 p3 stem + BN + ReLU, 3x3 s2 max-pool, four stages of two BasicBlocks (64, 128, 256,
+    512 planes; stride 2 from the second stage on), 3x3 valid `conv_out` to the code, optional output activation.  `bn_out` is
+    constructed -- and therefore initialised, saved and loaded -- but never applied, exactly like the reference."""
+
+    def __init__(self, pose_dim, nc=3, out_f=None):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(nc, 64, kernel_size=5, stride=2, padding=3)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, 2)
+        self.layer2 = self._make_layer(128, 2, stride=2)
+        self.layer3 = self._make_layer(256, 2, stride=2)
+        self.layer4 = self._make_layer(512, 2, stride=2)
+        self.conv_out = nn.Conv2d(512, pose_dim, kernel_size=3)
+        self.bn_out = nn.BatchNorm2d(pose_dim)
+        self.out_function = activation_factory(out_f)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride), nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x, return_skip=False):
+        h = x.reshape(x.size(0), -1, x.size(3), x.size(4))
+        h = run_layers(nn.Sequential(self.conv1, self.bn1, self.relu), h)
+        h = VF.MaxPool3s2.apply(h)
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for block in stage:
+                h = block(h)
+        h = run_layers(nn.Sequential(self.conv_out), h, final_act=activation_name(self.out_function), final_fp32=True)
+        return h.reshape(len(h), -1)
+

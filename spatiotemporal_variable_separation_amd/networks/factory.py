@@ -26,8 +26,7 @@ def get_encoder(nn_type, shape, output_size, hidden_size, n_layers, nt_cond, ini
         input_size = int(nt_cond * np.prod(np.array(shape)))
         encoder = MLPEncoder(input_size, hidden_size, output_size, n_layers)
     elif nn_type == 'resnet':
-        raise NotImplementedError('the chairs-only ResNet18 encoder (conv.py:433-564) is outside the MI355X hot-path '
-                                  'scope (SURVEY.md section 8f, rank 3)')
+        encoder = _conv().ResNet18(output_size, nc * nt_cond)
     else:
         raise ValueError(f'unknown encoder architecture `{nn_type}`')
     init_net(encoder, init_type=init_type, init_gain=init_gain)

@@ -34,6 +34,9 @@ def test_oracle_matches_reference_step(name):
     opt.zero_grad()
     total.backward()
     for k, p in net.named_parameters():
+        if p.grad is None:                           # never used in forward (ResNet18.bn_out): the reference has no gradient either
+            assert 'grad:' + k not in gold and 'cs:grad:' + k not in gold, k
+            continue
         check_tensor(gold, 'grad:' + k, p.grad, 2e-5)
     opt.step()
     for k, v in net.state_dict().items():

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 MLP_CONFIGS = ['mlp_mul', 'mlp_concat_partial', 'mlp_no_s']
 CONV_CONFIGS = ['dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'vgg64_skip', 'sst_skip', 'sst_noskip']
+CHAIRS_CONFIGS = ['chairs_resnet']               # ResNet18 encoders + DCGAN decoder
 
 
 def _available(name):
@@ -28,7 +29,7 @@ def _available(name):
         return False
 
 
-@pytest.mark.parametrize('name', MLP_CONFIGS + CONV_CONFIGS)
+@pytest.mark.parametrize('name', MLP_CONFIGS + CONV_CONFIGS + CHAIRS_CONFIGS)
 def test_step_fp32_matches_oracle(name):
     if not _available(name):
         pytest.skip('conv family not built yet')
@@ -37,7 +38,7 @@ def test_step_fp32_matches_oracle(name):
     print(name, {k: f'{v:.1e}' for k, v in errs.items()})
 
 
-@pytest.mark.parametrize('name', MLP_CONFIGS + CONV_CONFIGS)
+@pytest.mark.parametrize('name', MLP_CONFIGS + CONV_CONFIGS + CHAIRS_CONFIGS)
 def test_step_bf16_within_stated_bound(name):
     if not _available(name):
         pytest.skip('conv family not built yet')
