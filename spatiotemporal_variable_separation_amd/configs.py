@@ -1,4 +1,5 @@
-"""The five BASELINE.json configurations as option dictionaries (README.md recipes of the reference)."""
+"""The five BASELINE.json configurations as option dictionaries (README.md recipes of the reference), plus the chairs recipe
+(README.md:78) as an extra bench / parity workload."""
 
 BASELINE_CONFIGS = {
     # configs[0]: Moving MNIST 64x64, nt_cond=5 nt_pred=10, batch 16, DCGAN (options.py defaults)
@@ -26,4 +27,9 @@ BASELINE_CONFIGS = {
                 nt_cond=4, nt_pred=40, offset=0, batch=8, code_size_s=196, code_size_t=64, enc_hidden_size=64,
                 dec_hidden_size=64, res_hidden_size=512, n_blocks=2, mixing='concat', last_activation=None,
                 skipco=True, average_tloss=True, gain_resnet=0.71, lambdas=dict(ae=1.0, s=100.0, t=5e-6, pred=45.0)),
+    # not in BASELINE.json: 3D Warehouse chairs (README.md:78): ResNet18 encoders + DCGAN decoder, options.py defaults otherwise
+    'chairs': dict(data='chairs', architecture='resnet', decoder_architecture='dcgan', shape=[3, 64, 64], nt_cond=5, nt_pred=10,
+                   offset=5, batch=128, code_size_s=128, code_size_t=10, enc_hidden_size=64, dec_hidden_size=64,
+                   res_hidden_size=512, n_blocks=1, mixing='concat', last_activation='sigmoid', skipco=False, gain_resnet=0.71,
+                   lambdas=dict(ae=1.0, s=1.0, t=0.001, pred=45.0)),
 }

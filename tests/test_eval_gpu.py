@@ -21,7 +21,7 @@ def _pair(name):
     return cfg, o_net, h_net.cuda().eval()
 
 
-@pytest.mark.parametrize('name', ['mlp_mul', 'dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'sst_skip'])
+@pytest.mark.parametrize('name', ['mlp_mul', 'dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'sst_skip', 'chairs_resnet'])
 @pytest.mark.parametrize('fused', [True, False])
 def test_eval_forecast_matches_oracle(name, fused):
     cfg, o_net, h_net = _pair(name)

@@ -17,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
      '--res_hidden_size', '16', '--code_size_s', '12', '--code_size_t', '6', '--torch_amp'],
     ['--data', 'taxibj', '--architecture', 'vgg', '--nt_cond', '2', '--nt_pred', '2', '--offset', '2', '--enc_hidden_size', '8',
      '--dec_hidden_size', '8', '--res_hidden_size', '16', '--code_size_s', '12', '--code_size_t', '6', '--skipco'],
+    ['--data', 'chairs', '--architecture', 'resnet', '--decoder_architecture', 'dcgan', '--nt_cond', '2', '--nt_pred', '2', '--offset', '2',
+     '--dec_hidden_size', '8', '--res_hidden_size', '16', '--code_size_s', '12', '--code_size_t', '6', '--lamb_ae', '1', '--lamb_s', '1',
+     '--precision', 'bf16'],
 ])
 def test_main_trains_and_checkpoints(tmp_path, extra):
     cmd = [sys.executable, '-m', 'spatiotemporal_variable_separation_amd.main', '--xp_dir', str(tmp_path), '--data_dir',
