@@ -22,6 +22,8 @@ FAMILIES = [
     (r'train_losses_fwd_kernel', 'vs_train_losses_fwd'),
     (r'train_losses_bwd_kernel', 'vs_train_losses_bwd'),
     (r'splitk_reduce_kernel', 'splitk_reduce'),
+    (r'mix_codes_fwd_kernel', 'vs_mix_codes_fwd'),
+    (r'mix_codes_bwd_kernel', 'vs_mix_codes_bwd'),
 ]
 
 
