@@ -140,6 +140,7 @@ def main():
                                    seed=1234 + rank)
     lam = cfg['lambdas']
     VF.set_precision(args.precision)
+    VF.fold_repeated_gradients(sync is None and os.environ.get('VARSEP_FOLD_GRADS', '1') == '1')   # as train() does
 
     def step():
         if sync is not None:
@@ -153,6 +154,7 @@ def main():
         if sync is not None:
             sync.all_reduce()
         opt.step()
+        VF.flush_bn_call_counts()
         return total
 
     def barrier():

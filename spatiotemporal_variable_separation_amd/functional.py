@@ -36,6 +36,42 @@ def precision(p):
         _STATE['precision'] = old
 
 
+def fold_repeated_gradients(flag):
+    """Modules called many times per step (the integrator's convolutions: once per rollout step) produce one weight, bias, gamma
+    and beta gradient PER CALL, and autograd adds each of them to `.grad` with its own 3-4 us launch (SST, 40 predicted frames:
+    ~1200 such adds per step).  With this switch on, a block whose parameters already hold a gradient adds all of its
+    contributions with ONE multi-tensor launch and returns nothing to autograd for them.  Only valid without gradient hooks
+    (the bucketed all-reduce counts hook calls), so `train()` / `bench.py` turn it on for single-process runs only."""
+    if not flag:
+        flush_bn_call_counts()
+    _STATE['fold_grads'] = bool(flag)
+
+
+_BN_COUNTS = {}
+
+
+def count_bn_calls(bn, calls):
+    """`num_batches_tracked += calls` of a training-mode BatchNorm (one per reference call).  While gradients are folded (the
+    training loop owns the step and calls `flush_bn_call_counts()` at its end) the increments are collected and applied by ONE
+    multi-tensor launch per step instead of one launch per BatchNorm call (SST: ~300 per step)."""
+    if not _STATE.get('fold_grads'):
+        bn.num_batches_tracked += calls
+        return
+    ent = _BN_COUNTS.get(id(bn))
+    if ent is None:
+        _BN_COUNTS[id(bn)] = [bn.num_batches_tracked, calls]
+    else:
+        ent[1] += calls
+
+
+def flush_bn_call_counts():
+    if _BN_COUNTS:
+        bufs = [e[0] for e in _BN_COUNTS.values()]
+        incs = [e[1] for e in _BN_COUNTS.values()]
+        _BN_COUNTS.clear()
+        torch._foreach_add_(bufs, incs)
+
+
 def compute_dtype():
     return torch.float32 if _STATE['precision'] == 'fp32' else torch.bfloat16
 
@@ -417,13 +453,28 @@ class ConvBlock(torch.autograd.Function):
         if b is not None and b.requires_grad:
             # a conv bias in front of a training-mode BatchNorm has an exactly-zero gradient (the batch mean removes it);
             # the reference returns fp32 summation noise there, we return the exact value without a reduction pass
-            db = torch.zeros_like(b) if (has_bn and training) else ops.chan_sum(dz)
+            if has_bn and training:
+                db = None if (_STATE.get('fold_grads') and b.grad is not None) else torch.zeros_like(b)     # exactly zero: nothing to add
+            else:
+                db = ops.chan_sum(dz)
         dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed) if w.requires_grad else None
         dx = None
         if ctx.x_needs_grad:
             wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
             dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
                                 cols_from_wgrad=transposed and dw is not None)
+        if _STATE.get('fold_grads'):
+            into, what = [], []
+            for prm, g in ((w, dw), (b, db), (ctx.gamma, dgamma), (ctx.beta, dbeta)):
+                if g is not None and prm is not None and prm.grad is not None and prm.grad.shape == g.shape and prm.grad.dtype == g.dtype:
+                    into.append(prm.grad)
+                    what.append(g)
+            if into:
+                torch._foreach_add_(into, what)          # one launch for the block instead of one per parameter
+                dw = None if any(t is w.grad for t in into) else dw
+                db = None if b is not None and any(t is b.grad for t in into) else db
+                dgamma = None if ctx.gamma is not None and any(t is ctx.gamma.grad for t in into) else dgamma
+                dbeta = None if ctx.beta is not None and any(t is ctx.beta.grad for t in into) else dbeta
         return dx, dw, db, dgamma, dbeta, None, None, None
 
 

@@ -72,7 +72,7 @@ def run_layers(module, h, final_act='none', final_fp32=False, groups=1):
             assert m.kernel_size[0] == m.kernel_size[1] and m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1]
             training = bn.training if bn is not None else False
             if bn is not None and training:
-                bn.num_batches_tracked += groups       # per call, like nn.BatchNorm2d
+                VF.count_bn_calls(bn, groups)          # += groups: one per call, like nn.BatchNorm2d
             cfg = (isinstance(m, nn.ConvTranspose2d), m.stride[0], m.padding[0], bn is not None, act_name, training,
                    bn.momentum if bn is not None else 0.1, bn.eps if bn is not None else 1e-5,
                    bool(final_fp32 and last and extra is None), groups)

@@ -317,6 +317,8 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
 
     step, t_last = 0, time.time()
     graphed = None
+    from . import functional as VF
+    VF.fold_repeated_gradients(grad_sync is None)          # no gradient hooks in single-process runs
     try:
         for epoch in range(epochs):
             sep_net.train()
@@ -346,6 +348,7 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                 if grad_sync is not None:
                     grad_sync.all_reduce()
                 optimizer.step()
+                VF.flush_bn_call_counts()
                 step += 1
                 if log_interval and step % log_interval == 0:
                     torch.cuda.synchronize()
@@ -361,4 +364,6 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                 save(xp_dir, sep_net, epoch_number=epoch + 1)
     except KeyboardInterrupt:
         pass
+    finally:
+        VF.fold_repeated_gradients(False)
     save(xp_dir, sep_net)

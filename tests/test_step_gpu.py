@@ -7,6 +7,7 @@ bound (on these tiny, hash-filled networks one ReLU unit flipped by an operand r
 several percent -- torch's own bf16 autocast shows 3e-2..4e-1 on the same steps).
 """
 import pytest
+import torch
 
 from oracle.golden_configs import CONFIGS
 from golden_util import load_golden
@@ -203,3 +204,30 @@ def test_graphed_step_equals_eager_steps(side_streams):
     assert np.allclose(losses_g, losses_e[3:], rtol=2e-4), (losses_g, losses_e)
     for (k, a), (_, b) in zip(net_g.state_dict().items(), net_e.state_dict().items()):
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-5), k
+
+
+@pytest.mark.parametrize('name', ['sst_skip', 'dcgan_tiny', 'chairs_resnet'])
+def test_folded_repeated_gradients_equal_autograd_accumulation(name):
+    """functional.fold_repeated_gradients: a block whose parameters already hold a gradient (the integrator's convolutions,
+    called once per rollout step; the decoder, once per frame) adds its contributions with one multi-tensor launch instead of
+    handing them to autograd -- the accumulated gradients must be the ones autograd builds."""
+    from step_util import hip_step, oracle_step
+    from spatiotemporal_variable_separation_amd import functional as VF
+    cfg = CONFIGS[name]
+    t_random = int(load_golden(name)['t_random'])
+    o_net = oracle_step(cfg, t_random)[0]
+    net_a = hip_step(cfg, t_random, o_net, 'fp32')[0]
+    VF.fold_repeated_gradients(True)
+    try:
+        net_b = hip_step(cfg, t_random, o_net, 'fp32')[0]
+    finally:
+        VF.fold_repeated_gradients(False)
+    ga, gb = dict(net_a.named_parameters()), dict(net_b.named_parameters())
+    for k in ga:
+        if ga[k].grad is None:
+            assert gb[k].grad is None, k
+            continue
+        torch.testing.assert_close(gb[k].grad, ga[k].grad, rtol=1e-5, atol=1e-7, msg=k)     # same terms, fp32 add order differs
+    sa, sb = net_a.state_dict(), net_b.state_dict()
+    counters = [k for k in sa if k.endswith('num_batches_tracked')]
+    assert counters and all(int(sa[k]) == int(sb[k]) for k in counters) and any(int(sb[k]) > 0 for k in counters)   # increments applied
