@@ -155,30 +155,39 @@ def colsum(x, M, N, out=None, accumulate=False):
     return out
 
 
-def colsum_multi(jobs):
+def colsum_multi(jobs, outs=None):
     """jobs: list of (x [M, N] 2-D tensor).  Returns one fp32 vector of column sums per job (views of one flat buffer),
-    computed by a single launch (+ one memset)."""
+    computed by a single launch (+ one memset).  `outs`: caller-provided fp32 vectors that are ALREADY ZERO (the partial sums
+    are added to them, e.g. slices of a zeroed all-reduce bucket) -- then nothing is allocated or filled here."""
     import ctypes
-    outs = []
+    results = []
     for i in range(0, len(jobs), 12):
         chunk = jobs[i:i + 12]
         n = len(chunk)
         require_cuda(*chunk)
         total = sum(x.shape[1] for x in chunk)
-        flat = torch.empty((total,), dtype=torch.float32, device=chunk[0].device)
-        views, off = [], 0
-        for x in chunk:
-            views.append(flat[off:off + x.shape[1]])
-            off += x.shape[1]
+        if outs is None:
+            flat = torch.empty((total,), dtype=torch.float32, device=chunk[0].device)
+            views, off = [], 0
+            for x in chunk:
+                views.append(flat[off:off + x.shape[1]])
+                off += x.shape[1]
+            zero_base, zero_count = flat.data_ptr(), total
+        else:
+            views = outs[i:i + 12]
+            for v, x in zip(views, chunk):
+                assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == x.shape[1]
+            require_cuda(*views)
+            zero_base, zero_count = None, 0
         VP, I32, I64 = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
         e0 = _pb()
         check(_lib.load_library().vs_colsum_multi(
             n, VP(*[x.data_ptr() for x in chunk]), I32(*[dtype_code(x) for x in chunk]), I64(*[x.stride(0) for x in chunk]),
             I64(*[x.shape[0] for x in chunk]), I64(*[x.shape[1] for x in chunk]), VP(*[v.data_ptr() for v in views]),
-            flat.data_ptr(), total, stream_ptr()), 'vs_colsum_multi')
+            zero_base, zero_count, stream_ptr()), 'vs_colsum_multi')
         _pe(e0, 'vs_colsum_multi', nbytes=float(sum(x.numel() * x.element_size() for x in chunk)))
-        outs += views
-    return outs
+        results += list(views)
+    return results
 
 
 def act_fwd(x, act, out=None, out_dtype=None):

@@ -127,6 +127,28 @@ class Adam(torch.optim.Optimizer):
             self._launched = set()
         return loss
 
+    @torch.no_grad()
+    def step_subset(self, params):
+        """The Adam update of `params` (all of one param group, all with gradients) WITHOUT advancing the step counter: the caller
+        updates disjoint subsets one after the other -- e.g. one per all-reduce bucket, each as soon as its bucket has arrived --
+        and finishes with `finish_step()`.  Together they are exactly `step()`."""
+        for gi, group in enumerate(self.param_groups):
+            self._init_group(gi, group)
+            ids = {id(p) for p in group['params']}
+            live = [p for p in params if id(p) in ids]
+            if any(p.grad is None for p in live):
+                raise VarsepHipError('step_subset needs a gradient for every listed parameter')
+            if live:
+                self._update(gi, group, live)
+
+    @torch.no_grad()
+    def finish_step(self):
+        lib = _lib.load_library()
+        for gi, group in enumerate(self.param_groups):
+            self._init_group(gi, group)
+            main = torch.cuda.current_stream(group['params'][0].device)
+            _lib.check(lib.vs_adam_step_increment(group['step_dev'].data_ptr(), main.cuda_stream), 'vs_adam_step_increment')
+
     def _update(self, gi, group, live):
         """One vs_adam_multi launch per 64 tensors of `live` on the current stream (the step counter is not touched)."""
         from . import functional as VF

@@ -145,6 +145,19 @@ class GradAllReducer:
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 
+    def reduce_bucket(self, bi):
+        """Start the all-reduce of bucket `bi` on the comm stream (ordered after the current stream) and return an event that is
+        recorded when its averaged gradients are in place; None when nothing runs (single rank).  Buckets issued in order are
+        reduced in order, so a consumer that waits on event i can start while buckets i+1.. are still on the wire."""
+        if self.world_size == 1 and not self._force:
+            return None
+        self._launch(bi)
+        if self._comm_stream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._comm_stream)
+        return ev
+
     def payload_bytes(self):
         return sum(flat.numel() * 4 for flat, _ in self.buckets)
 

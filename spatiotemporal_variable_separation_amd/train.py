@@ -155,9 +155,9 @@ class GraphedStep:
     def __init__(self, sep_net, optimizer, cond, target, nt_cond, nt_pred, offset, lambdas, average_tloss=False, warmup=3,
                  side_streams=True, grad_sync=None):
         assert cond.is_cuda and _mlp_family(sep_net), 'GraphedStep supports the MLP family on a GPU'
-        # deferred weight gradients require that nothing reads a gradient before join_side_streams(): not the case when they
-        # are accumulated into the reducer's (pre-existing) flat buckets
-        self.side_streams = side_streams and grad_sync is None and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
+        # deferred weight gradients require that nothing reads a gradient before join_side_streams(); with a reducer the Linear
+        # chains therefore write straight into its flat buckets (VF.set_grad_outputs) instead of going through autograd's `+=`
+        self.side_streams = side_streams and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
         check_optimizer(optimizer)
         self.net, self.opt, self.sync = sep_net, optimizer, grad_sync
         self._one = torch.ones((), dtype=torch.float32, device=cond.device)
@@ -197,9 +197,22 @@ class GraphedStep:
             with torch.cuda.graph(self.graph):
                 self.loss = self._fwd_bwd()
             self._reduce()
-            self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt):
-                self.opt.step()
+            if hasattr(self.opt, 'step_subset') and os.environ.get('VARSEP_ADAM_PER_BUCKET', '1') == '1':
+                # one Adam recording per all-reduce bucket: the update of bucket i runs while buckets i+1.. are still on the wire
+                self.graph_opt = []
+                for _, plist in grad_sync.buckets:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self.opt.step_subset(plist)
+                    self.graph_opt.append(g)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.opt.finish_step()
+                self.graph_opt.append(g)
+            else:
+                self.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_opt):
+                    self.opt.step()
 
     def _draw(self):
         hi = self.T if self.offset == 0 else self.T + 1
@@ -216,6 +229,7 @@ class GraphedStep:
         from . import functional as VF
         if self.sync is not None:
             self.sync.zero_buffers()
+            VF.set_grad_outputs({p: p.grad for p in self.sync.params})
         else:
             self.opt.zero_grad(set_to_none=True)
         VF.enable_side_streams(self.side_streams)
@@ -226,6 +240,7 @@ class GraphedStep:
             VF.join_side_streams()
         finally:
             VF.enable_side_streams(False)
+            VF.set_grad_outputs(None)
         return total.detach()
 
     def step(self, cond=None, target=None):
@@ -237,7 +252,15 @@ class GraphedStep:
             self._capture()                          # a scheduler moved the learning rate: it is a launch argument of the recording
         self._draw()
         self.graph.replay()
-        if self.graph_opt is not None:
+        if isinstance(self.graph_opt, list):
+            events = [self.sync.reduce_bucket(bi) for bi in range(len(self.sync.buckets))]
+            main = torch.cuda.current_stream()
+            for ev, g in zip(events, self.graph_opt):
+                if ev is not None:
+                    main.wait_event(ev)
+                g.replay()
+            self.graph_opt[-1].replay()              # step counter
+        elif self.graph_opt is not None:
             self._reduce()
             self.graph_opt.replay()
         return self.loss

@@ -180,3 +180,29 @@ def test_update_in_backward_equals_plain_step(graph):
     assert sa == sb
     for k in a:
         assert torch.allclose(a[k], b[k], rtol=2e-4, atol=2e-6), k
+
+
+def test_step_by_subsets_equals_one_step():
+    """`step_subset()` over a partition of the parameters + `finish_step()` is `step()` (the data-parallel graph path updates
+    one all-reduce bucket at a time while the next buckets are still on the wire)."""
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    a, b = _params(7), _params(7)
+    oa = Adam(a, lr=3e-4, betas=(0.9, 0.99))
+    ob = Adam(b, lr=3e-4, betas=(0.9, 0.99))
+    g = torch.Generator().manual_seed(3)
+    for it in range(3):
+        for x, y in zip(a, b):
+            gr = (torch.rand(x.shape, generator=g) - 0.5).cuda()
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step_subset(b[3:])
+        ob.step_subset(b[:1])
+        ob.step_subset(b[1:3])
+        ob.finish_step()
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+        assert torch.equal(oa.state[x]['exp_avg'], ob.state[y]['exp_avg']) and torch.equal(oa.state[x]['exp_avg_sq'], ob.state[y]['exp_avg_sq'])
+    b[0].grad = None
+    with pytest.raises(Exception):
+        ob.step_subset(b[:1])
