@@ -129,7 +129,10 @@ def main():
         broadcast_module_state(net)
     # bf16 mode: gradients travel as bf16 (VARSEP_GRAD_COMM=fp32 keeps fp32 on the wire); reported in config.grad_allreduce
     comm_bf16 = args.precision == 'bf16' and os.environ.get('VARSEP_GRAD_COMM', 'bf16') == 'bf16'
-    sync = GradAllReducer(net.parameters(), force=(world == 1), comm_dtype=torch.bfloat16 if comm_bf16 else torch.float32) if ddp else None
+    from spatiotemporal_variable_separation_amd.train import chain_weight_parameters
+    direct = chain_weight_parameters(net) if (comm_bf16 and os.environ.get('VARSEP_GRAD_DIRECT_LOWP', '1') == '1') else None
+    sync = GradAllReducer(net.parameters(), force=(world == 1), comm_dtype=torch.bfloat16 if comm_bf16 else torch.float32,
+                          lowp_direct=direct) if ddp else None
     from spatiotemporal_variable_separation_amd.train import GraphedStep, _mlp_family
     use_graph = (not args.no_graph) and _mlp_family(net)
     from spatiotemporal_variable_separation_amd.optim import Adam

@@ -168,10 +168,12 @@ int vs_train_losses_bwd(const float* frames, const float* full, const int32_t* i
  * skipped (host array or NULL): optimizer steps a tensor sat out without gradient -- torch counts steps per parameter, so
  * its t is step[0] + 1 - skipped[i].
  * shadow_bf16 (array or NULL, entries may be NULL): bf16 copy of the updated parameter written in the same pass (the
- * operand copy the bf16 forward pass reads).  Tensors contiguous; 16-byte aligned ones take the vector path.                                  */
-int vs_adam_multi(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                  void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step, double lr, double beta1,
-                  double beta2, double eps, void* stream);
+ * operand copy the bf16 forward pass reads).  Tensors contiguous; 16-byte aligned ones take the vector path.
+ * grad_dtype (host array or NULL = all fp32): VS_BF16 entries read their gradient as bf16 -- the data-parallel wire image of a
+ * weight gradient, consumed without a cast back to fp32.                                                                  */
+int vs_adam_multi(int n_tensors, float* const* params, const void* const* grads, const int32_t* grad_dtype, float* const* exp_avg,
+                  float* const* exp_avg_sq, void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step,
+                  double lr, double beta1, double beta2, double eps, void* stream);
 int vs_adam_step_increment(int32_t* step, void* stream);
 
 /* Fused frame losses (train.py:85-86 ae_loss MSE and train.py:139 forecast MSE in one pass over the decoded frames).

@@ -87,7 +87,7 @@ SIGNATURES = {
     'vs_copy2d': (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp]),
     'vs_colsum': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     'vs_colsum_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    'vs_adam_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+    'vs_adam_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                              ctypes.c_double, _vp]),
     'vs_adam_step_increment': (_i32, [_vp, _vp]),
     'vs_gemm_batched_workspace_bytes': (_sz, [_i32, _i64, _i64, _i64]),

@@ -16,7 +16,8 @@ constexpr int AD_CHUNK = 4096;          // elements per workgroup iteration
 
 struct AdamJobs {
     float* p[AD_MAXJ];
-    const float* g[AD_MAXJ];
+    const void* g[AD_MAXJ];
+    int g_bf16[AD_MAXJ];                // gradient stored as bf16 (the data-parallel wire image) instead of fp32
     float* m[AD_MAXJ];
     float* v[AD_MAXJ];
     __bf16* shadow[AD_MAXJ];            // optional bf16 copy of the updated parameter
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
         const long long base = (long long)(ch - J.chunk_off[j]) * AD_CHUNK;
         const long long n = J.n[j];
         float* __restrict__ P = J.p[j];
-        const float* __restrict__ G = J.g[j];
+        const float* __restrict__ G = (const float*)J.g[j];
+        const __bf16* __restrict__ Gh = (const __bf16*)J.g[j];
+        const bool gh = J.g_bf16[j] != 0;
         float* __restrict__ M = J.m[j];
         float* __restrict__ V = J.v[j];
         __bf16* __restrict__ S = J.shadow[j];
@@ -54,7 +57,14 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
         for (int u = 0; u < AD_CHUNK / 1024; ++u) {
             const long long i = base + (long long)u * 1024 + threadIdx.x * 4;
             if (i + 3 < n && J.aligned[j]) {
-                f32x4 p = *reinterpret_cast<const f32x4*>(P + i), g = *reinterpret_cast<const f32x4*>(G + i);
+                f32x4 p = *reinterpret_cast<const f32x4*>(P + i), g;
+                if (gh) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4g;
+                    const bf16x4g t4 = *reinterpret_cast<const bf16x4g*>(Gh + i);
+                    g = f32x4{(float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]};
+                } else {
+                    g = *reinterpret_cast<const f32x4*>(G + i);
+                }
                 f32x4 m = *reinterpret_cast<const f32x4*>(M + i), v = *reinterpret_cast<const f32x4*>(V + i);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
                 }
             } else {
                 for (long long k = i; k < n && k < i + 4; ++k) {
-                    const float g = G[k];
+                    const float g = gh ? (float)Gh[k] : G[k];
                     const float m = M[k] + w1 * (g - M[k]);
                     const float v = V[k] * beta2 + (w2 * g) * g;
                     const float denom = sqrtf(v) / bc2_sqrt + eps;
@@ -90,9 +100,9 @@ __global__ void step_increment_kernel(int* step) { step[0] += 1; }
 
 }  // namespace
 
-extern "C" int vs_adam_multi(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                             void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step, double lr, double beta1, double beta2, double eps,
-                             void* stream) {
+extern "C" int vs_adam_multi(int n_tensors, float* const* params, const void* const* grads, const int32_t* grad_dtype, float* const* exp_avg,
+                             float* const* exp_avg_sq, void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step, double lr,
+                             double beta1, double beta2, double eps, void* stream) {
     VS_CHECK_ARG(n_tensors >= 1 && n_tensors <= AD_MAXJ && params && grads && exp_avg && exp_avg_sq && numel && step,
                  "vs_adam_multi: bad argument (1..%d tensors)", AD_MAXJ);
     VS_CHECK_ARG(lr > 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps > 0.0, "vs_adam_multi: bad hyper-parameter");
@@ -101,12 +111,15 @@ extern "C" int vs_adam_multi(int n_tensors, float* const* params, const float* c
     J.chunk_off[0] = 0;
     for (int j = 0; j < n_tensors; ++j) {
         VS_CHECK_ARG(params[j] && grads[j] && exp_avg[j] && exp_avg_sq[j] && numel[j] > 0, "vs_adam_multi: bad tensor %d", j);
-        VS_CHECK_ARG(((uintptr_t)params[j] | (uintptr_t)grads[j] | (uintptr_t)exp_avg[j] | (uintptr_t)exp_avg_sq[j]) % 4 == 0,
-                     "vs_adam_multi: tensor %d is not 4-byte aligned", j);
+        const int gd = grad_dtype ? grad_dtype[j] : VS_F32;
+        VS_CHECK_ARG(gd == VS_F32 || gd == VS_BF16, "vs_adam_multi: bad gradient dtype of tensor %d", j);
+        VS_CHECK_ARG(((uintptr_t)params[j] | (uintptr_t)exp_avg[j] | (uintptr_t)exp_avg_sq[j]) % 4 == 0 && (uintptr_t)grads[j] % (gd == VS_F32 ? 4 : 2) == 0,
+                     "vs_adam_multi: tensor %d is not aligned to its element size", j);
+        J.g_bf16[j] = gd == VS_BF16;
         J.p[j] = params[j]; J.g[j] = grads[j]; J.m[j] = exp_avg[j]; J.v[j] = exp_avg_sq[j];
         J.shadow[j] = shadow_bf16 ? (__bf16*)shadow_bf16[j] : nullptr;
-        J.aligned[j] = ((uintptr_t)params[j] | (uintptr_t)grads[j] | (uintptr_t)exp_avg[j] | (uintptr_t)exp_avg_sq[j]) % 16 == 0 &&
-                       (!J.shadow[j] || (uintptr_t)J.shadow[j] % 8 == 0);
+        J.aligned[j] = ((uintptr_t)params[j] | (uintptr_t)exp_avg[j] | (uintptr_t)exp_avg_sq[j]) % 16 == 0 &&
+                       (uintptr_t)grads[j] % (gd == VS_F32 ? 16 : 8) == 0 && (!J.shadow[j] || (uintptr_t)J.shadow[j] % 8 == 0);
         J.n[j] = numel[j];
         J.skipped[j] = skipped ? skipped[j] : 0;
         const int64_t chunks = (numel[j] + AD_CHUNK - 1) / AD_CHUNK;

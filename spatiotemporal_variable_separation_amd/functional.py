@@ -132,12 +132,30 @@ def set_grad_outputs(mapping):
     _GRAD_OUT.clear()
     if mapping:
         for prm, view in mapping.items():
-            assert view.shape == prm.shape and view.dtype == torch.float32 and view.is_contiguous()
+            assert view.shape == prm.shape and view.dtype in (torch.float32, torch.bfloat16) and view.is_contiguous()
             _GRAD_OUT[id(prm)] = view
 
 
 def grad_output(prm):
     return _GRAD_OUT.get(id(prm)) if _GRAD_OUT else None
+
+
+# A gradient destination may be a bf16 tensor (the reducer's wire image): the weight-gradient GEMM rounds once in its epilogue,
+# the all-reduce averages that image in place and the optimizer reads it (optim.Adam consults lowp_gradient), so the fp32
+# gradient of such a weight never exists and neither do the casts to and from the wire format.
+_LOWP_GRAD = {}
+
+
+def set_lowp_gradients(mapping):
+    _LOWP_GRAD.clear()
+    if mapping:
+        for prm, view in mapping.items():
+            assert view.shape == prm.shape and view.dtype == torch.bfloat16 and view.is_contiguous()
+            _LOWP_GRAD[id(prm)] = view
+
+
+def lowp_gradient(prm):
+    return _LOWP_GRAD.get(id(prm)) if _LOWP_GRAD else None
 
 
 def side_streams_in_use():

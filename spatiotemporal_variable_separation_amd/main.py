@@ -124,8 +124,10 @@ def main(argv=None):
     grad_sync = None
     if world > 1:
         broadcast_module_state(sep_net)
-        grad_sync = GradAllReducer(sep_net.parameters(),
-                                   comm_dtype=torch.bfloat16 if getattr(args, 'grad_comm', 'fp32') == 'bf16' else torch.float32)
+        lowp = getattr(args, 'grad_comm', 'fp32') == 'bf16'
+        from .train import chain_weight_parameters
+        grad_sync = GradAllReducer(sep_net.parameters(), comm_dtype=torch.bfloat16 if lowp else torch.float32,
+                                   lowp_direct=chain_weight_parameters(sep_net) if (lowp and getattr(args, 'hip_graph', False)) else None)
 
     # same constructor call as the reference (main.py:133); the update runs as one multi-tensor HIP launch (optim.py)
     from .optim import Adam

@@ -84,18 +84,22 @@ class Adam(torch.optim.Optimizer):
     def _table(self, gi, plist, shadows):
         """ctypes pointer tables of one chunk of <= 64 tensors; rebuilt only when a pointer changes (a new .grad tensor after
         zero_grad(set_to_none=True) in the eager loop; stable inside a recorded graph and with flat gradient buckets)."""
+        from . import functional as VF
         key = (gi, id(plist[0]), len(plist))
-        ptrs = tuple((p.data_ptr(), p.grad.data_ptr(), 0 if s is None else s.data_ptr(), self.state[p].get('skipped', 0))
-                     for p, s in zip(plist, shadows))
+        gsrc = [VF.lowp_gradient(p) for p in plist]                  # bf16 wire image of the gradient, where one is registered
+        gsrc = [p.grad if g is None else g for p, g in zip(plist, gsrc)]
+        ptrs = tuple((p.data_ptr(), g.data_ptr(), 0 if s is None else s.data_ptr(), self.state[p].get('skipped', 0))
+                     for p, g, s in zip(plist, gsrc, shadows))
         ent = self._tables.get(key)
         if ent is not None and ent[0] == ptrs:
             return ent[1]
         n = len(plist)
         VP, I64, I32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
-        tab = (VP(*[p.data_ptr() for p in plist]), VP(*[p.grad.data_ptr() for p in plist]),
+        tab = (VP(*[p.data_ptr() for p in plist]), VP(*[g.data_ptr() for g in gsrc]),
                VP(*[self.state[p]['exp_avg'].data_ptr() for p in plist]), VP(*[self.state[p]['exp_avg_sq'].data_ptr() for p in plist]),
                VP(*[None if s is None else s.data_ptr() for s in shadows]), I64(*[p.numel() for p in plist]),
-               I32(*[self.state[p].get('skipped', 0) for p in plist]))
+               I32(*[self.state[p].get('skipped', 0) for p in plist]),
+               I32(*[_lib.BF16 if g.dtype == torch.bfloat16 else _lib.F32 for g in gsrc]))
         self._tables[key] = (ptrs, tab)
         return tab
 
@@ -163,7 +167,7 @@ class Adam(torch.optim.Optimizer):
             shadows = [VF.shadow_buffer_for_update(p) for p in chunk]
             tab = self._table(gi, chunk, shadows)
             rc = lib.vs_adam_multi(len(chunk), ctypes.cast(tab[0], ctypes.c_void_p), ctypes.cast(tab[1], ctypes.c_void_p),
-                                   ctypes.cast(tab[2], ctypes.c_void_p), ctypes.cast(tab[3], ctypes.c_void_p),
+                                   ctypes.cast(tab[7], ctypes.c_void_p), ctypes.cast(tab[2], ctypes.c_void_p), ctypes.cast(tab[3], ctypes.c_void_p),
                                    ctypes.cast(tab[4], ctypes.c_void_p), ctypes.cast(tab[5], ctypes.c_void_p),
                                    ctypes.cast(tab[6], ctypes.c_void_p), group['step_dev'].data_ptr(), lr, b1, b2, eps, stream)
             _lib.check(rc, 'vs_adam_multi')

@@ -15,7 +15,8 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, overlap=True, force=False, comm_dtype=torch.float32):
+    def __init__(self, params, bucket_bytes=64 << 20, process_group=None, overlap=True, force=False, comm_dtype=torch.float32,
+                 lowp_direct=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -30,6 +31,14 @@ class GradAllReducer:
         assert comm_dtype in (torch.float32, torch.bfloat16)
         self.comm_dtype = comm_dtype
         self._wire = {}
+        # lowp_direct (bf16 wire only): parameters whose producer can write the bf16 wire image of their gradient itself (the
+        # weight-gradient GEMMs of the Linear chains in the recorded step).  They are laid out FIRST in their bucket; while
+        # `direct_lowp` is switched on (train.GraphedStep), only the small tail of the bucket is cast to / from the wire format
+        # and the optimizer reads the averaged bf16 image of the others (`lowp_views`).
+        self._direct_ids = {id(p) for p in (lowp_direct or [])} if comm_dtype != torch.float32 else set()
+        self.lowp_views = {}          # id(param) -> bf16 view of the wire buffer
+        self._tail = {}               # flat.data_ptr() -> first element of the not-direct region
+        self.direct_lowp = False
         self._build(bucket_bytes)
         self._comm_stream = None
         self._overlap = overlap and (self.world_size > 1 or force)
@@ -48,12 +57,21 @@ class GradAllReducer:
             self._finish_bucket(cur)
 
     def _finish_bucket(self, plist):
+        plist = [p for p in plist if id(p) in self._direct_ids] + [p for p in plist if id(p) not in self._direct_ids]
         total = sum(p.numel() for p in plist)
         flat = torch.zeros(total, dtype=torch.float32, device=plist[0].device)
+        wire = torch.zeros(total, dtype=self.comm_dtype, device=plist[0].device) if self._direct_ids else None
         off = 0
+        self._tail[flat.data_ptr()] = total
         for p in plist:
             p.grad = flat[off:off + p.numel()].view_as(p)
+            if id(p) in self._direct_ids:
+                self.lowp_views[id(p)] = wire[off:off + p.numel()].view_as(p)
+            elif self._tail[flat.data_ptr()] == total:
+                self._tail[flat.data_ptr()] = off
             off += p.numel()
+        if wire is not None:
+            self._wire[flat.data_ptr()] = wire
         self.buckets.append((flat, list(plist)))
 
     def zero_grad(self):
@@ -99,14 +117,20 @@ class GradAllReducer:
             wire = self._wire.get(flat.data_ptr())
             if wire is None:
                 wire = self._wire[flat.data_ptr()] = torch.empty_like(flat, dtype=self.comm_dtype)
-            wire.copy_(flat)                                   # fp32 -> bf16 (round to nearest even)
+            # with direct_lowp the head of the bucket already IS in wire format (written by the gradient GEMMs) and is consumed
+            # in wire format: only the tail (biases, integrator parameters) is converted
+            t0 = self._tail.get(flat.data_ptr(), 0) if self.direct_lowp else 0
+            src, dst = (flat[t0:], wire[t0:]) if t0 else (flat, wire)
+            if src.numel():
+                dst.copy_(src)                                 # fp32 -> bf16 (round to nearest even)
             if self.backend == 'nccl':
                 dist.all_reduce(wire, op=dist.ReduceOp.AVG, group=self.group)
             else:                                              # gloo (tests): no bf16 reduction there -- sum the bf16 values in fp32
                 host = wire.float().cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
                 wire.copy_((host / self.world_size).to(self.comm_dtype))
-            flat.copy_(wire)
+            if src.numel():
+                src.copy_(dst)
             return
         if self.backend == 'nccl':
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)

@@ -161,6 +161,11 @@ class GraphedStep:
         check_optimizer(optimizer)
         self.net, self.opt, self.sync = sep_net, optimizer, grad_sync
         self._one = torch.ones((), dtype=torch.float32, device=cond.device)
+        if grad_sync is not None and getattr(grad_sync, 'lowp_views', None) and hasattr(optimizer, 'step_subset'):
+            # the chains' weight gradients are produced, averaged and consumed as bf16 wire images (parallel.GradAllReducer)
+            from . import functional as VF
+            grad_sync.direct_lowp = True
+            VF.set_lowp_gradients({p: grad_sync.lowp_views[id(p)] for p in grad_sync.params if id(p) in grad_sync.lowp_views})
         enable_update_in_backward(optimizer, sep_net, grad_sync)
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
         # static inputs of the recording: one [B, T, ...] buffer, cond / target are views of it (no concatenation per step)
@@ -229,7 +234,8 @@ class GraphedStep:
         from . import functional as VF
         if self.sync is not None:
             self.sync.zero_buffers()
-            VF.set_grad_outputs({p: p.grad for p in self.sync.params})
+            lowp = self.sync.lowp_views if self.sync.direct_lowp else {}
+            VF.set_grad_outputs({p: lowp.get(id(p), p.grad) for p in self.sync.params})
         else:
             self.opt.zero_grad(set_to_none=True)
         VF.enable_side_streams(self.side_streams)
@@ -264,6 +270,19 @@ class GraphedStep:
             self._reduce()
             self.graph_opt.replay()
         return self.loss
+
+
+def chain_weight_parameters(sep_net):
+    """The 2-D weights of the encoders' and the decoder's Linear chains of an MLP-family model: the parameters whose gradients
+    the recorded data-parallel step can produce directly in the reducer's wire format (GradAllReducer(lowp_direct=...))."""
+    out = []
+    if not _mlp_family(sep_net):
+        return out
+    for mod in (sep_net.Es, sep_net.Et, sep_net.decoder):
+        mlp = getattr(mod, 'mlp', None)
+        if mlp is not None:
+            out += [lin.weight for lin in mlp.linears()]
+    return out
 
 
 def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False):

@@ -63,7 +63,7 @@ def _run(net, cond, target, cfg, sync, graph, steps):
     return losses
 
 
-def _worker(rank, world, port, backend, graph, out_dir, comm='fp32'):
+def _worker(rank, world, port, backend, graph, out_dir, comm='fp32', direct=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -76,8 +76,10 @@ def _worker(rank, world, port, backend, graph, out_dir, comm='fp32'):
     shard = slice(rank * per, rank * per + per)
     net = _build(cfg, cfg['salt'] + rank)                      # ranks start different, rank 0's state wins
     broadcast_module_state(net)
+    from spatiotemporal_variable_separation_amd.train import chain_weight_parameters
     sync = GradAllReducer(net.parameters(), bucket_bytes=16 << 10, force=(world == 1),
-                          comm_dtype=torch.bfloat16 if comm == 'bf16' else torch.float32)
+                          comm_dtype=torch.bfloat16 if comm == 'bf16' else torch.float32,
+                          lowp_direct=chain_weight_parameters(net) if direct else None)
     _run(net, cond[shard].cuda().contiguous(), target[shard].cuda().contiguous(), cfg, sync, graph, 3)
     torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
@@ -122,3 +124,22 @@ def test_two_ranks_bf16_gradient_wire_format(tmp_path):
     for k, v in ref.items():
         assert torch.equal(r0[k], r1[k]), f'replicas diverged at {k}'
         assert torch.allclose(r0[k], v, rtol=5e-2, atol=2e-4), f'{k}: bf16-wire DDP step far from the single-process step'
+
+
+@pytest.mark.parametrize('world,backend', [(1, 'nccl'), (2, 'gloo')])
+def test_graphed_step_with_directly_written_wire_gradients(tmp_path, world, backend):
+    """bf16 wire + lowp_direct: the chains' weight-gradient GEMMs write the bf16 wire image themselves, the all-reduce averages it
+    in place and Adam reads it.  Same rounding point as casting the fp32 bucket, so the step must be the one of the plain bf16-wire
+    graph path (up to the float-atomic bias sums), and replicas must stay identical."""
+    a, b = tmp_path / 'direct', tmp_path / 'cast'
+    a.mkdir(), b.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), backend, True, str(a), 'bf16', True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), backend, True, str(b), 'bf16', False), nprocs=world, join=True)
+    d0, c0 = torch.load(os.path.join(a, 'rank0.pt')), torch.load(os.path.join(b, 'rank0.pt'))
+    for k, v in c0.items():
+        assert torch.allclose(d0[k], v, rtol=2e-4, atol=2e-6), f'{k}: direct wire gradients changed the step by {(d0[k] - v).abs().max().item():.3e}'
+    if world == 2:
+        d1 = torch.load(os.path.join(a, 'rank1.pt'))
+        for k in d0:
+            assert torch.equal(d0[k], d1[k]), f'replicas diverged at {k}'
+
