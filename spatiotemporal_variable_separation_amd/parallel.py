@@ -157,7 +157,11 @@ class GradAllReducer:
     def zero_buffers(self):
         """Zero the flat buckets without arming the hooks (capturable: one memset per bucket)."""
         for flat, _ in self.buckets:
-            flat.zero_()
+            # with direct_lowp the head of a bucket is never read in fp32 (its gradients are written whole, in wire format, by the
+            # producing GEMMs every step): only the tail accumulates and needs zeros
+            t0 = self._tail.get(flat.data_ptr(), 0) if self.direct_lowp else 0
+            if t0 < flat.numel():
+                (flat[t0:] if t0 else flat).zero_()
         self._pending = {}
 
     def reduce_all(self):
