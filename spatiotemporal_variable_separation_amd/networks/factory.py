@@ -11,63 +11,82 @@ def _conv():
     return conv
 
 
+# One builder per architecture name; each checks the geometry the reference's classes assume and returns the un-initialised module.
+# (conv families are imported lazily: they pull in the conv kernels.)
+def _enc_dcgan(shape, code, hidden, n_layers, nt_cond):
+    assert shape[-1] == 64
+    return _conv().DCGAN64Encoder(shape[0] * nt_cond, code, hidden)
+
+
+def _enc_vgg(shape, code, hidden, n_layers, nt_cond):
+    assert shape[-1] in [32, 64]
+    return _conv().VGG64Encoder(shape[0] * nt_cond, code, hidden, vgg32=shape[-1] == 32)
+
+
+def _enc_resnet(shape, code, hidden, n_layers, nt_cond):
+    return _conv().ResNet18(code, shape[0] * nt_cond)
+
+
+def _enc_sst(shape, code, hidden, n_layers, nt_cond):
+    return _conv().EncoderSST(shape[0] * nt_cond, code)
+
+
+def _enc_mlp(shape, code, hidden, n_layers, nt_cond):
+    return MLPEncoder(int(nt_cond * np.prod(np.array(shape))), hidden, code, n_layers)
+
+
+_ENCODERS = {'dcgan': _enc_dcgan, 'vgg': _enc_vgg, 'resnet': _enc_resnet, 'encoderSST': _enc_sst, 'mlp': _enc_mlp}
+
+
 def get_encoder(nn_type, shape, output_size, hidden_size, n_layers, nt_cond, init_type, init_gain):
-    nc = shape[0]
-    dim = shape[-1]
-    if nn_type == 'dcgan':
-        assert dim == 64
-        encoder = _conv().DCGAN64Encoder(nc * nt_cond, output_size, hidden_size)
-    elif nn_type == 'vgg':
-        assert dim in [32, 64]
-        encoder = _conv().VGG64Encoder(nc * nt_cond, output_size, hidden_size, vgg32=dim == 32)
-    elif nn_type == 'encoderSST':
-        encoder = _conv().EncoderSST(nc * nt_cond, output_size)
-    elif nn_type == 'mlp':
-        input_size = int(nt_cond * np.prod(np.array(shape)))
-        encoder = MLPEncoder(input_size, hidden_size, output_size, n_layers)
-    elif nn_type == 'resnet':
-        encoder = _conv().ResNet18(output_size, nc * nt_cond)
-    else:
+    """factory.py:25-44 of the reference: same name, arguments and geometry asserts."""
+    if nn_type not in _ENCODERS:
         raise ValueError(f'unknown encoder architecture `{nn_type}`')
+    encoder = _ENCODERS[nn_type](shape, output_size, hidden_size, n_layers, nt_cond)
     init_net(encoder, init_type=init_type, init_gain=init_gain)
     return encoder
 
 
+def _dec_dcgan(shape, zdim, act, hidden, n_layers, mixing, skipco):
+    assert shape[-1] == 64
+    return _conv().DCGAN64Decoder(shape[0], zdim, hidden, skipco, act, mixing)
+
+
+def _dec_vgg(shape, zdim, act, hidden, n_layers, mixing, skipco):
+    assert shape[-1] in [32, 64]
+    return _conv().VGG64Decoder(shape[0], zdim, hidden, skipco, act, mixing, vgg32=shape[-1] == 32)
+
+
+def _dec_mlp(shape, zdim, act, hidden, n_layers, mixing, skipco):
+    return MLPDecoder(zdim, hidden, shape, n_layers, act, mixing)
+
+
+def _dec_sst(shape, zdim, act, hidden, n_layers, mixing, skipco):
+    assert mixing == 'concat'
+    cls = _conv().DecoderSST_Skip if skipco else _conv().DecoderSST
+    return cls(zdim, shape[0], act)
+
+
+_DECODERS = {'dcgan': _dec_dcgan, 'vgg': _dec_vgg, 'mlp': _dec_mlp, 'decoderSST': _dec_sst}
+
+
 def get_decoder(nn_type, shape, code_size_t, code_size_s, last_activation, hidden_size, n_layers, mixing, skipco,
                 init_type, init_gain):
+    """factory.py:47-76 of the reference: skip connections only for the conv decoders, `mul` mixing needs equal code sizes."""
     assert not skipco or nn_type in ['dcgan', 'vgg', 'decoderSST']
     if mixing == 'mul':
         assert code_size_t == code_size_s
-        input_size = code_size_t
-    else:
-        input_size = code_size_t + code_size_s
-    nc = shape[0]
-    dim = shape[-1]
-    if nn_type == 'dcgan':
-        assert dim == 64
-        decoder = _conv().DCGAN64Decoder(nc, input_size, hidden_size, skipco, last_activation, mixing)
-    elif nn_type == 'vgg':
-        assert dim in [32, 64]
-        decoder = _conv().VGG64Decoder(nc, input_size, hidden_size, skipco, last_activation, mixing, vgg32=dim == 32)
-    elif nn_type == 'mlp':
-        decoder = MLPDecoder(input_size, hidden_size, shape, n_layers, last_activation, mixing)
-    elif nn_type == 'decoderSST':
-        assert mixing == 'concat'
-        if skipco:
-            decoder = _conv().DecoderSST_Skip(input_size, nc, last_activation)
-        else:
-            decoder = _conv().DecoderSST(input_size, nc, last_activation)
-    else:
+    zdim = code_size_t if mixing == 'mul' else code_size_t + code_size_s
+    if nn_type not in _DECODERS:
         raise ValueError(f'unknown decoder architecture `{nn_type}`')
+    decoder = _DECODERS[nn_type](shape, zdim, last_activation, hidden_size, n_layers, mixing, skipco)
     init_net(decoder, init_type=init_type, init_gain=init_gain)
     return decoder
 
 
 def get_resnet(latent_size, n_blocks, hidden_size, init_type, gain_res, fully_conv=False):
-    if fully_conv:
-        resnet = _conv().ConvResnet(latent_size, n_blocks=n_blocks, nf=hidden_size)
-    else:
-        resnet = MLPResnet(latent_size, n_blocks, hidden_size)
+    """factory.py:79-87: the latent integrator, convolutional for the SST architecture."""
+    resnet = _conv().ConvResnet(latent_size, n_blocks=n_blocks, nf=hidden_size) if fully_conv else MLPResnet(latent_size, n_blocks, hidden_size)
     init_net(resnet, init_type=init_type, init_gain=gain_res)
     return resnet
 

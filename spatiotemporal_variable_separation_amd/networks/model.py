@@ -8,16 +8,11 @@ class SeparableNetwork(nn.Module):
 
     def __init__(self, Es, Et, t_resnet, decoder, nt_cond, skipco):
         super().__init__()
-        assert isinstance(Es, nn.Module)
-        assert isinstance(Et, nn.Module)
-        assert isinstance(t_resnet, nn.Module)
-        assert isinstance(decoder, nn.Module)
-        self.Es = Es
-        self.Et = Et
-        self.decoder = decoder
-        self.t_resnet = t_resnet
-        self.nt_cond = nt_cond
-        self.skipco = skipco
+        # registration order fixes parameters() / state_dict() order: Es, Et, decoder, t_resnet as in the reference (model.py:31-38)
+        for name, module in (('Es', Es), ('Et', Et), ('decoder', decoder), ('t_resnet', t_resnet)):
+            assert isinstance(module, nn.Module), f'{name} must be an nn.Module'
+            setattr(self, name, module)
+        self.nt_cond, self.skipco = nt_cond, skipco
         self._grad = True
         self.fused = True          # additive switch: False forces the reference's per-step launch structure
 
@@ -48,19 +43,21 @@ class SeparableNetwork(nn.Module):
             if hasattr(self.t_resnet, 'rollout'):
                 t_codes, t_residuals = self.t_resnet.rollout(t_code, n_forecast)
             else:
-                codes, t_residuals = [t_code], []
-                for _ in range(1, n_forecast):
-                    t_code, t_res = self.t_resnet(t_code)
-                    codes.append(t_code)
-                    t_residuals.append(t_res)
+                codes, t_residuals = self._roll(t_code, n_forecast)
                 t_codes = torch.stack(codes, dim=1)
             forecasts = self.decoder.decode_sequence(s_code, t_codes, skip=s_skipco)
             return forecasts, t_codes, s_code, t_residuals
 
-        t_codes, forecasts, t_residuals = [t_code], [self.decoder(s_code, t_code, skip=s_skipco)], []
-        for _ in range(1, n_forecast):
-            t_code, t_res = self.t_resnet(t_code)
-            t_codes.append(t_code)
-            t_residuals.append(t_res)
-            forecasts.append(self.decoder(s_code, t_code, skip=s_skipco))
-        return torch.stack(forecasts, dim=1), torch.stack(t_codes, dim=1), s_code, t_residuals
+        # the reference's launch structure: one decoder call per code
+        codes, t_residuals = self._roll(t_code, n_forecast)
+        frames = [self.decoder(s_code, code, skip=s_skipco) for code in codes]
+        return torch.stack(frames, dim=1), torch.stack(codes, dim=1), s_code, t_residuals
+
+    def _roll(self, t_code, n_forecast):
+        """[t_0, ..., t_{n-1}] with t_{k+1} = t_resnet(t_k), and the per-step residual lists."""
+        codes, residuals = [t_code], []
+        while len(codes) < n_forecast:
+            t_code, res = self.t_resnet(t_code)
+            codes.append(t_code)
+            residuals.append(res)
+        return codes, residuals
