@@ -83,6 +83,21 @@ __device__ __forceinline__ void chan_of(int64_t i, int64_t HW, int C, int64_t gr
     }
 }
 
+// ---- planes whose size is not a multiple of the vector width (17x17, 9x9, 33x33 maps of the chairs ResNet18) ----------------------------
+// vec == 2: a plane is cut into ceil(HW / w) units of w consecutive elements; all but the last are 16-byte accesses at element
+// (not 16-byte) alignment -- global memory takes them unaligned --, the last one is a short scalar tail.  Unit u of a tensor with
+// P planes: plane = u / upp, first element = (u % upp) * w.
+__device__ __forceinline__ int ld_unit(const void* x, int xd, int64_t idx, int left, float (&v)[8]) {
+    const int w = xd == VS_F32 ? 4 : 8;
+    if (left >= w) return ld_vec(x, xd, idx, v);
+    for (int j = 0; j < left; ++j) v[j] = vs_ld(x, xd, idx + j);
+    return left;
+}
+__device__ __forceinline__ void st_unit(void* y, int yd, int64_t idx, const float (&v)[8], int cnt, int full) {
+    if (cnt == full) { st_vec(y, yd, idx, v, cnt); return; }
+    for (int j = 0; j < cnt; ++j) vs_st(y, yd, idx + j, v[j]);
+}
+
 __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, int Bg, int C, int64_t HW, float* mean, float* invstd,
                                                        float* ubvar, float eps, int vec) {
     __shared__ double red[4];
@@ -91,7 +106,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, in
     const int64_t b0 = (int64_t)g * Bg;
     // single pass, fp64 sum and sum of squares: exact enough (53-bit accumulation of fp32/bf16 data) and half the HBM traffic
     double s = 0.0, q = 0.0;
-    if (vec) {
+    if (vec == 2) {
+        const int w = xd == VS_F32 ? 4 : 8;
+        const uint32_t upp = (uint32_t)((HW + w - 1) / w), nunit = (uint32_t)Bg * upp;
+        for (uint32_t i = threadIdx.x; i < nunit; i += 256) {
+            const uint32_t b = i / upp, e0 = (i - b * upp) * w;
+            float v[8];
+            const int cnt = ld_unit(x, xd, ((b0 + b) * C + c) * HW + e0, (int)(HW - e0), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < cnt) { s += (double)v[j]; q += (double)v[j] * (double)v[j]; }
+        }
+    } else if (vec) {
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t per = HW / w;                                  // vectors per plane
         const uint32_t per32 = (uint32_t)per, nvec = (uint32_t)Bg * per32;           // < 2^31: a channel of one call group
@@ -141,6 +167,25 @@ __global__ __launch_bounds__(256) void bn_running_kernel(const float* mean, cons
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, void* y, int yd, const float* mean, const float* invstd,
                                                          const float* gamma, const float* beta, int act, int C, int64_t HW, int64_t total,
                                                          int64_t group_elems, int vec) {
+    if (vec == 2) {
+        const int w = xd == VS_F32 ? 4 : 8;
+        const uint32_t upp = (uint32_t)((HW + w - 1) / w);
+        const int64_t planes = total / HW, nunit = planes * upp;
+        const uint32_t ppg = (uint32_t)(group_elems / HW);           // planes per call group
+        for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < nunit; u += (int64_t)gridDim.x * 256) {
+            const uint32_t plane = (uint32_t)(u / upp), e0 = (uint32_t)(u - (int64_t)plane * upp) * w;
+            const int c = (int)(plane % (uint32_t)C), gc = (int)(plane / ppg) * C + c;
+            const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
+            const int64_t i = (int64_t)plane * HW + e0;
+            float v[8];
+            const int cnt = ld_unit(x, xd, i, (int)(HW - e0), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < cnt) v[j] = vs_act((v[j] - mu) * is * g + bt, act);
+            st_unit(y, yd, i, v, cnt, w);
+        }
+        return;
+    }
     if (vec) {                                                       // 16-byte chunks never straddle a (sample, channel) plane
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t nv = total / w;
@@ -176,7 +221,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int 
     const int64_t b0 = (int64_t)grp * Bg;
     const float mu = mean[grp * C + c], is = invstd[grp * C + c], g = gamma[c], bt = beta[c];
     double s1 = 0.0, s2 = 0.0;
-    if (vec && xd == dyd) {
+    if (vec == 2) {
+        const int w = xd == VS_F32 ? 4 : 8;
+        const uint32_t upp = (uint32_t)((HW + w - 1) / w), nunit = (uint32_t)Bg * upp;
+        for (uint32_t i = threadIdx.x; i < nunit; i += 256) {
+            const uint32_t b = i / upp, e0 = (i - b * upp) * w;
+            const int64_t idx = ((b0 + b) * C + c) * HW + e0;
+            float xv[8], gv[8];
+            const int cnt = ld_unit(x, xd, idx, (int)(HW - e0), xv);
+            ld_unit(dy, dyd, idx, (int)(HW - e0), gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < cnt) {
+                    const float xh = (xv[j] - mu) * is;
+                    const float dz = gv[j] * act_grad_from_pre(xh * g + bt, act);
+                    s1 += (double)dz;
+                    s2 += (double)dz * (double)xh;
+                }
+            }
+        }
+    } else if (vec && xd == dyd) {
         // one 16-byte load per tensor and thread (8 bf16 / 4 fp32 of one plane); fp32 partial sums over the vector, fp64 across
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t per = HW / w;
@@ -233,6 +297,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int d
                                                            int64_t HW, int64_t total, int training, int vec) {
     const float inv_n = 1.f / (float)((int64_t)Bg * HW);
     const int64_t group_elems = (int64_t)Bg * C * HW;
+    if (vec == 2) {
+        const int w = xd == VS_F32 ? 4 : 8;
+        const uint32_t upp = (uint32_t)((HW + w - 1) / w);
+        const int64_t planes = total / HW, nunit = planes * upp;
+        const uint32_t ppg = (uint32_t)Bg * (uint32_t)C;
+        for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < nunit; u += (int64_t)gridDim.x * 256) {
+            const uint32_t plane = (uint32_t)(u / upp), e0 = (uint32_t)(u - (int64_t)plane * upp) * w;
+            const int c = (int)(plane % (uint32_t)C), gc = (int)(plane / ppg) * C + c;
+            const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
+            const float k1 = sum_dz[gc] * inv_n, k2 = sum_dz_xhat[gc] * inv_n;
+            const int64_t i = (int64_t)plane * HW + e0;
+            float xv[8], gv[8];
+            const int cnt = ld_unit(x, xd, i, (int)(HW - e0), xv);
+            ld_unit(dy, dyd, i, (int)(HW - e0), gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < cnt) {
+                    const float xh = (xv[j] - mu) * is;
+                    const float dz = gv[j] * act_grad_from_pre(xh * g + bt, act);
+                    xv[j] = training ? g * is * (dz - k1 - xh * k2) : g * is * dz;
+                }
+            }
+            st_unit(dx, dxd, i, xv, cnt, w);
+        }
+        return;
+    }
     if (vec && xd == dyd) {                                          // 16-byte loads of both tensors, one 16-byte (or 2 x 16) store
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t nv = total / w;
@@ -425,7 +515,9 @@ extern "C" int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW,
     VS_CHECK_ARG(x && mean && invstd && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_stats: bad argument");
     VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "vs_bn_stats: running_mean/var must come together");
     VS_CHECK_ARG(!running_mean || var_scratch, "vs_bn_stats: var_scratch [groups*C] is needed to update running statistics");
-    const int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0);
+    const int w_ = x_dtype == VS_F32 ? 4 : 8;
+    int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0);
+    if (!vec && HW % w_ != 0 && HW >= w_ && (int64_t)B * C * HW < ((int64_t)1 << 31) && (uintptr_t)x % 16 == 0) vec = 2;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups), dim3(256), 0, (hipStream_t)stream, x, x_dtype, B / groups, C, HW, mean, invstd,
                        running_mean ? var_scratch : nullptr, eps, vec);
     VS_CHECK_LAUNCH("vs_bn_stats");
@@ -441,7 +533,9 @@ extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, c
                              const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream) {
     VS_CHECK_ARG(x && y && mean && invstd && gamma && beta && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_act_fwd: bad argument");
     const int64_t total = (int64_t)B * C * HW;
-    const int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    const int w_ = x_dtype == VS_F32 ? 4 : 8;
+    int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    if (!vec && HW % w_ != 0 && HW >= w_ && total < ((int64_t)1 << 31) && x_dtype == y_dtype && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0) vec = 2;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
                        gamma, beta, act, C, HW, total, (int64_t)(B / groups) * C * HW, vec);
     VS_CHECK_LAUNCH("vs_bn_act_fwd");
@@ -453,7 +547,11 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
                              int dx_dtype, int B, int C, int64_t HW, void* stream) {
     VS_CHECK_ARG(dy && x && mean && invstd && gamma && beta && dgamma && dbeta && dx && B > 0 && C > 0 && HW > 0 && groups >= 1 &&
                      B % groups == 0, "vs_bn_act_bwd: bad argument");
-    const int vec = (HW % 8 == 0);
+    const int w_ = x_dtype == VS_F32 ? 4 : 8;
+    int vec = (HW % 8 == 0);
+    if (!vec && HW % w_ != 0 && HW >= w_ && (int64_t)B * C * HW < ((int64_t)1 << 31) && x_dtype == dy_dtype && x_dtype == dx_dtype &&
+        ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0)
+        vec = 2;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd, gamma,
                        beta, act, B / groups, C, HW, dbeta, dgamma, vec);
     VS_CHECK_LAUNCH("vs_bn_act_bwd reduce");

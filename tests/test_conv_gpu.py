@@ -186,3 +186,36 @@ def test_maxpool3s2_matches_torch(dtype, shape):
     assert tuple(y.shape) == tuple(yr.shape) and torch.equal(y.cpu().double(), yr.detach())
     y.backward(dy.cuda())
     torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-2 if dtype == torch.bfloat16 else 1e-6)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape,groups', [((6, 16, 17, 17), 1), ((4, 8, 9, 9), 2), ((3, 5, 33, 33), 1), ((8, 4, 3, 3), 2), ((2, 3, 5, 5), 1)])
+def test_batchnorm_planes_not_a_multiple_of_the_vector_width(dtype, shape, groups):
+    """The 17x17 / 9x9 / 33x33 maps of the chairs ResNet18: all tensors in one dtype take the unit-per-plane vector path
+    (unaligned 16-byte accesses + a scalar tail); results against per-group fp64 BatchNorm of the same (rounded) inputs."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, C, H, W = shape
+    x = (_rand(shape, 31) * 2 + 0.3).to(dtype)
+    dy = _rand(shape, 32).to(dtype)
+    gamma, beta = 1 + _rand((C,), 33, 0.3), _rand((C,), 34, 0.2)
+    xc, dyc = x.cuda(), dy.cuda()
+    mean, invstd = ops.bn_stats(xc, groups=groups)
+    y = ops.bn_act_fwd(xc, mean, invstd, gamma.cuda(), beta.cuda(), 'leaky_relu', dtype, groups=groups)
+    dx, dg, db = ops.bn_act_bwd(dyc, xc, mean, invstd, gamma.cuda(), beta.cuda(), 'leaky_relu', True, dtype, groups=groups)
+    ys, dxs, dgs, dbs = [], [], 0, 0
+    per = B // groups
+    for g in range(groups):
+        bn = torch.nn.BatchNorm2d(C).double()
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        xg = x[g * per:(g + 1) * per].double().requires_grad_(True)
+        yg = F.leaky_relu(bn(xg), 0.2)
+        yg.backward(dy[g * per:(g + 1) * per].double())
+        ys.append(yg.detach()); dxs.append(xg.grad)
+        dgs, dbs = dgs + bn.weight.grad, dbs + bn.bias.grad
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-5          # bf16: the OUTPUTS are stored in bf16
+
+    def rel(a, b):
+        return ((a.cpu().double() - b).norm() / (b.norm() + 1e-30)).item()
+    assert rel(y, torch.cat(ys)) < tol and rel(dx, torch.cat(dxs)) < tol
+    assert rel(dg, dgs) < 2e-5 and rel(db, dbs) < 2e-5       # fp32 sums of fp64-accumulated reductions
