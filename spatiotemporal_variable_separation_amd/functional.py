@@ -54,7 +54,7 @@ def count_bn_calls(bn, calls):
     """`num_batches_tracked += calls` of a training-mode BatchNorm (one per reference call).  While gradients are folded (the
     training loop owns the step and calls `flush_bn_call_counts()` at its end) the increments are collected and applied by ONE
     multi-tensor launch per step instead of one launch per BatchNorm call (SST: ~300 per step)."""
-    if not _STATE.get('fold_grads'):
+    if not _STATE.get('fold_grads') or torch.cuda.is_current_stream_capturing():      # a recording must contain the increment
         bn.num_batches_tracked += calls
         return
     ent = _BN_COUNTS.get(id(bn))

@@ -106,7 +106,7 @@ def _build():
                    help='Wire format of the gradient all-reduce with --ddp (bf16 halves the xGMI bytes; fp32 keeps N replicas '
                         'bit-compatible with the single-process step).')
     g.add_argument('--hip_graph', action='store_true',
-                   help='MLP architectures on one GPU: record the whole training step into a hipGraph and replay it.')
+                   help='Record the whole training step into a hipGraph and replay it (every architecture; the MLP family gains most).')
     g.add_argument('--log_interval', type=int, default=None, help='Print losses and frames/s every N steps.')
     g.add_argument('--synthetic_len', type=int, default=2048, help='Sequences per epoch of the synthetic dataset.')
     return p

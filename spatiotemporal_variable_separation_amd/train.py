@@ -30,14 +30,34 @@ def ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=None):
             t_random = np.random.randint(nt_cond, full_data.size(1))
         else:
             t_random = np.random.randint(nt_cond, full_data.size(1) + 1)
-    t_code_random = sep_net.Et(full_data[:, t_random - nt_cond:t_random])
+    if isinstance(t_random, torch.Tensor):
+        # one int32 element ON THE DEVICE (GraphedStep): the window and the supervision frame are cut out by a kernel that reads it,
+        # so the step can be recorded once and replayed while the random window moves
+        window, supervision_data = _device_window(full_data, t_random, nt_cond, offset)
+    else:
+        window, supervision_data = full_data[:, t_random - nt_cond:t_random], full_data[:, t_random - offset]
+    t_code_random = sep_net.Et(window)
     if skipco:
         reconstruction = sep_net.decoder(s_code_old[0], t_code_random, skip=s_code_old[1])
     else:
         reconstruction = sep_net.decoder(s_code_old, t_code_random)
-    supervision_data = full_data[:, t_random - offset]
     loss = F.mse_loss(supervision_data, reconstruction, reduction='mean')
     return loss, s_code_new, s_code_old
+
+
+def _device_window(full_data, t_dev, nt_cond, offset):
+    """full_data[:, t - nt_cond : t] and full_data[:, t - offset] for t = t_dev[0] read on the device (train.py:72-87)."""
+    from . import ops
+    B, T = full_data.shape[0], full_data.shape[1]
+    flat = full_data.reshape(B, T, -1)
+    if not flat.is_contiguous():
+        flat = flat.contiguous()
+    D = flat.shape[2]
+    window = torch.empty((B, nt_cond * D), dtype=flat.dtype, device=flat.device)
+    ops.copy2d(flat, B, nt_cond * D, T * D, window, nt_cond * D, col_offset_dev=t_dev, col_offset_scale=D, src_elem_offset=-nt_cond * D)
+    frame = torch.empty((B, D), dtype=flat.dtype, device=flat.device)
+    ops.copy2d(flat, B, D, T * D, frame, D, col_offset_dev=t_dev, col_offset_scale=D, src_elem_offset=-offset * D)
+    return window.view((B, nt_cond) + tuple(full_data.shape[2:])), frame.view((B,) + tuple(full_data.shape[2:]))
 
 
 _frame_index_cache = {}
@@ -143,7 +163,9 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
 
 
 class GraphedStep:
-    """One whole optimisation step (losses, backward, Adam) of an MLP-family model recorded into a hipGraph and replayed.
+    """One whole optimisation step (losses, backward, Adam) recorded into a hipGraph and replayed.  MLP family: the batched step
+    with side streams; conv families: the reference's call structure (GPU-bound at the BASELINE sizes, where replaying gains
+    nothing measurable -- chairs 43.8 vs 42.7-46 ms, SST 76 vs 72-85 ms -- but independent of the host's launch rate).
 
     The step launches ~110 kernels of 2-800 us; issued one by one from Python the host needs ~3.9 ms per step, more than the
     GPU needs to execute them, so the eager loop is host-bound.  Stream capture (torch.cuda.CUDAGraph = hipGraph on ROCm)
@@ -154,14 +176,18 @@ class GraphedStep:
 
     def __init__(self, sep_net, optimizer, cond, target, nt_cond, nt_pred, offset, lambdas, average_tloss=False, warmup=3,
                  side_streams=True, grad_sync=None):
-        assert cond.is_cuda and _mlp_family(sep_net), 'GraphedStep supports the MLP family on a GPU'
+        assert cond.is_cuda, 'GraphedStep records a hipGraph: the batch must be on the GPU'
+        self.mlp = _mlp_family(sep_net)
+        self.skipco = bool(getattr(sep_net, 'skipco', False))
         # deferred weight gradients require that nothing reads a gradient before join_side_streams(); with a reducer the Linear
         # chains therefore write straight into its flat buckets (VF.set_grad_outputs) instead of going through autograd's `+=`
-        self.side_streams = side_streams and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
+        # side streams and direct gradient destinations need ONE gradient per parameter and step: true for the batched MLP-family
+        # step only (a conv family calls E_s twice, its Linear layers get two contributions)
+        self.side_streams = side_streams and self.mlp and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
         check_optimizer(optimizer)
         self.net, self.opt, self.sync = sep_net, optimizer, grad_sync
         self._one = torch.ones((), dtype=torch.float32, device=cond.device)
-        if grad_sync is not None and getattr(grad_sync, 'lowp_views', None) and hasattr(optimizer, 'step_subset'):
+        if grad_sync is not None and self.mlp and getattr(grad_sync, 'lowp_views', None) and hasattr(optimizer, 'step_subset'):
             # the chains' weight gradients are produced, averaged and consumed as bf16 wire images (parallel.GradAllReducer)
             from . import functional as VF
             grad_sync.direct_lowp = True
@@ -174,6 +200,7 @@ class GraphedStep:
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=cond.device)
         self.T = cond.shape[1] + target.shape[1]
         self.nt_cond, self.offset = nt_cond, offset
+        from .functional import flush_bn_call_counts as VF_flush
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -182,6 +209,7 @@ class GraphedStep:
                 self._fwd_bwd()
                 self._reduce()
                 self.opt.step()
+                VF_flush()
         torch.cuda.current_stream().wait_stream(side)
         self._capture()
 
@@ -234,14 +262,19 @@ class GraphedStep:
         from . import functional as VF
         if self.sync is not None:
             self.sync.zero_buffers()
-            lowp = self.sync.lowp_views if self.sync.direct_lowp else {}
-            VF.set_grad_outputs({p: lowp.get(id(p), p.grad) for p in self.sync.params})
+            if self.mlp:
+                lowp = self.sync.lowp_views if self.sync.direct_lowp else {}
+                VF.set_grad_outputs({p: lowp.get(id(p), p.grad) for p in self.sync.params})
         else:
             self.opt.zero_grad(set_to_none=True)
         VF.enable_side_streams(self.side_streams)
         try:
-            total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
-                                                         l_pred, avg, self.t_dev, full_data=self.full)
+            if self.mlp:
+                total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
+                                                             l_pred, avg, self.t_dev, full_data=self.full)
+            else:                                    # conv families: the reference's call structure with a device-side window
+                total, _, _, _ = compute_losses(self.cond, self.target, self.net, nt_cond, nt_pred, offset, self.skipco, l_ae, l_s,
+                                                l_t, l_pred, avg, t_random=self.t_dev)
             total.backward(self._one)                # a resident 1.0: no ones_like fill per step
             VF.join_side_streams()
         finally:
@@ -341,8 +374,8 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
     """Same 20 positional arguments as the reference's `train` (train.py:91-92).
 
     Additive keyword arguments: `grad_sync` (a `parallel.GradAllReducer`, data-parallel gradient averaging over
-    RCCL), `log_interval` (print losses / frames-per-second every N steps) and `hip_graph` (MLP family: record
-    the whole step once into a hipGraph -- `GraphedStep` -- and replay it; the optimizer must be Adam(capturable=True)).  `use_apex_amp` is rejected (no
+    RCCL), `log_interval` (print losses / frames-per-second every N steps) and `hip_graph` (record
+    the whole step once into a hipGraph -- `GraphedStep` -- and replay it; the optimizer must be optim.Adam or Adam(capturable=True)).  `use_apex_amp` is rejected (no
     Apex on the MI355X path); `use_torch_amp` selects the bf16 compute mode, which needs no loss scaler.
     """
     import time
@@ -366,7 +399,7 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
             sep_net.train()
             for cond, target in train_loader:
                 cond, target = cond.to(device, non_blocking=True), target.to(device, non_blocking=True)
-                if hip_graph and _mlp_family(sep_net):
+                if hip_graph:
                     if graphed is None:
                         graphed = GraphedStep(sep_net, optimizer, cond, target, nt_cond, nt_pred, offset,
                                               (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss, grad_sync=grad_sync)

@@ -155,7 +155,7 @@ def test_step_fp32_unfused_structure_matches_oracle(name):
 
 
 @pytest.mark.parametrize('side_streams', [True, False])
-def test_graphed_step_equals_eager_steps(side_streams):
+def test_graphed_step_equals_eager_steps(side_streams, name='mlp_mul'):
     """train.GraphedStep (whole step recorded into a hipGraph, device-side t_random) == the eager loop, step for step, as a
     multi-stream capture and as a single-stream one (regression: memset nodes of a single-stream capture were not replayed in
     order on ROCm 7.0 and left the bias-gradient accumulators dirty; the library now zero-fills with a kernel)."""
@@ -167,7 +167,8 @@ def test_graphed_step_equals_eager_steps(side_streams):
     from spatiotemporal_variable_separation_amd import functional as VF
     from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
     from spatiotemporal_variable_separation_amd.train import GraphedStep, compute_losses
-    cfg = CONFIGS['mlp_mul']
+    cfg = CONFIGS[name]
+    skipco = bool(cfg.get('skipco', False))
     lam = cfg['lambdas']
     cond, target = make_batch(cfg)
     cond, target = cond.cuda(), target.cuda()
@@ -189,8 +190,8 @@ def test_graphed_step_equals_eager_steps(side_streams):
             if it == 3:
                 np.random.randint(cfg['nt_cond'], hi)
             opt_e.zero_grad()
-            total = compute_losses(cond, target, net_e, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], False, lam['ae'], lam['s'],
-                                   lam['t'], lam['pred'])[0]
+            total = compute_losses(cond, target, net_e, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], skipco, lam['ae'], lam['s'],
+                                   lam['t'], lam['pred'], average_tloss=bool(cfg.get('average_tloss')))[0]
             total.backward()
             opt_e.step()
             losses_e.append(total.item())
@@ -198,12 +199,27 @@ def test_graphed_step_equals_eager_steps(side_streams):
         opt_g = torch.optim.Adam(net_g.parameters(), lr=1e-3, capturable=True)
         np.random.seed(7)
         g = GraphedStep(net_g, opt_g, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'],
-                        (lam['ae'], lam['s'], lam['t'], lam['pred']), warmup=3, side_streams=side_streams)
+                        (lam['ae'], lam['s'], lam['t'], lam['pred']), average_tloss=bool(cfg.get('average_tloss')), warmup=3,
+                        side_streams=side_streams)
         losses_g = [g.step().item() for _ in range(4)]
     torch.cuda.synchronize()
-    assert np.allclose(losses_g, losses_e[3:], rtol=2e-4), (losses_g, losses_e)
+    assert np.allclose(losses_g, losses_e[3:], rtol=2e-4 if name == 'mlp_mul' else 2e-3), (losses_g, losses_e)
     for (k, a), (_, b) in zip(net_g.state_dict().items(), net_e.state_dict().items()):
-        assert torch.allclose(a, b, rtol=2e-3, atol=2e-5), k
+        if k.endswith('num_batches_tracked'):
+            assert int(a) == int(b), k               # every replay contains the per-call counter increments
+            continue
+        # conv families: Adam turns a last-bit difference of a near-zero gradient into +-lr per step, so parameters are compared on
+        # the scale of a few learning rates (lr = 1e-3, 7 steps); the per-step losses above are the sharp statement
+        assert torch.allclose(a.float(), b.float(), rtol=2e-3 if name == 'mlp_mul' else 2e-2, atol=2e-5 if name == 'mlp_mul' else 5e-3), k
+
+
+@pytest.mark.parametrize('name', ['dcgan_tiny', 'sst_skip', 'chairs_resnet'])
+def test_graphed_step_of_conv_families_equals_eager_steps(name):
+    """The recorded step is not MLP-only: a conv family is captured with the reference's call structure, the random window and the
+    supervision frame cut out by a kernel that reads t_random on the device, per-call BatchNorm counters inside the recording.
+    Tolerances are those of two fp32 runs whose float-atomic reductions differ in the last bit (amplified by per-call BatchNorm
+    over 2-3 samples and 7 Adam steps)."""
+    test_graphed_step_equals_eager_steps(False, name)
 
 
 @pytest.mark.parametrize('name', ['sst_skip', 'dcgan_tiny', 'chairs_resnet'])
