@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
      '--code_size_s', '8', '--mixing', 'mul', '--enc_hidden_size', '64', '--dec_hidden_size', '64', '--res_hidden_size', '32',
      '--n_blocks', '2', '--precision', 'bf16', '--hip_graph'],
     ['--data', 'mnist', '--nt_cond', '2', '--nt_pred', '3', '--offset', '2', '--enc_hidden_size', '8', '--dec_hidden_size', '8',
-     '--res_hidden_size', '16', '--code_size_s', '12', '--code_size_t', '6', '--torch_amp'],
+     '--res_hidden_size', '16', '--code_size_s', '12', '--code_size_t', '6', '--torch_amp', '--hip_graph'],
     ['--data', 'taxibj', '--architecture', 'vgg', '--nt_cond', '2', '--nt_pred', '2', '--offset', '2', '--enc_hidden_size', '8',
      '--dec_hidden_size', '8', '--res_hidden_size', '16', '--code_size_s', '12', '--code_size_t', '6', '--skipco'],
     ['--data', 'chairs', '--architecture', 'resnet', '--decoder_architecture', 'dcgan', '--nt_cond', '2', '--nt_pred', '2', '--offset', '2',
