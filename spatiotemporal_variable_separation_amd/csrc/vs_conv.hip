@@ -784,12 +784,16 @@ int transposed_form(const void* src, const void* wp, const float* bias, void* ou
         return gather_gemm<CT>(src, wp, bias, out, out_dtype, M, g, OH, OW, 1, 0, 0, ws, ws_bytes, st, what);
     }
     if (!phase_ok(kh, kw, s, p)) return vs_fail(VS_ERR_UNSUPPORTED, "%s: transposed geometry k%d s%d p%d is not supported", what, kh, s, p);
-    if (kh == 4 && kw == 4 && p == 1 && M <= 2 && W % 8 == 0 && OH == 2 * H && OW == 2 * W && (uintptr_t)src % 16 == 0 &&
+    if (kh == 4 && kw == 4 && p == 1 && M <= 4 && W % 8 == 0 && OH == 2 * H && OW == 2 * W && (uintptr_t)src % 16 == 0 &&
         getenv("VS_CONVT_SMALL") == nullptr) {
         const int64_t units = (int64_t)B * H * (W / 8);
         int64_t blocks = (units + 255) / 256;
         if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL((convt_k4s2_small_kernel<CT, 2>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)src, (const T*)wp, bias, out, out_dtype,
+        if (M <= 2)
+            hipLaunchKernelGGL((convt_k4s2_small_kernel<CT, 2>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)src, (const T*)wp, bias, out,
+                               out_dtype, B, Csrc, H, W, M);
+        else            // 3-channel frames (chairs): 128 accumulators per thread, still one pass over the input
+            hipLaunchKernelGGL((convt_k4s2_small_kernel<CT, 4>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)src, (const T*)wp, bias, out, out_dtype,
                            B, Csrc, H, W, M);
         VS_CHECK_LAUNCH(what);
         return VS_OK;

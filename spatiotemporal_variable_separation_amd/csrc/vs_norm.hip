@@ -87,16 +87,30 @@ __device__ __forceinline__ void chan_of(int64_t i, int64_t HW, int C, int64_t gr
 // vec == 2: a plane is cut into ceil(HW / w) units of w consecutive elements; all but the last are 16-byte accesses at element
 // (not 16-byte) alignment -- global memory takes them unaligned --, the last one is a short scalar tail.  Unit u of a tensor with
 // P planes: plane = u / upp, first element = (u % upp) * w.
-__device__ __forceinline__ int ld_unit(const void* x, int xd, int64_t idx, int left, float (&v)[8]) {
-    const int w = xd == VS_F32 ? 4 : 8;
-    if (left >= w) return ld_vec(x, xd, idx, v);
+// w = elements per unit: 8 when every tensor of the pass is bf16, 4 as soon as one is fp32 (a 4-element bf16 access is 8 bytes)
+__device__ __forceinline__ int ld_unit(const void* x, int xd, int64_t idx, int left, int w, float (&v)[8]) {
+    if (left >= w) {
+        if (xd == VS_F32) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>((const float*)x + idx);
+            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        } else if (w == 8) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>((const __bf16*)x + idx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+        } else {
+            const bf16x4 t = *reinterpret_cast<const bf16x4*>((const __bf16*)x + idx);
+            v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+        }
+        return w;
+    }
     for (int j = 0; j < left; ++j) v[j] = vs_ld(x, xd, idx + j);
     return left;
 }
-__device__ __forceinline__ void st_unit(void* y, int yd, int64_t idx, const float (&v)[8], int cnt, int full) {
-    if (cnt == full) { st_vec(y, yd, idx, v, cnt); return; }
+__device__ __forceinline__ void st_unit(void* y, int yd, int64_t idx, const float (&v)[8], int cnt, int w) {
+    if (cnt == w) { st_vec(y, yd, idx, v, cnt); return; }
     for (int j = 0; j < cnt; ++j) vs_st(y, yd, idx + j, v[j]);
 }
+__device__ __forceinline__ int unit_width(int d0, int d1, int d2) { return (d0 == VS_F32 || d1 == VS_F32 || d2 == VS_F32) ? 4 : 8; }
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, int Bg, int C, int64_t HW, float* mean, float* invstd,
                                                        float* ubvar, float eps, int vec) {
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, in
         for (uint32_t i = threadIdx.x; i < nunit; i += 256) {
             const uint32_t b = i / upp, e0 = (i - b * upp) * w;
             float v[8];
-            const int cnt = ld_unit(x, xd, ((b0 + b) * C + c) * HW + e0, (int)(HW - e0), v);
+            const int cnt = ld_unit(x, xd, ((b0 + b) * C + c) * HW + e0, (int)(HW - e0), w, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (j < cnt) { s += (double)v[j]; q += (double)v[j] * (double)v[j]; }
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, 
                                                          const float* gamma, const float* beta, int act, int C, int64_t HW, int64_t total,
                                                          int64_t group_elems, int vec) {
     if (vec == 2) {
-        const int w = xd == VS_F32 ? 4 : 8;
+        const int w = unit_width(xd, yd, VS_BF16);
         const uint32_t upp = (uint32_t)((HW + w - 1) / w);
         const int64_t planes = total / HW, nunit = planes * upp;
         const uint32_t ppg = (uint32_t)(group_elems / HW);           // planes per call group
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, 
             const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
             const int64_t i = (int64_t)plane * HW + e0;
             float v[8];
-            const int cnt = ld_unit(x, xd, i, (int)(HW - e0), v);
+            const int cnt = ld_unit(x, xd, i, (int)(HW - e0), w, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (j < cnt) v[j] = vs_act((v[j] - mu) * is * g + bt, act);
@@ -222,14 +236,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int 
     const float mu = mean[grp * C + c], is = invstd[grp * C + c], g = gamma[c], bt = beta[c];
     double s1 = 0.0, s2 = 0.0;
     if (vec == 2) {
-        const int w = xd == VS_F32 ? 4 : 8;
+        const int w = unit_width(xd, dyd, VS_BF16);
         const uint32_t upp = (uint32_t)((HW + w - 1) / w), nunit = (uint32_t)Bg * upp;
         for (uint32_t i = threadIdx.x; i < nunit; i += 256) {
             const uint32_t b = i / upp, e0 = (i - b * upp) * w;
             const int64_t idx = ((b0 + b) * C + c) * HW + e0;
             float xv[8], gv[8];
-            const int cnt = ld_unit(x, xd, idx, (int)(HW - e0), xv);
-            ld_unit(dy, dyd, idx, (int)(HW - e0), gv);
+            const int cnt = ld_unit(x, xd, idx, (int)(HW - e0), w, xv);
+            ld_unit(dy, dyd, idx, (int)(HW - e0), w, gv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (j < cnt) {
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int d
     const float inv_n = 1.f / (float)((int64_t)Bg * HW);
     const int64_t group_elems = (int64_t)Bg * C * HW;
     if (vec == 2) {
-        const int w = xd == VS_F32 ? 4 : 8;
+        const int w = unit_width(xd, dyd, dxd);
         const uint32_t upp = (uint32_t)((HW + w - 1) / w);
         const int64_t planes = total / HW, nunit = planes * upp;
         const uint32_t ppg = (uint32_t)Bg * (uint32_t)C;
@@ -309,8 +323,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int d
             const float k1 = sum_dz[gc] * inv_n, k2 = sum_dz_xhat[gc] * inv_n;
             const int64_t i = (int64_t)plane * HW + e0;
             float xv[8], gv[8];
-            const int cnt = ld_unit(x, xd, i, (int)(HW - e0), xv);
-            ld_unit(dy, dyd, i, (int)(HW - e0), gv);
+            const int cnt = ld_unit(x, xd, i, (int)(HW - e0), w, xv);
+            ld_unit(dy, dyd, i, (int)(HW - e0), w, gv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (j < cnt) {
@@ -535,7 +549,8 @@ extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, c
     const int64_t total = (int64_t)B * C * HW;
     const int w_ = x_dtype == VS_F32 ? 4 : 8;
     int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
-    if (!vec && HW % w_ != 0 && HW >= w_ && total < ((int64_t)1 << 31) && x_dtype == y_dtype && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0) vec = 2;
+    if (!vec && HW >= 8 && total < ((int64_t)1 << 31) && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0) vec = 2;   // also mixed dtypes
+    (void)w_;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
                        gamma, beta, act, C, HW, total, (int64_t)(B / groups) * C * HW, vec);
     VS_CHECK_LAUNCH("vs_bn_act_fwd");
@@ -549,9 +564,9 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
                      B % groups == 0, "vs_bn_act_bwd: bad argument");
     const int w_ = x_dtype == VS_F32 ? 4 : 8;
     int vec = (HW % 8 == 0);
-    if (!vec && HW % w_ != 0 && HW >= w_ && (int64_t)B * C * HW < ((int64_t)1 << 31) && x_dtype == dy_dtype && x_dtype == dx_dtype &&
-        ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0)
-        vec = 2;
+    if ((!vec || x_dtype != dy_dtype) && HW >= 8 && (int64_t)B * C * HW < ((int64_t)1 << 31) && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0)
+        vec = 2;                                                         // ragged planes and / or mixed dtypes: unit-per-plane path
+    (void)w_;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd, gamma,
                        beta, act, B / groups, C, HW, dbeta, dgamma, vec);
     VS_CHECK_LAUNCH("vs_bn_act_bwd reduce");

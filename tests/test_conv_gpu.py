@@ -39,6 +39,7 @@ GEOMS = [
     (2, 16, 5, 5, 24, 1, 2, 0, False),      # 5 -> 3
     (4, 24, 3, 3, 10, 3, 1, 0, False),      # conv_out: 3x3 valid -> 1x1
     (4, 64, 33, 33, 64, 3, 2, 1, False),    # 33 -> 17 with 64 channels: the column-matrix path on odd sizes
+    (3, 8, 32, 32, 3, 4, 2, 1, True),       # DCGAN decoder last layer for 3-channel frames (chairs): one-pass kernel with 4 row slots
 ]
 
 
@@ -219,3 +220,9 @@ def test_batchnorm_planes_not_a_multiple_of_the_vector_width(dtype, shape, group
         return ((a.cpu().double() - b).norm() / (b.norm() + 1e-30)).item()
     assert rel(y, torch.cat(ys)) < tol and rel(dx, torch.cat(dxs)) < tol
     assert rel(dg, dgs) < 2e-5 and rel(db, dbs) < 2e-5       # fp32 sums of fp64-accumulated reductions
+    if dtype == torch.bfloat16:
+        # mixed dtypes (bf16 activations, fp32 gradient in / out): 4-element units
+        y32 = ops.bn_act_fwd(xc, mean, invstd, gamma.cuda(), beta.cuda(), 'leaky_relu', torch.float32, groups=groups)
+        dx32, dg32, db32 = ops.bn_act_bwd(dyc.float(), xc, mean, invstd, gamma.cuda(), beta.cuda(), 'leaky_relu', True, torch.float32, groups=groups)
+        assert rel(y32, torch.cat(ys)) < 2e-5 and rel(dx32, torch.cat(dxs)) < 2e-5
+        assert rel(dg32, dgs) < 2e-5 and rel(db32, dbs) < 2e-5
