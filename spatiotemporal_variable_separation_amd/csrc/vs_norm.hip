@@ -15,14 +15,16 @@ namespace {
 // per-channel reductions accumulate in fp64 (like ATen's CPU BatchNorm): they are HBM-bound, the adds are free, and the
 // statistics feed every element of the layer, so their rounding noise is amplified by deep BatchNorm stacks
 __device__ __forceinline__ double block_sum(double v, double* red) {
-    // 256 threads = 4 waves of 64
+    // blockDim.x = 256 or 1024 threads = 4 or 16 waves of 64; `red` holds 16 doubles
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[w];          // fixed order: reproducible
+    return t;
 }
 
 // derivative of the activation from its PRE-activation input z
@@ -112,9 +114,9 @@ __device__ __forceinline__ void st_unit(void* y, int yd, int64_t idx, const floa
 }
 __device__ __forceinline__ int unit_width(int d0, int d1, int d2) { return (d0 == VS_F32 || d1 == VS_F32 || d2 == VS_F32) ? 4 : 8; }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, int Bg, int C, int64_t HW, float* mean, float* invstd,
+__global__ __launch_bounds__(1024) void bn_stats_kernel(const void* x, int xd, int Bg, int C, int64_t HW, float* mean, float* invstd,
                                                        float* ubvar, float eps, int vec) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int c = blockIdx.x, g = blockIdx.y;
     const int64_t n = (int64_t)Bg * HW;
     const int64_t b0 = (int64_t)g * Bg;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, in
     if (vec == 2) {
         const int w = xd == VS_F32 ? 4 : 8;
         const uint32_t upp = (uint32_t)((HW + w - 1) / w), nunit = (uint32_t)Bg * upp;
-        for (uint32_t i = threadIdx.x; i < nunit; i += 256) {
+        for (uint32_t i = threadIdx.x; i < nunit; i += blockDim.x) {
             const uint32_t b = i / upp, e0 = (i - b * upp) * w;
             float v[8];
             const int cnt = ld_unit(x, xd, ((b0 + b) * C + c) * HW + e0, (int)(HW - e0), w, v);
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, in
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t per = HW / w;                                  // vectors per plane
         const uint32_t per32 = (uint32_t)per, nvec = (uint32_t)Bg * per32;           // < 2^31: a channel of one call group
-        for (uint32_t i = threadIdx.x; i < nvec; i += 256) {
+        for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) {
             const uint32_t b = i / per32, p = (i - b * per32) * w;
             float v[8];
             const int cnt = ld_vec(x, xd, ((b0 + b) * C + c) * HW + p, v);
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* x, int xd, in
                 if (j < cnt) { s += (double)v[j]; q += (double)v[j] * (double)v[j]; }
         }
     } else {
-        for (int64_t i = threadIdx.x; i < n; i += 256) {
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
             const int64_t b = i / HW, p = i - b * HW;
             const double v = (double)vs_ld(x, xd, ((b0 + b) * C + c) * HW + p);
             s += v; q += v * v;
@@ -226,10 +228,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, 
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int dyd, const void* x, int xd, const float* mean,
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const void* dy, int dyd, const void* x, int xd, const float* mean,
                                                             const float* invstd, const float* gamma, const float* beta, int act, int Bg, int C,
                                                             int64_t HW, float* sum_dz, float* sum_dz_xhat, int vec) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int c = blockIdx.x, grp = blockIdx.y;
     const int64_t n = (int64_t)Bg * HW;
     const int64_t b0 = (int64_t)grp * Bg;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int 
     if (vec == 2) {
         const int w = unit_width(xd, dyd, VS_BF16);
         const uint32_t upp = (uint32_t)((HW + w - 1) / w), nunit = (uint32_t)Bg * upp;
-        for (uint32_t i = threadIdx.x; i < nunit; i += 256) {
+        for (uint32_t i = threadIdx.x; i < nunit; i += blockDim.x) {
             const uint32_t b = i / upp, e0 = (i - b * upp) * w;
             const int64_t idx = ((b0 + b) * C + c) * HW + e0;
             float xv[8], gv[8];
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int 
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t per = HW / w;
         const uint32_t per32 = (uint32_t)per, nvec = (uint32_t)Bg * per32;
-        for (uint32_t i = threadIdx.x; i < nvec; i += 256) {
+        for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) {
             const uint32_t b = i / per32, p = (i - b * per32) * w;
             const int64_t idx = ((b0 + b) * C + c) * HW + p;
             float xv[8], gv[8];
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int 
     } else if (vec) {
         const int w = (xd == VS_F32 || dyd == VS_F32) ? 4 : 8;
         const int64_t per = HW / w;
-        for (int64_t i = threadIdx.x; i < (int64_t)Bg * per; i += 256) {
+        for (int64_t i = threadIdx.x; i < (int64_t)Bg * per; i += blockDim.x) {
             const int64_t b = i / per, p = (i - b * per) * w;
             const int64_t idx = ((b0 + b) * C + c) * HW + p;
 #pragma unroll
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const void* dy, int 
             }
         }
     } else
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
         const int64_t b = i / HW, p = i - b * HW;
         const int64_t idx = ((b0 + b) * C + c) * HW + p;
         const float xh = (vs_ld(x, xd, idx) - mu) * is;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int d
 // per-channel sum; blockIdx.y splits the (batch x pixel) extent so that few-channel tensors (the 1-channel frames of the
 // last decoder layer) still fill the chip; partial sums meet in one float atomic per workgroup
 __global__ __launch_bounds__(256) void chan_sum_kernel(const void* x, int xd, int B, int C, int64_t HW, float* out) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int c = blockIdx.x;
     const int64_t n = (int64_t)B * HW;
     const int64_t per = (n + gridDim.y - 1) / gridDim.y;
@@ -532,7 +534,10 @@ extern "C" int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW,
     const int w_ = x_dtype == VS_F32 ? 4 : 8;
     int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0);
     if (!vec && HW % w_ != 0 && HW >= w_ && (int64_t)B * C * HW < ((int64_t)1 << 31) && (uintptr_t)x % 16 == 0) vec = 2;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups), dim3(256), 0, (hipStream_t)stream, x, x_dtype, B / groups, C, HW, mean, invstd,
+    // few workgroups with a long reduction each (encoders: C x groups = 64-512): the loop is latency bound, 1024 threads keep four
+    // times as many loads in flight per workgroup
+    const unsigned nt_ = ((int64_t)C * groups <= 1024 && (int64_t)(B / groups) * HW >= 8192) ? 1024u : 256u;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups), dim3(nt_), 0, (hipStream_t)stream, x, x_dtype, B / groups, C, HW, mean, invstd,
                        running_mean ? var_scratch : nullptr, eps, vec);
     VS_CHECK_LAUNCH("vs_bn_stats");
     if (running_mean) {
@@ -567,7 +572,8 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
     if ((!vec || x_dtype != dy_dtype) && HW >= 8 && (int64_t)B * C * HW < ((int64_t)1 << 31) && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0)
         vec = 2;                                                         // ragged planes and / or mixed dtypes: unit-per-plane path
     (void)w_;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd, gamma,
+    const unsigned nt_ = ((int64_t)C * groups <= 1024 && (int64_t)(B / groups) * HW >= 8192) ? 1024u : 256u;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups), dim3(nt_), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd, gamma,
                        beta, act, B / groups, C, HW, dbeta, dgamma, vec);
     VS_CHECK_LAUNCH("vs_bn_act_bwd reduce");
     const int64_t total = (int64_t)B * C * HW;
