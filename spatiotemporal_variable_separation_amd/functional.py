@@ -40,11 +40,23 @@ def fold_repeated_gradients(flag):
     """Modules called many times per step (the integrator's convolutions: once per rollout step) produce one weight, bias, gamma
     and beta gradient PER CALL, and autograd adds each of them to `.grad` with its own 3-4 us launch (SST, 40 predicted frames:
     ~1200 such adds per step).  With this switch on, a block whose parameters already hold a gradient adds all of its
-    contributions with ONE multi-tensor launch and returns nothing to autograd for them.  Only valid without gradient hooks
+    contributions with ONE multi-tensor launch, into the tensor autograd holds as the parameter's pending gradient, and returns
+    nothing to autograd for them.  Only valid without gradient hooks
     (the bucketed all-reduce counts hook calls), so `train()` / `bench.py` turn it on for single-process runs only."""
     if not flag:
         flush_bn_call_counts()
     _STATE['fold_grads'] = bool(flag)
+
+
+_FOLD = {'task': None, 'acc': {}}
+
+
+def _fold_slots():
+    """Per backward pass: parameter id -> the gradient tensor autograd already holds for it (its first contribution)."""
+    task = torch._C._current_graph_task_id()
+    if _FOLD['task'] != task:
+        _FOLD['task'], _FOLD['acc'] = task, {}
+    return _FOLD['acc']
 
 
 _BN_COUNTS = {}
@@ -505,7 +517,8 @@ class ConvBlock(torch.autograd.Function):
             # a conv bias in front of a training-mode BatchNorm has an exactly-zero gradient (the batch mean removes it);
             # the reference returns fp32 summation noise there, we return the exact value without a reduction pass
             if has_bn and training:
-                db = None if (_STATE.get('fold_grads') and b.grad is not None) else torch.zeros_like(b)     # exactly zero: nothing to add
+                # exactly zero: nothing to add once the parameter has a pending gradient in this pass
+                db = None if (_STATE.get('fold_grads') and id(b) in _fold_slots()) else torch.zeros_like(b)
             else:
                 db = ops.chan_sum(dz)
         dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed) if w.requires_grad else None
@@ -515,17 +528,26 @@ class ConvBlock(torch.autograd.Function):
             dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
                                 cols_from_wgrad=transposed and dw is not None)
         if _STATE.get('fold_grads'):
+            # the FIRST contribution of a parameter in this backward pass goes to autograd (which keeps that very tensor as the
+            # parameter's pending gradient); later contributions of the pass are added INTO it with one multi-tensor launch per
+            # block and autograd gets nothing for them (otherwise: one add launch per parameter and contribution)
+            acc = _fold_slots()
             into, what = [], []
-            for prm, g in ((w, dw), (b, db), (ctx.gamma, dgamma), (ctx.beta, dbeta)):
-                if g is not None and prm is not None and prm.grad is not None and prm.grad.shape == g.shape and prm.grad.dtype == g.dtype:
-                    into.append(prm.grad)
+            grads = {'w': dw, 'b': db, 'gamma': dgamma, 'beta': dbeta}
+            for key, prm in (('w', w), ('b', b), ('gamma', ctx.gamma), ('beta', ctx.beta)):
+                g = grads[key]
+                if g is None or prm is None:
+                    continue
+                first = acc.get(id(prm))
+                if first is None:
+                    acc[id(prm)] = g
+                elif first.shape == g.shape and first.dtype == g.dtype:
+                    into.append(first)
                     what.append(g)
+                    grads[key] = None
             if into:
-                torch._foreach_add_(into, what)          # one launch for the block instead of one per parameter
-                dw = None if any(t is w.grad for t in into) else dw
-                db = None if b is not None and any(t is b.grad for t in into) else db
-                dgamma = None if ctx.gamma is not None and any(t is ctx.gamma.grad for t in into) else dgamma
-                dbeta = None if ctx.beta is not None and any(t is ctx.beta.grad for t in into) else dbeta
+                torch._foreach_add_(into, what)
+            dw, db, dgamma, dbeta = grads['w'], grads['b'], grads['gamma'], grads['beta']
         return dx, dw, db, dgamma, dbeta, None, None, None
 
 

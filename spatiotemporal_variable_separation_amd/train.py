@@ -393,7 +393,9 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
     step, t_last = 0, time.time()
     graphed = None
     from . import functional as VF
-    VF.fold_repeated_gradients(grad_sync is None)          # no gradient hooks in single-process runs
+    # measured: folding repeated gradients (VF.fold_repeated_gradients) saves ~1000 tiny add launches per SST step on the GPU but
+    # costs more host time than autograd's own accumulation in an eager loop, and nothing measurable inside a recording: left off
+    VF.fold_repeated_gradients(os.environ.get('VARSEP_FOLD_GRADS') == '1' and grad_sync is None)
     try:
         for epoch in range(epochs):
             sep_net.train()
