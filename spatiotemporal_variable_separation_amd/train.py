@@ -166,7 +166,13 @@ class GraphedStep:
     """One whole optimisation step (losses, backward, Adam) recorded into a hipGraph and replayed.  MLP family: the batched step
     with side streams; conv families: the reference's call structure (same-box eager -> replay: SST 72.5 -> 68.5 ms, MNIST B=16
     7.5 -> 6.1 ms; independent of the host's launch rate).
-    """
+
+    The WaveEq step launches ~110 kernels of 2-800 us; issued one by one from Python the host needs ~3.9 ms per step, more than
+    the GPU needs to execute them, so the eager loop is host-bound.  Stream capture (torch.cuda.CUDAGraph = hipGraph on ROCm)
+    records the kernels the C-ABI library launches on the capture stream together with torch's own; the only per-step host
+    inputs -- the batch and the random window end `t_random` (train.py:72-75) -- enter through static device buffers, and
+    every use of `t_random` inside the step is device-side.  The optimizer is optim.Adam (HIP, always recordable) or
+    torch.optim.Adam(capturable=True); a learning-rate change by a scheduler triggers a re-recording."""
 
     def __init__(self, sep_net, optimizer, cond, target, nt_cond, nt_pred, offset, lambdas, average_tloss=False, warmup=3,
                  side_streams=True, grad_sync=None):
