@@ -75,3 +75,26 @@ def test_main_trains_on_a_resident_wave_set(wave_dir, tmp_path):
                 '--seed', '5', '--num_workers', '1', '--log_interval', '1', '--chkpt_interval', '1'])
     for stem in ('ov_Et', 'ov_Es', 'decoder', 't_resnet'):
         assert os.path.exists(os.path.join(xp, stem + '.pt'))
+
+
+def test_device_loader_sequential_drop_last_and_external_sampler(wave_dir):
+    """Loader plumbing around the gather: sequential order, drop_last, and a caller-supplied sampler (what main() passes under
+    torchrun: a DistributedSampler over the item indices)."""
+    from torch.utils.data.distributed import DistributedSampler
+    from spatiotemporal_variable_separation_amd.data.wave_eq import DeviceBatchLoader
+    ds = _dataset(wave_dir, 'full', True)
+    n = len(ds)
+    seq = list(DeviceBatchLoader(ds, 4, shuffle=False))
+    assert len(seq) == (n + 3) // 4 and sum(c.shape[0] for c, _ in seq) == n
+    want_c, want_t = ds.batch(list(range(n)))
+    assert torch.equal(torch.cat([c for c, _ in seq]), want_c) and torch.equal(torch.cat([t for _, t in seq]), want_t)
+    dropped = DeviceBatchLoader(ds, 4, shuffle=False, drop_last=True)
+    assert len(dropped) == n // 4 and all(c.shape[0] == 4 for c, _ in dropped)
+    parts = []
+    for rank in range(2):
+        sampler = DistributedSampler(ds, num_replicas=2, rank=rank, shuffle=True, seed=11)
+        items = list(sampler)
+        got = torch.cat([c for c, _ in DeviceBatchLoader(ds, 3, sampler=sampler)])
+        assert torch.equal(got, ds.batch(items)[0])
+        parts.append(set(items))
+    assert parts[0] | parts[1] == set(range(n))              # the two ranks cover the set between them
