@@ -108,13 +108,15 @@ class BaseEncoder(nn.Module):
         super().__init__()
         self.nh = nh
 
-    def forward(self, x, return_skip=False):
+    call_groups = True          # forward(..., groups=g): dim 0 holds g reference calls, every BatchNorm keeps per-call statistics
+
+    def forward(self, x, return_skip=False, groups=1):
         h = _fold_time(x)
         skips = []
         for layer in self.conv:
-            h = run_layers(layer, h)
+            h = run_layers(layer, h, groups=groups)
             skips.append(h)
-        h = run_layers(self.last_op, h, final_fp32=True).view(-1, self.nh)
+        h = run_layers(self.last_op, h, final_fp32=True, groups=groups).view(-1, self.nh)
         if return_skip:
             return h, skips[::-1]
         return h
@@ -241,11 +243,13 @@ class EncoderSST(nn.Module):
         self.conv3 = nn.Sequential(_pool(), _c3(128, 256), _c3(256, 256), _c3(256, 256))
         self.conv4 = nn.Sequential(_c3(256, 512), _c3(512, out_c), _c3(out_c, out_c, activation='none', bn=False))
 
-    def forward(self, x, return_skip=False):
-        h1 = run_layers(self.conv1, _fold_time(x))
-        h2 = run_layers(self.conv2, h1)
-        h3 = run_layers(self.conv3, h2)
-        h4 = run_layers(self.conv4, h3, final_fp32=True)
+    call_groups = True
+
+    def forward(self, x, return_skip=False, groups=1):
+        h1 = run_layers(self.conv1, _fold_time(x), groups=groups)
+        h2 = run_layers(self.conv2, h1, groups=groups)
+        h3 = run_layers(self.conv3, h2, groups=groups)
+        h4 = run_layers(self.conv4, h3, final_fp32=True, groups=groups)
         if return_skip:
             return h4, [h3, h2, h1]
         return h4
@@ -349,10 +353,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out = run_layers(nn.Sequential(self.conv1, self.bn1, self.relu), x)
-        out = run_layers(nn.Sequential(self.conv2, self.bn2), out)
-        residual = run_layers(self.downsample, x) if self.downsample is not None else x
+    def forward(self, x, groups=1):
+        out = run_layers(nn.Sequential(self.conv1, self.bn1, self.relu), x, groups=groups)
+        out = run_layers(nn.Sequential(self.conv2, self.bn2), out, groups=groups)
+        residual = run_layers(self.downsample, x, groups=groups) if self.downsample is not None else x
         if residual.dtype != out.dtype:
             residual = residual.to(out.dtype)
         return VF.Activation.apply(out + residual, 'relu')
@@ -387,13 +391,15 @@ class ResNet18(nn.Module):
         layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
-    def forward(self, x, return_skip=False):
+    call_groups = True
+
+    def forward(self, x, return_skip=False, groups=1):
         h = x.reshape(x.size(0), -1, x.size(3), x.size(4))
-        h = run_layers(nn.Sequential(self.conv1, self.bn1, self.relu), h)
+        h = run_layers(nn.Sequential(self.conv1, self.bn1, self.relu), h, groups=groups)
         h = VF.MaxPool3s2.apply(h)
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             for block in stage:
-                h = block(h)
+                h = block(h, groups=groups)
         h = run_layers(nn.Sequential(self.conv_out), h, final_act=activation_name(self.out_function), final_fp32=True)
         return h.reshape(len(h), -1)
 

@@ -45,6 +45,22 @@ def ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=None):
     return loss, s_code_new, s_code_old
 
 
+def _encode_pair(enc, xa, xb, return_skip):
+    """enc(xa), enc(xb) as one batch of two call groups (`forward(..., groups=2)`); outputs split with unbind (one stack kernel in
+    backward)."""
+    B = xa.shape[0]
+    out = enc(torch.cat([xa, xb], dim=0), return_skip=return_skip, groups=2)
+
+    def halves(t):
+        return t.view((2, B) + tuple(t.shape[1:])).unbind(0)
+    if return_skip:
+        code, skips = out
+        ca, cb = halves(code)
+        sk = [halves(sx) for sx in skips]
+        return (ca, [p[0] for p in sk]), (cb, [p[1] for p in sk])
+    return halves(out)
+
+
 def _device_window(full_data, t_dev, nt_cond, offset):
     """full_data[:, t - nt_cond : t] and full_data[:, t - offset] for t = t_dev[0] read on the device (train.py:72-87)."""
     from . import ops
@@ -353,10 +369,33 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
     if cond.is_cuda and _mlp_family(sep_net):
         return _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset, lamb_ae, lamb_s, lamb_t,
                                            lamb_pred, average_tloss, t_random)
-    ae_loss_value, s_recent, s_old = ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=t_random)
-    spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
     full_data = torch.cat([cond, target], dim=1)
-    forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_s_code=s_old)
+    pairs = (cond.is_cuda and getattr(sep_net, 'fused', False) and getattr(sep_net.Es, 'call_groups', False)
+             and getattr(sep_net.Et, 'call_groups', False) and os.environ.get('VARSEP_ENCODER_PAIRS', '1') == '1')
+    if pairs:
+        # the reference calls each encoder twice per step (E_s on the first and the last window, E_t on the random and the
+        # conditioning window): run each pair as ONE batch of two call groups -- every BatchNorm keeps per-call statistics and
+        # folds its running estimates in call order, so the arithmetic is the reference's; half the launches, twice the GEMM width
+        if t_random is None:
+            T = full_data.size(1)
+            t_random = np.random.randint(nt_cond, T) if offset == 0 else np.random.randint(nt_cond, T + 1)
+        if isinstance(t_random, torch.Tensor):
+            window, supervision_data = _device_window(full_data, t_random, nt_cond, offset)
+        else:
+            window, supervision_data = full_data[:, t_random - nt_cond:t_random], full_data[:, t_random - offset]
+        s_old, s_recent = _encode_pair(sep_net.Es, full_data[:, :nt_cond], full_data[:, -nt_cond:], skipco)
+        t_rand, t_cond = _encode_pair(sep_net.Et, window, cond, False)
+        if skipco:
+            reconstruction = sep_net.decoder(s_old[0], t_rand, skip=s_old[1])
+        else:
+            reconstruction = sep_net.decoder(s_old, t_rand)
+        ae_loss_value = F.mse_loss(supervision_data, reconstruction, reduction='mean')
+        spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
+        forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_t_code=t_cond, init_s_code=s_old)
+    else:
+        ae_loss_value, s_recent, s_old = ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=t_random)
+        spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
+        forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_s_code=s_old)
     forecast_offset = nt_cond if offset == 0 else 0
     forecast_loss = F.mse_loss(forecasts, full_data[:, forecast_offset:])
     if average_tloss:

@@ -210,7 +210,9 @@ def test_graphed_step_equals_eager_steps(side_streams, name='mlp_mul'):
             continue
         # conv families: Adam turns a last-bit difference of a near-zero gradient into +-lr per step, so parameters are compared on
         # the scale of a few learning rates (lr = 1e-3, 7 steps); the per-step losses above are the sharp statement
-        assert torch.allclose(a.float(), b.float(), rtol=2e-3 if name == 'mlp_mul' else 2e-2, atol=2e-5 if name == 'mlp_mul' else 5e-3), k
+        stat = k.endswith('running_mean') or k.endswith('running_var')   # activations downstream of the parameter noise: looser still
+        assert torch.allclose(a.float(), b.float(), rtol=2e-3 if name == 'mlp_mul' else (1e-1 if stat else 2e-2),
+                              atol=2e-5 if name == 'mlp_mul' else (5e-2 if stat else 5e-3)), k
 
 
 @pytest.mark.parametrize('name', ['dcgan_tiny', 'sst_skip', 'chairs_resnet'])
