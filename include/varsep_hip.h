@@ -15,9 +15,10 @@
  *   - return value: VS_OK (0) or a negative VS_ERR_* code; nothing throws; vs_last_error() returns a
  *     static description of the most recent failure on the calling thread;
  *   - matrices are row-major; tensors are NCHW contiguous unless a leading dimension is given;
- *   - dtype codes: VS_F32 = 0, VS_BF16 = 1.  "Compute type" selects the MFMA family: VS_F32 runs the
+ *   - dtype codes: VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2.  "Compute type" selects the MFMA family: VS_F32 runs the
  *     exact-fp32 v_mfma_f32_32x32x2_f32 path (parity mode, <=1e-3 vs the fp32 CPU oracle is met with
- *     orders of magnitude to spare), VS_BF16 runs v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+ *     orders of magnitude to spare), VS_BF16 / VS_F16 run v_mfma_f32_32x32x16_{bf16,f16} with fp32
+ *     accumulation.  Wherever a signature says VS_F32|VS_BF16 for a storage dtype, VS_F16 is accepted too.
  */
 #ifndef VARSEP_HIP_H
 #define VARSEP_HIP_H
@@ -37,6 +38,7 @@ extern "C" {
 
 #define VS_F32 0
 #define VS_BF16 1
+#define VS_F16 2 /* IEEE half: the operand type of the reference's --torch_amp (torch.cuda.amp autocast, train.py:96-97) */
 
 /* activation codes (networks/utils.py:50-72 activation_factory) */
 #define VS_ACT_NONE 0
@@ -133,12 +135,21 @@ int vs_gather_windows(const float* data, int64_t n_seq, int64_t nt, int64_t fram
                       int windows_per_seq, int seq_len, const int32_t* pixel_idx, int n_pixels, void* out, int out_dtype,
                       void* stream);
 
+/* One batch of Moving-MNIST training sequences rendered on the device (reference: data/moving_mnist.py:112-175 `__getitem__` +
+ * `_compute_trajectory`, :177-255 `_process_collision`, deterministic mode as main.py:81-82 constructs it).
+ * digits [n_digits_total, digit_h, digit_w] uint8 in HBM; init [batch, num_digits, 5] int32 = (digit index, start row, start column,
+ * row speed, column speed) per digit, i.e. the five np.random.randint draws of the reference in its order; out [batch, seq_len, 1,
+ * frame, frame] (fp32 or a 16-bit type): digits added at their bounced positions, clipped at 255, divided by 255.
+ * Trajectories are computed in IEEE double, operation for operation as the reference does in Python floats: bit-identical frames. */
+int vs_moving_mnist_batch(const uint8_t* digits, int64_t n_digits_total, int digit_h, int digit_w, const int32_t* init, int batch,
+                          int num_digits, int seq_len, int frame_size, void* out, int out_dtype, void* stream);
+
 /* Decoder input of the auto-encoding pair and of every rollout step in one launch (mlp_encdec.py:43-48 mixing applied at
  * model.py:74-83): z [B, 1+n, Cz] = mix(s [B, Cs], [t_rand [B, Ct] ; t_codes [B, n, Ct]]), mixing 0 = concat (Cz = Cs + Ct),
  * 1 = mul (Cz = Cs = Ct); out fp32, out_bf16 (may be NULL) the same values rounded for the decoder's first bf16 GEMM.
  * bwd: dz [B, 1+n, Cz] fp32 -> ds [B, Cs] (summed over the frames), dt_rand [B, Ct], dt_codes [B, n, Ct].                   */
 int vs_mix_codes_fwd(const float* s, const float* t_rand, const float* t_codes, int64_t B, int n, int Cs, int Ct, int mixing, float* out,
-                     void* out_bf16, void* stream);
+                     void* out_lowp, int lowp_dtype, void* stream);
 int vs_mix_codes_bwd(const float* dz, const float* s, const float* t_rand, const float* t_codes, int64_t B, int n, int Cs, int Ct,
                      int mixing, float* ds, float* dt_rand, float* dt_codes, void* stream);
 
@@ -175,6 +186,24 @@ int vs_adam_multi(int n_tensors, float* const* params, const void* const* grads,
                   float* const* exp_avg_sq, void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step,
                   double lr, double beta1, double beta2, double eps, void* stream);
 int vs_adam_step_increment(int32_t* step, void* stream);
+
+/* fp16 training with dynamic loss scaling (reference: train.py:96-97 `scaler = torch.cuda.amp.GradScaler()`, train.py:151-155
+ * `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()` under --torch_amp), kept on the device so that the
+ * whole step stays recordable into a hipGraph.  `scale_state` is 4 fp32 words on the device:
+ *   [0] loss scale S, [1] found_inf of the current step, [2] growth tracker (clean steps since the last change), [3] steps skipped.
+ * vs_check_finite_multi : found_inf[0] = 1 if any element of any listed gradient (fp32 or 16-bit) is inf / NaN   (GradScaler.unscale_'s check)
+ * vs_adam_multi_scaled  : vs_adam_multi with gradients read as g / S and the whole update suppressed when found_inf is set;
+ *                         shadow copies are written as `shadow_dtype` (VS_BF16 | VS_F16).  scale_state NULL = plain vs_adam_multi.
+ * vs_adam_step_increment_scaled : the step count does not advance on a skipped step.
+ * vs_loss_scale_update  : GradScaler.update(): S *= backoff and tracker = 0 on overflow, else tracker += 1 and S *= growth every
+ *                         `growth_interval` clean steps; clears found_inf.                                                        */
+int vs_check_finite_multi(int n_tensors, const void* const* grads, const int32_t* grad_dtype, const int64_t* numel, float* found_inf,
+                          void* stream);
+int vs_adam_multi_scaled(int n_tensors, float* const* params, const void* const* grads, const int32_t* grad_dtype, float* const* exp_avg,
+                         float* const* exp_avg_sq, void* const* shadow, int shadow_dtype, const int64_t* numel, const int32_t* skipped,
+                         int32_t* step, double lr, double beta1, double beta2, double eps, const float* scale_state, void* stream);
+int vs_adam_step_increment_scaled(int32_t* step, const float* scale_state, void* stream);
+int vs_loss_scale_update(float* scale_state, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
 /* Fused frame losses (train.py:85-86 ae_loss MSE and train.py:139 forecast MSE in one pass over the decoded frames).
  * frames [B, G, D] fp32: per sample the auto-encoding reconstruction (g = 0) followed by the G-1 forecasts; full [B, T, D]

@@ -67,5 +67,5 @@ def checksum(t):
     """(sum, L2, 16 strided samples) of a tensor in float64 -- pins tensors too large to commit."""
     f = t.detach().double().flatten()
     n = f.numel()
-    pick = torch.linspace(0, n - 1, 16).long() if n > 16 else torch.arange(n)
+    pick = torch.linspace(0, n - 1, 16).long().clamp_(max=n - 1) if n > 16 else torch.arange(n)    # fp32 linspace can round n-1 up
     return np.concatenate([[f.sum().item(), f.norm().item()], f[pick].numpy()]).astype(np.float64)

@@ -62,6 +62,32 @@ CONFIGS = {
 }
 
 
+# The five BASELINE.json configurations at FULL width and batch (README recipes; same dictionaries as the product's
+# configs.BASELINE_CONFIGS, restated here because test infrastructure does not import the product).  Their tensors are far above
+# FULL_LIMIT, so the fixtures `tests/golden/full_<name>.npz` hold checksums (sum, L2, 16 samples) of forecasts, codes, every
+# gradient and every post-Adam parameter of ONE reference training step.
+FULL_CONFIGS = {
+    'full_mnist_b16': dict(architecture='dcgan', shape=[1, 64, 64], nt_cond=5, nt_pred=10, offset=5, B=16, code_size_s=128,
+                           code_size_t=20, enc_hidden_size=64, dec_hidden_size=64, res_hidden_size=512, n_blocks=1,
+                           mixing='concat', last_activation='sigmoid', skipco=False, lambdas=_L, salt=31),
+    'full_waveeq': dict(architecture='mlp', shape=[1, 64, 64], nt_cond=5, nt_pred=20, offset=5, B=128, code_size_s=32,
+                        code_size_t=32, enc_hidden_size=1200, dec_hidden_size=1200, enc_n_layers=3, dec_n_layers=4,
+                        res_hidden_size=512, n_blocks=3, mixing='mul', last_activation='sigmoid', skipco=False,
+                        lambdas=dict(ae=1.0, s=45.0, t=0.001, pred=45.0), salt=32),
+    'full_mnist_b128': dict(architecture='dcgan', shape=[1, 64, 64], nt_cond=5, nt_pred=10, offset=5, B=128, code_size_s=128,
+                            code_size_t=20, enc_hidden_size=64, dec_hidden_size=64, res_hidden_size=512, n_blocks=1,
+                            mixing='concat', last_activation='sigmoid', skipco=False, lambdas=_L, salt=33),
+    'full_taxibj': dict(architecture='vgg', shape=[2, 32, 32], nt_cond=4, nt_pred=4, offset=4, B=100, code_size_s=128,
+                        code_size_t=20, enc_hidden_size=64, dec_hidden_size=64, res_hidden_size=512, n_blocks=1,
+                        mixing='concat', last_activation=None, skipco=False,
+                        lambdas=dict(ae=45.0, s=0.0001, t=0.001, pred=45.0), salt=34),
+    'full_sst': dict(architecture='encoderSST', decoder_architecture='decoderSST', shape=[1, 64, 64], nt_cond=4, nt_pred=40,
+                     offset=0, B=8, code_size_s=196, code_size_t=64, enc_hidden_size=64, dec_hidden_size=64,
+                     res_hidden_size=512, n_blocks=2, mixing='concat', last_activation=None, skipco=True, average_tloss=True,
+                     data_range='normal', lambdas=dict(ae=1.0, s=100.0, t=5e-6, pred=45.0), salt=35),
+}
+
+
 def make_batch(cfg):
     """(cond, target) of the dataset's shape: U[0,1) frames, or roughly z-scored (U-0.5)*3 for SST."""
     B, shape = cfg['B'], list(cfg['shape'])

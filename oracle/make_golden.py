@@ -3,6 +3,7 @@
 TEST INFRASTRUCTURE ONLY.  Runs in the build container (the reference never travels to the GPU box):
 
     python -m oracle.make_golden            # writes tests/golden/<config>.npz, prints a summary
+    python -m oracle.make_golden full       # additionally the five BASELINE configurations at full size (checksum fixtures)
 
 For every config in `oracle.golden_configs.CONFIGS` the script
   1. builds the four networks with the reference's own factories and fills them with the RNG-free
@@ -32,7 +33,7 @@ if ROOT not in sys.path:
 
 from oracle import cpu_ref                                    # noqa: E402
 from oracle.detdata import det_fill, det_uniform, checksum    # noqa: E402
-from oracle.golden_configs import CONFIGS, make_batch, FULL_LIMIT   # noqa: E402
+from oracle.golden_configs import CONFIGS, FULL_CONFIGS, make_batch, FULL_LIMIT   # noqa: E402
 
 
 def _reference_modules():
@@ -181,6 +182,10 @@ def main():
         if only and name not in only:
             continue
         run_config(name, cfg, mods)
+    # the BASELINE configurations at full size (minutes of CPU time): only when asked for by name, or with `full`
+    for name, cfg in FULL_CONFIGS.items():
+        if name in only or 'full' in only:
+            run_config(name, cfg, mods)
 
 
 if __name__ == '__main__':

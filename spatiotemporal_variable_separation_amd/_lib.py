@@ -14,9 +14,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvarsep_hip.so')
-SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip']
+SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip']
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 ACT = {'none': 0, None: 0, 'identity': 0, 'relu': 1, 'leaky_relu': 2, 'sigmoid': 3, 'tanh': 4, 'elu': 5}
 LAYOUT_R, LAYOUT_S = 0, 1
 
@@ -31,13 +32,17 @@ def _sources():
     return [os.path.join(_CSRC, s) for s in SOURCES if os.path.exists(os.path.join(_CSRC, s))]
 
 
+def _headers():
+    """Every header a source may include: all of csrc/*.h plus the public C-ABI header."""
+    import glob
+    return sorted(glob.glob(os.path.join(_CSRC, '*.h'))) + [os.path.join(_HERE, '..', 'include', 'varsep_hip.h')]
+
+
 def library_is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = _sources() + [os.path.join(_CSRC, 'vs_common.h'), os.path.join(_CSRC, 'vs_gemm_core.h'),
-                         os.path.join(_HERE, '..', 'include', 'varsep_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return any(os.path.getmtime(d) > t for d in _sources() + _headers())
 
 
 def build_library(force=False, verbose=False):
@@ -52,9 +57,7 @@ def build_library(force=False, verbose=False):
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + '.o')
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                os.path.getmtime(src), os.path.getmtime(os.path.join(_CSRC, 'vs_common.h')),
-                os.path.getmtime(os.path.join(_CSRC, 'vs_gemm_core.h')),
-                os.path.getmtime(os.path.join(_HERE, '..', 'include', 'varsep_hip.h'))):
+                [os.path.getmtime(src)] + [os.path.getmtime(h) for h in _headers()]):
             return obj
         cmd = [hipcc] + flags + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -90,14 +93,20 @@ SIGNATURES = {
     'vs_adam_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                              ctypes.c_double, _vp]),
     'vs_adam_step_increment': (_i32, [_vp, _vp]),
+    'vs_check_finite_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp]),
+    'vs_adam_multi_scaled': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                    ctypes.c_double, _vp, _vp]),
+    'vs_adam_step_increment_scaled': (_i32, [_vp, _vp, _vp]),
+    'vs_loss_scale_update': (_i32, [_vp, _f32, _f32, _i32, _vp]),
     'vs_gemm_batched_workspace_bytes': (_sz, [_i32, _i64, _i64, _i64]),
     'vs_gemm_batched': (_i32, [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _f32, _i32,
                                _vp, _sz, _vp]),
     'vs_train_losses_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     'vs_train_losses_bwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _i32, _vp, _i32, _vp]),
+    'vs_moving_mnist_batch': (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     'vs_gather_windows': (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
-    'vs_mix_codes_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'vs_mix_codes_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     'vs_mix_codes_bwd': (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     'vs_pack_rollout_weights': (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'vs_frames_sse_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp]),
@@ -162,7 +171,17 @@ def dtype_code(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise VarsepHipError('unsupported tensor dtype %s' % t.dtype)
+
+
+def code_of(dtype):
+    """dtype code of a torch dtype (F32 | BF16 | F16)."""
+    for code, dt in TORCH_DTYPE.items():
+        if dt == dtype:
+            return code
+    raise VarsepHipError('unsupported dtype %s' % dtype)
 
 
 def stream_ptr():

@@ -13,6 +13,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
 #define VS_WAVE 64
 
@@ -46,13 +50,32 @@ static inline hipError_t vs_zero_async(void* ptr, size_t bytes, hipStream_t stre
     return hipGetLastError();
 }
 
+// ---- 16-bit storage types: VS_BF16 and VS_F16 share every data-movement path; only the conversions differ -----------------
+__host__ __device__ __forceinline__ constexpr bool vs_is16(int dtype) { return dtype == VS_BF16 || dtype == VS_F16; }
+__host__ __device__ __forceinline__ constexpr bool vs_dtype_ok(int dtype) { return dtype == VS_F32 || dtype == VS_BF16 || dtype == VS_F16; }
+__host__ __device__ __forceinline__ constexpr int vs_esize(int dtype) { return dtype == VS_F32 ? 4 : 2; }
+
+// bits of a 16-bit element -> float / float -> bits (round to nearest even; a NaN stays a NaN: plain casts, see the guide)
+__device__ __forceinline__ float vs_h2f(unsigned short b, int dtype) {
+    if (dtype == VS_BF16) return __uint_as_float((unsigned)b << 16);
+    _Float16 h;
+    __builtin_memcpy(&h, &b, 2);
+    return (float)h;
+}
+__device__ __forceinline__ unsigned short vs_f2h(float v, int dtype) {
+    unsigned short b;
+    if (dtype == VS_BF16) { const __bf16 h = (__bf16)v; __builtin_memcpy(&b, &h, 2); }
+    else { const _Float16 h = (_Float16)v; __builtin_memcpy(&b, &h, 2); }
+    return b;
+}
+
 // ---- scalar load/store with dtype dispatch (dtype is wave-uniform) -------------------------------
 __device__ __forceinline__ float vs_ld(const void* p, int dtype, int64_t i) {
-    return dtype == VS_F32 ? ((const float*)p)[i] : (float)((const __bf16*)p)[i];
+    return dtype == VS_F32 ? ((const float*)p)[i] : vs_h2f(((const unsigned short*)p)[i], dtype);
 }
 __device__ __forceinline__ void vs_st(void* p, int dtype, int64_t i, float v) {
     if (dtype == VS_F32) ((float*)p)[i] = v;
-    else ((__bf16*)p)[i] = (__bf16)v;
+    else ((unsigned short*)p)[i] = vs_f2h(v, dtype);
 }
 
 // ---- activations (networks/utils.py:50-72) ---------------------------------------------------------

@@ -260,11 +260,11 @@ template <int CT, class OpA, class OpB>
 int run(const OpA& a, const OpB& b, int64_t M, int64_t N, int64_t K, const Epi& epi, void* ws, size_t ws_bytes, hipStream_t stream,
         const char* what) {
     typedef typename CTraits<CT>::T T;
-    constexpr int BK = CT == VS_BF16 ? 64 : 16;
+    constexpr int BK = CT != VS_F32 ? 64 : 16;
     Plan plan = make_plan(CT, M, N, K);
     constexpr bool both_dense = std::is_same<OpA, Dense<CT, OpA::layout>>::value && std::is_same<OpB, Dense<CT, OpB::layout>>::value;
     if (!both_dense && plan.bm == 128 && plan.bn == 128) plan.bn = 64;   // gather operands are register hungry: 128x128 drops to 2 waves/SIMD
-    if ((!both_dense || CT != VS_BF16) && plan.bm == 64 && plan.bn == 128) plan.bn = 64;
+    if ((!both_dense || CT == VS_F32) && plan.bm == 64 && plan.bn == 128) plan.bn = 64;
     float* slabs = nullptr;
     if (plan.splits > 1) {
         const size_t need = (size_t)plan.splits * (size_t)M * (size_t)N * sizeof(float);
@@ -285,7 +285,7 @@ int run(const OpA& a, const OpB& b, int64_t M, int64_t N, int64_t K, const Epi& 
     }
     if (plan.bm == 128 && plan.bn == 128) VS_LAUNCH(128, 128)
     else if (plan.bm == 128) VS_LAUNCH(128, 64)
-    else if (plan.bn == 128) { if constexpr (both_dense && CT == VS_BF16) VS_LAUNCH(64, 128) }
+    else if (plan.bn == 128) { if constexpr (both_dense && CT != VS_F32) VS_LAUNCH(64, 128) }
     else VS_LAUNCH(64, 64)
 #undef VS_LAUNCH
     VS_CHECK_LAUNCH(what);
@@ -309,7 +309,7 @@ inline Epi rowmajor_epi(void* out, int64_t ldc) {
 
 int check_conv(const char* what, int compute, const void* a, const void* b, const void* c, int B, int Cin, int H, int W, int Cout,
                int kh, int kw, int stride, int pad) {
-    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "%s: compute type %d", what, compute);
+    VS_CHECK_ARG(vs_dtype_ok(compute), "%s: compute type %d", what, compute);
     VS_CHECK_ARG(a && b && c, "%s: null pointer", what);
     VS_CHECK_ARG(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "%s: bad geometry", what);
     VS_CHECK_ARG(kh * kw <= MAXTAP, "%s: kernel %dx%d has more than %d taps", what, kh, kw, MAXTAP);
@@ -411,21 +411,23 @@ __global__ __launch_bounds__(256) void im2col_kernel(TapGather<CT> gth, typename
 // of ALL taps from at most three source rows, each fetched once as (left neighbour, aligned 16-byte unit, right neighbour) --
 // nine independent loads, no per-tap address math, shifts by v_alignbyte.  The generic kernel above spends one dependent,
 // branchy gather per (tap, unit) and reaches ~1 TB/s of column-matrix writes; this form is bound by the writes.
-__global__ __launch_bounds__(256) void im2col_s1_bf16_kernel(TapGather<VS_BF16> gth, __bf16* cols, int64_t ld, int64_t units_per_c) {
+template <int CT>
+__global__ __launch_bounds__(256) void im2col_s1_bf16_kernel(TapGather<CT> gth, typename CTraits<CT>::T* cols, int64_t ld, int64_t units_per_c) {
+    typedef typename CTraits<CT>::T __bf16_t;
     const TapGeo& g = gth.g;
     const int c = blockIdx.y, ntap = g.ntap, W = g.W, H = g.H;
     for (int64_t pu = (int64_t)blockIdx.x * 256 + threadIdx.x; pu < units_per_c; pu += (int64_t)gridDim.x * 256) {
         const int64_t pix0 = pu * 8;
         int b, gy, gx;
         g.split_pix(pix0, b, gy, gx);
-        const __bf16* plane = gth.src + ((int64_t)b * g.C + c) * H * W;
+        const __bf16_t* plane = gth.src + ((int64_t)b * g.C + c) * H * W;
         u32x4 u[3];
         unsigned l[3], r[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {                                   // source rows gy - 1, gy, gy + 1
             const int iy = gy + d - 1;
             const bool ok = iy >= 0 && iy < H;
-            const __bf16* row = plane + (int64_t)(ok ? iy : gy) * W + gx;
+            const __bf16_t* row = plane + (int64_t)(ok ? iy : gy) * W + gx;
             const u32x4 v = *reinterpret_cast<const u32x4*>(row);
             const unsigned short lv = *reinterpret_cast<const unsigned short*>(row + (gx > 0 ? -1 : 0));
             const unsigned short rv = *reinterpret_cast<const unsigned short*>(row + (gx + 8 < W ? 8 : 7));
@@ -461,20 +463,22 @@ __global__ __launch_bounds__(256) void im2col_s1_bf16_kernel(TapGather<VS_BF16> 
 // 16 taps from the four source rows 2 gy - 1 .. 2 gy + 2, each fetched once as (left neighbour, two aligned 16-byte units,
 // right neighbour) -- 16 independent loads.  Source column of grid pixel j under tap kx is 2 (gx + j) - 1 + kx: the even /
 // odd halves of the 16-element window, shifted by one element for kx = 0 and kx = 3.
-__global__ __launch_bounds__(256) void im2col_k4s2_bf16_kernel(TapGather<VS_BF16> gth, __bf16* cols, int64_t ld, int64_t units_per_c) {
+template <int CT>
+__global__ __launch_bounds__(256) void im2col_k4s2_bf16_kernel(TapGather<CT> gth, typename CTraits<CT>::T* cols, int64_t ld, int64_t units_per_c) {
+    typedef typename CTraits<CT>::T __bf16_t;
     const TapGeo& g = gth.g;
     const int c = blockIdx.y, W = g.W, H = g.H;
     for (int64_t pu = (int64_t)blockIdx.x * 256 + threadIdx.x; pu < units_per_c; pu += (int64_t)gridDim.x * 256) {
         const int64_t pix0 = pu * 8;
         int b, gy, gx;
         g.split_pix(pix0, b, gy, gx);
-        const __bf16* plane = gth.src + ((int64_t)b * g.C + c) * H * W;
+        const __bf16_t* plane = gth.src + ((int64_t)b * g.C + c) * H * W;
         const int x0 = 2 * gx;                                            // window = source columns x0 - 1 .. x0 + 16
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
             const int iy = 2 * gy - 1 + ky;
             const bool ok = iy >= 0 && iy < H;
-            const __bf16* row = plane + (int64_t)(ok ? iy : 0) * W + x0;
+            const __bf16_t* row = plane + (int64_t)(ok ? iy : 0) * W + x0;
             const u32x4 a = *reinterpret_cast<const u32x4*>(row), bq = *reinterpret_cast<const u32x4*>(row + 8);
             const unsigned short lv = *reinterpret_cast<const unsigned short*>(row + (x0 > 0 ? -1 : 0));
             const unsigned short rv = *reinterpret_cast<const unsigned short*>(row + (x0 + 16 < W ? 16 : 15));
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256) void im2col_k4s2_bf16_kernel(TapGather<VS_BF16
             ods[0] = (od[0] << 16) | L;
 #pragma unroll
             for (int j = 1; j < 4; ++j) ods[j] = __builtin_amdgcn_alignbyte(od[j], od[j - 1], 2);
-            __bf16* dst = cols + ((int64_t)c * 16 + ky * 4) * ld + pix0;          // tap t = ky * 4 + kx  (natural_taps order)
+            __bf16_t* dst = cols + ((int64_t)c * 16 + ky * 4) * ld + pix0;          // tap t = ky * 4 + kx  (natural_taps order)
             *reinterpret_cast<u32x4*>(dst) = ods;                                  // kx = 0: columns 2 j - 1
             *reinterpret_cast<u32x4*>(dst + ld) = ev;                              // kx = 1: columns 2 j
             *reinterpret_cast<u32x4*>(dst + 2 * ld) = od;                          // kx = 2: columns 2 j + 1
@@ -532,14 +536,14 @@ int materialise(const TapGather<CT>& gth, void* ws, hipStream_t st, const char* 
     const int64_t ld = cols_pitch<CT>(gth.npix), units = ld / U;
     int64_t bx = (units + 255) / 256;
     if (bx > 1024) bx = 1024;
-    if constexpr (CT == VS_BF16) {
+    if constexpr (CT != VS_F32) {
         if (s1_fast_ok(gth.g, gth.npix, gth.src)) {
-            hipLaunchKernelGGL(im2col_s1_bf16_kernel, dim3((unsigned)bx, (unsigned)gth.g.C), dim3(256), 0, st, gth, (__bf16*)ws, ld, units);
+            hipLaunchKernelGGL(im2col_s1_bf16_kernel<CT>, dim3((unsigned)bx, (unsigned)gth.g.C), dim3(256), 0, st, gth, (typename CTraits<CT>::T*)ws, ld, units);
             VS_CHECK_LAUNCH(what);
             return VS_OK;
         }
         if (k4s2_fast_ok(gth.g, gth.npix, gth.src)) {
-            hipLaunchKernelGGL(im2col_k4s2_bf16_kernel, dim3((unsigned)bx, (unsigned)gth.g.C), dim3(256), 0, st, gth, (__bf16*)ws, ld, units);
+            hipLaunchKernelGGL(im2col_k4s2_bf16_kernel<CT>, dim3((unsigned)bx, (unsigned)gth.g.C), dim3(256), 0, st, gth, (typename CTraits<CT>::T*)ws, ld, units);
             VS_CHECK_LAUNCH(what);
             return VS_OK;
         }
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(256) void gather_small_s1_kernel(Dense<CT, LR> A, T
                 const T* row = plane + (int64_t)(ok ? iy : gy) * W + gx;
                 T v[8];
                 *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(row);
-                if constexpr (CT != VS_BF16) *reinterpret_cast<u32x4*>(v + 4) = *reinterpret_cast<const u32x4*>(row + 4);
+                if constexpr (CT == VS_F32) *reinterpret_cast<u32x4*>(v + 4) = *reinterpret_cast<const u32x4*>(row + 4);
                 const T lv = row[gx > 0 ? -1 : 0], rv = row[gx + 8 < W ? 8 : 7];
                 xs[d][0] = (ok && gx > 0) ? (float)lv : 0.f;
                 xs[d][9] = (ok && gx + 8 < W) ? (float)rv : 0.f;
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(256) void convt_k4s2_small_kernel(const typename CT
                 const bool ok = iy >= 0 && iy < H;
                 const T* row = plane + (int64_t)(ok ? iy : y) * W + x0;
                 T v[8];
-                if constexpr (CT == VS_BF16) {
+                if constexpr (CT != VS_F32) {
                     *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(row);
                 } else {
                     *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(row);
@@ -882,7 +886,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, type
     }
 }
 
-#define VS_DISPATCH(compute, fn, ...) ((compute) == VS_BF16 ? fn<VS_BF16>(__VA_ARGS__) : fn<VS_F32>(__VA_ARGS__))
+#define VS_DISPATCH(compute, fn, ...) \
+    ((compute) == VS_BF16 ? fn<VS_BF16>(__VA_ARGS__) : (compute) == VS_F16 ? fn<VS_F16>(__VA_ARGS__) : fn<VS_F32>(__VA_ARGS__))
 
 }  // namespace
 
@@ -893,7 +898,7 @@ extern "C" size_t vs_conv_packed_elems(int D0, int D1, int kh, int kw, int strid
 }
 
 extern "C" int vs_conv_pack_weight(int compute, const float* w, int D0, int D1, int kh, int kw, int stride, int pad, void* dst, void* stream) {
-    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "vs_conv_pack_weight: compute type %d", compute);
+    VS_CHECK_ARG(vs_dtype_ok(compute), "vs_conv_pack_weight: compute type %d", compute);
     VS_CHECK_ARG(w && dst && D0 > 0 && D1 > 0 && kh * kw <= MAXTAP && kh > 0 && kw > 0, "vs_conv_pack_weight: bad argument");
     PackTable tb;
     if (stride == 1) {
@@ -912,6 +917,8 @@ extern "C" int vs_conv_pack_weight(int compute, const float* w, int D0, int D1, 
     if (blocks < 1) blocks = 1;
     if (compute == VS_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<VS_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)dst, D0, D1, kh * kw, tb);
+    else if (compute == VS_F16)
+        hipLaunchKernelGGL(pack_weight_kernel<VS_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)dst, D0, D1, kh * kw, tb);
     else
         hipLaunchKernelGGL(pack_weight_kernel<VS_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)dst, D0, D1, kh * kw, tb);
     VS_CHECK_LAUNCH("vs_conv_pack_weight");
@@ -930,7 +937,7 @@ extern "C" size_t vs_conv_workspace_bytes(int compute, int B, int Cin, int H, in
     // covers forward, input gradient and weight gradient of Conv2d(Cin, Cout) on [B, Cin, H, W] AND of the ConvTranspose2d with the
     // same numbers: the largest column matrix any of them materialises + the split-K slabs of the contraction behind it
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
-    const int64_t e = compute == VS_BF16 ? 2 : 4, U = 16 / e;
+    const int64_t e = vs_esize(compute), U = 16 / e;
     const int64_t OHc = (H + 2 * pad - kh) / stride + 1, OWc = (W + 2 * pad - kw) / stride + 1;       // Conv2d output
     const int64_t OHt = (int64_t)(H - 1) * stride - 2 * pad + kh, OWt = (int64_t)(W - 1) * stride - 2 * pad + kw;   // ConvTranspose2d output
     const int64_t khw = (int64_t)kh * kw;
@@ -1005,8 +1012,8 @@ extern "C" int vs_conv_transpose2d_dgrad(int compute, const void* dy, const void
     bool ready = false;
     if (cols_from_wgrad) {
         const int64_t Mw = Cin, Nw = (int64_t)Cout * kh * kw, Kw = (int64_t)B * H * W;
-        ready = compute == VS_BF16 ? wgrad_uses_cols<VS_BF16>(Mw, Nw, Kw, workspace, workspace_bytes)
-                                   : wgrad_uses_cols<VS_F32>(Mw, Nw, Kw, workspace, workspace_bytes);
+        ready = compute != VS_F32 ? wgrad_uses_cols<VS_BF16>(Mw, Nw, Kw, workspace, workspace_bytes)      // sizes only: bf16 == fp16
+                                  : wgrad_uses_cols<VS_F32>(Mw, Nw, Kw, workspace, workspace_bytes);
     }
     return VS_DISPATCH(compute, conv_form, dy, w, nullptr, dx, dx_dtype, B, Cout, OH, OW, Cin, kh, kw, stride, pad, H, W, workspace,
                        workspace_bytes, (hipStream_t)stream, "vs_conv_transpose2d_dgrad", ready);

@@ -15,7 +15,7 @@ int vs_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* vs_last_error(void) { return vs_err_buf; }
-extern "C" const char* vs_version(void) { return "varsep_hip 0.1 (gfx950)"; }
+extern "C" const char* vs_version(void) { return "varsep_hip 0.2 (gfx950)"; }
 
 namespace {
 
@@ -34,11 +34,11 @@ __device__ __forceinline__ void map4(const void* x, int xd, void* y, int yd, int
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float v[4];
         if (xd == VS_F32) { f32x4 t = ((const f32x4*)x)[i]; v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
-        else { bf16x4 t = ((const bf16x4*)x)[i]; v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3]; }
+        else { const u16x4 t = ((const u16x4*)x)[i]; v[0] = vs_h2f(t[0], xd); v[1] = vs_h2f(t[1], xd); v[2] = vs_h2f(t[2], xd); v[3] = vs_h2f(t[3], xd); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = f(v[j], i * 4 + j);
         if (yd == VS_F32) { f32x4 t = {v[0], v[1], v[2], v[3]}; ((f32x4*)y)[i] = t; }
-        else { bf16x4 t = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; ((bf16x4*)y)[i] = t; }
+        else { const u16x4 t = {vs_f2h(v[0], yd), vs_f2h(v[1], yd), vs_f2h(v[2], yd), vs_f2h(v[3], yd)}; ((u16x4*)y)[i] = t; }
     }
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         vs_st(y, yd, i, f(vs_ld(x, xd, i), i));
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumJobs J) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
     const bool vec = n + 8 <= N && ldx % 8 == 0 && (uintptr_t)X % 16 == 0;
-    if (vec && xd == VS_BF16) {
-        const __bf16* p = (const __bf16*)X + n;
+    if (vec && vs_is16(xd)) {
+        const unsigned short* p = (const unsigned short*)X + n;
         int64_t r = r0 + g;
         for (; r + 24 < r1; r += 32) {
             u32x4 v[4];
@@ -123,16 +123,16 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumJobs J) {
             for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(p + (r + 8 * u) * ldx);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const __bf16* h = reinterpret_cast<const __bf16*>(&v[u]);
+                const unsigned short* h = reinterpret_cast<const unsigned short*>(&v[u]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s[e] += (float)h[e];
+                for (int e = 0; e < 8; ++e) s[e] += vs_h2f(h[e], xd);
             }
         }
         for (; r < r1; r += 8) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(p + r * ldx);
-            const __bf16* h = reinterpret_cast<const __bf16*>(&v);
+            const unsigned short* h = reinterpret_cast<const unsigned short*>(&v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] += (float)h[e];
+            for (int e = 0; e < 8; ++e) s[e] += vs_h2f(h[e], xd);
         }
     } else if (vec && xd == VS_F32) {
         const float* p = (const float*)X + n;
@@ -328,10 +328,10 @@ __global__ __launch_bounds__(256) void train_losses_bwd_kernel(LossArgs a, const
             if (dz_dtype == VS_F32) {
                 *reinterpret_cast<f32x4*>((float*)dz + row0 + i) = f32x4{r[0], r[1], r[2], r[3]};
             } else {
-                bf16x4 w;
+                u16x4 w;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = (__bf16)r[j];
-                *reinterpret_cast<bf16x4*>((__bf16*)dz + row0 + i) = w;            // D % 4 tail handled below; row0 % 4 == 0 is checked by the host
+                for (int j = 0; j < 4; ++j) w[j] = vs_f2h(r[j], dz_dtype);
+                *reinterpret_cast<u16x4*>((unsigned short*)dz + row0 + i) = w;            // D % 4 tail handled below; row0 % 4 == 0 is checked by the host
             }
         }
         if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -396,7 +396,7 @@ extern "C" int vs_train_losses_bwd(const float* frames, const float* full, const
                             lambdas);
     if (rc != VS_OK) return rc;
     VS_CHECK_ARG(grad_total && (dframes || dz) && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_bwd: null pointer");
-    VS_CHECK_ARG(!dz || ((dz_dtype == VS_F32 || dz_dtype == VS_BF16) && frames_act >= VS_ACT_NONE && frames_act <= VS_ACT_ELU && D % 4 == 0),
+    VS_CHECK_ARG(!dz || (vs_dtype_ok(dz_dtype) && frames_act >= VS_ACT_NONE && frames_act <= VS_ACT_ELU && D % 4 == 0),
                  "vs_train_losses_bwd: dz needs a valid dtype / activation and D %% 4 == 0");
     unsigned gx = (unsigned)((D / 4 + 255) / 256);
     if (gx > 8) gx = 8;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void gather_windows_kernel(const float* data, 
         for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
             if (od == VS_F32) *reinterpret_cast<f32x4*>((float*)out + obase + i) = v;
-            else { bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; *reinterpret_cast<bf16x4*>((__bf16*)out + obase + i) = w; }
+            else { const u16x4 w = {vs_f2h(v[0], od), vs_f2h(v[1], od), vs_f2h(v[2], od), vs_f2h(v[3], od)}; *reinterpret_cast<u16x4*>((unsigned short*)out + obase + i) = w; }
         }
         return;
     }
@@ -445,7 +445,7 @@ extern "C" int vs_gather_windows(const float* data, int64_t n_seq, int64_t nt, i
                      seq_len <= nt, "vs_gather_windows: bad argument");
     VS_CHECK_ARG(windows_per_seq + seq_len - 1 <= nt, "vs_gather_windows: a window would run past the end of its sequence");
     VS_CHECK_ARG(!pixel_idx || n_pixels > 0, "vs_gather_windows: pixel table without a count");
-    VS_CHECK_ARG(out_dtype == VS_F32 || out_dtype == VS_BF16, "vs_gather_windows: bad out_dtype");
+    VS_CHECK_ARG(vs_dtype_ok(out_dtype), "vs_gather_windows: bad out_dtype");
     const int64_t total = (int64_t)seq_len * (pixel_idx ? n_pixels : frame_elems);
     int64_t gx = (total / 4 + 255) / 256;
     if (gx > 64) gx = 64;
@@ -463,7 +463,7 @@ extern "C" int vs_gather_windows(const float* data, int64_t n_seq, int64_t nt, i
 namespace {
 // mixing 0: concat (Cz = Cs + Ct), 1: mul (Cz = Cs = Ct)
 __global__ __launch_bounds__(256) void mix_codes_fwd_kernel(const float* s, const float* t_rand, const float* t_codes, int64_t B, int n, int Cs,
-                                                            int Ct, int mixing, float* out, __bf16* out_lp) {
+                                                            int Ct, int mixing, float* out, unsigned short* out_lp, int lp_dtype) {
     const int G = n + 1, Cz = mixing ? Cs : Cs + Ct;
     const int64_t total = B * G * Cz;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void mix_codes_fwd_kernel(const float* s, cons
             v = g == 0 ? t_rand[b * Ct + c - Cs] : t_codes[(b * n + g - 1) * Ct + c - Cs];
         }
         out[i] = v;
-        if (out_lp) out_lp[i] = (__bf16)v;
+        if (out_lp) out_lp[i] = vs_f2h(v, lp_dtype);
     }
 }
 
@@ -517,12 +517,13 @@ __global__ __launch_bounds__(256) void mix_codes_bwd_kernel(const float* dz, con
 }  // namespace
 
 extern "C" int vs_mix_codes_fwd(const float* s, const float* t_rand, const float* t_codes, int64_t B, int n, int Cs, int Ct, int mixing, float* out,
-                                void* out_bf16, void* stream) {
+                                void* out_lowp, int lowp_dtype, void* stream) {
+    VS_CHECK_ARG(!out_lowp || vs_is16(lowp_dtype), "vs_mix_codes_fwd: the second output is a 16-bit copy (VS_BF16 | VS_F16)");
     VS_CHECK_ARG(s && t_rand && (t_codes || n == 0) && out && B > 0 && n >= 0 && Cs > 0 && Ct > 0, "vs_mix_codes_fwd: bad argument");
     VS_CHECK_ARG((mixing == 0 || mixing == 1) && (mixing == 0 || Cs == Ct), "vs_mix_codes_fwd: mixing 1 (mul) needs Cs == Ct");
     const int64_t total = B * (n + 1) * (mixing ? Cs : Cs + Ct);
     hipLaunchKernelGGL(mix_codes_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, s, t_rand, t_codes, B, n, Cs, Ct, mixing, out,
-                       (__bf16*)out_bf16);
+                       (unsigned short*)out_lowp, lowp_dtype);
     VS_CHECK_LAUNCH("vs_mix_codes_fwd");
     return VS_OK;
 }
@@ -586,7 +587,7 @@ extern "C" int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dt
 
 extern "C" int vs_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
     VS_CHECK_ARG(src && dst && n >= 0, "vs_cast: bad argument");
-    VS_CHECK_ARG((sd == VS_F32 || sd == VS_BF16) && (dd == VS_F32 || dd == VS_BF16), "vs_cast: bad dtype");
+    VS_CHECK_ARG(vs_dtype_ok(sd) && vs_dtype_ok(dd), "vs_cast: bad dtype");
     if (n == 0) return VS_OK;
     hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, sd, dst, dd, n);
     VS_CHECK_LAUNCH("vs_cast");

@@ -42,7 +42,7 @@ int launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, in
     return VS_OK;
 }
 
-template <int LA, int LB>
+template <int CT, int LA, int LB>
 int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const Plan& plan, const Epi& epi,
                 float* slabs, hipStream_t stream) {
     const int batch = epi.splits_per_batch > 0 ? plan.batch : 1;
@@ -50,10 +50,10 @@ int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t 
     static const int forced = getenv("VS_GEMM_GLDS_STAGES") ? atoi(getenv("VS_GEMM_GLDS_STAGES")) : 0;
     const int stages = forced ? forced : ((int64_t)grid.x * grid.y * grid.z >= 1024 ? 2 : 1);
     if (stages == 2)
-        hipLaunchKernelGGL((gemm_glds_kernel<LA, LB, false, 2>), grid, dim3(256), 65536, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, M, N,
+        hipLaunchKernelGGL((gemm_glds_kernel<LA, LB, false, 2, CT>), grid, dim3(256), 65536, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, M, N,
                            K, (int)plan.k_tiles_per_split, epi, slabs);
     else
-        hipLaunchKernelGGL((gemm_glds_kernel<LA, LB, false, 1>), grid, dim3(256), 32768, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, M, N,
+        hipLaunchKernelGGL((gemm_glds_kernel<LA, LB, false, 1, CT>), grid, dim3(256), 32768, stream, (const __bf16*)A, lda, (const __bf16*)B, ldb, M, N,
                            K, (int)plan.k_tiles_per_split, epi, slabs);
     VS_CHECK_LAUNCH("vs_gemm (LDS-DMA tile)");
     return VS_OK;
@@ -62,7 +62,7 @@ int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t 
 template <int CT, int LA, int LB>
 int launch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const Plan& plan,
                 const Epi& epi, float* slabs, hipStream_t stream) {
-    if constexpr (CT == VS_BF16 && LA == LR && LB == LR) {
+    if constexpr (CT != VS_F32 && LA == LR && LB == LR) {
         // LDS-DMA staged tile (vs_gemm_glds.h) wherever the plan picks 128x128 (>= 1024 tiles).  Measured on MI355X
         // (tools/gemm_bench.py): 732 vs 588 TF/s at 4096^3 with two LDS buffers; with S operands it is not faster than the
         // register-staged tile yet (598 vs 593), so only R x R takes this path.  At 512-1023 tiles (the decoder's
@@ -71,16 +71,16 @@ int launch_tile(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t 
         static const int glds_mode = getenv("VS_GEMM_GLDS") ? atoi(getenv("VS_GEMM_GLDS")) : 1;
         if (plan.bm == 128 && plan.bn == 128 && glds_mode && glds_operand_ok(A, lda, LA, M, K, epi.batch_a) &&
             glds_operand_ok(B, ldb, LB, N, K, epi.batch_b))
-            return launch_glds<LA, LB>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
-    } else if constexpr (CT == VS_BF16) {
+            return launch_glds<CT, LA, LB>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
+    } else if constexpr (CT != VS_F32) {
         static const int glds_mode = getenv("VS_GEMM_GLDS") ? atoi(getenv("VS_GEMM_GLDS")) : 1;
         if (plan.bm == 128 && plan.bn == 128 && glds_mode == 2 && glds_operand_ok(A, lda, LA, M, K, epi.batch_a) &&
             glds_operand_ok(B, ldb, LB, N, K, epi.batch_b))
-            return launch_glds<LA, LB>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
+            return launch_glds<CT, LA, LB>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     }
     if (plan.bm == 128 && plan.bn == 128) return launch<CT, LA, LB, 128, 128>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     if (plan.bm == 128 && plan.bn == 64) return launch<CT, LA, LB, 128, 64>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
-    if constexpr (CT == VS_BF16)
+    if constexpr (CT != VS_F32)
         if (plan.bm == 64 && plan.bn == 128) return launch<CT, LA, LB, 64, 128>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     return launch<CT, LA, LB, 64, 64>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
 }
@@ -99,7 +99,7 @@ int launch_layout(int la, int lb, const void* A, int64_t lda, const void* B, int
 extern "C" size_t vs_gemm_batched_workspace_bytes(int batch, int64_t M, int64_t N, int64_t K) {
     if (batch <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
     size_t worst = 0;
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 2; ++c) {                        // fp32 and the 16-bit types (bf16 and fp16 plan alike)
         Plan p = make_plan(c, M, N, K, batch);
         if (p.splits > 1) {
             size_t b = (size_t)batch * p.splits * (size_t)M * (size_t)N * sizeof(float);
@@ -116,11 +116,11 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
                                int64_t stride_c, int c_dtype, float alpha, int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "vs_gemm_batched: compute type %d", compute);
+    VS_CHECK_ARG(vs_dtype_ok(compute), "vs_gemm_batched: compute type %d", compute);
     VS_CHECK_ARG(batch >= 1 && batch <= 1024 && M > 0 && N > 0 && K > 0, "vs_gemm_batched: bad sizes");
     VS_CHECK_ARG(A && B && C, "vs_gemm_batched: null operand");
     VS_CHECK_ARG((layout_a == LR || layout_a == LS) && (layout_b == LR || layout_b == LS), "vs_gemm_batched: bad layout");
-    VS_CHECK_ARG(c_dtype == VS_F32 || c_dtype == VS_BF16, "vs_gemm_batched: bad c_dtype");
+    VS_CHECK_ARG(vs_dtype_ok(c_dtype), "vs_gemm_batched: bad c_dtype");
     VS_CHECK_ARG(lda >= (layout_a == LR ? K : M) && ldb >= (layout_b == LR ? K : N) && ldc >= N, "vs_gemm_batched: leading dimension too small");
     Plan plan = make_plan(compute, M, N, K, batch);
     plan.batch = batch;
@@ -132,9 +132,9 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
             return vs_fail(VS_ERR_WORKSPACE, "vs_gemm_batched: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         slabs = (float*)workspace;
     }
-    int rc = compute == VS_BF16
-                 ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
-                 : launch_layout<VS_F32>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
+    int rc = compute == VS_BF16  ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
+             : compute == VS_F16 ? launch_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
+                                 : launch_layout<VS_F32>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     if (rc != VS_OK) return rc;
     if (slabs) {
         int64_t blocks = vs_cdiv(M * N, 256);
@@ -163,11 +163,11 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
                        const void* mask, int64_t ldmask, int mask_dtype, int mask_act, int accumulate, void* workspace,
                        size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "vs_gemm: compute type %d", compute);
+    VS_CHECK_ARG(vs_dtype_ok(compute), "vs_gemm: compute type %d", compute);
     VS_CHECK_ARG(M > 0 && N > 0 && K > 0, "vs_gemm: M, N, K must be positive (%lld %lld %lld)", (long long)M, (long long)N, (long long)K);
     VS_CHECK_ARG(A && B && C, "vs_gemm: null operand");
     VS_CHECK_ARG((layout_a == LR || layout_a == LS) && (layout_b == LR || layout_b == LS), "vs_gemm: bad layout");
-    VS_CHECK_ARG(c_dtype == VS_F32 || c_dtype == VS_BF16, "vs_gemm: bad c_dtype");
+    VS_CHECK_ARG(vs_dtype_ok(c_dtype) && (!mask || vs_dtype_ok(mask_dtype)), "vs_gemm: bad c_dtype / mask_dtype");
     VS_CHECK_ARG(lda >= (layout_a == LR ? K : M) && ldb >= (layout_b == LR ? K : N) && ldc >= N, "vs_gemm: leading dimension too small");
     VS_CHECK_ARG(!mask || ldmask >= N, "vs_gemm: ldmask too small");
     VS_CHECK_ARG(act >= VS_ACT_NONE && act <= VS_ACT_ELU, "vs_gemm: bad activation");
@@ -180,9 +180,9 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
             return vs_fail(VS_ERR_WORKSPACE, "vs_gemm: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         slabs = (float*)workspace;
     }
-    int rc = compute == VS_BF16
-                 ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
-                 : launch_layout<VS_F32>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
+    int rc = compute == VS_BF16  ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
+             : compute == VS_F16 ? launch_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
+                                 : launch_layout<VS_F32>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     if (rc != VS_OK) return rc;
     if (slabs) {
         int64_t blocks = vs_cdiv(M * N, 256);

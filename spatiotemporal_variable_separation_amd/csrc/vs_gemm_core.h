@@ -12,6 +12,16 @@ enum { LR = VS_LAYOUT_R, LS = VS_LAYOUT_S };
 template <int CT> struct CTraits;
 template <> struct CTraits<VS_F32> { typedef float T; static constexpr int U = 4; static constexpr int KSTEP = 8; };
 template <> struct CTraits<VS_BF16> { typedef __bf16 T; static constexpr int U = 8; static constexpr int KSTEP = 16; };
+template <> struct CTraits<VS_F16> { typedef _Float16 T; static constexpr int U = 8; static constexpr int KSTEP = 16; };
+
+// one 32x32x16 MFMA on 16-bit operands given as raw fragment bits (8 elements per lane): bf16 or IEEE half, fp32 accumulate
+template <int CT>
+__device__ __forceinline__ f32x16 mfma16_32(const u32x4& a, const u32x4& b, const f32x16& c) {
+    if constexpr (CT == VS_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 
 struct Epi {
     void* C; int64_t ldc; int c_dtype;
@@ -31,7 +41,7 @@ struct Epi {
 
 __device__ __forceinline__ Epi epi_for_batch(const Epi& e, int64_t batch) {
     Epi r = e;
-    if (batch) r.C = (char*)e.C + batch * e.batch_c * (e.c_dtype == VS_F32 ? 4 : 2);
+    if (batch) r.C = (char*)e.C + batch * e.batch_c * vs_esize(e.c_dtype);
     return r;
 }
 
@@ -113,7 +123,7 @@ struct TileGeom {
     static constexpr int U = CTraits<CT>::U;
     // R: [ROWS][BK+U]   (pitch odd multiple of 16 B -> ds_read_b128 conflict free)
     // S: [BK][ROWS+pad] (bf16: pad 32 -> the four k-rows of a tr_b16 read land in distinct 64-byte bank groups)
-    static constexpr int PITCH = LAYOUT == LR ? BK + U : (CT == VS_BF16 ? ROWS + 32 : ROWS + 4);
+    static constexpr int PITCH = LAYOUT == LR ? BK + U : (CT != VS_F32 ? ROWS + 32 : ROWS + 4);
     static constexpr int ELEMS = LAYOUT == LR ? ROWS * PITCH : BK * PITCH;
     static constexpr int UNITS = ROWS * BK / U;          // 16-byte units per tile
     static constexpr int PER_THREAD = UNITS / 256;
@@ -165,21 +175,30 @@ __device__ __forceinline__ void tile_commit(typename CTraits<CT>::T* lds,
     }
 }
 
-// ---- fragment fetch: bf16, one 32-row block, one 16-deep k step -> bf16x8 (lane r=l&31, h=l>>5 holds k=8h..8h+7)
+// ---- fragment fetch: 16-bit types, one 32-row block, one 16-deep k step -> 8 elements as raw bits (lane r=l&31, h=l>>5 holds
+// k=8h..8h+7)
+typedef __attribute__((ext_vector_type(4))) short vs_i16x4;
+__device__ __forceinline__ u32x4 vs_tr16_pair(const unsigned short* a, int second_offset_elems) {
+    // two ds_read_b64_tr_b16 (k = 8h..8h+3 and 8h+4..8h+7): the transposing read moves 16-bit elements, whatever they encode
+    typedef __attribute__((address_space(3))) vs_i16x4 lds_i16x4;
+    const vs_i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(a));
+    const vs_i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(a + second_offset_elems));
+    typedef __attribute__((ext_vector_type(8))) short i16x8;
+    const i16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(u32x4, both);
+}
+
 template <int LAYOUT, int PITCH>
-__device__ __forceinline__ bf16x8 frag_bf16(const __bf16* tile, int row0, int kk, int lane) {
+__device__ __forceinline__ u32x4 frag_bf16(const unsigned short* tile, int row0, int kk, int lane) {
     if (LAYOUT == LR) {
         const int r = lane & 31, h = lane >> 5;
-        return *reinterpret_cast<const bf16x8*>(tile + (row0 + r) * PITCH + kk + 8 * h);
+        return *reinterpret_cast<const u32x4*>(tile + (row0 + r) * PITCH + kk + 8 * h);
     } else {
         // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(row) block; lane 4q+p supplies the address of k-row q,
         // rows 4p..4p+3; lane i receives row i of the four k-rows.  Two reads cover k = 8h..8h+3 and 8h+4..8h+7.
         const int li = lane & 15, q = li >> 2, p = li & 3, cb = (lane >> 4) & 1, h = lane >> 5;
-        const __bf16* a = tile + (kk + 8 * h + q) * PITCH + row0 + 16 * cb + 4 * p;
-        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * PITCH));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const unsigned short* a = tile + (kk + 8 * h + q) * PITCH + row0 + 16 * cb + 4 * p;
+        return vs_tr16_pair(a, 4 * PITCH);
     }
 }
 
@@ -254,24 +273,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
             tile_fetch<CT, OpB, BN, BK>(B, stb, n0, (kt + 1) * BK, rb);
         }
 #endif
-        if constexpr (CT == VS_BF16) {
+        if constexpr (CT != VS_F32) {
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 16) {
-                bf16x8 fa[TM], fb[TN];
+                u32x4 fa[TM], fb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fa[i] = frag_bf16<OpA::layout, GA::PITCH>(reinterpret_cast<const __bf16*>(sA), wm + 32 * i, kk, lane);
+                    fa[i] = frag_bf16<OpA::layout, GA::PITCH>(reinterpret_cast<const unsigned short*>(sA), wm + 32 * i, kk, lane);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    fb[j] = frag_bf16<OpB::layout, GB::PITCH>(reinterpret_cast<const __bf16*>(sB), wn + 32 * j, kk, lane);
+                    fb[j] = frag_bf16<OpB::layout, GB::PITCH>(reinterpret_cast<const unsigned short*>(sB), wn + 32 * j, kk, lane);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
 #ifdef VS_DIAG_NO_MFMA
-                        acc[i][j][0] += (float)fa[i][0] + (float)fb[j][0];          // keeps the LDS reads alive, no matrix work
+                        acc[i][j][0] += (float)fa[i][0] + (float)fb[j][0];          // keeps the LDS reads alive, no matrix work (diagnostic)
 #else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16_32<CT>(fa[i], fb[j], acc[i][j]);
 #endif
                     }
             }
@@ -348,10 +367,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
 
 struct Plan { int bm, bn, splits; int64_t k_tiles_per_split; int batch = 1; };
 
-template <int CT> constexpr int bk_of() { return CT == VS_BF16 ? 64 : 16; }
+template <int CT> constexpr int bk_of() { return CT != VS_F32 ? 64 : 16; }
 
 Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1) {
-    const int bk = compute == VS_BF16 ? 64 : 16;
+    const int bk = compute != VS_F32 ? 64 : 16;
     Plan p;
     // Tile choice (measured on the config-2 shapes, tools/gemm_bench.py): the kernel keeps ~3 workgroups (12 waves) per CU
     // busy; with fewer than ~4 tiles of 128x128 per CU most SIMDs hold a single wave that cannot overlap its LDS reads with
@@ -370,7 +389,7 @@ Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1) 
     if (p.bm == 64) p.bn = 64;
     // <= 64 output rows x very many columns (64-channel convolution layers over a whole batch of pixels): a 64x128 tile gives
     // every wave two accumulators per A fragment (1.5 LDS fragment reads per MFMA instead of 2)
-    if (compute == VS_BF16 && !getenv("VS_GEMM_TILE") && M <= 64 && M > 32 && vs_cdiv(N, 128) >= 1024 && K >= 128) { p.bm = 64; p.bn = 128; }
+    if (compute != VS_F32 && !getenv("VS_GEMM_TILE") && M <= 64 && M > 32 && vs_cdiv(N, 128) >= 1024 && K >= 128) { p.bm = 64; p.bn = 128; }
     const int64_t tiles = vs_cdiv(M, p.bm) * vs_cdiv(N, p.bn) * batch;
     const int64_t kt = vs_cdiv(K, bk);
     int splits = 1;

@@ -67,24 +67,21 @@ struct GldsOperand {
 };
 
 template <int LAYOUT>
-__device__ __forceinline__ bf16x8 glds_frag(const __bf16* tile, int row0, int kk, int lane) {
+__device__ __forceinline__ u32x4 glds_frag(const unsigned short* tile, int row0, int kk, int lane) {
     if (LAYOUT == LR) {
         const int row = row0 + (lane & 31), q = (kk >> 3) + (lane >> 5);
-        return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((q ^ ((row >> 1) & 7)) << 3));
+        return *reinterpret_cast<const u32x4*>(tile + row * 64 + ((q ^ ((row >> 1) & 7)) << 3));
     } else {
         const int li = lane & 15, q = li >> 2, p = li & 3, cb = (lane >> 4) & 1, h = lane >> 5;
         const int k1 = kk + 8 * h + q;                             // k1 + 4 has the same (k & 3): same permutation
         const int rowoff = row0 + 16 * cb + 4 * p;
         const int slot = (rowoff >> 3) ^ ((k1 & 3) << 2);
-        const __bf16* a = tile + k1 * 128 + slot * 8 + (rowoff & 7);
-        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * 128));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const unsigned short* a = tile + k1 * 128 + slot * 8 + (rowoff & 7);
+        return vs_tr16_pair(a, 4 * 128);
     }
 }
 
-template <int LA, int LB, bool NCHW, int STAGES = 1>
+template <int LA, int LB, bool NCHW, int STAGES = 1, int CT = VS_BF16>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const __bf16* Ap, int64_t lda, const __bf16* Bp, int64_t ldb, int64_t M, int64_t N,
                                                         int64_t K, int k_tiles_per_split, Epi epi_in, float* slabs) {
     int zsplit = blockIdx.z;
@@ -124,17 +121,17 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const __bf16* Ap, int64_
     // fragments of k-step s+1 are requested before the MFMAs of k-step s are issued (two register sets, static names): with
     // one or two waves per SIMD nothing else hides the ds_read latency
     auto compute = [&](const char* tA, const char* tB) {
-        const __bf16* pa = reinterpret_cast<const __bf16*>(tA);
-        const __bf16* pb = reinterpret_cast<const __bf16*>(tB);
-        bf16x8 a0[2], b0[2], a1[2], b1[2];
+        const unsigned short* pa = reinterpret_cast<const unsigned short*>(tA);
+        const unsigned short* pb = reinterpret_cast<const unsigned short*>(tB);
+        u32x4 a0[2], b0[2], a1[2], b1[2];
 #define VS_GLDS_LOAD(fa, fb, kk)                                               \
         fa[0] = glds_frag<LA>(pa, wm, kk, lane); fa[1] = glds_frag<LA>(pa, wm + 32, kk, lane); \
         fb[0] = glds_frag<LB>(pb, wn, kk, lane); fb[1] = glds_frag<LB>(pb, wn + 32, kk, lane);
 #define VS_GLDS_MFMA(fa, fb)                                                   \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[0][0], 0, 0, 0); \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[0][1], 0, 0, 0); \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[1][0], 0, 0, 0); \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[1][1], 0, 0, 0);
+        acc[0][0] = mfma16_32<CT>(fa[0], fb[0], acc[0][0]); \
+        acc[0][1] = mfma16_32<CT>(fa[0], fb[1], acc[0][1]); \
+        acc[1][0] = mfma16_32<CT>(fa[1], fb[0], acc[1][0]); \
+        acc[1][1] = mfma16_32<CT>(fa[1], fb[1], acc[1][1]);
         VS_GLDS_LOAD(a0, b0, 0)
         VS_GLDS_LOAD(a1, b1, 16)
         VS_GLDS_MFMA(a0, b0)

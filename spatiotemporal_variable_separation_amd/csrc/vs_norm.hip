@@ -50,9 +50,9 @@ __device__ __forceinline__ int ld_vec(const void* x, int xd, int64_t idx, float 
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
         return 4;
     }
-    const bf16x8 t = *reinterpret_cast<const bf16x8*>((const __bf16*)x + idx);
+    const u16x8 t = *reinterpret_cast<const u16x8*>((const unsigned short*)x + idx);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+    for (int j = 0; j < 8; ++j) v[j] = vs_h2f(t[j], xd);
     return 8;
 }
 __device__ __forceinline__ void st_vec(void* y, int yd, int64_t idx, const float (&v)[8], int n) {
@@ -62,13 +62,13 @@ __device__ __forceinline__ void st_vec(void* y, int yd, int64_t idx, const float
             *reinterpret_cast<f32x4*>((float*)y + idx + o) = t;
         }
     } else if (n == 8) {
-        bf16x8 t;
+        u16x8 t;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = (__bf16)v[j];
-        *reinterpret_cast<bf16x8*>((__bf16*)y + idx) = t;
+        for (int j = 0; j < 8; ++j) t[j] = vs_f2h(v[j], yd);
+        *reinterpret_cast<u16x8*>((unsigned short*)y + idx) = t;
     } else {
-        bf16x4 t = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *reinterpret_cast<bf16x4*>((__bf16*)y + idx) = t;
+        const u16x4 t = {vs_f2h(v[0], yd), vs_f2h(v[1], yd), vs_f2h(v[2], yd), vs_f2h(v[3], yd)};
+        *reinterpret_cast<u16x4*>((unsigned short*)y + idx) = t;
     }
 }
 
@@ -96,12 +96,12 @@ __device__ __forceinline__ int ld_unit(const void* x, int xd, int64_t idx, int l
             const f32x4 t = *reinterpret_cast<const f32x4*>((const float*)x + idx);
             v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
         } else if (w == 8) {
-            const bf16x8 t = *reinterpret_cast<const bf16x8*>((const __bf16*)x + idx);
+            const u16x8 t = *reinterpret_cast<const u16x8*>((const unsigned short*)x + idx);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+            for (int j = 0; j < 8; ++j) v[j] = vs_h2f(t[j], xd);
         } else {
-            const bf16x4 t = *reinterpret_cast<const bf16x4*>((const __bf16*)x + idx);
-            v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+            const u16x4 t = *reinterpret_cast<const u16x4*>((const unsigned short*)x + idx);
+            v[0] = vs_h2f(t[0], xd); v[1] = vs_h2f(t[1], xd); v[2] = vs_h2f(t[2], xd); v[3] = vs_h2f(t[3], xd);
         }
         return w;
     }

@@ -20,7 +20,8 @@ struct AdamJobs {
     int g_bf16[AD_MAXJ];                // gradient stored as bf16 (the data-parallel wire image) instead of fp32
     float* m[AD_MAXJ];
     float* v[AD_MAXJ];
-    __bf16* shadow[AD_MAXJ];            // optional bf16 copy of the updated parameter
+    unsigned short* shadow[AD_MAXJ];    // optional 16-bit (bf16 / fp16: `shadow_dtype`) copy of the updated parameter
+    int shadow_dtype;
     long long n[AD_MAXJ];
     int aligned[AD_MAXJ];               // all four pointers 16-byte aligned (and the shadow 8-byte): vector path
     int skipped[AD_MAXJ];               // optimizer steps this tensor sat out (no gradient): its own step count lags the group's
@@ -28,8 +29,15 @@ struct AdamJobs {
     int nj;
 };
 
+// scale_state (optional, fp16 loss scaling): [0] = loss scale S (gradients arrive multiplied by S and are used as g / S),
+// [1] = found_inf flag of this step (non-zero: leave everything untouched, GradScaler.step semantics)
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* __restrict__ step, double lr_d, double beta1_d, double beta2_d,
-                                                         float eps) {
+                                                         float eps, const float* __restrict__ scale_state) {
+    float inv_scale = 1.f;
+    if (scale_state) {
+        if (scale_state[1] != 0.f) return;
+        inv_scale = 1.f / scale_state[0];
+    }
     // hyper-parameters arrive in double like the Python floats torch works with: 1 - beta and beta^t are formed in double
     const float lr = (float)lr_d, beta2 = (float)beta2_d;
     // bias corrections from the device-side step count (the count is incremented by a separate 1-thread launch AFTER this one,
@@ -52,7 +60,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
         const bool gh = J.g_bf16[j] != 0;
         float* __restrict__ M = J.m[j];
         float* __restrict__ V = J.v[j];
-        __bf16* __restrict__ S = J.shadow[j];
+        unsigned short* __restrict__ S = J.shadow[j];
+        const int sdt = J.shadow_dtype;
 #pragma unroll
         for (int u = 0; u < AD_CHUNK / 1024; ++u) {
             const long long i = base + (long long)u * 1024 + threadIdx.x * 4;
@@ -68,6 +77,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
                 f32x4 m = *reinterpret_cast<const f32x4*>(M + i), v = *reinterpret_cast<const f32x4*>(V + i);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    if (scale_state) g[e] *= inv_scale;                     // scaler.unscale_: grad * (1 / scale)
                     m[e] = m[e] + w1 * (g[e] - m[e]);                       // exp_avg.lerp_(grad, 1 - beta1)
                     v[e] = v[e] * beta2 + (w2 * g[e]) * g[e];              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
                     const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
@@ -77,32 +87,83 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
                 *reinterpret_cast<f32x4*>(M + i) = m;
                 *reinterpret_cast<f32x4*>(V + i) = v;
                 if (S) {
-                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-                    bf16x4 s = {(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3]};
-                    *reinterpret_cast<bf16x4*>(S + i) = s;
+                    const u16x4 s = {vs_f2h(p[0], sdt), vs_f2h(p[1], sdt), vs_f2h(p[2], sdt), vs_f2h(p[3], sdt)};
+                    *reinterpret_cast<u16x4*>(S + i) = s;
                 }
             } else {
                 for (long long k = i; k < n && k < i + 4; ++k) {
-                    const float g = gh ? (float)Gh[k] : G[k];
+                    float g = gh ? (float)Gh[k] : G[k];
+                    if (scale_state) g *= inv_scale;
                     const float m = M[k] + w1 * (g - M[k]);
                     const float v = V[k] * beta2 + (w2 * g) * g;
                     const float denom = sqrtf(v) / bc2_sqrt + eps;
                     const float p = P[k] - step_size * (m / denom);
                     P[k] = p; M[k] = m; V[k] = v;
-                    if (S) S[k] = (__bf16)p;
+                    if (S) S[k] = vs_f2h(p, sdt);
                 }
             }
         }
     }
 }
 
-__global__ void step_increment_kernel(int* step) { step[0] += 1; }
+__global__ void step_increment_kernel(int* step, const float* scale_state) {
+    if (scale_state && scale_state[1] != 0.f) return;         // overflow step: skipped, the step count does not advance
+    step[0] += 1;
+}
+
+// ---- fp16 loss scaling (reference train.py:96-97, 151-155: torch.cuda.amp.GradScaler) on the device ---------------------------
+// found_inf |= any non-finite element of any listed gradient tensor (fp32 or a 16-bit wire image)
+constexpr int CF_MAXJ = 64;
+struct FiniteJobs {
+    const void* g[CF_MAXJ]; int dt[CF_MAXJ]; long long n[CF_MAXJ]; int chunk_off[CF_MAXJ + 1]; int nj;
+};
+__global__ __launch_bounds__(256) void check_finite_kernel(FiniteJobs J, float* found_inf) {
+    const int total = J.chunk_off[J.nj];
+    bool bad = false;
+    for (int ch = blockIdx.x; ch < total; ch += gridDim.x) {
+        int j = 0;
+        while (J.chunk_off[j + 1] <= ch) ++j;
+        const long long base = (long long)(ch - J.chunk_off[j]) * AD_CHUNK, n = J.n[j];
+        const int dt = J.dt[j];
+        const bool vec = ((uintptr_t)J.g[j] % 16) == 0;
+#pragma unroll
+        for (int u = 0; u < AD_CHUNK / 1024; ++u) {
+            const long long i = base + (long long)u * 1024 + threadIdx.x * 4;
+            if (i + 3 < n && vec && dt == VS_F32) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>((const float*)J.g[j] + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bad |= (v[e] & 0x7f800000u) == 0x7f800000u;      // exponent all ones: inf or NaN
+            } else {
+                for (long long k = i; k < n && k < i + 4; ++k) {
+                    const float f = vs_ld(J.g[j], dt, k);
+                    bad |= (__float_as_uint(f) & 0x7f800000u) == 0x7f800000u;
+                }
+            }
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[0] = 1.f;       // benign race: every writer stores the same value
+}
+
+// state = [scale, found_inf, growth_tracker, skipped_steps]: GradScaler.update()
+__global__ void loss_scale_update_kernel(float* state, float growth, float backoff, int interval) {
+    if (state[1] != 0.f) {
+        state[0] *= backoff;
+        state[2] = 0.f;
+        state[3] += 1.f;
+    } else {
+        const float t = state[2] + 1.f;
+        if (t >= (float)interval) { state[0] *= growth; state[2] = 0.f; }
+        else state[2] = t;
+    }
+    state[1] = 0.f;
+}
 
 }  // namespace
 
-extern "C" int vs_adam_multi(int n_tensors, float* const* params, const void* const* grads, const int32_t* grad_dtype, float* const* exp_avg,
-                             float* const* exp_avg_sq, void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step, double lr,
-                             double beta1, double beta2, double eps, void* stream) {
+extern "C" int vs_adam_multi_scaled(int n_tensors, float* const* params, const void* const* grads, const int32_t* grad_dtype, float* const* exp_avg,
+                                    float* const* exp_avg_sq, void* const* shadow, int shadow_dtype, const int64_t* numel, const int32_t* skipped,
+                                    int32_t* step, double lr, double beta1, double beta2, double eps, const float* scale_state, void* stream) {
+    VS_CHECK_ARG(!shadow || vs_is16(shadow_dtype), "vs_adam_multi: the operand copies are 16-bit (VS_BF16 | VS_F16)");
     VS_CHECK_ARG(n_tensors >= 1 && n_tensors <= AD_MAXJ && params && grads && exp_avg && exp_avg_sq && numel && step,
                  "vs_adam_multi: bad argument (1..%d tensors)", AD_MAXJ);
     VS_CHECK_ARG(lr > 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps > 0.0, "vs_adam_multi: bad hyper-parameter");
@@ -117,7 +178,7 @@ extern "C" int vs_adam_multi(int n_tensors, float* const* params, const void* co
                      "vs_adam_multi: tensor %d is not aligned to its element size", j);
         J.g_bf16[j] = gd == VS_BF16;
         J.p[j] = params[j]; J.g[j] = grads[j]; J.m[j] = exp_avg[j]; J.v[j] = exp_avg_sq[j];
-        J.shadow[j] = shadow_bf16 ? (__bf16*)shadow_bf16[j] : nullptr;
+        J.shadow[j] = shadow ? (unsigned short*)shadow[j] : nullptr;
         J.aligned[j] = ((uintptr_t)params[j] | (uintptr_t)exp_avg[j] | (uintptr_t)exp_avg_sq[j]) % 16 == 0 &&
                        (uintptr_t)grads[j] % (gd == VS_F32 ? 16 : 8) == 0 && (!J.shadow[j] || (uintptr_t)J.shadow[j] % 8 == 0);
         J.n[j] = numel[j];
@@ -126,16 +187,59 @@ extern "C" int vs_adam_multi(int n_tensors, float* const* params, const void* co
         VS_CHECK_ARG(J.chunk_off[j] + chunks < (1ll << 30), "vs_adam_multi: too many elements");
         J.chunk_off[j + 1] = J.chunk_off[j] + (int)chunks;
     }
+    J.shadow_dtype = shadow ? shadow_dtype : VS_BF16;
     int blocks = J.chunk_off[n_tensors];
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J, step, lr, beta1, beta2, (float)eps);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J, step, lr, beta1, beta2, (float)eps, scale_state);
     VS_CHECK_LAUNCH("vs_adam_multi");
     return VS_OK;
 }
 
+extern "C" int vs_adam_multi(int n_tensors, float* const* params, const void* const* grads, const int32_t* grad_dtype, float* const* exp_avg,
+                             float* const* exp_avg_sq, void* const* shadow_bf16, const int64_t* numel, const int32_t* skipped, int32_t* step, double lr,
+                             double beta1, double beta2, double eps, void* stream) {
+    return vs_adam_multi_scaled(n_tensors, params, grads, grad_dtype, exp_avg, exp_avg_sq, shadow_bf16, VS_BF16, numel, skipped, step, lr, beta1, beta2,
+                                eps, nullptr, stream);
+}
+
 extern "C" int vs_adam_step_increment(int32_t* step, void* stream) {
     VS_CHECK_ARG(step, "vs_adam_step_increment: null pointer");
-    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, (const float*)nullptr);
     VS_CHECK_LAUNCH("vs_adam_step_increment");
+    return VS_OK;
+}
+
+extern "C" int vs_adam_step_increment_scaled(int32_t* step, const float* scale_state, void* stream) {
+    VS_CHECK_ARG(step, "vs_adam_step_increment_scaled: null pointer");
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, scale_state);
+    VS_CHECK_LAUNCH("vs_adam_step_increment_scaled");
+    return VS_OK;
+}
+
+extern "C" int vs_check_finite_multi(int n_tensors, const void* const* grads, const int32_t* grad_dtype, const int64_t* numel, float* found_inf,
+                                     void* stream) {
+    VS_CHECK_ARG(n_tensors >= 1 && n_tensors <= CF_MAXJ && grads && numel && found_inf, "vs_check_finite_multi: bad argument (1..%d tensors)", CF_MAXJ);
+    FiniteJobs J;
+    J.nj = n_tensors;
+    J.chunk_off[0] = 0;
+    for (int j = 0; j < n_tensors; ++j) {
+        const int gd = grad_dtype ? grad_dtype[j] : VS_F32;
+        VS_CHECK_ARG(grads[j] && numel[j] > 0 && vs_dtype_ok(gd), "vs_check_finite_multi: bad tensor %d", j);
+        J.g[j] = grads[j]; J.dt[j] = gd; J.n[j] = numel[j];
+        const int64_t chunks = (numel[j] + AD_CHUNK - 1) / AD_CHUNK;
+        VS_CHECK_ARG(J.chunk_off[j] + chunks < (1ll << 30), "vs_check_finite_multi: too many elements");
+        J.chunk_off[j + 1] = J.chunk_off[j] + (int)chunks;
+    }
+    int blocks = J.chunk_off[n_tensors];
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(check_finite_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J, found_inf);
+    VS_CHECK_LAUNCH("vs_check_finite_multi");
+    return VS_OK;
+}
+
+extern "C" int vs_loss_scale_update(float* state, float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+    VS_CHECK_ARG(state && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 1, "vs_loss_scale_update: bad argument");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, growth_factor, backoff_factor, growth_interval);
+    VS_CHECK_LAUNCH("vs_loss_scale_update");
     return VS_OK;
 }

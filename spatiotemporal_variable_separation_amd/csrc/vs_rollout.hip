@@ -44,8 +44,10 @@ struct RollParams {
     unsigned* m2_save;           // same for h2  (both [nb, n-1, B, P, 32]: one word per part)
     int P;                       // workgroups per slab (hidden dimension split)
     unsigned long long* xbuf;    // exchange area [2][nslabs][P][16*Cf] of {epoch, value} granules
-    unsigned* xerr;              // timeout flag (last 16 bytes of the workspace)
-    size_t xtotal;               // workspace bytes (zero-filled before every launch)
+    unsigned* xerr;              // STICKY timeout flag (last 16 bytes of the workspace: never zeroed by the library, the caller
+                                 // reads and clears it -- ops.rollout_exchange_error / train.check_rollout_exchange)
+    size_t xtotal;               // workspace bytes (all but the last 16 are zero-filled before every launch)
+    unsigned spin_limit;         // rounds a wait may take before it gives up (VS_ROLLOUT_SPIN_LIMIT, default 2^22)
     // backward
     const float* g;              // [B, n, C] gradient wrt every t_code
     float* dx0;                  // [B, C]
@@ -56,6 +58,7 @@ struct RollParams {
 
 template <int CT> struct RT;
 template <> struct RT<VS_BF16> { typedef __bf16 T; static constexpr int KS = 32; static constexpr int U = 8; };
+template <> struct RT<VS_F16> { typedef _Float16 T; static constexpr int KS = 32; static constexpr int U = 8; };
 template <> struct RT<VS_F32> { typedef float T; static constexpr int KS = 16; static constexpr int U = 4; };
 
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -67,6 +70,8 @@ __device__ __forceinline__ f32x4 mma16(const u32x4& av, const u32x4& bv, f32x4 a
     if constexpr (CT == VS_BF16) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&av), *reinterpret_cast<const bf16x8*>(&bv), acc,
                                                        0, 0, 0);
+    } else if constexpr (CT == VS_F16) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&av), *reinterpret_cast<const f16x8*>(&bv), acc, 0, 0, 0);
     } else {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(&av);
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bv);
@@ -300,6 +305,7 @@ struct Exchange {
     u64* base;            // [2][nslabs][P][16 * Cx]
     unsigned* err;
     int nslabs, P, Cx, slab, part;
+    unsigned spin_limit;
     __device__ __forceinline__ u64* slot(int buf, int who) const {
         return base + (((int64_t)buf * nslabs + slab) * P + who) * (16 * Cx);
     }
@@ -317,7 +323,7 @@ __device__ __forceinline__ float exchange_sum(const Exchange& x, unsigned epoch,
             u64 got = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
             while ((unsigned)(got >> 32) != epoch) {
-                if (++spins > (1u << 22)) { atomicOr(x.err, 1u); break; }
+                if (++spins > x.spin_limit) { atomicOr(x.err, 1u); break; }
                 __builtin_amdgcn_s_sleep(1);
                 got = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(NT) void rollout_fwd_kernel(RollParams p) {
     const int Hs = H / P, c_lo = part * Hs;                 // this workgroup's slice of the hidden dimension
     const int tilesH = (H + 15) / 16, tilesC = (C + 15) / 16, tilesS = (Hs + 15) / 16;
     const int stepsC = (C + KS - 1) / KS, stepsH = (H + KS - 1) / KS, stepsS = (Hs + KS - 1) / KS;
-    Exchange X{p.xbuf, p.xerr, nslabs, P, L.Cf, slab, part};
+    Exchange X{p.xbuf, p.xerr, nslabs, P, L.Cf, slab, part, p.spin_limit};
 
     // layer descriptors
     const LayerArgs A1{L.Ck, 0, 0, stepsC, stepsC, 0, tilesH, L.NpH, ksplit_for(tilesH, stepsC)};                     // h1 (all columns)
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(NT) void rollout_bwd_kernel(RollParams p) {
     const int Hs = H / P, c_lo = part * Hs;
     const int tilesH = (H + 15) / 16, tilesC = (C + 15) / 16, tilesS = (Hs + 15) / 16;
     const int stepsC = (C + KS - 1) / KS, stepsH = (H + KS - 1) / KS, stepsS = (Hs + KS - 1) / KS;
-    Exchange X{p.xbuf, p.xerr, nslabs, P, L.Cf, slab, part};
+    Exchange X{p.xbuf, p.xerr, nslabs, P, L.Cf, slab, part, p.spin_limit};
 
     const LayerArgs A3{L.Ck, 0, 0, stepsC, stepsC, 0, tilesH, L.NpH, ksplit_for(tilesH, stepsC)};                     // dh2 (all columns)
     const LayerArgs A2{L.Hk, 0, 0, stepsH, stepsH, P > 1 ? c_lo / 16 : 0, P > 1 ? tilesS : tilesH, L.NpH,
@@ -621,7 +627,6 @@ namespace wsr {
 constexpr int WT = 256;
 constexpr int XP = 40;            // LDS row pitch of the code operand (32 + 8: conflict-free ds_read_b128)
 constexpr int SP = 72;            // LDS row pitch of the hidden-slice operand (64 + 8)
-constexpr unsigned SPIN_LIMIT = 1u << 22;
 #ifndef WS_NAP
 #define WS_NAP 8                  // s_sleep units (64 clocks) between seeing the producer's input and polling its partials
 #endif
@@ -671,16 +676,27 @@ template <> struct GranulePairs<9> {
 // block-step only order LDS traffic, so they wait for the LDS counter alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+template <int CT>
 __device__ __forceinline__ f32x4 mma(const u32x4& a, const u32x4& b, f32x4 acc) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
+    if constexpr (CT == VS_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), acc, 0, 0, 0);
 }
-// two fp32 -> one dword of two bf16 (round to nearest even, hardware convert)
+// two fp32 -> one dword of two bf16 / fp16 (round to nearest even, hardware convert)
+template <int CT>
 __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = {(__bf16)lo, (__bf16)hi};
-    return *reinterpret_cast<unsigned*>(&v);
+    if constexpr (CT == VS_BF16) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 v = {(__bf16)lo, (__bf16)hi};
+        return *reinterpret_cast<unsigned*>(&v);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+        f16x2 v = {(_Float16)lo, (_Float16)hi};
+        return *reinterpret_cast<unsigned*>(&v);
+    }
 }
-// ReLU on two packed bf16: as signed 16-bit integers negative floats are negative, so max(x, 0) clears them
+// ReLU on two packed bf16 / fp16: as signed 16-bit integers negative floats are negative, so max(x, 0) clears them
 __device__ __forceinline__ unsigned pk_relu(unsigned v) {
     unsigned r;
     asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(v));
@@ -708,9 +724,9 @@ __device__ __forceinline__ void store_tile_masks(unsigned* dst, const u64* bal) 
 // next layer's weight fragments are loaded with).  Layer a -> layer b therefore never touches LDS: wave w computes the
 // feature tiles T = 4 j + w of layer a and contracts exactly those features in layer b (K split over the 4 waves, all 64
 // output features of the part); the four K-partials meet in LDS (16 KB, one barrier), wave w finishes output tile w.
-template <int KH, bool FWD>
+template <int KH, bool FWD, int CT>
 __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_pitch /* words per row of m1/m2 */, long long* dbg) {
-    typedef __bf16 T;
+    typedef typename RT<CT>::T T;
     constexpr int H = 32 * KH, P = KH / 2, NJ = KH / 2, NKB = NJ / 2 > 0 ? NJ / 2 : 1;
     static_assert(NJ % 2 == 0, "two layer-a tiles form one k-step of layer b");
     __shared__ __attribute__((aligned(16))) T xa[16 * XP];
@@ -815,7 +831,7 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
             // whole block-step of compute before the partials.  Phase 2: the partials are now ~1 us away -- after a fixed nap
             // every round fetches all granules, so the round that finds them complete IS the fetch.
             while ((unsigned)(gload(slot(epoch, P) + er * 32 + ec) >> 32) != epoch) {
-                if (++spins > SPIN_LIMIT) break;
+                if (++spins > p.spin_limit) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             __builtin_amdgcn_s_sleep(WS_NAP);
@@ -829,7 +845,7 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
 #pragma unroll
                 for (int s = 0; s <= P; ++s) ok = ok && v[s][1] == epoch && v[s][3] == epoch;
                 if (ok) break;
-                if (++spins > SPIN_LIMIT) { atomicOr(p.xerr, 1u); break; }
+                if (++spins > p.spin_limit) { atomicOr(p.xerr, 1u); break; }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -861,7 +877,7 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
             break;
         }
         const unsigned epoch_out = (unsigned)q + 1u;
-        *reinterpret_cast<unsigned*>(xa + er * XP + ec) = pk_bf16(xv[0], xv[1]);
+        *reinterpret_cast<unsigned*>(xa + er * XP + ec) = pk_bf16<CT>(xv[0], xv[1]);
         WS_STAMP(2);
         lds_barrier();
         WS_STAMP(3);
@@ -891,22 +907,22 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
         }
         if (FWD) ao = *reinterpret_cast<const f32x4*>(bias_a + 16 * own + 4 * g);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) aa[j] = mma(wa[j], xb, aa[j]);
-        ao = mma(wa_own, xb, ao);           // this wave's own tile once more, for the activation save (and the sign bits)
+        for (int j = 0; j < NJ; ++j) aa[j] = mma<CT>(wa[j], xb, aa[j]);
+        ao = mma<CT>(wa_own, xb, ao);           // this wave's own tile once more, for the activation save (and the sign bits)
         u32x4 hf[NKB];
 #pragma unroll
         for (int jj = 0; jj < NKB; ++jj) {
             f32x4 a0 = aa[2 * jj], a1 = aa[2 * jj + 1];
             if (FWD) {
-                hf[jj] = u32x4{pk_relu(pk_bf16(a0[0], a0[1])), pk_relu(pk_bf16(a0[2], a0[3])), pk_relu(pk_bf16(a1[0], a1[1])),
-                               pk_relu(pk_bf16(a1[2], a1[3]))};
+                hf[jj] = u32x4{pk_relu(pk_bf16<CT>(a0[0], a0[1])), pk_relu(pk_bf16<CT>(a0[2], a0[3])), pk_relu(pk_bf16<CT>(a1[0], a1[1])),
+                               pk_relu(pk_bf16<CT>(a1[2], a1[3]))};
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     a0[r] = keep_if(a0[r], mk_a[2 * jj][r], msh);          // ReLU mask of h2 gates dh2
                     a1[r] = keep_if(a1[r], mk_a[2 * jj + 1][r], msh);
                 }
-                hf[jj] = u32x4{pk_bf16(a0[0], a0[1]), pk_bf16(a0[2], a0[3]), pk_bf16(a1[0], a1[1]), pk_bf16(a1[2], a1[3])};
+                hf[jj] = u32x4{pk_bf16<CT>(a0[0], a0[1]), pk_bf16<CT>(a0[2], a0[3]), pk_bf16<CT>(a1[0], a1[1]), pk_bf16<CT>(a1[2], a1[3])};
             }
         }
 
@@ -918,7 +934,7 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
 #pragma unroll
             for (int jj = 0; jj < NKB; ++jj) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bb[i] = mma(wb[i][jj], hf[jj], bb[i]);
+                for (int i = 0; i < 4; ++i) bb[i] = mma<CT>(wb[i][jj], hf[jj], bb[i]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) pb[(w * 4 + i) * 64 + lane] = bb[i];
@@ -929,12 +945,12 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
                 u64 bal[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bal[r] = __ballot(ao[r] > 0.f);
-                pk = u32x2{pk_relu(pk_bf16(ao[0], ao[1])), pk_relu(pk_bf16(ao[2], ao[3]))};
+                pk = u32x2{pk_relu(pk_bf16<CT>(ao[0], ao[1])), pk_relu(pk_bf16<CT>(ao[2], ao[3]))};
                 if (lane == 0) store_tile_masks(p.m1_save + mofs + mown, bal);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ao[r] = keep_if(ao[r], mk_ao[r], msh);
-                pk = u32x2{pk_bf16(ao[0], ao[1]), pk_bf16(ao[2], ao[3])};
+                pk = u32x2{pk_bf16<CT>(ao[0], ao[1]), pk_bf16<CT>(ao[2], ao[3])};
             }
             if (vrow) {
                 T* dst = (FWD ? (T*)p.h1_save : (T*)p.dh2_save) + (sbase + c) * H + 16 * own + 4 * g;
@@ -958,12 +974,12 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
                 u64 bal[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bal[r] = __ballot(sum[r] > 0.f);
-                pk = u32x2{pk_relu(pk_bf16(sum[0], sum[1])), pk_relu(pk_bf16(sum[2], sum[3]))};
+                pk = u32x2{pk_relu(pk_bf16<CT>(sum[0], sum[1])), pk_relu(pk_bf16<CT>(sum[2], sum[3]))};
                 if (lane == 0) store_tile_masks(p.m2_save + mofs + mown, bal);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sum[r] = keep_if(sum[r], mk_b[r], msh);            // ReLU mask of h1 gates dh1
-                pk = u32x2{pk_bf16(sum[0], sum[1]), pk_bf16(sum[2], sum[3])};
+                pk = u32x2{pk_bf16<CT>(sum[0], sum[1]), pk_bf16<CT>(sum[2], sum[3])};
             }
             *reinterpret_cast<u32x2*>(ah2 + c * SP + 16 * w + 4 * g) = pk;
             if (vrow) {
@@ -979,8 +995,8 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
         if (w < 2) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const T* arow = ah2 + c * SP + g * 8;
-            acc = mma(*reinterpret_cast<const u32x4*>(arow), wc[0], acc);
-            acc = mma(*reinterpret_cast<const u32x4*>(arow + 32), wc[1], acc);
+            acc = mma<CT>(*reinterpret_cast<const u32x4*>(arow), wc[0], acc);
+            acc = mma<CT>(*reinterpret_cast<const u32x4*>(arow + 32), wc[1], acc);
             u64* dst = slot(epoch_out, part) + 16 * w + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) gstore(dst + (4 * g + r) * 32, ((u64)epoch_out << 32) | (u64)__float_as_uint(acc[r]));
@@ -993,7 +1009,7 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
 
 // usable when the register-resident fragments and the one-workgroup-per-(slab, block, part) grid fit
 inline bool usable(int compute, int B, int C, int H, int nb) {
-    if (compute != VS_BF16 || C > 32 || (H != 128 && H != 256 && H != 512)) return false;
+    if (!vs_is16(compute) || C > 32 || (H != 128 && H != 256 && H != 512)) return false;
     const int nslabs = (B + 15) / 16, P = H / 64;
     // all workgroups must be co-resident (they wait for each other): one per CU, with headroom for whatever else is running
     static int cus = -1;
@@ -1016,7 +1032,7 @@ inline size_t exchange_bytes(int B, int H) {
 
 int pick_parts(int compute, int B, int C, int H) {
     // split the hidden dimension over P workgroups per slab when slices stay MFMA/k-step aligned and LDS-friendly
-    const int KS = compute == VS_BF16 ? 32 : 16;
+    const int KS = compute != VS_F32 ? 32 : 16;
     const int nslabs = (B + 15) / 16;
     int P = 1;
     for (int cand = 2; cand <= 8; cand *= 2) {
@@ -1030,8 +1046,9 @@ int pick_parts(int compute, int B, int C, int H) {
     return P;
 }
 
-int launch_ws(bool fwd, const RollParams& p, int mask_pitch, size_t workspace_bytes, hipStream_t stream) {
-    if (vs_zero_async(p.xbuf, workspace_bytes, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: zero fill failed");
+int launch_ws(int compute, bool fwd, const RollParams& p, int mask_pitch, size_t workspace_bytes, hipStream_t stream) {
+    if (vs_zero_async(p.xbuf, p.xtotal - 16, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: zero fill failed");
+    (void)workspace_bytes;
     const int nslabs = (p.B + 15) / 16, P = p.H / 64;
     dim3 grid((unsigned)(nslabs * p.nb * P)), block(wsr::WT);
     long long* dbg = nullptr;
@@ -1043,8 +1060,13 @@ int launch_ws(bool fwd, const RollParams& p, int mask_pitch, size_t workspace_by
 #endif
 #define VS_WS_LAUNCH(KH)                                                                                              \
     do {                                                                                                              \
-        if (fwd) hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, true>), grid, block, 0, stream, p, mask_pitch, dbg);  \
-        else hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, false>), grid, block, 0, stream, p, mask_pitch, dbg);     \
+        if (compute == VS_BF16) {                                                                                     \
+            if (fwd) hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, true, VS_BF16>), grid, block, 0, stream, p, mask_pitch, dbg);  \
+            else hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, false, VS_BF16>), grid, block, 0, stream, p, mask_pitch, dbg);     \
+        } else {                                                                                                      \
+            if (fwd) hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, true, VS_F16>), grid, block, 0, stream, p, mask_pitch, dbg);   \
+            else hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, false, VS_F16>), grid, block, 0, stream, p, mask_pitch, dbg);      \
+        }                                                                                                             \
     } while (0)
     if (p.H == 512) VS_WS_LAUNCH(16);
     else if (p.H == 256) VS_WS_LAUNCH(8);
@@ -1085,7 +1107,7 @@ int launch_roll(bool fwd, const RollParams& p, hipStream_t stream) {
     }
     const int nslabs = (p.B + 15) / 16;
     if (p.P > 1) {
-        if (vs_zero_async(p.xbuf, p.xtotal, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: zero fill failed");
+        if (vs_zero_async(p.xbuf, p.xtotal - 16, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: zero fill failed");
     }
     dim3 grid((unsigned)(nslabs * p.P));
     if (fwd) hipLaunchKernelGGL(rollout_fwd_kernel<CT>, grid, dim3(NT), smem, stream, p);
@@ -1095,13 +1117,20 @@ int launch_roll(bool fwd, const RollParams& p, hipStream_t stream) {
 }
 
 int check_common(int compute, int B, int C, int H, int nb, int n) {
-    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "vs_mlp_rollout: compute type %d", compute);
+    VS_CHECK_ARG(vs_dtype_ok(compute), "vs_mlp_rollout: compute type %d", compute);
     VS_CHECK_ARG(B > 0 && C > 0 && H > 0 && n >= 1, "vs_mlp_rollout: bad sizes B=%d C=%d H=%d n=%d", B, C, H, n);
     VS_CHECK_ARG(nb >= 1 && nb <= MAXB, "vs_mlp_rollout: n_blocks=%d (supported: 1..%d)", nb, MAXB);
     return VS_OK;
 }
 
+inline unsigned spin_limit_from_env() {
+    const char* e = getenv("VS_ROLLOUT_SPIN_LIMIT");            // test aid: a tiny limit forces the time-out path
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (unsigned)v : (1u << 22);
+}
+
 int setup_exchange(RollParams& p, int compute, void* workspace, size_t workspace_bytes) {
+    p.spin_limit = spin_limit_from_env();
     p.P = pick_parts(compute, p.B, p.C, p.H);
     const int nslabs = (p.B + 15) / 16, Cf = round_up(p.C, 4);
     const size_t need = (size_t)2 * nslabs * p.P * 16 * Cf * sizeof(u64) + 16;
@@ -1114,6 +1143,7 @@ int setup_exchange(RollParams& p, int compute, void* workspace, size_t workspace
 
 // weight-stationary form: same decision in both directions (the sign-bit layout differs from the slab form)
 bool setup_ws(RollParams& p, int compute, void* workspace, size_t workspace_bytes, int* mask_pitch) {
+    p.spin_limit = spin_limit_from_env();
     if (!wsr::usable(compute, p.B, p.C, p.H, p.nb) || p.n < 2) return false;
     if (!workspace || workspace_bytes < wsr::exchange_bytes(p.B, p.H) + 16) return false;
     p.xbuf = (u64*)workspace;
@@ -1130,7 +1160,7 @@ extern "C" int vs_mlp_rollout_parts(int compute, int B, int C, int H) { return p
 extern "C" size_t vs_mlp_rollout_workspace_bytes(int compute, int B, int C, int H) {
     const int P = pick_parts(compute, B, C, H);
     size_t need = P > 1 ? (size_t)2 * ((B + 15) / 16) * P * 16 * round_up(C, 4) * sizeof(u64) + 16 : 0;
-    if (compute == VS_BF16 && C <= 32 && (H == 128 || H == 256 || H == 512)) {       // weight-stationary form (any n_blocks)
+    if (vs_is16(compute) && C <= 32 && (H == 128 || H == 256 || H == 512)) {       // weight-stationary form (any n_blocks)
         const size_t ws = wsr::exchange_bytes(B, H) + 16;
         if (ws > need) need = ws;
     }
@@ -1151,9 +1181,10 @@ extern "C" int vs_mlp_rollout_fwd(int compute, int B, int C, int H, int n_blocks
     p.x0 = x0; p.t_codes = t_codes; p.residuals = residuals;
     p.xin_save = xin_save; p.h1_save = h1_save; p.h2_save = h2_save; p.m1_save = m1_save; p.m2_save = m2_save;
     int mask_pitch = 0;
-    if (setup_ws(p, compute, workspace, workspace_bytes, &mask_pitch)) return launch_ws(true, p, mask_pitch, p.xtotal, (hipStream_t)stream);
+    if (setup_ws(p, compute, workspace, workspace_bytes, &mask_pitch)) return launch_ws(compute, true, p, mask_pitch, p.xtotal, (hipStream_t)stream);
     setup_exchange(p, compute, workspace, workspace_bytes);
-    return compute == VS_BF16 ? launch_roll<VS_BF16>(true, p, (hipStream_t)stream) : launch_roll<VS_F32>(true, p, (hipStream_t)stream);
+    return compute == VS_BF16 ? launch_roll<VS_BF16>(true, p, (hipStream_t)stream)
+           : compute == VS_F16 ? launch_roll<VS_F16>(true, p, (hipStream_t)stream) : launch_roll<VS_F32>(true, p, (hipStream_t)stream);
 }
 
 extern "C" int vs_mlp_rollout_bwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* grad_t_codes,
@@ -1172,9 +1203,10 @@ extern "C" int vs_mlp_rollout_bwd(int compute, int B, int C, int H, int n_blocks
     p.m1_save = const_cast<uint32_t*>(m1_save); p.m2_save = const_cast<uint32_t*>(m2_save);
     p.dr_save = dr_save; p.dh2_save = dh2_save; p.dh1_save = dh1_save;
     int mask_pitch = 0;
-    if (setup_ws(p, compute, workspace, workspace_bytes, &mask_pitch)) return launch_ws(false, p, mask_pitch, p.xtotal, (hipStream_t)stream);
+    if (setup_ws(p, compute, workspace, workspace_bytes, &mask_pitch)) return launch_ws(compute, false, p, mask_pitch, p.xtotal, (hipStream_t)stream);
     setup_exchange(p, compute, workspace, workspace_bytes);
-    return compute == VS_BF16 ? launch_roll<VS_BF16>(false, p, (hipStream_t)stream) : launch_roll<VS_F32>(false, p, (hipStream_t)stream);
+    return compute == VS_BF16 ? launch_roll<VS_BF16>(false, p, (hipStream_t)stream)
+           : compute == VS_F16 ? launch_roll<VS_F16>(false, p, (hipStream_t)stream) : launch_roll<VS_F32>(false, p, (hipStream_t)stream);
 }
 
 // dst[c, r] = (dst_dtype) src[r, c]   (src row-major [rows, cols]); transposed bf16/fp32 weight copies for the backward rollout
@@ -1274,9 +1306,9 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(PackJobs J) {
 
 extern "C" int vs_pack_rollout_weights(int compute, int n_jobs, const float* const* src, const int* transpose, const int* N, const int* K,
                                        void* const* dst, void* stream) {
-    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "vs_pack_rollout_weights: compute type %d", compute);
+    VS_CHECK_ARG(vs_dtype_ok(compute), "vs_pack_rollout_weights: compute type %d", compute);
     VS_CHECK_ARG(n_jobs >= 1 && n_jobs <= PK_MAXJ && src && transpose && N && K && dst, "vs_pack_rollout_weights: bad argument (1..%d jobs)", PK_MAXJ);
-    const int KS = compute == VS_BF16 ? 32 : 16;
+    const int KS = compute != VS_F32 ? 32 : 16;
     PackJobs J;
     J.nj = n_jobs;
     J.unit_off[0] = 0;
@@ -1288,25 +1320,28 @@ extern "C" int vs_pack_rollout_weights(int compute, int n_jobs, const float* con
     long long blocks = (J.unit_off[n_jobs] + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (compute == VS_BF16) hipLaunchKernelGGL(pack_multi_kernel<VS_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
+    else if (compute == VS_F16) hipLaunchKernelGGL(pack_multi_kernel<VS_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
     else hipLaunchKernelGGL(pack_multi_kernel<VS_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
     VS_CHECK_LAUNCH("vs_pack_rollout_weights");
     return VS_OK;
 }
 
 extern "C" size_t vs_rollout_packed_elems(int compute, int N, int K) {
-    const int KS = compute == VS_BF16 ? 32 : 16;
+    const int KS = compute != VS_F32 ? 32 : 16;
     return (size_t)((N + 15) / 16) * 16 * (size_t)((K + KS - 1) / KS) * KS;
 }
 
 extern "C" int vs_pack_rollout_weight(int compute, const float* src, int transpose, int N, int K, void* dst, void* stream) {
-    VS_CHECK_ARG(compute == VS_F32 || compute == VS_BF16, "vs_pack_rollout_weight: compute type %d", compute);
+    VS_CHECK_ARG(vs_dtype_ok(compute), "vs_pack_rollout_weight: compute type %d", compute);
     VS_CHECK_ARG(src && dst && N > 0 && K > 0, "vs_pack_rollout_weight: bad argument");
-    const int KS = compute == VS_BF16 ? 32 : 16;
+    const int KS = compute != VS_F32 ? 32 : 16;
     int64_t units = (int64_t)((N + 15) / 16) * ((K + KS - 1) / KS) * 64;
     int64_t blocks = (units + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (compute == VS_BF16)
         hipLaunchKernelGGL(pack_kernel<VS_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, transpose, N, K, (__bf16*)dst);
+    else if (compute == VS_F16)
+        hipLaunchKernelGGL(pack_kernel<VS_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, transpose, N, K, (_Float16*)dst);
     else
         hipLaunchKernelGGL(pack_kernel<VS_F32>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, transpose, N, K, (float*)dst);
     VS_CHECK_LAUNCH("vs_pack_rollout_weight");

@@ -6,6 +6,8 @@ Precision policy (`set_precision` / `precision(...)`):
   'bf16' -- GEMM operands and hidden activations in bf16, fp32 accumulation, fp32 master weights / gradients /
             codes / frames / losses.  bf16 shadow copies of the weights are refreshed when the parameter's
             version counter changes (i.e. once per optimizer step).
+  'fp16' -- the same rounding points with IEEE half operands (v_mfma_f32_*_f16): the reference's --torch_amp mode
+            (torch.cuda.amp autocast, train.py:96-97); trained with dynamic loss scaling (train.LossScaler).
 """
 import contextlib
 
@@ -18,7 +20,7 @@ _STATE = {'precision': 'fp32'}
 
 
 def set_precision(p):
-    assert p in ('fp32', 'bf16'), p
+    assert p in ('fp32', 'bf16', 'fp16'), p
     _STATE['precision'] = p
 
 
@@ -85,7 +87,7 @@ def flush_bn_call_counts():
 
 
 def compute_dtype():
-    return torch.float32 if _STATE['precision'] == 'fp32' else torch.bfloat16
+    return {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[_STATE['precision']]
 
 
 # ------------------------------------------------------------------------------------------------ side streams
@@ -195,8 +197,8 @@ def shadow(p, dtype):
         return p.detach()
     key = id(p)
     ent = _shadow.get(key)
-    if ent is None or ent[0] != p._version or ent[1].data_ptr() == 0 or ent[2] is not p:
-        buf = ent[1] if ent is not None and ent[2] is p and ent[1].shape == p.shape else None
+    if ent is None or ent[0] != p._version or ent[1].data_ptr() == 0 or ent[2] is not p or ent[1].dtype != dtype:
+        buf = ent[1] if ent is not None and ent[2] is p and ent[1].shape == p.shape and ent[1].dtype == dtype else None
         buf = ops.cast(p.detach(), dtype, out=buf)
         _shadow[key] = (p._version, buf, p)
         return buf
@@ -206,7 +208,8 @@ def shadow(p, dtype):
 def shadow_buffer_for_update(p):
     """The live bf16 operand copy of `p`, if one exists: the optimizer kernel rewrites it in the pass that updates `p`."""
     ent = _shadow.get(id(p))
-    if ent is not None and ent[2] is p and ent[1].shape == p.shape and ent[1].dtype == torch.bfloat16 and ent[1].is_contiguous():
+    if ent is not None and ent[2] is p and ent[1].shape == p.shape and ent[1].dtype == compute_dtype() and ent[1].dtype != torch.float32 \
+            and ent[1].is_contiguous():
         return ent[1]
     return None
 
@@ -219,8 +222,9 @@ def shadows_written(params):
             _shadow[id(p)] = (p._version, ent[1], p)
 
 
-def refresh_shadows(params, dtype=torch.bfloat16):
+def refresh_shadows(params, dtype=None):
     """Re-cast every shadow in place (same storage) -- the form used inside a captured hipGraph step."""
+    dtype = dtype or compute_dtype()
     for p in params:
         key = id(p)
         ent = _shadow.get(key)
@@ -662,7 +666,7 @@ class MixCodes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, t_rand, t_codes, mixing):
         cdt = compute_dtype()
-        z, z_lowp = ops.mix_codes_fwd(s, t_rand, t_codes, mixing, lowp=cdt == torch.bfloat16)
+        z, z_lowp = ops.mix_codes_fwd(s, t_rand, t_codes, mixing, lowp=None if cdt == torch.float32 else cdt)
         ctx.save_for_backward(s, t_rand, t_codes)
         ctx.mixing = mixing
         if z_lowp is None:

@@ -21,8 +21,8 @@ from .train import train
 
 def load_dataset(args, device=None):
     """`--data_dir synthetic` needs nothing.  The WaveEq sets (main.py:91-102 of the reference) are this package's own HBM-resident
-    datasets (data/wave_eq.py: batches gathered on the device).  The other real datasets are loaded through the user's
-    `var_sep.data` package when it is importable (host-side code outside this package)."""
+    datasets (data/wave_eq.py: batches gathered on the device); Moving MNIST is generated on the device (data/moving_mnist.py).
+    Nothing here imports the reference package."""
     if args.data_dir == 'synthetic':
         return SyntheticSequences(args.data, args.nt_cond, args.nt_pred, length=args.synthetic_len,
                                   seed=args.seed or 1234, n_wave_points=args.n_wave_points)
@@ -32,30 +32,14 @@ def load_dataset(args, device=None):
             return WaveEq(args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred, True, args.downsample, device=device)
         return WaveEqPartial(args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred, True, args.downsample, args.n_wave_points,
                              device=device)
-    try:
-        if args.data == 'mnist':
-            from var_sep.data.moving_mnist import MovingMNIST
-            return MovingMNIST.make_dataset(args.data_dir, 64, args.nt_cond, args.nt_cond + args.nt_pred, 4, True,
-                                            args.n_object, True)
-        if args.data == 'chairs':
-            from var_sep.data.chairs import Chairs
-            return Chairs(True, args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred)
-        if args.data == 'taxibj':
-            from var_sep.data.taxibj import TaxiBJ
-            return TaxiBJ.make_datasets(args.data_dir, len_closeness=args.nt_cond + args.nt_pred,
-                                        nt_cond=args.nt_cond)[0]
-        if args.data == 'sst':
-            from var_sep.data.sst import SST
-            return SST(args.data_dir, args.nt_cond, args.nt_pred, True, zones=args.zones)
-        if args.data == 'wave':
-            from var_sep.data.wave_eq import WaveEq
-            return WaveEq(args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred, True, args.downsample)
-        from var_sep.data.wave_eq import WaveEqPartial
-        return WaveEqPartial(args.data_dir, args.nt_cond, args.nt_cond + args.nt_pred, True, args.downsample,
-                             args.n_wave_points)
-    except ImportError as e:
-        raise ImportError('dataset loaders are host-side code outside this package: put the reference\'s `var_sep` '
-                          'package on PYTHONPATH, or pass --data_dir synthetic (%s)' % e)
+    if args.data == 'mnist' and device is not None and torch.device(device).type == 'cuda':
+        from .data.moving_mnist import MovingMNIST                  # sequences generated on the device (data/moving_mnist.py)
+        return MovingMNIST.make_dataset(args.data_dir, 64, args.nt_cond, args.nt_cond + args.nt_pred, 4, True, args.n_object, True,
+                                        device=device, seed=args.seed)
+    raise NotImplementedError(
+        'dataset %r: only the synthetic batches (--data_dir synthetic), the WaveEq sets and Moving MNIST are built into this package; '
+        'the TaxiBJ / SST / chairs loaders of the reference are host-side file readers (h5py / netCDF4 / image folders) outside the '
+        'MI355X hot path -- wrap them in any torch Dataset yielding (cond, target) and call train() directly' % args.data)
 
 
 def main(argv=None):
@@ -75,6 +59,9 @@ def main(argv=None):
     torch.cuda.set_device(device)
 
     seed = np.random.randint(0, 10000) if args.seed is None else args.seed
+    if args.ddp:
+        from .parallel import broadcast_seed
+        seed = broadcast_seed(seed)  # rank 0's draw: without --seed every rank would otherwise draw its own
     torch.manual_seed(seed)
     np.random.seed(seed)            # identical on every rank: one t_random per global step
 
@@ -97,7 +84,16 @@ def main(argv=None):
     if world > 1:
         from torch.utils.data.distributed import DistributedSampler
         sampler = DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True, seed=seed)
-    if getattr(train_set, 'device_resident', False):
+    if getattr(train_set, 'generated_on_device', False):
+        # Moving MNIST: every item is a fresh video, indices mean nothing -- no sampler.  The draws come from the global NumPy
+        # stream like the reference's; with several ranks that stream is shared (it also draws t_random and must agree across
+        # replicas), so each rank gets a private stream for its videos and 1/world of the epoch
+        from .data.moving_mnist import DeviceMovingLoader
+        if world > 1:
+            train_set.rng = np.random.RandomState(seed + 7919 * (rank + 1))
+        epoch_len = int(os.environ['VARSEP_MMNIST_EPOCH_LEN']) if os.environ.get('VARSEP_MMNIST_EPOCH_LEN') else None   # default 200000 (reference)
+        train_loader = DeviceMovingLoader(train_set, args.batch_size, world=world, epoch_len=epoch_len)
+    elif getattr(train_set, 'device_resident', False):
         from .data.wave_eq import DeviceBatchLoader                # same sampler stream as the DataLoader below, one gather launch per batch
         train_loader = DeviceBatchLoader(train_set, args.batch_size, shuffle=sampler is None, sampler=sampler)
     else:
@@ -137,11 +133,17 @@ def main(argv=None):
     scheduler = lr_scheduler.MultiStepLR(optimizer, args.scheduler_milestones, gamma=args.scheduler_decay) \
         if args.scheduler else None
 
-    VF.set_precision(args.precision or ('bf16' if args.torch_amp else 'fp32'))
-    train(args.xp_dir if rank == 0 else os.path.join(args.xp_dir, f'rank{rank}'), train_loader, device, sep_net,
-          optimizer, scheduler, args.apex_amp, args.torch_amp, args.epochs, args.lamb_ae, args.lamb_s, args.lamb_t,
-          args.lamb_pred, args.offset, args.nt_cond, args.nt_pred, args.no_s, args.skipco, args.chkpt_interval,
-          args.architecture == 'encoderSST', grad_sync=grad_sync, log_interval=args.log_interval, hip_graph=args.hip_graph)
+    # --torch_amp keeps the reference's meaning (fp16 autocast + GradScaler, train.py:96-97); --precision names a mode explicitly
+    precision = args.precision or ('fp16' if args.torch_amp else 'fp32')
+    VF.set_precision(precision)
+    if rank == 0:
+        print('compute precision: %s%s' % (precision, ' + dynamic loss scaling' if precision == 'fp16' else ''))
+    from .train import make_loss_scaler
+    scaler = make_loss_scaler(device) if precision == 'fp16' else None
+    train(args.xp_dir, train_loader, device, sep_net, optimizer, scheduler, args.apex_amp, False, args.epochs, args.lamb_ae,
+          args.lamb_s, args.lamb_t, args.lamb_pred, args.offset, args.nt_cond, args.nt_pred, args.no_s, args.skipco,
+          args.chkpt_interval, args.architecture == 'encoderSST', grad_sync=grad_sync, log_interval=args.log_interval,
+          hip_graph=args.hip_graph, scaler=scaler)
 
 
 if __name__ == "__main__":

@@ -2,7 +2,9 @@
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, ACT, LAYOUT_R, LAYOUT_S, check, dtype_code, stream_ptr, require_cuda
+from ._lib import F32, BF16, F16, ACT, LAYOUT_R, LAYOUT_S, check, code_of, dtype_code, stream_ptr, require_cuda
+
+_DT = {F32: 'f32', BF16: 'bf16', F16: 'fp16'}
 
 _ws_cache = {}
 _retired = []
@@ -101,7 +103,7 @@ def gemm(a, layout_a, b, layout_b, M, N, K, out=None, out_dtype=torch.float32, a
                       mask.stride(0) if mask is not None else 0, dtype_code(mask) if mask is not None else 0,
                       ACT[mask_act], int(bool(accumulate)), _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()),
           'vs_gemm')
-    _pe(e0, 'vs_gemm<%s,%s%s>' % ('bf16' if compute == BF16 else 'f32', _LNAME[layout_a], _LNAME[layout_b]),
+    _pe(e0, 'vs_gemm<%s,%s%s>' % (_DT[compute], _LNAME[layout_a], _LNAME[layout_b]),
         flops=2.0 * M * N * K, nbytes=float((M * K + N * K) * a.element_size() + M * N * out.element_size()))
     return out
 
@@ -122,7 +124,7 @@ def gemm_batched(a, layout_a, b, layout_b, M, N, K, out_dtype=torch.float32):
     check(lib.vs_gemm_batched(compute, batch, M, N, K, a.data_ptr(), a.stride(1), a.stride(0), layout_a, b.data_ptr(), b.stride(1),
                               b.stride(0), layout_b, out.data_ptr(), N, M * N, dtype_code(out), 1.0, 0, _ptr(ws),
                               ws.numel() if ws is not None else 0, stream_ptr()), 'vs_gemm_batched')
-    _pe(e0, 'vs_gemm<%s,%s%s>' % ('bf16' if compute == BF16 else 'f32', _LNAME[layout_a], _LNAME[layout_b]),
+    _pe(e0, 'vs_gemm<%s,%s%s>' % (_DT[compute], _LNAME[layout_a], _LNAME[layout_b]),
         flops=2.0 * batch * M * N * K, nbytes=float(batch * ((M * K + N * K) * a.element_size() + M * N * out.element_size())))
     return out
 
@@ -231,18 +233,27 @@ def _rollout_workspace(nbytes, device):
     buf = _roll_ws.get(device.index)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
+            buf._vs_rollout_ws = True
             _retired.append(buf)
         buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         _roll_ws[device.index] = buf
     return buf
 
 
-def rollout_exchange_error(device):
-    """Non-zero iff a bounded spin of the rollout exchange timed out since the last launch (debug aid; synchronises)."""
-    buf = _roll_ws.get(device.index)
-    if buf is None:
-        return 0
-    return int(buf[-16:-12].view(torch.int32).item())
+def rollout_exchange_error(device, reset=True):
+    """Non-zero iff a bounded spin of the rollout exchange timed out in any launch since the last call (the word is sticky: the
+    library never clears it).  Synchronises the device (reads one word)."""
+    device = torch.device(device) if not isinstance(device, torch.device) else device
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    err = 0
+    for buf in [_roll_ws.get(index)] + [b for b in _retired if b.device.index == index and getattr(b, '_vs_rollout_ws', False)]:
+        if buf is None:
+            continue
+        word = buf[buf.numel() // 16 * 16 - 16:buf.numel() // 16 * 16 - 12].view(torch.int32)
+        err |= int(word.item())
+        if reset and err:
+            word.zero_()
+    return err
 
 
 def _ptr_array(tensors):
@@ -257,7 +268,7 @@ def pack_rollout_weight(w, dtype, transpose, out=None):
     assert w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32
     N, K = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
     lib = _lib.load_library()
-    code = BF16 if dtype == torch.bfloat16 else F32
+    code = code_of(dtype)
     n = lib.vs_rollout_packed_elems(code, N, K)
     if out is None:
         out = torch.empty((n,), dtype=dtype, device=w.device)
@@ -270,7 +281,7 @@ def pack_rollout_weights(jobs, dtype):
     """jobs: list of (fp32 weight [rows, cols], transpose, out buffer or None).  One launch; returns the packed buffers."""
     import ctypes
     lib = _lib.load_library()
-    code = BF16 if dtype == torch.bfloat16 else F32
+    code = code_of(dtype)
     outs = []
     for i in range(0, len(jobs), 48):
         chunk = jobs[i:i + 48]
@@ -319,7 +330,7 @@ def mlp_rollout_fwd(x0, weights, biases, n_steps, H, want_residuals=True):
                                                  xws.numel() if xws is not None else 0, stream_ptr()),
           'vs_mlp_rollout_fwd')
     fl = 2.0 * B * steps * nb * (2 * C * H + H * H)
-    _pe(e0, 'vs_mlp_rollout_fwd<%s>' % ('bf16' if cdt == torch.bfloat16 else 'f32'), flops=fl)
+    _pe(e0, 'vs_mlp_rollout_fwd<%s>' % _DT[code_of(cdt)], flops=fl)
     return t_codes, residuals, (xin, h1, h2, m1, m2)
 
 
@@ -346,7 +357,7 @@ def mlp_rollout_bwd(grad_t_codes, weights_t, h1, h2, m1, m2, n_steps):
                                                  _ptr(xws), xws.numel() if xws is not None else 0, stream_ptr()),
           'vs_mlp_rollout_bwd')
     fl = 2.0 * B * steps * nb * (2 * C * H + H * H)
-    _pe(e0, 'vs_mlp_rollout_bwd<%s>' % ('bf16' if cdt == torch.bfloat16 else 'f32'), flops=fl)
+    _pe(e0, 'vs_mlp_rollout_bwd<%s>' % _DT[code_of(cdt)], flops=fl)
     return dx0, dr, dh2, dh1
 
 
@@ -365,7 +376,7 @@ def conv_pack_weight(w_master, dtype, stride, pad, out=None):
     lib = _lib.load_library()
     if out is None:
         out = torch.empty((lib.vs_conv_packed_elems(D0, D1, kh, kw, stride, pad),), dtype=dtype, device=w_master.device)
-    check(lib.vs_conv_pack_weight(BF16 if dtype == torch.bfloat16 else F32, w_master.data_ptr(), D0, D1, kh, kw, stride, pad,
+    check(lib.vs_conv_pack_weight(code_of(dtype), w_master.data_ptr(), D0, D1, kh, kw, stride, pad,
                                   out.data_ptr(), stream_ptr()), 'vs_conv_pack_weight')
     return out
 
@@ -401,7 +412,7 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     e0 = _pb()
     check(fn(dtype_code(x), x.data_ptr(), w_arg.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W, Cout, k, k,
              stride, pad, _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()), 'vs_conv_fwd')
-    _pe(e0, 'vs_conv%s_fwd<%s>' % ('T' if transposed else '', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
+    _pe(e0, 'vs_conv%s_fwd<%s>' % ('T' if transposed else '', _DT[dtype_code(x)]),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
         nbytes=float(x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()))
     return y
@@ -430,7 +441,7 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     check(fn(dtype_code(dy), dy.data_ptr(), w_arg.data_ptr(), dx.data_ptr(), dtype_code(dx), B, Cin, H, W, Cout, k, k, stride, pad,
              _ptr(ws), ws.numel() if ws is not None else 0, *extra, stream_ptr()), 'vs_conv_dgrad')
     OH, OW = dy.shape[2], dy.shape[3]
-    _pe(e0, 'vs_conv%s_dgrad<%s>' % ('T' if transposed else '', 'bf16' if dy.dtype == torch.bfloat16 else 'f32'),
+    _pe(e0, 'vs_conv%s_dgrad<%s>' % ('T' if transposed else '', _DT[dtype_code(dy)]),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
         nbytes=float(dy.numel() * dy.element_size() + w.numel() * w.element_size() + dx.numel() * dx.element_size()))
     return dx
@@ -454,7 +465,7 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed):
     e0 = _pb()
     check(fn(dtype_code(x), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, k, k, stride, pad, _ptr(ws),
              ws.numel() if ws is not None else 0, stream_ptr()), 'vs_conv_wgrad')
-    _pe(e0, 'vs_conv%s_wgrad<%s>' % ('T' if transposed else '', 'bf16' if x.dtype == torch.bfloat16 else 'f32'),
+    _pe(e0, 'vs_conv%s_wgrad<%s>' % ('T' if transposed else '', _DT[dtype_code(x)]),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
         nbytes=float(dy.numel() * dy.element_size() + x.numel() * x.element_size() + dw.numel() * 4))
     return dw
@@ -469,9 +480,11 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gro
     mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
     invstd = torch.empty((groups, C), dtype=torch.float32, device=x.device)
     scratch = torch.empty((groups, C), dtype=torch.float32, device=x.device) if running_mean is not None else None
+    e0 = _pb()
     check(_lib.load_library().vs_bn_stats(x.data_ptr(), dtype_code(x), B, C, HW, groups, mean.data_ptr(), invstd.data_ptr(),
                                           _ptr(scratch), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
                                           stream_ptr()), 'vs_bn_stats')
+    _pe(e0, 'vs_bn_stats', nbytes=float(x.numel() * x.element_size()))
     return mean, invstd
 
 
@@ -665,8 +678,8 @@ def gather_windows(data, item_idx, windows_per_seq, seq_len, pixel_idx=None, out
 _MIXING = {'concat': 0, 'mul': 1}
 
 
-def mix_codes_fwd(s, t_rand, t_codes, mixing, lowp=False):
-    """-> (z [B, 1+n, Cz] fp32, the same in bf16 or None); mixing 'concat' | 'mul' (mlp_encdec.py:43-48)."""
+def mix_codes_fwd(s, t_rand, t_codes, mixing, lowp=None):
+    """-> (z [B, 1+n, Cz] fp32, the same in the 16-bit dtype `lowp` or None); mixing 'concat' | 'mul' (mlp_encdec.py:43-48)."""
     require_cuda(s, t_rand, t_codes)
     assert s.dtype == t_rand.dtype == t_codes.dtype == torch.float32
     assert s.is_contiguous() and t_rand.is_contiguous() and t_codes.is_contiguous()
@@ -675,10 +688,10 @@ def mix_codes_fwd(s, t_rand, t_codes, mixing, lowp=False):
     assert t_rand.shape == (B, Ct) and t_codes.shape[0] == B
     Cz = Cs if mixing == 'mul' else Cs + Ct
     z = torch.empty((B, n + 1, Cz), dtype=torch.float32, device=s.device)
-    z_lowp = torch.empty((B, n + 1, Cz), dtype=torch.bfloat16, device=s.device) if lowp else None
+    z_lowp = torch.empty((B, n + 1, Cz), dtype=lowp, device=s.device) if lowp is not None else None
     e0 = _pb()
     check(_lib.load_library().vs_mix_codes_fwd(s.data_ptr(), t_rand.data_ptr(), t_codes.data_ptr(), B, n, Cs, Ct, _MIXING[mixing],
-                                               z.data_ptr(), _ptr(z_lowp), stream_ptr()), 'vs_mix_codes_fwd')
+                                               z.data_ptr(), _ptr(z_lowp), code_of(lowp) if lowp is not None else BF16, stream_ptr()), 'vs_mix_codes_fwd')
     _pe(e0, 'vs_mix_codes_fwd', nbytes=float(z.numel() * 8))
     return z, z_lowp
 
@@ -706,3 +719,29 @@ def frames_sse_bwd(frames, full, idx, coef):
                                                 coef.data_ptr(), out.data_ptr(), stream_ptr()), 'vs_frames_sse_bwd')
     _pe(e0, 'vs_frames_sse_bwd', nbytes=float(3 * frames.numel() * 4))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ fp16 loss scaling
+def check_finite_multi(grads, scale_state):
+    """scale_state[1] (found_inf) = 1 when any gradient tensor holds an inf / NaN; one launch per 64 tensors."""
+    import ctypes
+    require_cuda(scale_state, *grads)
+    assert scale_state.dtype == torch.float32 and scale_state.numel() >= 4
+    lib = _lib.load_library()
+    found = scale_state.data_ptr() + 4
+    for i in range(0, len(grads), 64):
+        chunk = grads[i:i + 64]
+        n = len(chunk)
+        for g in chunk:
+            assert g.is_contiguous()
+        VP, I32, I64 = ctypes.c_void_p * n, ctypes.c_int32 * n, ctypes.c_int64 * n
+        e0 = _pb()
+        check(lib.vs_check_finite_multi(n, VP(*[g.data_ptr() for g in chunk]), I32(*[dtype_code(g) for g in chunk]),
+                                        I64(*[g.numel() for g in chunk]), found, stream_ptr()), 'vs_check_finite_multi')
+        _pe(e0, 'vs_check_finite_multi', nbytes=float(sum(g.numel() * g.element_size() for g in chunk)))
+
+
+def loss_scale_update(scale_state, growth_factor, backoff_factor, growth_interval):
+    require_cuda(scale_state)
+    check(_lib.load_library().vs_loss_scale_update(scale_state.data_ptr(), float(growth_factor), float(backoff_factor), int(growth_interval),
+                                                   stream_ptr()), 'vs_loss_scale_update')

@@ -104,7 +104,16 @@ class Adam(torch.optim.Optimizer):
         return tab
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale_state=None):
+        """`grad_scale_state` (train.LossScaler.state, fp32 [scale, found_inf, ...] on the device): gradients are used as g / scale and
+        the whole step -- parameters, moments, step count -- is skipped when found_inf is set (GradScaler.step semantics)."""
+        self._scale_state = grad_scale_state
+        try:
+            return self._step(closure)
+        finally:
+            self._scale_state = None
+
+    def _step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -125,7 +134,11 @@ class Adam(torch.optim.Optimizer):
             main = torch.cuda.current_stream(group['params'][0].device)
             if gi == 0 and self._launched:
                 main.wait_stream(self._stream)
-            _lib.check(lib.vs_adam_step_increment(group['step_dev'].data_ptr(), main.cuda_stream), 'vs_adam_step_increment')
+            if getattr(self, '_scale_state', None) is not None:
+                _lib.check(lib.vs_adam_step_increment_scaled(group['step_dev'].data_ptr(), self._scale_state.data_ptr(), main.cuda_stream),
+                           'vs_adam_step_increment_scaled')
+            else:
+                _lib.check(lib.vs_adam_step_increment(group['step_dev'].data_ptr(), main.cuda_stream), 'vs_adam_step_increment')
         if self._buckets:
             self._left = [len(b) for b in self._buckets]
             self._launched = set()
@@ -155,22 +168,32 @@ class Adam(torch.optim.Optimizer):
 
     def _update(self, gi, group, live):
         """One vs_adam_multi launch per 64 tensors of `live` on the current stream (the step counter is not touched)."""
-        from . import functional as VF
+        from . import functional as VF, ops
         lib = _lib.load_library()
         for p in live:
             if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or not p.grad.is_cuda:
                 raise VarsepHipError('HIP Adam needs contiguous fp32 CUDA gradients')
         stream = torch.cuda.current_stream(live[0].device).cuda_stream
         lr, (b1, b2), eps = group['lr'], group['betas'], group['eps']
+        scale_state = getattr(self, '_scale_state', None)
+        sdt = _lib.code_of(VF.compute_dtype()) if VF.compute_dtype() != torch.float32 else _lib.BF16
         for i in range(0, len(live), 64):
             chunk = live[i:i + 64]
             shadows = [VF.shadow_buffer_for_update(p) for p in chunk]
             tab = self._table(gi, chunk, shadows)
-            rc = lib.vs_adam_multi(len(chunk), ctypes.cast(tab[0], ctypes.c_void_p), ctypes.cast(tab[1], ctypes.c_void_p),
-                                   ctypes.cast(tab[7], ctypes.c_void_p), ctypes.cast(tab[2], ctypes.c_void_p), ctypes.cast(tab[3], ctypes.c_void_p),
-                                   ctypes.cast(tab[4], ctypes.c_void_p), ctypes.cast(tab[5], ctypes.c_void_p),
-                                   ctypes.cast(tab[6], ctypes.c_void_p), group['step_dev'].data_ptr(), lr, b1, b2, eps, stream)
+            e0 = ops._pb()
+            rc = lib.vs_adam_multi_scaled(len(chunk), ctypes.cast(tab[0], ctypes.c_void_p), ctypes.cast(tab[1], ctypes.c_void_p),
+                                          ctypes.cast(tab[7], ctypes.c_void_p), ctypes.cast(tab[2], ctypes.c_void_p),
+                                          ctypes.cast(tab[3], ctypes.c_void_p), ctypes.cast(tab[4], ctypes.c_void_p), sdt,
+                                          ctypes.cast(tab[5], ctypes.c_void_p), ctypes.cast(tab[6], ctypes.c_void_p),
+                                          group['step_dev'].data_ptr(), lr, b1, b2, eps,
+                                          None if scale_state is None else scale_state.data_ptr(), stream)
             _lib.check(rc, 'vs_adam_multi')
+            if e0 is not None:
+                # algorithmic bytes: p, m, v read + written (24 B), the gradient read (4 or 2 B), the 16-bit operand copy (2 B)
+                nb = sum(p.numel() * (24 + (2 if VF.lowp_gradient(p) is not None else 4) + (2 if s is not None else 0))
+                         for p, s in zip(chunk, shadows))
+                ops._pe(e0, 'vs_adam_multi', nbytes=float(nb))
         for p in live:
             # the kernel wrote through raw pointers: tell autograd / the operand caches that the parameter changed
             torch.autograd.graph.increment_version(p)
@@ -187,8 +210,8 @@ class Adam(torch.optim.Optimizer):
         sd = super().state_dict()
         for g in sd['param_groups']:
             g.pop('step_dev', None)
-        for st in sd['state'].values():
-            st.pop('skipped', None)
+        # super().state_dict() shares the live per-parameter dicts: strip the private entry from COPIES
+        sd['state'] = {k: {kk: vv for kk, vv in st.items() if kk != 'skipped'} for k, st in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):

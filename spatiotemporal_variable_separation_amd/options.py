@@ -22,7 +22,8 @@ def _build():
     g = p.add_argument_group(title='Mixed-precision training',
                              description='Choice of mixed-precision training library.').add_mutually_exclusive_group()
     g.add_argument('--torch_amp', action='store_true',
-                   help='Mixed precision: bf16 MFMA operands with fp32 accumulation and fp32 master weights.')
+                   help='Mixed precision as in the reference (torch.cuda.amp): fp16 MFMA operands, fp32 accumulation and master weights, '
+                        'dynamic loss scaling.  (--precision bf16 selects the bf16 mode, which needs no scaling.)')
     g.add_argument('--apex_amp', action='store_true', help='Rejected on MI355X (no Apex); kept for CLI compatibility.')
 
     g = p.add_argument_group(title='Distributed',
@@ -97,8 +98,9 @@ def _build():
     A('--n_object', type=int, metavar='NUMBER', default=2, help='Number of digits in the Moving MNIST data.')
 
     g = p.add_argument_group(title='MI355X', description='Additive options of the MI355X-native path.')
-    g.add_argument('--precision', type=str, default=None, choices=['fp32', 'bf16'],
-                   help='Compute precision of the HIP kernels (default fp32; --torch_amp implies bf16).')
+    g.add_argument('--precision', type=str, default=None, choices=['fp32', 'bf16', 'fp16'],
+                   help='Compute precision of the HIP kernels (default fp32).  fp16 = fp16 MFMA operands + dynamic loss scaling, '
+                        'which is what --torch_amp selects (as torch.cuda.amp in the reference); bf16 needs no loss scaling.')
     g.add_argument('--seed', type=int, default=None, help='Seed (the reference draws an unsaved random seed).')
     g.add_argument('--ddp', action='store_true',
                    help='Batch-sharded data parallelism: launch with torchrun, one process per GPU, RCCL all-reduce.')

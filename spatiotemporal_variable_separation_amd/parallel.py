@@ -20,6 +20,7 @@ class GradAllReducer:
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.buckets = []            # (flat, [params])
         self._pending = {}
@@ -202,3 +203,28 @@ def broadcast_module_state(module, src=0, process_group=None):
             t.data.copy_(host)
         else:
             dist.broadcast(t.data, src=src, group=process_group)
+
+
+def broadcast_buffers(module, src=0, process_group=None):
+    """Rank `src`'s buffers (BatchNorm running statistics, num_batches_tracked) to every replica: called at checkpoint time, the
+    replicas' statistics are per-replica in between (no SyncBN in the reference)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    staged = dist.get_backend(process_group) != 'nccl'
+    for t in module.buffers():
+        if staged and t.is_cuda:
+            host = t.data.cpu()
+            dist.broadcast(host, src=src, group=process_group)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t.data, src=src, group=process_group)
+
+
+def broadcast_seed(seed, src=0, process_group=None):
+    """One seed for every rank (rank `src`'s): the shuffle permutation of the DistributedSampler and the global NumPy stream that
+    draws `t_random` (train.py:72-75) must agree across replicas."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return int(seed)
+    box = [int(seed)]
+    dist.broadcast_object_list(box, src=src, group=process_group)
+    return int(box[0])

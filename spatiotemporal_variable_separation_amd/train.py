@@ -191,7 +191,7 @@ class GraphedStep:
     torch.optim.Adam(capturable=True); a learning-rate change by a scheduler triggers a re-recording."""
 
     def __init__(self, sep_net, optimizer, cond, target, nt_cond, nt_pred, offset, lambdas, average_tloss=False, warmup=3,
-                 side_streams=True, grad_sync=None):
+                 side_streams=True, grad_sync=None, scaler=None, keep_warmup_updates=False):
         assert cond.is_cuda, 'GraphedStep records a hipGraph: the batch must be on the GPU'
         self.mlp = _mlp_family(sep_net)
         self.skipco = bool(getattr(sep_net, 'skipco', False))
@@ -200,8 +200,8 @@ class GraphedStep:
         # side streams and direct gradient destinations need ONE gradient per parameter and step: true for the batched MLP-family
         # step only (a conv family calls E_s twice, its Linear layers get two contributions)
         self.side_streams = side_streams and self.mlp and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
-        check_optimizer(optimizer)
-        self.net, self.opt, self.sync = sep_net, optimizer, grad_sync
+        check_optimizer(optimizer, for_graph=True)
+        self.net, self.opt, self.sync, self.scaler = sep_net, optimizer, grad_sync, scaler
         self._one = torch.ones((), dtype=torch.float32, device=cond.device)
         if grad_sync is not None and self.mlp and getattr(grad_sync, 'lowp_views', None) and hasattr(optimizer, 'step_subset'):
             # the chains' weight gradients are produced, averaged and consumed as bf16 wire images (parallel.GradAllReducer)
@@ -217,6 +217,10 @@ class GraphedStep:
         self.T = cond.shape[1] + target.shape[1]
         self.nt_cond, self.offset = nt_cond, offset
         from .functional import flush_bn_call_counts as VF_flush
+        # the warm-up steps exist to size workspaces / build caches before the capture; they must not train: parameters, optimizer
+        # state, BatchNorm buffers, the loss scale and the NumPy stream (t_random) are put back afterwards, so the first replayed
+        # step is step 1 of the reference loop on batch 0 (keep_warmup_updates=True keeps them, e.g. for throughput runs)
+        snap = None if keep_warmup_updates else _TrainState(sep_net, optimizer, scaler)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -224,9 +228,11 @@ class GraphedStep:
                 self._draw()
                 self._fwd_bwd()
                 self._reduce()
-                self.opt.step()
+                self._opt_step()
                 VF_flush()
         torch.cuda.current_stream().wait_stream(side)
+        if snap is not None:
+            snap.restore()
         self._capture()
 
     def _capture(self):
@@ -238,7 +244,7 @@ class GraphedStep:
         if grad_sync is None:
             with torch.cuda.graph(self.graph):
                 self.loss = self._fwd_bwd()
-                self.opt.step()
+                self._opt_step()
         else:
             # data parallel: losses + backward into the reducer's flat gradient buckets in one graph, the bucket
             # all-reduces issued eagerly in between (4 RCCL calls at WaveEq size; no collective inside a capture), Adam in
@@ -246,7 +252,7 @@ class GraphedStep:
             with torch.cuda.graph(self.graph):
                 self.loss = self._fwd_bwd()
             self._reduce()
-            if hasattr(self.opt, 'step_subset') and os.environ.get('VARSEP_ADAM_PER_BUCKET', '1') == '1':
+            if self.scaler is None and hasattr(self.opt, 'step_subset') and os.environ.get('VARSEP_ADAM_PER_BUCKET', '1') == '1':
                 # one Adam recording per all-reduce bucket: the update of bucket i runs while buckets i+1.. are still on the wire
                 self.graph_opt = []
                 for _, plist in grad_sync.buckets:
@@ -261,7 +267,13 @@ class GraphedStep:
             else:
                 self.graph_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_opt):
-                    self.opt.step()
+                    self._opt_step()
+
+    def _opt_step(self):
+        if self.scaler is not None:
+            self.scaler.step(self.opt)               # finite check, unscale inside the update, skip on overflow, scale update
+        else:
+            self.opt.step()
 
     def _draw(self):
         hi = self.T if self.offset == 0 else self.T + 1
@@ -291,7 +303,8 @@ class GraphedStep:
             else:                                    # conv families: the reference's call structure with a device-side window
                 total, _, _, _ = compute_losses(self.cond, self.target, self.net, nt_cond, nt_pred, offset, self.skipco, l_ae, l_s,
                                                 l_t, l_pred, avg, t_random=self.t_dev)
-            total.backward(self._one)                # a resident 1.0: no ones_like fill per step
+            # a resident 1.0 (no ones_like fill per step), or the loss scale of fp16 training (train.py:152 scaler.scale(loss))
+            total.backward(self._one if self.scaler is None else self.scaler.scale_tensor())
             VF.join_side_streams()
         finally:
             VF.enable_side_streams(False)
@@ -352,12 +365,123 @@ def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False):
             optimizer.overlap_with_backward(buckets)
 
 
-def check_optimizer(optimizer):
+def check_optimizer(optimizer, for_graph=False):
     """torch's fused=True optimizers update parameters without bumping their version counters, which is what the bf16 operand
-    copies and the pre-packed weights are keyed on: training would silently continue on stale weights.  Refuse them."""
+    copies and the pre-packed weights are keyed on: training would silently continue on stale weights.  Refuse them.  A recorded
+    step (`for_graph`) additionally needs an optimizer whose step is capturable: optim.Adam (HIP) or torch's capturable=True."""
     if getattr(optimizer, 'defaults', {}).get('fused'):
         raise ValueError('torch optimizers with fused=True do not invalidate the bf16 operand copies / weight pre-packs of the HIP '
                          'path; use spatiotemporal_variable_separation_amd.optim.Adam (one HIP launch) or a non-fused optimizer')
+    if for_graph:
+        from .optim import Adam as HipAdam
+        if not isinstance(optimizer, HipAdam) and not getattr(optimizer, 'defaults', {}).get('capturable'):
+            raise ValueError('a recorded training step (hipGraph) needs spatiotemporal_variable_separation_amd.optim.Adam or a torch '
+                             'optimizer constructed with capturable=True')
+
+
+class _TrainState:
+    """Snapshot of everything one optimisation step changes -- parameters, BatchNorm buffers, optimizer state, loss scale and the
+    global NumPy stream (`t_random`, train.py:72-75) -- so that GraphedStep's warm-up steps leave no trace."""
+
+    def __init__(self, sep_net, optimizer, scaler=None):
+        self.tensors = [t for t in list(sep_net.parameters()) + list(sep_net.buffers())]
+        for group in optimizer.param_groups:
+            if isinstance(group.get('step_dev'), torch.Tensor):
+                self.tensors.append(group['step_dev'])
+        for st in optimizer.state.values():
+            self.tensors += [v for v in st.values() if isinstance(v, torch.Tensor)]
+        if scaler is not None:
+            self.tensors.append(scaler.state)
+        self.fresh_opt = optimizer if not optimizer.state else None       # state is created by the first step: drop it again
+        self.values = [t.detach().clone() for t in self.tensors]
+        self.np_state = np.random.get_state()
+        self.skipped = {id(p): st.get('skipped') for p, st in optimizer.state.items() if isinstance(st, dict) and 'skipped' in st}
+        self.opt = optimizer
+
+    def restore(self):
+        with torch.no_grad():
+            for t, v in zip(self.tensors, self.values):
+                t.copy_(v)                                # in-place: bumps the version counter, operand copies refresh themselves
+            if self.fresh_opt is not None:
+                for st in self.fresh_opt.state.values():                  # created during the warm-up: back to "never stepped"
+                    for v in st.values():
+                        if isinstance(v, torch.Tensor):
+                            v.zero_()
+                    if 'skipped' in st:
+                        st['skipped'] = 0
+                for group in self.fresh_opt.param_groups:
+                    if isinstance(group.get('step_dev'), torch.Tensor):
+                        group['step_dev'].zero_()
+            else:
+                for p, st in self.opt.state.items():
+                    if id(p) in self.skipped:
+                        st['skipped'] = self.skipped[id(p)]
+        np.random.set_state(self.np_state)
+
+
+class LossScaler:
+    """Dynamic loss scaling of fp16 training with torch.cuda.amp.GradScaler's semantics and defaults (reference train.py:96-97,
+    151-155: `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`), kept entirely on the device so the step
+    stays recordable into a hipGraph: `state` = [scale, found_inf, growth_tracker, skipped_steps] (fp32).
+
+      backward(loss)  -- d loss = scale (the scaled loss is never formed: the scale enters as the initial gradient);
+      step(optimizer) -- vs_check_finite_multi over every gradient sets found_inf; the Adam kernel multiplies gradients by 1/scale
+                         on the fly and leaves parameters, moments and the step count untouched when found_inf is set;
+                         vs_loss_scale_update then backs the scale off (x0.5) or grows it (x2 after 2000 clean steps)."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.init_scale = init_scale
+
+    def scale_tensor(self):
+        return self.state[0]
+
+    def get_scale(self):
+        return float(self.state[0].item())
+
+    def skipped_steps(self):
+        return int(self.state[3].item())
+
+    def backward(self, loss):
+        loss.backward(self.state[0])
+
+    def step(self, optimizer):
+        from . import functional as VF, ops
+        from .optim import Adam as HipAdam
+        if not isinstance(optimizer, HipAdam):
+            raise ValueError('fp16 loss scaling is implemented by spatiotemporal_variable_separation_amd.optim.Adam (device-side skip)')
+        grads = []
+        for group in optimizer.param_groups:
+            for p in group['params']:
+                g = VF.lowp_gradient(p)
+                g = p.grad if g is None else g
+                if g is not None:
+                    grads.append(g)
+        ops.check_finite_multi(grads, self.state)
+        optimizer.step(grad_scale_state=self.state)
+        ops.loss_scale_update(self.state, self.growth_factor, self.backoff_factor, self.growth_interval)
+
+    def describe(self):
+        return ('dynamic loss scaling (GradScaler semantics on the device: init %g, x%g after %d clean steps, x%g on overflow); '
+                'scale now %g, %d step(s) skipped' % (self.init_scale, self.growth_factor, self.growth_interval, self.backoff_factor,
+                                                      self.get_scale(), self.skipped_steps()))
+
+
+def make_loss_scaler(device, **kw):
+    return LossScaler(device, **kw)
+
+
+def check_rollout_exchange(device):
+    """The weight-stationary rollout kernels exchange partial sums between workgroups with bounded spins; a spin that gives up sets
+    an error word and the step's numbers are garbage.  Raise instead of training on (called at log / checkpoint time: it reads one
+    device word, i.e. synchronises)."""
+    from . import ops
+    from ._lib import VarsepHipError
+    err = ops.rollout_exchange_error(device)
+    if err:
+        raise VarsepHipError('rollout kernel: inter-workgroup exchange timed out (code %d) -- the integrator results of at least one '
+                             'step since the last check are invalid; not continuing' % err)
 
 
 def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb_ae, lamb_s, lamb_t, lamb_pred,
@@ -409,21 +533,27 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
 
 def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_amp, use_torch_amp, epochs, lamb_ae,
           lamb_s, lamb_t, lamb_pred, offset, nt_cond, nt_pred, no_s, skipco, chkpt_interval, average_tloss,
-          grad_sync=None, log_interval=None, hip_graph=False):
+          grad_sync=None, log_interval=None, hip_graph=False, scaler=None):
     """Same 20 positional arguments as the reference's `train` (train.py:91-92).
 
     Additive keyword arguments: `grad_sync` (a `parallel.GradAllReducer`, data-parallel gradient averaging over
-    RCCL), `log_interval` (print losses / frames-per-second every N steps) and `hip_graph` (record
-    the whole step once into a hipGraph -- `GraphedStep` -- and replay it; the optimizer must be optim.Adam or Adam(capturable=True)).  `use_apex_amp` is rejected (no
-    Apex on the MI355X path); `use_torch_amp` selects the bf16 compute mode, which needs no loss scaler.
+    RCCL), `log_interval` (print losses / frames-per-second every N steps), `hip_graph` (record
+    the whole step once into a hipGraph -- `GraphedStep` -- and replay it; the optimizer must be optim.Adam or Adam(capturable=True))
+    and `scaler` (a `LossScaler`; created here when `use_torch_amp` is set).  `use_apex_amp` is rejected (no Apex on the MI355X
+    path).  `use_torch_amp` has the reference's meaning (train.py:96-97, 151-155): fp16 compute (fp16 MFMA operands and hidden
+    activations, fp32 accumulation and master weights) with dynamic loss scaling; the bf16 mode is selected explicitly with
+    `functional.set_precision('bf16')` / `--precision bf16` and needs no scaler.
     """
     import time
     from . import functional as VF
     check_optimizer(optimizer)
     if use_apex_amp:
-        raise ImportError('Apex is not part of the MI355X-native path; use --torch_amp (bf16 MFMA, fp32 master weights)')
+        raise ImportError('Apex is not part of the MI355X-native path; use --torch_amp (fp16 MFMA + loss scaling, as torch.cuda.amp) '
+                          'or --precision bf16')
     if use_torch_amp:
-        VF.set_precision('bf16')
+        VF.set_precision('fp16')
+        if scaler is None:
+            scaler = LossScaler(device)
     if no_s:
         lamb_t = 0
         print("No regularization on T as there is no S")
@@ -431,55 +561,91 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
 
     step, t_last = 0, time.time()
     graphed = None
-    from . import functional as VF
-    # measured: folding repeated gradients (VF.fold_repeated_gradients) saves ~1000 tiny add launches per SST step on the GPU but
-    # costs more host time than autograd's own accumulation in an eager loop, and nothing measurable inside a recording: left off
-    VF.fold_repeated_gradients(os.environ.get('VARSEP_FOLD_GRADS') == '1' and grad_sync is None)
+    rank = grad_sync.rank if grad_sync is not None else 0
+    world = grad_sync.world_size if grad_sync is not None else 1
+    # folding repeated gradients (VF.fold_repeated_gradients) replaces ~1000 tiny add launches per SST step by one multi-tensor
+    # add per block; only valid without gradient hooks (the bucketed all-reduce counts hook calls)
+    VF.fold_repeated_gradients(os.environ.get('VARSEP_FOLD_GRADS', '1') == '1' and grad_sync is None)
+
+    def checkpoint(epoch_number=None):
+        # data parallel: replicas hold identical parameters; BatchNorm buffers are per replica (no SyncBN), rank 0's are the ones
+        # kept and broadcast so that every replica continues from what was saved; only rank 0 writes
+        check_rollout_exchange(device)
+        if grad_sync is not None and world > 1:
+            from .parallel import broadcast_buffers
+            broadcast_buffers(sep_net, process_group=grad_sync.group)
+        if rank == 0:
+            save(xp_dir, sep_net, epoch_number=epoch_number)
+
     try:
         for epoch in range(epochs):
             sep_net.train()
+            sampler = getattr(train_loader, 'sampler', None)
+            if hasattr(sampler, 'set_epoch'):
+                sampler.set_epoch(epoch)             # DistributedSampler: a new permutation per epoch, the same on every rank
             for cond, target in train_loader:
                 cond, target = cond.to(device, non_blocking=True), target.to(device, non_blocking=True)
                 if hip_graph:
                     if graphed is None:
                         graphed = GraphedStep(sep_net, optimizer, cond, target, nt_cond, nt_pred, offset,
-                                              (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss, grad_sync=grad_sync)
+                                              (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss, grad_sync=grad_sync, scaler=scaler)
                     if cond.shape == graphed.cond.shape:
                         total_loss = graphed.step(cond, target)
                         step += 1
                         if log_interval and step % log_interval == 0:
                             torch.cuda.synchronize()
+                            check_rollout_exchange(device)
                             dt, t_last = time.time() - t_last, time.time()
-                            world = grad_sync.world_size if grad_sync is not None else 1
-                            print(f'epoch {epoch} step {step}: total {total_loss.item():.5f} | '
-                                  f'{world * log_interval * cond.shape[0] * nt_pred / dt:.0f} frames/s (hipGraph)')
+                            if rank == 0:
+                                print(f'epoch {epoch} step {step}: total {total_loss.item():.5f} | '
+                                      f'{world * log_interval * cond.shape[0] * nt_pred / dt:.0f} frames/s (hipGraph)')
                         continue                     # a ragged last batch falls through to the eager path below
-                if grad_sync is not None:
-                    grad_sync.zero_grad()            # gradients are views into flat all-reduce buckets
-                else:
-                    optimizer.zero_grad()
-                total_loss, terms, _, _ = compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco,
-                                                         lamb_ae, lamb_s, lamb_t, lamb_pred, average_tloss)
-                total_loss.backward()
-                if grad_sync is not None:
-                    grad_sync.all_reduce()
-                optimizer.step()
+                # eager step.  After a recorded data-parallel step with directly written bf16 wire gradients, the chains' weight
+                # gradients of THIS step go through autograd into the fp32 buckets: switch the wire shortcut off for its duration,
+                # or the reducer would skip them and Adam would read the previous step's bf16 images
+                lowp_saved = None
+                if grad_sync is not None and getattr(grad_sync, 'direct_lowp', False):
+                    lowp_saved = dict(VF._LOWP_GRAD)
+                    grad_sync.direct_lowp = False
+                    VF.set_lowp_gradients(None)
+                try:
+                    if grad_sync is not None:
+                        grad_sync.zero_grad()            # gradients are views into flat all-reduce buckets
+                    else:
+                        optimizer.zero_grad()
+                    total_loss, terms, _, _ = compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco,
+                                                             lamb_ae, lamb_s, lamb_t, lamb_pred, average_tloss)
+                    if scaler is not None:
+                        scaler.backward(total_loss)
+                    else:
+                        total_loss.backward()
+                    if grad_sync is not None:
+                        grad_sync.all_reduce()
+                    if scaler is not None:
+                        scaler.step(optimizer)
+                    else:
+                        optimizer.step()
+                finally:
+                    if lowp_saved is not None:
+                        grad_sync.direct_lowp = True
+                        VF._LOWP_GRAD.update(lowp_saved)
                 VF.flush_bn_call_counts()
                 step += 1
                 if log_interval and step % log_interval == 0:
                     torch.cuda.synchronize()
+                    check_rollout_exchange(device)
                     dt = time.time() - t_last
                     t_last = time.time()
-                    world = grad_sync.world_size if grad_sync is not None else 1
                     fps = log_interval * cond.shape[0] * nt_pred * world / dt
-                    print(f'epoch {epoch} step {step}: total {total_loss.item():.5f} ' +
-                          ' '.join(f'{k} {v.item():.5f}' for k, v in terms.items()) + f' | {fps:.0f} frames/s')
+                    if rank == 0:
+                        print(f'epoch {epoch} step {step}: total {total_loss.item():.5f} ' +
+                              ' '.join(f'{k} {v.item():.5f}' for k, v in terms.items()) + f' | {fps:.0f} frames/s')
             if scheduler is not None:
                 scheduler.step()
             if chkpt_interval is not None and (epoch + 1) % chkpt_interval == 0:
-                save(xp_dir, sep_net, epoch_number=epoch + 1)
+                checkpoint(epoch + 1)
     except KeyboardInterrupt:
         pass
     finally:
         VF.fold_repeated_gradients(False)
-    save(xp_dir, sep_net)
+    checkpoint()

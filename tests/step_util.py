@@ -57,14 +57,17 @@ def hip_step(cfg, t_random, oracle_net, precision='fp32', fused=True):
     return net, total, terms, forecasts, t_codes
 
 
-def emulated_bf16_step(cfg, t_random):
-    """The fp32 oracle with the product's bf16 rounding points patched in (oracle/bf16_emu.py)."""
+_LOWP_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16}
+
+
+def emulated_bf16_step(cfg, t_random, precision='bf16'):
+    """The fp32 oracle with the product's bf16 (fp16) rounding points patched in (oracle/bf16_emu.py)."""
     from oracle.bf16_emu import emulate_bf16
-    with emulate_bf16():
+    with emulate_bf16(_LOWP_DTYPE[precision]):
         return oracle_step(cfg, t_random)
 
 
-def emulated_product_step(cfg, t_random):
+def emulated_product_step(cfg, t_random, precision='bf16'):
     """bf16 mode of the conv families: the product's module tree and host logic on the CPU with every functional entry point
     replaced by its bf16-rounding torch emulation (oracle/bf16_emu.py, second half)."""
     from oracle.bf16_emu import emulate_product_bf16
@@ -74,7 +77,7 @@ def emulated_product_step(cfg, t_random):
     o_net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
     lam = cfg['lambdas']
     lamb_t = 0 if cfg.get('no_s') else lam['t']
-    with emulate_product_bf16():
+    with emulate_product_bf16(_LOWP_DTYPE[precision]):
         net = build_sep_net(cfg)
         net.load_state_dict({k: v.clone() for k, v in o_net.state_dict().items()}, strict=True)
         net.train()
@@ -85,13 +88,13 @@ def emulated_product_step(cfg, t_random):
     return net, total, terms, forecasts, t_codes
 
 
-def compare_step_bf16_conv(cfg, t_random, tol_out=2e-3, tol_grad=5e-2):
+def compare_step_bf16_conv(cfg, t_random, tol_out=2e-3, tol_grad=5e-2, precision='bf16'):
     """HIP bf16 step of a conv family against the emulation above: same rounding points, so outputs / losses agree to
     accumulation-order noise and one-ulp bf16 flips (tol_out); gradients go through ill-conditioned per-call BatchNorm stacks at
     batch 2-3 (see compare_step), so they get the wider tol_grad -- still 10x tighter than anything bf16 vs fp32 could give."""
     o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
-    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, 'bf16')
-    e_net, e_total, e_terms, e_fore, e_tc = emulated_product_step(cfg, t_random)
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision)
+    e_net, e_total, e_terms, e_fore, e_tc = emulated_product_step(cfg, t_random, precision)
     errs = {'forecasts': rel_err(h_fore.detach().cpu().float(), e_fore.detach().float()),
             't_codes': rel_err(h_tc.detach().cpu().float(), e_tc.detach().float()),
             'total': abs(h_total.item() - e_total.item()) / abs(e_total.item())}
@@ -113,15 +116,15 @@ def compare_step_bf16_conv(cfg, t_random, tol_out=2e-3, tol_grad=5e-2):
     return errs
 
 
-def compare_step_bf16(cfg, t_random, tol=2e-3, sanity=0.6, emulate=True):
+def compare_step_bf16(cfg, t_random, tol=2e-3, sanity=0.6, emulate=True, precision='bf16'):
     """bf16 mode: (1) MLP family: must match the CPU emulation of its own rounding scheme to `tol` relative L2
     (accumulation-order noise only); (2) every family: outputs within 5e-2 and gradients within a loose `sanity` bound
     of the fp32 oracle (the conv kernels' bf16 arithmetic is pinned exactly, op by op, in tests/test_conv_gpu.py)."""
     o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
-    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, 'bf16')
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision)
     o_net, o_total, o_terms, o_fore, o_tc = oracle_step(cfg, t_random)
     if emulate:
-        e_net, e_total, e_terms, e_fore, e_tc = emulated_bf16_step(cfg, t_random)
+        e_net, e_total, e_terms, e_fore, e_tc = emulated_bf16_step(cfg, t_random, precision)
 
     def errors(r_net, r_total, r_fore, r_tc):
         rg = dict(r_net.named_parameters())

@@ -1,0 +1,144 @@
+"""GPU: the BASELINE.json configurations at FULL width and batch, one whole training step end to end.
+
+The reduced-width step tests (test_step_gpu.py) never reach the kernels the bench times: the weight-stationary rollout
+(hidden size 512), the column-matrix / LDS-staged convolution routes (>= 64 channels), the LDS-DMA GEMM tiles and the split-K
+plans of the 20480-wide encoder layer.  Here every BASELINE workload runs through `train.compute_losses` + backward + Adam at
+the size `bench.py` uses and is checked
+
+  (1) against the fixtures `tests/golden/full_<name>.npz`, which `oracle/make_golden.py full` recorded from the REFERENCE's own
+      `train()` step in the build container (checksums: sum, L2 norm, 16 samples of forecasts, codes, every gradient and every
+      post-Adam parameter; the four loss terms in full), and
+  (2) element-wise against the CPU oracle computed live on the GPU box (forecasts, codes, losses, gradients),
+
+in fp32 mode at the 1e-3 relative bar of BASELINE.json; the MLP workload additionally in bf16 / fp16 against the CPU emulation
+of the mode's rounding points.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+from oracle.detdata import det_fill
+from oracle.golden_configs import FULL_CONFIGS, make_batch
+from golden_util import check_tensor, load_golden, rel_err
+from step_util import grad_err, grad_floor, hip_step, oracle_step
+
+pytestmark = pytest.mark.gpu
+
+# oracle cost on the host (fp32, ~16 threads): waveeq 1 s, mnist_b16 1 s, mnist_b128 10 s, taxibj 8 s, sst (40 frames) ~1 min
+LIVE_ORACLE = ['full_waveeq', 'full_mnist_b16', 'full_mnist_b128', 'full_taxibj']
+
+
+def _fixture(name):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.npz')
+    if not os.path.exists(path):
+        pytest.skip('fixture %s.npz not generated' % name)
+    return load_golden(name)
+
+
+def _hip_training_step(cfg, t_random, precision='fp32'):
+    """compute_losses + backward + one Adam step (lr 4e-4, betas (0.9, 0.99): main.py:133 defaults) on the HIP path."""
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision)
+    grads = {k: p.grad.detach().clone() for k, p in h_net.named_parameters() if p.grad is not None}
+    opt = Adam(h_net.parameters(), lr=cfg.get('lr', 4e-4), betas=(0.9, 0.99))
+    opt.step()
+    torch.cuda.synchronize()
+    from spatiotemporal_variable_separation_amd import ops
+    assert ops.rollout_exchange_error(torch.device('cuda', torch.cuda.current_device())) == 0, 'rollout exchange timed out'
+    return h_net, h_total, h_terms, h_fore, h_tc, grads
+
+
+@pytest.mark.parametrize('name', list(FULL_CONFIGS))
+def test_full_size_step_matches_reference_fixture(name):
+    """HIP fp32 step vs the checksums the reference produced for the same (hash-filled) weights and batch."""
+    cfg = FULL_CONFIGS[name]
+    gold = _fixture(name)
+    h_net, h_total, h_terms, h_fore, h_tc, grads = _hip_training_step(cfg, int(gold['t_random']))
+    tol = 1e-3
+    assert abs(h_total.item() - float(gold['total'])) <= tol * abs(float(gold['total'])), (h_total.item(), float(gold['total']))
+    for k, v in h_terms.items():
+        ref = float(gold['loss:' + k])
+        assert abs(v.item() - ref) <= tol * max(abs(ref), 1e-6), f'loss {k}: {v.item()} vs {ref}'
+    worst = {'forecasts': check_tensor(gold, 'forecasts', h_fore, tol), 't_codes': check_tensor(gold, 't_codes', h_tc, tol)}
+    # gradients: checksum comparison at 2e-3 (sum / L2 / samples of each tensor); a conv bias in front of a training-mode
+    # BatchNorm has an exactly-zero gradient that the reference returns as summation noise -- compared on the scale of the
+    # whole gradient instead of its own (meaningless) norm
+    total_norm = np.sqrt(sum(float(gold[k][1]) ** 2 if k.startswith('cs:grad:') else float((gold[k].astype(np.float64) ** 2).sum())
+                             for k in gold if k.startswith('cs:grad:') or k.startswith('grad:')))
+    gw = 0.0
+    for k, g in grads.items():
+        key = 'grad:' + k
+        ref_norm = float(gold['cs:' + key][1]) if 'cs:' + key in gold else float(np.linalg.norm(gold[key].astype(np.float64)))
+        if ref_norm < 1e-4 * total_norm:
+            assert g.double().norm().item() <= 2e-4 * total_norm, f'{key}: should be ~0 on the scale of the whole gradient'
+            continue
+        gw = max(gw, check_tensor(gold, key, g, 2e-3))
+    worst['grad'] = gw
+    # parameters and BatchNorm buffers after the Adam step
+    pw = 0.0
+    for k, v in h_net.state_dict().items():
+        if k.endswith('num_batches_tracked'):
+            key = 'after:' + k
+            ref = gold[key] if key in gold else None
+            if ref is not None:
+                assert int(v) == int(ref), k
+            continue
+        pw = max(pw, check_tensor(gold, 'after:' + k, v.float(), 1e-3))
+    worst['after'] = pw
+    print(name, 'HIP fp32 vs reference fixture:', {k: '%.1e' % v for k, v in worst.items()})
+
+
+@pytest.mark.parametrize('name', LIVE_ORACLE)
+def test_full_size_step_matches_live_oracle_elementwise(name):
+    """Every element of forecasts / codes and every gradient tensor against the CPU oracle evaluated on this host."""
+    cfg = FULL_CONFIGS[name]
+    gold = _fixture(name)
+    t_random = int(gold['t_random'])
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    h_net, h_total, h_terms, h_fore, h_tc, grads = _hip_training_step(cfg, t_random)
+    o_net, o_total, o_terms, o_fore, o_tc = oracle_step(cfg, t_random)
+    errs = {'forecasts': rel_err(h_fore.detach().cpu(), o_fore.detach()), 't_codes': rel_err(h_tc.detach().cpu(), o_tc.detach()),
+            'total': abs(h_total.item() - o_total.item()) / abs(o_total.item())}
+    for k in o_terms:
+        errs['loss:' + k] = abs(h_terms[k].item() - o_terms[k].item()) / max(abs(o_terms[k].item()), 1e-8)
+    for k, v in errs.items():
+        assert v <= 1e-3, f'{k}: {v:.3e} > 1e-3'
+    floor = grad_floor(o_net)
+    og = dict(o_net.named_parameters())
+    worst = 0.0
+    for k, g in grads.items():
+        e = grad_err(g.cpu(), og[k].grad, floor)
+        worst = max(worst, e)
+        assert e <= 2e-3, f'gradient {k}: {e:.3e} > 2e-3 (fp32 HIP vs fp32 CPU oracle)'
+    errs['grad_worst'] = worst
+    print(name, 'HIP fp32 vs live oracle:', {k: '%.1e' % v for k, v in errs.items()})
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_full_size_waveeq_lowp_matches_rounding_point_emulation(precision):
+    """The WaveEq workload in the 16-bit modes: the weight-stationary rollout, split-K plans and LDS-DMA tiles run here; the
+    result must match the CPU emulation of the mode's rounding points (oracle/bf16_emu.py) to accumulation-order noise."""
+    from step_util import emulated_bf16_step
+    cfg = FULL_CONFIGS['full_waveeq']
+    gold = _fixture('full_waveeq')
+    t_random = int(gold['t_random'])
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision)
+    e_net, e_total, e_terms, e_fore, e_tc = emulated_bf16_step(cfg, t_random, precision)
+    errs = {'forecasts': rel_err(h_fore.detach().cpu(), e_fore.detach()), 't_codes': rel_err(h_tc.detach().cpu(), e_tc.detach()),
+            'total': abs(h_total.item() - e_total.item()) / abs(e_total.item())}
+    for k, v in errs.items():
+        assert v <= 2e-3, f'{k}: HIP {precision} vs emulation {v:.3e}'
+    floor = grad_floor(e_net)
+    eg = dict(e_net.named_parameters())
+    worst = max(grad_err(p.grad.detach().cpu(), eg[k].grad, floor) for k, p in h_net.named_parameters())
+    # one hidden unit whose pre-activation sits on a rounding boundary flips between the MFMA and the CPU summation order and
+    # moves a gradient row by its whole magnitude; over 1200-wide layers that is ~1e-3 of a tensor's norm
+    assert worst <= 2e-2, f'gradients: HIP {precision} vs emulation {worst:.3e}'
+    errs['grad_worst'] = worst
+    print('full_waveeq', precision, 'vs emulation:', {k: '%.1e' % v for k, v in errs.items()})

@@ -5,15 +5,20 @@ import torch
 
 from oracle import cpu_ref
 from oracle.detdata import det_fill
-from oracle.golden_configs import CONFIGS, make_batch
+from oracle.golden_configs import CONFIGS, FULL_CONFIGS, make_batch
 from golden_util import load_golden, check_tensor
 
 TOL = 1e-5          # fp32 CPU vs fp32 CPU; bit-exact in the build container, slack for other BLAS builds
 
 
-@pytest.mark.parametrize('name', list(CONFIGS))
+# the two BASELINE configurations whose full-size oracle step takes ~1 s of CPU are replayed here too; the larger ones
+# (Moving-MNIST B=128, TaxiBJ, SST with 40 predicted frames) are replayed against the HIP path in tests/test_baseline_gpu.py
+FULL_ON_CPU = ['full_waveeq', 'full_mnist_b16']
+
+
+@pytest.mark.parametrize('name', list(CONFIGS) + FULL_ON_CPU)
 def test_oracle_matches_reference_step(name):
-    cfg = CONFIGS[name]
+    cfg = CONFIGS[name] if name in CONFIGS else FULL_CONFIGS[name]
     gold = load_golden(name)
     torch.manual_seed(0)
     cond, target = make_batch(cfg)

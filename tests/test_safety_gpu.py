@@ -1,0 +1,127 @@
+"""GPU: failure paths that must be loud -- the rollout's bounded inter-workgroup waits, the bench's multi-rank launch, the eager
+fallback of a recorded data-parallel step."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.detdata import det_fill
+from oracle.golden_configs import CONFIGS, make_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rollout_exchange_timeout_is_sticky_and_raises():
+    """A wait that gives up (forced here with a spin limit of 1) leaves a STICKY error word: the next check raises, whatever ran
+    in between, and clears it."""
+    from spatiotemporal_variable_separation_amd import functional as VF, ops
+    from spatiotemporal_variable_separation_amd._lib import VarsepHipError
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.train import check_rollout_exchange, compute_losses
+    cfg = dict(CONFIGS['mlp_mul'], B=32, res_hidden_size=128, n_blocks=2)       # weight-stationary form: hidden 128, bf16
+    net = det_fill(build_sep_net(cfg), salt=cfg['salt']).cuda()
+    net.train()
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    lam = cfg['lambdas']
+    dev = cond.device
+
+    def run():
+        with VF.precision('bf16'):
+            total = compute_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], False, lam['ae'], lam['s'], lam['t'],
+                                   lam['pred'], t_random=4)[0]
+            total.backward()
+        torch.cuda.synchronize()
+        return total.item()
+    ref = run()
+    check_rollout_exchange(dev)                      # healthy run: nothing to report
+    os.environ['VS_ROLLOUT_SPIN_LIMIT'] = '1'
+    try:
+        run()
+    finally:
+        del os.environ['VS_ROLLOUT_SPIN_LIMIT']
+    again = run()                                    # a healthy launch afterwards must NOT clear the word
+    assert abs(again - ref) <= 1e-5 * abs(ref)
+    with pytest.raises(VarsepHipError, match='exchange timed out'):
+        check_rollout_exchange(dev)
+    check_rollout_exchange(dev)                      # cleared by the check that reported it
+    assert ops.rollout_exchange_error(dev) == 0
+
+
+def test_bench_gpus_2_launches_two_ranks():
+    """`python bench.py --gpus 2` starts two rank processes itself; on the one-GPU box they share cuda:0 and average gradients
+    over gloo (VARSEP_BENCH_SHARE_GPU=1).  The JSON line must say n_gpus 2 and a doubled global batch."""
+    env = dict(os.environ, VARSEP_BENCH_SHARE_GPU='1')
+    env.pop('RANK', None), env.pop('WORLD_SIZE', None), env.pop('LOCAL_RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--repeats', '2',
+                        '--batch', '32', '--no_cpu_baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 64 and out['config']['parallelism'] == 'dp2'
+    assert out['value'] > 0 and np.isfinite(out['config']['final_loss'])
+    assert 'gloo' in out['config']['grad_allreduce']
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.parallel import GradAllReducer, broadcast_module_state
+    from spatiotemporal_variable_separation_amd.train import chain_weight_parameters, train
+    cfg = dict(CONFIGS['mlp_mul'], B=8)
+    net = det_fill(build_sep_net(cfg), salt=cfg['salt']).cuda()
+    broadcast_module_state(net)
+    cond, target = make_batch(cfg)
+    per = 8 // world
+    sh = slice(rank * per, rank * per + per)
+    full = (cond[sh].cuda(), target[sh].cuda())
+    ragged = (cond[sh][:per - 1].cuda(), target[sh][:per - 1].cuda())            # the last batch of the epoch is one sample short
+    loader = [full, full, ragged]
+    sync = GradAllReducer(net.parameters(), bucket_bytes=16 << 10, comm_dtype=torch.bfloat16, lowp_direct=chain_weight_parameters(net))
+    opt = Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.99))
+    lam = cfg['lambdas']
+    np.random.seed(3)
+    VF.set_precision('bf16')
+    train(os.path.join(out_dir, 'xp'), loader, torch.device('cuda', 0), net, opt, None, False, False, 1, lam['ae'], lam['s'], lam['t'], lam['pred'],
+          cfg['offset'], cfg['nt_cond'], cfg['nt_pred'], False, False, None, False, grad_sync=sync, hip_graph=True)
+    # what the eager fallback must have used for its Adam step: the gradients of the RAGGED batch, averaged over the ranks
+    chain = chain_weight_parameters(net)
+    stale = []
+    for p in chain:
+        wire = sync.lowp_views[id(p)].float()
+        stale.append(float((p.grad - wire).abs().max()))                       # fp32 bucket (this step) vs bf16 wire image (previous step)
+    torch.save({'state': {k: v.detach().cpu() for k, v in net.state_dict().items()}, 'stale': stale,
+                'saved': os.path.exists(os.path.join(out_dir, 'xp', 'ov_Et.pt'))}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_ddp_graph_with_ragged_last_batch_uses_this_steps_gradients(tmp_path):
+    """--ddp --hip_graph --grad_comm bf16 with a ragged last batch: the eager fallback must average and apply the gradients of
+    THAT batch (it used to leave the Linear chains' weights on the previous step's bf16 wire images).  Replicas stay identical,
+    the fp32 buckets hold fresh gradients that differ from the stale wire images, and only rank 0 writes the checkpoint."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(os.path.join(tmp_path, 'rank0.pt')), torch.load(os.path.join(tmp_path, 'rank1.pt'))
+    for k in r0['state']:
+        assert torch.equal(r0['state'][k], r1['state'][k]), f'replicas diverged at {k}'
+    assert max(r0['stale']) > 0, 'the fp32 buckets of the chain weights were not written by the eager step'
+    assert r0['saved'] and r1['saved']               # same directory: rank 0 wrote it (rank 1 sees the files, wrote none itself)
+    assert not os.path.exists(os.path.join(tmp_path, 'xp', 'rank1'))
