@@ -66,26 +66,46 @@ CONFIGS = {
 # configs.BASELINE_CONFIGS, restated here because test infrastructure does not import the product).  Their tensors are far above
 # FULL_LIMIT, so the fixtures `tests/golden/full_<name>.npz` hold checksums (sum, L2, 16 samples) of forecasts, codes, every
 # gradient and every post-Adam parameter of ONE reference training step.
+# `res_scale`: det_fill's weights have gain ~1.2 per layer, which makes the residual integrator double the latent code at every
+# block; over the 14-40 steps x 1-3 blocks of the full recipes the code grows to 1e12 and the step becomes numerically meaningless
+# (the fp32 oracle itself then sits 1e-3 / O(1) away from its own fp64 evaluation on forecasts / gradients).  The integrator's
+# parameters are therefore scaled by `res_scale` after det_fill (`fill_net` below; the reference's own init uses gain 0.71-1.41 on
+# orthogonal matrices, i.e. a contraction of similar size).
 FULL_CONFIGS = {
-    'full_mnist_b16': dict(architecture='dcgan', shape=[1, 64, 64], nt_cond=5, nt_pred=10, offset=5, B=16, code_size_s=128,
+    'full_mnist_b16': dict(res_scale=0.3, architecture='dcgan', shape=[1, 64, 64], nt_cond=5, nt_pred=10, offset=5, B=16, code_size_s=128,
                            code_size_t=20, enc_hidden_size=64, dec_hidden_size=64, res_hidden_size=512, n_blocks=1,
                            mixing='concat', last_activation='sigmoid', skipco=False, lambdas=_L, salt=31),
-    'full_waveeq': dict(architecture='mlp', shape=[1, 64, 64], nt_cond=5, nt_pred=20, offset=5, B=128, code_size_s=32,
+    'full_waveeq': dict(res_scale=0.3, architecture='mlp', shape=[1, 64, 64], nt_cond=5, nt_pred=20, offset=5, B=128, code_size_s=32,
                         code_size_t=32, enc_hidden_size=1200, dec_hidden_size=1200, enc_n_layers=3, dec_n_layers=4,
                         res_hidden_size=512, n_blocks=3, mixing='mul', last_activation='sigmoid', skipco=False,
                         lambdas=dict(ae=1.0, s=45.0, t=0.001, pred=45.0), salt=32),
-    'full_mnist_b128': dict(architecture='dcgan', shape=[1, 64, 64], nt_cond=5, nt_pred=10, offset=5, B=128, code_size_s=128,
+    'full_mnist_b128': dict(res_scale=0.3, architecture='dcgan', shape=[1, 64, 64], nt_cond=5, nt_pred=10, offset=5, B=128, code_size_s=128,
                             code_size_t=20, enc_hidden_size=64, dec_hidden_size=64, res_hidden_size=512, n_blocks=1,
                             mixing='concat', last_activation='sigmoid', skipco=False, lambdas=_L, salt=33),
-    'full_taxibj': dict(architecture='vgg', shape=[2, 32, 32], nt_cond=4, nt_pred=4, offset=4, B=100, code_size_s=128,
+    'full_taxibj': dict(res_scale=0.3, architecture='vgg', shape=[2, 32, 32], nt_cond=4, nt_pred=4, offset=4, B=100, code_size_s=128,
                         code_size_t=20, enc_hidden_size=64, dec_hidden_size=64, res_hidden_size=512, n_blocks=1,
                         mixing='concat', last_activation=None, skipco=False,
                         lambdas=dict(ae=45.0, s=0.0001, t=0.001, pred=45.0), salt=34),
-    'full_sst': dict(architecture='encoderSST', decoder_architecture='decoderSST', shape=[1, 64, 64], nt_cond=4, nt_pred=40,
+    'full_sst': dict(res_scale=0.3, architecture='encoderSST', decoder_architecture='decoderSST', shape=[1, 64, 64], nt_cond=4, nt_pred=40,
                      offset=0, B=8, code_size_s=196, code_size_t=64, enc_hidden_size=64, dec_hidden_size=64,
                      res_hidden_size=512, n_blocks=2, mixing='concat', last_activation=None, skipco=True, average_tloss=True,
                      data_range='normal', lambdas=dict(ae=1.0, s=100.0, t=5e-6, pred=45.0), salt=35),
 }
+
+
+def fill_net(net, cfg):
+    """RNG-free weights of a parity configuration: det_fill, then the integrator scaled by cfg['res_scale'] when given.  Works on
+    the oracle's, the reference's and the product's SeparableNetwork alike (all expose `.t_resnet`)."""
+    import torch
+    from oracle.detdata import det_fill
+    det_fill(net, salt=cfg['salt'])
+    scale = cfg.get('res_scale')
+    if scale:
+        with torch.no_grad():
+            for name, p in net.t_resnet.named_parameters():
+                if p.dim() > 1:                          # weights only; biases / BatchNorm affine parameters keep their scale
+                    p.mul_(scale)
+    return net
 
 
 def make_batch(cfg):

@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 
 from oracle import cpu_ref                                    # noqa: E402
 from oracle.detdata import det_fill, det_uniform, checksum    # noqa: E402
-from oracle.golden_configs import CONFIGS, FULL_CONFIGS, make_batch, FULL_LIMIT   # noqa: E402
+from oracle.golden_configs import CONFIGS, FULL_CONFIGS, fill_net, make_batch, FULL_LIMIT   # noqa: E402
 
 
 def _reference_modules():
@@ -105,7 +105,7 @@ def run_config(name, cfg, mods):
     lam = cfg['lambdas']
 
     # (2) the real training loop, one step
-    net_a = det_fill(build_reference(cfg, rf, rm, ru), salt=cfg['salt'])
+    net_a = fill_net(build_reference(cfg, rf, rm, ru), cfg)
     opt = torch.optim.Adam(net_a.parameters(), **adam)
     np.random.seed(seed)
     with tempfile.TemporaryDirectory() as tmp:
@@ -114,7 +114,7 @@ def run_config(name, cfg, mods):
                  cfg.get('skipco', False), None, bool(cfg.get('average_tloss')))
 
     # (3) replay through the reference's functions
-    net_b = det_fill(build_reference(cfg, rf, rm, ru), salt=cfg['salt'])
+    net_b = fill_net(build_reference(cfg, rf, rm, ru), cfg)
     net_b.train()
     opt_b = torch.optim.Adam(net_b.parameters(), **adam)
     np.random.seed(seed)
@@ -133,7 +133,7 @@ def run_config(name, cfg, mods):
     # (4) the oracle on the same inputs
     ocfg = dict(cfg)
     net_o = cpu_ref.build_sep_net(ocfg)
-    det_fill(net_o, salt=cfg['salt'])
+    fill_net(net_o, cfg)
     missing = set(net_o.state_dict()) ^ set(build_reference(cfg, rf, rm, ru).state_dict())
     assert not missing, f'{name}: state_dict keys differ: {sorted(missing)[:5]}'
     net_o.train()

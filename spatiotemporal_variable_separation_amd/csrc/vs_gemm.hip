@@ -21,6 +21,7 @@
 //     result is bitwise reproducible (no float atomics).
 #include "vs_gemm_core.h"
 #include "vs_gemm_glds.h"
+#include "vs_gemm_big.h"
 
 namespace {
 
@@ -57,6 +58,44 @@ int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t 
                            K, (int)plan.k_tiles_per_split, epi, slabs);
     VS_CHECK_LAUNCH("vs_gemm (LDS-DMA tile)");
     return VS_OK;
+}
+
+template <int CT, int LA, int LB>
+int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const BigPlan& bp, int batch, const Epi& epi,
+               float* slabs, hipStream_t stream) {
+    if constexpr (CT == VS_F32) {
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm: the 256x256 tile is a 16-bit kernel");
+    } else {
+        auto kfn = gemm_big_kernel<CT, LA, LB, false>;
+        static bool attr_set = false;                  // 128 KiB of dynamic LDS: above the 64 KiB default limit
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess)
+                return vs_fail(VS_ERR_LAUNCH, "vs_gemm: cannot raise the dynamic LDS limit to 128 KiB");
+            attr_set = true;
+        }
+        dim3 grid((unsigned)(bp.tiles_m * bp.tiles_n), 1, (unsigned)(bp.splits * batch));
+        hipLaunchKernelGGL(kfn, grid, dim3(512), 131072, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K,
+                           (int)bp.k_tiles_per_split, bp.tiles_n, epi, slabs);
+        VS_CHECK_LAUNCH("vs_gemm (256x256 tile)");
+        return VS_OK;
+    }
+}
+
+template <int CT>
+int launch_big_layout(int la, int lb, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const BigPlan& bp,
+                      int batch, const Epi& epi, float* slabs, hipStream_t stream) {
+    if (la == LR && lb == LR) return launch_big<CT, LR, LR>(A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
+    if (la == LR && lb == LS) return launch_big<CT, LR, LS>(A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
+    if (la == LS && lb == LR) return launch_big<CT, LS, LR>(A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
+    return launch_big<CT, LS, LS>(A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
+}
+
+// the 256x256 tile is taken when its plan says so and both operands fit the LDS-DMA loader (alignment, multiples of 8)
+inline BigPlan big_plan_for(int compute, int64_t M, int64_t N, int64_t K, int64_t batch, const void* A, int64_t lda, int la, const void* B,
+                            int64_t ldb, int lb, int64_t stride_a, int64_t stride_b) {
+    BigPlan bp = make_big_plan(compute, M, N, K, batch);
+    if (bp.use && !(glds_operand_ok(A, lda, la, M, K, stride_a) && glds_operand_ok(B, ldb, lb, N, K, stride_b))) bp.use = false;
+    return bp;
 }
 
 template <int CT, int LA, int LB>
@@ -105,6 +144,11 @@ extern "C" size_t vs_gemm_batched_workspace_bytes(int batch, int64_t M, int64_t 
             size_t b = (size_t)batch * p.splits * (size_t)M * (size_t)N * sizeof(float);
             if (b > worst) worst = b;
         }
+        const BigPlan bp = make_big_plan(c, M, N, K, batch);
+        if (bp.use && bp.splits > 1) {
+            size_t b = (size_t)batch * bp.splits * (size_t)M * (size_t)N * sizeof(float);
+            if (b > worst) worst = b;
+        }
     }
     return worst;
 }
@@ -124,6 +168,8 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
     VS_CHECK_ARG(lda >= (layout_a == LR ? K : M) && ldb >= (layout_b == LR ? K : N) && ldc >= N, "vs_gemm_batched: leading dimension too small");
     Plan plan = make_plan(compute, M, N, K, batch);
     plan.batch = batch;
+    const BigPlan bp = big_plan_for(compute, M, N, K, batch, A, lda, layout_a, B, ldb, layout_b, stride_a, stride_b);
+    if (bp.use) { plan.splits = bp.splits; plan.k_tiles_per_split = bp.k_tiles_per_split; }
     Epi epi{C, ldc, c_dtype, alpha, nullptr, VS_ACT_NONE, nullptr, 0, 0, 0, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0, plan.splits, stride_a, stride_b, stride_c};
     float* slabs = nullptr;
     if (plan.splits > 1) {
@@ -132,7 +178,12 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
             return vs_fail(VS_ERR_WORKSPACE, "vs_gemm_batched: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         slabs = (float*)workspace;
     }
-    int rc = compute == VS_BF16  ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
+    int rc;
+    if (bp.use)
+        rc = compute == VS_BF16 ? launch_big_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream)
+                                : launch_big_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
+    else
+        rc = compute == VS_BF16  ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
              : compute == VS_F16 ? launch_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
                                  : launch_layout<VS_F32>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     if (rc != VS_OK) return rc;
@@ -154,6 +205,11 @@ extern "C" size_t vs_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
             size_t b = (size_t)p.splits * (size_t)M * (size_t)N * sizeof(float);
             if (b > worst) worst = b;
         }
+        const BigPlan bp = make_big_plan(c, M, N, K, 1);
+        if (bp.use && bp.splits > 1) {
+            size_t b = (size_t)bp.splits * (size_t)M * (size_t)N * sizeof(float);
+            if (b > worst) worst = b;
+        }
     }
     return worst;
 }
@@ -173,6 +229,8 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
     VS_CHECK_ARG(act >= VS_ACT_NONE && act <= VS_ACT_ELU, "vs_gemm: bad activation");
     Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     Plan plan = make_plan(compute, M, N, K);
+    const BigPlan bp = big_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);
+    if (bp.use) { plan.splits = bp.splits; plan.k_tiles_per_split = bp.k_tiles_per_split; }
     float* slabs = nullptr;
     if (plan.splits > 1) {
         const size_t need = (size_t)plan.splits * (size_t)M * (size_t)N * sizeof(float);
@@ -180,7 +238,12 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
             return vs_fail(VS_ERR_WORKSPACE, "vs_gemm: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         slabs = (float*)workspace;
     }
-    int rc = compute == VS_BF16  ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
+    int rc;
+    if (bp.use)
+        rc = compute == VS_BF16 ? launch_big_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, 1, epi, slabs, stream)
+                                : launch_big_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, 1, epi, slabs, stream);
+    else
+        rc = compute == VS_BF16  ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
              : compute == VS_F16 ? launch_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
                                  : launch_layout<VS_F32>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     if (rc != VS_OK) return rc;

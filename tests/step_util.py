@@ -3,7 +3,7 @@ import torch
 
 from oracle import cpu_ref
 from oracle.detdata import det_fill
-from oracle.golden_configs import make_batch
+from oracle.golden_configs import fill_net, make_batch
 from golden_util import rel_err
 
 
@@ -23,7 +23,7 @@ def grad_err(a, b, floor):
 def oracle_step(cfg, t_random, dtype=torch.float32):
     cond, target = make_batch(cfg)
     cond, target = cond.to(dtype), target.to(dtype)
-    net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt']).to(dtype)
+    net = fill_net(cpu_ref.build_sep_net(cfg), cfg).to(dtype)
     net.train()
     lam = cfg['lambdas']
     lamb_t = 0 if cfg.get('no_s') else lam['t']
@@ -74,7 +74,7 @@ def emulated_product_step(cfg, t_random, precision='bf16'):
     from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
     from spatiotemporal_variable_separation_amd.train import compute_losses
     cond, target = make_batch(cfg)
-    o_net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    o_net = fill_net(cpu_ref.build_sep_net(cfg), cfg)
     lam = cfg['lambdas']
     lamb_t = 0 if cfg.get('no_s') else lam['t']
     with emulate_product_bf16(_LOWP_DTYPE[precision]):
@@ -92,7 +92,7 @@ def compare_step_bf16_conv(cfg, t_random, tol_out=2e-3, tol_grad=5e-2, precision
     """HIP bf16 step of a conv family against the emulation above: same rounding points, so outputs / losses agree to
     accumulation-order noise and one-ulp bf16 flips (tol_out); gradients go through ill-conditioned per-call BatchNorm stacks at
     batch 2-3 (see compare_step), so they get the wider tol_grad -- still 10x tighter than anything bf16 vs fp32 could give."""
-    o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    o_net0 = fill_net(cpu_ref.build_sep_net(cfg), cfg)
     h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision)
     e_net, e_total, e_terms, e_fore, e_tc = emulated_product_step(cfg, t_random, precision)
     errs = {'forecasts': rel_err(h_fore.detach().cpu().float(), e_fore.detach().float()),
@@ -120,7 +120,7 @@ def compare_step_bf16(cfg, t_random, tol=2e-3, sanity=0.6, emulate=True, precisi
     """bf16 mode: (1) MLP family: must match the CPU emulation of its own rounding scheme to `tol` relative L2
     (accumulation-order noise only); (2) every family: outputs within 5e-2 and gradients within a loose `sanity` bound
     of the fp32 oracle (the conv kernels' bf16 arithmetic is pinned exactly, op by op, in tests/test_conv_gpu.py)."""
-    o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    o_net0 = fill_net(cpu_ref.build_sep_net(cfg), cfg)
     h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision)
     o_net, o_total, o_terms, o_fore, o_tc = oracle_step(cfg, t_random)
     if emulate:
@@ -153,7 +153,7 @@ def compare_step_bf16(cfg, t_random, tol=2e-3, sanity=0.6, emulate=True, precisi
 
 def compare_step(cfg, t_random, precision, tol_out, tol_grad, fused=True):
     """Returns a dict of worst relative errors; asserts against the tolerances."""
-    o_net0 = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])          # pristine weights for the HIP net
+    o_net0 = fill_net(cpu_ref.build_sep_net(cfg), cfg)          # pristine weights for the HIP net
     h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision, fused=fused)
     o_net, o_total, o_terms, o_fore, o_tc = oracle_step(cfg, t_random)
     errs = {'forecasts': rel_err(h_fore.detach().cpu(), o_fore.detach()),

@@ -48,7 +48,7 @@ def _rand(shape, salt, scale=1.0):
     return (det_uniform(shape, salt) - 0.5) * 2.0 * scale
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('geom', GEOMS)
 def test_conv_fwd_dgrad_wgrad(dtype, geom):
     from spatiotemporal_variable_separation_amd import ops
@@ -87,7 +87,7 @@ def test_conv_fwd_dgrad_wgrad(dtype, geom):
 
 
 @pytest.mark.parametrize('act', ['leaky_relu', 'relu', 'none', 'sigmoid'])
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_batchnorm_act_fwd_bwd(act, dtype):
     from spatiotemporal_variable_separation_amd import ops
     B, C, H, W = 5, 7, 12, 10
@@ -121,7 +121,7 @@ def test_batchnorm_act_fwd_bwd(act, dtype):
     assert rel(rmc, bn.running_mean) < 1e-5 and rel(rvc, bn.running_var) < 1e-5
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_pool_upsample(dtype):
     from spatiotemporal_variable_separation_amd import ops
     x = _rand((3, 5, 8, 12), 21).to(dtype)
@@ -171,7 +171,7 @@ def test_grouped_batchnorm_equals_sequential_calls():
     assert torch.allclose(dg, dg_s, rtol=1e-6, atol=1e-6) and torch.allclose(db, db_s, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(2, 5, 33, 33), (3, 4, 8, 8), (1, 3, 5, 7), (2, 2, 1, 1)])
 def test_maxpool3s2_matches_torch(dtype, shape):
     """nn.MaxPool2d(3, 2, 1) (ResNet18 stem): overlapping windows, gradient routed to the first maximum; ties included."""
@@ -186,10 +186,10 @@ def test_maxpool3s2_matches_torch(dtype, shape):
     y = VF.MaxPool3s2.apply(xd)
     assert tuple(y.shape) == tuple(yr.shape) and torch.equal(y.cpu().double(), yr.detach())
     y.backward(dy.cuda())
-    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-2 if dtype == torch.bfloat16 else 1e-6)
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-2 if dtype != torch.float32 else 1e-6, atol=1e-2 if dtype != torch.float32 else 1e-6)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape,groups', [((6, 16, 17, 17), 1), ((4, 8, 9, 9), 2), ((3, 5, 33, 33), 1), ((8, 4, 3, 3), 2), ((2, 3, 5, 5), 1)])
 def test_batchnorm_planes_not_a_multiple_of_the_vector_width(dtype, shape, groups):
     """The 17x17 / 9x9 / 33x33 maps of the chairs ResNet18: all tensors in one dtype take the unit-per-plane vector path
@@ -214,13 +214,13 @@ def test_batchnorm_planes_not_a_multiple_of_the_vector_width(dtype, shape, group
         yg.backward(dy[g * per:(g + 1) * per].double())
         ys.append(yg.detach()); dxs.append(xg.grad)
         dgs, dbs = dgs + bn.weight.grad, dbs + bn.bias.grad
-    tol = 1e-2 if dtype == torch.bfloat16 else 2e-5          # bf16: the OUTPUTS are stored in bf16
+    tol = 1e-2 if dtype != torch.float32 else 2e-5          # bf16: the OUTPUTS are stored in bf16
 
     def rel(a, b):
         return ((a.cpu().double() - b).norm() / (b.norm() + 1e-30)).item()
     assert rel(y, torch.cat(ys)) < tol and rel(dx, torch.cat(dxs)) < tol
     assert rel(dg, dgs) < 2e-5 and rel(db, dbs) < 2e-5       # fp32 sums of fp64-accumulated reductions
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         # mixed dtypes (bf16 activations, fp32 gradient in / out): 4-element units
         y32 = ops.bn_act_fwd(xc, mean, invstd, gamma.cuda(), beta.cuda(), 'leaky_relu', torch.float32, groups=groups)
         dx32, dg32, db32 = ops.bn_act_bwd(dyc.float(), xc, mean, invstd, gamma.cuda(), beta.cuda(), 'leaky_relu', True, torch.float32, groups=groups)

@@ -21,7 +21,7 @@ def _operand(rows, K, layout, dtype, salt):
     return x.double(), (dev if layout == 0 else dev.t().contiguous())
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('la,lb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize('shape', SHAPES)
 def test_gemm_layouts(dtype, la, lb, shape):
@@ -46,7 +46,7 @@ def test_gemm_integer_exact_asymmetric():
         a[m, (m * 3) % K] += 2.0
     b = (torch.arange(N).view(N, 1) * 3 + torch.arange(K).view(1, K) * 7) % 13 - 6.0
     ref = a @ b.t()
-    for dtype in (torch.float32, torch.bfloat16):
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
         for la in (0, 1):
             for lb in (0, 1):
                 aa = a.to(dtype).cuda()
@@ -57,7 +57,7 @@ def test_gemm_integer_exact_asymmetric():
                 assert torch.equal(out, ref), f'{dtype} ({la},{lb}) max diff {(out - ref).abs().max()}'
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_epilogue(dtype):
     from spatiotemporal_variable_separation_amd import ops
     from oracle.detdata import det_uniform
@@ -169,7 +169,7 @@ def test_colsum_multi_shapes_and_dtypes():
         assert torch.allclose(o.double(), r, rtol=1e-5, atol=1e-3 * x.shape[0] ** 0.5 * 1e-2), (x.shape, (o.double() - r).abs().max().item())
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('dims', [(3, 512, 32, 3072, 1, 1), (3, 512, 512, 3072, 1, 1), (2, 32, 512, 96, 1, 1), (4, 100, 72, 264, 0, 0),
                                   (5, 64, 40, 128, 0, 1)])
 def test_gemm_batched_equals_loop(dt, dims):
@@ -237,3 +237,31 @@ def test_gemm_lds_dma_tile_all_layouts_forced(stages):
     assert r.returncode == 0, r.stderr[-2000:]
     worst = float(r.stdout.strip().split('WORST')[-1])
     assert worst < 2e-6, r.stdout
+
+
+# ---- the 256x256 LDS-DMA tile (vs_gemm_big.h): taken for 16-bit problems whose 256-wide tiles (x split-K) fit one round of CUs ----
+BIG_SHAPES = [(3328, 4096, 1200), (3328, 1200, 4096), (4096, 1200, 3328), (1200, 1200, 3328), (3328, 1200, 1200),
+              (1000, 1016, 520), (520, 2048, 776)]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('la,lb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('shape', BIG_SHAPES)
+def test_gemm_big_tile_all_layouts(dtype, la, lb, shape):
+    """The decoder-sized problems of the WaveEq step (and two ragged ones): every operand layout, split-K slabs, row / column /
+    K tails of the 256x256x64 tile, against fp64 on the same rounded operands."""
+    from spatiotemporal_variable_separation_amd import ops
+    M, N, K = shape
+    a64, a = _operand(M, K, la, dtype, 3)
+    b64, b = _operand(N, K, lb, dtype, 5)
+    from oracle.detdata import det_uniform
+    bias = ((det_uniform((N,), 9) - 0.5) * 0.5).cuda()
+    out = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='relu')
+    out16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=dtype)
+    torch.cuda.synchronize()
+    ref = a64 @ b64.t()
+    refa = torch.relu(ref + bias.cpu().double())
+    err = ((out.cpu().double() - refa).norm() / refa.norm()).item()
+    assert err < 2e-6, f'{dtype} layouts ({la},{lb}) shape {shape}: rel err {err:.3e}'
+    err16 = ((out16.cpu().double() - ref).norm() / ref.norm()).item()
+    assert err16 < (6e-3 if dtype == torch.bfloat16 else 8e-4), f'{dtype} 16-bit output ({la},{lb}) {shape}: {err16:.3e}'

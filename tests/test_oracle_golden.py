@@ -5,7 +5,7 @@ import torch
 
 from oracle import cpu_ref
 from oracle.detdata import det_fill
-from oracle.golden_configs import CONFIGS, FULL_CONFIGS, make_batch
+from oracle.golden_configs import CONFIGS, FULL_CONFIGS, fill_net, make_batch
 from golden_util import load_golden, check_tensor
 
 TOL = 1e-5          # fp32 CPU vs fp32 CPU; bit-exact in the build container, slack for other BLAS builds
@@ -22,7 +22,7 @@ def test_oracle_matches_reference_step(name):
     gold = load_golden(name)
     torch.manual_seed(0)
     cond, target = make_batch(cfg)
-    net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    net = fill_net(cpu_ref.build_sep_net(cfg), cfg)
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=cfg.get('lr', 4e-4), betas=(0.9, 0.99))
     lam = cfg['lambdas']

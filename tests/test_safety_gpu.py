@@ -69,7 +69,7 @@ def test_bench_gpus_2_launches_two_ranks():
     assert 'gloo' in out['config']['grad_allreduce']
 
 
-def _ddp_worker(rank, world, port, out_dir):
+def _ddp_worker(rank, world, port, out_dir, graph):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -85,43 +85,51 @@ def _ddp_worker(rank, world, port, out_dir):
     net = det_fill(build_sep_net(cfg), salt=cfg['salt']).cuda()
     broadcast_module_state(net)
     cond, target = make_batch(cfg)
+    other_c, other_t = make_batch(dict(cfg, salt=cfg['salt'] + 100))           # different frames: different gradients
     per = 8 // world
     sh = slice(rank * per, rank * per + per)
     full = (cond[sh].cuda(), target[sh].cuda())
-    ragged = (cond[sh][:per - 1].cuda(), target[sh][:per - 1].cuda())            # the last batch of the epoch is one sample short
+    ragged = (other_c[sh][:per - 1].cuda(), other_t[sh][:per - 1].cuda())       # the last batch of the epoch is one sample short
     loader = [full, full, ragged]
-    sync = GradAllReducer(net.parameters(), bucket_bytes=16 << 10, comm_dtype=torch.bfloat16, lowp_direct=chain_weight_parameters(net))
+    sync = GradAllReducer(net.parameters(), bucket_bytes=16 << 10, comm_dtype=torch.bfloat16,
+                          lowp_direct=chain_weight_parameters(net) if graph else None)
     opt = Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.99))
     lam = cfg['lambdas']
     np.random.seed(3)
+    if not graph:                                    # GraphedStep's capture consumes one draw of the t_random stream
+        np.random.randint(cfg['nt_cond'], cond.shape[1] + target.shape[1] + 1)
     VF.set_precision('bf16')
-    train(os.path.join(out_dir, 'xp'), loader, torch.device('cuda', 0), net, opt, None, False, False, 1, lam['ae'], lam['s'], lam['t'], lam['pred'],
-          cfg['offset'], cfg['nt_cond'], cfg['nt_pred'], False, False, None, False, grad_sync=sync, hip_graph=True)
-    # what the eager fallback must have used for its Adam step: the gradients of the RAGGED batch, averaged over the ranks
-    chain = chain_weight_parameters(net)
-    stale = []
-    for p in chain:
-        wire = sync.lowp_views[id(p)].float()
-        stale.append(float((p.grad - wire).abs().max()))                       # fp32 bucket (this step) vs bf16 wire image (previous step)
-    torch.save({'state': {k: v.detach().cpu() for k, v in net.state_dict().items()}, 'stale': stale,
-                'saved': os.path.exists(os.path.join(out_dir, 'xp', 'ov_Et.pt'))}, os.path.join(out_dir, f'rank{rank}.pt'))
+    xp = os.path.join(out_dir, 'xp_graph' if graph else 'xp_eager')
+    train(xp, loader, torch.device('cuda', 0), net, opt, None, False, False, 1, lam['ae'], lam['s'], lam['t'], lam['pred'],
+          cfg['offset'], cfg['nt_cond'], cfg['nt_pred'], False, False, None, False, grad_sync=sync, hip_graph=graph)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.save({'state': {k: v.detach().cpu() for k, v in net.state_dict().items()}, 'saved': os.path.exists(os.path.join(xp, 'ov_Et.pt')),
+                'rank_dir': os.path.exists(os.path.join(xp, 'rank1'))}, os.path.join(out_dir, f'{"g" if graph else "e"}_rank{rank}.pt'))
     dist.destroy_process_group()
 
 
 def test_ddp_graph_with_ragged_last_batch_uses_this_steps_gradients(tmp_path):
     """--ddp --hip_graph --grad_comm bf16 with a ragged last batch: the eager fallback must average and apply the gradients of
-    THAT batch (it used to leave the Linear chains' weights on the previous step's bf16 wire images).  Replicas stay identical,
-    the fp32 buckets hold fresh gradients that differ from the stale wire images, and only rank 0 writes the checkpoint."""
+    THAT batch (it used to leave the Linear chains' weights on the previous step's bf16 wire images).  Checked against the same
+    three steps run entirely in the eager data-parallel loop: identical up to where the bf16 rounding of a gradient happens
+    (GEMM epilogue vs cast of the fp32 bucket); a stale gradient would differ by ~lr on every chain weight.  Replicas stay
+    identical and only rank 0 writes the checkpoint."""
     import socket
     import torch.multiprocessing as mp
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = torch.load(os.path.join(tmp_path, 'rank0.pt')), torch.load(os.path.join(tmp_path, 'rank1.pt'))
-    for k in r0['state']:
-        assert torch.equal(r0['state'][k], r1['state'][k]), f'replicas diverged at {k}'
-    assert max(r0['stale']) > 0, 'the fp32 buckets of the chain weights were not written by the eager step'
-    assert r0['saved'] and r1['saved']               # same directory: rank 0 wrote it (rank 1 sees the files, wrote none itself)
-    assert not os.path.exists(os.path.join(tmp_path, 'xp', 'rank1'))
+
+    def port():
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        p = s.getsockname()[1]
+        s.close()
+        return p
+    mp.spawn(_ddp_worker, args=(2, port(), str(tmp_path), True), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, port(), str(tmp_path), False), nprocs=2, join=True)
+    g0, g1 = torch.load(os.path.join(tmp_path, 'g_rank0.pt')), torch.load(os.path.join(tmp_path, 'g_rank1.pt'))
+    e0 = torch.load(os.path.join(tmp_path, 'e_rank0.pt'))
+    for k in g0['state']:
+        assert torch.equal(g0['state'][k], g1['state'][k]), f'replicas diverged at {k}'
+        a, b = g0['state'][k], e0['state'][k]
+        assert torch.allclose(a, b, rtol=1e-3, atol=1.5e-4), f'{k}: recorded + ragged-eager differs from all-eager by {(a - b).abs().max().item():.3e}'
+    assert g0['saved'] and not g0['rank_dir'], 'rank 0 writes the checkpoint, no per-rank directories'
