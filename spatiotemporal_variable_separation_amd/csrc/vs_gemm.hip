@@ -69,13 +69,14 @@ int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M
         auto kfn = gemm_big_kernel<CT, LA, LB, false>;
         static bool attr_set = false;                  // 128 KiB of dynamic LDS: above the 64 KiB default limit
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_STAGES * BIG_TILE_BYTES) != hipSuccess)
                 return vs_fail(VS_ERR_LAUNCH, "vs_gemm: cannot raise the dynamic LDS limit to 128 KiB");
             attr_set = true;
         }
+        static const int diag = getenv("VS_BIG_DIAG") ? atoi(getenv("VS_BIG_DIAG")) : 0;     // timing diagnostics only: wrong results
         dim3 grid((unsigned)(bp.tiles_m * bp.tiles_n), 1, (unsigned)(bp.splits * batch));
-        hipLaunchKernelGGL(kfn, grid, dim3(512), 131072, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K,
-                           (int)bp.k_tiles_per_split, bp.tiles_n, epi, slabs);
+        hipLaunchKernelGGL(kfn, grid, dim3(512), BIG_STAGES * BIG_TILE_BYTES, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K,
+                           (int)bp.k_tiles_per_split, bp.tiles_n, epi, slabs, diag);
         VS_CHECK_LAUNCH("vs_gemm (256x256 tile)");
         return VS_OK;
     }

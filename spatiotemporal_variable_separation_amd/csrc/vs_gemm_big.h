@@ -1,70 +1,94 @@
-// vs_gemm_big.h -- 256x256x64 tile, 8 waves, LDS-DMA double buffered: the 16-bit GEMM kernel for problems whose 256x256 tiles
-// (x split-K) fit ONE round of the 256 CUs (decoder layers of the WaveEq model: 3328 x 4096 x 1200 = 208 tiles).
+// vs_gemm_big.h -- 256x256 output tile, 8 waves, K in steps of 32 through a 4-deep LDS-DMA ring: the 16-bit GEMM kernel for
+// problems whose 256x256 tiles (x split-K) fit ONE round of the 256 CUs (decoder layers of the WaveEq model: 3328 x 4096 x 1200
+// = 208 tiles).
 //
 // Why a second kernel: the 128x64 / 128x128 tiles of gemm_kernel / gemm_glds_kernel need 1.0-1.5 KiB of LDS fragment reads per
 // 32x32x16 MFMA and saturate the CU's LDS port (256 B/clk) long before the matrix pipes; they also quantise badly on this model
 // (832 / 494 / 260 tiles on 256 CUs leave a mostly empty last round).  Here every wave owns a 128 x 64 block of C (4 x 2
 // accumulators of the 32x32 shape = 128 registers): 6 fragment reads feed 8 MFMAs (0.75 KiB per MFMA, 37 % of the LDS port), and
-// one workgroup per CU holds the whole 128 KiB double buffer.
-//   * 512 threads = 8 waves as 2 (M) x 4 (N), two waves per SIMD: while one wave of a SIMD waits for its fragments the other
-//     issues MFMAs;
-//   * a K tile (256 x 64 of A and of B) is four 16 KiB half-tiles [A rows 0-127 | A rows 128-255 | B rows 0-127 | B rows 128-255],
-//     each filled by two global_load_lds_dwordx4 per thread (1 KiB per wave instruction, no VGPRs); the half-tile images are the
-//     swizzled, unpadded ones of vs_gemm_glds.h (R: piece ^ ((row >> 1) & 7); S: piece ^ ((k & 3) << 2), read with
-//     ds_read_b64_tr_b16), so all four operand layouts are served and every LDS read is conflict free;
-//   * K loop: one barrier per K tile.  The four half-tiles of tile t+1 are requested right after the barrier that releases their
-//     buffer, so their DMA is in flight while tile t is multiplied; `s_waitcnt vmcnt(0)` + raw `s_barrier` ends the tile;
-//     fragments of k-step s+1 are requested before the MFMAs of k-step s (two register sets);
+// one workgroup per CU owns the whole 128 KiB ring.
+//   * 512 threads = 8 waves as 2 (M) x 4 (N), two waves per SIMD.
+//   * Operand movement is what bounds a one-workgroup-per-CU GEMM on MI355X: a CU pulls ~25-70 GB/s through LDS-DMA depending on
+//     where the bytes sit and how many are in flight (MI355X_MICROARCH: ldsdma-fill, indexed rows), and a first version with two
+//     64-deep buffers (ONE tile in flight, drained to vmcnt(0) every tile) ran at the latency of one 64 KiB burst per tile:
+//     3.1 us per K tile, 300 TFLOP/s.  So: K tiles of 32 (32 KiB: A 256 x 32 + B 256 x 32), FOUR ring slots, the DMA of tiles
+//     t+1 .. t+3 in flight while tile t is multiplied, counted `s_waitcnt vmcnt(8)` (never 0 inside the loop) + raw `s_barrier`
+//     once per tile; a tile is requested right after the barrier that frees its slot.  Tiles past the end of the split are
+//     requested from a block of zeros so the count stays uniform.
+//   * a K tile is four 8 KiB half-tiles [A rows 0-127 | A rows 128-255 | B rows 0-127 | B rows 128-255], one
+//     global_load_lds_dwordx4 per thread each (1 KiB per wave instruction, no VGPRs).  Unpadded, swizzled images (the DMA
+//     destination is lane-linear, so the permutation sits on the SOURCE address and on the read address):
+//       R [128 rows][32 k]: 64-byte rows, piece p (8 k) of row r in slot p ^ ((r >> 2) & 3): the 16 lanes of a ds_read_b128 group
+//                           (rows r..r+3, r+12..15, r+20..27 of one piece) cover all 16 slots of the 256-byte bank row;
+//       S [32 k][128 rows]: 256-byte k-rows, piece p (8 rows) of k-row k in slot p ^ ((k & 3) << 2), read with ds_read_b64_tr_b16
+//                           (the four k-rows of a transposing read sit in four different 64-byte bank groups).
+//   * epilogue through LDS: the accumulators (column on the lane) are laid out row-major in the (now idle) ring, 64 rows per wave
+//     at a time, and read back as float4 along the rows: every store instruction writes whole 256-byte row segments, and the
+//     epilogue arithmetic (bias / activation / mask / accumulate / 16-bit convert) exists once, in a loop, instead of 128
+//     unrolled scalar copies (which the compiler answered by spilling the accumulators to scratch).
 //   * blockIdx -> tile map groups the tiles of one XCD (blocks b, b+8, ...) into a contiguous run of the row-major tile order,
-//     so the A row panel of a run stays in that XCD's L2;
-//   * split-K, the epilogue (bias / activation / mask / NCHW) and the slab reduction are those of gemm_kernel.
+//     so the A row panel of a run stays in that XCD's L2.
+//   * split-K and the slab reduction are those of gemm_kernel.
 #pragma once
 #include "vs_gemm_glds.h"
 
 namespace {
 
-// Per-thread source pointers of one operand's two half-tiles (2 DMA pieces per half): advanced by one K tile per stage call.
+constexpr int BIG_BK = 32;
+constexpr int BIG_STAGES = 4;
+constexpr int BIG_TILE_BYTES = 4 * 8192;          // A0 | A1 | B0 | B1
+
+// Per-thread source pointer of one operand's two half-tiles (one 16-byte DMA piece per half and K tile).
 template <int LAYOUT>
 struct BigOperand {
-    const unsigned short* src[2][2];     // [half][round]
-    int kofs[2];                         // k of the piece inside the tile (same for both halves)
-    bool ok[2][2];
+    const unsigned short* src[2];        // [half]: piece of the next K tile to request
+    int kofs;                            // k of the piece inside the tile
+    bool ok[2];
     int64_t step;
 
     __device__ __forceinline__ void prepare(const unsigned short* p, int64_t ld, int64_t rows, int64_t i0, int64_t k_begin) {
+        const int u = (int)threadIdx.x;                         // linear 16-byte slot of the 8 KiB half-tile image
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int u = r * 512 + (int)threadIdx.x;               // linear 16-byte slot of the 16 KiB half-tile image
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int64_t base = i0 + 128 * h;
-                if (LAYOUT == LR) {
-                    const int row = u >> 3, piece = (u & 7) ^ ((row >> 1) & 7);
-                    ok[h][r] = base + row < rows;
-                    kofs[r] = piece * 8;
-                    src[h][r] = p + (base + row) * ld + k_begin + piece * 8;
-                    step = 64;
-                } else {
-                    const int k = u >> 4, piece = (u & 15) ^ ((k & 3) << 2);
-                    ok[h][r] = base + piece * 8 < rows;
-                    kofs[r] = k;
-                    src[h][r] = p + (k_begin + k) * ld + base + piece * 8;
-                    step = 64 * ld;
-                }
+        for (int h = 0; h < 2; ++h) {
+            const int64_t base = i0 + 128 * h;
+            if (LAYOUT == LR) {
+                const int row = u >> 2, piece = (u & 3) ^ ((row >> 2) & 3);
+                ok[h] = base + row < rows;
+                kofs = piece * 8;
+                src[h] = p + (base + row) * ld + k_begin + piece * 8;
+                step = BIG_BK;
+            } else {
+                const int k = u >> 4, piece = (u & 15) ^ ((k & 3) << 2);
+                ok[h] = base + piece * 8 < rows;                // rows % 8 == 0: a piece is inside or outside as a whole
+                kofs = k;
+                src[h] = p + (k_begin + k) * ld + base + piece * 8;
+                step = BIG_BK * ld;
             }
         }
     }
-    // issue the 2 DMA pieces of half `h` of the K tile starting at k0 into `lds` (16 KiB, wave-linear) and advance
-    __device__ __forceinline__ void stage(int h, char* lds, int64_t k0, int64_t K) {
+    // request half `h` of the K tile starting at k0 into `lds` (8 KiB, wave-linear) and advance; `live` false -> zeros
+    __device__ __forceinline__ void stage(int h, char* lds, int64_t k0, int64_t K, bool live) {
         const int wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const void* g = (ok[h][r] && k0 + kofs[r] < K) ? (const void*)src[h][r] : (const void*)vs_glds_zero;
-            __builtin_amdgcn_global_load_lds((glds_glb_ptr*)g, (glds_lds_ptr*)(lds + (r * 512 + wave * 64) * 16), 16, 0, 0);
-            src[h][r] += step;
-        }
+        const void* g = (live && ok[h] && k0 + kofs < K) ? (const void*)src[h] : (const void*)vs_glds_zero;
+        __builtin_amdgcn_global_load_lds((glds_glb_ptr*)g, (glds_lds_ptr*)(lds + wave * 1024), 16, 0, 0);
+        src[h] += step;
     }
 };
+
+// fragment of one 32-row block and one 16-deep k-step (kk = 0 or 16) of a half-tile image
+template <int LAYOUT>
+__device__ __forceinline__ u32x4 big_frag(const unsigned short* tile, int row0, int kk, int lane) {
+    if (LAYOUT == LR) {
+        const int row = row0 + (lane & 31), q = (kk >> 3) + (lane >> 5);
+        return *reinterpret_cast<const u32x4*>(tile + row * 32 + ((q ^ ((row >> 2) & 3)) << 3));
+    } else {
+        const int li = lane & 15, q = li >> 2, p = li & 3, cb = (lane >> 4) & 1, h = lane >> 5;
+        const int k1 = kk + 8 * h + q;                             // k1 + 4 has the same (k & 3): same permutation
+        const int rowoff = row0 + 16 * cb + 4 * p;
+        const int slot = (rowoff >> 3) ^ ((k1 & 3) << 2);
+        return vs_tr16_pair(tile + k1 * 128 + slot * 8 + (rowoff & 7), 4 * 128);
+    }
+}
 
 // XCD-aware, bijective block -> tile index (blocks b and b + 8 share an XCD under round-robin dispatch: speed only)
 __device__ __forceinline__ unsigned big_tile_of(unsigned b, unsigned nwg) {
@@ -72,9 +96,45 @@ __device__ __forceinline__ unsigned big_tile_of(unsigned b, unsigned nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
+// four consecutive columns n..n+3 of row m; vector I/O when the row-major addresses allow it
+template <bool NCHW>
+__device__ __forceinline__ void big_store4(const Epi& e, int64_t m, int64_t n, int64_t N, const f32x4& v, float* slab_row) {
+    if (slab_row) {                                               // split-K partial: raw fp32, reduced (with the epilogue) later
+        if (n + 3 < N && ((uintptr_t)(slab_row + n) & 15) == 0) *reinterpret_cast<f32x4*>(slab_row + n) = v;
+        else
+            for (int t = 0; t < 4; ++t)
+                if (n + t < N) slab_row[n + t] = v[t];
+        return;
+    }
+    if constexpr (NCHW) {
+        for (int t = 0; t < 4; ++t)
+            if (n + t < N) epi_store_nchw(e, m, nchw_col_base(e, n + t), v[t]);
+    } else {
+        const bool vec = n + 3 < N && ((e.ldc | n) & 3) == 0 && !e.mask && !e.accumulate && ((uintptr_t)e.C & 15) == 0;
+        if (vec) {
+            f32x4 r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float x = v[t] * e.alpha;
+                if (e.bias) x += e.bias[n + t];
+                r[t] = vs_act(x, e.act);
+            }
+            if (e.c_dtype == VS_F32) {
+                *reinterpret_cast<f32x4*>((float*)e.C + m * e.ldc + n) = r;
+            } else {
+                const u16x4 h = {vs_f2h(r[0], e.c_dtype), vs_f2h(r[1], e.c_dtype), vs_f2h(r[2], e.c_dtype), vs_f2h(r[3], e.c_dtype)};
+                *reinterpret_cast<u16x4*>((unsigned short*)e.C + m * e.ldc + n) = h;
+            }
+        } else {
+            for (int t = 0; t < 4; ++t)
+                if (n + t < N) epi_store(e, m, n + t, v[t]);
+        }
+    }
+}
+
 template <int CT, int LA, int LB, bool NCHW>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
-                                                       int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs) {
+                                                       int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs, int diag) {
     int zsplit = blockIdx.z;
     int batch = 0;
     if (epi_in.splits_per_batch > 0) {
@@ -84,13 +144,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap,
         Bp += batch * epi_in.batch_b;
     }
     const Epi epi = epi_for_batch(epi_in, batch);
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // the ONLY LDS object: 2 x [A0 | A1 | B0 | B1] x 16 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // the ONLY LDS object: 4 x [A0 | A1 | B0 | B1] x 8 KiB
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const unsigned tile = big_tile_of(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(tile / (unsigned)tiles_n) * 256, n0 = (int64_t)(tile % (unsigned)tiles_n) * 256;
-    const int64_t kt_total = (K + 63) / 64;
+    const int64_t kt_total = (K + BIG_BK - 1) / BIG_BK;
     const int64_t kt_begin = (int64_t)zsplit * k_tiles_per_split;
     int64_t kt_end = kt_begin + k_tiles_per_split;
     if (kt_end > kt_total) kt_end = kt_total;
@@ -105,108 +165,135 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap,
 
     BigOperand<LA> ga;
     BigOperand<LB> gb;
-    ga.prepare(Ap, lda, M, m0, kt_begin * 64);
-    gb.prepare(Bp, ldb, N, n0, kt_begin * 64);
+    ga.prepare(Ap, lda, M, m0, kt_begin * BIG_BK);
+    gb.prepare(Bp, ldb, N, n0, kt_begin * BIG_BK);
 
-    // half-tile q of buffer `buf`: q = 0, 1 -> A rows 0-127 / 128-255; q = 2, 3 -> B rows 0-127 / 128-255
-    auto half_ptr = [&](int buf, int q) -> char* { return smem + buf * 65536 + q * 16384; };
-    auto stage_half = [&](int buf, int q, int64_t kt) {
-        if (q < 2) ga.stage(q, half_ptr(buf, q), kt * 64, K);
-        else gb.stage(q - 2, half_ptr(buf, q), kt * 64, K);
+    // request K tile `kt` into ring slot `slot` (4 DMA instructions per thread, always: the vmcnt arithmetic below relies on it)
+    auto stage_tile = [&](int slot, int64_t kt) {
+        char* base = smem + slot * BIG_TILE_BYTES;
+        const bool live = kt < kt_end;
+        ga.stage(0, base, kt * BIG_BK, K, live);
+        ga.stage(1, base + 8192, kt * BIG_BK, K, live);
+        gb.stage(0, base + 16384, kt * BIG_BK, K, live);
+        gb.stage(1, base + 24576, kt * BIG_BK, K, live);
     };
 
-    if (kt_begin < kt_end) {
+    // Software pipeline across K tiles: the fragments of tile t+1 are read (and tile t+4 requested) WHILE the MFMAs of tile t
+    // run, so after each barrier the matrix pipes restart at once instead of waiting for 4 DMA issues + 12 LDS reads of both
+    // waves of the SIMD (measured with all waves doing load -> multiply in step: DMA 0.76 us, compute 0.8 us, both 1.06 us per
+    // tile; a ping-pong of the two halves of the workgroup with two barriers per tile: 1.2 us).  Three fragment sets rotate:
+    // X = k-step 0, Y = k-step 1 of tile t; k-step 0 of tile t+1 goes to Z, k-step 1 to X once the MFMAs of X are issued.
+    // Ring: tile t+1 is being read, t+2 and t+3 are in flight, t+4 takes the slot of tile t, whose fragments are in registers.
+    struct Frags { u32x4 a[4], b[2]; };
+    Frags f0, f1, f2;
+    const int bcol = (wc & 1) * 64;
+    auto load_frags = [&](Frags& f, int slot_, int kk) {
+        const unsigned short* pa = reinterpret_cast<const unsigned short*>(smem + slot_ * BIG_TILE_BYTES + wr * 8192);
+        const unsigned short* pb = reinterpret_cast<const unsigned short*>(smem + slot_ * BIG_TILE_BYTES + 16384 + (wc >> 1) * 8192);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) stage_half(0, q, kt_begin);
+        for (int i = 0; i < 4; ++i) f.a[i] = big_frag<LA>(pa, 32 * i, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) f.b[j] = big_frag<LB>(pb, bcol + 32 * j, kk, lane);
+    };
+    auto mfma8 = [&](const Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16_32<CT>(f.a[i], f.b[j], acc[i][j]);
+    };
+    stage_tile(0, kt_begin);
+    stage_tile(1, kt_begin + 1);
+    stage_tile(2, kt_begin + 2);
+    stage_tile(3, kt_begin + 3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 // tile 0 (this wave's pieces) ...
+    __builtin_amdgcn_s_barrier();                                      // ... and everybody else's
+    load_frags(f0, 0, 0);
+    load_frags(f1, 0, 16);
+    int slot = 0;                                                      // ring slot of tile kt
+    int64_t kt = kt_begin;
+    // X, Y: fragments of tile kt (k-steps 0 / 1), Z: free set
+#define VS_BIG_BODY(X, Y, Z)                                                                          \
+    {                                                                                                 \
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); /* tile kt+1 landed; my reads of tile kt are done */ \
+        __builtin_amdgcn_s_barrier();                                                                 \
+        if (!(diag & 1)) stage_tile(slot, kt + 4); else stage_tile(slot, kt_end);                     \
+        const int nslot = (slot + 1) & 3;                                                             \
+        load_frags(Z, nslot, 0);                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                \
+        if (!(diag & 2)) mfma8(X);                                                                    \
+        __builtin_amdgcn_s_setprio(0);                                                                \
+        load_frags(X, nslot, 16);                                                                     \
+        __builtin_amdgcn_s_setprio(1);                                                                \
+        if (!(diag & 2)) mfma8(Y);                                                                    \
+        __builtin_amdgcn_s_setprio(0);                                                                \
+        slot = nslot;                                                                                 \
+        ++kt;                                                                                         \
     }
-    int cur = 0;
-    for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                  // tile kt landed for every wave; every wave is done reading tile kt - 1
-        const unsigned short* pa = reinterpret_cast<const unsigned short*>(half_ptr(cur, wr));
-        const unsigned short* pb = reinterpret_cast<const unsigned short*>(half_ptr(cur, 2 + (wc >> 1)));
-        const int bcol = (wc & 1) * 64;
-        const bool more = kt + 1 < kt_end;
-        u32x4 a0[4], b0[2], a1[4], b1[2];
-#define VS_BIG_LOAD(fa, fb, kk)                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = glds_frag<LA>(pa, 32 * i, kk, lane); \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) fb[j] = glds_frag<LB>(pb, bcol + 32 * j, kk, lane);
-#define VS_BIG_MFMA(fa, fb)                                                          \
-        __builtin_amdgcn_s_setprio(1);                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma16_32<CT>(fa[i], fb[j], acc[i][j]); \
-        __builtin_amdgcn_s_setprio(0);
-        // the whole next tile is requested NOW: its DMA has this tile's 32 MFMAs per wave (x 2 waves per SIMD) to land.  (Issued
-        // one half-tile per k-step, the last half had only one k-step of cover and every tile ended in a ~1 us vmcnt stall:
-        // 108 us instead of 76 us at 3328 x 4096 x 1200.)
-        if (more) {
-            stage_half(cur ^ 1, 0, kt + 1);
-            stage_half(cur ^ 1, 1, kt + 1);
-        }
-        VS_BIG_LOAD(a0, b0, 0)
-        if (more) {
-            stage_half(cur ^ 1, 2, kt + 1);
-            stage_half(cur ^ 1, 3, kt + 1);
-        }
-        VS_BIG_LOAD(a1, b1, 16)
-        VS_BIG_MFMA(a0, b0)
-        VS_BIG_LOAD(a0, b0, 32)
-        VS_BIG_MFMA(a1, b1)
-        VS_BIG_LOAD(a1, b1, 48)
-        VS_BIG_MFMA(a0, b0)
-        VS_BIG_MFMA(a1, b1)
-#undef VS_BIG_LOAD
-#undef VS_BIG_MFMA
-        cur ^= 1;
+    while (kt < kt_end) {
+        VS_BIG_BODY(f0, f1, f2)
+        if (kt >= kt_end) break;
+        VS_BIG_BODY(f2, f0, f1)
+        if (kt >= kt_end) break;
+        VS_BIG_BODY(f1, f2, f0)
     }
+#undef VS_BIG_BODY
+    // drain the (zero-source) requests still in flight before the ring is reused as the epilogue's staging area
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
-    // C/D map of the 32x32 MFMA shape: column = lane & 31, row = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)
+    // ---- epilogue: accumulators -> LDS (row-major, 64 rows x 64 columns of fp32 per wave and pass) -> coalesced row stores ----
+    float* stg = reinterpret_cast<float*>(smem) + wave * (64 * 64);          // 16 KiB per wave, 128 KiB in all
     const int cj = lane & 31, rh = 4 * (lane >> 5);
+    float* slab_base = slabs ? slabs + (int64_t)blockIdx.z * M * N : nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t n = n0 + wc * 64 + 32 * j + cj;
-            if (n >= N) continue;
-            int64_t col_base = 0;
-            if constexpr (NCHW) col_base = nchw_col_base(epi, n);
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int64_t m = m0 + wr * 128 + 32 * i + (v & 3) + 8 * (v >> 2) + rh;
-                if (m >= M) continue;
-                if (slabs) slabs[((int64_t)blockIdx.z * M + m) * N + n] = acc[i][j][v];
-                else if constexpr (NCHW) epi_store_nchw(epi, m, col_base, acc[i][j][v]);
-                else epi_store(epi, m, n, acc[i][j][v]);
-            }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    stg[(32 * ii + (v & 3) + 8 * (v >> 2) + rh) * 64 + 32 * j + cj] = acc[2 * pass + ii][j][v];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // own writes only: a wave reads back what it wrote itself
+        const int64_t nn = n0 + wc * 64 + (lane & 15) * 4;
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + (lane >> 4);
+            const int64_t m = m0 + wr * 128 + 64 * pass + r;
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + r * 64 + (lane & 15) * 4);
+            if (m < M && nn < N) big_store4<NCHW>(epi, m, nn, N, v4, slab_base ? slab_base + m * N : nullptr);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next pass overwrites the area
+    }
 }
 
 // ---- when to take it ---------------------------------------------------------------------------------------------------------
-// One workgroup per CU.  The plan asks for at most ONE round of 256 workgroups: tiles x splits <= 256, >= 6 K tiles per split
-// (amortises prologue + epilogue), and enough work that the 256-wide tile is not mostly padding.  VS_GEMM_BIG=0 disables,
-// =2 takes it whenever the operands allow (tests).
+// One workgroup per CU.  The plan asks for ONE round of 160..256 workgroups, >= 12 K tiles (of 32) (amortises prologue + epilogue:
+// ~26 us of a 63 us launch at 3328 x 4096 x 1200 are launch, ring fill and the 54 MB of fp32 output), and enough work that the
+// 256-wide tile is not mostly padding.  VS_GEMM_BIG=0 disables, =2 takes it whenever the operands allow (tests; split-K off).
+// k_tiles_per_split counts K tiles of BIG_BK.  Measured (MI355X, bf16, random operands): 3328 x 4096 x 1200 63 us (128x64 tile:
+// 76 us), 4096^3 158 us = 870 TFLOP/s (128x128 LDS-DMA tile: 184 us).  Timing-only variants of the loop (VS_BIG_DIAG): without
+// the MFMAs and fragment reads the DMA ring alone runs at 0.57 us per 32 KiB tile (57 GB/s per CU), without real DMA traffic
+// the multiply alone at 0.74 us per tile (MFMA-issue bound at the clock the chip holds under load), both together at 1.03 us.
 struct BigPlan { bool use; int splits; int64_t k_tiles_per_split; int tiles_m, tiles_n; };
 
 inline BigPlan make_big_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch) {
     BigPlan p{false, 1, 0, (int)vs_cdiv(M, 256), (int)vs_cdiv(N, 256)};
-    static const int mode = getenv("VS_GEMM_BIG") ? atoi(getenv("VS_GEMM_BIG")) : 1;
+    const char* env = getenv("VS_GEMM_BIG");                      // read per call: tests switch it
+    const int mode = env ? atoi(env) : 1;
     if (compute == VS_F32 || mode == 0) return p;
-    const int64_t kt = vs_cdiv(K, 64);
+    const int64_t kt = vs_cdiv(K, BIG_BK);
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * batch;
     p.k_tiles_per_split = kt;
     if (mode == 2) { p.use = tiles <= 65535; return p; }
-    if (M < 512 || N < 512 || kt < 6 || tiles > 256) return p;
+    if (M < 512 || N < 512 || kt < 12 || tiles > 256) return p;
     // padding waste of the 256-wide tiles
     const double fill = (double)M * (double)N / ((double)p.tiles_m * 256.0 * (double)p.tiles_n * 256.0);
     if (fill < 0.8) return p;
-    int splits = (int)(256 / tiles);
-    const int64_t max_by_k = kt / 6;
-    if (splits > max_by_k) splits = (int)max_by_k;
-    if (splits < 1) splits = 1;
-    if (splits > 16) splits = 16;
-    // a split costs a slab round trip (4 B written + read per output element and split): only split when the CUs would
-    // otherwise idle for more than that costs
-    if (tiles >= 160) splits = 1;
+    // Split-K is NOT planned: measured on the WaveEq decoder shapes the slab round trip of 256-wide tiles (4 B written + read per
+    // output element and split) costs more than it buys -- 3328x1200x4096: 90 us split in 3 vs 78 us on the 128x64 tile,
+    // 3328x1200x1200: 53 vs 35 us -- so the tile is taken where its tiles alone fill most of the chip (>= 160 of 256 CUs).
+    int splits = 1;
+    if (tiles < 160) return p;
     p.k_tiles_per_split = vs_cdiv(kt, splits);
     p.splits = (int)vs_cdiv(kt, p.k_tiles_per_split);
     p.use = true;

@@ -248,16 +248,21 @@ BIG_SHAPES = [(3328, 4096, 1200), (3328, 1200, 4096), (4096, 1200, 3328), (1200,
 @pytest.mark.parametrize('la,lb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize('shape', BIG_SHAPES)
 def test_gemm_big_tile_all_layouts(dtype, la, lb, shape):
-    """The decoder-sized problems of the WaveEq step (and two ragged ones): every operand layout, split-K slabs, row / column /
-    K tails of the 256x256x64 tile, against fp64 on the same rounded operands."""
+    """The decoder-sized problems of the WaveEq step (and two ragged ones): every operand layout, row / column / K tails of the
+    256x256 tile with its 4-deep K ring, fp32 and 16-bit outputs, against fp64 on the same rounded operands."""
+    import os
     from spatiotemporal_variable_separation_amd import ops
     M, N, K = shape
     a64, a = _operand(M, K, la, dtype, 3)
     b64, b = _operand(N, K, lb, dtype, 5)
     from oracle.detdata import det_uniform
     bias = ((det_uniform((N,), 9) - 0.5) * 0.5).cuda()
-    out = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='relu')
-    out16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=dtype)
+    os.environ['VS_GEMM_BIG'] = '2'                  # take the 256x256 tile whatever the plan would say (it is read per call)
+    try:
+        out = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='relu')
+        out16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=dtype)
+    finally:
+        del os.environ['VS_GEMM_BIG']
     torch.cuda.synchronize()
     ref = a64 @ b64.t()
     refa = torch.relu(ref + bias.cpu().double())
