@@ -135,6 +135,39 @@ int vs_gather_windows(const float* data, int64_t n_seq, int64_t nt, int64_t fram
                       int windows_per_seq, int seq_len, const int32_t* pixel_idx, int n_pixels, void* out, int out_dtype,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ConvTranspose2d k4 s2 p1 forward without any column matrix (reference: the three middle layers of DCGAN64Decoder,
+ * networks/conv.py:259-262 `make_conv_block(nn.ConvTranspose2d(.., 4, 2, 1, bias=False), ..)` and their BatchNorm2d).
+ * "Tap GEMM + col2im epilogue" (csrc/vs_conv_tap.hip): per block of 16 output channels and tile of 256 input pixels (whole
+ * images of 4x4, 8x8 or 16x16) one 256x256 MFMA tile over K = Cin whose rows are (tap, channel); the input tile is staged in LDS
+ * by LDS-DMA straight from NCHW, the 16 tap maps are combined in LDS, rounded once, written as 16-byte output runs.
+ *   vs_convt_tap_supported : 1 when the geometry is served (16-bit compute, square 4x4 / 8x8 / 16x16 inputs, Cin % 8 == 0,
+ *                            Cin >= 32, Cout >= 8, (B / groups) % (256 / (H*W)) == 0), else 0 -> use vs_conv_transpose2d_fwd.
+ *   vs_convt_tap_pack_weight: fp32 master weight [Cin][Cout][4][4] -> dst [ceil(Cout/16)][16 taps x 16 channels][Cin] (compute type;
+ *                            vs_convt_tap_packed_elems elements), once per optimizer step.
+ *   vs_convt_k4s2_tap_fwd  : y [B, Cout, 2H, 2W] (compute type) = convT(x [B, Cin, H, W]) + bias.  bn_sums (fp64 [groups][Cout][2],
+ *                            may be NULL): sum and sum of squares of the STORED outputs per (BatchNorm call group, channel),
+ *                            zeroed and accumulated by this call -- feeds vs_bn_stats_from_sums, replacing the vs_bn_stats pass.
+ *   vs_bn_stats_from_sums  : vs_bn_stats's outputs (mean, invstd [groups, C]; running statistics folded group by group) from
+ *                            those sums; n_per_group = elements per (group, channel).                                        */
+int vs_convt_tap_supported(int compute, int B, int Cin, int H, int W, int Cout, int groups);
+size_t vs_convt_tap_packed_elems(int Cin, int Cout);
+int vs_convt_tap_pack_weight(int compute, const float* w, int Cin, int Cout, void* dst, void* stream);
+int vs_convt_k4s2_tap_fwd(int compute, const void* x, const void* w_tap, const float* bias, void* y, double* bn_sums, int B, int Cin, int H,
+                          int W, int Cout, int groups, void* stream);
+/* Conv2d k3 s1 p1 the same way (reference: every 3x3 block of EncoderSST / DecoderSST(_Skip) conv.py:323-426, ConvResBlock
+ * resnet.py:53-88, VGG64Encoder / VGG64Decoder conv.py:127-171, 267-320) on 4x4 / 8x8 / 16x16 maps: tile rows = 9 taps x 28
+ * channels, out[m][y][x] = sum_t G_t[m][y+ky-1][x+kx-1] in the epilogue.  The input gradient is the same kernel on dz with the
+ * weight read transposed and flipped: pack with flip = 1, Cin := the conv's Cout, Cout := the conv's Cin.
+ * y_dtype may be VS_F32 (a module's final block keeps fp32 outputs).                                                        */
+int vs_conv_k3_tap_supported(int compute, int B, int Cin, int H, int W, int Cout, int groups);
+size_t vs_conv_k3_tap_packed_elems(int Cin, int Cout);
+int vs_conv_k3_tap_pack_weight(int compute, const float* w, int Cin, int Cout, int flip, void* dst, void* stream);
+int vs_conv_k3s1_tap_fwd(int compute, const void* x, const void* w_tap, const float* bias, void* y, int y_dtype, double* bn_sums, int B,
+                         int Cin, int H, int W, int Cout, int groups, void* stream);
+int vs_bn_stats_from_sums(const double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* var_scratch,
+                          float* running_mean, float* running_var, float momentum, float eps, void* stream);
+
 /* One batch of Moving-MNIST training sequences rendered on the device (reference: data/moving_mnist.py:112-175 `__getitem__` +
  * `_compute_trajectory`, :177-255 `_process_collision`, deterministic mode as main.py:81-82 constructs it).
  * digits [n_digits_total, digit_h, digit_w] uint8 in HBM; init [batch, num_digits, 5] int32 = (digit index, start row, start column,

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvarsep_hip.so')
-SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip']
+SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip', 'vs_conv_tap.hip']
 
 F32, BF16, F16 = 0, 1, 2
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
@@ -104,6 +104,15 @@ SIGNATURES = {
     'vs_train_losses_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     'vs_train_losses_bwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _i32, _vp, _i32, _vp]),
+    'vs_convt_tap_supported': (_i32, [_i32] * 7),
+    'vs_convt_tap_packed_elems': (_sz, [_i32, _i32]),
+    'vs_convt_tap_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _vp, _vp]),
+    'vs_convt_k4s2_tap_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 6 + [_vp]),
+    'vs_conv_k3_tap_supported': (_i32, [_i32] * 7),
+    'vs_conv_k3_tap_packed_elems': (_sz, [_i32, _i32]),
+    'vs_conv_k3_tap_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'vs_conv_k3s1_tap_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _vp] + [_i32] * 6 + [_vp]),
+    'vs_bn_stats_from_sums': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp]),
     'vs_moving_mnist_batch': (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     'vs_gather_windows': (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     'vs_mix_codes_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),

@@ -208,8 +208,7 @@ def shadow(p, dtype):
 def shadow_buffer_for_update(p):
     """The live bf16 operand copy of `p`, if one exists: the optimizer kernel rewrites it in the pass that updates `p`."""
     ent = _shadow.get(id(p))
-    if ent is not None and ent[2] is p and ent[1].shape == p.shape and ent[1].dtype == compute_dtype() and ent[1].dtype != torch.float32 \
-            and ent[1].is_contiguous():
+    if ent is not None and ent[2] is p and ent[1].shape == p.shape and ent[1].dtype in (torch.bfloat16, torch.float16) and ent[1].is_contiguous():
         return ent[1]
     return None
 
@@ -467,6 +466,36 @@ def packed_conv_weight(p, dtype, stride, pad):
     return ent[1]
 
 
+_packed_tap = {}
+
+
+def packed_tap_weight(p, dtype):
+    """Tap-GEMM pre-pack of a ConvTranspose2d k4 s2 p1 weight (ops.convt_tap_pack_weight), cached per parameter version."""
+    key = (id(p), dtype)
+    ent = _packed_tap.get(key)
+    if ent is None or ent[0] != p._version or ent[2] is not p:
+        buf = ent[1] if ent is not None and ent[2] is p else None
+        buf = ops.convt_tap_pack_weight(p.detach().contiguous(), dtype, out=buf)
+        _packed_tap[key] = (p._version, buf, p)
+        return buf
+    return ent[1]
+
+
+_packed_k3 = {}
+
+
+def packed_k3_weight(p, dtype, flip):
+    """Tap-GEMM pre-pack of a Conv2d k3 s1 p1 weight (forward, or flipped / transposed for the input gradient)."""
+    key = (id(p), dtype, bool(flip))
+    ent = _packed_k3.get(key)
+    if ent is None or ent[0] != p._version or ent[2] is not p:
+        buf = ent[1] if ent is not None and ent[2] is p else None
+        buf = ops.conv_k3_tap_pack_weight(p.detach().contiguous(), dtype, flip, out=buf)
+        _packed_k3[key] = (p._version, buf, p)
+        return buf
+    return ent[1]
+
+
 class ConvBlock(torch.autograd.Function):
     """conv / transposed conv -> [BatchNorm2d (per-call batch statistics)] -> [activation]  (conv.py:41-60).
 
@@ -482,10 +511,29 @@ class ConvBlock(torch.autograd.Function):
         cdt = compute_dtype()
         out_dt = torch.float32 if out_fp32 else cdt
         xc = to_compute(x, cdt)
-        wc = shadow(w, cdt)
-        wp = packed_conv_weight(w, cdt, stride, pad) if transposed else None
         bias = b.detach() if b is not None else None
-        if has_bn:
+        # ConvTranspose2d k4 s2 p1 on 4x4 / 8x8 / 16x16 maps (the DCGAN decoder's middle layers): LDS-staged tap GEMM with the
+        # col2im and the BatchNorm sums in its epilogue -- no column matrix, no separate statistics pass
+        tap = (transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4 and has_bn
+               and ops.convt_tap_supported(xc, w.shape[1], groups))
+        k3 = (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
+              and ops.conv_k3_tap_supported(xc, w.shape[0], groups))
+        if tap or (k3 and has_bn):
+            if tap:
+                z, sums = ops.convt_tap_fwd(xc, packed_tap_weight(w, cdt), bias, w.shape[1], groups=groups, want_sums=training)
+            else:
+                z, sums = ops.conv_k3_tap_fwd(xc, packed_k3_weight(w, cdt, False), bias, w.shape[0], cdt, groups=groups, want_sums=training)
+            if training:
+                n_per = (z.shape[0] // groups) * z.shape[2] * z.shape[3]
+                mean, invstd = ops.bn_stats_from_sums(sums, n_per, rmean, rvar, momentum, eps)
+            else:
+                mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
+                invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
+            y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
+            ctx.save_for_backward(xc, z, mean, invstd)
+        elif has_bn:
+            wc = shadow(w, cdt)
+            wp = packed_conv_weight(w, cdt, stride, pad) if transposed else None
             z = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, cdt, w_packed=wp)
             if training:
                 mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
@@ -495,7 +543,12 @@ class ConvBlock(torch.autograd.Function):
             y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
             ctx.save_for_backward(xc, z, mean, invstd)
         else:
-            y = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, out_dt, w_packed=wp)
+            if k3:
+                y, _ = ops.conv_k3_tap_fwd(xc, packed_k3_weight(w, cdt, False), bias, w.shape[0], out_dt, groups=1)
+            else:
+                wc = shadow(w, cdt)
+                wp = packed_conv_weight(w, cdt, stride, pad) if transposed else None
+                y = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, out_dt, w_packed=wp)
             if act not in ('none', None):
                 ops.act_fwd(y, act, out=y)
             ctx.save_for_backward(xc, y)
@@ -528,9 +581,19 @@ class ConvBlock(torch.autograd.Function):
         dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed) if w.requires_grad else None
         dx = None
         if ctx.x_needs_grad:
-            wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
-            dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
-                                cols_from_wgrad=transposed and dw is not None)
+            # the input gradient of Conv2d k4 s2 p1 IS a ConvTranspose2d k4 s2 p1 of dz with the same weight tensor ([Cout, Cin, 4, 4]
+            # read as [in, out, 4, 4]): on 4x4 / 8x8 / 16x16 gradient maps it takes the LDS-staged tap kernel (no column matrix)
+            if (not transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4 and ctx.x_dtype == dz.dtype
+                    and xc.shape[2] == 2 * dz.shape[2] and xc.shape[3] == 2 * dz.shape[3] and ops.convt_tap_supported(dz, w.shape[1], 1)):
+                dx, _ = ops.convt_tap_fwd(dz, packed_tap_weight(w, cdt), None, w.shape[1], groups=1, want_sums=False, name='vs_conv_dgrad')
+            elif (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
+                  and ops.conv_k3_tap_supported(dz, w.shape[1], 1)):
+                # Conv2d k3 s1 p1: the input gradient is the same convolution of dz with the weight transposed and flipped
+                dx, _ = ops.conv_k3_tap_fwd(dz, packed_k3_weight(w, cdt, True), None, w.shape[1], ctx.x_dtype, groups=1, name='vs_conv_dgrad')
+            else:
+                wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
+                dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
+                                    cols_from_wgrad=transposed and dw is not None)
         if _STATE.get('fold_grads'):
             # the FIRST contribution of a parameter in this backward pass goes to autograd (which keeps that very tensor as the
             # parameter's pending gradient); later contributions of the pass are added INTO it with one multi-tensor launch per

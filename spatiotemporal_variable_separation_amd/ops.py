@@ -471,6 +471,93 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed):
     return dw
 
 
+# ---- ConvTranspose2d k4 s2 p1 forward as tap GEMM + col2im epilogue (csrc/vs_conv_tap.hip) -------------------------------------
+def convt_tap_supported(x, Cout, groups):
+    import os
+    if os.environ.get('VS_CONV_TAP') == '0' or x.dtype == torch.float32:
+        return False
+    B, Cin, H, W = x.shape
+    return bool(_lib.load_library().vs_convt_tap_supported(dtype_code(x), B, Cin, H, W, Cout, groups))
+
+
+def convt_tap_pack_weight(w_master, dtype, out=None):
+    """fp32 ConvTranspose2d weight [Cin, Cout, 4, 4] -> [ceil(Cout/16), 16 taps x 16 channels, Cin] in `dtype`."""
+    require_cuda(w_master)
+    assert w_master.dtype == torch.float32 and w_master.is_contiguous() and tuple(w_master.shape[2:]) == (4, 4)
+    Cin, Cout = w_master.shape[0], w_master.shape[1]
+    lib = _lib.load_library()
+    if out is None:
+        out = torch.empty((lib.vs_convt_tap_packed_elems(Cin, Cout),), dtype=dtype, device=w_master.device)
+    check(lib.vs_convt_tap_pack_weight(code_of(dtype), w_master.data_ptr(), Cin, Cout, out.data_ptr(), stream_ptr()), 'vs_convt_tap_pack_weight')
+    return out
+
+
+def convt_tap_fwd(x, w_tap, bias, Cout, groups=1, want_sums=True, name='vs_convT_fwd'):
+    """-> (y [B, Cout, 2H, 2W] in x's dtype, fp64 sums [groups, Cout, 2] of the stored outputs or None)."""
+    require_cuda(x, w_tap, bias)
+    assert x.is_contiguous() and x.dtype == w_tap.dtype
+    B, Cin, H, W = x.shape
+    y = torch.empty((B, Cout, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+    sums = torch.empty((groups, Cout, 2), dtype=torch.float64, device=x.device) if want_sums else None
+    e0 = _pb()
+    check(_lib.load_library().vs_convt_k4s2_tap_fwd(dtype_code(x), x.data_ptr(), w_tap.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(sums), B, Cin, H, W,
+                                                    Cout, groups, stream_ptr()), 'vs_convt_k4s2_tap_fwd')
+    _pe(e0, '%s<%s>' % (name, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 16,
+        nbytes=float(x.numel() * x.element_size() + w_tap.numel() * 2 + y.numel() * y.element_size()))
+    return y, sums
+
+
+def conv_k3_tap_supported(x, Cout, groups):
+    import os
+    if os.environ.get('VS_CONV_TAP') == '0' or x.dtype == torch.float32:
+        return False
+    B, Cin, H, W = x.shape
+    return bool(_lib.load_library().vs_conv_k3_tap_supported(dtype_code(x), B, Cin, H, W, Cout, groups))
+
+
+def conv_k3_tap_pack_weight(w_master, dtype, flip, out=None):
+    """fp32 Conv2d weight [Cout, Cin, 3, 3] -> tap-GEMM rows [ceil(M/28), 9 taps x 28 channels (256 rows), K] in `dtype`.
+    flip=False: forward (M = Cout, K = Cin).  flip=True: input gradient (M = Cin, K = Cout, taps flipped)."""
+    require_cuda(w_master)
+    assert w_master.dtype == torch.float32 and w_master.is_contiguous() and tuple(w_master.shape[2:]) == (3, 3)
+    Cout, Cin = w_master.shape[0], w_master.shape[1]
+    M, K = (Cin, Cout) if flip else (Cout, Cin)
+    lib = _lib.load_library()
+    if out is None:
+        out = torch.empty((lib.vs_conv_k3_tap_packed_elems(K, M),), dtype=dtype, device=w_master.device)
+    check(lib.vs_conv_k3_tap_pack_weight(code_of(dtype), w_master.data_ptr(), K, M, int(bool(flip)), out.data_ptr(), stream_ptr()),
+          'vs_conv_k3_tap_pack_weight')
+    return out
+
+
+def conv_k3_tap_fwd(x, w_tap, bias, Cout, out_dtype, groups=1, want_sums=False, name='vs_conv_fwd'):
+    """-> (y [B, Cout, H, W] in out_dtype, fp64 sums [groups, Cout, 2] of the stored outputs or None)."""
+    require_cuda(x, w_tap, bias)
+    assert x.is_contiguous() and x.dtype == w_tap.dtype
+    B, Cin, H, W = x.shape
+    y = torch.empty((B, Cout, H, W), dtype=out_dtype, device=x.device)
+    sums = torch.empty((groups, Cout, 2), dtype=torch.float64, device=x.device) if want_sums else None
+    e0 = _pb()
+    check(_lib.load_library().vs_conv_k3s1_tap_fwd(dtype_code(x), x.data_ptr(), w_tap.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), _ptr(sums),
+                                                   B, Cin, H, W, Cout, groups, stream_ptr()), 'vs_conv_k3s1_tap_fwd')
+    _pe(e0, '%s<%s>' % (name, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
+        nbytes=float(x.numel() * x.element_size() + w_tap.numel() * 2 + y.numel() * y.element_size()))
+    return y, sums
+
+
+def bn_stats_from_sums(sums, n_per_group, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """(mean, invstd) [groups, C] from the fp64 (sum, sum of squares) a fused conv epilogue produced; folds the running statistics."""
+    require_cuda(sums)
+    groups, C = sums.shape[0], sums.shape[1]
+    mean = torch.empty((groups, C), dtype=torch.float32, device=sums.device)
+    invstd = torch.empty((groups, C), dtype=torch.float32, device=sums.device)
+    scratch = torch.empty((groups, C), dtype=torch.float32, device=sums.device) if running_mean is not None else None
+    check(_lib.load_library().vs_bn_stats_from_sums(sums.data_ptr(), groups, C, int(n_per_group), mean.data_ptr(), invstd.data_ptr(), _ptr(scratch),
+                                                    _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), stream_ptr()),
+          'vs_bn_stats_from_sums')
+    return mean, invstd
+
+
 # ------------------------------------------------------------------------------------------------ norm / pool / upsample
 def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, groups=1):
     """Per-(group, channel) batch statistics; returns (mean [groups, C], invstd [groups, C])."""

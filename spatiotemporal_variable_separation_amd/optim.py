@@ -176,10 +176,16 @@ class Adam(torch.optim.Optimizer):
         stream = torch.cuda.current_stream(live[0].device).cuda_stream
         lr, (b1, b2), eps = group['lr'], group['betas'], group['eps']
         scale_state = getattr(self, '_scale_state', None)
-        sdt = _lib.code_of(VF.compute_dtype()) if VF.compute_dtype() != torch.float32 else _lib.BF16
+        written = []
         for i in range(0, len(live), 64):
             chunk = live[i:i + 64]
             shadows = [VF.shadow_buffer_for_update(p) for p in chunk]
+            # one 16-bit type per launch: the live operand copies are all of the current compute dtype; a stray copy of the other
+            # type (left from an earlier mode) is not rewritten here and refreshes itself on next use (version counter)
+            kinds = [s.dtype for s in shadows if s is not None]
+            sdt = _lib.code_of(kinds[0]) if kinds else _lib.BF16
+            shadows = [s if (s is not None and s.dtype == kinds[0]) else None for s in shadows]
+            written += [p for p, s in zip(chunk, shadows) if s is not None]
             tab = self._table(gi, chunk, shadows)
             e0 = ops._pb()
             rc = lib.vs_adam_multi_scaled(len(chunk), ctypes.cast(tab[0], ctypes.c_void_p), ctypes.cast(tab[1], ctypes.c_void_p),
@@ -197,7 +203,7 @@ class Adam(torch.optim.Optimizer):
         for p in live:
             # the kernel wrote through raw pointers: tell autograd / the operand caches that the parameter changed
             torch.autograd.graph.increment_version(p)
-        VF.shadows_written(live)
+        VF.shadows_written(written)
 
     def state_dict(self):
         # keep the per-parameter `step` entries (torch layout) in sync with the device counter before serialising

@@ -226,3 +226,94 @@ def test_batchnorm_planes_not_a_multiple_of_the_vector_width(dtype, shape, group
         dx32, dg32, db32 = ops.bn_act_bwd(dyc.float(), xc, mean, invstd, gamma.cuda(), beta.cuda(), 'leaky_relu', True, torch.float32, groups=groups)
         assert rel(y32, torch.cat(ys)) < 2e-5 and rel(dx32, torch.cat(dxs)) < 2e-5
         assert rel(dg32, dgs) < 2e-5 and rel(db32, dbs) < 2e-5
+
+
+# ---- ConvTranspose2d k4 s2 p1 as tap GEMM + col2im epilogue (csrc/vs_conv_tap.hip) ------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom', [
+    # (B, Cin, H, Cout, groups)
+    (32, 64, 4, 32, 2),       # 4x4 maps: 16 samples per 256-pixel tile
+    (16, 128, 8, 64, 4),      # 8x8 maps: 4 samples per tile
+    (6, 96, 16, 40, 3),       # 16x16 maps: one sample per tile; Cout not a multiple of 16, K = 96 (three K tiles)
+    (48, 32, 4, 8, 1),        # a single K tile, 8 output channels (half an m-block)
+    (20, 200, 8, 24, 5),      # K tail (200 = 6 x 32 + 8), last pixel tile partly empty (20 x 64 = 1280 = 5 x 256)
+    (128, 512, 4, 256, 1),    # DCGAN decoder layer 1 at full width
+])
+def test_convt_tap_kernel_matches_fp64_and_yields_batchnorm_sums(dtype, geom):
+    """Output = fp64 transposed convolution of the same rounded operands, rounded once to the storage type; the epilogue's fp64
+    sums are those of the stored values per (call group, channel), so vs_bn_stats_from_sums reproduces vs_bn_stats."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, Cin, H, Cout, groups = geom
+    x = _rand((B, Cin, H, H), 41).to(dtype)
+    w32 = _rand((Cin, Cout, 4, 4), 42, 0.3)
+    w = w32.to(dtype)
+    bias = _rand((Cout,), 43)
+    xc = x.cuda()
+    assert ops.convt_tap_supported(xc, Cout, groups)
+    wt = ops.convt_tap_pack_weight(w.float().cuda(), dtype)
+    y, sums = ops.convt_tap_fwd(xc, wt, bias.cuda(), Cout, groups=groups)
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(x.double(), w.double(), bias.double(), stride=2, padding=1)
+    assert tuple(y.shape) == tuple(ref.shape) and y.dtype == dtype
+    want = ref.to(dtype)                                        # one rounding of the exact sum
+    diff = (y.cpu().double() - want.double()).abs()
+    ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * want.double().abs().clamp_min(1e-3)     # >= one unit in the last place
+    slack = 2e-6 * want.double().abs().max()                     # fp32 accumulation noise on near-zero sums (K up to 2048 products)
+    assert (diff <= 1.01 * ulp + slack).all(), f'{geom} {dtype}: max {diff.max().item():.3e}'     # fp32 accumulation order: at most one ulp
+    assert (diff > 0).double().mean().item() < 0.02, 'more than 2 % of the elements differ by an ulp'
+    # sums of the STORED values
+    ys = y.cpu().double().view(groups, B // groups, Cout, -1)
+    s1, s2 = ys.sum(dim=(1, 3)), (ys * ys).sum(dim=(1, 3))
+    got = sums.cpu()
+    assert torch.allclose(got[..., 0], s1, rtol=1e-6, atol=1e-6) and torch.allclose(got[..., 1], s2, rtol=1e-6, atol=1e-6)
+    rm, rv = torch.zeros(Cout).cuda(), torch.ones(Cout).cuda()
+    rm2, rv2 = rm.clone(), rv.clone()
+    mean, invstd = ops.bn_stats_from_sums(sums, (B // groups) * 4 * H * H, rm, rv, 0.1, 1e-5)
+    mean2, invstd2 = ops.bn_stats(y, rm2, rv2, 0.1, 1e-5, groups=groups)
+    assert torch.allclose(mean, mean2, rtol=1e-6, atol=1e-7) and torch.allclose(invstd, invstd2, rtol=1e-5)
+    assert torch.allclose(rm, rm2, rtol=1e-6, atol=1e-7) and torch.allclose(rv, rv2, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom', [
+    # (B, Cin, H, Cout, groups)
+    (32, 64, 4, 40, 2),       # 4x4 maps (VGG encoder tail): 4-pixel work items
+    (16, 128, 8, 64, 4),      # 8x8
+    (5, 96, 16, 30, 1),       # 16x16, Cout = one full block of 28 + 2
+    (8, 64, 16, 512, 1),      # ConvResBlock of the SST integrator, first conv (64 -> 512 at 16x16)
+    (3, 520, 16, 64, 3),      # K tail (520 = 16 x 32 + 8), three call groups
+])
+def test_conv_k3_tap_kernel_forward_and_input_gradient(dtype, geom):
+    """Conv2d k3 s1 p1 through the tap kernel: output (one rounding of the exact sum), BatchNorm sums of the stored values, fp32
+    output form, and the input gradient via the flipped / transposed pack."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, Cin, H, Cout, groups = geom
+    x = _rand((B, Cin, H, H), 51).to(dtype)
+    w32 = _rand((Cout, Cin, 3, 3), 52, 0.3)
+    w = w32.to(dtype)
+    bias = _rand((Cout,), 53)
+    xc = x.cuda()
+    assert ops.conv_k3_tap_supported(xc, Cout, groups)
+    wt = ops.conv_k3_tap_pack_weight(w.float().cuda(), dtype, False)
+    y, sums = ops.conv_k3_tap_fwd(xc, wt, bias.cuda(), Cout, dtype, groups=groups, want_sums=True)
+    y32, _ = ops.conv_k3_tap_fwd(xc, wt, bias.cuda(), Cout, torch.float32)
+    torch.cuda.synchronize()
+    x64 = x.double().requires_grad_(True)
+    ref = F.conv2d(x64, w.double(), bias.double(), stride=1, padding=1)
+    want = ref.detach().to(dtype)
+    diff = (y.cpu().double() - want.double()).abs()
+    ulp = (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * want.double().abs().clamp_min(1e-3)
+    slack = 2e-6 * want.double().abs().max()
+    assert (diff <= 1.01 * ulp + slack).all(), f'{geom} {dtype}: max {diff.max().item():.3e}'
+    assert (diff > 0).double().mean().item() < 0.02
+    assert ((y32.cpu().double() - ref.detach()).norm() / ref.detach().norm()).item() < 1e-5
+    ys = y.cpu().double().view(groups, B // groups, Cout, -1)
+    got = sums.cpu()
+    assert torch.allclose(got[..., 0], ys.sum(dim=(1, 3)), rtol=1e-6, atol=1e-6) and torch.allclose(got[..., 1], (ys * ys).sum(dim=(1, 3)), rtol=1e-6, atol=1e-6)
+    # input gradient: dz (16-bit) -> dx, fp32 and 16-bit outputs
+    dz = _rand(tuple(ref.shape), 54).to(dtype)
+    ref.backward(dz.double())
+    if ops.conv_k3_tap_supported(dz.cuda(), Cin, 1):
+        wtf = ops.conv_k3_tap_pack_weight(w.float().cuda(), dtype, True)
+        dx, _ = ops.conv_k3_tap_fwd(dz.cuda(), wtf, None, Cin, torch.float32)
+        assert ((dx.cpu().double() - x64.grad).norm() / x64.grad.norm()).item() < 1e-5, f'dgrad {geom} {dtype}'
