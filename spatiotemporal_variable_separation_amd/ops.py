@@ -507,11 +507,18 @@ def convt_tap_fwd(x, w_tap, bias, Cout, groups=1, want_sums=True, name='vs_convT
     return y, sums
 
 
-def conv_k3_tap_supported(x, Cout, groups):
+def conv_k3_tap_supported(x, Cout, groups, force=False):
+    """Whether Conv2d k3 s1 p1 on `x` takes the tap kernel.  Measured (tools/conv_bench.py): with 9 taps x 28 channels per tile the
+    epilogue (shift-sum of nine maps) outweighs the saved column matrix unless the contraction is long -- 512 -> 512 at 16x16
+    (the SST integrator): 45 vs 65 us; 128 -> 128 (K = 4 tiles): 489 vs 371 us -- so it is taken for Cin >= 384, Cout >= 256
+    (VS_CONV_TAP=2 or force=True: whenever the geometry is supported; VS_CONV_TAP=0: never)."""
     import os
-    if os.environ.get('VS_CONV_TAP') == '0' or x.dtype == torch.float32:
+    mode = os.environ.get('VS_CONV_TAP')
+    if mode == '0' or x.dtype == torch.float32:
         return False
     B, Cin, H, W = x.shape
+    if not (force or mode == '2') and (Cin < 384 or Cout < 256):
+        return False
     return bool(_lib.load_library().vs_conv_k3_tap_supported(dtype_code(x), B, Cin, H, W, Cout, groups))
 
 

@@ -293,7 +293,7 @@ def test_conv_k3_tap_kernel_forward_and_input_gradient(dtype, geom):
     w = w32.to(dtype)
     bias = _rand((Cout,), 53)
     xc = x.cuda()
-    assert ops.conv_k3_tap_supported(xc, Cout, groups)
+    assert ops.conv_k3_tap_supported(xc, Cout, groups, force=True)
     wt = ops.conv_k3_tap_pack_weight(w.float().cuda(), dtype, False)
     y, sums = ops.conv_k3_tap_fwd(xc, wt, bias.cuda(), Cout, dtype, groups=groups, want_sums=True)
     y32, _ = ops.conv_k3_tap_fwd(xc, wt, bias.cuda(), Cout, torch.float32)
@@ -313,7 +313,7 @@ def test_conv_k3_tap_kernel_forward_and_input_gradient(dtype, geom):
     # input gradient: dz (16-bit) -> dx, fp32 and 16-bit outputs
     dz = _rand(tuple(ref.shape), 54).to(dtype)
     ref.backward(dz.double())
-    if ops.conv_k3_tap_supported(dz.cuda(), Cin, 1):
+    if ops.conv_k3_tap_supported(dz.cuda(), Cin, 1, force=True):
         wtf = ops.conv_k3_tap_pack_weight(w.float().cuda(), dtype, True)
         dx, _ = ops.conv_k3_tap_fwd(dz.cuda(), wtf, None, Cin, torch.float32)
         assert ((dx.cpu().double() - x64.grad).norm() / x64.grad.norm()).item() < 1e-5, f'dgrad {geom} {dtype}'
