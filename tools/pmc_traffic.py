@@ -14,9 +14,11 @@ import sys
 from collections import defaultdict
 
 GEMM = re.compile(r'gemm_kernel<1, (?:\(anonymous namespace\)::)?Dense<1, (\d)>, (?:\(anonymous namespace\)::)?Dense<1, (\d)>,')
+GEMM_BIG = re.compile(r'gemm_big_kernel<1, (\d), (\d),')          # 256x256 LDS-DMA ring tile
+GEMM_GLDS = re.compile(r'gemm_glds_kernel<(\d), (\d),')          # 128x128 LDS-DMA tile
 FAMILIES = [
-    (r'rollout_ws_kernel<\d+, true>', 'vs_mlp_rollout_fwd<bf16>'),
-    (r'rollout_ws_kernel<\d+, false>', 'vs_mlp_rollout_bwd<bf16>'),
+    (r'rollout_ws_kernel<\d+, true', 'vs_mlp_rollout_fwd<bf16>'),
+    (r'rollout_ws_kernel<\d+, false', 'vs_mlp_rollout_bwd<bf16>'),
     (r'colsum_multi_kernel', 'vs_colsum_multi'),
     (r'adam_multi_kernel', 'vs_adam_multi'),
     (r'train_losses_fwd_kernel', 'vs_train_losses_fwd'),
@@ -24,13 +26,21 @@ FAMILIES = [
     (r'splitk_reduce_kernel', 'splitk_reduce'),
     (r'mix_codes_fwd_kernel', 'vs_mix_codes_fwd'),
     (r'mix_codes_bwd_kernel', 'vs_mix_codes_bwd'),
+    (r'convt_k4s2_tap_kernel', 'vs_convT_fwd<bf16> (tap kernel)'),
+    (r'conv_k3s1_tap_kernel', 'vs_conv_fwd<bf16> (3x3 tap kernel)'),
+    (r'im2col_', 'im2col (column-matrix gathers)'),
+    (r'bn_act_fwd_kernel', 'vs_bn_act_fwd'),
+    (r'bn_bwd_', 'vs_bn_act_bwd'),
+    (r'bn_stats_kernel', 'vs_bn_stats'),
+    (r'gemm_kernel<1, .*ChanRows', 'vs_conv_wgrad<bf16> (GEMM part)'),
 ]
 
 
 def family(name):
-    m = GEMM.search(name)
-    if m:
-        return 'vs_gemm<bf16,%s%s>' % ('RS'[int(m.group(1))], 'RS'[int(m.group(2))])
+    for pat in (GEMM, GEMM_BIG, GEMM_GLDS):
+        m = pat.search(name)
+        if m:
+            return 'vs_gemm<bf16,%s%s>' % ('RS'[int(m.group(1))], 'RS'[int(m.group(2))])
     for pat, fam in FAMILIES:
         if re.search(pat, name):
             return fam
@@ -65,7 +75,7 @@ def main():
     out['_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --no_graph --steps 6 --warmup 2`; FETCH_SIZE x2 (gfx950)'
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     with open(sys.argv[4], 'w') as md:
-        md.write('# Round 1 HBM-side traffic (rocprofv3 --pmc, separate passes for FETCH_SIZE and WRITE_SIZE) -- WaveEq bf16\n\n')
+        md.write('# HBM-side traffic (rocprofv3 --pmc, separate passes for FETCH_SIZE and WRITE_SIZE), bf16: %s\n\n' % (sys.argv[5] if len(sys.argv) > 5 else 'WaveEq'))
         md.write('FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B, MI355X_MICROARCH.md section HBM); WRITE_SIZE as reported.\n'
                  'Infinity-Cache hits are counted by these fabric-side counters, so this is traffic beyond L2, an upper bound on HBM bytes.\n\n')
         md.write('| kernel family | launches | fetch MB/launch (x2) | write MB/launch |\n|---|---|---|---|\n')
