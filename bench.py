@@ -30,6 +30,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import spatiotemporal_variable_separation_amd  # noqa: E402,F401  (sets the HIP runtime's queue knobs before torch initialises HIP)
 
 import numpy as np          # noqa: E402
 import torch                # noqa: E402

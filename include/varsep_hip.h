@@ -236,6 +236,10 @@ int vs_adam_multi_scaled(int n_tensors, float* const* params, const void* const*
                          float* const* exp_avg_sq, void* const* shadow, int shadow_dtype, const int64_t* numel, const int32_t* skipped,
                          int32_t* step, double lr, double beta1, double beta2, double eps, const float* scale_state, void* stream);
 int vs_adam_step_increment_scaled(int32_t* step, const float* scale_state, void* stream);
+/* Caps the grid of the following vs_adam_multi* launches of this process at `blocks` workgroups (0: the default, 4096), returns
+ * the previous cap.  A bucket updated WHILE backward is still running is launched with a small grid (2 workgroups per CU) so
+ * that it streams HBM in the background and leaves the wave slots to the GEMMs on the critical path.                         */
+int vs_adam_set_max_blocks(int blocks);
 int vs_loss_scale_update(float* scale_state, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
 /* Fused frame losses (train.py:85-86 ae_loss MSE and train.py:139 forecast MSE in one pass over the decoded frames).

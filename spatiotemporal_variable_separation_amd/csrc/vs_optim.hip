@@ -29,6 +29,8 @@ struct AdamJobs {
     int nj;
 };
 
+int g_adam_max_blocks = 0;                 // vs_adam_set_max_blocks: grid cap of the next launches (0 = default)
+
 // scale_state (optional, fp16 loss scaling): [0] = loss scale S (gradients arrive multiplied by S and are used as g / S),
 // [1] = found_inf flag of this step (non-zero: leave everything untouched, GradScaler.step semantics)
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* __restrict__ step, double lr_d, double beta1_d, double beta2_d,
@@ -189,10 +191,17 @@ extern "C" int vs_adam_multi_scaled(int n_tensors, float* const* params, const v
     }
     J.shadow_dtype = shadow ? shadow_dtype : VS_BF16;
     int blocks = J.chunk_off[n_tensors];
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const int cap = g_adam_max_blocks > 0 ? g_adam_max_blocks : 256 * 16;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J, step, lr, beta1, beta2, (float)eps, scale_state);
     VS_CHECK_LAUNCH("vs_adam_multi");
     return VS_OK;
+}
+
+extern "C" int vs_adam_set_max_blocks(int blocks) {
+    const int prev = g_adam_max_blocks;
+    g_adam_max_blocks = blocks > 0 ? blocks : 0;
+    return prev;
 }
 
 extern "C" int vs_adam_multi(int n_tensors, float* const* params, const void* const* grads, const int32_t* grad_dtype, float* const* exp_avg,

@@ -10,6 +10,7 @@ Precision policy (`set_precision` / `precision(...)`):
             (torch.cuda.amp autocast, train.py:96-97); trained with dynamic loss scaling (train.LossScaler).
 """
 import contextlib
+import os
 
 import torch
 
@@ -98,11 +99,17 @@ def compute_dtype():
 #     E_s encoder, its backward overlaps the decoder/encoder weight gradients.
 # Only valid when every parameter receives ONE gradient per step (the batched MLP-family step) and without hook-driven
 # gradient all-reduce; `train._compute_losses_mlp_batched` / `GraphedStep` switch it on, everything else leaves it off.
-_SIDE = {'on': False, 'wgrad': None, 'rollout': None}
+_SIDE = {'on': False, 'lanes': [], 'next_lane': 0, 'rollout': None, 'hold': False, 'held': [], 'hold_main': None}
+# Deferred gradient work is spread over a few streams ("lanes", one per Linear chain / integrator backward in turn): most of it
+# is GEMMs of 10-50 us that fill a fraction of the chip each, and one stream would run them one after the other.
+N_LANES = max(1, int(os.environ.get('VARSEP_WGRAD_LANES', '3')))
 
 
 def enable_side_streams(flag):
     _SIDE['on'] = bool(flag)
+    _SIDE['next_lane'] = 0
+    if not flag:
+        _SIDE['hold'], _SIDE['held'] = False, []
 
 
 def side_streams_enabled():
@@ -115,21 +122,102 @@ def _side_stream(name):
     return _SIDE[name]
 
 
-def run_deferred(fn, *inputs):
-    """Run `fn()` (weight-gradient launches) on the wgrad stream behind everything queued so far on the current stream."""
-    if not _SIDE['on']:
-        return fn()
-    main, ws = torch.cuda.current_stream(), _side_stream('wgrad')
-    ws.wait_stream(main)
+def _lane_stream(i):
+    while len(_SIDE['lanes']) <= i:
+        _SIDE['lanes'].append(torch.cuda.Stream())
+    return _SIDE['lanes'][i]
+
+
+def next_lane():
+    """The lane the next group of deferred launches should use (round robin)."""
+    i = _SIDE['next_lane']
+    _SIDE['next_lane'] = (i + 1) % N_LANES
+    return i
+
+
+def hold_deferred(flag=True):
+    """While held, deferred gradient work is only COLLECTED; `release_deferred()` launches it.  The batched MLP-family step
+    holds the decoder's and E_s's weight gradients until the integrator's backward kernel has been launched: that kernel is a
+    latency-bound chain on 192 workgroups (215 us at WaveEq size with the rest of the chip idle), the weight-gradient GEMMs fill
+    the chip under it, and the decoder's input-gradient chain -- the critical path up to there -- has the GPU to itself instead
+    of sharing it with them (measured on the WaveEq step: the decoder's backward 432 -> 190 us)."""
+    _SIDE['hold'] = bool(flag) and _SIDE['on']
+    _SIDE['hold_main'] = torch.cuda.current_stream() if _SIDE['hold'] else None
+    if not flag:
+        _SIDE['held'] = []
+
+
+def deferred_held():
+    return _SIDE['on'] and _SIDE['hold']
+
+
+def _record_on(ws, inputs, outs):
     for t in inputs:
         t.record_stream(ws)
+    for t in (outs if isinstance(outs, (list, tuple)) else [outs]):
+        if isinstance(t, torch.Tensor):
+            t.record_stream(ws)
+
+
+def run_deferred(fn, *inputs, outs=None, lane=0):
+    """Run `fn()` (weight-gradient launches) on a gradient stream behind everything queued so far on the current stream.
+    `outs`: the tensors `fn` writes, allocated by the caller -- required for the work to be holdable (hold_deferred); they are
+    returned in place of fn's result."""
+    if not _SIDE['on']:
+        out = fn()
+        return out if outs is None else outs
+    if _SIDE['hold'] and outs is not None:
+        _SIDE['held'].append((fn, inputs, outs, lane))
+        return outs
+    main, ws = torch.cuda.current_stream(), _lane_stream(lane)
+    ws.wait_stream(main)
     with torch.cuda.stream(ws):
         out = fn()
-    outs = out if isinstance(out, (list, tuple)) else [out]
-    for t in outs:
+    if outs is not None:
+        out = outs
+    _record_on(ws, inputs, out if outs is not None else ())
+    for t in (out if isinstance(out, (list, tuple)) else [out]):
         if isinstance(t, torch.Tensor):
             t.record_stream(main)
     return out
+
+
+def defer_call(fn):
+    """Queue `fn` (launches that consume held gradients, e.g. an optimizer bucket) behind ALL the held work; False if nothing is held."""
+    if not deferred_held():
+        return False
+    _SIDE['held'].append((fn, (), (), None))
+    return True
+
+
+def release_deferred(after=None):
+    """Launch everything collected since hold_deferred() on the gradient streams, in order, behind the work queued so far on the
+    stream the hold was declared on (the producer of every input of the held closures) and behind the event `after`."""
+    held, _SIDE['held'] = _SIDE['held'], []
+    was, _SIDE['hold'] = _SIDE['hold'], False
+    if not held:
+        return
+    main = _SIDE['hold_main'] if (was and _SIDE['hold_main'] is not None) else torch.cuda.current_stream()
+    started = set()
+    for fn, inputs, outs, lane in held:
+        if lane is None:                       # consumes everything released so far: lane 0 behind the other lanes
+            ws = _lane_stream(0)
+            if 0 not in started:
+                ws.wait_stream(main)
+                started.add(0)
+            for l in started:
+                if l != 0:
+                    ws.wait_stream(_lane_stream(l))
+        else:
+            ws = _lane_stream(lane)
+            if lane not in started:
+                ws.wait_stream(main)
+                if after is not None:
+                    ws.wait_event(after)
+                started.add(lane)
+        with torch.cuda.stream(ws):
+            fn()
+        _record_on(ws, inputs, outs)
 
 
 # ---- gradient destinations ------------------------------------------------------------------------------------------------------
@@ -174,17 +262,19 @@ def lowp_gradient(prm):
 
 def side_streams_in_use():
     """Streams that deferred gradient work of the current step may still be running on."""
-    return [s for s in (_SIDE['wgrad'], _SIDE['rollout']) if s is not None] if _SIDE['on'] else []
+    return (list(_SIDE['lanes']) + ([_SIDE['rollout']] if _SIDE['rollout'] is not None else [])) if _SIDE['on'] else []
 
 
 def join_side_streams():
     """Make the current stream wait for all deferred gradient work (call before the optimizer step)."""
     if not _SIDE['on']:
         return          # nothing was deferred; waiting on a stream outside the running capture would break the capture
-    if _SIDE['wgrad'] is not None:
-        torch.cuda.current_stream().wait_stream(_SIDE['wgrad'])
+    release_deferred()  # (a step without the integrator's backward never reached the release point)
+    cur = torch.cuda.current_stream()
+    for ws in _SIDE['lanes']:
+        cur.wait_stream(ws)
     if _SIDE['rollout'] is not None:
-        torch.cuda.current_stream().wait_stream(_SIDE['rollout'])
+        cur.wait_stream(_SIDE['rollout'])
 
 
 # ------------------------------------------------------------------------------------------------ weight shadows
@@ -319,6 +409,7 @@ class MLPChain(torch.autograd.Function):
                 dz = dz + handed
         grads = [None] * (2 * L)
         dx = None
+        lane = next_lane()                   # this chain's weight / bias gradients: one gradient stream, in order
         bias_jobs = []                       # (slot, dz): all bias gradients of the chain in one launch at the end
         for l in range(L - 1, -1, -1):
             W, b = params[2 * l], params[2 * l + 1]
@@ -327,9 +418,15 @@ class MLPChain(torch.autograd.Function):
             if W.requires_grad:               # dW = dz^T h_in (fp32); off the critical path -> wgrad stream when enabled
                 dst = grad_output(W)
                 if dst is not None:           # straight into the all-reduce bucket; autograd gets nothing for this parameter
-                    run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, dst=dst: ops.gemm(dz, S, h_in, S, N, K, M, out=dst), dz, h_in)
+                    run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, dst=dst: ops.gemm(dz, S, h_in, S, N, K, M, out=dst), dz, h_in,
+                                 lane=lane)
                 else:
-                    grads[2 * l] = run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K: ops.gemm(dz, S, h_in, S, N, K, M), dz, h_in)
+                    # autograd keeps the tensor it is handed only if nobody else references it (it CLONES it otherwise -- here
+                    # before the deferred GEMM has written it): the closure writes through a second tensor on the same storage
+                    buf = torch.empty((N * K,), dtype=torch.float32, device=dz.device)
+                    grads[2 * l] = buf.view(N, K)
+                    run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, dw=buf.view(N, K): ops.gemm(dz, S, h_in, S, N, K, M, out=dw),
+                                 dz, h_in, outs=buf, lane=lane)
             if b is not None and b.requires_grad:
                 bias_jobs.append((2 * l + 1, dz, grad_output(b)))
             if l > 0:
@@ -342,11 +439,14 @@ class MLPChain(torch.autograd.Function):
         bias_jobs = [j for j in bias_jobs if j[2] is None]
         if direct:                            # added to the (zeroed) bucket slices
             dzs, dsts = [j[1] for j in direct], [j[2] for j in direct]
-            run_deferred(lambda: ops.colsum_multi(dzs, outs=dsts), *dzs)
+            run_deferred(lambda: ops.colsum_multi(dzs, outs=dsts), *dzs, lane=lane)
         if bias_jobs:
             dzs = [j[1] for j in bias_jobs]
-            for (slot, _, _), db in zip(bias_jobs, run_deferred(lambda: ops.colsum_multi(dzs), *dzs)):
+            flat, views = ops.colsum_alloc(dzs)
+            for (slot, _, _), db in zip(bias_jobs, views):
                 grads[slot] = db
+            views = ops.colsum_alloc(dzs, flat)[1]       # the closure's own views (see the weight gradients above)
+            run_deferred(lambda views=views: ops.colsum_multi(dzs, outs=views, zero_flat=flat), *dzs, outs=flat, lane=lane)
         return (dx, None, None, None) + tuple(grads)
 
 
@@ -425,7 +525,16 @@ class MLPRollout(torch.autograd.Function):
         for b in range(nb):
             W1, W2, W3 = params[6 * b], params[6 * b + 2], params[6 * b + 4]
             wts += [packed_weight(W3, cdt, True), packed_weight(W2, cdt, True), packed_weight(W1, cdt, True)]
-        dx0, dr, dh2, dh1 = ops.mlp_rollout_bwd(g_codes.contiguous().float(), wts, h1, h2, m1, m2, n_steps)
+        g_codes = g_codes.contiguous().float()
+        ready = None
+        if deferred_held():
+            # held weight gradients (decoder, E_s) fill the chip under the latency-bound kernel launched next.  They become
+            # eligible together with it, not earlier: a 600-workgroup GEMM that starts first keeps the kernel's 192 workgroups
+            # (all of which must be resident before the chain moves) waiting for register space for most of its run time
+            ready = torch.cuda.Event()
+            ready.record()
+        dx0, dr, dh2, dh1 = ops.mlp_rollout_bwd(g_codes, wts, h1, h2, m1, m2, n_steps)
+        release_deferred(after=ready)
         B, C = dx0.shape
         H = h1.shape[-1]
         rows = (n_steps - 1) * B
@@ -446,7 +555,7 @@ class MLPRollout(torch.autograd.Function):
             return grads
         # with gradient destinations registered these gradients still go through autograd's `+=` into the bucket views, which
         # runs on THIS node's stream: compute them here, not on the wgrad stream
-        grads = weight_grads() if _GRAD_OUT else run_deferred(weight_grads, dr, dh2, dh1, xin, h1, h2)
+        grads = weight_grads() if _GRAD_OUT else run_deferred(weight_grads, dr, dh2, dh1, xin, h1, h2, lane=next_lane())
         return (dx0, None) + tuple(grads)
 
 

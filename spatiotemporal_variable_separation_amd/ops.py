@@ -157,10 +157,22 @@ def colsum(x, M, N, out=None, accumulate=False):
     return out
 
 
-def colsum_multi(jobs, outs=None):
+def colsum_alloc(jobs, flat=None):
+    """(flat, views): the result vectors colsum_multi(jobs) would allocate, for callers that launch it later (zero_flat=flat)."""
+    if flat is None:
+        flat = torch.empty((sum(x.shape[1] for x in jobs),), dtype=torch.float32, device=jobs[0].device)
+    views, off = [], 0
+    for x in jobs:
+        views.append(flat[off:off + x.shape[1]])
+        off += x.shape[1]
+    return flat, views
+
+
+def colsum_multi(jobs, outs=None, zero_flat=None):
     """jobs: list of (x [M, N] 2-D tensor).  Returns one fp32 vector of column sums per job (views of one flat buffer),
     computed by a single launch (+ one memset).  `outs`: caller-provided fp32 vectors that are ALREADY ZERO (the partial sums
-    are added to them, e.g. slices of a zeroed all-reduce bucket) -- then nothing is allocated or filled here."""
+    are added to them, e.g. slices of a zeroed all-reduce bucket) -- then nothing is allocated or filled here; with `zero_flat`
+    (colsum_alloc) they are consecutive views of that buffer and are zeroed by the launch."""
     import ctypes
     results = []
     for i in range(0, len(jobs), 12):
@@ -181,6 +193,8 @@ def colsum_multi(jobs, outs=None):
                 assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == x.shape[1]
             require_cuda(*views)
             zero_base, zero_count = None, 0
+            if zero_flat is not None:
+                zero_base, zero_count = views[0].data_ptr(), sum(v.numel() for v in views)
         VP, I32, I64 = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
         e0 = _pb()
         check(_lib.load_library().vs_colsum_multi(

@@ -8,6 +8,7 @@ WaveEq model keep every CU streaming.  The step count lives on the device, so `s
 (train.GraphedStep) without `capturable=True` plumbing.  Only what the reference uses is supported: no weight decay, no
 amsgrad, no maximize; fp32 CUDA parameters (anything else raises: there is no CPU fallback on the product path)."""
 import ctypes
+import os
 
 import torch
 
@@ -52,6 +53,12 @@ class Adam(torch.optim.Optimizer):
         group = self.param_groups[0]
         self._init_group(0, group)
         from . import functional as VF
+        bg = int(os.environ.get('VARSEP_ADAM_BG_BLOCKS', '512'))
+        if VF.defer_call(lambda: self._update(0, group, self._buckets[bi], max_blocks=bg)):
+            # the bucket's weight gradients are being held back (functional.hold_deferred): the update joins that queue and runs
+            # on the gradient stream right behind them; step() joins that stream like any deferred gradient work
+            self._launched.add(bi)
+            return
         main = torch.cuda.current_stream(p.device)
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=p.device)
@@ -132,7 +139,7 @@ class Adam(torch.optim.Optimizer):
             if live:
                 self._update(gi, group, live)
             main = torch.cuda.current_stream(group['params'][0].device)
-            if gi == 0 and self._launched:
+            if gi == 0 and self._launched and self._stream is not None:
                 main.wait_stream(self._stream)
             if getattr(self, '_scale_state', None) is not None:
                 _lib.check(lib.vs_adam_step_increment_scaled(group['step_dev'].data_ptr(), self._scale_state.data_ptr(), main.cuda_stream),
@@ -166,10 +173,17 @@ class Adam(torch.optim.Optimizer):
             main = torch.cuda.current_stream(group['params'][0].device)
             _lib.check(lib.vs_adam_step_increment(group['step_dev'].data_ptr(), main.cuda_stream), 'vs_adam_step_increment')
 
-    def _update(self, gi, group, live):
-        """One vs_adam_multi launch per 64 tensors of `live` on the current stream (the step counter is not touched)."""
+    def _update(self, gi, group, live, max_blocks=0):
+        """One vs_adam_multi launch per 64 tensors of `live` on the current stream (the step counter is not touched).
+        `max_blocks` > 0: a background update with that many workgroups (vs_adam_set_max_blocks)."""
         from . import functional as VF, ops
         lib = _lib.load_library()
+        if max_blocks:
+            prev = lib.vs_adam_set_max_blocks(int(max_blocks))
+            try:
+                return self._update(gi, group, live)
+            finally:
+                lib.vs_adam_set_max_blocks(prev)
         for p in live:
             if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or not p.grad.is_cuda:
                 raise VarsepHipError('HIP Adam needs contiguous fp32 CUDA gradients')

@@ -175,6 +175,9 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
         None if no_s else s_new.reshape(B, -1).float().contiguous(), t0.reshape(B, -1).float().contiguous(),
         (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss, handoff)
     terms = {'ae': ae_loss_value, 'zero': spatial_ode_loss, 'pred': forecast_loss, 't_reg': t_reg}
+    if VF.side_streams_enabled() and os.environ.get('VARSEP_HOLD_WGRADS', '1') == '1':
+        # backward: collect the decoder's and E_s's weight gradients and launch them under the integrator's backward kernel
+        VF.hold_deferred(True)
     return total_loss, terms, forecasts, t_codes
 
 
@@ -364,8 +367,9 @@ def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False):
         return
     if isinstance(optimizer, HipAdam) and grad_sync is None and not optimizer._buckets and len(optimizer.param_groups) == 1:
         owned = {id(p) for p in optimizer.param_groups[0]['params']}
-        early = [p for m in (sep_net.decoder, sep_net.t_resnet, sep_net.Es) for p in m.parameters() if id(p) in owned]
-        buckets = [early, [p for p in sep_net.Et.parameters() if id(p) in owned]]
+        early = [p for m in (sep_net.decoder, sep_net.Es) for p in m.parameters() if id(p) in owned]
+        buckets = [early, [p for p in sep_net.t_resnet.parameters() if id(p) in owned],
+                   [p for p in sep_net.Et.parameters() if id(p) in owned]]
         if sum(len(b) for b in buckets) == len(owned):
             optimizer.overlap_with_backward(buckets)
 
