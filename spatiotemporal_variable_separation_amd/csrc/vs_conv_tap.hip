@@ -56,7 +56,7 @@ struct TapPixels {
 template <int CT>
 __device__ __forceinline__ void tap_k_loop(f32x16 (&acc)[4][2], const unsigned short* At_tile, const unsigned short* X, int Cin, int HW, int64_t npix,
                                            int64_t n0, char* smem) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = wave >> 2, wc = wave & 3;
     const int64_t K = Cin, kt_end = (K + BIG_BK - 1) / BIG_BK;
 #pragma unroll
@@ -72,8 +72,9 @@ __device__ __forceinline__ void tap_k_loop(f32x16 (&acc)[4][2], const unsigned s
     auto stage_tile = [&](int slot, int64_t kt) {
         char* base = smem + slot * BIG_TILE_BYTES;
         const bool live = kt < kt_end;
-        ga.stage(0, base, kt * BIG_BK, K, live);
-        ga.stage(1, base + 8192, kt * BIG_BK, K, live);
+        ga.stage_checked(0, base + wave * 1024, kt * BIG_BK, K, live);
+        ga.stage_checked(1, base + 8192 + wave * 1024, kt * BIG_BK, K, live);
+        ga.advance();
         gb.stage(0, base + 16384, kt * BIG_BK, K, live);
         gb.stage(1, base + 24576, kt * BIG_BK, K, live);
     };

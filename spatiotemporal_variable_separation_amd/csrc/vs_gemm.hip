@@ -22,6 +22,7 @@
 #include "vs_gemm_core.h"
 #include "vs_gemm_glds.h"
 #include "vs_gemm_big.h"
+#include "vs_gemm_mid.h"
 
 namespace {
 
@@ -69,14 +70,13 @@ int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M
         auto kfn = gemm_big_kernel<CT, LA, LB, false>;
         static bool attr_set = false;                  // 128 KiB of dynamic LDS: above the 64 KiB default limit
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_STAGES * BIG_TILE_BYTES) != hipSuccess)
-                return vs_fail(VS_ERR_LAUNCH, "vs_gemm: cannot raise the dynamic LDS limit to 128 KiB");
+            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_STAGES * BIG_TILE_BYTES) != hipSuccess)
+                return vs_fail(VS_ERR_LAUNCH, "vs_gemm: cannot raise the dynamic LDS limit to 160 KiB");
             attr_set = true;
         }
-        static const int diag = getenv("VS_BIG_DIAG") ? atoi(getenv("VS_BIG_DIAG")) : 0;     // timing diagnostics only: wrong results
         dim3 grid((unsigned)(bp.tiles_m * bp.tiles_n), 1, (unsigned)(bp.splits * batch));
-        hipLaunchKernelGGL(kfn, grid, dim3(512), BIG_STAGES * BIG_TILE_BYTES, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K,
-                           (int)bp.k_tiles_per_split, bp.tiles_n, epi, slabs, diag);
+        hipLaunchKernelGGL(kfn, grid, dim3(512), GEMM_BIG_STAGES * BIG_TILE_BYTES, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K,
+                           (int)bp.k_tiles_per_split, bp.tiles_n, epi, slabs);
         VS_CHECK_LAUNCH("vs_gemm (256x256 tile)");
         return VS_OK;
     }
@@ -91,11 +91,55 @@ int launch_big_layout(int la, int lb, const void* A, int64_t lda, const void* B,
     return launch_big<CT, LS, LS>(A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
 }
 
+template <int CT, int LA, int LB>
+int launch_mid(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const MidPlan& mp, int batch, const Epi& epi,
+               float* slabs, hipStream_t stream) {
+    if constexpr (CT == VS_F32) {
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm: the 128x128 LDS-DMA ring tile is a 16-bit kernel");
+    } else {
+        dim3 grid((unsigned)(mp.tiles_m * mp.tiles_n), 1, (unsigned)(mp.splits * batch));
+        auto go = [&](auto kfn, int stages, bool& attr_set) -> int {
+            const int lds = stages * MID_TILE_BYTES;
+            if (!attr_set) {                           // above the 64 KiB default limit of dynamic LDS
+                if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                    return vs_fail(VS_ERR_LAUNCH, "vs_gemm: cannot raise the dynamic LDS limit to %d bytes", lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K,
+                               (int)mp.k_tiles_per_split, mp.tiles_n, epi, slabs);
+            return VS_OK;
+        };
+        static bool set5 = false, set10 = false;
+        const int rc = mp.stages == 10 ? go(gemm_mid_kernel<CT, LA, LB, false, 10>, 10, set10) : go(gemm_mid_kernel<CT, LA, LB, false, 5>, 5, set5);
+        if (rc != VS_OK) return rc;
+        VS_CHECK_LAUNCH("vs_gemm (128x128 ring tile)");
+        return VS_OK;
+    }
+}
+
+template <int CT>
+int launch_mid_layout(int la, int lb, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const MidPlan& mp,
+                      int batch, const Epi& epi, float* slabs, hipStream_t stream) {
+    if (la == LR && lb == LR) return launch_mid<CT, LR, LR>(A, lda, B, ldb, M, N, K, mp, batch, epi, slabs, stream);
+    if (la == LR && lb == LS) return launch_mid<CT, LR, LS>(A, lda, B, ldb, M, N, K, mp, batch, epi, slabs, stream);
+    if (la == LS && lb == LR) return launch_mid<CT, LS, LR>(A, lda, B, ldb, M, N, K, mp, batch, epi, slabs, stream);
+    return launch_mid<CT, LS, LS>(A, lda, B, ldb, M, N, K, mp, batch, epi, slabs, stream);
+}
+
+inline MidPlan mid_plan_for(int compute, int64_t M, int64_t N, int64_t K, int64_t batch, const void* A, int64_t lda, int la, const void* B,
+                            int64_t ldb, int lb, int64_t stride_a, int64_t stride_b) {
+    MidPlan mp = make_mid_plan(compute, M, N, K, batch);
+    if (mp.use && !(glds_operand_ok(A, lda, la, M, K, stride_a) && glds_operand_ok(B, ldb, lb, N, K, stride_b))) mp.use = false;
+    if (mp.use && (lda >= (1ll << 23) || ldb >= (1ll << 23))) mp.use = false;       // 32-bit lane offsets inside a tile
+    return mp;
+}
+
 // the 256x256 tile is taken when its plan says so and both operands fit the LDS-DMA loader (alignment, multiples of 8)
 inline BigPlan big_plan_for(int compute, int64_t M, int64_t N, int64_t K, int64_t batch, const void* A, int64_t lda, int la, const void* B,
                             int64_t ldb, int lb, int64_t stride_a, int64_t stride_b) {
     BigPlan bp = make_big_plan(compute, M, N, K, batch);
     if (bp.use && !(glds_operand_ok(A, lda, la, M, K, stride_a) && glds_operand_ok(B, ldb, lb, N, K, stride_b))) bp.use = false;
+    if (bp.use && (lda >= (1ll << 22) || ldb >= (1ll << 22))) bp.use = false;       // 32-bit lane offsets inside a tile
     return bp;
 }
 
@@ -150,6 +194,11 @@ extern "C" size_t vs_gemm_batched_workspace_bytes(int batch, int64_t M, int64_t 
             size_t b = (size_t)batch * bp.splits * (size_t)M * (size_t)N * sizeof(float);
             if (b > worst) worst = b;
         }
+        const MidPlan mp = make_mid_plan(c, M, N, K, batch);
+        if (mp.use && mp.splits > 1) {
+            size_t b = (size_t)batch * mp.splits * (size_t)M * (size_t)N * sizeof(float);
+            if (b > worst) worst = b;
+        }
     }
     return worst;
 }
@@ -170,7 +219,10 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
     Plan plan = make_plan(compute, M, N, K, batch);
     plan.batch = batch;
     const BigPlan bp = big_plan_for(compute, M, N, K, batch, A, lda, layout_a, B, ldb, layout_b, stride_a, stride_b);
+    MidPlan mp{false, 1, 0, 0, 0, 5};
+    if (!bp.use) mp = mid_plan_for(compute, M, N, K, batch, A, lda, layout_a, B, ldb, layout_b, stride_a, stride_b);
     if (bp.use) { plan.splits = bp.splits; plan.k_tiles_per_split = bp.k_tiles_per_split; }
+    if (mp.use) { plan.splits = mp.splits; plan.k_tiles_per_split = mp.k_tiles_per_split; }
     Epi epi{C, ldc, c_dtype, alpha, nullptr, VS_ACT_NONE, nullptr, 0, 0, 0, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0, plan.splits, stride_a, stride_b, stride_c};
     float* slabs = nullptr;
     if (plan.splits > 1) {
@@ -183,6 +235,9 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
     if (bp.use)
         rc = compute == VS_BF16 ? launch_big_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream)
                                 : launch_big_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
+    else if (mp.use)
+        rc = compute == VS_BF16 ? launch_mid_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, mp, batch, epi, slabs, stream)
+                                : launch_mid_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, mp, batch, epi, slabs, stream);
     else
         rc = compute == VS_BF16  ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
              : compute == VS_F16 ? launch_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
@@ -211,6 +266,11 @@ extern "C" size_t vs_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
             size_t b = (size_t)bp.splits * (size_t)M * (size_t)N * sizeof(float);
             if (b > worst) worst = b;
         }
+        const MidPlan mp = make_mid_plan(c, M, N, K, 1);
+        if (mp.use && mp.splits > 1) {
+            size_t b = (size_t)mp.splits * (size_t)M * (size_t)N * sizeof(float);
+            if (b > worst) worst = b;
+        }
     }
     return worst;
 }
@@ -231,7 +291,10 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
     Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     Plan plan = make_plan(compute, M, N, K);
     const BigPlan bp = big_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);
+    MidPlan mp{false, 1, 0, 0, 0, 5};
+    if (!bp.use) mp = mid_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);
     if (bp.use) { plan.splits = bp.splits; plan.k_tiles_per_split = bp.k_tiles_per_split; }
+    if (mp.use) { plan.splits = mp.splits; plan.k_tiles_per_split = mp.k_tiles_per_split; }
     float* slabs = nullptr;
     if (plan.splits > 1) {
         const size_t need = (size_t)plan.splits * (size_t)M * (size_t)N * sizeof(float);
@@ -243,6 +306,9 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
     if (bp.use)
         rc = compute == VS_BF16 ? launch_big_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, 1, epi, slabs, stream)
                                 : launch_big_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, 1, epi, slabs, stream);
+    else if (mp.use)
+        rc = compute == VS_BF16 ? launch_mid_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, mp, 1, epi, slabs, stream)
+                                : launch_mid_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, mp, 1, epi, slabs, stream);
     else
         rc = compute == VS_BF16  ? launch_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
              : compute == VS_F16 ? launch_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)

@@ -35,43 +35,71 @@
 namespace {
 
 constexpr int BIG_BK = 32;
-constexpr int BIG_STAGES = 4;
+constexpr int BIG_STAGES = 4;                     // the tap convolutions' ring (vs_conv_tap.hip)
+// the GEMM's ring: five slots = all 160 KiB of the CU.  What a CU pulls through LDS-DMA is (bytes in flight) / (latency), and the
+// operands of a large GEMM stream from HBM / the Infinity Cache at 1.3-2 us per request under load: four tiles (128 KiB) in flight
+// instead of three.
+#define VS_GB_ST 5
+#define VS_GB_WAIT_FIRST 16                       // 4 * (ST - 1): tile 0 has landed
+#define VS_GB_WAIT_LOOP 12                        // 4 * (ST - 2): tile kt + 1 has landed
+#define VS_STR_(x) #x
+#define VS_STR(x) VS_STR_(x)
+static_assert(VS_GB_WAIT_FIRST == 4 * (VS_GB_ST - 1) && VS_GB_WAIT_LOOP == 4 * (VS_GB_ST - 2), "vmcnt immediates follow the ring depth");
+constexpr int GEMM_BIG_STAGES = VS_GB_ST;
 constexpr int BIG_TILE_BYTES = 4 * 8192;          // A0 | A1 | B0 | B1
 
-// Per-thread source pointer of one operand's two half-tiles (one 16-byte DMA piece per half and K tile).
+// Per-thread source pointer of one operand's two half-tiles (one 16-byte DMA piece per half and K tile).  Rows past the end of
+// the operand are CLAMPED to its last row / last 8-row piece (valid memory): what they contribute lands in output rows or
+// columns that are never stored, and the request needs no per-lane select.  Only k past K must read zeros (it meets valid rows
+// of the other operand): the one partial K tile of a problem goes through stage_checked().
 template <int LAYOUT>
 struct BigOperand {
-    const unsigned short* src[2];        // [half]: piece of the next K tile to request
+    const char* base;                    // UNIFORM: first element of the next K tile (advances by `step` bytes per tile)
+    uint32_t voff[2];                    // [half]: this lane's byte offset from `base` (fixed for the whole launch)
     int kofs;                            // k of the piece inside the tile
-    bool ok[2];
     int64_t step;
 
     __device__ __forceinline__ void prepare(const unsigned short* p, int64_t ld, int64_t rows, int64_t i0, int64_t k_begin) {
         const int u = (int)threadIdx.x;                         // linear 16-byte slot of the 8 KiB half-tile image
+        // offsets are taken from the tile's first row / column so that they fit 32 bits (256 rows x ld x 2 B < 4 GiB: ld < 2^23)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int64_t base = i0 + 128 * h;
+            const int64_t first = i0 + 128 * h;
             if (LAYOUT == LR) {
                 const int row = u >> 2, piece = (u & 3) ^ ((row >> 2) & 3);
-                ok[h] = base + row < rows;
+                int64_t r = first + row;
+                if (r > rows - 1) r = rows - 1;
                 kofs = piece * 8;
-                src[h] = p + (base + row) * ld + k_begin + piece * 8;
-                step = BIG_BK;
+                voff[h] = (uint32_t)(((r - i0) * ld + piece * 8) * 2);
             } else {
                 const int k = u >> 4, piece = (u & 15) ^ ((k & 3) << 2);
-                ok[h] = base + piece * 8 < rows;                // rows % 8 == 0: a piece is inside or outside as a whole
+                int64_t c = first + piece * 8;                  // rows % 8 == 0: a piece is inside or outside as a whole
+                if (c > rows - 8) c = rows - 8;
                 kofs = k;
-                src[h] = p + (k_begin + k) * ld + base + piece * 8;
-                step = BIG_BK * ld;
+                voff[h] = (uint32_t)((k * ld + (c - i0)) * 2);
             }
         }
+        if (LAYOUT == LR) {
+            base = reinterpret_cast<const char*>(p + i0 * ld + k_begin);
+            step = BIG_BK * 2;
+        } else {
+            base = reinterpret_cast<const char*>(p + k_begin * ld + i0);
+            step = BIG_BK * ld * 2;
+        }
     }
-    // request half `h` of the K tile starting at k0 into `lds` (8 KiB, wave-linear) and advance; `live` false -> zeros
-    __device__ __forceinline__ void stage(int h, char* lds, int64_t k0, int64_t K, bool live) {
-        const int wave = threadIdx.x >> 6;
-        const void* g = (live && ok[h] && k0 + kofs < K) ? (const void*)src[h] : (const void*)vs_glds_zero;
-        __builtin_amdgcn_global_load_lds((glds_glb_ptr*)g, (glds_lds_ptr*)(lds + wave * 1024), 16, 0, 0);
-        src[h] += step;
+    __device__ __forceinline__ void advance() { base += step; }
+    // request half `h` of a FULL K tile into `lds` (this wave's 1 KiB of the 8 KiB image): scalar base + 32-bit lane offset.
+    // Written out (the builtin takes a flat pointer and costs two 64-bit VALU adds per request): M0 = LDS address of the wave's
+    // piece, `global_load_lds_dwordx4 voffset, sbase`.  The request counts on vmcnt like any load; the loop waits by hand.
+    __device__ __forceinline__ void stage(int h, char* lds) const {
+        const uint32_t dst = (uint32_t)(uintptr_t)lds;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff[h]), "s"(base) : "memory", "m0");
+    }
+    // the same for a tile that may be partial (k0 + 32 > K) or past the end of the split (`live` false): zeros there
+    __device__ __forceinline__ void stage_checked(int h, char* lds, int64_t k0, int64_t K, bool live) const {
+        const void* g = (live && k0 + kofs < K) ? (const void*)(base + voff[h]) : (const void*)vs_glds_zero;
+        const uint32_t dst = (uint32_t)(uintptr_t)lds;           // (asm as well: M0 has ONE writer in this kernel)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(g) : "memory", "m0");
     }
 };
 
@@ -132,9 +160,17 @@ __device__ __forceinline__ void big_store4(const Epi& e, int64_t m, int64_t n, i
     }
 }
 
+// Instruction order inside one K tile ("block") of the main loop is pinned in the source (sched_barrier(0) fences between the
+// groups): an MFMA holds the SIMD's issue port for 8 of its 32 cycles, so the 12 fragment reads, the 4 DMA requests and their
+// address arithmetic of a block are dealt out one or two per MFMA instead of ahead of them.  (All waves in step and everything
+// issued ahead: DMA issue ~500 cycles with the matrix pipes idle, then the two waves of a SIMD queueing for the pipe -- 1550
+// cycles per tile against the 1024 the 32 MFMAs of a SIMD need.  The scheduler left to itself, or steered with
+// sched_group_barrier, clumps the reads behind the MFMAs.)
+#define VS_FENCE __builtin_amdgcn_sched_barrier(0)
+
 template <int CT, int LA, int LB, bool NCHW>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
-                                                       int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs, int diag) {
+                                                       int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs) {
     int zsplit = blockIdx.z;
     int batch = 0;
     if (epi_in.splits_per_batch > 0) {
@@ -144,9 +180,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap,
         Bp += batch * epi_in.batch_b;
     }
     const Epi epi = epi_for_batch(epi_in, batch);
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // the ONLY LDS object: 4 x [A0 | A1 | B0 | B1] x 8 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // the ONLY LDS object: STAGES x [A0 | A1 | B0 | B1] x 8 KiB
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // scalar: DMA destinations need no v_readfirstlane
     const int wr = wave >> 2, wc = wave & 3;
     const unsigned tile = big_tile_of(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(tile / (unsigned)tiles_n) * 256, n0 = (int64_t)(tile % (unsigned)tiles_n) * 256;
@@ -154,6 +191,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap,
     const int64_t kt_begin = (int64_t)zsplit * k_tiles_per_split;
     int64_t kt_end = kt_begin + k_tiles_per_split;
     if (kt_end > kt_total) kt_end = kt_total;
+    int64_t kt_full = K / BIG_BK;                                    // tiles [kt_begin, kt_full) are full and live
+    if (kt_full > kt_end) kt_full = kt_end;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -168,73 +207,94 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap,
     ga.prepare(Ap, lda, M, m0, kt_begin * BIG_BK);
     gb.prepare(Bp, ldb, N, n0, kt_begin * BIG_BK);
 
-    // request K tile `kt` into ring slot `slot` (4 DMA instructions per thread, always: the vmcnt arithmetic below relies on it)
-    auto stage_tile = [&](int slot, int64_t kt) {
-        char* base = smem + slot * BIG_TILE_BYTES;
-        const bool live = kt < kt_end;
-        ga.stage(0, base, kt * BIG_BK, K, live);
-        ga.stage(1, base + 8192, kt * BIG_BK, K, live);
-        gb.stage(0, base + 16384, kt * BIG_BK, K, live);
-        gb.stage(1, base + 24576, kt * BIG_BK, K, live);
+    // request piece `q` (A0 | A1 | B0 | B1) of K tile kt + 4 into ring slot `slot`: 4 DMA instructions per thread and tile, always
+    // (the vmcnt arithmetic relies on it)
+    char* const my_piece = smem + wave * 1024;
+    auto stage_full = [&](int slot, int q) {
+        char* base = my_piece + slot * BIG_TILE_BYTES + q * 8192;
+        if (q < 2) ga.stage(q, base); else gb.stage(q - 2, base);
+        if (q == 1) ga.advance();
+        if (q == 3) gb.advance();
+    };
+    int64_t kt = kt_begin;                                             // the tile being multiplied
+    auto stage_any = [&](int slot, int q) {
+        char* base = my_piece + slot * BIG_TILE_BYTES + q * 8192;
+        const int64_t k4 = kt + GEMM_BIG_STAGES;
+        const bool live = k4 < kt_end;
+        if (q < 2) ga.stage_checked(q, base, k4 * BIG_BK, K, live); else gb.stage_checked(q - 2, base, k4 * BIG_BK, K, live);
+        if (q == 1) ga.advance();
+        if (q == 3) gb.advance();
     };
 
     // Software pipeline across K tiles: the fragments of tile t+1 are read (and tile t+4 requested) WHILE the MFMAs of tile t
-    // run, so after each barrier the matrix pipes restart at once instead of waiting for 4 DMA issues + 12 LDS reads of both
-    // waves of the SIMD (measured with all waves doing load -> multiply in step: DMA 0.76 us, compute 0.8 us, both 1.06 us per
-    // tile; a ping-pong of the two halves of the workgroup with two barriers per tile: 1.2 us).  Three fragment sets rotate:
-    // X = k-step 0, Y = k-step 1 of tile t; k-step 0 of tile t+1 goes to Z, k-step 1 to X once the MFMAs of X are issued.
-    // Ring: tile t+1 is being read, t+2 and t+3 are in flight, t+4 takes the slot of tile t, whose fragments are in registers.
+    // run.  Three fragment sets rotate: X = k-step 0, Y = k-step 1 of tile t; k-step 0 of tile t+1 goes to Z, k-step 1 to X once
+    // the MFMAs of X are issued.  Ring: tile t+1 is being read, t+2 and t+3 are in flight, t+4 takes the slot of tile t, whose
+    // fragments are in registers.
     struct Frags { u32x4 a[4], b[2]; };
     Frags f0, f1, f2;
     const int bcol = (wc & 1) * 64;
-    auto load_frags = [&](Frags& f, int slot_, int kk) {
-        const unsigned short* pa = reinterpret_cast<const unsigned short*>(smem + slot_ * BIG_TILE_BYTES + wr * 8192);
-        const unsigned short* pb = reinterpret_cast<const unsigned short*>(smem + slot_ * BIG_TILE_BYTES + 16384 + (wc >> 1) * 8192);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f.a[i] = big_frag<LA>(pa, 32 * i, kk, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) f.b[j] = big_frag<LB>(pb, bcol + 32 * j, kk, lane);
+    const int a_off = wr * 8192, b_off = 16384 + (wc >> 1) * 8192;
+    auto rd_a = [&](Frags& f, int slot_, int kk, int i) {
+        f.a[i] = big_frag<LA>(reinterpret_cast<const unsigned short*>(smem + slot_ * BIG_TILE_BYTES + a_off), 32 * i, kk, lane);
     };
-    auto mfma8 = [&](const Frags& f) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16_32<CT>(f.a[i], f.b[j], acc[i][j]);
+    auto rd_b = [&](Frags& f, int slot_, int kk, int j) {
+        f.b[j] = big_frag<LB>(reinterpret_cast<const unsigned short*>(smem + slot_ * BIG_TILE_BYTES + b_off), bcol + 32 * j, kk, lane);
     };
-    stage_tile(0, kt_begin);
-    stage_tile(1, kt_begin + 1);
-    stage_tile(2, kt_begin + 2);
-    stage_tile(3, kt_begin + 3);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                 // tile 0 (this wave's pieces) ...
+    auto mf = [&](const Frags& f, int i, int j) { acc[i][j] = mfma16_32<CT>(f.a[i], f.b[j], acc[i][j]); };
+    // prologue: tiles 0 .. 3 requested (zeros past the end), tile 0 read
+    kt = kt_begin - GEMM_BIG_STAGES;                                   // stage_any requests tile kt + STAGES
+    for (int s4 = 0; s4 < GEMM_BIG_STAGES; ++s4) {
+        for (int q = 0; q < 4; ++q) stage_any(s4, q);
+        ++kt;
+    }
+    asm volatile("s_waitcnt vmcnt(" VS_STR(VS_GB_WAIT_FIRST) ")" ::: "memory");   // tile 0 (this wave's pieces) ...
     __builtin_amdgcn_s_barrier();                                      // ... and everybody else's
-    load_frags(f0, 0, 0);
-    load_frags(f1, 0, 16);
+    for (int i = 0; i < 4; ++i) { rd_a(f0, 0, 0, i); rd_a(f1, 0, 16, i); }
+    for (int j = 0; j < 2; ++j) { rd_b(f0, 0, 0, j); rd_b(f1, 0, 16, j); }
     int slot = 0;                                                      // ring slot of tile kt
-    int64_t kt = kt_begin;
-    // X, Y: fragments of tile kt (k-steps 0 / 1), Z: free set
-#define VS_BIG_BODY(X, Y, Z)                                                                          \
+    // X, Y: fragments of tile kt (k-steps 0 / 1), Z: free set.  STAGE(q) requests piece q of tile kt + 4 into the slot of tile kt.
+#define VS_BIG_BODY(X, Y, Z, STAGE)                                                                   \
     {                                                                                                 \
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); /* tile kt+1 landed; my reads of tile kt are done */ \
+        /* two MFMAs are queued ahead of the barrier: a wave that arrives early leaves the pipe busy */ \
+        mf(X, 0, 0); mf(X, 0, 1); VS_FENCE;                                                           \
+        asm volatile("s_waitcnt vmcnt(" VS_STR(VS_GB_WAIT_LOOP) ") lgkmcnt(0)" ::: "memory"); /* tile kt+1 landed; my reads of tile kt done */ \
         __builtin_amdgcn_s_barrier();                                                                 \
-        if (!(diag & 1)) stage_tile(slot, kt + 4); else stage_tile(slot, kt_end);                     \
-        const int nslot = (slot + 1) & 3;                                                             \
-        load_frags(Z, nslot, 0);                                                                      \
-        __builtin_amdgcn_s_setprio(1);                                                                \
-        if (!(diag & 2)) mfma8(X);                                                                    \
-        __builtin_amdgcn_s_setprio(0);                                                                \
-        load_frags(X, nslot, 16);                                                                     \
-        __builtin_amdgcn_s_setprio(1);                                                                \
-        if (!(diag & 2)) mfma8(Y);                                                                    \
-        __builtin_amdgcn_s_setprio(0);                                                                \
+        VS_FENCE;                                                                                     \
+        const int nslot = slot + 1 == GEMM_BIG_STAGES ? 0 : slot + 1;                                 \
+        STAGE(slot, 0); rd_a(Z, nslot, 0, 0); VS_FENCE;                                               \
+        mf(X, 1, 0); VS_FENCE; rd_a(Z, nslot, 0, 1); VS_FENCE;                                        \
+        mf(X, 1, 1); VS_FENCE; rd_a(Z, nslot, 0, 2); VS_FENCE;                                        \
+        mf(X, 2, 0); VS_FENCE; STAGE(slot, 1); rd_a(Z, nslot, 0, 3); VS_FENCE;                        \
+        mf(X, 2, 1); VS_FENCE; rd_b(Z, nslot, 0, 0); VS_FENCE;                                        \
+        mf(X, 3, 0); VS_FENCE; rd_b(Z, nslot, 0, 1); VS_FENCE;                                        \
+        mf(X, 3, 1); VS_FENCE;                                                                        \
+        mf(Y, 0, 0); VS_FENCE; STAGE(slot, 2); rd_a(X, nslot, 16, 0); VS_FENCE;                       \
+        mf(Y, 0, 1); VS_FENCE; rd_a(X, nslot, 16, 1); VS_FENCE;                                       \
+        mf(Y, 1, 0); VS_FENCE; rd_a(X, nslot, 16, 2); VS_FENCE;                                       \
+        mf(Y, 1, 1); VS_FENCE; STAGE(slot, 3); rd_a(X, nslot, 16, 3); VS_FENCE;                       \
+        mf(Y, 2, 0); VS_FENCE; rd_b(X, nslot, 16, 0); VS_FENCE;                                       \
+        mf(Y, 2, 1); VS_FENCE; rd_b(X, nslot, 16, 1); VS_FENCE;                                       \
+        mf(Y, 3, 0);                                                                                  \
+        mf(Y, 3, 1); VS_FENCE;                                                                        \
         slot = nslot;                                                                                 \
         ++kt;                                                                                         \
     }
+    // main loop: a multiple of three blocks whose tile kt + 4 is full and live (no per-lane selects, no branch in the body)
+    {
+        int64_t n3 = (kt_full - GEMM_BIG_STAGES - kt_begin) / 3;
+        for (; n3 > 0; --n3) {
+            VS_BIG_BODY(f0, f1, f2, stage_full)
+            VS_BIG_BODY(f2, f0, f1, stage_full)
+            VS_BIG_BODY(f1, f2, f0, stage_full)
+        }
+    }
+    // the remaining (>= 4) blocks: the partial K tile, if any, and the zero-source requests that keep the count uniform
     while (kt < kt_end) {
-        VS_BIG_BODY(f0, f1, f2)
+        VS_BIG_BODY(f0, f1, f2, stage_any)
         if (kt >= kt_end) break;
-        VS_BIG_BODY(f2, f0, f1)
+        VS_BIG_BODY(f2, f0, f1, stage_any)
         if (kt >= kt_end) break;
-        VS_BIG_BODY(f1, f2, f0)
+        VS_BIG_BODY(f1, f2, f0, stage_any)
     }
 #undef VS_BIG_BODY
     // drain the (zero-source) requests still in flight before the ring is reused as the epilogue's staging area

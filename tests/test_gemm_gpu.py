@@ -270,3 +270,38 @@ def test_gemm_big_tile_all_layouts(dtype, la, lb, shape):
     assert err < 2e-6, f'{dtype} layouts ({la},{lb}) shape {shape}: rel err {err:.3e}'
     err16 = ((out16.cpu().double() - ref).norm() / ref.norm()).item()
     assert err16 < (6e-3 if dtype == torch.bfloat16 else 8e-4), f'{dtype} 16-bit output ({la},{lb}) {shape}: {err16:.3e}'
+
+
+MID_SHAPES = [(3328, 1200, 1200), (256, 1200, 20480), (1200, 1200, 3328), (136, 264, 40), (520, 1000, 776), (128, 128, 32)]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('la,lb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('shape', MID_SHAPES)
+@pytest.mark.parametrize('mode', ['2', '1'])
+def test_gemm_mid_tile_all_layouts(dtype, la, lb, shape, mode):
+    """The 128x128 ring tile (vs_gemm_mid.h): every operand layout, row / column / K tails, one K tile only, split-K as planned
+    (mode 1: the plan decides and may fall through to the other kernels) and forced (mode 2), fp32 and 16-bit outputs, against
+    fp64 on the same rounded operands."""
+    import os
+    from spatiotemporal_variable_separation_amd import ops
+    M, N, K = shape
+    a64, a = _operand(M, K, la, dtype, 13)
+    b64, b = _operand(N, K, lb, dtype, 15)
+    from oracle.detdata import det_uniform
+    bias = ((det_uniform((N,), 19) - 0.5) * 0.5).cuda()
+    os.environ['VS_GEMM_MID'] = mode
+    os.environ['VS_GEMM_BIG'] = '0'
+    try:
+        out = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='relu')
+        out16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=dtype)
+    finally:
+        del os.environ['VS_GEMM_MID']
+        del os.environ['VS_GEMM_BIG']
+    torch.cuda.synchronize()
+    ref = a64 @ b64.t()
+    refa = torch.relu(ref + bias.cpu().double())
+    err = ((out.cpu().double() - refa).norm() / refa.norm()).item()
+    assert err < 2e-6, f'{dtype} layouts ({la},{lb}) shape {shape}: rel err {err:.3e}'
+    err16 = ((out16.cpu().double() - ref).norm() / ref.norm()).item()
+    assert err16 < (6e-3 if dtype == torch.bfloat16 else 8e-4), f'{dtype} 16-bit output ({la},{lb}) {shape}: {err16:.3e}'

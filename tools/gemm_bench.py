@@ -1,4 +1,8 @@
-"""Micro-benchmark of vs_gemm on the WaveEq (config 2) shapes.  Usage: python tools/gemm_bench.py [bf16|f32]"""
+"""Micro-benchmark of vs_gemm on the WaveEq (config 2) shapes.  Usage: python tools/gemm_bench.py [bf16|f32] [cold]
+
+`cold`: every launch works on its own copy of the operands and output, ~600 MB in rotation (more than the 256 MB Infinity Cache),
+as inside a training step where operands were last touched a millisecond and a gigabyte of traffic ago.  Re-running one launch on
+the same buffers (the default) keeps them in the Infinity Cache and flatters kernels whose loop is bound by request latency."""
 import os
 import sys
 import time
@@ -9,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatiotemporal_variable_separation_amd import ops  # noqa: E402
 
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
+COLD = 'cold' in sys.argv[2:]
 SHAPES = [  # (name, M, N, K, la, lb) -- every GEMM of one WaveEq training step (B=128: encoder rows 256, decoder rows 3328)
     ('dec fwd 1200->4096', 3328, 4096, 1200, 0, 0),
     ('dec fwd 1200->1200 x2', 3328, 1200, 1200, 0, 0),
@@ -31,32 +36,35 @@ SHAPES = [  # (name, M, N, K, la, lb) -- every GEMM of one WaveEq training step 
     ('square 4096 SS', 4096, 4096, 4096, 1, 1),
 ]
 for name, M, N, K, la, lb in SHAPES:
-    a = (torch.rand((M, K) if la == 0 else (K, M), device='cuda') - 0.5).to(dt)
-    b = (torch.rand((N, K) if lb == 0 else (K, N), device='cuda') - 0.5).to(dt)
-    out = torch.empty((M, N), device='cuda', dtype=torch.float32)
-    for _ in range(3):
-        ops.gemm(a, la, b, lb, M, N, K, out=out)
+    per_set = (M * K + N * K) * (2 if dt == torch.bfloat16 else 4) + M * N * 4
+    nset = max(1, min(64, int(600e6 // per_set))) if COLD else 1
+    As = [(torch.rand((M, K) if la == 0 else (K, M), device='cuda') - 0.5).to(dt) for _ in range(nset)]
+    Bs = [(torch.rand((N, K) if lb == 0 else (K, N), device='cuda') - 0.5).to(dt) for _ in range(nset)]
+    outs = [torch.empty((M, N), device='cuda', dtype=torch.float32) for _ in range(nset)]
+    for i in range(max(3, nset)):
+        ops.gemm(As[i % nset], la, Bs[i % nset], lb, M, N, K, out=outs[i % nset])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    iters = 20
+    iters = max(20, nset)
     e0.record()
-    for _ in range(iters):
-        ops.gemm(a, la, b, lb, M, N, K, out=out)
+    for i in range(iters):
+        ops.gemm(As[i % nset], la, Bs[i % nset], lb, M, N, K, out=outs[i % nset])
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     # torch (hipBLASLt) for orientation only
-    ta = a if la == 0 else a.t()
-    tb = b if lb == 0 else b.t()
-    for _ in range(3):
-        torch.matmul(ta, tb.t())
+    tas = [a if la == 0 else a.t() for a in As]
+    tbs = [b if lb == 0 else b.t() for b in Bs]
+    for i in range(max(3, nset)):
+        torch.matmul(tas[i % nset], tbs[i % nset].t())
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        torch.matmul(ta, tb.t())
+    for i in range(iters):
+        torch.matmul(tas[i % nset], tbs[i % nset].t())
     e1.record()
     torch.cuda.synchronize()
     ms_t = e0.elapsed_time(e1) / iters
     fl = 2.0 * M * N * K
     print(f'{name:24s} {str(dt)[6:]:9s} M={M:5d} N={N:5d} K={K:5d}  vs_gemm {ms * 1e3:8.1f} us {fl / ms / 1e9:8.1f} TF/s   '
-          f'[torch.matmul {ms_t * 1e3:8.1f} us {fl / ms_t / 1e9:8.1f} TF/s]')
+          f'[torch.matmul {ms_t * 1e3:8.1f} us {fl / ms_t / 1e9:8.1f} TF/s]' + ('  cold x%d' % nset if COLD else ''))
+    del As, Bs, outs, tas, tbs
