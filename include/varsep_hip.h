@@ -240,6 +240,16 @@ int vs_adam_step_increment_scaled(int32_t* step, const float* scale_state, void*
  * the previous cap.  A bucket updated WHILE backward is still running is launched with a small grid (2 workgroups per CU) so
  * that it streams HBM in the background and leaves the wave slots to the GEMMs on the critical path.                         */
 int vs_adam_set_max_blocks(int blocks);
+/* Weight gradient + Adam in one launch (replaces, for one 2-D parameter, the weight-gradient vs_gemm of a Linear layer -- reference
+ * mlp.py:66-75 backward -- followed by its share of optimizer.step(), train.py:156-158):  G = alpha * A * B^T with the operand
+ * conventions of vs_gemm is the gradient of the contiguous fp32 parameter `param` [M, N]; the epilogue updates param / exp_avg /
+ * exp_avg_sq exactly as vs_adam_multi would from a stored G (`step` = the group's device step count BEFORE the increment,
+ * `skipped` as there) and rewrites the 16-bit operand copy `shadow` (NULL: none).  G is never stored.  16-bit compute types;
+ * operands must fit the LDS-DMA loader (16-byte aligned, leading dimensions / extents multiples of 8): VS_ERR_UNSUPPORTED
+ * otherwise and nothing is launched.                                                                                          */
+int vs_gemm_adam(int compute, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, int layout_a, const void* B, int64_t ldb,
+                 int layout_b, float alpha, float* param, float* exp_avg, float* exp_avg_sq, void* shadow, int shadow_dtype,
+                 const int32_t* step, int32_t skipped, double lr, double beta1, double beta2, double eps, void* stream);
 int vs_loss_scale_update(float* scale_state, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
 /* Fused frame losses (train.py:85-86 ae_loss MSE and train.py:139 forecast MSE in one pass over the decoded frames).

@@ -95,6 +95,8 @@ SIGNATURES = {
     'vs_adam_step_increment': (_i32, [_vp, _vp]),
     'vs_check_finite_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp]),
     'vs_adam_set_max_blocks': (_i32, [_i32]),
+    'vs_gemm_adam': (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _i32, ctypes.c_float, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
+                     ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp]),
     'vs_adam_multi_scaled': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, _vp, _vp]),
     'vs_adam_step_increment_scaled': (_i32, [_vp, _vp, _vp]),

@@ -252,6 +252,33 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
     return VS_OK;
 }
 
+// Weight gradient + optimizer in one launch: G = A * B^T (as vs_gemm) is the gradient of the fp32 parameter `param` [M, N]; the
+// epilogue applies the Adam update (vs_adam_math.h: bitwise what vs_adam_multi computes from a stored G) to param / exp_avg /
+// exp_avg_sq and rewrites the 16-bit operand copy.  The gradient never reaches HBM: per parameter 12 B read + 14 B written instead
+// of 4 B (gradient store) + 30 B (optimizer pass).  16-bit operands that fit the LDS-DMA loader only (VS_ERR_UNSUPPORTED otherwise:
+// the caller falls back to vs_gemm + vs_adam_multi); no split-K, whatever K.
+extern "C" int vs_gemm_adam(int compute, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, int layout_a, const void* B, int64_t ldb,
+                            int layout_b, float alpha, float* param, float* exp_avg, float* exp_avg_sq, void* shadow, int shadow_dtype,
+                            const int32_t* step, int32_t skipped, double lr, double beta1, double beta2, double eps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK_ARG(compute == VS_BF16 || compute == VS_F16, "vs_gemm_adam: 16-bit compute types only (%d)", compute);
+    VS_CHECK_ARG(M > 0 && N > 0 && K > 0, "vs_gemm_adam: M, N, K must be positive");
+    VS_CHECK_ARG(A && B && param && exp_avg && exp_avg_sq && step, "vs_gemm_adam: null pointer");
+    VS_CHECK_ARG((layout_a == LR || layout_a == LS) && (layout_b == LR || layout_b == LS), "vs_gemm_adam: bad layout");
+    VS_CHECK_ARG(lda >= (layout_a == LR ? K : M) && ldb >= (layout_b == LR ? K : N), "vs_gemm_adam: leading dimension too small");
+    VS_CHECK_ARG(!shadow || shadow_dtype == VS_BF16 || shadow_dtype == VS_F16, "vs_gemm_adam: bad shadow dtype");
+    if (!(glds_operand_ok(A, lda, layout_a, M, K, 0) && glds_operand_ok(B, ldb, layout_b, N, K, 0)) || lda >= (1ll << 23) || ldb >= (1ll << 23))
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm_adam: operands do not fit the LDS-DMA loader (16-byte alignment, multiples of 8)");
+    Epi epi{param, N, VS_F32, alpha, nullptr, VS_ACT_NONE, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    epi.adam_m = exp_avg; epi.adam_v = exp_avg_sq; epi.adam_shadow = (unsigned short*)shadow; epi.adam_shadow_dtype = shadow_dtype;
+    epi.adam_step = step; epi.adam_skipped = skipped;
+    epi.adam_lr = lr; epi.adam_beta1 = beta1; epi.adam_beta2 = beta2; epi.adam_eps = (float)eps;
+    MidPlan mp{true, 1, vs_cdiv(K, BIG_BK), (int)vs_cdiv(M, 128), (int)vs_cdiv(N, 128), 5};
+    if ((int64_t)mp.tiles_m * mp.tiles_n > 0x7fffffffll) return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm_adam: too many tiles");
+    return compute == VS_BF16 ? launch_mid_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, mp, 1, epi, nullptr, stream)
+                              : launch_mid_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, mp, 1, epi, nullptr, stream);
+}
+
 extern "C" size_t vs_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     size_t worst = 0;

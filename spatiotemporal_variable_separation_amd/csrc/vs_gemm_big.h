@@ -125,6 +125,39 @@ __device__ __forceinline__ unsigned big_tile_of(unsigned b, unsigned nwg) {
 }
 
 // four consecutive columns n..n+3 of row m; vector I/O when the row-major addresses allow it
+// the Adam update of four consecutive parameters (row m, columns n..n+3) with the accumulators as their gradient
+__device__ __forceinline__ void big_adam4(const Epi& e, const AdamCoef& c, int64_t m, int64_t n, int64_t N, const f32x4& g) {
+    const int64_t idx = m * e.ldc + n;
+    float* P = (float*)e.C + idx;
+    float* Mo = e.adam_m + idx;
+    float* Vo = e.adam_v + idx;
+    if (n + 3 < N && (e.ldc & 3) == 0 && (n & 3) == 0) {
+        f32x4 p = *reinterpret_cast<const f32x4*>(P), mm = *reinterpret_cast<const f32x4*>(Mo), vv = *reinterpret_cast<const f32x4*>(Vo);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float pe = p[t], me = mm[t], ve = vv[t];
+            vs_adam_elem(c, g[t] * e.alpha, pe, me, ve);
+            p[t] = pe; mm[t] = me; vv[t] = ve;
+        }
+        *reinterpret_cast<f32x4*>(P) = p;
+        *reinterpret_cast<f32x4*>(Mo) = mm;
+        *reinterpret_cast<f32x4*>(Vo) = vv;
+        if (e.adam_shadow) {
+            const u16x4 h = {vs_f2h(p[0], e.adam_shadow_dtype), vs_f2h(p[1], e.adam_shadow_dtype), vs_f2h(p[2], e.adam_shadow_dtype),
+                             vs_f2h(p[3], e.adam_shadow_dtype)};
+            *reinterpret_cast<u16x4*>(e.adam_shadow + idx) = h;
+        }
+    } else {
+        for (int t = 0; t < 4; ++t)
+            if (n + t < N) {
+                float pe = P[t], me = Mo[t], ve = Vo[t];
+                vs_adam_elem(c, g[t] * e.alpha, pe, me, ve);
+                P[t] = pe; Mo[t] = me; Vo[t] = ve;
+                if (e.adam_shadow) e.adam_shadow[idx + t] = vs_f2h(pe, e.adam_shadow_dtype);
+            }
+    }
+}
+
 template <bool NCHW>
 __device__ __forceinline__ void big_store4(const Epi& e, int64_t m, int64_t n, int64_t N, const f32x4& v, float* slab_row) {
     if (slab_row) {                                               // split-K partial: raw fp32, reduced (with the epilogue) later

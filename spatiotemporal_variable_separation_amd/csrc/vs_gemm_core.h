@@ -23,6 +23,8 @@ __device__ __forceinline__ f32x16 mfma16_32(const u32x4& a, const u32x4& b, cons
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+#include "vs_adam_math.h"
+
 struct Epi {
     void* C; int64_t ldc; int c_dtype;
     float alpha; const float* bias; int act;
@@ -37,6 +39,12 @@ struct Epi {
     // batched dense GEMM (vs_gemm_batched): gridDim.z = batch * splits; operand / output element strides between problems
     int splits_per_batch;
     int64_t batch_a, batch_b, batch_c;
+    // fused optimizer (vs_gemm_adam, ring-tile kernels only): the result is the GRADIENT of the fp32 parameter C [M, ldc]; the
+    // epilogue applies the Adam update to C / adam_m / adam_v (same layout) and refreshes the 16-bit operand copy, the gradient
+    // is never stored
+    float* adam_m; float* adam_v; unsigned short* adam_shadow; int adam_shadow_dtype;
+    const int* adam_step; int adam_skipped;
+    double adam_lr, adam_beta1, adam_beta2; float adam_eps;
 };
 
 __device__ __forceinline__ Epi epi_for_batch(const Epi& e, int64_t batch) {

@@ -198,6 +198,17 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
                 stg[(32 * ii + (v & 3) + 8 * (v >> 2) + rh) * 64 + 32 * j + cj] = acc[ii][j][v];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // own writes only: a wave reads back what it wrote itself
     const int64_t nn = n0 + wc * 64 + (lane & 15) * 4;
+    if (epi.adam_m && !slab_base) {
+        // fused optimizer: the tile is a block of the parameter's gradient
+        const AdamCoef coef = vs_adam_coef(epi.adam_lr, epi.adam_beta1, epi.adam_beta2, epi.adam_eps, (double)(epi.adam_step[0] + 1 - epi.adam_skipped));
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + (lane >> 4);
+            const int64_t m = m0 + wr * 64 + r;
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + r * 64 + (lane & 15) * 4);
+            if (m < M && nn < N) big_adam4(epi, coef, m, nn, N, v4);
+        }
+        return;
+    }
     for (int it = 0; it < 16; ++it) {
         const int r = it * 4 + (lane >> 4);
         const int64_t m = m0 + wr * 64 + r;

@@ -7,6 +7,7 @@
 // model has two 24.6 M-element matrices next to 32-element biases).  The step count lives on the device, so the launch is
 // recordable into a hipGraph.
 #include "vs_common.h"
+#include "vs_adam_math.h"
 #include <math.h>
 
 namespace {
@@ -40,20 +41,14 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
         if (scale_state[1] != 0.f) return;
         inv_scale = 1.f / scale_state[0];
     }
-    // hyper-parameters arrive in double like the Python floats torch works with: 1 - beta and beta^t are formed in double
-    const float lr = (float)lr_d, beta2 = (float)beta2_d;
     // bias corrections from the device-side step count (the count is incremented by a separate 1-thread launch AFTER this one,
     // so every workgroup of this launch reads the same value)
     const int t_group = step[0] + 1;
-    const float w1 = (float)(1.0 - beta1_d), w2 = (float)(1.0 - beta2_d);
     const int total = J.chunk_off[J.nj];
     for (int ch = blockIdx.x; ch < total; ch += gridDim.x) {
         int j = 0;                                            // uniform per workgroup: scalar search over <= 64 entries
         while (J.chunk_off[j + 1] <= ch) ++j;
-        const double t = (double)(t_group - J.skipped[j]);
-        const float bc1 = (float)(1.0 - pow(beta1_d, t));
-        const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2_d, t));
-        const float step_size = lr / bc1;
+        const AdamCoef c = vs_adam_coef(lr_d, beta1_d, beta2_d, eps, (double)(t_group - J.skipped[j]));
         const long long base = (long long)(ch - J.chunk_off[j]) * AD_CHUNK;
         const long long n = J.n[j];
         float* __restrict__ P = J.p[j];
@@ -80,10 +75,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (scale_state) g[e] *= inv_scale;                     // scaler.unscale_: grad * (1 / scale)
-                    m[e] = m[e] + w1 * (g[e] - m[e]);                       // exp_avg.lerp_(grad, 1 - beta1)
-                    v[e] = v[e] * beta2 + (w2 * g[e]) * g[e];              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-                    const float denom = sqrtf(v[e]) / bc2_sqrt + eps;
-                    p[e] = p[e] - step_size * (m[e] / denom);              // param.addcdiv_(exp_avg, denom, -step_size)
+                    float pe = p[e], me = m[e], ve = v[e];
+                    vs_adam_elem(c, g[e], pe, me, ve);
+                    p[e] = pe; m[e] = me; v[e] = ve;
                 }
                 *reinterpret_cast<f32x4*>(P + i) = p;
                 *reinterpret_cast<f32x4*>(M + i) = m;
@@ -96,12 +90,10 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
                 for (long long k = i; k < n && k < i + 4; ++k) {
                     float g = gh ? (float)Gh[k] : G[k];
                     if (scale_state) g *= inv_scale;
-                    const float m = M[k] + w1 * (g - M[k]);
-                    const float v = V[k] * beta2 + (w2 * g) * g;
-                    const float denom = sqrtf(v) / bc2_sqrt + eps;
-                    const float p = P[k] - step_size * (m / denom);
-                    P[k] = p; M[k] = m; V[k] = v;
-                    if (S) S[k] = vs_f2h(p, sdt);
+                    float pe = P[k], me = M[k], ve = V[k];
+                    vs_adam_elem(c, g, pe, me, ve);
+                    P[k] = pe; M[k] = me; V[k] = ve;
+                    if (S) S[k] = vs_f2h(pe, sdt);
                 }
             }
         }

@@ -260,6 +260,26 @@ def lowp_gradient(prm):
     return _LOWP_GRAD.get(id(prm)) if _LOWP_GRAD else None
 
 
+# ---- optimizer fused into the weight gradient -----------------------------------------------------------------------------------
+# optim.Adam.fuse_into_wgrad(params) registers 2-D Linear weights whose weight-gradient GEMM applies the Adam update in its epilogue
+# (ops.gemm_adam): the gradient of such a weight is never stored and autograd gets nothing for it.  Valid where the chain's
+# backward produces THE gradient of the step (one contribution, no all-reduce, no loss scaling) -- the recorded single-GPU MLP step.
+_FUSED_OPT = {}
+
+
+def set_fused_optimizer(mapping):
+    """mapping: {parameter: optimizer with fused_update(parameter, a, la, b, lb, M, N, K)} or None to clear."""
+    _FUSED_OPT.clear()
+    if mapping:
+        for prm, opt in mapping.items():
+            _FUSED_OPT[id(prm)] = (prm, opt)
+
+
+def fused_optimizer(prm):
+    ent = _FUSED_OPT.get(id(prm)) if _FUSED_OPT else None
+    return ent[1] if ent is not None and ent[0] is prm else None
+
+
 def side_streams_in_use():
     """Streams that deferred gradient work of the current step may still be running on."""
     return (list(_SIDE['lanes']) + ([_SIDE['rollout']] if _SIDE['rollout'] is not None else [])) if _SIDE['on'] else []
@@ -417,7 +437,12 @@ class MLPChain(torch.autograd.Function):
             h_in = saved[l]
             if W.requires_grad:               # dW = dz^T h_in (fp32); off the critical path -> wgrad stream when enabled
                 dst = grad_output(W)
-                if dst is not None:           # straight into the all-reduce bucket; autograd gets nothing for this parameter
+                fused = fused_optimizer(W) if dst is None else None
+                if fused is not None and cdt != torch.float32 and fused.can_fuse(W, dz, h_in):
+                    # the weight-gradient GEMM's epilogue IS this weight's optimizer step; nothing is stored, autograd gets nothing
+                    run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, W=W, fused=fused: fused.fused_update(W, dz, S, h_in, S, N, K, M),
+                                 dz, h_in, outs=(), lane=lane)
+                elif dst is not None:           # straight into the all-reduce bucket; autograd gets nothing for this parameter
                     run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, dst=dst: ops.gemm(dz, S, h_in, S, N, K, M, out=dst), dz, h_in,
                                  lane=lane)
                 else:

@@ -108,6 +108,25 @@ def gemm(a, layout_a, b, layout_b, M, N, K, out=None, out_dtype=torch.float32, a
     return out
 
 
+def gemm_adam(a, layout_a, b, layout_b, M, N, K, param, exp_avg, exp_avg_sq, shadow, step_dev, skipped, lr, betas, eps, alpha=1.0):
+    """param [M, N] (fp32, contiguous) takes one Adam step with G = alpha * A B^T as its gradient; G is never stored
+    (vs_gemm_adam).  Raises VarsepHipError(code VS_ERR_UNSUPPORTED) when the operands do not fit the LDS-DMA loader."""
+    require_cuda(a, b, param, exp_avg, exp_avg_sq, step_dev)
+    lib = _lib.load_library()
+    assert a.dtype == b.dtype and a.dtype in (torch.bfloat16, torch.float16) and a.stride(-1) == 1 and b.stride(-1) == 1
+    assert param.dtype == torch.float32 and param.is_contiguous() and tuple(param.shape) == (M, N)
+    assert exp_avg.is_contiguous() and exp_avg_sq.is_contiguous() and exp_avg.shape == param.shape == exp_avg_sq.shape
+    assert shadow is None or (shadow.is_contiguous() and shadow.shape == param.shape and shadow.dtype in (torch.bfloat16, torch.float16))
+    e0 = _pb()
+    check(lib.vs_gemm_adam(dtype_code(a), M, N, K, a.data_ptr(), a.stride(0), layout_a, b.data_ptr(), b.stride(0), layout_b, float(alpha),
+                           param.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), _ptr(shadow),
+                           code_of(shadow.dtype) if shadow is not None else BF16, step_dev.data_ptr(), int(skipped), float(lr),
+                           float(betas[0]), float(betas[1]), float(eps), stream_ptr()), 'vs_gemm_adam')
+    # algorithmic bytes: the operands, p / m / v read and written, the 16-bit copy
+    _pe(e0, 'vs_gemm_adam<%s,%s%s>' % (_DT[dtype_code(a)], _LNAME[layout_a], _LNAME[layout_b]), flops=2.0 * M * N * K,
+        nbytes=float((M * K + N * K) * a.element_size() + M * N * (24 + (2 if shadow is not None else 0))))
+
+
 def gemm_batched(a, layout_a, b, layout_b, M, N, K, out_dtype=torch.float32):
     """a [batch, ., .], b [batch, ., .] contiguous 3-D tensors of one dtype: out[i] = A_i B_i^T for every i in ONE launch."""
     require_cuda(a, b)

@@ -25,6 +25,7 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._tables = {}
         self._buckets, self._bucket_of, self._left, self._launched, self._stream = [], {}, [], set(), None
+        self._fused, self._fused_done = [], set()
 
     # ---- update-in-backward ------------------------------------------------------------------------------------------
     def overlap_with_backward(self, buckets):
@@ -42,6 +43,45 @@ class Adam(torch.optim.Optimizer):
         for b in self._buckets:
             for p in b:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # ---- update fused into the weight-gradient GEMM ---------------------------------------------------------------
+    def fuse_into_wgrad(self, params):
+        """The listed 2-D weights take their Adam step inside the epilogue of their weight-gradient GEMM (functional.MLPChain ->
+        ops.gemm_adam): per parameter 26 B of HBM traffic instead of 4 (gradient store) + 30 (this optimizer's pass), and the
+        gradient is never materialised (`p.grad` stays None).  Contract as overlap_with_backward: one backward pass per step(),
+        one gradient contribution per listed weight, no gradient all-reduce, no loss scaling; the learning rate is read when the
+        GEMM is launched (a recorded step is re-recorded when it changes).  `step()` skips what was updated this way."""
+        from . import functional as VF
+        assert len(self.param_groups) == 1, 'fuse_into_wgrad: one param group'
+        owned = {id(p) for p in self.param_groups[0]['params']}
+        self._fused = [p for p in params if id(p) in owned and p.dim() == 2 and p.requires_grad]
+        self._fused_done = set()
+        VF.set_fused_optimizer({p: self for p in self._fused})
+
+    def unfuse(self):
+        from . import functional as VF
+        self._fused, self._fused_done = [], set()
+        VF.set_fused_optimizer(None)
+
+    def can_fuse(self, p, a, b):
+        return (getattr(self, '_scale_state', None) is None and p.is_contiguous() and p.dtype == torch.float32 and a.dtype == b.dtype
+                and a.dtype in (torch.bfloat16, torch.float16) and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+                and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0)
+
+    @torch.no_grad()
+    def fused_update(self, p, a, layout_a, b, layout_b, M, N, K):
+        """One Adam step of `p` [M, N] with a(M, K) . b(N, K)^T as its gradient (operand conventions of ops.gemm)."""
+        from . import functional as VF, ops
+        group = self.param_groups[0]
+        self._init_group(0, group)
+        st = self.state[p]
+        shadow = VF.shadow_buffer_for_update(p)
+        ops.gemm_adam(a, layout_a, b, layout_b, M, N, K, p, st['exp_avg'], st['exp_avg_sq'], shadow, group['step_dev'], st.get('skipped', 0),
+                      group['lr'], group['betas'], group['eps'])
+        torch.autograd.graph.increment_version(p)
+        if shadow is not None:
+            VF.shadows_written([p])
+        self._fused_done.add(id(p))
 
     def _on_grad(self, p):
         bi = self._bucket_of.get(id(p))
@@ -132,9 +172,11 @@ class Adam(torch.optim.Optimizer):
             if gi == 0 and self._launched:          # buckets already updated from the backward hooks
                 for bi in self._launched:
                     done.update(id(p) for p in self._buckets[bi])
+            fused_done = getattr(self, '_fused_done', set())
+            done |= fused_done                       # updated by their weight-gradient GEMMs during backward
             live = [p for p in group['params'] if p.grad is not None and id(p) not in done]
             for p in group['params']:
-                if p.grad is None:                   # torch counts steps per parameter: this one falls one behind the group
+                if p.grad is None and id(p) not in fused_done:   # torch counts steps per parameter: this one falls one behind the group
                     self.state[p]['skipped'] = self.state[p].get('skipped', 0) + 1
             if live:
                 self._update(gi, group, live)
@@ -149,6 +191,8 @@ class Adam(torch.optim.Optimizer):
         if self._buckets:
             self._left = [len(b) for b in self._buckets]
             self._launched = set()
+        if getattr(self, '_fused_done', None):
+            self._fused_done = set()
         return loss
 
     @torch.no_grad()

@@ -212,6 +212,7 @@ class GraphedStep:
             grad_sync.direct_lowp = True
             VF.set_lowp_gradients({p: grad_sync.lowp_views[id(p)] for p in grad_sync.params if id(p) in grad_sync.lowp_views})
         enable_update_in_backward(optimizer, sep_net, grad_sync)
+        enable_fused_update(optimizer, sep_net, grad_sync, scaler)
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
         # static inputs of the recording: one [B, T, ...] buffer, cond / target are views of it (no concatenation per step)
         self.full = torch.cat([cond, target], dim=1).contiguous()
@@ -372,6 +373,23 @@ def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False):
                    [p for p in sep_net.Et.parameters() if id(p) in owned]]
         if sum(len(b) for b in buckets) == len(owned):
             optimizer.overlap_with_backward(buckets)
+
+
+def enable_fused_update(optimizer, sep_net, grad_sync=None, scaler=None, min_numel=1 << 22):
+    """Single GPU, HIP Adam, 16-bit compute, no loss scaling: the large Linear weights of an MLP-family model (WaveEq: the encoders'
+    20480 x 1200 first layers and the decoder's 1200 x 4096 last layer, 54 M of the model's 60 M parameters) take their Adam step
+    in the epilogue of their weight-gradient GEMM (optim.Adam.fuse_into_wgrad): 26 B of HBM traffic per parameter instead of 34,
+    and the optimizer pass at the end of the step shrinks to the remaining 6 M parameters.  VARSEP_FUSE_ADAM=0 disables."""
+    from .optim import Adam as HipAdam
+    if os.environ.get('VARSEP_FUSE_ADAM', '1') != '1' or not isinstance(optimizer, HipAdam):
+        return False
+    if grad_sync is not None or scaler is not None or not _mlp_family(sep_net) or len(optimizer.param_groups) != 1 or optimizer._buckets:
+        return False
+    big = [p for p in chain_weight_parameters(sep_net) if p.numel() >= min_numel]
+    if not big:
+        return False
+    optimizer.fuse_into_wgrad(big)
+    return True
 
 
 def check_optimizer(optimizer, for_graph=False):

@@ -206,3 +206,89 @@ def test_step_by_subsets_equals_one_step():
     b[0].grad = None
     with pytest.raises(Exception):
         ob.step_subset(b[:1])
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(1200, 2048, 256), (136, 264, 40), (512, 1000, 3328)])
+def test_gemm_adam_equals_gemm_then_adam(dtype, shape):
+    """vs_gemm_adam (the weight-gradient GEMM whose epilogue is the optimizer step) == the same GEMM storing its result followed by
+    vs_adam_multi: bitwise the same parameters, moments and 16-bit copies over three steps, including ragged tiles."""
+    import os
+    from oracle.detdata import det_uniform
+    from spatiotemporal_variable_separation_amd import ops, functional as VF
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    M, N, K = shape                                 # parameter [M, N]; operands dz [K, M], h [K, N] in the S layout of a weight gradient
+    p0 = (det_uniform((M, N), 3) - 0.5).cuda()
+    pa, pb = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    oa, ob = Adam([pa], lr=4e-4, betas=(0.9, 0.99)), Adam([pb], lr=4e-4, betas=(0.9, 0.99))
+    with VF.precision('bf16' if dtype == torch.bfloat16 else 'fp16'):
+        sa, sb = VF.shadow(pa, dtype), VF.shadow(pb, dtype)           # live operand copies: both paths must keep them current
+        for step in range(3):
+            dz = ((det_uniform((K, M), 10 + step) - 0.5) * 0.1).cuda().to(dtype)
+            h = (det_uniform((K, N), 20 + step) - 0.5).cuda().to(dtype)
+            # (a) fused
+            oa.fuse_into_wgrad([pa])
+            assert oa.can_fuse(pa, dz, h)
+            oa.fused_update(pa, dz, 1, h, 1, M, N, K)
+            oa.step()                                                  # nothing left to update; advances the step count
+            oa.unfuse()
+            # (b) the same kernel storing the gradient (128x128 ring tile, no split-K), then the optimizer's own launch
+            os.environ['VS_GEMM_MID'] = '2'
+            os.environ['VS_GEMM_BIG'] = '0'
+            try:
+                pb.grad = ops.gemm(dz, 1, h, 1, M, N, K)
+            finally:
+                del os.environ['VS_GEMM_MID'], os.environ['VS_GEMM_BIG']
+            ob.step()
+            torch.cuda.synchronize()
+            assert torch.equal(pa, pb), (step, (pa - pb).abs().max().item())
+            for name in ('exp_avg', 'exp_avg_sq'):
+                assert torch.equal(oa.state[pa][name], ob.state[pb][name]), (step, name)
+            assert torch.equal(VF.shadow(pa, dtype), VF.shadow(pb, dtype)) and torch.equal(VF.shadow(pa, dtype), pa.detach().to(dtype))
+    assert float(oa.state_dict()['state'][0]['step']) == 3.0
+
+
+def test_fused_update_in_the_recorded_step_equals_the_plain_step(name='mlp_mul'):
+    """GraphedStep with the Linear weights' Adam steps fused into their weight-gradient GEMMs == the same recorded step with the
+    optimizer's own launch for every parameter (bf16 mode; the gradients differ only in their split-K summation order)."""
+    import os
+    import numpy as np
+    from oracle import cpu_ref
+    from oracle.detdata import det_fill
+    from oracle.golden_configs import CONFIGS, make_batch
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.train import GraphedStep, chain_weight_parameters
+    cfg = dict(CONFIGS[name], B=8)
+    lam = cfg['lambdas']
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    o_net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    results = []
+    for fused in (True, False):
+        net = build_sep_net(cfg)
+        net.load_state_dict(o_net.state_dict())
+        net = net.cuda().train()
+        with VF.precision('bf16'):
+            opt = Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.99))
+            os.environ['VARSEP_FUSE_ADAM'] = '0'        # GraphedStep's own choice (weights >= 4 M elements) is off: chosen here
+            try:
+                if fused:
+                    opt.fuse_into_wgrad(chain_weight_parameters(net))
+                    assert len(opt._fused) >= 6
+                np.random.seed(11)
+                g = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], (lam['ae'], lam['s'], lam['t'], lam['pred']),
+                                warmup=2)
+                losses = [g.step().item() for _ in range(4)]
+            finally:
+                del os.environ['VARSEP_FUSE_ADAM']
+                opt.unfuse()
+        torch.cuda.synchronize()
+        results.append((losses, {k: v.clone() for k, v in net.state_dict().items()}, float(opt.state_dict()['state'][0]['step'])))
+    (la, sa, ta), (lb, sb, tb) = results
+    assert ta == tb == 4.0
+    assert np.allclose(la, lb, rtol=2e-3), (la, lb)
+    for k in sa:
+        # Adam normalises: a near-zero gradient that differs in its last bits moves a weight by up to lr in either direction
+        assert torch.allclose(sa[k], sb[k], rtol=2e-3, atol=2.5e-3), f'{k}: {(sa[k] - sb[k]).abs().max().item():.3e}'
