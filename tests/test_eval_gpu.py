@@ -66,3 +66,36 @@ def test_checkpoint_round_trip(tmp_path):
     a, b = fresh.state_dict(), o_net.state_dict()
     for k in b:
         assert torch.equal(a[k].cpu(), b[k]), k
+
+
+EVAL_NAMES = ['mlp_mul', 'mlp_concat_partial', 'mlp_no_s', 'dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'sst_skip', 'chairs_resnet']
+
+
+@pytest.mark.parametrize('name', EVAL_NAMES)
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_eval_forecast_matches_reference_fixture(name, precision):
+    """HIP inference path against the vectors the REFERENCE produced (tests/golden/eval_<name>.npz, oracle/make_golden_eval.py):
+    `.eval()` + no_grad `get_forecast` over 12 frames and the content swap through `init_s_code` (test/wave/test.py:41-48,
+    test/mnist/test_disentanglement.py).  fp32 mode at the 1e-3 bar; bf16 mode at its rounding level."""
+    from golden_util import check_tensor, load_golden
+    from oracle.golden_configs import fill_net
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    cfg = CONFIGS[name]
+    gold = load_golden('eval_' + name)
+    o_net = fill_net(cpu_ref.build_sep_net(dict(cfg)), cfg)
+    h_net = build_sep_net(cfg)
+    h_net.load_state_dict(o_net.state_dict(), strict=True)
+    h_net = h_net.cuda().eval()
+    cond, _ = make_batch(cfg)
+    cond = cond.cuda()
+    skip = bool(cfg.get('skipco', False))
+    tol = 1e-3 if precision == 'fp32' else 4e-2
+    with torch.no_grad(), VF.precision(precision):
+        fore, codes, s, _ = h_net.get_forecast(cond, int(gold['horizon']))
+        swap = h_net.get_forecast(cond, int(gold['swap_horizon']), init_s_code=h_net.Es(cond.flip(0), return_skip=skip))[0]
+    torch.cuda.synchronize()
+    errs = {'forecasts': check_tensor(gold, 'forecasts', fore, tol), 't_codes': check_tensor(gold, 't_codes', codes, tol),
+            's_code': check_tensor(gold, 's_code', s[0] if isinstance(s, (tuple, list)) else s, tol),
+            'swap': check_tensor(gold, 'swap_forecasts', swap, tol)}
+    print(name, precision, 'eval vs reference fixture:', {k: '%.1e' % v for k, v in errs.items()})

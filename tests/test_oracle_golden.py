@@ -55,3 +55,28 @@ def test_t_random_comes_from_global_numpy_rng():
     np.random.seed(cfg.get('np_seed', 1234))
     hi = cfg['nt_cond'] + cfg['nt_pred'] + (0 if cfg['offset'] == 0 else 1)
     assert int(np.random.randint(cfg['nt_cond'], hi)) == int(gold['t_random'])
+
+
+EVAL_NAMES = ['mlp_mul', 'mlp_concat_partial', 'mlp_no_s', 'dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'sst_skip', 'chairs_resnet']
+
+
+@pytest.mark.parametrize('name', EVAL_NAMES)
+def test_oracle_eval_forecast_matches_reference_fixture(name):
+    """The oracle's inference path (eval-mode BatchNorm, no_grad, horizon 12, content swap) against tests/golden/eval_<name>.npz,
+    which oracle/make_golden_eval.py recorded from the reference's own `get_forecast` (test/wave/test.py:41-48 usage)."""
+    import torch
+    from oracle import cpu_ref
+    from oracle.golden_configs import CONFIGS, fill_net, make_batch
+    from golden_util import check_tensor, load_golden
+    cfg = CONFIGS[name]
+    gold = load_golden('eval_' + name)
+    net = fill_net(cpu_ref.build_sep_net(dict(cfg)), cfg).eval()
+    cond, _ = make_batch(cfg)
+    skip = bool(cfg.get('skipco', False))
+    with torch.no_grad():
+        fore, codes, s, _ = net.get_forecast(cond, int(gold['horizon']))
+        swap = net.get_forecast(cond, int(gold['swap_horizon']), init_s_code=net.Es(cond.flip(0), return_skip=skip))[0]
+    check_tensor(gold, 'forecasts', fore, 1e-5)
+    check_tensor(gold, 't_codes', codes, 1e-5)
+    check_tensor(gold, 's_code', s[0] if isinstance(s, (tuple, list)) else s, 1e-5)
+    check_tensor(gold, 'swap_forecasts', swap, 1e-5)
