@@ -99,7 +99,7 @@ def compute_dtype():
 #     E_s encoder, its backward overlaps the decoder/encoder weight gradients.
 # Only valid when every parameter receives ONE gradient per step (the batched MLP-family step) and without hook-driven
 # gradient all-reduce; `train._compute_losses_mlp_batched` / `GraphedStep` switch it on, everything else leaves it off.
-_SIDE = {'on': False, 'lanes': [], 'next_lane': 0, 'rollout': None, 'hold': False, 'held': [], 'hold_main': None}
+_SIDE = {'on': False, 'lanes': [], 'next_lane': 0, 'rollout': None, 'hold': False, 'held': [], 'hold_main': None, 'late': []}
 # Deferred gradient work is spread over a few streams ("lanes", one per Linear chain / integrator backward in turn): most of it
 # is GEMMs of 10-50 us that fill a fraction of the chip each, and one stream would run them one after the other.
 N_LANES = max(1, int(os.environ.get('VARSEP_WGRAD_LANES', '3')))
@@ -109,7 +109,7 @@ def enable_side_streams(flag):
     _SIDE['on'] = bool(flag)
     _SIDE['next_lane'] = 0
     if not flag:
-        _SIDE['hold'], _SIDE['held'] = False, []
+        _SIDE['hold'], _SIDE['held'], _SIDE['late'] = False, [], []
 
 
 def side_streams_enabled():
@@ -180,6 +180,18 @@ def run_deferred(fn, *inputs, outs=None, lane=0):
         if isinstance(t, torch.Tensor):
             t.record_stream(main)
     return out
+
+
+def run_late(fn, *inputs, outs, lane=0):
+    """Deferred work that must not be recorded NOW: it is launched by join_side_streams(), i.e. after the rest of backward has been
+    issued.  The integrator's own weight gradients use it: recorded right behind the integrator's backward kernel they end up, in
+    the replayed hipGraph, on the same queue as E_t's input-gradient chain and AHEAD of it (120 us of small GEMMs in front of
+    the critical path of the WaveEq step)."""
+    if not _SIDE['on']:
+        fn()
+        return outs
+    _SIDE['late'].append((fn, inputs, outs, lane, torch.cuda.current_stream()))
+    return outs
 
 
 def defer_call(fn):
@@ -290,6 +302,13 @@ def join_side_streams():
     if not _SIDE['on']:
         return          # nothing was deferred; waiting on a stream outside the running capture would break the capture
     release_deferred()  # (a step without the integrator's backward never reached the release point)
+    late, _SIDE['late'] = _SIDE['late'], []
+    for fn, inputs, outs, lane, producer in late:
+        ws = _lane_stream(lane)
+        ws.wait_stream(producer)
+        with torch.cuda.stream(ws):
+            fn()
+        _record_on(ws, inputs, outs)
     cur = torch.cuda.current_stream()
     for ws in _SIDE['lanes']:
         cur.wait_stream(ws)
@@ -566,21 +585,40 @@ class MLPRollout(torch.autograd.Function):
         if rows == 0:
             return (dx0, None) + tuple(torch.zeros_like(p) for p in params)
 
-        def weight_grads():
+        bias_in = []
+        for b in range(nb):
+            bias_in += [dh1[b].view(rows, H), dh2[b].view(rows, H), dr[b].view(rows, C)]
+
+        def weight_grads(dW1=None, dW2=None, dW3=None, bias_out=None, bias_flat=None):
             # the three weight gradients of ALL blocks: one batched launch per layer (the saves are [block][step*B][feature])
-            dW1 = ops.gemm_batched(dh1.view(nb, rows, H), S, xin.view(nb, rows, C), S, H, C, rows)
-            dW2 = ops.gemm_batched(dh2.view(nb, rows, H), S, h1.view(nb, rows, H), S, H, H, rows)
-            dW3 = ops.gemm_batched(dr.view(nb, rows, C), S, h2.view(nb, rows, H), S, C, H, rows)
-            grads, bias_jobs = [], []
+            dW1 = ops.gemm_batched(dh1.view(nb, rows, H), S, xin.view(nb, rows, C), S, H, C, rows, out=dW1)
+            dW2 = ops.gemm_batched(dh2.view(nb, rows, H), S, h1.view(nb, rows, H), S, H, H, rows, out=dW2)
+            dW3 = ops.gemm_batched(dr.view(nb, rows, C), S, h2.view(nb, rows, H), S, C, H, rows, out=dW3)
+            dbs = ops.colsum_multi(bias_in, outs=bias_out, zero_flat=bias_flat)
+            grads = []
             for b in range(nb):
-                grads += [dW1[b], None, dW2[b], None, dW3[b], None]
-                bias_jobs += [dh1[b].view(rows, H), dh2[b].view(rows, H), dr[b].view(rows, C)]
-            for i, db in enumerate(ops.colsum_multi(bias_jobs)):
-                grads[2 * i + 1] = db
+                grads += [dW1[b], dbs[3 * b], dW2[b], dbs[3 * b + 1], dW3[b], dbs[3 * b + 2]]
             return grads
-        # with gradient destinations registered these gradients still go through autograd's `+=` into the bucket views, which
-        # runs on THIS node's stream: compute them here, not on the wgrad stream
-        grads = weight_grads() if _GRAD_OUT else run_deferred(weight_grads, dr, dh2, dh1, xin, h1, h2, lane=next_lane())
+        if _GRAD_OUT:
+            # with gradient destinations registered these gradients still go through autograd's `+=` into the bucket views, which
+            # runs on THIS node's stream: compute them here, not on a gradient stream
+            grads = weight_grads()
+        elif _SIDE['on'] and os.environ.get('VARSEP_ROLLOUT_WGRAD_LATE', '1') == '1':
+            # recorded at the END of backward (run_late), into buffers allocated now; autograd is handed views of its own (a tensor
+            # somebody else references would be cloned, here before it has been written)
+            dev = dx0.device
+            w1, w2, w3 = (torch.empty(shape, dtype=torch.float32, device=dev) for shape in ((nb, H, C), (nb, H, H), (nb, C, H)))
+            flat, views = ops.colsum_alloc(bias_in)
+            grads = []
+            for b in range(nb):
+                grads += [w1[b], views[3 * b], w2[b], views[3 * b + 1], w3[b], views[3 * b + 2]]
+            mine = ops.colsum_alloc(bias_in, flat)[1]
+            del views
+            run_late(lambda a=w1.view(nb, H, C), b_=w2.view(nb, H, H), c=w3.view(nb, C, H): weight_grads(a, b_, c, mine, flat),
+                     dr, dh2, dh1, xin, h1, h2, outs=(w1, w2, w3, flat), lane=next_lane())
+            del w1, w2, w3
+        else:
+            grads = run_deferred(weight_grads, dr, dh2, dh1, xin, h1, h2, lane=next_lane())
         return (dx0, None) + tuple(grads)
 
 

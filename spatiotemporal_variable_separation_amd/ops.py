@@ -127,7 +127,7 @@ def gemm_adam(a, layout_a, b, layout_b, M, N, K, param, exp_avg, exp_avg_sq, sha
         nbytes=float((M * K + N * K) * a.element_size() + M * N * (24 + (2 if shadow is not None else 0))))
 
 
-def gemm_batched(a, layout_a, b, layout_b, M, N, K, out_dtype=torch.float32):
+def gemm_batched(a, layout_a, b, layout_b, M, N, K, out_dtype=torch.float32, out=None):
     """a [batch, ., .], b [batch, ., .] contiguous 3-D tensors of one dtype: out[i] = A_i B_i^T for every i in ONE launch."""
     require_cuda(a, b)
     lib = _lib.load_library()
@@ -136,7 +136,9 @@ def gemm_batched(a, layout_a, b, layout_b, M, N, K, out_dtype=torch.float32):
     assert a.dim() == 3 and b.dim() == 3 and a.is_contiguous() and b.is_contiguous() and a.shape[0] == b.shape[0]
     batch = a.shape[0]
     compute = dtype_code(a)
-    out = torch.empty((batch, M, N), dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty((batch, M, N), dtype=out_dtype, device=a.device)
+    assert out.is_contiguous() and tuple(out.shape) == (batch, M, N)
     ws_bytes = lib.vs_gemm_batched_workspace_bytes(batch, M, N, K)
     ws = _workspace(ws_bytes, a.device) if ws_bytes else None
     e0 = _pb()
