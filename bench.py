@@ -176,7 +176,7 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None):
     from spatiotemporal_variable_separation_amd.optim import Adam
     from spatiotemporal_variable_separation_amd.parallel import GradAllReducer, broadcast_module_state
     from spatiotemporal_variable_separation_amd.train import (GraphedStep, chain_weight_parameters, compute_losses,
-                                                               enable_update_in_backward, make_loss_scaler)
+                                                               enable_fused_update, enable_update_in_backward, make_loss_scaler)
     dev = rk.dev
     cfg = dict(BASELINE_CONFIGS[name])
     if batch:
@@ -199,6 +199,8 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None):
     lam = cfg['lambdas']
     VF.set_precision(args.precision)
     scaler = make_loss_scaler(dev) if args.precision == 'fp16' else None     # reference train.py:96-97: GradScaler with fp16 autocast
+    if args.precision != 'fp32':
+        enable_fused_update(opt, net, sync, scaler)      # (GraphedStep does the same; here for --no_graph and the instrumented eager steps)
     VF.fold_repeated_gradients(sync is None and os.environ.get('VARSEP_FOLD_GRADS', '1') == '1')
 
     def step():
@@ -288,8 +290,8 @@ def rooflines(res, precision, traffic=None, top=6):
     def roof_of(name, rec):
         base = {'kernel': name, 'launches_per_step': round(rec['n'] / sampled, 2), 'avg_launch_us': round(rec['ms'] * 1e3 / rec['n'], 2),
                 'share_of_step': round(rec['ms'] / (ms * sampled), 3), 'traffic': None}
-        if rec['flops'] > 0:
-            peak = 157.3 if precision == 'fp32' else 2500.0
+        if rec['flops'] > 0 and not name.startswith('vs_gemm_adam'):     # (the fused weight-gradient + Adam launch is HBM-bound:
+            peak = 157.3 if precision == 'fp32' else 2500.0              # 26 B per parameter against 2 K flop, K = 256)
             ach = rec['flops'] / (rec['ms'] * 1e-3) / 1e12
             base.update({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4)})
         else:

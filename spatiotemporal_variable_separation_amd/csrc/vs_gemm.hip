@@ -109,8 +109,10 @@ int launch_mid(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M
                                (int)mp.k_tiles_per_split, mp.tiles_n, epi, slabs);
             return VS_OK;
         };
-        static bool set5 = false, set10 = false;
-        const int rc = mp.stages == 10 ? go(gemm_mid_kernel<CT, LA, LB, false, 10>, 10, set10) : go(gemm_mid_kernel<CT, LA, LB, false, 5>, 5, set5);
+        static bool set5 = false, set10 = false, set_adam = false;
+        const int rc = epi.adam_m ? go(gemm_mid_kernel<CT, LA, LB, false, 5, true>, 5, set_adam)
+                       : mp.stages == 10 ? go(gemm_mid_kernel<CT, LA, LB, false, 10, false>, 10, set10)
+                                         : go(gemm_mid_kernel<CT, LA, LB, false, 5, false>, 5, set5);
         if (rc != VS_OK) return rc;
         VS_CHECK_LAUNCH("vs_gemm (128x128 ring tile)");
         return VS_OK;

@@ -71,7 +71,7 @@ struct MidOperand {
 
 // ST ring slots of 16 KiB: 5 (80 KiB) where two workgroups share a CU, 10 (all 160 KiB) where the launch has at most one per CU --
 // what a CU pulls through LDS-DMA is (bytes in flight) / (1.3-2 us), so the ring is as deep as the LDS allows.
-template <int CT, int LA, int LB, bool NCHW, int ST>
+template <int CT, int LA, int LB, bool NCHW, int ST, bool ADAM>
 __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
                                                           int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs) {
     int zsplit = blockIdx.z;
@@ -198,8 +198,9 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
                 stg[(32 * ii + (v & 3) + 8 * (v >> 2) + rh) * 64 + 32 * j + cj] = acc[ii][j][v];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // own writes only: a wave reads back what it wrote itself
     const int64_t nn = n0 + wc * 64 + (lane & 15) * 4;
-    if (epi.adam_m && !slab_base) {
-        // fused optimizer: the tile is a block of the parameter's gradient
+    if constexpr (ADAM) {
+        // fused optimizer (vs_gemm_adam; an instantiation of its own, so that profiles tell it from the plain GEMM): the tile is
+        // a block of the parameter's gradient
         const AdamCoef coef = vs_adam_coef(epi.adam_lr, epi.adam_beta1, epi.adam_beta2, epi.adam_eps, (double)(epi.adam_step[0] + 1 - epi.adam_skipped));
         for (int it = 0; it < 16; ++it) {
             const int r = it * 4 + (lane >> 4);

@@ -16,6 +16,8 @@ from collections import defaultdict
 GEMM = re.compile(r'gemm_kernel<1, (?:\(anonymous namespace\)::)?Dense<1, (\d)>, (?:\(anonymous namespace\)::)?Dense<1, (\d)>,')
 GEMM_BIG = re.compile(r'gemm_big_kernel<1, (\d), (\d),')          # 256x256 LDS-DMA ring tile
 GEMM_GLDS = re.compile(r'gemm_glds_kernel<(\d), (\d),')          # 128x128 LDS-DMA tile
+GEMM_MID = re.compile(r'gemm_mid_kernel<1, (\d), (\d), false, \d+, false>')      # 128x128 ring tile
+GEMM_ADAM = re.compile(r'gemm_mid_kernel<1, (\d), (\d), false, \d+, true>')      # the same with the Adam epilogue (vs_gemm_adam)
 FAMILIES = [
     (r'rollout_ws_kernel<\d+, true', 'vs_mlp_rollout_fwd<bf16>'),
     (r'rollout_ws_kernel<\d+, false', 'vs_mlp_rollout_bwd<bf16>'),
@@ -37,7 +39,10 @@ FAMILIES = [
 
 
 def family(name):
-    for pat in (GEMM, GEMM_BIG, GEMM_GLDS):
+    m = GEMM_ADAM.search(name)
+    if m:
+        return 'vs_gemm_adam<bf16,%s%s>' % ('RS'[int(m.group(1))], 'RS'[int(m.group(2))])
+    for pat in (GEMM, GEMM_BIG, GEMM_GLDS, GEMM_MID):
         m = pat.search(name)
         if m:
             return 'vs_gemm<bf16,%s%s>' % ('RS'[int(m.group(1))], 'RS'[int(m.group(2))])
