@@ -779,7 +779,9 @@ class ConvBlock(torch.autograd.Function):
                     continue
                 first = acc.get(id(prm))
                 if first is None:
-                    acc[id(prm)] = g
+                    # a second tensor on the same storage: autograd keeps the tensor it is handed only while nobody else references
+                    # it and CLONES it otherwise (one D2D copy per parameter and step: 63 x 5 us in the Moving-MNIST step)
+                    acc[id(prm)] = g.detach()
                 elif first.shape == g.shape and first.dtype == g.dtype:
                     into.append(first)
                     what.append(g)
@@ -847,6 +849,36 @@ class Activation(torch.autograd.Function):
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         return ops.act_bwd(dy, y, ctx.act, out_dtype=y.dtype), None
+
+
+class FramesMSE(torch.autograd.Function):
+    """F.mse_loss(frames, full[:, idx]) of a [B, G, D] stack of decoded frames against observed frames picked by a device-side
+    index vector: one pass forward, one backward (the same two kernels as FrameLosses), instead of slice / sub / pow / mean and
+    their five backward launches.  The conv families' two frame losses (train.py:85-86, 139)."""
+
+    @staticmethod
+    def forward(ctx, frames, full, idx):
+        B, G, D = frames.shape
+        sums = ops.frames_sse_fwd(frames, full, idx)
+        ctx.save_for_backward(frames, full, idx)
+        ctx.scale = 1.0 / (B * G * D)
+        return (sums[0] + sums[1]) * ctx.scale
+
+    @staticmethod
+    def backward(ctx, g):
+        frames, full, idx = ctx.saved_tensors
+        coef = (g.float() * (2.0 * ctx.scale)).reshape(1).expand(2).contiguous()
+        return ops.frames_sse_bwd(frames, full, idx, coef), None, None
+
+
+def frames_mse(frames, full, idx):
+    """mean((frames - full[:, idx])^2); frames [B, G, ...] or [B, ...] (G = 1), full [B, T, ...], idx int32 [G] on the device."""
+    B, T = full.shape[0], full.shape[1]
+    flat = full.reshape(B, T, -1)
+    if not flat.is_contiguous():
+        flat = flat.contiguous()
+    G = idx.numel()
+    return FramesMSE.apply(frames.reshape(B, G, -1).contiguous().float(), flat.float(), idx)
 
 
 # ------------------------------------------------------------------------------------------------ all training losses

@@ -540,7 +540,17 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
             reconstruction = sep_net.decoder(s_old[0], t_rand, skip=s_old[1])
         else:
             reconstruction = sep_net.decoder(s_old, t_rand)
-        ae_loss_value = F.mse_loss(supervision_data, reconstruction, reduction='mean')
+        fused_mse = os.environ.get('VARSEP_FUSED_FRAME_MSE', '1') == '1' and full_data.dtype == torch.float32
+        if fused_mse:
+            # both frame losses through the fused kernels (no supervision-frame copy, no slices of full_data)
+            from . import functional as VF
+            if isinstance(t_random, torch.Tensor):
+                ae_idx = (t_random.reshape(1) - offset).to(torch.int32)
+            else:
+                ae_idx = _frame_index(int(t_random) - offset, 0, 0, full_data.device, full_data.size(1) + 1)[:1]
+            ae_loss_value = VF.frames_mse(reconstruction, full_data, ae_idx)
+        else:
+            ae_loss_value = F.mse_loss(supervision_data, reconstruction, reduction='mean')
         spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
         forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_t_code=t_cond, init_s_code=s_old)
     else:
@@ -548,7 +558,12 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
         spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
         forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_s_code=s_old)
     forecast_offset = nt_cond if offset == 0 else 0
-    forecast_loss = F.mse_loss(forecasts, full_data[:, forecast_offset:])
+    if pairs and fused_mse:
+        n_f = forecasts.shape[1]
+        f_idx = _frame_index(0, forecast_offset, n_f, full_data.device, full_data.size(1) + 1)[1:]
+        forecast_loss = VF.frames_mse(forecasts, full_data, f_idx)
+    else:
+        forecast_loss = F.mse_loss(forecasts, full_data[:, forecast_offset:])
     if average_tloss:
         t_reg = 0.5 * (t_codes[:, 0].pow(2).view(full_data.shape[0], -1)).mean()
     else:
