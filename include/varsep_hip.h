@@ -366,6 +366,13 @@ int vs_conv2d_dgrad(int compute, const void* dy, const void* w_packed, void* dx,
                     int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
 int vs_conv2d_wgrad(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh, int kw,
                     int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
+/* The weight gradients with an `accumulate` flag: dw += (non-zero) instead of dw =.  A module applied many times per step
+ * (ConvResBlock inside the rollout loop of model.py:78-83: one call per predicted frame) adds each call's contribution in the
+ * GEMM / split-K epilogue instead of a separate add launch per call and parameter.                                          */
+int vs_conv2d_wgrad_acc(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                        int stride, int pad, void* workspace, size_t workspace_bytes, int accumulate, void* stream);
+int vs_conv_transpose2d_wgrad_acc(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh,
+                                  int kw, int stride, int pad, void* workspace, size_t workspace_bytes, int accumulate, void* stream);
 int vs_conv_transpose2d_fwd(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H,
                             int W, int Cout, int kh, int kw, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
 int vs_conv_transpose2d_dgrad(int compute, const void* dy, const void* w, void* dx, int dx_dtype, int B, int Cin, int H, int W, int Cout,
@@ -402,6 +409,15 @@ int vs_maxpool3s2_bwd(const void* x, int x_dtype, const void* dy, int dy_dtype, 
  */
 int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW, int groups, float* mean, float* invstd, float* var_scratch,
                 float* running_mean, float* running_var, float momentum, float eps, void* stream);
+/* Training-mode BatchNorm2d + activation of ONE reference call on a small tensor (slabs B*HW <= 8192 per channel: the SST
+ * integrator's 8 x 16 x 16 maps, conv.py:41-60 blocks inside resnet.py:53-88) in one launch: statistics, running-statistics update
+ * (momentum, unbiased variance; NULL = not tracked), y = act(gamma * x_hat + beta); mean / invstd [C] are kept for vs_bn_act_bwd.
+ * vs_bn_train_fwd_small_supported tells whether a tensor is served (else: vs_bn_stats + vs_bn_act_fwd, same results up to summation
+ * order).  vs_bn_act_bwd takes the matching one-launch path by itself.                                                      */
+int vs_bn_train_fwd_small_supported(int x_dtype, int B, int C, int64_t HW);
+int vs_bn_train_fwd_small(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int act, float* mean,
+                          float* invstd, float* running_mean, float* running_var, float momentum, float eps, int B, int C, int64_t HW,
+                          void* stream);
 int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream);
 int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd, const float* gamma,

@@ -132,6 +132,10 @@ SIGNATURES = {
     'vs_conv2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _vp]),
     'vs_conv2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _vp]),
     'vs_conv2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
+    'vs_bn_train_fwd_small_supported': (_i32, [_i32, _i32, _i32, _i64]),
+    'vs_bn_train_fwd_small': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32, _i32, _i64, _vp]),
+    'vs_conv2d_wgrad_acc': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _i32, _vp]),
+    'vs_conv_transpose2d_wgrad_acc': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _i32, _vp]),
     'vs_conv_transpose2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _vp]),
     'vs_conv_transpose2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _i32, _vp]),
     'vs_conv_transpose2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),

@@ -842,7 +842,7 @@ inline bool wgrad_uses_cols(int64_t M, int64_t N, int64_t K, const void* ws, siz
 // grid, G has Cg channels of size (GH,GW)
 template <int CT>
 int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH, int PW, int Cg, int GH, int GW, int kh, int kw, int s, int p,
-               void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
+               void* ws, size_t ws_bytes, hipStream_t st, const char* what, int accumulate = 0) {
     typedef typename CTraits<CT>::T T;
     const int64_t M = Cr, N = (int64_t)Cg * kh * kw, K = (int64_t)B * PH * PW;
     const int64_t hw = (int64_t)PH * PW;
@@ -859,9 +859,13 @@ int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH
         if (rc != VS_OK) return rc;
         const int64_t ld = cols_pitch<CT>(K);
         Dense<CT, LR> bd{(const T*)ws, ld, N, K, 1};               // element (q, k = pixel) at cols[q * ld + k]
-        return run<CT>(a, bd, M, N, K, rowmajor_epi(dw, N), (char*)ws + cols_bytes, ws_bytes - cols_bytes, st, what);
+        Epi e = rowmajor_epi(dw, N);
+        e.accumulate = accumulate;
+        return run<CT>(a, bd, M, N, K, e, (char*)ws + cols_bytes, ws_bytes - cols_bytes, st, what);
     }
-    return run<CT>(a, b, M, N, K, rowmajor_epi(dw, N), ws, ws_bytes, st, what);
+    Epi e = rowmajor_epi(dw, N);
+    e.accumulate = accumulate;
+    return run<CT>(a, b, M, N, K, e, ws, ws_bytes, st, what);
 }
 
 // ---- weight pre-pack for the transposed form ---------------------------------------------------------------------------
@@ -987,6 +991,28 @@ extern "C" int vs_conv2d_wgrad(int compute, const void* dy, const void* x, float
     const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
     return VS_DISPATCH(compute, wgrad_form, dy, x, dw, B, Cout, OH, OW, Cin, H, W, kh, kw, stride, pad, workspace, workspace_bytes,
                        (hipStream_t)stream, "vs_conv2d_wgrad");
+}
+
+// dw += ... instead of dw = ...: a module applied many times per step (the SST integrator's convolutions: 39 calls) adds each call's
+// weight gradient straight into the accumulated one (GEMM / split-K reduce epilogue) instead of storing it and adding it with a
+// second launch
+extern "C" int vs_conv2d_wgrad_acc(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout, int kh,
+                                   int kw, int stride, int pad, void* workspace, size_t workspace_bytes, int accumulate, void* stream) {
+    int rc = check_conv("vs_conv2d_wgrad_acc", compute, dy, x, dw, B, Cin, H, W, Cout, kh, kw, stride, pad);
+    if (rc) return rc;
+    const int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
+    return VS_DISPATCH(compute, wgrad_form, dy, x, dw, B, Cout, OH, OW, Cin, H, W, kh, kw, stride, pad, workspace, workspace_bytes,
+                       (hipStream_t)stream, "vs_conv2d_wgrad_acc", accumulate ? 1 : 0);
+}
+
+extern "C" int vs_conv_transpose2d_wgrad_acc(int compute, const void* dy, const void* x, float* dw, int B, int Cin, int H, int W, int Cout,
+                                             int kh, int kw, int stride, int pad, void* workspace, size_t workspace_bytes, int accumulate,
+                                             void* stream) {
+    int rc = check_conv("vs_conv_transpose2d_wgrad_acc", compute, dy, x, dw, B, Cin, H, W, Cout, kh, kw, stride, pad);
+    if (rc) return rc;
+    const int OH = (H - 1) * stride - 2 * pad + kh, OW = (W - 1) * stride - 2 * pad + kw;
+    return VS_DISPATCH(compute, wgrad_form, x, dy, dw, B, Cin, H, W, Cout, OH, OW, kh, kw, stride, pad, workspace, workspace_bytes,
+                       (hipStream_t)stream, "vs_conv_transpose2d_wgrad_acc", accumulate ? 1 : 0);
 }
 
 extern "C" int vs_conv_transpose2d_fwd(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B,

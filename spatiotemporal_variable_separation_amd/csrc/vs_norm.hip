@@ -9,6 +9,7 @@
 // extent of a channel is streamed with coalesced reads, reduced in registers -> LDS, no atomics -> reproducible);
 // element-wise passes are grid-stride with the channel recovered from the flat NCHW index.
 #include "vs_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -394,6 +395,126 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int d
     }
 }
 
+// Small slabs (one (call group, channel) slab of <= 8192 elements: the SST integrator's 8 x 16 x 16 maps, 276 BatchNorm calls per
+// step): reduce AND apply in one launch.  A 256-thread workgroup owns the slab, keeps dz and x-hat of its <= 32 elements per thread in
+// registers between the two phases (same-dtype 16-byte vector path only), so dy and x are read once and the second launch
+// (8-9 us each at these sizes, pure launch latency) disappears.
+template <int NV>                    // 16-byte vectors per thread
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(const void* dy, const void* x, int xd, const float* mean, const float* invstd,
+                                                          const float* gamma, const float* beta, int act, float* sum_dz, float* sum_dz_xhat,
+                                                          void* dx, int dxd, int Bg, int C, int HW, int training) {
+    __shared__ double red[16];
+    const int c = blockIdx.x, grp = blockIdx.y;
+    const int w = xd == VS_F32 ? 4 : 8;
+    const int per = HW / w, nvec = Bg * per;
+    const int64_t b0 = (int64_t)grp * Bg;
+    const float mu = mean[grp * C + c], is = invstd[grp * C + c], g = gamma[c], bt = beta[c];
+    float dzv[NV][8], xhv[NV][8];
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int i = threadIdx.x + r * 256;
+        if (i < nvec) {
+            const int b = i / per, p = (i - b * per) * w;
+            const int64_t idx = ((b0 + b) * C + c) * (int64_t)HW + p;
+            float xv[8], gv[8];
+            const int cnt = ld_vec(x, xd, idx, xv);
+            ld_vec(dy, xd, idx, gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < cnt) {
+                    const float xh = (xv[j] - mu) * is;
+                    const float dz = gv[j] * act_grad_from_pre(xh * g + bt, act);
+                    xhv[r][j] = xh; dzv[r][j] = dz;
+                    a1 += dz; a2 += dz * xh;
+                }
+            }
+        }
+    }
+    const double t1 = block_sum((double)a1, red);
+    const double t2 = block_sum((double)a2, red);
+    if (threadIdx.x == 0) { sum_dz[grp * C + c] = (float)t1; sum_dz_xhat[grp * C + c] = (float)t2; }
+    const float inv_n = 1.f / (float)((int64_t)Bg * HW);
+    const float k1 = (float)t1 * inv_n, k2 = (float)t2 * inv_n;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int i = threadIdx.x + r * 256;
+        if (i < nvec) {
+            const int b = i / per, p = (i - b * per) * w;
+            const int64_t idx = ((b0 + b) * C + c) * (int64_t)HW + p;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = training ? g * is * (dzv[r][j] - k1 - xhv[r][j] * k2) : g * is * dzv[r][j];
+            st_vec(dx, dxd, idx, o, w);
+        }
+    }
+}
+
+// The forward counterpart for ONE call group: batch statistics, running-statistics update, affine + activation in one launch
+// (vs_bn_stats is two launches -- statistics, running update -- and vs_bn_act_fwd a third).  Two-pass variance from registers.
+template <int NV>
+__global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd, void* y, int yd, const float* gamma, const float* beta, int act,
+                                                          float* mean, float* invstd, float* rmean, float* rvar, float momentum, float eps, int B,
+                                                          int C, int HW) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    const int w = xd == VS_F32 ? 4 : 8;
+    const int per = HW / w, nvec = B * per;
+    const int64_t n = (int64_t)B * HW;
+    float xv[NV][8];
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int i = threadIdx.x + r * 256;
+        if (i < nvec) {
+            const int b = i / per, p = (i - b * per) * w;
+            const int cnt = ld_vec(x, xd, ((int64_t)b * C + c) * (int64_t)HW + p, xv[r]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < cnt) a += xv[r][j];
+        }
+    }
+    const double mu_d = block_sum((double)a, red) / (double)n;
+    const float mu = (float)mu_d;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int i = threadIdx.x + r * 256;
+        if (i < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < w) { const float d = xv[r][j] - mu; q += d * d; }
+        }
+    }
+    double ss = block_sum((double)q, red);
+    // (sum (x - fl(mu))^2 = sum (x - mu)^2 + n (mu - fl(mu))^2: remove the rounding of the mean)
+    ss -= (double)n * (mu_d - (double)mu) * (mu_d - (double)mu);
+    if (ss < 0.0) ss = 0.0;
+    const double var = ss / (double)n;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        mean[c] = mu;
+        invstd[c] = is;
+        if (rmean) {
+            const double ub = n > 1 ? ss / (double)(n - 1) : var;
+            rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * (double)mu);
+            rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * (double)(float)ub);
+        }
+    }
+    const float g = gamma[c], bt = beta[c];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int i = threadIdx.x + r * 256;
+        if (i < nvec) {
+            const int b = i / per, p = (i - b * per) * w;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = vs_act((xv[r][j] - mu) * is * g + bt, act);
+            st_vec(y, yd, ((int64_t)b * C + c) * (int64_t)HW + p, o, w);
+        }
+    }
+}
+
 // per-channel sum; blockIdx.y splits the (batch x pixel) extent so that few-channel tensors (the 1-channel frames of the
 // last decoder layer) still fill the chip; partial sums meet in one float atomic per workgroup
 __global__ __launch_bounds__(256) void chan_sum_kernel(const void* x, int xd, int B, int C, int64_t HW, float* out) {
@@ -548,6 +669,36 @@ extern "C" int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW,
     return VS_OK;
 }
 
+// 1 when vs_bn_train_fwd_small serves the tensor: one call group, slabs of <= 8192 elements, 16-byte vectors
+extern "C" int vs_bn_train_fwd_small_supported(int x_dtype, int B, int C, int64_t HW) {
+    static const int small_mode = getenv("VS_BN_SMALL") ? atoi(getenv("VS_BN_SMALL")) : 1;
+    const int w = x_dtype == VS_F32 ? 4 : 8;
+    return small_mode && vs_dtype_ok(x_dtype) && B > 0 && C >= 32 && HW > 0 && HW % 8 == 0 && (int64_t)B * HW <= 8192 && HW % w == 0;
+}
+
+// Training-mode BatchNorm2d forward of ONE reference call on a small tensor in one launch: mean / invstd [C] (kept for backward),
+// running statistics updated in place (NULL: not tracked), y = act(gamma * x_hat + beta).  Same results as vs_bn_stats +
+// vs_bn_act_fwd up to summation order.
+extern "C" int vs_bn_train_fwd_small(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int act, float* mean,
+                                     float* invstd, float* running_mean, float* running_var, float momentum, float eps, int B, int C, int64_t HW,
+                                     void* stream) {
+    VS_CHECK_ARG(x && y && gamma && beta && mean && invstd && vs_dtype_ok(y_dtype), "vs_bn_train_fwd_small: bad argument");
+    VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "vs_bn_train_fwd_small: running_mean/var must come together");
+    if (!vs_bn_train_fwd_small_supported(x_dtype, B, C, HW) || ((uintptr_t)x | (uintptr_t)y) % 16 != 0)
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_bn_train_fwd_small: tensor not served (use vs_bn_stats + vs_bn_act_fwd)");
+    const int64_t nvec = (int64_t)B * HW / (x_dtype == VS_F32 ? 4 : 8);
+#define VS_BN_SMALL(NV)                                                                                                                 \
+    hipLaunchKernelGGL(bn_fwd_small_kernel<NV>, dim3(C), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, gamma, beta, act, mean, invstd, \
+                       running_mean, running_var, momentum, eps, B, C, (int)HW)
+    if (nvec <= 256) VS_BN_SMALL(1);
+    else if (nvec <= 512) VS_BN_SMALL(2);
+    else if (nvec <= 1024) VS_BN_SMALL(4);
+    else VS_BN_SMALL(8);
+#undef VS_BN_SMALL
+    VS_CHECK_LAUNCH("vs_bn_train_fwd_small");
+    return VS_OK;
+}
+
 extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream) {
     VS_CHECK_ARG(x && y && mean && invstd && gamma && beta && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_act_fwd: bad argument");
@@ -572,6 +723,27 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
     if ((!vec || x_dtype != dy_dtype) && HW >= 8 && (int64_t)B * C * HW < ((int64_t)1 << 31) && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0)
         vec = 2;                                                         // ragged planes and / or mixed dtypes: unit-per-plane path
     (void)w_;
+    {
+        // one launch for small slabs (see bn_bwd_small_kernel); enough workgroups to be worth it
+        static const int small_mode = getenv("VS_BN_SMALL") ? atoi(getenv("VS_BN_SMALL")) : 1;
+        const int64_t nslab = (int64_t)(B / groups) * HW;
+        const int wv = x_dtype == VS_F32 ? 4 : 8;
+        if (small_mode && vec == 1 && x_dtype == dy_dtype && nslab <= 8192 && HW < (1 << 20) &&
+            ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0 && (int64_t)C * groups >= 32) {
+            const int64_t nvec = nslab / wv;
+            const dim3 grid(C, groups);
+#define VS_BN_SMALL(NV)                                                                                                              \
+            hipLaunchKernelGGL(bn_bwd_small_kernel<NV>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, x_dtype, mean, invstd, gamma, beta, act,  \
+                               dbeta, dgamma, dx, dx_dtype, B / groups, C, (int)HW, training)
+            if (nvec <= 256) VS_BN_SMALL(1);
+            else if (nvec <= 512) VS_BN_SMALL(2);
+            else if (nvec <= 1024) VS_BN_SMALL(4);
+            else VS_BN_SMALL(8);
+#undef VS_BN_SMALL
+            VS_CHECK_LAUNCH("vs_bn_act_bwd (small slabs)");
+            return VS_OK;
+        }
+    }
     const unsigned nt_ = ((int64_t)C * groups <= 1024 && (int64_t)(B / groups) * HW >= 8192) ? 1024u : 256u;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, groups), dim3(nt_), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd, gamma,
                        beta, act, B / groups, C, HW, dbeta, dgamma, vec);

@@ -69,7 +69,9 @@ def count_bn_calls(bn, calls):
     """`num_batches_tracked += calls` of a training-mode BatchNorm (one per reference call).  While gradients are folded (the
     training loop owns the step and calls `flush_bn_call_counts()` at its end) the increments are collected and applied by ONE
     multi-tensor launch per step instead of one launch per BatchNorm call (SST: ~300 per step)."""
-    if not _STATE.get('fold_grads') or torch.cuda.is_current_stream_capturing():      # a recording must contain the increment
+    # a recording must contain the increment: either right here, or -- when the recorder has promised to call
+    # flush_bn_call_counts() inside the capture (train.GraphedStep) -- in that one multi-tensor launch
+    if not _STATE.get('fold_grads') or (torch.cuda.is_current_stream_capturing() and not _STATE.get('bn_counts_flushed_in_capture')):
         bn.num_batches_tracked += calls
         return
     ent = _BN_COUNTS.get(id(bn))
@@ -77,6 +79,11 @@ def count_bn_calls(bn, calls):
         _BN_COUNTS[id(bn)] = [bn.num_batches_tracked, calls]
     else:
         ent[1] += calls
+
+
+def bn_counts_flushed_in_capture(flag):
+    """The caller records `flush_bn_call_counts()` into its capture: per-call counter increments may be collected during it."""
+    _STATE['bn_counts_flushed_in_capture'] = bool(flag)
 
 
 def flush_bn_call_counts():
@@ -707,12 +714,16 @@ class ConvBlock(torch.autograd.Function):
             wc = shadow(w, cdt)
             wp = packed_conv_weight(w, cdt, stride, pad) if transposed else None
             z = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, cdt, w_packed=wp)
-            if training:
-                mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
+            if training and groups == 1 and ops.bn_small_supported(z):
+                # small maps (the SST integrator: 8 x 16 x 16 per channel): statistics, running update, affine + activation in one launch
+                y, mean, invstd = ops.bn_train_fwd_small(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps)
             else:
-                mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
-                invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
-            y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
+                if training:
+                    mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
+                else:
+                    mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
+                    invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
+                y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
             ctx.save_for_backward(xc, z, mean, invstd)
         else:
             if k3:
@@ -750,7 +761,15 @@ class ConvBlock(torch.autograd.Function):
                 db = None if (_STATE.get('fold_grads') and id(b) in _fold_slots()) else torch.zeros_like(b)
             else:
                 db = ops.chan_sum(dz)
-        dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed) if w.requires_grad else None
+        dw = None
+        if w.requires_grad:
+            # a weight that already holds a gradient from an earlier call of this pass (the integrator's blocks: one call per predicted
+            # frame) gets this call's contribution ADDED in the weight-gradient GEMM's epilogue -- no temporary, no add launch
+            first_w = _fold_slots().get(id(w)) if _STATE.get('fold_grads') else None
+            if first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
+                ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed, into=first_w)
+            else:
+                dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed)
         dx = None
         if ctx.x_needs_grad:
             # the input gradient of Conv2d k4 s2 p1 IS a ConvTranspose2d k4 s2 p1 of dz with the same weight tensor ([Cout, Cin, 4, 4]
@@ -765,7 +784,7 @@ class ConvBlock(torch.autograd.Function):
             else:
                 wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
                 dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
-                                    cols_from_wgrad=transposed and dw is not None)
+                                    cols_from_wgrad=transposed and bool(w.requires_grad))
         if _STATE.get('fold_grads'):
             # the FIRST contribution of a parameter in this backward pass goes to autograd (which keeps that very tensor as the
             # parameter's pending gradient); later contributions of the pass are added INTO it with one multi-tensor launch per

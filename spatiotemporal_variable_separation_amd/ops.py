@@ -482,24 +482,28 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     return dx
 
 
-def conv_wgrad(dy, x, w_shape, stride, pad, transposed):
+def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None):
+    """Weight gradient of a (transposed) convolution; `into`: an fp32 tensor of the weight's shape that the result is ADDED to
+    (in the GEMM / split-K epilogue) instead of a fresh tensor."""
     require_cuda(dy, x)
     assert dy.is_contiguous() and x.is_contiguous() and dy.dtype == x.dtype
     B, Cin, H, W = x.shape
     k = w_shape[2]
     Cout = w_shape[1] if transposed else w_shape[0]
     OH, OW = dy.shape[2], dy.shape[3]
-    dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    if into is not None:
+        assert into.dtype == torch.float32 and into.is_contiguous() and tuple(into.shape) == tuple(w_shape)
+    dw = into if into is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
     lib = _lib.load_library()
     pix_h, pix_w = (H, W) if transposed else (OH, OW)
     ws = _conv_workspace(dtype_code(x), B, Cin, H, W, Cout, k, stride, pad, x.device)
     if ws is None:
         ws_bytes = lib.vs_conv_wgrad_workspace_bytes(B, Cin, pix_h, pix_w, Cout, k, k)
         ws = _workspace(ws_bytes, x.device) if ws_bytes else None
-    fn = lib.vs_conv_transpose2d_wgrad if transposed else lib.vs_conv2d_wgrad
+    fn = lib.vs_conv_transpose2d_wgrad_acc if transposed else lib.vs_conv2d_wgrad_acc
     e0 = _pb()
     check(fn(dtype_code(x), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, k, k, stride, pad, _ptr(ws),
-             ws.numel() if ws is not None else 0, stream_ptr()), 'vs_conv_wgrad')
+             ws.numel() if ws is not None else 0, 1 if into is not None else 0, stream_ptr()), 'vs_conv_wgrad')
     _pe(e0, 'vs_conv%s_wgrad<%s>' % ('T' if transposed else '', _DT[dtype_code(x)]),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
         nbytes=float(dy.numel() * dy.element_size() + x.numel() * x.element_size() + dw.numel() * 4))
@@ -615,6 +619,27 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gro
                                           stream_ptr()), 'vs_bn_stats')
     _pe(e0, 'vs_bn_stats', nbytes=float(x.numel() * x.element_size()))
     return mean, invstd
+
+
+def bn_small_supported(x):
+    B, C = x.shape[0], x.shape[1]
+    return x.is_contiguous() and bool(_lib.load_library().vs_bn_train_fwd_small_supported(dtype_code(x), B, C, x.numel() // (B * C)))
+
+
+def bn_train_fwd_small(x, gamma, beta, act, out_dtype, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """Training-mode BatchNorm + activation of one call in ONE launch (small tensors).  Returns (y, mean [1, C], invstd [1, C])."""
+    require_cuda(x)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty((1, C), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((1, C), dtype=torch.float32, device=x.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_bn_train_fwd_small(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), gamma.data_ptr(), beta.data_ptr(),
+                                                    ACT[act], mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                                    float(momentum), float(eps), B, C, HW, stream_ptr()), 'vs_bn_train_fwd_small')
+    _pe(e0, 'vs_bn_act_fwd', nbytes=float(x.numel() * (x.element_size() + y.element_size())))
+    return y, mean, invstd
 
 
 def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype, groups=1):

@@ -251,9 +251,15 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
         if grad_sync is None:
-            with torch.cuda.graph(self.graph):
-                self.loss = self._fwd_bwd()
-                self._opt_step()
+            from . import functional as VF
+            VF.bn_counts_flushed_in_capture(True)        # SST: ~200 per-call `num_batches_tracked += 1` launches become one
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.loss = self._fwd_bwd()
+                    self._opt_step()
+                    VF.flush_bn_call_counts()
+            finally:
+                VF.bn_counts_flushed_in_capture(False)
         else:
             # data parallel: losses + backward into the reducer's flat gradient buckets in one graph, the bucket
             # all-reduces issued eagerly in between (4 RCCL calls at WaveEq size; no collective inside a capture), Adam in
