@@ -527,7 +527,8 @@ inline int64_t cols_pitch(int64_t npix) { return (npix + CTraits<CT>::U - 1) / C
 // when the column matrix pays: enough output channels that the contraction dominates the extra HBM pass
 inline bool cols_worthwhile(int64_t M, int64_t npix, int64_t nq) {
     if (getenv("VS_CONV_COLS_FORCE")) return M > 4 && nq <= 65535;      // test aid: the column-matrix form at any size
-    return M >= 64 && npix * nq >= (1 << 20) && nq <= 65535;
+    static const int64_t min_work = getenv("VS_CONV_COLS_MIN") ? atoll(getenv("VS_CONV_COLS_MIN")) : ((int64_t)1 << 20);
+    return M >= 64 && npix * nq >= min_work && nq <= 65535;
 }
 
 template <int CT>

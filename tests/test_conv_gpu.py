@@ -317,3 +317,73 @@ def test_conv_k3_tap_kernel_forward_and_input_gradient(dtype, geom):
         wtf = ops.conv_k3_tap_pack_weight(w.float().cuda(), dtype, True)
         dx, _ = ops.conv_k3_tap_fwd(dz.cuda(), wtf, None, Cin, torch.float32)
         assert ((dx.cpu().double() - x64.grad).norm() / x64.grad.norm()).item() < 1e-5, f'dgrad {geom} {dtype}'
+
+
+@pytest.mark.parametrize('act', ['leaky_relu', 'relu'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(8, 64, 16, 16), (3, 40, 8, 8), (8, 32, 32, 32), (2, 512, 4, 4), (5, 33, 8, 24)])
+def test_batchnorm_small_slab_one_launch_paths(act, dtype, shape):
+    """vs_bn_train_fwd_small (statistics + running update + affine + activation in ONE launch) and the one-launch backward that
+    vs_bn_act_bwd takes for slabs of <= 8192 elements per channel (the SST integrator's maps), against torch's BatchNorm2d in
+    fp64 on the same (rounded) inputs: outputs, running statistics after 1 and 16 sequential calls, all three gradients; and
+    against the two-/three-launch kernels they replace."""
+    import os
+    from spatiotemporal_variable_separation_amd import ops
+    B, C, H, W = shape
+    x = (_rand(shape, 21) * 2 + 0.3).to(dtype)
+    gamma, beta = 1 + _rand((C,), 22, 0.3), _rand((C,), 23, 0.2)
+    dy = _rand(shape, 24).to(dtype)
+    rm, rv = _rand((C,), 25, 0.1), 1 + _rand((C,), 26, 0.2)
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    acts = {'leaky_relu': lambda t: F.leaky_relu(t, 0.2), 'relu': torch.relu}
+    x64 = x.double().requires_grad_(True)
+    y64 = acts[act](bn(x64))
+    y64.backward(dy.double())
+    xc, dyc = x.cuda(), dy.cuda()
+    assert ops.bn_small_supported(xc), shape
+    rmc, rvc = rm.clone().cuda(), rv.clone().cuda()
+    y, mean, invstd = ops.bn_train_fwd_small(xc, gamma.cuda(), beta.cuda(), act, torch.float32, rmc, rvc, 0.1, 1e-5)
+    dx, dg, db = ops.bn_act_bwd(dyc, xc, mean, invstd, gamma.cuda(), beta.cuda(), act, True, torch.float32)
+
+    def rel(a, b):
+        return ((a.cpu().double() - b.cpu().double()).norm() / (b.cpu().double().norm() + 1e-30)).item()
+    assert rel(y, y64.detach()) < 2e-6
+    assert rel(rmc, bn.running_mean) < 2e-6 and rel(rvc, bn.running_var) < 2e-6
+    assert rel(dx, x64.grad) < 2e-5
+    assert rel(dg, bn.weight.grad) < 2e-5 and rel(db, bn.bias.grad) < 2e-5
+    # the kernels they replace (same results up to summation order); 16-bit outputs too
+    rm2, rv2 = rm.clone().cuda(), rv.clone().cuda()
+    m2, i2 = ops.bn_stats(xc, rm2, rv2, 0.1, 1e-5)
+    assert rel(mean, m2) < 1e-6 and rel(invstd, i2) < 1e-6 and rel(rmc, rm2) < 1e-6 and rel(rvc, rv2) < 1e-6
+    if dtype != torch.float32:
+        y16 = ops.bn_train_fwd_small(xc, gamma.cuda(), beta.cuda(), act, dtype, None, None, 0.1, 1e-5)[0]
+        assert rel(y16, y64.detach()) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+        dx16 = ops.bn_act_bwd(dyc, xc, mean, invstd, gamma.cuda(), beta.cuda(), act, True, dtype)[0]
+        assert rel(dx16, x64.grad) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+    for _ in range(15):
+        bn(x64.detach())
+        ops.bn_train_fwd_small(xc, gamma.cuda(), beta.cuda(), act, torch.float32, rmc, rvc, 0.1, 1e-5)
+    assert rel(rmc, bn.running_mean) < 1e-5 and rel(rvc, bn.running_var) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('transposed,geom', [(False, (8, 64, 16, 512, 3, 1, 1)), (False, (4, 24, 16, 40, 4, 2, 1)), (True, (6, 32, 8, 16, 4, 2, 1))])
+def test_conv_wgrad_accumulates_into_an_existing_gradient(dtype, transposed, geom):
+    """ops.conv_wgrad(..., into=g): g += dW in the GEMM / split-K epilogue == g + conv_wgrad(...) (the integrator's blocks add one
+    contribution per predicted frame)."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, Cin, H, Cout, k, stride, pad = geom
+    x = _rand((B, Cin, H, H), 31).to(dtype).cuda()
+    OH = (H - 1) * stride - 2 * pad + k if transposed else (H + 2 * pad - k) // stride + 1
+    dy = _rand((B, Cout, OH, OH), 32).to(dtype).cuda()
+    w_shape = (Cin, Cout, k, k) if transposed else (Cout, Cin, k, k)
+    base = _rand(w_shape, 33).cuda()
+    fresh = ops.conv_wgrad(dy, x, w_shape, stride, pad, transposed)
+    acc = base.clone()
+    ops.conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=acc)
+    ops.conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=acc)
+    torch.cuda.synchronize()
+    ref = base.double() + 2 * fresh.double()
+    assert ((acc.double() - ref).norm() / ref.norm()).item() < 1e-6
