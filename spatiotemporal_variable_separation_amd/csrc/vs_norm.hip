@@ -115,6 +115,122 @@ __device__ __forceinline__ void st_unit(void* y, int yd, int64_t idx, const floa
 }
 __device__ __forceinline__ int unit_width(int d0, int d1, int d2) { return (d0 == VS_F32 || d1 == VS_F32 || d2 == VS_F32) ? 4 : 8; }
 
+// ---- hot loops of the 16-byte vector paths, element count per vector as a template constant --------------------------------------
+template <int W>
+__device__ __forceinline__ void ld_vecw(const void* x, int xd, int64_t idx, float (&v)[W]) {
+    if constexpr (W == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>((const float*)x + idx);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+        const u16x8 t = *reinterpret_cast<const u16x8*>((const unsigned short*)x + idx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = vs_h2f(t[j], xd);
+    }
+}
+template <int W>
+__device__ __forceinline__ void st_vecw(void* y, int yd, int64_t idx, const float (&v)[W]) {
+    if (yd == VS_F32) {
+#pragma unroll
+        for (int o = 0; o < W; o += 4) {
+            f32x4 t = {v[o], v[o + 1], v[o + 2], v[o + 3]};
+            *reinterpret_cast<f32x4*>((float*)y + idx + o) = t;
+        }
+    } else if constexpr (W == 8) {
+        u16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = vs_f2h(v[j], yd);
+        *reinterpret_cast<u16x8*>((unsigned short*)y + idx) = t;
+    } else {
+        const u16x4 t = {vs_f2h(v[0], yd), vs_f2h(v[1], yd), vs_f2h(v[2], yd), vs_f2h(v[3], yd)};
+        *reinterpret_cast<u16x4*>((unsigned short*)y + idx) = t;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void bn_fwd_vec_loop(const void* x, int xd, void* y, int yd, const float* mean, const float* invstd, const float* gamma,
+                                                const float* beta, int act, int C, int64_t HW, int64_t nv, int64_t group_elems, bool small) {
+    for (int64_t iv0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; iv0 < nv; iv0 += (int64_t)gridDim.x * 1024) {
+        float v[4][W];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (iv0 + k * 256 < nv) ld_vecw<W>(x, xd, (iv0 + k * 256) * W, v[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = (iv0 + k * 256) * W;
+            if (iv0 + k * 256 < nv) {
+                int c, gc;
+                chan_of(i, HW, C, group_elems, small, c, gc);
+                const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
+#pragma unroll
+                for (int j = 0; j < W; ++j) v[k][j] = vs_act((v[k][j] - mu) * is * g + bt, act);
+                st_vecw<W>(y, yd, i, v[k]);
+            }
+        }
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void bn_bwd_apply_vec_loop(const void* dy, const void* x, int xd, const float* mean, const float* invstd, const float* gamma,
+                                                      const float* beta, int act, const float* sum_dz, const float* sum_dz_xhat, void* dx, int dxd,
+                                                      int C, int64_t HW, int64_t nv, int64_t group_elems, bool small, float inv_n, int training) {
+    for (int64_t iv0 = (int64_t)blockIdx.x * 512 + threadIdx.x; iv0 < nv; iv0 += (int64_t)gridDim.x * 512) {
+        float xv[2][W], gv[2][W];                                    // two vectors of each tensor in flight per thread
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (iv0 + k * 256 < nv) { ld_vecw<W>(x, xd, (iv0 + k * 256) * W, xv[k]); ld_vecw<W>(dy, xd, (iv0 + k * 256) * W, gv[k]); }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t i = (iv0 + k * 256) * W;
+            if (iv0 + k * 256 < nv) {
+                int c, gc;
+                chan_of(i, HW, C, group_elems, small, c, gc);
+                const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
+                const float k1 = sum_dz[gc] * inv_n, k2 = sum_dz_xhat[gc] * inv_n;
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const float xh = (xv[k][j] - mu) * is;
+                    const float dz = gv[k][j] * act_grad_from_pre(xh * g + bt, act);
+                    xv[k][j] = training ? g * is * (dz - k1 - xh * k2) : g * is * dz;
+                }
+                st_vecw<W>(dx, dxd, i, xv[k]);
+            }
+        }
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void bn_bwd_reduce_vec_loop(const void* dy, const void* x, int xd, float mu, float is, float g, float bt, int act, int64_t b0,
+                                                       int c, int C, int64_t HW, uint32_t per32, uint32_t nvec, double& s1, double& s2) {
+    for (uint32_t i0 = threadIdx.x; i0 < nvec; i0 += 2 * blockDim.x) {
+        float xv[2][W], gv[2][W];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t i = i0 + k * blockDim.x;
+            if (i < nvec) {
+                const uint32_t b = i / per32, p = (i - b * per32) * W;
+                const int64_t idx = ((b0 + b) * C + c) * HW + p;
+                ld_vecw<W>(x, xd, idx, xv[k]);
+                ld_vecw<W>(dy, xd, idx, gv[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (i0 + k * blockDim.x < nvec) {
+                float a1 = 0.f, a2 = 0.f;                            // fp32 over the elements of a vector, fp64 across vectors
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    const float xh = (xv[k][j] - mu) * is;
+                    const float dz = gv[k][j] * act_grad_from_pre(xh * g + bt, act);
+                    a1 += dz;
+                    a2 += dz * xh;
+                }
+                s1 += (double)a1;
+                s2 += (double)a2;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void bn_stats_kernel(const void* x, int xd, int Bg, int C, int64_t HW, float* mean, float* invstd,
                                                        float* ubvar, float eps, int vec) {
     __shared__ double red[16];
@@ -207,18 +323,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, 
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t nv = total / w;
         const bool small = total < (int64_t)1 << 31;
-        for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += (int64_t)gridDim.x * 256) {
-            const int64_t i = iv * w;
-            int c, gc;
-            chan_of(i, HW, C, group_elems, small, c, gc);
-            const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
-            float v[8];
-            const int cnt = ld_vec(x, xd, i, v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < cnt) v[j] = vs_act((v[j] - mu) * is * g + bt, act);
-            st_vec(y, yd, i, v, cnt);
-        }
+        // four 16-byte vectors in flight per thread before any of the per-vector index arithmetic (two divisions, four table
+        // look-ups): with one vector per iteration the pass ran at 2.3-3.5 TB/s.  (W is a template constant: with a run-time element
+        // count the register arrays go to scratch.)
+        if (xd == VS_F32) bn_fwd_vec_loop<4>(x, xd, y, yd, mean, invstd, gamma, beta, act, C, HW, nv, group_elems, small);
+        else bn_fwd_vec_loop<8>(x, xd, y, yd, mean, invstd, gamma, beta, act, C, HW, nv, group_elems, small);
         return;
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -262,22 +371,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const void* dy, int
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t per = HW / w;
         const uint32_t per32 = (uint32_t)per, nvec = (uint32_t)Bg * per32;
-        for (uint32_t i = threadIdx.x; i < nvec; i += blockDim.x) {
-            const uint32_t b = i / per32, p = (i - b * per32) * w;
-            const int64_t idx = ((b0 + b) * C + c) * HW + p;
-            float xv[8], gv[8];
-            const int cnt = ld_vec(x, xd, idx, xv);
-            ld_vec(dy, dyd, idx, gv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j < cnt) {
-                    const float xh = (xv[j] - mu) * is;
-                    const float dz = gv[j] * act_grad_from_pre(xh * g + bt, act);
-                    s1 += (double)dz;
-                    s2 += (double)dz * (double)xh;
-                }
-            }
-        }
+        if (xd == VS_F32) bn_bwd_reduce_vec_loop<4>(dy, x, xd, mu, is, g, bt, act, b0, c, C, HW, per32, nvec, s1, s2);
+        else bn_bwd_reduce_vec_loop<8>(dy, x, xd, mu, is, g, bt, act, b0, c, C, HW, per32, nvec, s1, s2);
     } else if (vec) {
         const int w = (xd == VS_F32 || dyd == VS_F32) ? 4 : 8;
         const int64_t per = HW / w;
@@ -344,25 +439,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int d
         const int w = xd == VS_F32 ? 4 : 8;
         const int64_t nv = total / w;
         const bool small = total < (int64_t)1 << 31;
-        for (int64_t iv = (int64_t)blockIdx.x * 256 + threadIdx.x; iv < nv; iv += (int64_t)gridDim.x * 256) {
-            const int64_t i = iv * w;
-            int c, gc;
-            chan_of(i, HW, C, group_elems, small, c, gc);
-            const float mu = mean[gc], is = invstd[gc], g = gamma[c], bt = beta[c];
-            const float k1 = sum_dz[gc] * inv_n, k2 = sum_dz_xhat[gc] * inv_n;
-            float xv[8], gv[8];
-            const int cnt = ld_vec(x, xd, i, xv);
-            ld_vec(dy, dyd, i, gv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j < cnt) {
-                    const float xh = (xv[j] - mu) * is;
-                    const float dz = gv[j] * act_grad_from_pre(xh * g + bt, act);
-                    xv[j] = training ? g * is * (dz - k1 - xh * k2) : g * is * dz;
-                }
-            }
-            st_vec(dx, dxd, i, xv, cnt);
-        }
+        if (xd == VS_F32) bn_bwd_apply_vec_loop<4>(dy, x, xd, mean, invstd, gamma, beta, act, sum_dz, sum_dz_xhat, dx, dxd, C, HW, nv, group_elems, small, inv_n, training);
+        else bn_bwd_apply_vec_loop<8>(dy, x, xd, mean, invstd, gamma, beta, act, sum_dz, sum_dz_xhat, dx, dxd, C, HW, nv, group_elems, small, inv_n, training);
         return;
     }
     if (vec) {
@@ -707,7 +785,7 @@ extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, c
     int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
     if (!vec && HW >= 8 && total < ((int64_t)1 << 31) && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0) vec = 2;   // also mixed dtypes
     (void)w_;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(vec == 1 ? total / 16 : total / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
                        gamma, beta, act, C, HW, total, (int64_t)(B / groups) * C * HW, vec);
     VS_CHECK_LAUNCH("vs_bn_act_fwd");
     return VS_OK;
@@ -749,7 +827,7 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
                        beta, act, B / groups, C, HW, dbeta, dgamma, vec);
     VS_CHECK_LAUNCH("vs_bn_act_bwd reduce");
     const int64_t total = (int64_t)B * C * HW;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(vec == 1 && x_dtype == dy_dtype ? total / 8 : total / 4)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd,
                        gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, HW, total, training, vec);
     VS_CHECK_LAUNCH("vs_bn_act_bwd apply");
     return VS_OK;
