@@ -32,6 +32,7 @@
 // 326-343,362-382,402-417 and networks/resnet.py:57-59, plus their autograd.
 #include <type_traits>
 #include "vs_gemm_core.h"
+#include "vs_gemm_mid.h"
 #include <stdlib.h>
 
 namespace {
@@ -862,6 +863,42 @@ int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH
         Dense<CT, LR> bd{(const T*)ws, ld, N, K, 1};               // element (q, k = pixel) at cols[q * ld + k]
         Epi e = rowmajor_epi(dw, N);
         e.accumulate = accumulate;
+        if constexpr (CT != VS_F32) {
+            // the 128x128 LDS-DMA ring tile (vs_gemm_mid.h) with dy as a channel-rows operand: planes of a multiple of 32 pixels (a K
+            // tile never straddles two images), split-K over the batch x pixel axis into slabs; 2x the register-staged tile on the
+            // DCGAN / VGG weight gradients (K = 10^4 .. 10^5, 16-64 output tiles)
+            static const int mid_mode = getenv("VS_CONV_WGRAD_MID") ? atoi(getenv("VS_CONV_WGRAD_MID")) : 1;
+            const int64_t kt = K / BIG_BK, tiles = vs_cdiv(M, 128) * vs_cdiv(N, 128);
+            if (mid_mode && hw % BIG_BK == 0 && K % BIG_BK == 0 && M % 8 == 0 && N % 8 == 0 && (uintptr_t)r % 16 == 0 && hw < (1ll << 23) &&
+                ld < (1ll << 23) && kt >= 32 && tiles <= 512 && (M >= 96 || mid_mode == 2)) {
+                int splits = 1;
+                if (tiles < 448) {
+                    splits = (int)(448 / tiles);
+                    const int64_t max_by_k = kt / 16;
+                    if (splits > max_by_k) splits = (int)max_by_k;
+                    if (splits > 64) splits = 64;
+                    if (splits < 1) splits = 1;
+                }
+                const int64_t ktps = vs_cdiv(kt, splits);
+                splits = (int)vs_cdiv(kt, ktps);
+                float* slabs = nullptr;
+                const size_t need = splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+                if (need <= ws_bytes - cols_bytes) {
+                    if (splits > 1) slabs = (float*)((char*)ws + cols_bytes);
+                    const int stages = tiles * splits <= 256 ? 10 : 5;
+                    int rc2 = mid_launch<CT, LR, LR>(r, hw, ws, ld, M, N, K, splits, ktps, stages, 1, e, slabs, st, hw);
+                    if (rc2 != VS_OK) return rc2;
+                    VS_CHECK_LAUNCH(what);
+                    if (slabs) {
+                        int64_t blocks = vs_cdiv(M * N, 256);
+                        if (blocks > 2048) blocks = 2048;
+                        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slabs, splits, M, N, e);
+                        VS_CHECK_LAUNCH(what);
+                    }
+                    return VS_OK;
+                }
+            }
+        }
         return run<CT>(a, bd, M, N, K, e, (char*)ws + cols_bytes, ws_bytes - cols_bytes, st, what);
     }
     Epi e = rowmajor_epi(dw, N);

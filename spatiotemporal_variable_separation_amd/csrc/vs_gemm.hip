@@ -94,29 +94,10 @@ int launch_big_layout(int la, int lb, const void* A, int64_t lda, const void* B,
 template <int CT, int LA, int LB>
 int launch_mid(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const MidPlan& mp, int batch, const Epi& epi,
                float* slabs, hipStream_t stream) {
-    if constexpr (CT == VS_F32) {
-        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm: the 128x128 LDS-DMA ring tile is a 16-bit kernel");
-    } else {
-        dim3 grid((unsigned)(mp.tiles_m * mp.tiles_n), 1, (unsigned)(mp.splits * batch));
-        auto go = [&](auto kfn, int stages, bool& attr_set) -> int {
-            const int lds = stages * MID_TILE_BYTES;
-            if (!attr_set) {                           // above the 64 KiB default limit of dynamic LDS
-                if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-                    return vs_fail(VS_ERR_LAUNCH, "vs_gemm: cannot raise the dynamic LDS limit to %d bytes", lds);
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K,
-                               (int)mp.k_tiles_per_split, mp.tiles_n, epi, slabs);
-            return VS_OK;
-        };
-        static bool set5 = false, set10 = false, set_adam = false;
-        const int rc = epi.adam_m ? go(gemm_mid_kernel<CT, LA, LB, false, 5, true>, 5, set_adam)
-                       : mp.stages == 10 ? go(gemm_mid_kernel<CT, LA, LB, false, 10, false>, 10, set10)
-                                         : go(gemm_mid_kernel<CT, LA, LB, false, 5, false>, 5, set5);
-        if (rc != VS_OK) return rc;
-        VS_CHECK_LAUNCH("vs_gemm (128x128 ring tile)");
-        return VS_OK;
-    }
+    const int rc = mid_launch<CT, LA, LB>(A, lda, B, ldb, M, N, K, mp.splits, mp.k_tiles_per_split, mp.stages, batch, epi, slabs, stream);
+    if (rc != VS_OK) return rc;
+    VS_CHECK_LAUNCH("vs_gemm (128x128 ring tile)");
+    return VS_OK;
 }
 
 template <int CT>

@@ -56,8 +56,26 @@ struct MidOperand {
             base = reinterpret_cast<const char*>(p + k_begin * ld + i0);
             step = BIG_BK * ld * 2;
         }
+        run_tiles = 0; t_in_run = 0; run_jump = 0;
     }
-    __device__ __forceinline__ void advance() { base += step; }
+    // "channel rows" (LAYOUT R only): element (m = channel, k = (image b, pixel)) of an NCHW tensor at (b * C + m) * HW + pixel, i.e. an
+    // R operand with leading dimension HW whose K axis comes in runs of HW (one image) with a jump of (C - 1) * HW between them --
+    // the dy operand of a convolution's weight gradient.  HW % 32 == 0: a K tile never straddles two images.
+    int run_tiles, t_in_run;             // K tiles per run (0: plain dense operand), position inside the current run
+    int64_t run_jump;                    // extra bytes at the end of a run
+
+    __device__ __forceinline__ void prepare_runs(const unsigned short* p, int64_t C, int64_t HW, int64_t i0, int64_t k_begin) {
+        prepare(p, HW, C, i0, 0);
+        const int64_t b = k_begin / HW, r = k_begin - b * HW;
+        base = reinterpret_cast<const char*>(p + (b * C + i0) * HW + r);
+        run_tiles = (int)(HW / BIG_BK);
+        t_in_run = (int)(r / BIG_BK);
+        run_jump = (C * HW - HW) * 2;
+    }
+    __device__ __forceinline__ void advance() {
+        base += step;
+        if (run_tiles && ++t_in_run == run_tiles) { t_in_run = 0; base += run_jump; }
+    }
     __device__ __forceinline__ void stage(int q, char* lds) const {
         const uint32_t dst = (uint32_t)(uintptr_t)lds;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff[q]), "s"(base) : "memory", "m0");
@@ -73,7 +91,7 @@ struct MidOperand {
 // what a CU pulls through LDS-DMA is (bytes in flight) / (1.3-2 us), so the ring is as deep as the LDS allows.
 template <int CT, int LA, int LB, bool NCHW, int ST, bool ADAM>
 __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
-                                                          int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs) {
+                                                          int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs, int64_t a_chan_hw) {
     int zsplit = blockIdx.z;
     int batch = 0;
     if (epi_in.splits_per_batch > 0) {
@@ -107,7 +125,8 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
 
     MidOperand<LA> ga;
     MidOperand<LB> gb;
-    ga.prepare(Ap, lda, M, m0, kt_begin * BIG_BK);
+    if (LA == LR && a_chan_hw > 0) ga.prepare_runs(Ap, M, a_chan_hw, m0, kt_begin * BIG_BK);      // A = channel rows of an NCHW tensor (M channels)
+    else ga.prepare(Ap, lda, M, m0, kt_begin * BIG_BK);
     gb.prepare(Bp, ldb, N, n0, kt_begin * BIG_BK);
 
     // piece q of a tile: 0, 1 = A pieces tid / tid + 256, 2, 3 = B; destination = image byte u * 16 = wave * 1024 (+ 4096 for q odd)
@@ -215,6 +234,34 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
         const int64_t m = m0 + wr * 64 + r;
         const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + r * 64 + (lane & 15) * 4);
         if (m < M && nn < N) big_store4<NCHW>(epi, m, nn, N, v4, slab_base ? slab_base + m * N : nullptr);
+    }
+}
+
+// launch (shared by vs_gemm.hip and the convolution weight gradients of vs_conv.hip); a_chan_hw > 0: A is the channel-rows view of an
+// NCHW tensor with M channels and planes of a_chan_hw elements (lda is ignored)
+template <int CT, int LA, int LB>
+int mid_launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int splits, int64_t k_tiles_per_split,
+               int stages, int batch, const Epi& epi, float* slabs, hipStream_t stream, int64_t a_chan_hw = 0) {
+    if constexpr (CT == VS_F32) {
+        return vs_fail(VS_ERR_UNSUPPORTED, "the 128x128 LDS-DMA ring tile is a 16-bit kernel");
+    } else {
+        const int tiles_m = (int)vs_cdiv(M, 128), tiles_n = (int)vs_cdiv(N, 128);
+        dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(splits * batch));
+        auto go = [&](auto kfn, int st_, bool& attr_set) -> int {
+            const int lds = st_ * MID_TILE_BYTES;
+            if (!attr_set) {                           // above the 64 KiB default limit of dynamic LDS
+                if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                    return vs_fail(VS_ERR_LAUNCH, "cannot raise the dynamic LDS limit to %d bytes", lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K,
+                               (int)k_tiles_per_split, tiles_n, epi, slabs, a_chan_hw);
+            return VS_OK;
+        };
+        static bool set5 = false, set10 = false, set_adam = false;
+        return epi.adam_m ? go(gemm_mid_kernel<CT, LA, LB, false, 5, true>, 5, set_adam)
+               : stages == 10 ? go(gemm_mid_kernel<CT, LA, LB, false, 10, false>, 10, set10)
+                              : go(gemm_mid_kernel<CT, LA, LB, false, 5, false>, 5, set5);
     }
 }
 
