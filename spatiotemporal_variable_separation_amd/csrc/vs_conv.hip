@@ -658,6 +658,19 @@ int gather_gemm(const void* src, const void* wd, const float* bias, void* out, i
         }
         const int64_t ld = cols_pitch<CT>(N);
         Dense<CT, LS> bd{(const T*)ws, ld, N, K, 1};               // element (pixel n, k = q) at cols[q * ld + n]
+        if constexpr (CT != VS_F32) {
+            // many 128-wide pixel tiles, >= 96 output channels: the 128x128 LDS-DMA ring tile (weights R, column matrix S, NCHW epilogue
+            // with 8-byte / 16-byte stores along the pixels)
+            static const int mid_mode = getenv("VS_CONV_FWD_MID") ? atoi(getenv("VS_CONV_FWD_MID")) : 1;
+            const int64_t kt = vs_cdiv(K, BIG_BK), tiles = vs_cdiv((int64_t)M, 128) * vs_cdiv(N, 128);
+            if (mid_mode && e.g_hw == 0 && K % 8 == 0 && N % 8 == 0 && (uintptr_t)wd % 16 == 0 && K < (1ll << 23) && ld < (1ll << 23) &&
+                kt >= 8 && tiles >= 192 && (M >= 96 || mid_mode == 2)) {
+                int rc2 = mid_launch<CT, LR, LS, true>(wd, K, ws, ld, M, N, K, 1, kt, 5, 1, e, nullptr, st, 0);
+                if (rc2 != VS_OK) return rc2;
+                VS_CHECK_LAUNCH(what);
+                return VS_OK;
+            }
+        }
         return run<CT>(a, bd, M, N, K, e, (char*)ws + cols_bytes, ws_bytes - cols_bytes, st, what);
     }
     return run<CT>(a, b, M, N, K, e, ws, ws_bytes, st, what);     // implicit gather; the workspace (if any) serves split-K
@@ -870,7 +883,7 @@ int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH
             static const int mid_mode = getenv("VS_CONV_WGRAD_MID") ? atoi(getenv("VS_CONV_WGRAD_MID")) : 1;
             const int64_t kt = K / BIG_BK, tiles = vs_cdiv(M, 128) * vs_cdiv(N, 128);
             if (mid_mode && hw % BIG_BK == 0 && K % BIG_BK == 0 && M % 8 == 0 && N % 8 == 0 && (uintptr_t)r % 16 == 0 && hw < (1ll << 23) &&
-                ld < (1ll << 23) && kt >= 32 && tiles <= 512 && (M >= 96 || mid_mode == 2)) {
+                ld < (1ll << 23) && kt >= 32 && tiles <= 512 && (M >= 64 || mid_mode == 2)) {
                 int splits = 1;
                 if (tiles < 448) {
                     splits = (int)(448 / tiles);

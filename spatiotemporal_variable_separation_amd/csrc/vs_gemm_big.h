@@ -168,8 +168,23 @@ __device__ __forceinline__ void big_store4(const Epi& e, int64_t m, int64_t n, i
         return;
     }
     if constexpr (NCHW) {
-        for (int t = 0; t < 4; ++t)
-            if (n + t < N) epi_store_nchw(e, m, nchw_col_base(e, n + t), v[t]);
+        // rows = channels, columns = pixels (b * hw + pix): four consecutive pixels of one plane are contiguous in NCHW
+        if (n + 3 < N && e.g_hw == 0 && (e.nchw_hw & 3) == 0 && (n & 3) == 0 && !e.mask && !e.accumulate && ((uintptr_t)e.C & 15) == 0) {
+            const int64_t idx = nchw_col_base(e, n) + m * e.nchw_hw;
+            const float bsv = e.bias ? e.bias[m] : 0.f;
+            f32x4 r;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r[t] = vs_act(v[t] * e.alpha + bsv, e.act);
+            if (e.c_dtype == VS_F32) {
+                *reinterpret_cast<f32x4*>((float*)e.C + idx) = r;
+            } else {
+                const u16x4 h = {vs_f2h(r[0], e.c_dtype), vs_f2h(r[1], e.c_dtype), vs_f2h(r[2], e.c_dtype), vs_f2h(r[3], e.c_dtype)};
+                *reinterpret_cast<u16x4*>((unsigned short*)e.C + idx) = h;
+            }
+        } else {
+            for (int t = 0; t < 4; ++t)
+                if (n + t < N) epi_store_nchw(e, m, nchw_col_base(e, n + t), v[t]);
+        }
     } else {
         const bool vec = n + 3 < N && ((e.ldc | n) & 3) == 0 && !e.mask && !e.accumulate && ((uintptr_t)e.C & 15) == 0;
         if (vec) {

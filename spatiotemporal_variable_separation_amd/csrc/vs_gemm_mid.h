@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
 
 // launch (shared by vs_gemm.hip and the convolution weight gradients of vs_conv.hip); a_chan_hw > 0: A is the channel-rows view of an
 // NCHW tensor with M channels and planes of a_chan_hw elements (lda is ignored)
-template <int CT, int LA, int LB>
+template <int CT, int LA, int LB, bool NCHW = false>
 int mid_launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, int splits, int64_t k_tiles_per_split,
                int stages, int batch, const Epi& epi, float* slabs, hipStream_t stream, int64_t a_chan_hw = 0) {
     if constexpr (CT == VS_F32) {
@@ -259,9 +259,13 @@ int mid_launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M
             return VS_OK;
         };
         static bool set5 = false, set10 = false, set_adam = false;
-        return epi.adam_m ? go(gemm_mid_kernel<CT, LA, LB, false, 5, true>, 5, set_adam)
-               : stages == 10 ? go(gemm_mid_kernel<CT, LA, LB, false, 10, false>, 10, set10)
-                              : go(gemm_mid_kernel<CT, LA, LB, false, 5, false>, 5, set5);
+        if constexpr (NCHW) {
+            return stages == 10 ? go(gemm_mid_kernel<CT, LA, LB, true, 10, false>, 10, set10) : go(gemm_mid_kernel<CT, LA, LB, true, 5, false>, 5, set5);
+        } else {
+            return epi.adam_m ? go(gemm_mid_kernel<CT, LA, LB, false, 5, true>, 5, set_adam)
+                   : stages == 10 ? go(gemm_mid_kernel<CT, LA, LB, false, 10, false>, 10, set10)
+                                  : go(gemm_mid_kernel<CT, LA, LB, false, 5, false>, 5, set5);
+        }
     }
 }
 
