@@ -168,6 +168,14 @@ int vs_conv_k3s1_tap_fwd(int compute, const void* x, const void* w_tap, const fl
 int vs_bn_stats_from_sums(const double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* var_scratch,
                           float* running_mean, float* running_var, float momentum, float eps, void* stream);
 
+/* Frame metrics of the evaluation scripts (test/mnist/test.py:136-142): for every plane pair (pred, target) [planes, H, W] fp32
+ * mse[plane] = mean squared error (PSNR = 10 log10(1 / mse) follows on the host as in the reference) and ssim[plane] = mean over the
+ * (H - 10) x (W - 10) "valid" window positions of the SSIM index of utils/ssim.py:81-111 (11 x 11 Gaussian window of the given
+ * sigma, c1 = (k1 max_val)^2, c2 = (k2 max_val)^2) -- what `_ssim_wrapper` (test/utils.py:19-24) returns per (sample, frame, channel).
+ * One launch, planes up to ~80 x 80 (VS_ERR_UNSUPPORTED beyond); either output may be NULL.                                  */
+int vs_frame_metrics(const float* pred, const float* target, int64_t planes, int H, int W, float max_val, float k1, float k2, float sigma,
+                     float* mse, float* ssim, void* stream);
+
 /* One batch of Moving-MNIST training sequences rendered on the device (reference: data/moving_mnist.py:112-175 `__getitem__` +
  * `_compute_trajectory`, :177-255 `_process_collision`, deterministic mode as main.py:81-82 constructs it).
  * digits [n_digits_total, digit_h, digit_w] uint8 in HBM; init [batch, num_digits, 5] int32 = (digit index, start row, start column,

@@ -899,3 +899,19 @@ def loss_scale_update(scale_state, growth_factor, backoff_factor, growth_interva
     require_cuda(scale_state)
     check(_lib.load_library().vs_loss_scale_update(scale_state.data_ptr(), float(growth_factor), float(backoff_factor), int(growth_interval),
                                                    stream_ptr()), 'vs_loss_scale_update')
+
+
+# ------------------------------------------------------------------------------------------------ evaluation metrics
+def frame_metrics(pred, target, max_val=1.0, k1=0.01, k2=0.03, sigma=1.5, want_ssim=True):
+    """pred, target [..., H, W] fp32 (any leading dims): per-plane (mse, mean SSIM) with the leading shape (vs_frame_metrics)."""
+    require_cuda(pred, target)
+    assert pred.shape == target.shape and pred.dim() >= 2
+    H, W = pred.shape[-2], pred.shape[-1]
+    lead = tuple(pred.shape[:-2])
+    p = pred.reshape(-1, H, W).float().contiguous()
+    t = target.reshape(-1, H, W).float().contiguous()
+    mse = torch.empty((p.shape[0],), dtype=torch.float32, device=p.device)
+    ssim = torch.empty((p.shape[0],), dtype=torch.float32, device=p.device) if want_ssim else None
+    check(_lib.load_library().vs_frame_metrics(p.data_ptr(), t.data_ptr(), p.shape[0], H, W, float(max_val), float(k1), float(k2), float(sigma),
+                                               mse.data_ptr(), _ptr(ssim), stream_ptr()), 'vs_frame_metrics')
+    return mse.view(lead), (ssim.view(lead) if want_ssim else None)

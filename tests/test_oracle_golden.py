@@ -80,3 +80,19 @@ def test_oracle_eval_forecast_matches_reference_fixture(name):
     check_tensor(gold, 't_codes', codes, 1e-5)
     check_tensor(gold, 's_code', s[0] if isinstance(s, (tuple, list)) else s, 1e-5)
     check_tensor(gold, 'swap_forecasts', swap, 1e-5)
+
+
+def test_oracle_frame_metrics_match_reference_fixture():
+    """oracle/ssim_ref.py (SSIM / MSE / PSNR of the evaluation scripts) against tests/golden/frame_metrics.npz, recorded from the
+    reference's `_ssim_wrapper` and the metric lines of test/mnist/test.py."""
+    import torch
+    from oracle import ssim_ref
+    from oracle.make_golden_metrics import CASES, make_pair
+    from golden_util import load_golden
+    gold = load_golden('frame_metrics')
+    for i, (name, shape) in enumerate(CASES.items()):
+        pred, target = make_pair(shape, 100 + 10 * i)
+        o = ssim_ref.frame_metrics(pred, target)
+        assert torch.allclose(o['ssim_plane'], torch.from_numpy(gold[name + ':ssim']), rtol=1e-6, atol=1e-7), name
+        assert torch.allclose(o['mse_plane'], torch.from_numpy(gold[name + ':mse']), rtol=1e-6, atol=1e-9), name
+        assert torch.allclose(o['psnr'], torch.from_numpy(gold[name + ':psnr']), rtol=1e-6), name
