@@ -53,6 +53,35 @@ def fold_repeated_gradients(flag):
 
 _FOLD = {'task': None, 'acc': {}}
 
+# ---- weight gradients of convolutions that are applied many times per step, batched over the calls -----------------------------------
+# The SST integrator applies each of its 3x3 convolutions once per predicted frame (39 calls per step) on B = 8 samples of 16 x 16:
+# 234 weight gradients of ~1 GFLOP, each a column-matrix gather + a split-K GEMM + a reduce (about 60 us of launch-bound work, 14 ms
+# of the step).  A weight gradient is a sum over the batch axis, so the calls of one weight are ONE weight gradient over the
+# concatenation of their (dz, x) pairs: in fold mode such calls only REMEMBER their pair; when the backward pass ends (an autograd
+# engine callback) each weight's pairs are concatenated along the batch axis and its gradient is computed by one launch sequence
+# (K = 39 x 2048 pixels: a long, efficient reduction) into the tensor autograd was handed at the weight's first call.
+_DEFER_W = {'slots': {}, 'queued': False}
+
+
+def _defer_wgrad_ok(dz, transposed, stride):
+    return (_STATE.get('fold_grads') and os.environ.get('VARSEP_DEFER_WGRADS', '1') == '1' and not transposed and stride == 1
+            and dz.shape[0] * dz.shape[2] * dz.shape[3] <= 16384 and not torch.is_grad_enabled())
+
+
+def flush_deferred_wgrads():
+    """Compute the remembered weight gradients (see above).  Runs by itself at the end of every backward pass that deferred any."""
+    slots, _DEFER_W['slots'] = _DEFER_W['slots'], {}
+    _DEFER_W['queued'] = False
+    for slot in slots.values():
+        with torch.cuda.stream(slot['stream']):
+            pairs = slot['pairs']
+            if len(pairs) == 1:
+                dz, xc = pairs[0]
+            else:
+                dz = torch.cat([p[0] for p in pairs], dim=0)
+                xc = torch.cat([p[1] for p in pairs], dim=0)
+            ops.conv_wgrad(dz, xc, slot['shape'], slot['stride'], slot['pad'], False, into=slot['g'])
+
 
 def _fold_slots():
     """Per backward pass: parameter id -> the gradient tensor autograd already holds for it (its first contribution)."""
@@ -766,7 +795,24 @@ class ConvBlock(torch.autograd.Function):
             # a weight that already holds a gradient from an earlier call of this pass (the integrator's blocks: one call per predicted
             # frame) gets this call's contribution ADDED in the weight-gradient GEMM's epilogue -- no temporary, no add launch
             first_w = _fold_slots().get(id(w)) if _STATE.get('fold_grads') else None
-            if first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
+            if _defer_wgrad_ok(dz, transposed, stride):
+                slot = _DEFER_W['slots'].get(id(w))
+                if slot is None:
+                    if first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
+                        g = first_w                          # the weight already holds a gradient of this pass: the batch is added to it
+                    else:
+                        # zeros: the batched gradient is ADDED at the end, so other (non-deferred) calls of the same weight may add to
+                        # this tensor in between; autograd gets a tensor of its own on the same storage (it keeps an unshared tensor)
+                        buf = torch.zeros((w.numel(),), dtype=torch.float32, device=dz.device)
+                        g = buf.view(w.shape)
+                        dw = buf.view(w.shape)
+                    slot = _DEFER_W['slots'][id(w)] = {'g': g, 'pairs': [], 'shape': tuple(w.shape), 'stride': stride, 'pad': pad,
+                                                      'stream': torch.cuda.current_stream()}
+                    if not _DEFER_W['queued']:
+                        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_wgrads)
+                        _DEFER_W['queued'] = True
+                slot['pairs'].append((dz, xc))
+            elif first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
                 ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed, into=first_w)
             else:
                 dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed)

@@ -482,9 +482,9 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     return dx
 
 
-def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None):
+def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
     """Weight gradient of a (transposed) convolution; `into`: an fp32 tensor of the weight's shape that the result is ADDED to
-    (in the GEMM / split-K epilogue) instead of a fresh tensor."""
+    (in the GEMM / split-K epilogue) instead of a fresh tensor; `out`: an fp32 tensor that receives it."""
     require_cuda(dy, x)
     assert dy.is_contiguous() and x.is_contiguous() and dy.dtype == x.dtype
     B, Cin, H, W = x.shape
@@ -493,7 +493,9 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None):
     OH, OW = dy.shape[2], dy.shape[3]
     if into is not None:
         assert into.dtype == torch.float32 and into.is_contiguous() and tuple(into.shape) == tuple(w_shape)
-    dw = into if into is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    if out is not None:
+        assert into is None and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(w_shape)
+    dw = into if into is not None else (out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device))
     lib = _lib.load_library()
     pix_h, pix_w = (H, W) if transposed else (OH, OW)
     ws = _conv_workspace(dtype_code(x), B, Cin, H, W, Cout, k, stride, pad, x.device)
