@@ -79,6 +79,8 @@ def spawn_ranks(args):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        for k in env.pop('VARSEP_PACKAGE_SET', '').split():     # single-GPU runtime knobs the package set in THIS process
+            env.pop(k, None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rcs = [p.wait() for p in procs]

@@ -498,8 +498,9 @@ class MLPChain(torch.autograd.Function):
                     run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, W=W, fused=fused: fused.fused_update(W, dz, S, h_in, S, N, K, M),
                                  dz, h_in, outs=(), lane=lane)
                 elif dst is not None:           # straight into the all-reduce bucket; autograd gets nothing for this parameter
+                    # (holdable like the single-GPU path: the destination exists already)
                     run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, dst=dst: ops.gemm(dz, S, h_in, S, N, K, M, out=dst), dz, h_in,
-                                 lane=lane)
+                                 outs=dst, lane=lane)
                 else:
                     # autograd keeps the tensor it is handed only if nobody else references it (it CLONES it otherwise -- here
                     # before the deferred GEMM has written it): the closure writes through a second tensor on the same storage
@@ -519,7 +520,7 @@ class MLPChain(torch.autograd.Function):
         bias_jobs = [j for j in bias_jobs if j[2] is None]
         if direct:                            # added to the (zeroed) bucket slices
             dzs, dsts = [j[1] for j in direct], [j[2] for j in direct]
-            run_deferred(lambda: ops.colsum_multi(dzs, outs=dsts), *dzs, lane=lane)
+            run_deferred(lambda: ops.colsum_multi(dzs, outs=dsts), *dzs, outs=dsts, lane=lane)
         if bias_jobs:
             dzs = [j[1] for j in bias_jobs]
             flat, views = ops.colsum_alloc(dzs)
