@@ -181,6 +181,12 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     return total_loss, terms, forecasts, t_codes
 
 
+# Stream capture in 'thread_local' error mode: with a process group alive, ProcessGroupNCCL's watchdog thread polls its work events
+# (hipEventQuery) at any time; in the default 'global' mode such a call from ANOTHER thread while this thread captures is an error that
+# terminates the process ("operation not permitted when stream is capturing" -- seen in 3 of 6 runs of the data-parallel GPU tests).
+_CAPTURE_MODE = 'thread_local'
+
+
 class GraphedStep:
     """One whole optimisation step (losses, backward, Adam) recorded into a hipGraph and replayed.  MLP family: the batched step
     with side streams; conv families: the reference's call structure (same-box eager -> replay: SST 72.5 -> 68.5 ms, MNIST B=16
@@ -254,7 +260,7 @@ class GraphedStep:
             from . import functional as VF
             VF.bn_counts_flushed_in_capture(True)        # SST: ~200 per-call `num_batches_tracked += 1` launches become one
             try:
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
                     self.loss = self._fwd_bwd()
                     self._opt_step()
                     VF.flush_bn_call_counts()
@@ -264,7 +270,7 @@ class GraphedStep:
             # data parallel: losses + backward into the reducer's flat gradient buckets in one graph, the bucket
             # all-reduces issued eagerly in between (4 RCCL calls at WaveEq size; no collective inside a capture), Adam in
             # a second graph
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
                 self.loss = self._fwd_bwd()
             self._reduce()
             if self.scaler is None and hasattr(self.opt, 'step_subset') and os.environ.get('VARSEP_ADAM_PER_BUCKET', '1') == '1':
@@ -272,16 +278,16 @@ class GraphedStep:
                 self.graph_opt = []
                 for _, plist in grad_sync.buckets:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                         self.opt.step_subset(plist)
                     self.graph_opt.append(g)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                     self.opt.finish_step()
                 self.graph_opt.append(g)
             else:
                 self.graph_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_opt):
+                with torch.cuda.graph(self.graph_opt, capture_error_mode=_CAPTURE_MODE):
                     self._opt_step()
 
     def _opt_step(self):
