@@ -211,6 +211,15 @@ int vs_train_losses_bwd(const float* frames, const float* full, const int32_t* i
                         const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
                         int average_tloss, const float* lambdas, const float* grad_total, float* dframes, float* ds_old,
                         float* ds_new, float* dt0, int frames_act, void* dz, int dz_dtype, void* stream);
+/* Both of the above in ONE pass over the frames, for an upstream gradient known when the forward runs (a recorded training step
+ * passes its resident 1.0 or loss scale: `grad_total`, one float on the device): `out` as vs_train_losses_fwd; dz (the gradient of
+ * the producing chain's pre-activation, compute dtype) / ds_old / ds_new / dt0 as vs_train_losses_bwd writes them.  D % 4 == 0.
+ * `out` must hold 16 + 2 * 4096 floats here: the frame sums go through per-workgroup partials (no float atomics: reproducible). */
+int vs_train_losses_fwd_grad(const float* frames, const float* full, const int32_t* idx, const int32_t* t_random_dev, int ae_shift,
+                             int first_forecast, int64_t B, int G, int T, int64_t D, const float* s_old, const float* s_new, int64_t n_s,
+                             const float* t0, int64_t Bt, int64_t Ct, int average_tloss, const float* lambdas, float* out,
+                             const float* grad_total, float* ds_old, float* ds_new, float* dt0, int frames_act, void* dz, int dz_dtype,
+                             void* stream);
 
 /* Adam update of up to 64 fp32 tensors in one launch (reference: train.py:156-158 `optimizer.step()` on
  * torch.optim.Adam(lr, betas): weight_decay 0, amsgrad off; same operation order as torch's single-tensor path:

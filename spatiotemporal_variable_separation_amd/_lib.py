@@ -105,6 +105,8 @@ SIGNATURES = {
     'vs_gemm_batched': (_i32, [_i32, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _f32, _i32,
                                _vp, _sz, _vp]),
     'vs_train_losses_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    'vs_train_losses_fwd_grad': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp,
+                                        _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     'vs_train_losses_bwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _i32, _vp, _i32, _vp]),
     'vs_convt_tap_supported': (_i32, [_i32] * 7),

@@ -249,14 +249,24 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 
 // out: [0..3] raw sums (SSE frame 0, SSE frames 1.., sum (s_old - s_new)^2, sum t0^2), [4] total, [5] ae, [6] zero, [7] pred,
 //      [8] t_reg
-__global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float* out) {
+// GRAD: the same pass also writes the gradients of `total` for an upstream gradient *g that is known when the forward runs (a
+// recorded step passes its resident 1.0 / loss scale): dz = k (y - target) act'(y) in the compute dtype for the producing chain and
+// the three small code gradients -- the frames and targets are read ONCE per step instead of twice (D % 4 == 0).
+constexpr int VS_LOSS_MAX_PARTIALS = 4096;          // vs_train_losses_fwd_grad: `out` holds 16 + 2 * 4096 floats
+struct LossGrads { const float* g; void* dz; int dz_dtype; int act; float* ds_old; float* ds_new; float* dt0; };
+
+template <bool GRAD>
+__global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float* out, LossGrads gr) {
     __shared__ float red[4];
     float s0 = 0.f, s1 = 0.f;
+    float up = 1.f;
+    if constexpr (GRAD) up = gr.g[0];
     for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
         const int g = (int)(r % a.G);
         const int64_t b = r / a.G;
         const float* f = a.frames + r * a.D;
         const float* t = a.full + (b * a.T + loss_target_frame(a, g)) * a.D;
+        const float k = g == 0 ? up * a.l_ae * 2.f * a.inv_ae : up * a.l_pred * 2.f * a.inv_pred;
         float s = 0.f;
         int64_t i = (int64_t)threadIdx.x * 4;
         for (; i + 3 * 1024 + 3 < a.D; i += 4096) {            // four 16-byte loads of each stream in flight per thread
@@ -264,26 +274,68 @@ __global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float
 #pragma unroll
             for (int u = 0; u < 4; ++u) { x[u] = *reinterpret_cast<const f32x4*>(f + i + u * 1024); y[u] = *reinterpret_cast<const f32x4*>(t + i + u * 1024); }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+                float rr[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = x[u][j] - y[u][j]; s += d * d; }
+                for (int j = 0; j < 4; ++j) {
+                    const float d = x[u][j] - y[u][j];
+                    s += d * d;
+                    if constexpr (GRAD) rr[j] = (k * d) * vs_act_grad_from_out(x[u][j], gr.act);
+                }
+                if constexpr (GRAD) {
+                    const int64_t o = r * a.D + i + u * 1024;
+                    if (gr.dz_dtype == VS_F32) *reinterpret_cast<f32x4*>((float*)gr.dz + o) = f32x4{rr[0], rr[1], rr[2], rr[3]};
+                    else {
+                        const u16x4 w = {vs_f2h(rr[0], gr.dz_dtype), vs_f2h(rr[1], gr.dz_dtype), vs_f2h(rr[2], gr.dz_dtype), vs_f2h(rr[3], gr.dz_dtype)};
+                        *reinterpret_cast<u16x4*>((unsigned short*)gr.dz + o) = w;
+                    }
+                }
+            }
         }
         for (; i + 3 < a.D; i += 1024) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(f + i), y = *reinterpret_cast<const f32x4*>(t + i);
+            float rr[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const float d = x[j] - y[j]; s += d * d; }
+            for (int j = 0; j < 4; ++j) {
+                const float d = x[j] - y[j];
+                s += d * d;
+                if constexpr (GRAD) rr[j] = (k * d) * vs_act_grad_from_out(x[j], gr.act);
+            }
+            if constexpr (GRAD) {
+                const int64_t o = r * a.D + i;
+                if (gr.dz_dtype == VS_F32) *reinterpret_cast<f32x4*>((float*)gr.dz + o) = f32x4{rr[0], rr[1], rr[2], rr[3]};
+                else {
+                    const u16x4 w = {vs_f2h(rr[0], gr.dz_dtype), vs_f2h(rr[1], gr.dz_dtype), vs_f2h(rr[2], gr.dz_dtype), vs_f2h(rr[3], gr.dz_dtype)};
+                    *reinterpret_cast<u16x4*>((unsigned short*)gr.dz + o) = w;
+                }
+            }
         }
         if (threadIdx.x == 0)
-            for (int64_t k = a.D & ~(int64_t)3; k < a.D; ++k) { const float d = f[k] - t[k]; s += d * d; }
+            for (int64_t kk = a.D & ~(int64_t)3; kk < a.D; ++kk) { const float d = f[kk] - t[kk]; s += d * d; }      // (GRAD requires D % 4 == 0)
         if (g == 0) s0 += s; else s1 += s;
     }
     s0 = block_sum_256(s0, red);
     s1 = block_sum_256(s1, red);
-    if (threadIdx.x == 0) { atomicAdd(out, s0); atomicAdd(out + 1, s1); }
+    if constexpr (GRAD) {
+        // per-workgroup partials (out[16 + 2 wg ..]), summed in workgroup order by the finalize launch: no float atomics (thousands of
+        // them on two addresses serialise in L2) and a reproducible sum
+        if (threadIdx.x == 0) { out[16 + 2 * blockIdx.x] = s0; out[17 + 2 * blockIdx.x] = s1; }
+    } else {
+        if (threadIdx.x == 0) { atomicAdd(out, s0); atomicAdd(out + 1, s1); }
+    }
     if (blockIdx.x == 0) {                                     // the two code terms are tiny: one workgroup, fixed order
         float ss = 0.f, st = 0.f;
-        for (int64_t i = threadIdx.x; i < a.n_s; i += 256) { const float d = a.s_old[i] - a.s_new[i]; ss += d * d; }
-        for (int64_t i = threadIdx.x; i < a.Bt * a.Ct; i += 256) { const float v = a.t0[i]; st += v * v; }
+        const float cs = up * a.l_s * 2.f * a.inv_s, ct = up * a.l_t * a.inv_t;
+        for (int64_t i = threadIdx.x; i < a.n_s; i += 256) {
+            const float d = a.s_old[i] - a.s_new[i];
+            ss += d * d;
+            if constexpr (GRAD) { gr.ds_old[i] = cs * d; gr.ds_new[i] = -(cs * d); }
+        }
+        for (int64_t i = threadIdx.x; i < a.Bt * a.Ct; i += 256) {
+            const float v = a.t0[i];
+            st += v * v;
+            if constexpr (GRAD) gr.dt0[i] = ct * v;
+        }
         ss = block_sum_256(ss, red);
         st = block_sum_256(st, red);
         if (threadIdx.x == 0) { atomicAdd(out + 2, ss); atomicAdd(out + 3, st); }
@@ -292,7 +344,18 @@ __global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float
 
 // A device-scope release fence per workgroup (the "last ticket assembles" pattern) costs more than this whole kernel on
 // gfx950 (each fence writes back the XCD's L2: +45 us at 1024 workgroups), so the scalars are assembled by a 1-thread launch.
-__global__ void train_losses_finalize_kernel(LossArgs a, float* out) {
+// (partials > 0: the frame sums arrive as that many per-workgroup pairs at out[16 ..])
+__global__ __launch_bounds__(256) void train_losses_finalize_kernel(LossArgs a, float* out, int partials) {
+    if (partials > 0) {
+        __shared__ float red[4];
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = threadIdx.x; i < partials; i += 256) { s0 += out[16 + 2 * i]; s1 += out[17 + 2 * i]; }
+        s0 = block_sum_256(s0, red);
+        s1 = block_sum_256(s1, red);
+        if (threadIdx.x == 0) { out[0] = s0; out[1] = s1; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
     const float ae = out[0] * a.inv_ae, pred = out[1] * a.inv_pred, zero = out[2] * a.inv_s, treg = 0.5f * out[3] * a.inv_t;
     out[5] = ae; out[6] = zero; out[7] = pred; out[8] = treg;
     out[4] = a.l_ae * ae + a.l_s * zero + a.l_pred * pred + a.l_t * treg;          // same association as train.py:146-149
@@ -380,9 +443,34 @@ extern "C" int vs_train_losses_fwd(const float* frames, const float* full, const
     if (vs_zero_async(out, 10 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_train_losses_fwd: zero fill failed");
     int64_t wgs = B * G;
     if (wgs > 1024) wgs = 1024;
-    hipLaunchKernelGGL(train_losses_fwd_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, out);
-    hipLaunchKernelGGL(train_losses_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, out);
+    hipLaunchKernelGGL(train_losses_fwd_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, out, LossGrads{});
+    hipLaunchKernelGGL(train_losses_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, out, 0);
     VS_CHECK_LAUNCH("vs_train_losses_fwd");
+    return VS_OK;
+}
+
+// vs_train_losses_fwd + vs_train_losses_bwd in ONE pass over the frames, for an upstream gradient that is known up front
+// (`grad_total`: one float on the device, read by the kernel): out as vs_train_losses_fwd, dz / ds_old / ds_new / dt0 as
+// vs_train_losses_bwd writes them (dz form only: the frames are the outputs of activation `frames_act`).
+extern "C" int vs_train_losses_fwd_grad(const float* frames, const float* full, const int32_t* idx, const int32_t* t_random_dev, int ae_shift,
+                                        int first_forecast, int64_t B, int G, int T, int64_t D, const float* s_old, const float* s_new, int64_t n_s,
+                                        const float* t0, int64_t Bt, int64_t Ct, int average_tloss, const float* lambdas, float* out,
+                                        const float* grad_total, float* ds_old, float* ds_new, float* dt0, int frames_act, void* dz, int dz_dtype,
+                                        void* stream) {
+    LossArgs a;
+    int rc = fill_loss_args(a, frames, full, idx, t_random_dev, ae_shift, first_forecast, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss,
+                            lambdas);
+    if (rc != VS_OK) return rc;
+    VS_CHECK_ARG(out && grad_total && dz && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_fwd_grad: null pointer");
+    VS_CHECK_ARG(vs_dtype_ok(dz_dtype) && frames_act >= VS_ACT_NONE && frames_act <= VS_ACT_ELU && D % 4 == 0,
+                 "vs_train_losses_fwd_grad: needs a valid dz dtype / activation and D %% 4 == 0");
+    if (vs_zero_async(out, 10 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_train_losses_fwd_grad: zero fill failed");
+    int64_t wgs = B * G;                                       // one row per workgroup: every load of the pass is issued at once
+    if (wgs > VS_LOSS_MAX_PARTIALS) wgs = VS_LOSS_MAX_PARTIALS;
+    LossGrads gr{grad_total, dz, dz_dtype, frames_act, ds_old, ds_new, dt0};
+    hipLaunchKernelGGL(train_losses_fwd_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, a, out, gr);
+    hipLaunchKernelGGL(train_losses_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, out, (int)wgs);
+    VS_CHECK_LAUNCH("vs_train_losses_fwd_grad");
     return VS_OK;
 }
 

@@ -123,6 +123,13 @@ def flush_bn_call_counts():
         torch._foreach_add_(bufs, incs)
 
 
+def promise_loss_gradient(t):
+    """`t` (one fp32 element on the device, or None) is the tensor the caller WILL pass as the gradient of the total loss
+    (`total.backward(t)`): TrainLosses then writes its gradients in the forward pass (one read of the frame stack per step instead of
+    two).  The value is read on the device when the forward kernel runs; a backward call with any other tensor recomputes."""
+    _STATE['promised_loss_grad'] = t
+
+
 def compute_dtype():
     return {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[_STATE['precision']]
 
@@ -963,7 +970,17 @@ class TrainLosses(torch.autograd.Function):
         if isinstance(idx, tuple):
             ctx.window, idx = (int(idx[1]), int(idx[2])), idx[0]
         idx_arg = idx if ctx.window is None else (idx,) + ctx.window
-        out = ops.train_losses_fwd(frames, full, idx_arg, s_old, s_new, t0, lambdas, average_tloss)
+        ctx.early = None
+        up = _STATE.get('promised_loss_grad')
+        if (up is not None and handoff is not None and handoff.act not in ('none', None) and frames.shape[-1] % 4 == 0 and ctx.needs_input_grad[0]
+                and up.device == frames.device):
+            # the caller has promised the tensor it will pass to backward (a recorded step: its resident 1.0 / loss scale): the
+            # gradients are written by the same pass that sums the losses; backward hands them out if the promise was kept
+            out, dz, ds_old, ds_new, dt0 = ops.train_losses_fwd_grad(frames, full, idx_arg, s_old, s_new, t0, lambdas, average_tloss, up,
+                                                                       handoff.act, handoff.cdt)
+            ctx.early = (up.data_ptr(), up._version, dz, ds_old, ds_new, dt0)
+        else:
+            out = ops.train_losses_fwd(frames, full, idx_arg, s_old, s_new, t0, lambdas, average_tloss)
         ctx.set_materialize_grads(False)             # no zero tensors for the (unused) gradients of the four logging terms
         ctx.save_for_backward(frames, full, idx, s_old, s_new, t0)
         ctx.lambdas, ctx.average = tuple(float(v) for v in lambdas), bool(average_tloss)
@@ -978,6 +995,10 @@ class TrainLosses(torch.autograd.Function):
             return (None,) * 9
         idx_arg = idx if ctx.window is None else (idx,) + ctx.window
         h = ctx.handoff
+        if ctx.early is not None and g_total.data_ptr() == ctx.early[0] and g_total.numel() == 1:
+            _, _, h.dz, ds_old, ds_new, dt0 = ctx.early           # computed by the forward pass for exactly this upstream gradient
+            ctx.early = None
+            return GradHandoff.placeholder(frames), None, None, ds_old, ds_new, dt0, None, None, None
         if h is not None and h.act not in ('none', None) and frames.shape[-1] % 4 == 0:
             # the frames are the outputs of the producing chain's last activation: write d/d(pre-activation) for it directly
             h.dz, ds_old, ds_new, dt0 = ops.train_losses_bwd(frames, full, idx_arg, s_old, s_new, t0, ctx.lambdas, ctx.average,

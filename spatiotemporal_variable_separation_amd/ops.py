@@ -793,6 +793,24 @@ def train_losses_fwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss
     return out
 
 
+def train_losses_fwd_grad(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss, grad_total, frames_act, dz_dtype):
+    """train_losses_fwd and train_losses_bwd (dz form) in one pass, for the upstream gradient `grad_total` (one device float) known now.
+    -> (out [10], dz, ds_old, ds_new, dt0)."""
+    args, keep = _loss_args(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss)
+    require_cuda(grad_total)
+    assert grad_total.dtype == torch.float32 and grad_total.numel() == 1
+    out = torch.empty((16 + 2 * 4096,), dtype=torch.float32, device=frames.device)      # [0..9] results, [16..] per-workgroup partial sums
+    dz = torch.empty(frames.shape, dtype=dz_dtype, device=frames.device)
+    ds_old = torch.empty_like(s_old) if s_old is not None else None
+    ds_new = torch.empty_like(s_new) if s_new is not None else None
+    dt0 = torch.empty_like(t0)
+    e0 = _pb()
+    check(_lib.load_library().vs_train_losses_fwd_grad(*args, out.data_ptr(), grad_total.data_ptr(), _ptr(ds_old), _ptr(ds_new), dt0.data_ptr(),
+                                                       ACT[frames_act], dz.data_ptr(), dtype_code(dz), stream_ptr()), 'vs_train_losses_fwd_grad')
+    _pe(e0, 'vs_train_losses_fwd', nbytes=float(2 * frames.numel() * 4 + dz.numel() * dz.element_size()))
+    return out, dz, ds_old, ds_new, dt0
+
+
 def train_losses_bwd(frames, full, idx, s_old, s_new, t0, lambdas, average_tloss, grad_total, frames_act=None, dz_dtype=None):
     """-> (dframes, ds_old, ds_new, dt0).  With `frames_act` (the activation whose outputs `frames` are) the first result is instead
     the gradient of that activation's input, dframes * act'(frames), in `dz_dtype`."""

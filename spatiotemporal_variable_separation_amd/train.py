@@ -317,6 +317,8 @@ class GraphedStep:
         else:
             self.opt.zero_grad(set_to_none=True)
         VF.enable_side_streams(self.side_streams)
+        up = self._one if self.scaler is None else self.scaler.scale_tensor()
+        VF.promise_loss_gradient(up if (self.mlp and os.environ.get('VARSEP_LOSS_ONE_PASS', '1') == '1') else None)
         try:
             if self.mlp:
                 total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
@@ -325,9 +327,10 @@ class GraphedStep:
                 total, _, _, _ = compute_losses(self.cond, self.target, self.net, nt_cond, nt_pred, offset, self.skipco, l_ae, l_s,
                                                 l_t, l_pred, avg, t_random=self.t_dev)
             # a resident 1.0 (no ones_like fill per step), or the loss scale of fp16 training (train.py:152 scaler.scale(loss))
-            total.backward(self._one if self.scaler is None else self.scaler.scale_tensor())
+            total.backward(up)
             VF.join_side_streams()
         finally:
+            VF.promise_loss_gradient(None)
             VF.enable_side_streams(False)
             VF.set_grad_outputs(None)
         return total.detach()
