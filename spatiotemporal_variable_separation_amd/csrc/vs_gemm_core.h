@@ -386,11 +386,16 @@ Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1) 
     // few-tile problems go to split-K, where larger tiles mean fewer fp32 slabs.
     const int64_t t128 = vs_cdiv(M, 128) * vs_cdiv(N, 128);
     const int64_t t12864 = vs_cdiv(M, 128) * vs_cdiv(N, 64);
+    // 128x64 only from ~2.3 tiles per CU upwards.  Below that the step is faster with 64x64 tiles although the isolated kernel is
+    // not (WaveEq B=128, whole recorded step: 1.51 -> 1.43 ms; 3328x1200 outputs are 494 tiles of 128x64 but 988 of 64x64, and
+    // the 256x1200 encoder outputs 38 against 76): the launches overlap with the gradient branches, where more and lighter
+    // workgroups fill the CUs the neighbours leave.  VS_GEMM_T64_BELOW moves the threshold (0 = the round-1 rule).
+    static const int64_t t64_below = getenv("VS_GEMM_T64_BELOW") ? atoll(getenv("VS_GEMM_T64_BELOW")) : 600;
     if (const char* f = getenv("VS_GEMM_TILE")) {                       // debugging aid: force a tile ("128x128", "128x64", "64x64")
         p.bm = atoi(f); const char* x = strchr(f, 'x'); p.bn = x ? atoi(x + 1) : p.bm;
     } else if (K <= 512 && t128 >= 256) { p.bm = 64; p.bn = 64; }      // short K: prologue/epilogue bound, many small tiles win
     else if (t128 >= 1024) { p.bm = 128; p.bn = 128; }                 // >= 4 big tiles per CU: best LDS reuse
-    else if ((t12864 >= 160 || vs_cdiv(M, 64) * vs_cdiv(N, 64) < 256) && M > 64) { p.bm = 128; p.bn = 64; }
+    else if ((t12864 >= 160 || vs_cdiv(M, 64) * vs_cdiv(N, 64) < 256) && M > 64 && t12864 >= t64_below) { p.bm = 128; p.bn = 64; }
     else { p.bm = 64; p.bn = 64; }
     if (M <= 64) p.bm = 64;
     if (N <= 64) p.bn = 64;
