@@ -165,6 +165,19 @@ size_t vs_conv_k3_tap_packed_elems(int Cin, int Cout);
 int vs_conv_k3_tap_pack_weight(int compute, const float* w, int Cin, int Cout, int flip, void* dst, void* stream);
 int vs_conv_k3s1_tap_fwd(int compute, const void* x, const void* w_tap, const float* bias, void* y, int y_dtype, double* bn_sums, int B,
                          int Cin, int H, int W, int Cout, int groups, void* stream);
+/* Conv2d k3 s1 p1 on a FEW 16x16 maps with many channels -- the ConvResnet integrator of the SST recipe (ConvResBlock resnet.py:53-70:
+ * 64 -> 512 -> 512 -> 64 on 8 maps, applied once per predicted frame) -- as ONE launch that fills the chip: workgroup = (image, 32 output
+ * channels, split of the input channels), the split's channels of the image in LDS, weights streamed in MFMA fragment order from the
+ * pre-pack, the x shift of the taps taken on the result.  The split partial sums go to fp32 slabs
+ * [vs_conv3_img16_splits(B, Cin, Cout)][B][Cout][256] WITHOUT bias; vs_bn_train_fwd_small_slabs (conv bias + BatchNorm + activation)
+ * or vs_slab_sum (bias, output type) consume them.  Input gradient: the same call on dz with the weight packed with flip = 1,
+ * Cin := the conv's Cout, Cout := the conv's Cin.  Cin must be a multiple of 64.                                                  */
+int vs_conv3_img16_supported(int compute, int B, int Cin, int H, int W, int Cout);
+int vs_conv3_img16_splits(int B, int Cin, int Cout);
+size_t vs_conv3_img16_packed_elems(int Cin, int Cout);
+int vs_conv3_img16_pack_weight(int compute, const float* w, int Cin, int Cout, int flip, void* dst, void* stream);
+int vs_conv3_img16(int compute, const void* x, const void* w_packed, float* slabs, int B, int Cin, int Cout, void* stream);
+int vs_slab_sum(const float* slabs, int nslabs, const float* bias, void* out, int out_dtype, int B, int C, int64_t HW, void* stream);
 int vs_bn_stats_from_sums(const double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* var_scratch,
                           float* running_mean, float* running_var, float momentum, float eps, void* stream);
 
@@ -435,6 +448,11 @@ int vs_bn_train_fwd_small_supported(int x_dtype, int B, int C, int64_t HW);
 int vs_bn_train_fwd_small(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int act, float* mean,
                           float* invstd, float* running_mean, float* running_var, float momentum, float eps, int B, int C, int64_t HW,
                           void* stream);
+/* vs_bn_train_fwd_small on the split slabs of vs_conv3_img16: z = round(sum of the slabs + bias[c]) in the 16-bit z_dtype is written
+ * (vs_bn_act_bwd needs it), everything else as above.                                                                          */
+int vs_bn_train_fwd_small_slabs(const float* slabs, int nslabs, const float* bias, void* z, int z_dtype, void* y, int y_dtype, const float* gamma,
+                                const float* beta, int act, float* mean, float* invstd, float* running_mean, float* running_var,
+                                float momentum, float eps, int B, int C, int64_t HW, void* stream);
 int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream);
 int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd, const float* gamma,

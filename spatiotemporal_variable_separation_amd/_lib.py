@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvarsep_hip.so')
-SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip', 'vs_conv_tap.hip', 'vs_metrics.hip']
+SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip', 'vs_conv_tap.hip', 'vs_metrics.hip', 'vs_conv_img.hip']
 
 F32, BF16, F16 = 0, 1, 2
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
@@ -135,6 +135,14 @@ SIGNATURES = {
     'vs_conv2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _vp]),
     'vs_conv2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
     'vs_frame_metrics': (_i32, [_vp, _vp, _i64, _i32, _i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
+    'vs_conv3_img16_supported': (_i32, [_i32] * 6),
+    'vs_conv3_img16_splits': (_i32, [_i32] * 3),
+    'vs_conv3_img16_packed_elems': (_sz, [_i32, _i32]),
+    'vs_conv3_img16_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'vs_conv3_img16': (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'vs_slab_sum': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    'vs_bn_train_fwd_small_slabs': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
+                                           _i32, _i32, _i64, _vp]),
     'vs_bn_train_fwd_small_supported': (_i32, [_i32, _i32, _i32, _i64]),
     'vs_bn_train_fwd_small': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32, _i32, _i64, _vp]),
     'vs_conv2d_wgrad_acc': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _i32, _vp]),

@@ -1,0 +1,256 @@
+// vs_conv_img.hip -- Conv2d k3 s1 p1 on a FEW 16x16 images with many channels (gfx950 only).
+//
+// The SST recipe's ConvResnet integrator (resnet.py:53-88 of the reference) applies 64 -> 512 -> 512 -> 64 convolutions to a
+// batch of 8 maps of 16 x 16 pixels, 78 times per training step each way.  One such convolution is 1-10 GFLOP on 2048 pixels:
+// as "column matrix + GEMM" or as the tap GEMM of vs_conv_tap.hip it is a chain of 10-45 us launches that fill a fraction of
+// the chip.  This kernel is shaped for that case:
+//   * workgroup = (image, 32 output channels, split of the input channels); 4 waves, wave w owns the image rows 4w .. 4w+3
+//     (two 32-pixel MFMA column tiles).  8 images x 16 channel tiles x 2 splits = 256 workgroups for 512 -> 512.
+//   * the split's input channels of the image go to LDS ONCE as [channel][18 rows][16 px] (zero rows above and below): up to
+//     256 channels = 144 KiB, no ring, one barrier.
+//   * the x shift of a tap is taken on the OUTPUT side: G_kx[m][y][x] = sum_{c, ky} W[m][c][ky][kx] X[c][y + ky - 1][x] needs
+//     the pixel operand unshifted in x, so one transposing LDS read (ds_read_b64_tr_b16 pair) of the rows y + ky - 1 serves the
+//     three kx taps, and out[y][x] = G_0[x - 1] + G_1[x] + G_2[x + 1] is two DPP row shifts per accumulator register in the
+//     epilogue (a 16-lane DPP row IS an image row of the MFMA result; shifted-in lanes read 0 = the zero padding).
+//   * the weights never touch LDS: they are pre-packed in MFMA fragment order (vs_conv3_img16_pack_weight), every lane loads
+//     its 16 bytes of a fragment straight from global memory, twelve (chunk, ky) groups = 36 fragments ahead of their use
+//     (the four waves of a workgroup read the same fragments: L1 hits).
+//   * split partial sums go to fp32 slabs [split][B][Cout][256]; the consumer adds them: vs_bn_train_fwd_small_slabs (bias +
+//     16-bit rounding + BatchNorm statistics + running update + affine + activation in one launch, vs_norm.hip) or vs_slab_sum.
+// The input gradient is the same kernel on dz with the weight packed transposed and flipped (flip = 1).
+#include "vs_gemm_core.h"
+
+namespace {
+
+constexpr int IMG_CPITCH = 288;          // LDS elements per channel: 18 rows x 16 pixels
+constexpr int IMG_AHEAD = 12;            // (chunk, ky) groups of weight fragments in flight = 4 chunks of 16 channels
+
+__device__ __forceinline__ float dpp_row_shr1(float v) {      // lane i <- lane i - 1 inside its 16-lane row, 0 into lane 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_row_shl1(float v) {      // lane i <- lane i + 1, 0 into lane 15
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+
+// Weight fragments: three 1 KiB wave loads (the kx taps of one (chunk, ky) group) written as asm so that they STAY where they are
+// issued -- twelve groups ahead of their use; left to the compiler the loads sink to just in front of the MFMAs that read them and
+// every group waits for a full L2 round trip.  The loads are invisible to the compiler's counter tracking, so the matching wait is
+// written out too: at the use of a group exactly (IMG_AHEAD - 1) * 3 = 33 younger fragment loads are outstanding.  The wait names
+// the registers as in/out operands: the MFMAs that read them cannot be scheduled above it.
+__device__ __forceinline__ void img_load3(u32x4& a0, u32x4& a1, u32x4& a2, const void* sbase, unsigned voff) {
+    asm volatile("global_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:1024\n\tglobal_load_dwordx4 %2, %3, %4 offset:2048"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2)
+                 : "v"(voff), "s"(sbase)
+                 : "memory");
+}
+__device__ __forceinline__ void img_wait3(u32x4& a0, u32x4& a1, u32x4& a2) {
+    static_assert((IMG_AHEAD - 1) * 3 == 33, "the wait count is written into the instruction");
+    asm volatile("s_waitcnt vmcnt(33)" : "+v"(a0), "+v"(a1), "+v"(a2) : : "memory");
+}
+
+// NP 16-byte pieces per thread of the staged image: piece u = channel (u >> 5), 8 pixels (u & 31) -> the channel's rows 1 .. 16 in LDS
+template <int NP>
+__device__ __forceinline__ void img_stage(unsigned short* xs, const unsigned short* xb, int u0) {
+    u32x4 v[NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) v[r] = *reinterpret_cast<const u32x4*>(xb + (int64_t)(u0 + r * 256) * 8);
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+        const int u = u0 + r * 256;
+        *reinterpret_cast<u32x4*>(xs + (u >> 5) * IMG_CPITCH + 16 + (u & 31) * 8) = v[r];
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void conv3_img16_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, float* __restrict__ slabs,
+                                                          int B, int Cin, int Cout, int cs, int splits, int mtiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [cs][18][16]
+    int id = blockIdx.x;
+    const int split = id % splits;
+    id /= splits;
+    const int mt = id % mtiles, b = id / mtiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = split * cs;
+
+    // ---- weight fragments of the first twelve (chunk, ky) groups: requested first, they travel while the image is staged -----
+    // group g, tap column kx: 1 KiB of fragments at wbase + g * 3072 + kx * 1024 (+ lane * 16)
+    const int chunks_total = Cin >> 4;
+    const char* wbase = reinterpret_cast<const char*>(Wp + ((int64_t)(mt * chunks_total + (c0 >> 4)) * 3) * 192);
+    const unsigned voff = lane * 16;
+    u32x4 a[IMG_AHEAD][3];
+#pragma unroll
+    for (int gg = 0; gg < IMG_AHEAD; ++gg) img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + gg * 3072, voff);
+
+    // ---- the split's channels of image b -> LDS (16-byte pieces: 32 per channel), halo rows zeroed ----------------------
+    const unsigned short* xb = X + ((int64_t)b * Cin + c0) * 256;
+    const int pieces = cs * 32;
+    int base = 0;
+    for (; base + 4096 <= pieces; base += 4096) img_stage<16>(xs, xb, base + tid);          // pieces is a multiple of 2048 (cs % 64 == 0)
+    if (base < pieces) img_stage<8>(xs, xb, base + tid);
+    for (int u = tid; u < cs * 4; u += 256) {
+        const int cl = u >> 2, h = u & 3;
+        *reinterpret_cast<u32x4*>(xs + cl * IMG_CPITCH + (h >> 1) * 17 * 16 + (h & 1) * 8) = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[kx][j][v] = 0.f;
+
+    // transposing read: lane 4q + p of a 16-lane group supplies k-row q, pixels 4p .. 4p + 3; cb = image row of the pair, h = k half
+    const int li = lane & 15, q = li >> 2, p = li & 3, cb = (lane >> 4) & 1, h = lane >> 5;
+    const unsigned short* lb = xs + (8 * h + q) * IMG_CPITCH + (4 * wave + cb) * 16 + 4 * p;
+
+    const int ngroups = (cs >> 4) * 3;                                            // (chunk, ky) groups of this split
+
+    for (int g0 = 0; g0 < ngroups; g0 += IMG_AHEAD) {
+        const unsigned short* lc = lb + (g0 / 3) * 16 * IMG_CPITCH;
+#pragma unroll
+        for (int gg = 0; gg < IMG_AHEAD; ++gg) {
+            const int ch = gg / 3, ky = gg % 3;
+            u32x4 bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = vs_tr16_pair(lc + ch * 16 * IMG_CPITCH + (2 * j + ky) * 16, 4 * IMG_CPITCH);
+            img_wait3(a[gg][0], a[gg][1], a[gg][2]);                              // all but the 33 youngest fragment loads have landed
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[kx][j] = mfma16_32<CT>(a[gg][kx], bf[j], acc[kx][j]);
+            int gn = g0 + IMG_AHEAD + gg;                                         // the group this register set serves next
+            if (gn > ngroups - 1) gn = ngroups - 1;                               // past the end: a harmless repeat of the last group
+            img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + (int64_t)gn * 3072, voff);
+        }
+    }
+
+    // ---- out[y][x] = G_1[x] + G_0[x - 1] + G_2[x + 1], fp32 slab of this split ------------------------------------------
+    float* out = slabs + (((int64_t)split * B + b) * Cout) * 256;
+    const int mrow = mt * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pix = (4 * wave + 2 * j) * 16 + (lane & 31);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float o = acc[1][j][v] + dpp_row_shr1(acc[0][j][v]) + dpp_row_shl1(acc[2][j][v]);
+            const int m = mrow + (v & 3) + 8 * (v >> 2);
+            if (m < Cout) out[(int64_t)m * 256 + pix] = o;
+        }
+    }
+}
+
+// Wp[mt][chunk][ky][kx][lane][8]: lane (r = lane & 31, h = lane >> 5) holds W[m = 32 mt + r][c = 16 chunk + 8 h .. + 7][ky][kx]
+// (flip = 0, w = [M][K][3][3]) or, for the input gradient (flip = 1, w = the conv's [K][M][3][3]), w[c][m][2 - ky][2 - kx]
+template <int CT>
+__global__ __launch_bounds__(256) void conv3_img16_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int M, int K, int flip, int64_t total) {
+    const int chunks = K >> 4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int jj = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        int64_t t = e >> 9;
+        const int kx = (int)(t % 3); t /= 3;
+        const int ky = (int)(t % 3); t /= 3;
+        const int chunk = (int)(t % chunks), mt = (int)(t / chunks);
+        const int m = mt * 32 + (lane & 31), c = chunk * 16 + 8 * (lane >> 5) + jj;
+        float v = 0.f;
+        if (m < M)
+            v = flip ? w[(((int64_t)c * M + m) * 3 + (2 - ky)) * 3 + (2 - kx)] : w[(((int64_t)m * K + c) * 3 + ky) * 3 + kx];
+        dst[e] = vs_f2h(v, CT);
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslabs, int64_t total, const float* __restrict__ bias, int C,
+                                                       int HW, void* __restrict__ out, int od) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
+        for (int k = 1; k < nslabs; ++k) {                                         // fixed order: reproducible
+            const f32x4 t = *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * total + i);
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        if (bias) {
+            const float bv = bias[(i / HW) % C];
+            s[0] += bv; s[1] += bv; s[2] += bv; s[3] += bv;
+        }
+        if (od == VS_F32) *reinterpret_cast<f32x4*>((float*)out + i) = s;
+        else *reinterpret_cast<u16x4*>((unsigned short*)out + i) = u16x4{vs_f2h(s[0], od), vs_f2h(s[1], od), vs_f2h(s[2], od), vs_f2h(s[3], od)};
+    }
+}
+
+// input-channel splits: enough workgroups to cover the chip once, at most 256 channels (144 KiB of LDS) per split, >= 64 per split
+int img16_splits(int B, int Cin, int Cout) {
+    const int64_t base = (int64_t)B * vs_cdiv(Cout, 32);
+    int s = 1;
+    while (Cin / s > 256 || (base * s < 256 && Cin / (2 * s) >= 64)) {
+        if ((Cin / s) % 128 != 0) break;                                           // halving would leave a split that is not a multiple of 64
+        s *= 2;
+    }
+    return s;
+}
+
+}  // namespace
+
+extern "C" int vs_conv3_img16_supported(int compute, int B, int Cin, int H, int W, int Cout) {
+    if (!vs_is16(compute) || H != 16 || W != 16 || B < 1 || Cout < 1 || Cin < 64 || Cin % 64 != 0) return 0;
+    const int s = img16_splits(B, Cin, Cout);
+    if (Cin % s != 0 || (Cin / s) % 64 != 0 || Cin / s > 256) return 0;
+    if ((int64_t)B * vs_cdiv(Cout, 32) * s >= (1ll << 31)) return 0;
+    return 1;
+}
+
+extern "C" int vs_conv3_img16_splits(int B, int Cin, int Cout) { return img16_splits(B, Cin, Cout); }
+
+extern "C" size_t vs_conv3_img16_packed_elems(int Cin, int Cout) { return (size_t)vs_cdiv(Cout, 32) * (size_t)(Cin / 16) * 9 * 512; }
+
+// flip = 0: w is the Conv2d weight [Cout][Cin][3][3].  flip = 1 (input gradient): pass the SAME tensor with Cin := the conv's Cout
+// (the contraction) and Cout := the conv's Cin (the rows).
+extern "C" int vs_conv3_img16_pack_weight(int compute, const float* w, int Cin, int Cout, int flip, void* dst, void* stream) {
+    VS_CHECK_ARG(vs_is16(compute) && w && dst && Cin >= 16 && Cin % 16 == 0 && Cout > 0, "vs_conv3_img16_pack_weight: bad argument");
+    const int64_t total = (int64_t)vs_conv3_img16_packed_elems(Cin, Cout);
+    int64_t blocks = vs_cdiv(total, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (compute == VS_BF16)
+        hipLaunchKernelGGL(conv3_img16_pack_kernel<VS_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)dst, Cout, Cin, flip, total);
+    else
+        hipLaunchKernelGGL(conv3_img16_pack_kernel<VS_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)dst, Cout, Cin, flip, total);
+    VS_CHECK_LAUNCH("vs_conv3_img16_pack_weight");
+    return VS_OK;
+}
+
+// x [B][Cin][16][16] (16-bit), w_packed from vs_conv3_img16_pack_weight -> slabs [vs_conv3_img16_splits][B][Cout][256] fp32 (no bias)
+extern "C" int vs_conv3_img16(int compute, const void* x, const void* w_packed, float* slabs, int B, int Cin, int Cout, void* stream) {
+    VS_CHECK_ARG(x && w_packed && slabs, "vs_conv3_img16: bad argument");
+    VS_CHECK_ARG(vs_conv3_img16_supported(compute, B, Cin, 16, 16, Cout), "vs_conv3_img16: unsupported geometry (query vs_conv3_img16_supported)");
+    VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)slabs) % 16 == 0, "vs_conv3_img16: operands must be 16-byte aligned");
+    const int splits = img16_splits(B, Cin, Cout), cs = Cin / splits, mtiles = (int)vs_cdiv(Cout, 32);
+    const size_t lds = (size_t)cs * IMG_CPITCH * 2;
+    auto kb = conv3_img16_kernel<VS_BF16>;
+    auto kh = conv3_img16_kernel<VS_F16>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * IMG_CPITCH * 2) != hipSuccess ||
+            hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * IMG_CPITCH * 2) != hipSuccess)
+            return vs_fail(VS_ERR_LAUNCH, "vs_conv3_img16: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)((int64_t)B * mtiles * splits));
+    if (compute == VS_BF16)
+        hipLaunchKernelGGL(kb, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)x, (const u32x4*)w_packed, slabs, B, Cin, Cout, cs, splits, mtiles);
+    else
+        hipLaunchKernelGGL(kh, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)x, (const u32x4*)w_packed, slabs, B, Cin, Cout, cs, splits, mtiles);
+    VS_CHECK_LAUNCH("vs_conv3_img16");
+    return VS_OK;
+}
+
+// out[b][c][p] = sum_s slabs[s][b][c][p] (+ bias[c]) in out_dtype; `total` = B * C * HW elements per slab (a multiple of 4)
+extern "C" int vs_slab_sum(const float* slabs, int nslabs, const float* bias, void* out, int out_dtype, int B, int C, int64_t HW, void* stream) {
+    VS_CHECK_ARG(slabs && out && nslabs >= 1 && B > 0 && C > 0 && HW > 0 && HW % 4 == 0 && vs_dtype_ok(out_dtype), "vs_slab_sum: bad argument");
+    VS_CHECK_ARG(((uintptr_t)slabs | (uintptr_t)out) % 16 == 0, "vs_slab_sum: operands must be 16-byte aligned");
+    const int64_t total = (int64_t)B * C * HW;
+    int64_t blocks = vs_cdiv(total, 1024);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, total, bias, C, (int)HW, out, out_dtype);
+    VS_CHECK_LAUNCH("vs_slab_sum");
+    return VS_OK;
+}

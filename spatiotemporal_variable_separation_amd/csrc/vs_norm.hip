@@ -533,7 +533,8 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const void* dy, const
 template <int NV>
 __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd, void* y, int yd, const float* gamma, const float* beta, int act,
                                                           float* mean, float* invstd, float* rmean, float* rvar, float momentum, float eps, int B,
-                                                          int C, int HW) {
+                                                          int C, int HW, const float* slabs = nullptr, int nslabs = 0, const float* bias = nullptr,
+                                                          void* z = nullptr) {
     __shared__ double red[16];
     const int c = blockIdx.x;
     const int w = xd == VS_F32 ? 4 : 8;
@@ -546,7 +547,29 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd
         const int i = threadIdx.x + r * 256;
         if (i < nvec) {
             const int b = i / per, p = (i - b * per) * w;
-            const int cnt = ld_vec(x, xd, ((int64_t)b * C + c) * (int64_t)HW + p, xv[r]);
+            const int64_t idx = ((int64_t)b * C + c) * (int64_t)HW + p;
+            int cnt = 8;
+            if (slabs) {
+                // the convolution left split partial sums (fp32 slabs of the whole tensor): z = round16(sum of the slabs in order + bias) is
+                // stored for backward and normalised here (xd is the 16-bit type of z: 8 elements per thread and round)
+                const int64_t stride = (int64_t)B * C * HW;
+                f32x4 lo = *reinterpret_cast<const f32x4*>(slabs + idx), hi = *reinterpret_cast<const f32x4*>(slabs + idx + 4);
+                for (int k = 1; k < nslabs; ++k) {
+                    const f32x4 l2 = *reinterpret_cast<const f32x4*>(slabs + k * stride + idx), h2 = *reinterpret_cast<const f32x4*>(slabs + k * stride + idx + 4);
+                    lo[0] += l2[0]; lo[1] += l2[1]; lo[2] += l2[2]; lo[3] += l2[3];
+                    hi[0] += h2[0]; hi[1] += h2[1]; hi[2] += h2[2]; hi[3] += h2[3];
+                }
+                const float bv = bias ? bias[c] : 0.f;
+                u16x8 zb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    zb[j] = vs_f2h((j < 4 ? lo[j] : hi[j - 4]) + bv, xd);
+                    xv[r][j] = vs_h2f(zb[j], xd);
+                }
+                *reinterpret_cast<u16x8*>((unsigned short*)z + idx) = zb;
+            } else {
+                cnt = ld_vec(x, xd, idx, xv[r]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (j < cnt) a += xv[r][j];
@@ -774,6 +797,29 @@ extern "C" int vs_bn_train_fwd_small(const void* x, int x_dtype, void* y, int y_
     else VS_BN_SMALL(8);
 #undef VS_BN_SMALL
     VS_CHECK_LAUNCH("vs_bn_train_fwd_small");
+    return VS_OK;
+}
+
+// The same on the fp32 split slabs [nslabs][B][C][HW] a convolution left (vs_conv3_img16): z = round(sum of the slabs + bias) in z_dtype
+// (16-bit) is written for backward, statistics / running update / affine / activation as vs_bn_train_fwd_small -- the slab reduction,
+// the bias and the BatchNorm forward in one launch.
+extern "C" int vs_bn_train_fwd_small_slabs(const float* slabs, int nslabs, const float* bias, void* z, int z_dtype, void* y, int y_dtype, const float* gamma,
+                                           const float* beta, int act, float* mean, float* invstd, float* running_mean, float* running_var,
+                                           float momentum, float eps, int B, int C, int64_t HW, void* stream) {
+    VS_CHECK_ARG(slabs && nslabs >= 1 && z && y && gamma && beta && mean && invstd && vs_is16(z_dtype) && vs_dtype_ok(y_dtype), "vs_bn_train_fwd_small_slabs: bad argument");
+    VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "vs_bn_train_fwd_small_slabs: running_mean/var must come together");
+    if (!vs_bn_train_fwd_small_supported(z_dtype, B, C, HW) || ((uintptr_t)slabs | (uintptr_t)z | (uintptr_t)y) % 16 != 0)
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_bn_train_fwd_small_slabs: tensor not served (vs_slab_sum + vs_bn_stats + vs_bn_act_fwd)");
+    const int64_t nvec = (int64_t)B * HW / 8;
+#define VS_BN_SMALL(NV)                                                                                                                 \
+    hipLaunchKernelGGL(bn_fwd_small_kernel<NV>, dim3(C), dim3(256), 0, (hipStream_t)stream, (const void*)nullptr, z_dtype, y, y_dtype, gamma, beta, act, mean, \
+                       invstd, running_mean, running_var, momentum, eps, B, C, (int)HW, slabs, nslabs, bias, z)
+    if (nvec <= 256) VS_BN_SMALL(1);
+    else if (nvec <= 512) VS_BN_SMALL(2);
+    else if (nvec <= 1024) VS_BN_SMALL(4);
+    else VS_BN_SMALL(8);
+#undef VS_BN_SMALL
+    VS_CHECK_LAUNCH("vs_bn_train_fwd_small_slabs");
     return VS_OK;
 }
 

@@ -712,6 +712,21 @@ def packed_k3_weight(p, dtype, flip):
     return ent[1]
 
 
+_packed_img = {}
+
+
+def packed_img_weight(p, dtype, flip):
+    """MFMA-fragment pre-pack of a Conv2d k3 s1 p1 weight for `ops.conv3_img16` (forward, or flipped / transposed: input gradient)."""
+    key = (id(p), dtype, bool(flip))
+    ent = _packed_img.get(key)
+    if ent is None or ent[0] != p._version or ent[2] is not p:
+        buf = ent[1] if ent is not None and ent[2] is p else None
+        buf = ops.conv3_img16_pack_weight(p.detach().contiguous(), dtype, flip, out=buf)
+        _packed_img[key] = (p._version, buf, p)
+        return buf
+    return ent[1]
+
+
 class ConvBlock(torch.autograd.Function):
     """conv / transposed conv -> [BatchNorm2d (per-call batch statistics)] -> [activation]  (conv.py:41-60).
 
@@ -734,7 +749,31 @@ class ConvBlock(torch.autograd.Function):
                and ops.convt_tap_supported(xc, w.shape[1], groups))
         k3 = (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
               and ops.conv_k3_tap_supported(xc, w.shape[0], groups))
-        if tap or (k3 and has_bn):
+        # Conv2d k3 s1 p1 on a few 16x16 maps (the SST ConvResnet integrator, resnet.py:53-88): one chip-filling launch that leaves
+        # split partial sums; the slab sum, the bias and the whole BatchNorm forward are the next (single) launch
+        img = (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3 and groups == 1
+               and ops.conv3_img16_supported(xc, w.shape[0]))
+        if img:
+            slabs = ops.conv3_img16(xc, packed_img_weight(w, cdt, False), w.shape[0])
+            if has_bn:
+                if training and ops.bn_small_supported_shape(cdt, xc.shape[0], w.shape[0], 256):
+                    y, z, mean, invstd = ops.bn_train_fwd_small_slabs(slabs, bias, cdt, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar,
+                                                                      momentum, eps)
+                else:
+                    z = ops.slab_sum(slabs, bias, cdt)
+                    if training:
+                        mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=1)
+                    else:
+                        mean = rmean.detach().unsqueeze(0).contiguous()
+                        invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).contiguous()
+                    y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=1)
+                ctx.save_for_backward(xc, z, mean, invstd)
+            else:
+                y = ops.slab_sum(slabs, bias, out_dt)
+                if act not in ('none', None):
+                    ops.act_fwd(y, act, out=y)
+                ctx.save_for_backward(xc, y)
+        elif tap or (k3 and has_bn):
             if tap:
                 z, sums = ops.convt_tap_fwd(xc, packed_tap_weight(w, cdt), bias, w.shape[1], groups=groups, want_sums=training)
             else:
@@ -831,6 +870,10 @@ class ConvBlock(torch.autograd.Function):
             if (not transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4 and ctx.x_dtype == dz.dtype
                     and xc.shape[2] == 2 * dz.shape[2] and xc.shape[3] == 2 * dz.shape[3] and ops.convt_tap_supported(dz, w.shape[1], 1)):
                 dx, _ = ops.convt_tap_fwd(dz, packed_tap_weight(w, cdt), None, w.shape[1], groups=1, want_sums=False, name='vs_conv_dgrad')
+            elif (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3 and groups == 1
+                  and ops.conv3_img16_supported(dz, w.shape[1])):
+                # few 16x16 maps: the same one-launch kernel on dz with the weight packed transposed and flipped
+                dx = ops.slab_sum(ops.conv3_img16(dz, packed_img_weight(w, cdt, True), w.shape[1], name='vs_conv_dgrad'), None, ctx.x_dtype)
             elif (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
                   and ops.conv_k3_tap_supported(dz, w.shape[1], 1)):
                 # Conv2d k3 s1 p1: the input gradient is the same convolution of dz with the weight transposed and flipped

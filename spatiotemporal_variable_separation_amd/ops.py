@@ -563,6 +563,59 @@ def conv_k3_tap_supported(x, Cout, groups, force=False):
     return bool(_lib.load_library().vs_conv_k3_tap_supported(dtype_code(x), B, Cin, H, W, Cout, groups))
 
 
+def conv3_img16_supported(x, Cout):
+    """Whether Conv2d k3 s1 p1 on `x` takes the few-images kernel (`conv3_img16`): 16x16 maps, 16-bit, Cin a multiple of 64 and a batch
+    small enough that the per-image tiling pays (the SST integrator: 8 maps).  VS_CONV_IMG=0: never."""
+    import os
+    if os.environ.get('VS_CONV_IMG') == '0' or x.dtype == torch.float32 or x.dim() != 4:
+        return False
+    B, Cin, H, W = x.shape
+    if B > 32:
+        return False
+    return bool(_lib.load_library().vs_conv3_img16_supported(dtype_code(x), B, Cin, H, W, Cout))
+
+
+def conv3_img16_pack_weight(w_master, dtype, flip, out=None):
+    """fp32 Conv2d weight [Cout, Cin, 3, 3] -> MFMA-fragment order for `conv3_img16` in `dtype`.  flip=False: forward (rows = Cout,
+    contraction = Cin); flip=True: input gradient (rows = Cin, contraction = Cout, taps flipped)."""
+    require_cuda(w_master)
+    assert w_master.dtype == torch.float32 and w_master.is_contiguous() and tuple(w_master.shape[2:]) == (3, 3)
+    Cout, Cin = w_master.shape[0], w_master.shape[1]
+    M, K = (Cin, Cout) if flip else (Cout, Cin)
+    lib = _lib.load_library()
+    if out is None:
+        out = torch.empty((lib.vs_conv3_img16_packed_elems(K, M),), dtype=dtype, device=w_master.device)
+    check(lib.vs_conv3_img16_pack_weight(code_of(dtype), w_master.data_ptr(), K, M, int(bool(flip)), out.data_ptr(), stream_ptr()),
+          'vs_conv3_img16_pack_weight')
+    return out
+
+
+def conv3_img16(x, w_packed, Cout, name='vs_conv_fwd'):
+    """Conv2d k3 s1 p1 of x [B, Cin, 16, 16] -> fp32 split slabs [S, B, Cout, 16, 16] WITHOUT bias (S = vs_conv3_img16_splits); consumers:
+    `bn_train_fwd_small_slabs`, `slab_sum`."""
+    require_cuda(x, w_packed)
+    assert x.is_contiguous() and x.dtype == w_packed.dtype
+    B, Cin, H, W = x.shape
+    lib = _lib.load_library()
+    S = lib.vs_conv3_img16_splits(B, Cin, Cout)
+    slabs = torch.empty((S, B, Cout, H, W), dtype=torch.float32, device=x.device)
+    e0 = _pb()
+    check(lib.vs_conv3_img16(dtype_code(x), x.data_ptr(), w_packed.data_ptr(), slabs.data_ptr(), B, Cin, Cout, stream_ptr()), 'vs_conv3_img16')
+    _pe(e0, '%s<%s>' % (name, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
+        nbytes=float(x.numel() * x.element_size() + w_packed.numel() * 2 + slabs.numel() * 4))
+    return slabs
+
+
+def slab_sum(slabs, bias, out_dtype):
+    """sum over the leading (split) axis of fp32 slabs [S, B, C, H, W] (+ bias[c]) -> [B, C, H, W] in out_dtype, one launch."""
+    require_cuda(slabs)
+    S, B, C = slabs.shape[0], slabs.shape[1], slabs.shape[2]
+    HW = slabs.numel() // (S * B * C)
+    out = torch.empty(slabs.shape[1:], dtype=out_dtype, device=slabs.device)
+    check(_lib.load_library().vs_slab_sum(slabs.data_ptr(), S, _ptr(bias), out.data_ptr(), dtype_code(out), B, C, HW, stream_ptr()), 'vs_slab_sum')
+    return out
+
+
 def conv_k3_tap_pack_weight(w_master, dtype, flip, out=None):
     """fp32 Conv2d weight [Cout, Cin, 3, 3] -> tap-GEMM rows [ceil(M/28), 9 taps x 28 channels (256 rows), K] in `dtype`.
     flip=False: forward (M = Cout, K = Cin).  flip=True: input gradient (M = Cin, K = Cout, taps flipped)."""
@@ -628,6 +681,11 @@ def bn_small_supported(x):
     return x.is_contiguous() and bool(_lib.load_library().vs_bn_train_fwd_small_supported(dtype_code(x), B, C, x.numel() // (B * C)))
 
 
+def bn_small_supported_shape(dtype, B, C, HW):
+    """`bn_small_supported` for a tensor that does not exist yet ([B, C, ...] of HW elements per plane in `dtype`)."""
+    return bool(_lib.load_library().vs_bn_train_fwd_small_supported(code_of(dtype), B, C, HW))
+
+
 def bn_train_fwd_small(x, gamma, beta, act, out_dtype, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     """Training-mode BatchNorm + activation of one call in ONE launch (small tensors).  Returns (y, mean [1, C], invstd [1, C])."""
     require_cuda(x)
@@ -642,6 +700,25 @@ def bn_train_fwd_small(x, gamma, beta, act, out_dtype, running_mean=None, runnin
                                                     float(momentum), float(eps), B, C, HW, stream_ptr()), 'vs_bn_train_fwd_small')
     _pe(e0, 'vs_bn_act_fwd', nbytes=float(x.numel() * (x.element_size() + y.element_size())))
     return y, mean, invstd
+
+
+def bn_train_fwd_small_slabs(slabs, bias, z_dtype, gamma, beta, act, out_dtype, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """`bn_train_fwd_small` on the split slabs [S, B, C, H, W] (fp32) of `conv3_img16`: the slab sum, the conv bias, the 16-bit rounding of
+    the conv output z and the BatchNorm forward in one launch.  Returns (y, z, mean [1, C], invstd [1, C])."""
+    require_cuda(slabs)
+    S, B, C = slabs.shape[0], slabs.shape[1], slabs.shape[2]
+    HW = slabs.numel() // (S * B * C)
+    z = torch.empty(slabs.shape[1:], dtype=z_dtype, device=slabs.device)
+    y = torch.empty(slabs.shape[1:], dtype=out_dtype, device=slabs.device)
+    mean = torch.empty((1, C), dtype=torch.float32, device=slabs.device)
+    invstd = torch.empty((1, C), dtype=torch.float32, device=slabs.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_bn_train_fwd_small_slabs(slabs.data_ptr(), S, _ptr(bias), z.data_ptr(), dtype_code(z), y.data_ptr(), dtype_code(y),
+                                                          gamma.data_ptr(), beta.data_ptr(), ACT[act], mean.data_ptr(), invstd.data_ptr(),
+                                                          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), B, C, HW,
+                                                          stream_ptr()), 'vs_bn_train_fwd_small_slabs')
+    _pe(e0, 'vs_bn_act_fwd', nbytes=float(slabs.numel() * 4 + z.numel() * (z.element_size() + y.element_size())))
+    return y, z, mean, invstd
 
 
 def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype, groups=1):

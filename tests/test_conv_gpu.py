@@ -387,3 +387,65 @@ def test_conv_wgrad_accumulates_into_an_existing_gradient(dtype, transposed, geo
     torch.cuda.synchronize()
     ref = base.double() + 2 * fresh.double()
     assert ((acc.double() - ref).norm() / ref.norm()).item() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom', [
+    (8, 512, 512),            # ConvResBlock of the SST integrator (resnet.py:53-70), middle conv: 2 splits of 256 channels
+    (8, 64, 512),             # first conv: one split, one pass of 12 fragment groups
+    (8, 512, 64),             # last conv: 8 splits of 64 channels
+    (3, 128, 40),             # ragged output-channel tile (40 = 32 + 8), 2 splits
+    (1, 192, 96),             # 192 channels in one split (three passes), a single map
+    (32, 64, 33),             # the largest batch the few-maps path takes
+])
+def test_conv3_img16_forward_and_input_gradient(dtype, geom):
+    """Conv2d k3 s1 p1 on a few 16x16 maps through vs_conv3_img16 (split slabs) + vs_slab_sum: against fp64 conv2d on the same 16-bit
+    operands, the sum of the slabs without bias, the 16-bit output rounding, and the input gradient via the flipped / transposed pack."""
+    from spatiotemporal_variable_separation_amd import ops, _lib
+    B, Cin, Cout = geom
+    x = _rand((B, Cin, 16, 16), 61).to(dtype)
+    w = _rand((Cout, Cin, 3, 3), 62, 0.3).to(dtype)
+    bias = _rand((Cout,), 63)
+    xc = x.cuda()
+    assert ops.conv3_img16_supported(xc, Cout)
+    wp = ops.conv3_img16_pack_weight(w.float().cuda(), dtype, False)
+    slabs = ops.conv3_img16(xc, wp, Cout)
+    assert slabs.shape == (_lib.load_library().vs_conv3_img16_splits(B, Cin, Cout), B, Cout, 16, 16)
+    y32 = ops.slab_sum(slabs, bias.cuda(), torch.float32)
+    y16 = ops.slab_sum(slabs, bias.cuda(), dtype)
+    torch.cuda.synchronize()
+    x64 = x.double().requires_grad_(True)
+    ref = F.conv2d(x64, w.double(), bias.double(), stride=1, padding=1)
+    assert ((y32.cpu().double() - ref.detach()).norm() / ref.detach().norm()).item() < 1e-5
+    assert ((slabs.sum(0).cpu().double() + bias.double().view(1, -1, 1, 1) - ref.detach()).norm() / ref.detach().norm()).item() < 1e-5
+    assert torch.equal(y16.cpu(), y32.cpu().to(dtype))
+    dz = _rand(tuple(ref.shape), 64).to(dtype)
+    ref.backward(dz.double())
+    if ops.conv3_img16_supported(dz.cuda(), Cin):
+        wf = ops.conv3_img16_pack_weight(w.float().cuda(), dtype, True)
+        dx = ops.slab_sum(ops.conv3_img16(dz.cuda(), wf, Cin), None, torch.float32)
+        assert ((dx.cpu().double() - x64.grad).norm() / x64.grad.norm()).item() < 1e-5, f'dgrad {geom} {dtype}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(3, 8, 64), (2, 8, 512), (8, 2, 40)])
+def test_batchnorm_small_from_split_slabs_equals_sum_then_batchnorm(dtype, shape):
+    """vs_bn_train_fwd_small_slabs == vs_slab_sum (bias, 16-bit rounding) followed by vs_bn_train_fwd_small, bit for bit: z, y, batch
+    statistics and running statistics."""
+    from spatiotemporal_variable_separation_amd import ops
+    S, B, C = shape
+    slabs = _rand((S, B, C, 16, 16), 71).cuda()
+    bias = _rand((C,), 72).cuda()
+    gamma, beta = (1 + _rand((C,), 73, 0.3)).cuda(), _rand((C,), 74, 0.2).cuda()
+    rm1, rv1 = _rand((C,), 75, 0.1).cuda(), (1 + _rand((C,), 76, 0.2)).cuda()
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    y1, z1, m1, i1 = ops.bn_train_fwd_small_slabs(slabs, bias, dtype, gamma, beta, 'leaky_relu', dtype, rm1, rv1, 0.1, 1e-5)
+    z2 = ops.slab_sum(slabs, bias, dtype)
+    y2, m2, i2 = ops.bn_train_fwd_small(z2, gamma, beta, 'leaky_relu', dtype, rm2, rv2, 0.1, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z2) and torch.equal(y1, y2)
+    assert torch.equal(m1, m2) and torch.equal(i1, i2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+    y3 = ops.bn_train_fwd_small_slabs(slabs, None, dtype, gamma, beta, 'none', torch.float32, None, None, 0.1, 1e-5)[0]
+    assert y3.dtype == torch.float32 and torch.isfinite(y3).all()
