@@ -177,7 +177,8 @@ int vs_conv3_img16_splits(int B, int Cin, int Cout);
 size_t vs_conv3_img16_packed_elems(int Cin, int Cout);
 int vs_conv3_img16_pack_weight(int compute, const float* w, int Cin, int Cout, int flip, void* dst, void* stream);
 int vs_conv3_img16(int compute, const void* x, const void* w_packed, float* slabs, int B, int Cin, int Cout, void* stream);
-int vs_slab_sum(const float* slabs, int nslabs, const float* bias, void* out, int out_dtype, int B, int C, int64_t HW, void* stream);
+int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,
+                void* stream);
 int vs_bn_stats_from_sums(const double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* var_scratch,
                           float* running_mean, float* running_var, float momentum, float eps, void* stream);
 
@@ -449,10 +450,18 @@ int vs_bn_train_fwd_small(const void* x, int x_dtype, void* y, int y_dtype, cons
                           float* invstd, float* running_mean, float* running_var, float momentum, float eps, int B, int C, int64_t HW,
                           void* stream);
 /* vs_bn_train_fwd_small on the split slabs of vs_conv3_img16: z = round(sum of the slabs + bias[c]) in the 16-bit z_dtype is written
- * (vs_bn_act_bwd needs it), everything else as above.                                                                          */
+ * (vs_bn_act_bwd needs it), everything else as above.  skip / xnew (fp32, both or neither) and xnew16 (z_dtype, optional): the tail of
+ * a residual block (ConvResBlock.forward resnet.py:66-70) -- xnew = skip + y and its 16-bit copy for the next block.           */
 int vs_bn_train_fwd_small_slabs(const float* slabs, int nslabs, const float* bias, void* z, int z_dtype, void* y, int y_dtype, const float* gamma,
                                 const float* beta, int act, float* mean, float* invstd, float* running_mean, float* running_var,
-                                float momentum, float eps, int B, int C, int64_t HW, void* stream);
+                                float momentum, float eps, const float* skip, float* xnew, void* xnew16, int B, int C, int64_t HW,
+                                void* stream);
+/* Backward of the same block in one launch (training mode, one call, 16-bit z): the upstream gradient is the sum of split slabs
+ * (slabs != NULL: what a vs_conv3_img16 input-gradient launch left) or dy_a (+ dy_b, fp32: the two outputs of a residual block,
+ * resnet.py:66-70); accumulate != 0 adds d gamma / d beta to the vectors given (the parameter's pending gradient of this pass).  */
+int vs_bn_act_bwd_small_ex(const void* dy_a, int dy_a_dtype, const float* dy_b, const float* slabs, int nslabs, const void* z, int z_dtype,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta, int act, float* dgamma,
+                           float* dbeta, int accumulate, void* dx, int dx_dtype, int B, int C, int64_t HW, void* stream);
 int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream);
 int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd, const float* gamma,

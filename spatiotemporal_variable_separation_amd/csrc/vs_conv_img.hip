@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void conv3_img16_pack_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslabs, int64_t total, const float* __restrict__ bias, int C,
-                                                       int HW, void* __restrict__ out, int od) {
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslabs, int64_t total, const float* __restrict__ bias,
+                                                       const float* __restrict__ addend, int C, int HW, void* __restrict__ out, int od) {
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
         f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
         for (int k = 1; k < nslabs; ++k) {                                         // fixed order: reproducible
@@ -172,6 +172,10 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
         if (bias) {
             const float bv = bias[(i / HW) % C];
             s[0] += bv; s[1] += bv; s[2] += bv; s[3] += bv;
+        }
+        if (addend) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(addend + i);
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
         }
         if (od == VS_F32) *reinterpret_cast<f32x4*>((float*)out + i) = s;
         else *reinterpret_cast<u16x4*>((unsigned short*)out + i) = u16x4{vs_f2h(s[0], od), vs_f2h(s[1], od), vs_f2h(s[2], od), vs_f2h(s[3], od)};
@@ -243,14 +247,15 @@ extern "C" int vs_conv3_img16(int compute, const void* x, const void* w_packed, 
     return VS_OK;
 }
 
-// out[b][c][p] = sum_s slabs[s][b][c][p] (+ bias[c]) in out_dtype; `total` = B * C * HW elements per slab (a multiple of 4)
-extern "C" int vs_slab_sum(const float* slabs, int nslabs, const float* bias, void* out, int out_dtype, int B, int C, int64_t HW, void* stream) {
+// out[b][c][p] = sum_s slabs[s][b][c][p] (+ bias[c]) (+ addend[b][c][p], fp32) in out_dtype; HW a multiple of 4
+extern "C" int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,
+                           void* stream) {
     VS_CHECK_ARG(slabs && out && nslabs >= 1 && B > 0 && C > 0 && HW > 0 && HW % 4 == 0 && vs_dtype_ok(out_dtype), "vs_slab_sum: bad argument");
-    VS_CHECK_ARG(((uintptr_t)slabs | (uintptr_t)out) % 16 == 0, "vs_slab_sum: operands must be 16-byte aligned");
+    VS_CHECK_ARG(((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)addend) % 16 == 0, "vs_slab_sum: operands must be 16-byte aligned");
     const int64_t total = (int64_t)B * C * HW;
     int64_t blocks = vs_cdiv(total, 1024);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, total, bias, C, (int)HW, out, out_dtype);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, total, bias, addend, C, (int)HW, out, out_dtype);
     VS_CHECK_LAUNCH("vs_slab_sum");
     return VS_OK;
 }

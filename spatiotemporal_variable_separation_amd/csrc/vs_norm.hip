@@ -528,13 +528,90 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const void* dy, const
     }
 }
 
+// The same for the fused residual block (functional.ConvResBlockFn): training mode, one call group, z in a 16-bit type; the upstream
+// gradient is EITHER the split slabs a vs_conv3_img16 input-gradient launch left (summed here in order) OR one or two tensors (dy_a in
+// any type, dy_b fp32: the gradients of the block's two outputs); d gamma / d beta are written or ADDED to a pending gradient.
+template <int NV>
+__global__ __launch_bounds__(256) void bn_bwd_small_ex_kernel(const void* dy_a, int dad, const float* dy_b, const float* slabs, int nslabs, const void* x,
+                                                             int xd, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                                             int act, float* dbeta, float* dgamma, int accumulate, void* dx, int dxd, int B, int C,
+                                                             int HW) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    const int per = HW / 8, nvec = B * per;
+    const float mu = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    const int64_t stride = (int64_t)B * C * HW;
+    float dzv[NV][8], xhv[NV][8];
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int i = threadIdx.x + r * 256;
+        if (i < nvec) {
+            const int b = i / per, p = (i - b * per) * 8;
+            const int64_t idx = ((int64_t)b * C + c) * (int64_t)HW + p;
+            float xv[8], gv[8];
+            ld_vec(x, xd, idx, xv);
+            if (slabs) {
+                f32x4 lo = *reinterpret_cast<const f32x4*>(slabs + idx), hi = *reinterpret_cast<const f32x4*>(slabs + idx + 4);
+                for (int k = 1; k < nslabs; ++k) {
+                    const f32x4 l2 = *reinterpret_cast<const f32x4*>(slabs + k * stride + idx), h2 = *reinterpret_cast<const f32x4*>(slabs + k * stride + idx + 4);
+                    lo[0] += l2[0]; lo[1] += l2[1]; lo[2] += l2[2]; lo[3] += l2[3];
+                    hi[0] += h2[0]; hi[1] += h2[1]; hi[2] += h2[2]; hi[3] += h2[3];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { gv[j] = lo[j]; gv[j + 4] = hi[j]; }
+            } else {
+                if (dad == VS_F32) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>((const float*)dy_a + idx), hi = *reinterpret_cast<const f32x4*>((const float*)dy_a + idx + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { gv[j] = lo[j]; gv[j + 4] = hi[j]; }
+                } else {
+                    ld_vec(dy_a, dad, idx, gv);
+                }
+                if (dy_b) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(dy_b + idx), hi = *reinterpret_cast<const f32x4*>(dy_b + idx + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { gv[j] += lo[j]; gv[j + 4] += hi[j]; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (xv[j] - mu) * is;
+                const float dz = gv[j] * act_grad_from_pre(xh * g + bt, act);
+                xhv[r][j] = xh; dzv[r][j] = dz;
+                a1 += dz; a2 += dz * xh;
+            }
+        }
+    }
+    const double t1 = block_sum((double)a1, red);
+    const double t2 = block_sum((double)a2, red);
+    if (threadIdx.x == 0) {
+        if (accumulate) { dbeta[c] += (float)t1; dgamma[c] += (float)t2; }
+        else { dbeta[c] = (float)t1; dgamma[c] = (float)t2; }
+    }
+    const float inv_n = 1.f / (float)((int64_t)B * HW);
+    const float k1 = (float)t1 * inv_n, k2 = (float)t2 * inv_n;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        const int i = threadIdx.x + r * 256;
+        if (i < nvec) {
+            const int b = i / per, p = (i - b * per) * 8;
+            const int64_t idx = ((int64_t)b * C + c) * (int64_t)HW + p;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = g * is * (dzv[r][j] - k1 - xhv[r][j] * k2);
+            st_vec(dx, dxd, idx, o, 8);
+        }
+    }
+}
+
 // The forward counterpart for ONE call group: batch statistics, running-statistics update, affine + activation in one launch
 // (vs_bn_stats is two launches -- statistics, running update -- and vs_bn_act_fwd a third).  Two-pass variance from registers.
 template <int NV>
 __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd, void* y, int yd, const float* gamma, const float* beta, int act,
                                                           float* mean, float* invstd, float* rmean, float* rvar, float momentum, float eps, int B,
                                                           int C, int HW, const float* slabs = nullptr, int nslabs = 0, const float* bias = nullptr,
-                                                          void* z = nullptr) {
+                                                          void* z = nullptr, const float* skip = nullptr, float* xnew = nullptr, void* xnew16 = nullptr) {
     __shared__ double red[16];
     const int c = blockIdx.x;
     const int w = xd == VS_F32 ? 4 : 8;
@@ -611,7 +688,19 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = vs_act((xv[r][j] - mu) * is * g + bt, act);
-            st_vec(y, yd, ((int64_t)b * C + c) * (int64_t)HW + p, o, w);
+            const int64_t idx = ((int64_t)b * C + c) * (int64_t)HW + p;
+            st_vec(y, yd, idx, o, w);
+            if (skip) {
+                // residual block tail (resnet.py:66-70): the block output skip + y in fp32 and as the next block's 16-bit operand (w == 8)
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(skip + idx), s1 = *reinterpret_cast<const f32x4*>(skip + idx + 4);
+                f32x4 n0, n1;
+                u16x8 nb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { n0[j] = s0[j] + o[j]; n1[j] = s1[j] + o[j + 4]; nb[j] = vs_f2h(n0[j], xd); nb[j + 4] = vs_f2h(n1[j], xd); }
+                *reinterpret_cast<f32x4*>(xnew + idx) = n0;
+                *reinterpret_cast<f32x4*>(xnew + idx + 4) = n1;
+                if (xnew16) *reinterpret_cast<u16x8*>((unsigned short*)xnew16 + idx) = nb;
+            }
         }
     }
 }
@@ -805,15 +894,18 @@ extern "C" int vs_bn_train_fwd_small(const void* x, int x_dtype, void* y, int y_
 // the bias and the BatchNorm forward in one launch.
 extern "C" int vs_bn_train_fwd_small_slabs(const float* slabs, int nslabs, const float* bias, void* z, int z_dtype, void* y, int y_dtype, const float* gamma,
                                            const float* beta, int act, float* mean, float* invstd, float* running_mean, float* running_var,
-                                           float momentum, float eps, int B, int C, int64_t HW, void* stream) {
+                                           float momentum, float eps, const float* skip, float* xnew, void* xnew16, int B, int C, int64_t HW,
+                                           void* stream) {
     VS_CHECK_ARG(slabs && nslabs >= 1 && z && y && gamma && beta && mean && invstd && vs_is16(z_dtype) && vs_dtype_ok(y_dtype), "vs_bn_train_fwd_small_slabs: bad argument");
+    VS_CHECK_ARG((skip == nullptr) == (xnew == nullptr) && (skip || !xnew16), "vs_bn_train_fwd_small_slabs: skip and xnew come together (xnew16 optional)");
+    VS_CHECK_ARG(((uintptr_t)skip | (uintptr_t)xnew | (uintptr_t)xnew16) % 16 == 0, "vs_bn_train_fwd_small_slabs: skip / xnew must be 16-byte aligned");
     VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "vs_bn_train_fwd_small_slabs: running_mean/var must come together");
     if (!vs_bn_train_fwd_small_supported(z_dtype, B, C, HW) || ((uintptr_t)slabs | (uintptr_t)z | (uintptr_t)y) % 16 != 0)
         return vs_fail(VS_ERR_UNSUPPORTED, "vs_bn_train_fwd_small_slabs: tensor not served (vs_slab_sum + vs_bn_stats + vs_bn_act_fwd)");
     const int64_t nvec = (int64_t)B * HW / 8;
 #define VS_BN_SMALL(NV)                                                                                                                 \
     hipLaunchKernelGGL(bn_fwd_small_kernel<NV>, dim3(C), dim3(256), 0, (hipStream_t)stream, (const void*)nullptr, z_dtype, y, y_dtype, gamma, beta, act, mean, \
-                       invstd, running_mean, running_var, momentum, eps, B, C, (int)HW, slabs, nslabs, bias, z)
+                       invstd, running_mean, running_var, momentum, eps, B, C, (int)HW, slabs, nslabs, bias, z, skip, xnew, xnew16)
     if (nvec <= 256) VS_BN_SMALL(1);
     else if (nvec <= 512) VS_BN_SMALL(2);
     else if (nvec <= 1024) VS_BN_SMALL(4);
@@ -876,6 +968,30 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(vec == 1 && x_dtype == dy_dtype ? total / 8 : total / 4)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd,
                        gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, HW, total, training, vec);
     VS_CHECK_LAUNCH("vs_bn_act_bwd apply");
+    return VS_OK;
+}
+
+// Training-mode BatchNorm2d + activation backward of one call on a small 16-bit tensor z (vs_bn_train_fwd_small_supported) in one
+// launch, with the upstream gradient taken from split slabs (slabs != NULL: [nslabs][B][C][HW] fp32, dy_a / dy_b ignored) or from
+// dy_a (+ dy_b, fp32, optional); accumulate != 0 ADDS d gamma / d beta to the given vectors (a pending gradient) instead of storing.
+extern "C" int vs_bn_act_bwd_small_ex(const void* dy_a, int dy_a_dtype, const float* dy_b, const float* slabs, int nslabs, const void* z, int z_dtype,
+                                      const float* mean, const float* invstd, const float* gamma, const float* beta, int act, float* dgamma,
+                                      float* dbeta, int accumulate, void* dx, int dx_dtype, int B, int C, int64_t HW, void* stream) {
+    VS_CHECK_ARG((slabs ? nslabs >= 1 : dy_a != nullptr) && z && mean && invstd && gamma && beta && dgamma && dbeta && dx && vs_is16(z_dtype) &&
+                     vs_dtype_ok(dx_dtype) && (slabs || vs_dtype_ok(dy_a_dtype)), "vs_bn_act_bwd_small_ex: bad argument");
+    if (!vs_bn_train_fwd_small_supported(z_dtype, B, C, HW) ||
+        ((uintptr_t)dy_a | (uintptr_t)dy_b | (uintptr_t)slabs | (uintptr_t)z | (uintptr_t)dx) % 16 != 0)
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_bn_act_bwd_small_ex: tensor not served (vs_bn_act_bwd)");
+    const int64_t nvec = (int64_t)B * HW / 8;
+#define VS_BN_SMALL(NV)                                                                                                                  \
+    hipLaunchKernelGGL(bn_bwd_small_ex_kernel<NV>, dim3(C), dim3(256), 0, (hipStream_t)stream, dy_a, dy_a_dtype, dy_b, slabs, nslabs, z, z_dtype, mean, \
+                       invstd, gamma, beta, act, dbeta, dgamma, accumulate, dx, dx_dtype, B, C, (int)HW)
+    if (nvec <= 256) VS_BN_SMALL(1);
+    else if (nvec <= 512) VS_BN_SMALL(2);
+    else if (nvec <= 1024) VS_BN_SMALL(4);
+    else VS_BN_SMALL(8);
+#undef VS_BN_SMALL
+    VS_CHECK_LAUNCH("vs_bn_act_bwd_small_ex");
     return VS_OK;
 }
 

@@ -712,6 +712,64 @@ def packed_k3_weight(p, dtype, flip):
     return ent[1]
 
 
+def _conv_weight_grad(w, dz, xc, stride, pad, transposed):
+    """Weight gradient of one convolution call for autograd, or None when it was added to / will be batched into the tensor autograd
+    already holds."""
+    # a weight that already holds a gradient from an earlier call of this pass (the integrator's blocks: one call per predicted
+    # frame) gets this call's contribution ADDED in the weight-gradient GEMM's epilogue -- no temporary, no add launch
+    dw = None
+    first_w = _fold_slots().get(id(w)) if _STATE.get('fold_grads') else None
+    if _defer_wgrad_ok(dz, transposed, stride):
+        slot = _DEFER_W['slots'].get(id(w))
+        if slot is None:
+            if first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
+                g = first_w                          # the weight already holds a gradient of this pass: the batch is added to it
+            else:
+                # zeros: the batched gradient is ADDED at the end, so other (non-deferred) calls of the same weight may add to
+                # this tensor in between; autograd gets a tensor of its own on the same storage (it keeps an unshared tensor)
+                buf = torch.zeros((w.numel(),), dtype=torch.float32, device=dz.device)
+                g = buf.view(w.shape)
+                dw = buf.view(w.shape)
+            slot = _DEFER_W['slots'][id(w)] = {'g': g, 'pairs': [], 'shape': tuple(w.shape), 'stride': stride, 'pad': pad,
+                                              'stream': torch.cuda.current_stream()}
+            if not _DEFER_W['queued']:
+                torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_wgrads)
+                _DEFER_W['queued'] = True
+        slot['pairs'].append((dz, xc))
+    elif first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
+        ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed, into=first_w)
+    else:
+        dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed)
+    return dw
+
+
+def _fold_param_grads(pairs):
+    """pairs = ((parameter, gradient or None), ...) of one block -> the gradients to hand to autograd, in order.  In fold mode the FIRST
+    contribution of a parameter in this backward pass goes to autograd (which keeps that very tensor as the parameter's pending
+    gradient); later contributions of the pass are added INTO it with one multi-tensor launch per block and autograd gets nothing for
+    them (otherwise: one add launch per parameter and contribution)."""
+    out = [g for _, g in pairs]
+    if not _STATE.get('fold_grads'):
+        return out
+    acc = _fold_slots()
+    into, what = [], []
+    for i, (prm, g) in enumerate(pairs):
+        if g is None or prm is None:
+            continue
+        first = acc.get(id(prm))
+        if first is None:
+            # a second tensor on the same storage: autograd keeps the tensor it is handed only while nobody else references
+            # it and CLONES it otherwise (one D2D copy per parameter and step: 63 x 5 us in the Moving-MNIST step)
+            acc[id(prm)] = g.detach()
+        elif first.shape == g.shape and first.dtype == g.dtype:
+            into.append(first)
+            what.append(g)
+            out[i] = None
+    if into:
+        torch._foreach_add_(into, what)
+    return out
+
+
 _packed_img = {}
 
 
@@ -725,6 +783,106 @@ def packed_img_weight(p, dtype, flip):
         _packed_img[key] = (p._version, buf, p)
         return buf
     return ent[1]
+
+
+def conv_res_block_fusable(x, convs, bns, cdt=None):
+    """Whether `ConvResBlockFn` serves a ConvResBlock (resnet.py:53-70): three Conv2d k3 s1 p1 + training-mode BatchNorm on a few 16x16
+    maps in a 16-bit compute type, identity skip."""
+    cdt = cdt or compute_dtype()
+    if os.environ.get('VARSEP_FUSED_RESBLOCK', '1') != '1' or cdt == torch.float32 or not x.is_cuda or x.dim() != 4:
+        return False
+    if x.dtype != torch.float32 or not x.is_contiguous() or len(convs) != 3 or convs[2].out_channels != x.shape[1]:
+        return False
+    probe = torch.empty((0,), dtype=cdt, device=x.device)
+    cin = x.shape[1]
+    for conv, bn in zip(convs, bns):
+        if (bn is None or not bn.training or not bn.track_running_stats or tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (1, 1)
+                or tuple(conv.padding) != (1, 1) or conv.in_channels != cin or conv.groups != 1):
+            return False
+        shape_in = (x.shape[0], cin, x.shape[2], x.shape[3])
+        if not ops.conv3_img16_supported(probe.new_empty(shape_in), conv.out_channels):
+            return False
+        if not ops.conv3_img16_supported(probe.new_empty((x.shape[0], conv.out_channels, x.shape[2], x.shape[3])), cin):
+            return False
+        if not ops.bn_small_supported_shape(cdt, x.shape[0], conv.out_channels, x.shape[2] * x.shape[3]):
+            return False
+        cin = conv.out_channels
+    return True
+
+
+class ConvResBlockFn(torch.autograd.Function):
+    """One ConvResBlock (resnet.py:53-70) of the ConvResnet integrator on a few 16x16 maps: x -> (x + r, r), r = BN(conv(act(BN(conv(act(BN(conv
+    x))))))).  Forward = 6 launches (per layer: `ops.conv3_img16` into split slabs, then slab sum + bias + BatchNorm + activation in one;
+    the last one also adds the skip and writes the 16-bit copy the next block's convolution reads), backward = 7 (per layer: BatchNorm
+    backward that takes its upstream gradient straight from the slabs of the following input-gradient launch and adds d gamma / d beta to
+    the pending gradients, then the input-gradient launch; the skip gradient joins in the last slab sum).  Weight gradients are batched
+    over the calls of the step as in `ConvBlock`.
+
+    apply(x, x16 or None, w1, b1, g1, be1, w2, ..., be3, cfg) with cfg = ((rmean, rvar, momentum, eps, act) x 3); returns
+    (x + r fp32, its 16-bit copy (not differentiable), r fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, x16, *rest):
+        prm, cfg = rest[:12], rest[12]
+        cdt = compute_dtype()
+        h = x16 if (x16 is not None and x16.dtype == cdt and x16.shape == x.shape) else to_compute(x, cdt)
+        saved = []
+        for li in range(3):
+            w, b, gm, bt = prm[4 * li:4 * li + 4]
+            rmean, rvar, momentum, eps, act = cfg[li]
+            slabs = ops.conv3_img16(h, packed_img_weight(w, cdt, False), w.shape[0])
+            bias = b.detach() if b is not None else None
+            if li < 2:
+                y, z, mean, invstd = ops.bn_train_fwd_small_slabs(slabs, bias, cdt, gm.detach(), bt.detach(), act, cdt, rmean, rvar, momentum, eps)
+            else:
+                y, z, mean, invstd, xnew, xnew16 = ops.bn_train_fwd_small_slabs(slabs, bias, cdt, gm.detach(), bt.detach(), act, torch.float32, rmean,
+                                                                                rvar, momentum, eps, skip=x.detach(), want16=True)
+            saved += [h, z, mean, invstd]
+            h = y
+        ctx.save_for_backward(*saved)
+        ctx.prm, ctx.acts, ctx.cdt = prm, tuple(c[4] for c in cfg), cdt
+        ctx.x_needs_grad = x.requires_grad
+        ctx.mark_non_differentiable(xnew16)
+        ctx.set_materialize_grads(False)          # an unused output arrives as None, not as a tensor of zeros
+        return xnew, xnew16, y
+
+    @staticmethod
+    def backward(ctx, g_new, _g16, g_res):
+        prm, cdt, saved = ctx.prm, ctx.cdt, ctx.saved_tensors
+        if g_new is None and g_res is None:
+            return (None,) * 15
+        dy_a = g_res if g_res is not None else g_new
+        dy_b = g_new if g_res is not None else None
+        dy_a = dy_a.contiguous()
+        if dy_b is not None:
+            dy_b = dy_b.contiguous().float()
+        grads = [None] * 12
+        slabs = None
+        fold = _STATE.get('fold_grads')
+        for li in (2, 1, 0):
+            w, b, gm, bt = prm[4 * li:4 * li + 4]
+            h, z, mean, invstd = saved[4 * li:4 * li + 4]
+            acc = None
+            if fold:
+                fg, fb = _fold_slots().get(id(gm)), _fold_slots().get(id(bt))
+                if fg is not None and fb is not None and fg.dtype == torch.float32 and fb.dtype == torch.float32 and fg.is_contiguous() and fb.is_contiguous():
+                    acc = (fg, fb)
+            if slabs is not None:
+                dz, dgamma, dbeta = ops.bn_act_bwd_small_ex(z, mean, invstd, gm.detach(), bt.detach(), ctx.acts[li], cdt, slabs=slabs, acc=acc)
+            else:
+                dz, dgamma, dbeta = ops.bn_act_bwd_small_ex(z, mean, invstd, gm.detach(), bt.detach(), ctx.acts[li], cdt, dy_a=dy_a, dy_b=dy_b, acc=acc)
+            db = None
+            if b is not None and b.requires_grad:
+                # exactly zero in front of a training-mode BatchNorm (see ConvBlock.backward)
+                db = None if (fold and id(b) in _fold_slots()) else torch.zeros_like(b)
+            dw = _conv_weight_grad(w, dz, h, 1, 1, False) if w.requires_grad else None
+            grads[4 * li:4 * li + 4] = _fold_param_grads(((w, dw), (b, db), (gm, dgamma), (bt, dbeta)))
+            if li > 0 or ctx.x_needs_grad:
+                slabs = ops.conv3_img16(dz, packed_img_weight(w, cdt, True), w.shape[1], name='vs_conv_dgrad')
+        dx = None
+        if ctx.x_needs_grad:
+            dx = ops.slab_sum(slabs, None, torch.float32, addend=g_new.contiguous().float() if g_new is not None else None)
+        return (dx, None) + tuple(grads) + (None,)
 
 
 class ConvBlock(torch.autograd.Function):
@@ -837,32 +995,7 @@ class ConvBlock(torch.autograd.Function):
                 db = None if (_STATE.get('fold_grads') and id(b) in _fold_slots()) else torch.zeros_like(b)
             else:
                 db = ops.chan_sum(dz)
-        dw = None
-        if w.requires_grad:
-            # a weight that already holds a gradient from an earlier call of this pass (the integrator's blocks: one call per predicted
-            # frame) gets this call's contribution ADDED in the weight-gradient GEMM's epilogue -- no temporary, no add launch
-            first_w = _fold_slots().get(id(w)) if _STATE.get('fold_grads') else None
-            if _defer_wgrad_ok(dz, transposed, stride):
-                slot = _DEFER_W['slots'].get(id(w))
-                if slot is None:
-                    if first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
-                        g = first_w                          # the weight already holds a gradient of this pass: the batch is added to it
-                    else:
-                        # zeros: the batched gradient is ADDED at the end, so other (non-deferred) calls of the same weight may add to
-                        # this tensor in between; autograd gets a tensor of its own on the same storage (it keeps an unshared tensor)
-                        buf = torch.zeros((w.numel(),), dtype=torch.float32, device=dz.device)
-                        g = buf.view(w.shape)
-                        dw = buf.view(w.shape)
-                    slot = _DEFER_W['slots'][id(w)] = {'g': g, 'pairs': [], 'shape': tuple(w.shape), 'stride': stride, 'pad': pad,
-                                                      'stream': torch.cuda.current_stream()}
-                    if not _DEFER_W['queued']:
-                        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_wgrads)
-                        _DEFER_W['queued'] = True
-                slot['pairs'].append((dz, xc))
-            elif first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
-                ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed, into=first_w)
-            else:
-                dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed)
+        dw = _conv_weight_grad(w, dz, xc, stride, pad, transposed) if w.requires_grad else None
         dx = None
         if ctx.x_needs_grad:
             # the input gradient of Conv2d k4 s2 p1 IS a ConvTranspose2d k4 s2 p1 of dz with the same weight tensor ([Cout, Cin, 4, 4]
@@ -882,29 +1015,7 @@ class ConvBlock(torch.autograd.Function):
                 wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
                 dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
                                     cols_from_wgrad=transposed and bool(w.requires_grad))
-        if _STATE.get('fold_grads'):
-            # the FIRST contribution of a parameter in this backward pass goes to autograd (which keeps that very tensor as the
-            # parameter's pending gradient); later contributions of the pass are added INTO it with one multi-tensor launch per
-            # block and autograd gets nothing for them (otherwise: one add launch per parameter and contribution)
-            acc = _fold_slots()
-            into, what = [], []
-            grads = {'w': dw, 'b': db, 'gamma': dgamma, 'beta': dbeta}
-            for key, prm in (('w', w), ('b', b), ('gamma', ctx.gamma), ('beta', ctx.beta)):
-                g = grads[key]
-                if g is None or prm is None:
-                    continue
-                first = acc.get(id(prm))
-                if first is None:
-                    # a second tensor on the same storage: autograd keeps the tensor it is handed only while nobody else references
-                    # it and CLONES it otherwise (one D2D copy per parameter and step: 63 x 5 us in the Moving-MNIST step)
-                    acc[id(prm)] = g.detach()
-                elif first.shape == g.shape and first.dtype == g.dtype:
-                    into.append(first)
-                    what.append(g)
-                    grads[key] = None
-            if into:
-                torch._foreach_add_(into, what)
-            dw, db, dgamma, dbeta = grads['w'], grads['b'], grads['gamma'], grads['beta']
+        dw, db, dgamma, dbeta = _fold_param_grads(((w, dw), (b, db), (ctx.gamma, dgamma), (ctx.beta, dbeta)))
         return dx, dw, db, dgamma, dbeta, None, None, None
 
 

@@ -316,6 +316,31 @@ class ConvResBlock(nn.Module):
         self.up = _c3(in_c, out_c, activation='none') if in_c != out_c else nn.Identity()
 
     def forward(self, x):
+        if isinstance(self.up, nn.Identity) and torch.is_grad_enabled():
+            # a few 16x16 maps in a 16-bit compute type (the SST integrator): the whole block as 6 launches forward / 7 backward
+            layers = [m for m in _flatten_modules(self.conv, []) if not isinstance(m, nn.Identity)]
+            convs = [m for m in layers if isinstance(m, nn.Conv2d)]
+            if len(convs) == 3 and len(layers) <= 8:
+                bns, acts = [], []
+                for c in convs:
+                    i = layers.index(c)
+                    bn = layers[i + 1] if i + 1 < len(layers) and isinstance(layers[i + 1], nn.BatchNorm2d) else None
+                    j = i + (2 if bn is not None else 1)
+                    act = layers[j] if j < len(layers) and isinstance(layers[j], _ACT_TYPES) else None
+                    bns.append(bn)
+                    acts.append(activation_name(act) if act is not None else 'none')
+                if acts[2] == 'none' and VF.conv_res_block_fusable(x, convs, bns):
+                    args, cfg = [], []
+                    for c, bn, act in zip(convs, bns, acts):
+                        VF.count_bn_calls(bn, 1)
+                        args += [c.weight, c.bias, bn.weight, bn.bias]
+                        cfg.append((bn.running_mean, bn.running_var, bn.momentum, bn.eps, act))
+                    prev = getattr(x, '_vs16', None)
+                    xnew, x16, residual = VF.ConvResBlockFn.apply(x, prev[0] if prev is not None and prev[1] == x._version else None, *args,
+                                                                  tuple(cfg))
+                    # the next block's convolution operand (same values, already in the compute type), valid while xnew is not written to
+                    xnew._vs16 = (x16, xnew._version)
+                    return xnew, residual
         residual = run_layers(self.conv, x, final_fp32=True)
         skip = x if isinstance(self.up, nn.Identity) else run_layers(self.up, x, final_fp32=True)
         return skip + residual, residual

@@ -606,13 +606,17 @@ def conv3_img16(x, w_packed, Cout, name='vs_conv_fwd'):
     return slabs
 
 
-def slab_sum(slabs, bias, out_dtype):
-    """sum over the leading (split) axis of fp32 slabs [S, B, C, H, W] (+ bias[c]) -> [B, C, H, W] in out_dtype, one launch."""
+def slab_sum(slabs, bias, out_dtype, addend=None):
+    """sum over the leading (split) axis of fp32 slabs [S, B, C, H, W] (+ bias[c]) (+ addend, fp32 [B, C, H, W]) -> [B, C, H, W] in
+    out_dtype, one launch."""
     require_cuda(slabs)
     S, B, C = slabs.shape[0], slabs.shape[1], slabs.shape[2]
     HW = slabs.numel() // (S * B * C)
+    if addend is not None:
+        assert addend.dtype == torch.float32 and addend.is_contiguous() and addend.numel() == B * C * HW
     out = torch.empty(slabs.shape[1:], dtype=out_dtype, device=slabs.device)
-    check(_lib.load_library().vs_slab_sum(slabs.data_ptr(), S, _ptr(bias), out.data_ptr(), dtype_code(out), B, C, HW, stream_ptr()), 'vs_slab_sum')
+    check(_lib.load_library().vs_slab_sum(slabs.data_ptr(), S, _ptr(bias), _ptr(addend), out.data_ptr(), dtype_code(out), B, C, HW, stream_ptr()),
+          'vs_slab_sum')
     return out
 
 
@@ -702,9 +706,11 @@ def bn_train_fwd_small(x, gamma, beta, act, out_dtype, running_mean=None, runnin
     return y, mean, invstd
 
 
-def bn_train_fwd_small_slabs(slabs, bias, z_dtype, gamma, beta, act, out_dtype, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+def bn_train_fwd_small_slabs(slabs, bias, z_dtype, gamma, beta, act, out_dtype, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
+                             skip=None, want16=False):
     """`bn_train_fwd_small` on the split slabs [S, B, C, H, W] (fp32) of `conv3_img16`: the slab sum, the conv bias, the 16-bit rounding of
-    the conv output z and the BatchNorm forward in one launch.  Returns (y, z, mean [1, C], invstd [1, C])."""
+    the conv output z and the BatchNorm forward in one launch.  Returns (y, z, mean [1, C], invstd [1, C]); with `skip` (fp32, the block
+    input of a residual block) additionally (skip + y in fp32, its `z_dtype` copy or None)."""
     require_cuda(slabs)
     S, B, C = slabs.shape[0], slabs.shape[1], slabs.shape[2]
     HW = slabs.numel() // (S * B * C)
@@ -712,13 +718,51 @@ def bn_train_fwd_small_slabs(slabs, bias, z_dtype, gamma, beta, act, out_dtype, 
     y = torch.empty(slabs.shape[1:], dtype=out_dtype, device=slabs.device)
     mean = torch.empty((1, C), dtype=torch.float32, device=slabs.device)
     invstd = torch.empty((1, C), dtype=torch.float32, device=slabs.device)
+    xnew = xnew16 = None
+    if skip is not None:
+        assert skip.dtype == torch.float32 and skip.is_contiguous() and skip.numel() == y.numel()
+        xnew = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
+        xnew16 = torch.empty(slabs.shape[1:], dtype=z_dtype, device=slabs.device) if want16 else None
     e0 = _pb()
     check(_lib.load_library().vs_bn_train_fwd_small_slabs(slabs.data_ptr(), S, _ptr(bias), z.data_ptr(), dtype_code(z), y.data_ptr(), dtype_code(y),
                                                           gamma.data_ptr(), beta.data_ptr(), ACT[act], mean.data_ptr(), invstd.data_ptr(),
-                                                          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), B, C, HW,
-                                                          stream_ptr()), 'vs_bn_train_fwd_small_slabs')
+                                                          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(skip),
+                                                          _ptr(xnew), _ptr(xnew16), B, C, HW, stream_ptr()), 'vs_bn_train_fwd_small_slabs')
     _pe(e0, 'vs_bn_act_fwd', nbytes=float(slabs.numel() * 4 + z.numel() * (z.element_size() + y.element_size())))
+    if skip is not None:
+        return y, z, mean, invstd, xnew, xnew16
     return y, z, mean, invstd
+
+
+def bn_act_bwd_small_ex(z, mean, invstd, gamma, beta, act, dx_dtype, dy_a=None, dy_b=None, slabs=None, acc=None):
+    """One-launch training-mode BatchNorm + activation backward on a small 16-bit z with the upstream gradient from split slabs
+    [S, B, C, H, W] or from dy_a (+ dy_b, fp32).  `acc` = (dgamma, dbeta) vectors the parameter gradients are ADDED to (returns
+    (dx, None, None)); otherwise fresh (dx, dgamma, dbeta)."""
+    require_cuda(z)
+    B, C = z.shape[0], z.shape[1]
+    HW = z.numel() // (B * C)
+    dx = torch.empty(z.shape, dtype=dx_dtype, device=z.device)
+    if acc is None:
+        dgamma = torch.empty((C,), dtype=torch.float32, device=z.device)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=z.device)
+    else:
+        dgamma, dbeta = acc
+        assert dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32 and dgamma.numel() == C and dbeta.numel() == C
+    if slabs is not None:
+        assert slabs.dtype == torch.float32 and slabs.is_contiguous() and slabs.numel() == slabs.shape[0] * z.numel()
+    else:
+        assert dy_a is not None and dy_a.is_contiguous() and dy_a.numel() == z.numel()
+        assert dy_b is None or (dy_b.dtype == torch.float32 and dy_b.is_contiguous() and dy_b.numel() == z.numel())
+    e0 = _pb()
+    check(_lib.load_library().vs_bn_act_bwd_small_ex(_ptr(dy_a), dtype_code(dy_a) if dy_a is not None else F32, _ptr(dy_b), _ptr(slabs),
+                                                     slabs.shape[0] if slabs is not None else 0, z.data_ptr(), dtype_code(z), mean.data_ptr(),
+                                                     invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], dgamma.data_ptr(),
+                                                     dbeta.data_ptr(), int(acc is not None), dx.data_ptr(), dtype_code(dx), B, C, HW, stream_ptr()),
+          'vs_bn_act_bwd_small_ex')
+    _pe(e0, 'vs_bn_act_bwd', nbytes=float(z.numel() * (z.element_size() + dx.element_size() + 4)))
+    if acc is not None:
+        return dx, None, None
+    return dx, dgamma, dbeta
 
 
 def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype, groups=1):

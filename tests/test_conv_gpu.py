@@ -449,3 +449,44 @@ def test_batchnorm_small_from_split_slabs_equals_sum_then_batchnorm(dtype, shape
     assert torch.equal(m1, m2) and torch.equal(i1, i2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
     y3 = ops.bn_train_fwd_small_slabs(slabs, None, dtype, gamma, beta, 'none', torch.float32, None, None, 0.1, 1e-5)[0]
     assert y3.dtype == torch.float32 and torch.isfinite(y3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_fused_conv_res_block_equals_layer_by_layer(precision, monkeypatch):
+    """ConvResBlock (resnet.py:53-70) through functional.ConvResBlockFn (6 launches forward, 7 backward) against the same block run
+    layer by layer: forward outputs and running statistics bit for bit (same kernels), gradients to the tolerance of the one difference
+    -- the fused backward hands the inner BatchNorms the fp32 input gradient, the layered one a 16-bit rounding of it --, and a second
+    chained block re-uses the 16-bit copy of the first one's output."""
+    import copy
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.conv import ConvResnet
+    with VF.precision(precision):
+        torch.manual_seed(5)
+        net = ConvResnet(64, n_blocks=2, nf=128).cuda().train()
+        ref = copy.deepcopy(net)
+        x0 = _rand((4, 64, 16, 16), 81).cuda()
+        ga, gb = _rand((4, 64, 16, 16), 82).cuda(), _rand((4, 64, 16, 16), 83).cuda()
+        outs = []
+        for fused, m in (('1', net), ('0', ref)):
+            monkeypatch.setenv('VARSEP_FUSED_RESBLOCK', fused)
+            x = x0.clone().requires_grad_(True)
+            y, residuals = m(x)
+            assert hasattr(y, '_vs16') == (fused == '1')          # the fused path leaves the 16-bit copy of its output
+            (y * ga).sum().add((residuals[0] * gb).sum()).add((residuals[1] * ga).sum()).backward()
+            torch.cuda.synchronize()
+            outs.append((y.detach(), [r.detach() for r in residuals], x.grad))
+        (y1, r1, g1), (y2, r2, g2) = outs
+        assert torch.equal(y1, y2) and torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+        for (n1, b1), (_, b2) in zip(net.named_buffers(), ref.named_buffers()):
+            assert torch.equal(b1, b2), n1
+        tol = 2e-2 if precision == 'bf16' else 3e-3
+
+        def rel(a, b):
+            return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+        assert rel(g1, g2) < tol
+        for (n1, p1), (_, p2) in zip(net.named_parameters(), ref.named_parameters()):
+            if p2.grad.abs().max().item() == 0:
+                assert p1.grad.abs().max().item() == 0, n1          # conv biases in front of BatchNorm
+            else:
+                assert rel(p1.grad, p2.grad) < tol, (n1, rel(p1.grad, p2.grad))
