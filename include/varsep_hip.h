@@ -177,6 +177,13 @@ int vs_conv3_img16_splits(int B, int Cin, int Cout);
 size_t vs_conv3_img16_packed_elems(int Cin, int Cout);
 int vs_conv3_img16_pack_weight(int compute, const float* w, int Cin, int Cout, int flip, void* dst, void* stream);
 int vs_conv3_img16(int compute, const void* x, const void* w_packed, float* slabs, int B, int Cin, int Cout, void* stream);
+/* The same contraction for MANY maps of width 16 / 32 / 64 (every 3x3 block of EncoderSST / DecoderSST(_Skip) conv.py:323-426 and of the VGG
+ * encoders / decoders conv.py:127-171, 267-320 on whole batches): workgroup = 256 consecutive pixels of one map (256 / W rows) x 32 output
+ * channels, the band's rows + halo of 64 channels at a time in LDS by double-buffered LDS-DMA, no column matrix.  H a multiple of 256 / W,
+ * Cin a multiple of 64; weights from vs_conv3_img16_pack_weight (flip = 1 for the input gradient); y in any type, bias added.   */
+int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W, int Cout);
+int vs_conv3_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
+                  int Cout, void* stream);
 int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,
                 void* stream);
 int vs_bn_stats_from_sums(const double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* var_scratch,

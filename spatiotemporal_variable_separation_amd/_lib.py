@@ -140,6 +140,8 @@ SIGNATURES = {
     'vs_conv3_img16_packed_elems': (_sz, [_i32, _i32]),
     'vs_conv3_img16_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     'vs_conv3_img16': (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'vs_conv3_band_supported': (_i32, [_i32] * 6),
+    'vs_conv3_band': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vs_slab_sum': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     'vs_bn_train_fwd_small_slabs': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                            _vp, _vp, _vp, _i32, _i32, _i64, _vp]),

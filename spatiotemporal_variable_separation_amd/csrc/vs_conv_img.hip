@@ -18,7 +18,7 @@
 //   * split partial sums go to fp32 slabs [split][B][Cout][256]; the consumer adds them: vs_bn_train_fwd_small_slabs (bias +
 //     16-bit rounding + BatchNorm statistics + running update + affine + activation in one launch, vs_norm.hip) or vs_slab_sum.
 // The input gradient is the same kernel on dz with the weight packed transposed and flipped (flip = 1).
-#include "vs_gemm_core.h"
+#include "vs_gemm_glds.h"
 
 namespace {
 
@@ -30,6 +30,10 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {      // lane i <- lane 
 }
 __device__ __forceinline__ float dpp_row_shl1(float v) {      // lane i <- lane i + 1, 0 into lane 15
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float lane_gather(int byte_index, float v) {       // value of lane byte_index / 4
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_index, __builtin_bit_cast(int, v)));
 }
 
 // Weight fragments: three 1 KiB wave loads (the kx taps of one (chunk, ky) group) written as asm so that they STAY where they are
@@ -127,6 +131,10 @@ __global__ __launch_bounds__(256) void conv3_img16_kernel(const unsigned short* 
         }
     }
 
+    // the repeated fragment loads of the last groups are still in flight and their destination registers are dead to the compiler:
+    // they must land before it re-uses those registers (for the store addresses below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
     // ---- out[y][x] = G_1[x] + G_0[x - 1] + G_2[x + 1], fp32 slab of this split ------------------------------------------
     float* out = slabs + (((int64_t)split * B + b) * Cout) * 256;
     const int mrow = mt * 32 + 4 * (lane >> 5);
@@ -138,6 +146,138 @@ __global__ __launch_bounds__(256) void conv3_img16_kernel(const unsigned short* 
             const float o = acc[1][j][v] + dpp_row_shr1(acc[0][j][v]) + dpp_row_shl1(acc[2][j][v]);
             const int m = mrow + (v & 3) + 8 * (v >> 2);
             if (m < Cout) out[(int64_t)m * 256 + pix] = o;
+        }
+    }
+}
+
+// ---- many maps of 16 / 32 / 64 pixels width: the same contraction on row BANDS -------------------------------------------------
+// Every 3x3 block of the SST / VGG encoders and decoders (conv.py:127-171, 267-426 of the reference) on hundreds of maps: as "column
+// matrix + GEMM" the gather writes and the GEMM re-reads 9 x the input (64 -> 64 channels on 352 maps of 64 x 64: 1.7 GB each way, 0.8 +
+// 0.5 ms for 0.1 TFLOP).  Here a workgroup owns 256 consecutive pixels of one map (R = 256 / W whole rows) and 32 output channels:
+//   * the band's R + 2 input rows of 64 channels at a time go to LDS by LDS-DMA (global_load_lds_dwordx4; the [channel][row][pixel]
+//     image is lane-linear in the 16-byte piece index, rows outside the map come from a block of zeros), double buffered: the DMA of
+//     channels 64 (p + 1) .. is in flight while channels 64 p .. are multiplied.  It is covered by the same counted wait as the weight
+//     stream: it is older than the 33 fragment loads the last group of a phase leaves outstanding.
+//   * weights, fragment stream and the unshifted pixel operand exactly as above (same pre-pack); wave w owns pixels 64 w .. 64 w + 63.
+//   * x shift on the result: a column tile is 32 consecutive pixels of a row, so the neighbour of its first / last lane is the last /
+//     first lane of the wave's other tile (W = 64) or the zero padding: one ds_bpermute rotation per tile and side, a select per value.
+//   * output in the caller's type with the bias, straight from the registers (128-byte runs along the pixels).
+template <int CT, int W>
+__global__ __launch_bounds__(256) void conv3_band_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
+                                                         void* __restrict__ Y, int yd, int B, int Cin, int H, int Cout, int mtiles, int bands) {
+    constexpr int R = 256 / W, RP = R + 2, PW = W / 8;
+    constexpr int NP = 64 * RP * PW / 256;                                       // 16-byte pieces per thread and phase: 12 / 10 / 9
+    constexpr int BUF = 64 * RP * W;                                             // elements per buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [2][64 channels][RP rows][W]
+    int id = blockIdx.x;
+    const int mt = id % mtiles;
+    id /= mtiles;
+    const int band = id % bands, b = id / bands;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nph = Cin >> 6;
+
+    auto dma = [&](int ph) {
+        char* dst = reinterpret_cast<char*>(xs + (ph & 1) * BUF);
+        const unsigned short* xc = X + ((int64_t)b * Cin + ph * 64) * H * W;
+#pragma unroll
+        for (int r = 0; r < NP; ++r) {
+            const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
+            const int y = band * R + rr - 1;
+            const void* g = (y >= 0 && y < H) ? (const void*)(xc + ((int64_t)cl * H + y) * W + pc * 8) : (const void*)vs_glds_zero;
+            // asm: the compiler orders a builtin LDS-DMA against every later LDS read with s_waitcnt vmcnt(0), which would also drain the
+            // weight stream at every phase; the DMA is covered by the counted waits below instead (M0 has this one writer)
+            const uint32_t d = (uint32_t)(uintptr_t)(dst + (r * 256 + wave * 64) * 16);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(g) : "memory", "m0");
+        }
+    };
+    dma(0);
+
+    const int chunks_total = Cin >> 4;
+    const char* wbase = reinterpret_cast<const char*>(Wp + ((int64_t)mt * chunks_total * 3) * 192);
+    const unsigned voff = lane * 16;
+    u32x4 a[IMG_AHEAD][3];
+#pragma unroll
+    for (int gg = 0; gg < IMG_AHEAD; ++gg) img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + gg * 3072, voff);
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[kx][j][v] = 0.f;
+
+    const int li = lane & 15, q = li >> 2, p = li & 3, cb = (lane >> 4) & 1, h = lane >> 5;
+    int lofs[2];                                                                  // element offset of this lane's piece of tile j, k-row 0, tap row 0
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q0 = wave * 64 + j * 32 + 16 * cb + 4 * p;
+        lofs[j] = ((8 * h + q) * RP + q0 / W) * W + q0 % W;
+    }
+    const int ngroups = chunks_total * 3;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // phase 0 (and the first fragments) have landed
+    __builtin_amdgcn_s_barrier();
+
+    for (int ph = 0; ph < nph; ++ph) {
+        if (ph + 1 < nph) dma(ph + 1);
+        const unsigned short* buf = xs + (ph & 1) * BUF;
+        const int g0 = ph * IMG_AHEAD;
+#pragma unroll
+        for (int gg = 0; gg < IMG_AHEAD; ++gg) {
+            const int ch = gg / 3, ky = gg % 3;
+            u32x4 bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = vs_tr16_pair(buf + lofs[j] + (ch * 16 * RP + ky) * W, 4 * RP * W);
+            img_wait3(a[gg][0], a[gg][1], a[gg][2]);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[kx][j] = mfma16_32<CT>(a[gg][kx], bf[j], acc[kx][j]);
+            int gn = g0 + IMG_AHEAD + gg;
+            if (gn > ngroups - 1) gn = ngroups - 1;
+            img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + (int64_t)gn * 3072, voff);
+        }
+        // the last wait of the phase left <= 33 loads outstanding, all younger than the DMA of the next phase: it has landed for this
+        // wave; behind the barrier for all of them, and nobody reads this phase's buffer any more
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // the repeated fragment loads of the last groups are still in flight and their destination registers are dead to the compiler:
+    // they must land before it re-uses those registers (for the store addresses below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- out[x] = G_1[x] + G_0[x - 1] + G_2[x + 1] inside the image row, + bias, typed store -------------------------------------------
+    const int l31 = lane & 31;
+    const int idx_l = ((lane & 32) | ((lane - 1) & 31)) * 4, idx_r = ((lane & 32) | ((lane + 1) & 31)) * 4;
+    const int mrow = mt * 32 + 4 * (lane >> 5);
+    const int64_t obase = ((int64_t)b * Cout * H + (int64_t)band * R) * W + wave * 64 + l31;
+    const int col0 = (wave * 64 + l31) % W, col1 = (wave * 64 + 32 + l31) % W;
+    float bvs[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int m = mrow + (v & 3) + 8 * (v >> 2);
+        bvs[v] = (bias && m < Cout) ? bias[m] : 0.f;
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int m = mrow + (v & 3) + 8 * (v >> 2);
+        float rl[2], rr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float gl = acc[0][j][v], gr = acc[2][j][v];          // (a bit_cast applied to the vector element itself read element 0)
+            rl[j] = lane_gather(idx_l, gl);
+            rr[j] = lane_gather(idx_r, gr);
+        }
+        const float left0 = (l31 != 0 && col0 != 0) ? rl[0] : 0.f;
+        const float left1 = col1 == 0 ? 0.f : (l31 != 0 ? rl[1] : rl[0]);
+        const float right0 = col0 == W - 1 ? 0.f : (l31 != 31 ? rr[0] : rr[1]);
+        const float right1 = (l31 != 31 && col1 != W - 1) ? rr[1] : 0.f;
+        if (m < Cout) {
+            const float bv = bvs[v];
+            const int64_t o = obase + (int64_t)m * H * W;
+            vs_st(Y, yd, o, acc[1][0][v] + left0 + right0 + bv);
+            vs_st(Y, yd, o + 32, acc[1][1][v] + left1 + right1 + bv);
         }
     }
 }
@@ -257,5 +397,52 @@ extern "C" int vs_slab_sum(const float* slabs, int nslabs, const float* bias, co
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, total, bias, addend, C, (int)HW, out, out_dtype);
     VS_CHECK_LAUNCH("vs_slab_sum");
+    return VS_OK;
+}
+
+// ---- row-band form: many maps, W in {16, 32, 64}, H a multiple of 256 / W, Cin a multiple of 64; y in any type, bias added --------------
+extern "C" int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W, int Cout) {
+    if (!vs_is16(compute) || (W != 16 && W != 32 && W != 64) || B < 1 || Cout < 1 || Cin < 64 || Cin % 64 != 0) return 0;
+    const int R = 256 / W;
+    if (H < R || H % R != 0) return 0;
+    if ((int64_t)B * (H / R) * vs_cdiv(Cout, 32) >= (1ll << 31)) return 0;
+    return 1;
+}
+
+template <int W>
+static int launch_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
+                       hipStream_t stream) {
+    constexpr int R = 256 / W;
+    const size_t lds = (size_t)2 * 64 * (R + 2) * W * 2;
+    auto kb = conv3_band_kernel<VS_BF16, W>;
+    auto kh = conv3_band_kernel<VS_F16, W>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return vs_fail(VS_ERR_LAUNCH, "vs_conv3_band: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const int mtiles = (int)vs_cdiv(Cout, 32), bands = H / R;
+    const dim3 grid((unsigned)((int64_t)B * bands * mtiles));
+    if (compute == VS_BF16)
+        hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands);
+    else
+        hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands);
+    return VS_OK;
+}
+
+// x [B][Cin][H][W] (16-bit), w_packed from vs_conv3_img16_pack_weight (same pre-pack) -> y [B][Cout][H][W] in y_dtype, bias added
+extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
+                             int Cout, void* stream) {
+    VS_CHECK_ARG(x && w_packed && y && vs_dtype_ok(y_dtype), "vs_conv3_band: bad argument");
+    VS_CHECK_ARG(vs_conv3_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_band: unsupported geometry (query vs_conv3_band_supported)");
+    VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0, "vs_conv3_band: operands must be 16-byte aligned");
+    int rc;
+    if (W == 64) rc = launch_band<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    else if (W == 32) rc = launch_band<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    else rc = launch_band<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    if (rc != VS_OK) return rc;
+    VS_CHECK_LAUNCH("vs_conv3_band");
     return VS_OK;
 }

@@ -885,6 +885,12 @@ class ConvResBlockFn(torch.autograd.Function):
         return (dx, None) + tuple(grads) + (None,)
 
 
+def band_ok(x, w, transposed, stride, pad, dgrad=False):
+    """Conv2d k3 s1 p1 of `x` with weight `w` ([Cout, Cin, 3, 3]) -- or, dgrad=True, its input gradient from x = dz -- on the row-band kernel."""
+    return (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
+            and ops.conv3_band_supported(x, w.shape[1] if dgrad else w.shape[0]))
+
+
 class ConvBlock(torch.autograd.Function):
     """conv / transposed conv -> [BatchNorm2d (per-call batch statistics)] -> [activation]  (conv.py:41-60).
 
@@ -928,6 +934,26 @@ class ConvBlock(torch.autograd.Function):
                 ctx.save_for_backward(xc, z, mean, invstd)
             else:
                 y = ops.slab_sum(slabs, bias, out_dt)
+                if act not in ('none', None):
+                    ops.act_fwd(y, act, out=y)
+                ctx.save_for_backward(xc, y)
+        elif band_ok(xc, w, transposed, stride, pad) and not tap:
+            # 3x3 on many maps of width 16 / 32 / 64: row bands through LDS, no column matrix; BatchNorm as for the column-matrix path
+            wpk = packed_img_weight(w, cdt, False)
+            if has_bn:
+                z = ops.conv3_band(xc, wpk, bias, w.shape[0], cdt)
+                if training and groups == 1 and ops.bn_small_supported(z):
+                    y, mean, invstd = ops.bn_train_fwd_small(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps)
+                else:
+                    if training:
+                        mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
+                    else:
+                        mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
+                        invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
+                    y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
+                ctx.save_for_backward(xc, z, mean, invstd)
+            else:
+                y = ops.conv3_band(xc, wpk, bias, w.shape[0], out_dt)
                 if act not in ('none', None):
                     ops.act_fwd(y, act, out=y)
                 ctx.save_for_backward(xc, y)
@@ -1007,6 +1033,8 @@ class ConvBlock(torch.autograd.Function):
                   and ops.conv3_img16_supported(dz, w.shape[1])):
                 # few 16x16 maps: the same one-launch kernel on dz with the weight packed transposed and flipped
                 dx = ops.slab_sum(ops.conv3_img16(dz, packed_img_weight(w, cdt, True), w.shape[1], name='vs_conv_dgrad'), None, ctx.x_dtype)
+            elif band_ok(dz, w, transposed, stride, pad, dgrad=True):
+                dx = ops.conv3_band(dz, packed_img_weight(w, cdt, True), None, w.shape[1], ctx.x_dtype, name='vs_conv_dgrad')
             elif (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
                   and ops.conv_k3_tap_supported(dz, w.shape[1], 1)):
                 # Conv2d k3 s1 p1: the input gradient is the same convolution of dz with the weight transposed and flipped

@@ -606,6 +606,30 @@ def conv3_img16(x, w_packed, Cout, name='vs_conv_fwd'):
     return slabs
 
 
+def conv3_band_supported(x, Cout):
+    """Whether Conv2d k3 s1 p1 on `x` takes the row-band kernel (`conv3_band`: many maps of width 16 / 32 / 64, Cin a multiple of 64, no
+    column matrix).  VS_CONV_BAND=0: never."""
+    import os
+    if os.environ.get('VS_CONV_BAND') == '0' or x.dtype == torch.float32 or x.dim() != 4:
+        return False
+    B, Cin, H, W = x.shape
+    return bool(_lib.load_library().vs_conv3_band_supported(dtype_code(x), B, Cin, H, W, Cout))
+
+
+def conv3_band(x, w_packed, bias, Cout, out_dtype, name='vs_conv_fwd'):
+    """Conv2d k3 s1 p1 of x [B, Cin, H, W] (16-bit) with the `conv3_img16_pack_weight` pre-pack -> y [B, Cout, H, W] in out_dtype (+ bias)."""
+    require_cuda(x, w_packed, bias)
+    assert x.is_contiguous() and x.dtype == w_packed.dtype
+    B, Cin, H, W = x.shape
+    y = torch.empty((B, Cout, H, W), dtype=out_dtype, device=x.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_conv3_band(dtype_code(x), x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W,
+                                            Cout, stream_ptr()), 'vs_conv3_band')
+    _pe(e0, '%s<%s>' % (name, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
+        nbytes=float(x.numel() * x.element_size() + w_packed.numel() * 2 + y.numel() * y.element_size()))
+    return y
+
+
 def slab_sum(slabs, bias, out_dtype, addend=None):
     """sum over the leading (split) axis of fp32 slabs [S, B, C, H, W] (+ bias[c]) (+ addend, fp32 [B, C, H, W]) -> [B, C, H, W] in
     out_dtype, one launch."""

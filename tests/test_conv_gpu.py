@@ -490,3 +490,41 @@ def test_fused_conv_res_block_equals_layer_by_layer(precision, monkeypatch):
                 assert p1.grad.abs().max().item() == 0, n1          # conv biases in front of BatchNorm
             else:
                 assert rel(p1.grad, p2.grad) < tol, (n1, rel(p1.grad, p2.grad))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom', [
+    (2, 64, 64, 64, 64),      # one phase, W = 64 (the two column tiles of a wave are the halves of one row)
+    (3, 128, 32, 32, 40),     # two phases, W = 32, ragged output-channel tile
+    (5, 192, 16, 16, 96),     # three phases, W = 16 (a column tile = two rows)
+    (2, 64, 8, 64, 33),       # H != W: two bands of four rows
+    (70, 256, 16, 16, 64),    # more workgroups than CUs: fragment loads still in flight when a workgroup ends
+    (9, 128, 64, 64, 32),
+])
+def test_conv3_band_forward_and_input_gradient(dtype, geom):
+    """Conv2d k3 s1 p1 on many maps through vs_conv3_band (row bands in LDS, no column matrix) against fp64 conv2d on the same 16-bit
+    operands: fp32 output, the 16-bit output rounding, launch-to-launch reproducibility, and the input gradient (flipped pack)."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, Cin, H, W, Cout = geom
+    x = _rand((B, Cin, H, W), 91).to(dtype)
+    w = _rand((Cout, Cin, 3, 3), 92, 0.3).to(dtype)
+    bias = _rand((Cout,), 93)
+    xc = x.cuda()
+    assert ops.conv3_band_supported(xc, Cout)
+    wp = ops.conv3_img16_pack_weight(w.float().cuda(), dtype, False)
+    y32 = ops.conv3_band(xc, wp, bias.cuda(), Cout, torch.float32)
+    y16 = ops.conv3_band(xc, wp, bias.cuda(), Cout, dtype)
+    again = ops.conv3_band(xc, wp, bias.cuda(), Cout, torch.float32)
+    torch.cuda.synchronize()
+    x64 = x.double().requires_grad_(True)
+    ref = F.conv2d(x64, w.double(), bias.double(), stride=1, padding=1)
+    assert ((y32.cpu().double() - ref.detach()).norm() / ref.detach().norm()).item() < 1e-5
+    assert ((y32.cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max()).item() < 1e-5
+    assert torch.equal(y16.cpu(), y32.cpu().to(dtype)) and torch.equal(again, y32)
+    dz = _rand(tuple(ref.shape), 94).to(dtype)
+    ref.backward(dz.double())
+    if ops.conv3_band_supported(dz.cuda(), Cin):
+        wf = ops.conv3_img16_pack_weight(w.float().cuda(), dtype, True)
+        dx = ops.conv3_band(dz.cuda(), wf, None, Cin, torch.float32)
+        assert ((dx.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max()).item() < 1e-5, f'dgrad {geom} {dtype}'
