@@ -65,6 +65,11 @@ __device__ __forceinline__ void img_stage(unsigned short* xs, const unsigned sho
     }
 }
 
+template <int N>
+__device__ __forceinline__ void img_wait3n(u32x4& a0, u32x4& a1, u32x4& a2) {   // as img_wait3 with N younger loads allowed in flight
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a0), "+v"(a1), "+v"(a2) : "n"(N) : "memory");
+}
+
 template <int CT>
 __global__ __launch_bounds__(256) void conv3_img16_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, float* __restrict__ slabs,
                                                           int B, int Cin, int Cout, int cs, int splits, int mtiles) {
@@ -162,8 +167,11 @@ __global__ __launch_bounds__(256) void conv3_img16_kernel(const unsigned short* 
 //   * x shift on the result: a column tile is 32 consecutive pixels of a row, so the neighbour of its first / last lane is the last /
 //     first lane of the wave's other tile (W = 64) or the zero padding: one ds_bpermute rotation per tile and side, a select per value.
 //   * output in the caller's type with the bias, straight from the registers (128-byte runs along the pixels).
-template <int CT, int W>
-__global__ __launch_bounds__(256) void conv3_band_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
+//   * two forms: AHEAD = 12 fragment groups in flight and one workgroup per CU (the registers of 36 fragments), or AHEAD = 4 and TWO
+//     workgroups per CU where their LDS fits (one 64-channel phase, or W = 16): a workgroup's launch, first DMA and epilogue are then
+//     covered by its neighbour's MFMA phase instead of by a deep prefetch.
+template <int CT, int W, int AHEAD, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
                                                          void* __restrict__ Y, int yd, int B, int Cin, int H, int Cout, int mtiles, int bands) {
     constexpr int R = 256 / W, RP = R + 2, PW = W / 8;
     constexpr int NP = 64 * RP * PW / 256;                                       // 16-byte pieces per thread and phase: 12 / 10 / 9
@@ -196,9 +204,9 @@ __global__ __launch_bounds__(256) void conv3_band_kernel(const unsigned short* _
     const int chunks_total = Cin >> 4;
     const char* wbase = reinterpret_cast<const char*>(Wp + ((int64_t)mt * chunks_total * 3) * 192);
     const unsigned voff = lane * 16;
-    u32x4 a[IMG_AHEAD][3];
+    u32x4 a[AHEAD][3];
 #pragma unroll
-    for (int gg = 0; gg < IMG_AHEAD; ++gg) img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + gg * 3072, voff);
+    for (int gg = 0; gg < AHEAD; ++gg) img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + gg * 3072, voff);
 
     f32x16 acc[3][2];
 #pragma unroll
@@ -222,23 +230,24 @@ __global__ __launch_bounds__(256) void conv3_band_kernel(const unsigned short* _
     for (int ph = 0; ph < nph; ++ph) {
         if (ph + 1 < nph) dma(ph + 1);
         const unsigned short* buf = xs + (ph & 1) * BUF;
-        const int g0 = ph * IMG_AHEAD;
+        const int g0 = ph * 12;
 #pragma unroll
-        for (int gg = 0; gg < IMG_AHEAD; ++gg) {
+        for (int gg = 0; gg < 12; ++gg) {
             const int ch = gg / 3, ky = gg % 3;
             u32x4 bf[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = vs_tr16_pair(buf + lofs[j] + (ch * 16 * RP + ky) * W, 4 * RP * W);
-            img_wait3(a[gg][0], a[gg][1], a[gg][2]);
+            const int sl = gg % AHEAD;                                           // register set of this group (12 % AHEAD == 0; a constant once unrolled)
+            img_wait3n<(AHEAD - 1) * 3>(a[sl][0], a[sl][1], a[sl][2]);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[kx][j] = mfma16_32<CT>(a[gg][kx], bf[j], acc[kx][j]);
-            int gn = g0 + IMG_AHEAD + gg;
+                for (int j = 0; j < 2; ++j) acc[kx][j] = mfma16_32<CT>(a[sl][kx], bf[j], acc[kx][j]);
+            int gn = g0 + AHEAD + gg;
             if (gn > ngroups - 1) gn = ngroups - 1;
-            img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + (int64_t)gn * 3072, voff);
+            img_load3(a[sl][0], a[sl][1], a[sl][2], wbase + (int64_t)gn * 3072, voff);
         }
-        // the last wait of the phase left <= 33 loads outstanding, all younger than the DMA of the next phase: it has landed for this
+        // the last wait of the phase left <= (AHEAD - 1) * 3 loads outstanding, all younger than the DMA of the next phase: it has landed for this
         // wave; behind the barrier for all of them, and nobody reads this phase's buffer any more
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -409,17 +418,18 @@ extern "C" int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W
     return 1;
 }
 
-template <int W>
+template <int W, int AHEAD, int MINB>
 static int launch_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
                        hipStream_t stream) {
     constexpr int R = 256 / W;
-    const size_t lds = (size_t)2 * 64 * (R + 2) * W * 2;
-    auto kb = conv3_band_kernel<VS_BF16, W>;
-    auto kh = conv3_band_kernel<VS_F16, W>;
+    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * 64 * (R + 2) * W * 2;        // one buffer when there is a single 64-channel phase
+    auto kb = conv3_band_kernel<VS_BF16, W, AHEAD, MINB>;
+    auto kh = conv3_band_kernel<VS_F16, W, AHEAD, MINB>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        const int most = 2 * 64 * (R + 2) * W * 2;
+        if (hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess ||
+            hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess)
             return vs_fail(VS_ERR_LAUNCH, "vs_conv3_band: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
@@ -432,6 +442,17 @@ static int launch_band(int compute, const void* x, const void* w_packed, const f
     return VS_OK;
 }
 
+template <int W>
+static int launch_band_w(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
+                         hipStream_t stream) {
+    // two workgroups per CU where 2 x LDS fits (VS_CONV_BAND_PAIR=0: always the deep-prefetch form)
+    static const int pair_mode = getenv("VS_CONV_BAND_PAIR") ? atoi(getenv("VS_CONV_BAND_PAIR")) : 1;
+    constexpr int R = 256 / W;
+    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * 64 * (R + 2) * W * 2;
+    if (pair_mode && 2 * lds <= 160 * 1024) return launch_band<W, 4, 2>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
+    return launch_band<W, 12, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
+}
+
 // x [B][Cin][H][W] (16-bit), w_packed from vs_conv3_img16_pack_weight (same pre-pack) -> y [B][Cout][H][W] in y_dtype, bias added
 extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
                              int Cout, void* stream) {
@@ -439,9 +460,9 @@ extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, c
     VS_CHECK_ARG(vs_conv3_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_band: unsupported geometry (query vs_conv3_band_supported)");
     VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0, "vs_conv3_band: operands must be 16-byte aligned");
     int rc;
-    if (W == 64) rc = launch_band<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
-    else if (W == 32) rc = launch_band<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
-    else rc = launch_band<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    if (W == 64) rc = launch_band_w<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    else if (W == 32) rc = launch_band_w<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    else rc = launch_band_w<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
     if (rc != VS_OK) return rc;
     VS_CHECK_LAUNCH("vs_conv3_band");
     return VS_OK;
