@@ -179,8 +179,8 @@ int vs_conv3_img16_pack_weight(int compute, const float* w, int Cin, int Cout, i
 int vs_conv3_img16(int compute, const void* x, const void* w_packed, float* slabs, int B, int Cin, int Cout, void* stream);
 /* The same contraction for MANY maps of width 16 / 32 / 64 (every 3x3 block of EncoderSST / DecoderSST(_Skip) conv.py:323-426 and of the VGG
  * encoders / decoders conv.py:127-171, 267-320 on whole batches): workgroup = 256 consecutive pixels of one map (256 / W rows) x 32 output
- * channels, the band's rows + halo of 64 channels at a time in LDS by double-buffered LDS-DMA, no column matrix.  H a multiple of 256 / W,
- * Cin a multiple of 64; weights from vs_conv3_img16_pack_weight (flip = 1 for the input gradient); y in any type, bias added.   */
+ * channels, the band's rows + halo of 64 channels at a time in LDS by double-buffered LDS-DMA, no column matrix.  H a multiple of 256 / W
+ * (W = 8: whole 8 x 8 maps, four per workgroup), Cin a multiple of 64; weights from vs_conv3_img16_pack_weight (flip = 1 for the input gradient); y in any type, bias added.   */
 int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W, int Cout);
 int vs_conv3_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
                   int Cout, void* stream);

@@ -173,10 +173,11 @@ __global__ __launch_bounds__(256) void conv3_img16_kernel(const unsigned short* 
 template <int CT, int W, int AHEAD, int MINB>
 __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
                                                          void* __restrict__ Y, int yd, int B, int Cin, int H, int Cout, int mtiles, int bands) {
-    constexpr int R = 256 / W, RP = R + 2, PW = W / 8;
-    constexpr int NP = 64 * RP * PW / 256;                                       // 16-byte pieces per thread and phase: 12 / 10 / 9
+    // W >= 16: the tile is R = 256 / W rows of ONE map (`band` = which rows); W = 8: FOUR whole 8 x 8 maps (`band` = which four, b = 0)
+    constexpr int IPB = W == 8 ? 4 : 1, RI = W == 8 ? 8 : 256 / W, RPI = RI + 2, RP = IPB * RPI, PW = W / 8;
+    constexpr int NP = 64 * RP * PW / 256;                                       // 16-byte pieces per thread and phase: 12 / 10 / 9 / 10
     constexpr int BUF = 64 * RP * W;                                             // elements per buffer
-    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [2][64 channels][RP rows][W]
+    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [2][64 channels][IPB maps][RPI rows][W]
     int id = blockIdx.x;
     const int mt = id % mtiles;
     id /= mtiles;
@@ -187,12 +188,13 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
 
     auto dma = [&](int ph) {
         char* dst = reinterpret_cast<char*>(xs + (ph & 1) * BUF);
-        const unsigned short* xc = X + ((int64_t)b * Cin + ph * 64) * H * W;
 #pragma unroll
         for (int r = 0; r < NP; ++r) {
             const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
-            const int y = band * R + rr - 1;
-            const void* g = (y >= 0 && y < H) ? (const void*)(xc + ((int64_t)cl * H + y) * W + pc * 8) : (const void*)vs_glds_zero;
+            const int y = (IPB == 1 ? band * RI : 0) + rr % RPI - 1;
+            const int img = IPB == 1 ? b : band * IPB + rr / RPI;
+            const void* g = (y >= 0 && y < H && img < B) ? (const void*)(X + ((((int64_t)img * Cin + ph * 64 + cl) * H + y) * W + pc * 8))
+                                                        : (const void*)vs_glds_zero;
             // asm: the compiler orders a builtin LDS-DMA against every later LDS read with s_waitcnt vmcnt(0), which would also drain the
             // weight stream at every phase; the DMA is covered by the counted waits below instead (M0 has this one writer)
             const uint32_t d = (uint32_t)(uintptr_t)(dst + (r * 256 + wave * 64) * 16);
@@ -220,8 +222,8 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
     int lofs[2];                                                                  // element offset of this lane's piece of tile j, k-row 0, tap row 0
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int q0 = wave * 64 + j * 32 + 16 * cb + 4 * p;
-        lofs[j] = ((8 * h + q) * RP + q0 / W) * W + q0 % W;
+        const int q0 = wave * 64 + j * 32 + 16 * cb + 4 * p, qi = q0 % (RI * W);
+        lofs[j] = ((8 * h + q) * RP + (q0 / (RI * W)) * RPI + qi / W) * W + qi % W;
     }
     const int ngroups = chunks_total * 3;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // phase 0 (and the first fragments) have landed
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
     const int l31 = lane & 31;
     const int idx_l = ((lane & 32) | ((lane - 1) & 31)) * 4, idx_r = ((lane & 32) | ((lane + 1) & 31)) * 4;
     const int mrow = mt * 32 + 4 * (lane >> 5);
-    const int64_t obase = ((int64_t)b * Cout * H + (int64_t)band * R) * W + wave * 64 + l31;
+    const int oimg = IPB == 1 ? b : band * IPB + wave;                            // W = 8: wave w owns map w of the four
+    const int64_t obase = (int64_t)oimg * Cout * H * W + (IPB == 1 ? band * RI * W + wave * 64 : 0) + l31;
     const int col0 = (wave * 64 + l31) % W, col1 = (wave * 64 + 32 + l31) % W;
     float bvs[16];
 #pragma unroll
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
         const float left1 = col1 == 0 ? 0.f : (l31 != 0 ? rl[1] : rl[0]);
         const float right0 = col0 == W - 1 ? 0.f : (l31 != 31 ? rr[0] : rr[1]);
         const float right1 = (l31 != 31 && col1 != W - 1) ? rr[1] : 0.f;
-        if (m < Cout) {
+        if (m < Cout && oimg < B) {
             const float bv = bvs[v];
             const int64_t o = obase + (int64_t)m * H * W;
             vs_st(Y, yd, o, acc[1][0][v] + left0 + right0 + bv);
@@ -409,9 +412,10 @@ extern "C" int vs_slab_sum(const float* slabs, int nslabs, const float* bias, co
     return VS_OK;
 }
 
-// ---- row-band form: many maps, W in {16, 32, 64}, H a multiple of 256 / W, Cin a multiple of 64; y in any type, bias added --------------
+// ---- row-band form: many maps, W in {16, 32, 64} with H a multiple of 256 / W, or 8 x 8 maps; Cin a multiple of 64; y in any type, bias added --
 extern "C" int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W, int Cout) {
-    if (!vs_is16(compute) || (W != 16 && W != 32 && W != 64) || B < 1 || Cout < 1 || Cin < 64 || Cin % 64 != 0) return 0;
+    if (!vs_is16(compute) || (W != 8 && W != 16 && W != 32 && W != 64) || B < 1 || Cout < 1 || Cin < 64 || Cin % 64 != 0) return 0;
+    if (W == 8) return H == 8 && (int64_t)vs_cdiv(B, 4) * vs_cdiv(Cout, 32) < (1ll << 31);       // whole 8 x 8 maps, four per workgroup
     const int R = 256 / W;
     if (H < R || H % R != 0) return 0;
     if ((int64_t)B * (H / R) * vs_cdiv(Cout, 32) >= (1ll << 31)) return 0;
@@ -421,20 +425,20 @@ extern "C" int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W
 template <int W, int AHEAD, int MINB>
 static int launch_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
                        hipStream_t stream) {
-    constexpr int R = 256 / W;
-    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * 64 * (R + 2) * W * 2;        // one buffer when there is a single 64-channel phase
+    constexpr int R = W == 8 ? 8 : 256 / W, RPT = (W == 8 ? 4 : 1) * (R + 2);
+    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * 64 * RPT * W * 2;            // one buffer when there is a single 64-channel phase
     auto kb = conv3_band_kernel<VS_BF16, W, AHEAD, MINB>;
     auto kh = conv3_band_kernel<VS_F16, W, AHEAD, MINB>;
     static bool attr_set = false;
     if (!attr_set) {
-        const int most = 2 * 64 * (R + 2) * W * 2;
+        const int most = 2 * 64 * RPT * W * 2;
         if (hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess ||
             hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess)
             return vs_fail(VS_ERR_LAUNCH, "vs_conv3_band: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    const int mtiles = (int)vs_cdiv(Cout, 32), bands = H / R;
-    const dim3 grid((unsigned)((int64_t)B * bands * mtiles));
+    const int mtiles = (int)vs_cdiv(Cout, 32), bands = W == 8 ? (int)vs_cdiv(B, 4) : H / R;
+    const dim3 grid((unsigned)((int64_t)(W == 8 ? 1 : B) * bands * mtiles));
     if (compute == VS_BF16)
         hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands);
     else
@@ -447,8 +451,8 @@ static int launch_band_w(int compute, const void* x, const void* w_packed, const
                          hipStream_t stream) {
     // two workgroups per CU where 2 x LDS fits (VS_CONV_BAND_PAIR=0: always the deep-prefetch form)
     static const int pair_mode = getenv("VS_CONV_BAND_PAIR") ? atoi(getenv("VS_CONV_BAND_PAIR")) : 1;
-    constexpr int R = 256 / W;
-    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * 64 * (R + 2) * W * 2;
+    constexpr int R = W == 8 ? 8 : 256 / W, RPT = (W == 8 ? 4 : 1) * (R + 2);
+    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * 64 * RPT * W * 2;
     if (pair_mode && 2 * lds <= 160 * 1024) return launch_band<W, 4, 2>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
     return launch_band<W, 12, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
 }
@@ -462,7 +466,8 @@ extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, c
     int rc;
     if (W == 64) rc = launch_band_w<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
     else if (W == 32) rc = launch_band_w<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
-    else rc = launch_band_w<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    else if (W == 16) rc = launch_band_w<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    else rc = launch_band_w<8>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
     if (rc != VS_OK) return rc;
     VS_CHECK_LAUNCH("vs_conv3_band");
     return VS_OK;

@@ -501,6 +501,8 @@ def test_fused_conv_res_block_equals_layer_by_layer(precision, monkeypatch):
     (2, 64, 8, 64, 33),       # H != W: two bands of four rows
     (70, 256, 16, 16, 64),    # more workgroups than CUs: fragment loads still in flight when a workgroup ends
     (9, 128, 64, 64, 32),
+    (10, 128, 8, 8, 72),      # 8 x 8 maps, four per workgroup: 10 = 2 full groups + 2 maps
+    (3, 256, 8, 8, 256),
 ])
 def test_conv3_band_forward_and_input_gradient(dtype, geom):
     """Conv2d k3 s1 p1 on many maps through vs_conv3_band (row bands in LDS, no column matrix) against fp64 conv2d on the same 16-bit
