@@ -28,6 +28,11 @@ FAMILIES = [
     (r'splitk_reduce_kernel', 'splitk_reduce'),
     (r'mix_codes_fwd_kernel', 'vs_mix_codes_fwd'),
     (r'mix_codes_bwd_kernel', 'vs_mix_codes_bwd'),
+    (r'conv3_band_kernel', 'vs_conv3_band<bf16> (row-band 3x3)'),
+    (r'conv3_img16_kernel', 'vs_conv3_img16<bf16> (few-maps 3x3)'),
+    (r'bn_fwd_small_kernel', 'vs_bn_train_fwd_small(_slabs)'),
+    (r'bn_bwd_small', 'vs_bn_act_bwd (one-launch forms)'),
+    (r'slab_sum_kernel', 'vs_slab_sum'),
     (r'convt_k4s2_tap_kernel', 'vs_convT_fwd<bf16> (tap kernel)'),
     (r'conv_k3s1_tap_kernel', 'vs_conv_fwd<bf16> (3x3 tap kernel)'),
     (r'im2col_', 'im2col (column-matrix gathers)'),
