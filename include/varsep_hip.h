@@ -184,6 +184,14 @@ int vs_conv3_img16(int compute, const void* x, const void* w_packed, float* slab
 int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W, int Cout);
 int vs_conv3_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
                   int Cout, void* stream);
+/* Weight gradient of the same convolution without a column matrix (the backward of every Conv2d(k=3, s=1, p=1) above): workgroup = (32 output
+ * channels, 32 input channels, a share of the batch's row bands); dz and three column-shifted copies of the x band in LDS, nine 32x32
+ * accumulators (one per tap) per wave.  Leaves vs_conv3_wgrad_band_slabs(...) fp32 partial gradients [Cout][Cin][3][3]; vs_slab_sum adds
+ * them (addend = the pending gradient for an accumulating call).  W in {16, 32, 64}, H a multiple of 256 / W.                       */
+int vs_slab_sum_grouped(const float* slabs, int nslabs, int groups, float* partial, int64_t total, void* stream);   /* first pass over many slabs */
+int vs_conv3_wgrad_band_supported(int compute, int B, int Cin, int H, int W, int Cout);
+int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout);
+int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int W, int Cout, void* stream);
 int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,
                 void* stream);
 int vs_bn_stats_from_sums(const double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* var_scratch,

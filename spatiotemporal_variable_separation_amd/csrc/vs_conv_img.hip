@@ -294,6 +294,135 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
     }
 }
 
+// ---- weight gradient of the same convolution without a column matrix -------------------------------------------------------------------
+// dW[m][c][ky][kx] = sum over maps and pixels of dz[m][y][x] * x[c][y + ky - 1][x + kx - 1]: the contraction runs over PIXELS, so the tap
+// shift sits on the contraction axis and cannot be taken on the result.  Workgroup = (32 output channels, 32 input channels, share ks of
+// the row bands of the batch); per band (256 consecutive pixels of one map = 256 / W rows) it stages
+//     dz  [32 m][256 px]                          rows of 264 elements (odd multiple of 16 bytes: conflict-free ds_read_b128 over rows)
+//     x   [3 column shifts][32 c][R + 2 rows][W]  channel pitch an odd multiple of 16 bytes; copy kx holds x[..][col + kx - 1], zero beyond
+// through registers (the +-1 pixel copies are built with v_alignbyte from the piece and one neighbour pixel each side), so that EVERY
+// fragment read is an aligned ds_read_b128 (an unaligned one is replayed at 64 cycles).  The band's 16 k-steps of 16 pixels are split
+// over the four waves; a k-step is one dz fragment and nine x fragments (copy kx, row + ky) -> nine MFMAs into nine 32x32 accumulators.
+// The next band's global loads are issued before the MFMA phase of the current one.  Each wave leaves its nine accumulators in an fp32
+// slab of the weight's shape ([ksplit x 4][Cout][Cin][9]); vs_slab_sum adds the slabs (and the pending gradient, if any).
+// MW = 32-row output-channel sub-tiles per workgroup (4, 2 or 1): wave w owns sub-tile w % MW and the k-steps of part w / MW of 4 / MW.
+// With MW = 4 every wave walks all 16 k-steps of a band for its own 32 rows (144 MFMAs per staged band, one slab per workgroup share).
+template <int CT, int W, int MW>
+__global__ __launch_bounds__(256) void wgrad3_band_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DZ, float* __restrict__ slabs,
+                                                          int B, int Cin, int H, int Cout, int ctiles, int ksplit) {
+    constexpr int R = 256 / W, RP = R + 2, PW = W / 8;
+    constexpr int CPITCH = RP * W + 8;                                           // 392 / 328 / 296 elements: (CPITCH / 8) odd
+    constexpr int ZPITCH = 264;
+    constexpr int NX = 32 * RP * PW;                                             // 16-byte pieces of the x tile: 1536 / 1280 / 1152
+    constexpr int NXT = (NX + 255) / 256;                                        // per thread: 6 / 5 / 5 (the last partly)
+    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [3][32][CPITCH] then dz [32 MW][ZPITCH]
+    constexpr int KW = 4 / MW, KSTEPS = 16 / KW;                                 // k parts per band, k-steps per wave and band
+    unsigned short* zs = xs + 3 * 32 * CPITCH;
+    int id = blockIdx.x;
+    const int ks = id % ksplit;
+    id /= ksplit;
+    const int ct = id % ctiles, mt = id / ctiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bands = H / R;
+    const int64_t items = (int64_t)B * bands;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+    u32x4 xr[NXT], zr[4 * MW];
+    unsigned xe[NXT];                                                            // neighbour pixels: low half = the one before the piece, high half = after
+    auto load_item = [&](int64_t it) {
+        const int b = (int)(it / bands), band = (int)(it % bands);
+#pragma unroll
+        for (int r = 0; r < NXT; ++r) {
+            const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
+            const int y = band * R + rr - 1, c = ct * 32 + cl;
+            // every load is unconditional and the SELECT sits on the address (a block of zeros for what lies outside): a conditional load
+            // makes the compiler wait for each one where the two paths merge -- ten serial round trips per band
+            const bool ok = u < NX && y >= 0 && y < H && c < Cin;
+            const unsigned short* zero = reinterpret_cast<const unsigned short*>(vs_glds_zero);
+            const unsigned short* src = ok ? X + (((int64_t)b * Cin + c) * H + y) * W + pc * 8 : zero;
+            const unsigned short* pb = (ok && pc > 0) ? src - 1 : zero;
+            const unsigned short* pa = (ok && pc + 1 < PW) ? src + 8 : zero;
+            xr[r] = *reinterpret_cast<const u32x4*>(src);
+            xe[r] = (unsigned)*pb | ((unsigned)*pa << 16);
+        }
+#pragma unroll
+        for (int r = 0; r < 4 * MW; ++r) {
+            const int u = r * 256 + tid, ml = u >> 5, pc = u & 31, m = mt * (32 * MW) + ml;
+            const unsigned short* src = m < Cout ? DZ + (((int64_t)b * Cout + m) * H + band * R) * W + pc * 8
+                                                 : reinterpret_cast<const unsigned short*>(vs_glds_zero);
+            zr[r] = *reinterpret_cast<const u32x4*>(src);
+        }
+    };
+    auto store_item = [&]() {
+#pragma unroll
+        for (int r = 0; r < NXT; ++r) {
+            const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
+            if (u < NX) {
+                unsigned short* dst = xs + cl * CPITCH + rr * W + pc * 8;
+                const u32x4 d = xr[r];
+                const unsigned before = xe[r] << 16, after = xe[r] >> 16;           // `before` in the HIGH half: (d0 : before) >> 16 starts with it
+                u32x4 lft, rgt;
+                lft[0] = __builtin_amdgcn_alignbyte(d[0], before, 2);
+                lft[1] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
+                lft[2] = __builtin_amdgcn_alignbyte(d[2], d[1], 2);
+                lft[3] = __builtin_amdgcn_alignbyte(d[3], d[2], 2);
+                rgt[0] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
+                rgt[1] = __builtin_amdgcn_alignbyte(d[2], d[1], 2);
+                rgt[2] = __builtin_amdgcn_alignbyte(d[3], d[2], 2);
+                rgt[3] = __builtin_amdgcn_alignbyte(after, d[3], 2);
+                *reinterpret_cast<u32x4*>(dst) = lft;                                  // copy 0: x[col - 1]
+                *reinterpret_cast<u32x4*>(dst + 32 * CPITCH) = d;                      // copy 1: x[col]
+                *reinterpret_cast<u32x4*>(dst + 64 * CPITCH) = rgt;                    // copy 2: x[col + 1]
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4 * MW; ++r) {
+            const int u = r * 256 + tid, ml = u >> 5, pc = u & 31;
+            *reinterpret_cast<u32x4*>(zs + ml * ZPITCH + pc * 8) = zr[r];
+        }
+    };
+
+    const int rl = lane & 31, h = lane >> 5;
+    const int msub = wave % MW, kpart = wave / MW;
+    int64_t it = ks;
+    if (it < items) load_item(it);
+    for (; it < items; it += ksplit) {
+        __syncthreads();                                                         // the previous band's fragments have been read
+        store_item();
+        __syncthreads();
+        if (it + ksplit < items) load_item(it + ksplit);                         // travels during the MFMA phase
+#pragma unroll 4
+        for (int tt = 0; tt < KSTEPS; ++tt) {
+            const int t = kpart * KSTEPS + tt, p0 = t * 16, row = p0 / W, x0 = p0 % W;
+            const u32x4 af = *reinterpret_cast<const u32x4*>(zs + (msub * 32 + rl) * ZPITCH + p0 + 8 * h);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const u32x4 bf = *reinterpret_cast<const u32x4*>(xs + (kx * 32 + rl) * CPITCH + (row + ky) * W + x0 + 8 * h);
+                    acc[ky * 3 + kx] = mfma16_32<CT>(af, bf, acc[ky * 3 + kx]);
+                }
+        }
+    }
+
+    // ---- this wave's nine 32 x 32 partial sums -> slab (ks, kpart): dW[m][c][tap] ---------------------------------------------------------
+    float* out = slabs + ((int64_t)ks * KW + kpart) * ((int64_t)Cout * Cin * 9);
+    const int c = ct * 32 + rl;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int m = mt * (32 * MW) + msub * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+            if (m < Cout && c < Cin) out[((int64_t)m * Cin + c) * 9 + t] = acc[t][v];
+        }
+}
+
 // Wp[mt][chunk][ky][kx][lane][8]: lane (r = lane & 31, h = lane >> 5) holds W[m = 32 mt + r][c = 16 chunk + 8 h .. + 7][ky][kx]
 // (flip = 0, w = [M][K][3][3]) or, for the input gradient (flip = 1, w = the conv's [K][M][3][3]), w[c][m][2 - ky][2 - kx]
 template <int CT>
@@ -331,6 +460,20 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
         }
         if (od == VS_F32) *reinterpret_cast<f32x4*>((float*)out + i) = s;
         else *reinterpret_cast<u16x4*>((unsigned short*)out + i) = u16x4{vs_f2h(s[0], od), vs_f2h(s[1], od), vs_f2h(s[2], od), vs_f2h(s[3], od)};
+    }
+}
+
+// partial[g][i] = sum of the slabs of group g (consecutive runs of `per` slabs), fixed order: the first pass over MANY slabs of a small
+// tensor (hundreds of weight-gradient slabs of a 64 x 64 x 3 x 3 weight: one pass would be 36 workgroups adding 512 values each)
+__global__ __launch_bounds__(256) void slab_sum_grouped_kernel(const float* __restrict__ slabs, int nslabs, int per, int64_t total, float* __restrict__ partial) {
+    const int g = blockIdx.y, s0 = g * per, s1 = s0 + per < nslabs ? s0 + per : nslabs;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = s0; k < s1; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * total + i);
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        *reinterpret_cast<f32x4*>(partial + (int64_t)g * total + i) = s;
     }
 }
 
@@ -470,5 +613,82 @@ extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, c
     else rc = launch_band_w<8>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
     if (rc != VS_OK) return rc;
     VS_CHECK_LAUNCH("vs_conv3_band");
+    return VS_OK;
+}
+
+// ---- weight gradient on row bands: x [B][Cin][H][W], dz [B][Cout][H][W] (16-bit) -> fp32 slabs [vs_conv3_wgrad_band_slabs][Cout][Cin][3][3] ----
+extern "C" int vs_conv3_wgrad_band_supported(int compute, int B, int Cin, int H, int W, int Cout) {
+    if (!vs_is16(compute) || (W != 16 && W != 32 && W != 64) || B < 1 || Cout < 8 || Cin < 8) return 0;
+    const int R = 256 / W;
+    if (H < R || H % R != 0) return 0;
+    return 1;
+}
+
+static int wgrad_band_mw(int Cout) { return Cout > 64 ? 4 : (Cout > 32 ? 2 : 1); }      // 32-row sub-tiles per workgroup
+
+static int wgrad_band_ksplit(int B, int Cin, int H, int W, int Cout) {
+    const int mw = wgrad_band_mw(Cout);
+    const int64_t tiles = vs_cdiv(Cout, 32 * mw) * vs_cdiv(Cin, 32), items = (int64_t)B * (H / (256 / W));
+    int64_t ks = vs_cdiv(512, tiles);                                           // ~2 rounds of workgroups over the launch
+    if (ks > items) ks = items;
+    const int64_t slab_bytes = (int64_t)Cout * Cin * 9 * 4;
+    while (ks > 1 && ks * (4 / mw) * slab_bytes > ((int64_t)96 << 20)) --ks;    // at most 96 MiB of slabs
+    return (int)(ks < 1 ? 1 : ks);
+}
+
+extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout) {
+    return (4 / wgrad_band_mw(Cout)) * wgrad_band_ksplit(B, Cin, H, W, Cout);
+}
+
+template <int W, int MW>
+static void launch_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
+    constexpr int R = 256 / W;
+    const size_t lds = (size_t)(3 * 32 * ((R + 2) * W + 8) + 32 * MW * 264) * 2;
+    auto kb = wgrad3_band_kernel<VS_BF16, W, MW>;
+    auto kh = wgrad3_band_kernel<VS_F16, W, MW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int mtiles = (int)vs_cdiv(Cout, 32 * MW), ctiles = (int)vs_cdiv(Cin, 32);
+    const dim3 grid((unsigned)((int64_t)mtiles * ctiles * ksplit));
+    if (compute == VS_BF16)
+        hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, (const unsigned short*)x, (const unsigned short*)dz, slabs, B, Cin, H, Cout, ctiles, ksplit);
+    else
+        hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, (const unsigned short*)x, (const unsigned short*)dz, slabs, B, Cin, H, Cout, ctiles, ksplit);
+}
+
+template <int W>
+static void launch_wgrad_band_w(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
+    const int mw = wgrad_band_mw(Cout);
+    if (mw == 4) launch_wgrad_band<W, 4>(compute, x, dz, slabs, B, Cin, H, Cout, ksplit, stream);
+    else if (mw == 2) launch_wgrad_band<W, 2>(compute, x, dz, slabs, B, Cin, H, Cout, ksplit, stream);
+    else launch_wgrad_band<W, 1>(compute, x, dz, slabs, B, Cin, H, Cout, ksplit, stream);
+}
+
+extern "C" int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int W, int Cout, void* stream) {
+    VS_CHECK_ARG(x && dz && slabs, "vs_conv3_wgrad_band: bad argument");
+    VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_wgrad_band: unsupported geometry (query vs_conv3_wgrad_band_supported)");
+    VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)dz | (uintptr_t)slabs) % 16 == 0, "vs_conv3_wgrad_band: operands must be 16-byte aligned");
+    const int ks = wgrad_band_ksplit(B, Cin, H, W, Cout);
+    if (W == 64) launch_wgrad_band_w<64>(compute, x, dz, slabs, B, Cin, H, Cout, ks, (hipStream_t)stream);
+    else if (W == 32) launch_wgrad_band_w<32>(compute, x, dz, slabs, B, Cin, H, Cout, ks, (hipStream_t)stream);
+    else launch_wgrad_band_w<16>(compute, x, dz, slabs, B, Cin, H, Cout, ks, (hipStream_t)stream);
+    VS_CHECK_LAUNCH("vs_conv3_wgrad_band");
+    return VS_OK;
+}
+
+// partial[g][i] = sum over the slabs g * per .. g * per + per - 1 (per = ceil(nslabs / groups)) of slabs[s][i], i < total (a multiple of 4):
+// first pass over many slabs of a small tensor; vs_slab_sum over the `groups` partials finishes.
+extern "C" int vs_slab_sum_grouped(const float* slabs, int nslabs, int groups, float* partial, int64_t total, void* stream) {
+    VS_CHECK_ARG(slabs && partial && nslabs >= 1 && groups >= 1 && groups <= nslabs && total > 0 && total % 4 == 0, "vs_slab_sum_grouped: bad argument");
+    VS_CHECK_ARG(((uintptr_t)slabs | (uintptr_t)partial) % 16 == 0, "vs_slab_sum_grouped: operands must be 16-byte aligned");
+    const int per = (nslabs + groups - 1) / groups;
+    int64_t blocks = vs_cdiv(total, 1024);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(slab_sum_grouped_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, per, total, partial);
+    VS_CHECK_LAUNCH("vs_slab_sum_grouped");
     return VS_OK;
 }

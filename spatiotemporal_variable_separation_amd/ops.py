@@ -482,6 +482,19 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     return dx
 
 
+def conv3_wgrad_band_supported(x, Cout):
+    """Whether the weight gradient of Conv2d k3 s1 p1 with input `x` takes the row-band kernel (no column matrix).  VS_CONV_WGRAD_BAND=0: never."""
+    import os
+    if os.environ.get('VS_CONV_WGRAD_BAND') == '0' or x.dtype == torch.float32 or x.dim() != 4:
+        return False
+    B, Cin, H, W = x.shape
+    if (Cin * Cout * 9) % 4 != 0:
+        return False
+    if W == 16 and Cin < 128 and os.environ.get('VS_CONV_WGRAD_BAND') != '2':
+        return False        # few input channels on 16-wide maps: the column matrix is small and the GEMM wins (123 vs 180 us at 64 -> 512 x 312 maps)
+    return bool(_lib.load_library().vs_conv3_wgrad_band_supported(dtype_code(x), B, Cin, H, W, Cout))
+
+
 def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
     """Weight gradient of a (transposed) convolution; `into`: an fp32 tensor of the weight's shape that the result is ADDED to
     (in the GEMM / split-K epilogue) instead of a fresh tensor; `out`: an fp32 tensor that receives it."""
@@ -497,6 +510,23 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
         assert into is None and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(w_shape)
     dw = into if into is not None else (out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device))
     lib = _lib.load_library()
+    if not transposed and k == 3 and stride == 1 and pad == 1 and conv3_wgrad_band_supported(x, Cout):
+        # 3x3 on maps of width 16 / 32 / 64: row bands in LDS, no column matrix; partial gradients in slabs, one launch adds them
+        nslabs = lib.vs_conv3_wgrad_band_slabs(B, Cin, H, W, Cout)
+        slabs = torch.empty((nslabs,) + tuple(w_shape), dtype=torch.float32, device=x.device)
+        e0 = _pb()
+        check(lib.vs_conv3_wgrad_band(dtype_code(x), x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), B, Cin, H, W, Cout, stream_ptr()), 'vs_conv3_wgrad_band')
+        src, n = slabs, nslabs
+        if nslabs > 24:
+            # many slabs of a small weight: a first pass in 16 groups (every workgroup adds <= nslabs / 16 coalesced slabs), then the 16 partials
+            n = 16
+            src = torch.empty((n,) + tuple(w_shape), dtype=torch.float32, device=x.device)
+            check(lib.vs_slab_sum_grouped(slabs.data_ptr(), nslabs, n, src.data_ptr(), dw.numel(), stream_ptr()), 'vs_slab_sum_grouped')
+            n = -(-nslabs // (-(-nslabs // 16)))          # groups that received slabs: ceil(nslabs / per)
+        check(lib.vs_slab_sum(src.data_ptr(), n, None, _ptr(into), dw.data_ptr(), F32, 1, 1, dw.numel(), stream_ptr()), 'vs_slab_sum')
+        _pe(e0, 'vs_conv_wgrad<%s>' % _DT[dtype_code(x)], flops=2.0 * B * Cout * OH * OW * Cin * 9,
+            nbytes=float(dy.numel() * dy.element_size() + x.numel() * x.element_size() + slabs.numel() * 8))
+        return dw
     pix_h, pix_w = (H, W) if transposed else (OH, OW)
     ws = _conv_workspace(dtype_code(x), B, Cin, H, W, Cout, k, stride, pad, x.device)
     if ws is None:

@@ -530,3 +530,35 @@ def test_conv3_band_forward_and_input_gradient(dtype, geom):
         wf = ops.conv3_img16_pack_weight(w.float().cuda(), dtype, True)
         dx = ops.conv3_band(dz.cuda(), wf, None, Cin, torch.float32)
         assert ((dx.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max()).item() < 1e-5, f'dgrad {geom} {dtype}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom', [
+    (2, 64, 64, 64, 64),      # W = 64: four-row bands
+    (3, 128, 32, 32, 40),     # ragged output-channel tile
+    (5, 96, 16, 16, 72),      # W = 16, 3 x 3 tiles of 32 channels
+    (2, 40, 8, 64, 33),       # ragged both ways, H != W
+    (40, 64, 32, 32, 64),     # several bands per workgroup share
+    (312, 64, 16, 16, 512),   # the SST integrator's batched call (39 x 8 maps)
+])
+def test_conv3_wgrad_band_matches_fp64(dtype, geom, monkeypatch):
+    """Weight gradient of Conv2d k3 s1 p1 through vs_conv3_wgrad_band + vs_slab_sum (ops.conv_wgrad picks it) against fp64 autograd on the
+    same 16-bit operands, fresh and accumulated into a pending gradient; equal to the column-matrix path up to summation order."""
+    from spatiotemporal_variable_separation_amd import ops
+    monkeypatch.setenv('VS_CONV_WGRAD_BAND', '2')            # also where the plan prefers the column matrix
+    B, Cin, H, W, Cout = geom
+    x = _rand((B, Cin, H, W), 101).to(dtype)
+    dz = _rand((B, Cout, H, W), 102).to(dtype)
+    assert ops.conv3_wgrad_band_supported(x.cuda(), Cout)
+    w64 = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w64, None, stride=1, padding=1).backward(dz.double())
+    dw = ops.conv_wgrad(dz.cuda(), x.cuda(), (Cout, Cin, 3, 3), 1, 1, False)
+    again = ops.conv_wgrad(dz.cuda(), x.cuda(), (Cout, Cin, 3, 3), 1, 1, False)
+    pend = _rand((Cout, Cin, 3, 3), 103).cuda()
+    acc = ops.conv_wgrad(dz.cuda(), x.cuda(), (Cout, Cin, 3, 3), 1, 1, False, into=pend.clone())
+    torch.cuda.synchronize()
+    scale = w64.grad.abs().max()
+    assert ((dw.cpu().double() - w64.grad).abs().max() / scale).item() < 2e-6, geom
+    assert torch.equal(dw, again)
+    assert ((acc.cpu().double() - (w64.grad + pend.cpu().double())).abs().max() / scale).item() < 2e-6
