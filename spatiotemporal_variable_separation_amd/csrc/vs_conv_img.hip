@@ -307,9 +307,17 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
 // slab of the weight's shape ([ksplit x 4][Cout][Cin][9]); vs_slab_sum adds the slabs (and the pending gradient, if any).
 // MW = 32-row output-channel sub-tiles per workgroup (4, 2 or 1): wave w owns sub-tile w % MW and the k-steps of part w / MW of 4 / MW.
 // With MW = 4 every wave walks all 16 k-steps of a band for its own 32 rows (144 MFMAs per staged band, one slab per workgroup share).
+// The batch may come in up to 64 equal pieces (the remembered (dz, x) pairs of a convolution that is applied once per predicted frame:
+// functional.flush_deferred_wgrads) -- map b lives in piece b / maps_per_piece; the pointers travel as kernel arguments.
+constexpr int WG_MAX_PIECES = 64;
+struct WgradPieces {
+    const unsigned short* x[WG_MAX_PIECES];
+    const unsigned short* dz[WG_MAX_PIECES];
+    int maps_per_piece;
+};
+
 template <int CT, int W, int MW>
-__global__ __launch_bounds__(256) void wgrad3_band_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DZ, float* __restrict__ slabs,
-                                                          int B, int Cin, int H, int Cout, int ctiles, int ksplit) {
+__global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, float* __restrict__ slabs, int B, int Cin, int H, int Cout, int ctiles, int ksplit) {
     constexpr int R = 256 / W, RP = R + 2, PW = W / 8;
     constexpr int CPITCH = RP * W + 8;                                           // 392 / 328 / 296 elements: (CPITCH / 8) odd
     constexpr int ZPITCH = 264;
@@ -336,7 +344,10 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(const unsigned short* 
     u32x4 xr[NXT], zr[4 * MW];
     unsigned xe[NXT];                                                            // neighbour pixels: low half = the one before the piece, high half = after
     auto load_item = [&](int64_t it) {
-        const int b = (int)(it / bands), band = (int)(it % bands);
+        const int bg = (int)(it / bands), band = (int)(it % bands);
+        const int piece = bg / pieces.maps_per_piece, b = bg - piece * pieces.maps_per_piece;
+        const unsigned short* X = pieces.x[piece];
+        const unsigned short* DZ = pieces.dz[piece];
 #pragma unroll
         for (int r = 0; r < NXT; ++r) {
             const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
@@ -641,7 +652,7 @@ extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout)
 }
 
 template <int W, int MW>
-static void launch_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
+static void launch_wgrad_band(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
     constexpr int R = 256 / W;
     const size_t lds = (size_t)(3 * 32 * ((R + 2) * W + 8) + 32 * MW * 264) * 2;
     auto kb = wgrad3_band_kernel<VS_BF16, W, MW>;
@@ -655,29 +666,55 @@ static void launch_wgrad_band(int compute, const void* x, const void* dz, float*
     const int mtiles = (int)vs_cdiv(Cout, 32 * MW), ctiles = (int)vs_cdiv(Cin, 32);
     const dim3 grid((unsigned)((int64_t)mtiles * ctiles * ksplit));
     if (compute == VS_BF16)
-        hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, (const unsigned short*)x, (const unsigned short*)dz, slabs, B, Cin, H, Cout, ctiles, ksplit);
+        hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, pieces, slabs, B, Cin, H, Cout, ctiles, ksplit);
     else
-        hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, (const unsigned short*)x, (const unsigned short*)dz, slabs, B, Cin, H, Cout, ctiles, ksplit);
+        hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, pieces, slabs, B, Cin, H, Cout, ctiles, ksplit);
 }
 
 template <int W>
-static void launch_wgrad_band_w(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
+static void launch_wgrad_band_w(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
     const int mw = wgrad_band_mw(Cout);
-    if (mw == 4) launch_wgrad_band<W, 4>(compute, x, dz, slabs, B, Cin, H, Cout, ksplit, stream);
-    else if (mw == 2) launch_wgrad_band<W, 2>(compute, x, dz, slabs, B, Cin, H, Cout, ksplit, stream);
-    else launch_wgrad_band<W, 1>(compute, x, dz, slabs, B, Cin, H, Cout, ksplit, stream);
+    if (mw == 4) launch_wgrad_band<W, 4>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
+    else if (mw == 2) launch_wgrad_band<W, 2>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
+    else launch_wgrad_band<W, 1>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
+}
+
+static int wgrad_band_go(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int W, int Cout, hipStream_t stream) {
+    const int ks = wgrad_band_ksplit(B, Cin, H, W, Cout);
+    if (W == 64) launch_wgrad_band_w<64>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    else if (W == 32) launch_wgrad_band_w<32>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    else launch_wgrad_band_w<16>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    VS_CHECK_LAUNCH("vs_conv3_wgrad_band");
+    return VS_OK;
 }
 
 extern "C" int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int W, int Cout, void* stream) {
     VS_CHECK_ARG(x && dz && slabs, "vs_conv3_wgrad_band: bad argument");
     VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_wgrad_band: unsupported geometry (query vs_conv3_wgrad_band_supported)");
     VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)dz | (uintptr_t)slabs) % 16 == 0, "vs_conv3_wgrad_band: operands must be 16-byte aligned");
-    const int ks = wgrad_band_ksplit(B, Cin, H, W, Cout);
-    if (W == 64) launch_wgrad_band_w<64>(compute, x, dz, slabs, B, Cin, H, Cout, ks, (hipStream_t)stream);
-    else if (W == 32) launch_wgrad_band_w<32>(compute, x, dz, slabs, B, Cin, H, Cout, ks, (hipStream_t)stream);
-    else launch_wgrad_band_w<16>(compute, x, dz, slabs, B, Cin, H, Cout, ks, (hipStream_t)stream);
-    VS_CHECK_LAUNCH("vs_conv3_wgrad_band");
-    return VS_OK;
+    WgradPieces pieces = {};
+    pieces.x[0] = (const unsigned short*)x;
+    pieces.dz[0] = (const unsigned short*)dz;
+    pieces.maps_per_piece = B;
+    return wgrad_band_go(compute, pieces, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
+}
+
+// The same over a batch that lies in `npieces` (<= 64) separate tensors of `maps_per_piece` maps each (x[i] [maps][Cin][H][W], dz[i]
+// [maps][Cout][H][W]): the gradient over their concatenation without building it.  Slabs as for B = npieces * maps_per_piece.
+extern "C" int vs_conv3_wgrad_band_pieces(int compute, int npieces, const void* const* x, const void* const* dz, int maps_per_piece, float* slabs, int Cin,
+                                          int H, int W, int Cout, void* stream) {
+    VS_CHECK_ARG(x && dz && slabs && npieces >= 1 && npieces <= WG_MAX_PIECES && maps_per_piece >= 1, "vs_conv3_wgrad_band_pieces: bad argument");
+    const int B = npieces * maps_per_piece;
+    VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_wgrad_band_pieces: unsupported geometry");
+    WgradPieces pieces = {};
+    for (int i = 0; i < npieces; ++i) {
+        VS_CHECK_ARG(x[i] && dz[i] && ((uintptr_t)x[i] | (uintptr_t)dz[i]) % 16 == 0, "vs_conv3_wgrad_band_pieces: every piece must be a 16-byte aligned tensor");
+        pieces.x[i] = (const unsigned short*)x[i];
+        pieces.dz[i] = (const unsigned short*)dz[i];
+    }
+    pieces.maps_per_piece = maps_per_piece;
+    VS_CHECK_ARG((uintptr_t)slabs % 16 == 0, "vs_conv3_wgrad_band_pieces: slabs must be 16-byte aligned");
+    return wgrad_band_go(compute, pieces, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
 }
 
 // partial[g][i] = sum over the slabs g * per .. g * per + per - 1 (per = ceil(nslabs / groups)) of slabs[s][i], i < total (a multiple of 4):

@@ -78,6 +78,10 @@ def flush_deferred_wgrads():
             if len(pairs) == 1:
                 dz, xc = pairs[0]
             else:
+                # 3x3 on the row-band kernel: the pairs are addressed where they lie (no concatenation: 2 x 39 copies of 2 MB in the SST step)
+                if (slot['shape'][2:] == (3, 3) and slot['stride'] == 1 and slot['pad'] == 1
+                        and ops.conv3_wgrad_band_pieces(pairs, slot['shape'], into=slot['g']) is not None):
+                    continue
                 dz = torch.cat([p[0] for p in pairs], dim=0)
                 xc = torch.cat([p[1] for p in pairs], dim=0)
             ops.conv_wgrad(dz, xc, slot['shape'], slot['stride'], slot['pad'], False, into=slot['g'])

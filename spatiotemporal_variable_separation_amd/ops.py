@@ -482,8 +482,9 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     return dx
 
 
-def conv3_wgrad_band_supported(x, Cout):
-    """Whether the weight gradient of Conv2d k3 s1 p1 with input `x` takes the row-band kernel (no column matrix).  VS_CONV_WGRAD_BAND=0: never."""
+def conv3_wgrad_band_supported(x, Cout, dtype_code_of=None):
+    """Whether the weight gradient of Conv2d k3 s1 p1 with input `x` takes the row-band kernel (no column matrix).  VS_CONV_WGRAD_BAND=0: never.
+    (`x` may be a meta tensor that only carries the shape; then `dtype_code_of` is the operand type code.)"""
     import os
     if os.environ.get('VS_CONV_WGRAD_BAND') == '0' or x.dtype == torch.float32 or x.dim() != 4:
         return False
@@ -492,7 +493,48 @@ def conv3_wgrad_band_supported(x, Cout):
         return False
     if W == 16 and Cin < 128 and os.environ.get('VS_CONV_WGRAD_BAND') != '2':
         return False        # few input channels on 16-wide maps: the column matrix is small and the GEMM wins (123 vs 180 us at 64 -> 512 x 312 maps)
-    return bool(_lib.load_library().vs_conv3_wgrad_band_supported(dtype_code(x), B, Cin, H, W, Cout))
+    return bool(_lib.load_library().vs_conv3_wgrad_band_supported(dtype_code_of if dtype_code_of is not None else dtype_code(x), B, Cin, H, W, Cout))
+
+
+def _slab_reduce(slabs, nslabs, w_shape, into, dw):
+    """dw = sum of `nslabs` fp32 partial gradients (+ the pending gradient `into`); two passes when a small weight has many slabs."""
+    lib = _lib.load_library()
+    src, n = slabs, nslabs
+    if nslabs > 24:
+        # many slabs of a small weight: a first pass in 16 groups (every workgroup adds <= nslabs / 16 coalesced slabs), then the 16 partials
+        src = torch.empty((16,) + tuple(w_shape), dtype=torch.float32, device=slabs.device)
+        check(lib.vs_slab_sum_grouped(slabs.data_ptr(), nslabs, 16, src.data_ptr(), dw.numel(), stream_ptr()), 'vs_slab_sum_grouped')
+        n = -(-nslabs // (-(-nslabs // 16)))          # groups that received slabs: ceil(nslabs / per)
+    check(lib.vs_slab_sum(src.data_ptr(), n, None, _ptr(into), dw.data_ptr(), F32, 1, 1, dw.numel(), stream_ptr()), 'vs_slab_sum')
+
+
+def conv3_wgrad_band_pieces(pairs, w_shape, into=None):
+    """Weight gradient of Conv2d k3 s1 p1 over the batch formed by the (dz, x) pairs -- equal shapes, each contiguous -- WITHOUT concatenating
+    them (`vs_conv3_wgrad_band_pieces`: the piece pointers travel as kernel arguments).  Returns None when the row-band kernel does not
+    serve the concatenated shape or there are more than 64 pieces (the caller concatenates)."""
+    import ctypes
+    dz0, x0 = pairs[0]
+    n = len(pairs)
+    mp, Cin, H, W = x0.shape
+    Cout = w_shape[0]
+    if n > 64 or any(p[0].shape != dz0.shape or p[1].shape != x0.shape or not p[0].is_contiguous() or not p[1].is_contiguous()
+                     or p[0].dtype != x0.dtype or p[1].dtype != x0.dtype for p in pairs):
+        return None
+    if not conv3_wgrad_band_supported(torch.empty((n * mp, Cin, H, W), dtype=x0.dtype, device='meta'), Cout, dtype_code_of=dtype_code(x0)):
+        return None
+    lib = _lib.load_library()
+    B = n * mp
+    nslabs = lib.vs_conv3_wgrad_band_slabs(B, Cin, H, W, Cout)
+    slabs = torch.empty((nslabs,) + tuple(w_shape), dtype=torch.float32, device=x0.device)
+    dw = into if into is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x0.device)
+    xs = (ctypes.c_void_p * n)(*[p[1].data_ptr() for p in pairs])
+    dzs = (ctypes.c_void_p * n)(*[p[0].data_ptr() for p in pairs])
+    e0 = _pb()
+    check(lib.vs_conv3_wgrad_band_pieces(dtype_code(x0), n, xs, dzs, mp, slabs.data_ptr(), Cin, H, W, Cout, stream_ptr()), 'vs_conv3_wgrad_band_pieces')
+    _slab_reduce(slabs, nslabs, w_shape, into, dw)
+    _pe(e0, 'vs_conv_wgrad<%s>' % _DT[dtype_code(x0)], flops=2.0 * B * Cout * H * W * Cin * 9,
+        nbytes=float(n * (dz0.numel() + x0.numel()) * x0.element_size() + slabs.numel() * 8))
+    return dw
 
 
 def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
@@ -516,14 +558,7 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
         slabs = torch.empty((nslabs,) + tuple(w_shape), dtype=torch.float32, device=x.device)
         e0 = _pb()
         check(lib.vs_conv3_wgrad_band(dtype_code(x), x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), B, Cin, H, W, Cout, stream_ptr()), 'vs_conv3_wgrad_band')
-        src, n = slabs, nslabs
-        if nslabs > 24:
-            # many slabs of a small weight: a first pass in 16 groups (every workgroup adds <= nslabs / 16 coalesced slabs), then the 16 partials
-            n = 16
-            src = torch.empty((n,) + tuple(w_shape), dtype=torch.float32, device=x.device)
-            check(lib.vs_slab_sum_grouped(slabs.data_ptr(), nslabs, n, src.data_ptr(), dw.numel(), stream_ptr()), 'vs_slab_sum_grouped')
-            n = -(-nslabs // (-(-nslabs // 16)))          # groups that received slabs: ceil(nslabs / per)
-        check(lib.vs_slab_sum(src.data_ptr(), n, None, _ptr(into), dw.data_ptr(), F32, 1, 1, dw.numel(), stream_ptr()), 'vs_slab_sum')
+        _slab_reduce(slabs, nslabs, w_shape, into, dw)
         _pe(e0, 'vs_conv_wgrad<%s>' % _DT[dtype_code(x)], flops=2.0 * B * Cout * OH * OW * Cin * 9,
             nbytes=float(dy.numel() * dy.element_size() + x.numel() * x.element_size() + slabs.numel() * 8))
         return dw

@@ -562,3 +562,23 @@ def test_conv3_wgrad_band_matches_fp64(dtype, geom, monkeypatch):
     assert ((dw.cpu().double() - w64.grad).abs().max() / scale).item() < 2e-6, geom
     assert torch.equal(dw, again)
     assert ((acc.cpu().double() - (w64.grad + pend.cpu().double())).abs().max() / scale).item() < 2e-6
+
+
+@pytest.mark.gpu
+def test_conv3_wgrad_band_over_separate_pieces_equals_the_concatenated_batch():
+    """vs_conv3_wgrad_band_pieces (the remembered (dz, x) pairs of a repeatedly applied convolution, addressed where they lie) == the same
+    kernel on the concatenation, bit for bit, fresh and accumulated."""
+    from spatiotemporal_variable_separation_amd import ops
+    dtype = torch.bfloat16
+    pairs = [(_rand((8, 256, 16, 16), 200 + i).to(dtype).cuda(), _rand((8, 128, 16, 16), 300 + i).to(dtype).cuda()) for i in range(5)]
+    shape = (256, 128, 3, 3)
+    dz, x = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
+    assert ops.conv3_wgrad_band_supported(x, 256)
+    want = ops.conv_wgrad(dz, x, shape, 1, 1, False)
+    got = ops.conv3_wgrad_band_pieces(pairs, shape)
+    pend = _rand(shape, 77).cuda()
+    acc_want = ops.conv_wgrad(dz, x, shape, 1, 1, False, into=pend.clone())
+    acc_got = ops.conv3_wgrad_band_pieces(pairs, shape, into=pend.clone())
+    torch.cuda.synchronize()
+    assert got is not None and torch.equal(got, want) and torch.equal(acc_got, acc_want)
+    assert ops.conv3_wgrad_band_pieces(pairs * 13, shape) is None            # more than 64 pieces: the caller concatenates
