@@ -48,8 +48,12 @@ __device__ __forceinline__ void img_load3(u32x4& a0, u32x4& a1, u32x4& a2, const
                  : "memory");
 }
 __device__ __forceinline__ void img_wait3(u32x4& a0, u32x4& a1, u32x4& a2) {
-    static_assert((IMG_AHEAD - 1) * 3 == 33, "the wait count is written into the instruction");
     asm volatile("s_waitcnt vmcnt(33)" : "+v"(a0), "+v"(a1), "+v"(a2) : : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void img_wait3n(u32x4& a0, u32x4& a1, u32x4& a2) {   // as img_wait3 with N younger loads allowed in flight
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a0), "+v"(a1), "+v"(a2) : "n"(N) : "memory");
 }
 
 // NP 16-byte pieces per thread of the staged image: piece u = channel (u >> 5), 8 pixels (u & 31) -> the channel's rows 1 .. 16 in LDS
@@ -65,13 +69,10 @@ __device__ __forceinline__ void img_stage(unsigned short* xs, const unsigned sho
     }
 }
 
-template <int N>
-__device__ __forceinline__ void img_wait3n(u32x4& a0, u32x4& a1, u32x4& a2) {   // as img_wait3 with N younger loads allowed in flight
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a0), "+v"(a1), "+v"(a2) : "n"(N) : "memory");
-}
-
-template <int CT>
-__global__ __launch_bounds__(256) void conv3_img16_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, float* __restrict__ slabs,
+// AHEAD = 12, MINB = 1: the deep prefetch, one workgroup per CU.  AHEAD = 4, MINB = 2: two workgroups per CU (splits of <= 128 channels =
+// 72 KiB of LDS each) that cover each other's staging and epilogue -- taken when that doubles the number of resident workgroups.
+template <int CT, int AHEAD, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, float* __restrict__ slabs,
                                                           int B, int Cin, int Cout, int cs, int splits, int mtiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [cs][18][16]
     int id = blockIdx.x;
@@ -87,9 +88,9 @@ __global__ __launch_bounds__(256) void conv3_img16_kernel(const unsigned short* 
     const int chunks_total = Cin >> 4;
     const char* wbase = reinterpret_cast<const char*>(Wp + ((int64_t)(mt * chunks_total + (c0 >> 4)) * 3) * 192);
     const unsigned voff = lane * 16;
-    u32x4 a[IMG_AHEAD][3];
+    u32x4 a[AHEAD][3];
 #pragma unroll
-    for (int gg = 0; gg < IMG_AHEAD; ++gg) img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + gg * 3072, voff);
+    for (int gg = 0; gg < AHEAD; ++gg) img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + gg * 3072, voff);
 
     // ---- the split's channels of image b -> LDS (16-byte pieces: 32 per channel), halo rows zeroed ----------------------
     const unsigned short* xb = X + ((int64_t)b * Cin + c0) * 256;
@@ -117,22 +118,23 @@ __global__ __launch_bounds__(256) void conv3_img16_kernel(const unsigned short* 
 
     const int ngroups = (cs >> 4) * 3;                                            // (chunk, ky) groups of this split
 
-    for (int g0 = 0; g0 < ngroups; g0 += IMG_AHEAD) {
+    for (int g0 = 0; g0 < ngroups; g0 += 12) {
         const unsigned short* lc = lb + (g0 / 3) * 16 * IMG_CPITCH;
 #pragma unroll
-        for (int gg = 0; gg < IMG_AHEAD; ++gg) {
+        for (int gg = 0; gg < 12; ++gg) {
             const int ch = gg / 3, ky = gg % 3;
             u32x4 bf[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = vs_tr16_pair(lc + ch * 16 * IMG_CPITCH + (2 * j + ky) * 16, 4 * IMG_CPITCH);
-            img_wait3(a[gg][0], a[gg][1], a[gg][2]);                              // all but the 33 youngest fragment loads have landed
+            const int sl = gg % AHEAD;                                           // register set of this group (12 % AHEAD == 0)
+            img_wait3n<(AHEAD - 1) * 3>(a[sl][0], a[sl][1], a[sl][2]);           // all but the (AHEAD - 1) * 3 youngest fragment loads have landed
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[kx][j] = mfma16_32<CT>(a[gg][kx], bf[j], acc[kx][j]);
-            int gn = g0 + IMG_AHEAD + gg;                                         // the group this register set serves next
+                for (int j = 0; j < 2; ++j) acc[kx][j] = mfma16_32<CT>(a[sl][kx], bf[j], acc[kx][j]);
+            int gn = g0 + AHEAD + gg;                                         // the group this register set serves next
             if (gn > ngroups - 1) gn = ngroups - 1;                               // past the end: a harmless repeat of the last group
-            img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + (int64_t)gn * 3072, voff);
+            img_load3(a[sl][0], a[sl][1], a[sl][2], wbase + (int64_t)gn * 3072, voff);
         }
     }
 
@@ -496,6 +498,10 @@ int img16_splits(int B, int Cin, int Cout) {
         if ((Cin / s) % 128 != 0) break;                                           // halving would leave a split that is not a multiple of 64
         s *= 2;
     }
+    // VS_CONV_IMG_PAIR=1: one full round of one workgroup per CU with splits of > 128 channels is halved and run as TWO workgroups per CU.
+    // Measured on the SST step and NOT the default: 25.66 vs 25.52 ms (twice the slabs for the BatchNorm launch to add, no faster launch).
+    static const int pair_mode = getenv("VS_CONV_IMG_PAIR") ? atoi(getenv("VS_CONV_IMG_PAIR")) : 0;
+    if (pair_mode && base * s >= 256 && base * s < 512 && Cin / s > 128 && (Cin / s) % 128 == 0) s *= 2;
     return s;
 }
 
@@ -535,16 +541,17 @@ extern "C" int vs_conv3_img16(int compute, const void* x, const void* w_packed, 
     VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)slabs) % 16 == 0, "vs_conv3_img16: operands must be 16-byte aligned");
     const int splits = img16_splits(B, Cin, Cout), cs = Cin / splits, mtiles = (int)vs_cdiv(Cout, 32);
     const size_t lds = (size_t)cs * IMG_CPITCH * 2;
-    auto kb = conv3_img16_kernel<VS_BF16>;
-    auto kh = conv3_img16_kernel<VS_F16>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const dim3 grid((unsigned)((int64_t)B * mtiles * splits));
+    const bool pair = cs <= 128 && grid.x > 256;                                 // two workgroups per CU fit (72 KiB each) and there are enough of them
+    auto kb = pair ? conv3_img16_kernel<VS_BF16, 4, 2> : conv3_img16_kernel<VS_BF16, 12, 1>;
+    auto kh = pair ? conv3_img16_kernel<VS_F16, 4, 2> : conv3_img16_kernel<VS_F16, 12, 1>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[pair]) {
         if (hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * IMG_CPITCH * 2) != hipSuccess ||
             hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * IMG_CPITCH * 2) != hipSuccess)
             return vs_fail(VS_ERR_LAUNCH, "vs_conv3_img16: cannot raise the dynamic LDS limit");
-        attr_set = true;
+        attr_set[pair] = true;
     }
-    const dim3 grid((unsigned)((int64_t)B * mtiles * splits));
     if (compute == VS_BF16)
         hipLaunchKernelGGL(kb, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)x, (const u32x4*)w_packed, slabs, B, Cin, Cout, cs, splits, mtiles);
     else
