@@ -320,8 +320,9 @@ struct WgradPieces {
 
 template <int CT, int W, int MW>
 __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, float* __restrict__ slabs, int B, int Cin, int H, int Cout, int ctiles, int ksplit) {
-    constexpr int R = 256 / W, RP = R + 2, PW = W / 8;
-    constexpr int CPITCH = RP * W + 8;                                           // 392 / 328 / 296 elements: (CPITCH / 8) odd
+    // W >= 16: an item is a band of R = 256 / W rows of one map; W = 8: FOUR whole 8 x 8 maps (rows of one 16-byte piece, no column neighbours)
+    constexpr int IPB = W == 8 ? 4 : 1, R = W == 8 ? 8 : 256 / W, RPI = R + 2, RP = IPB * RPI, PW = W / 8;
+    constexpr int CPITCH = RP * W + 8;                                           // 392 / 328 / 296 / 328 elements: (CPITCH / 8) odd
     constexpr int ZPITCH = 264;
     constexpr int NX = 32 * RP * PW;                                             // 16-byte pieces of the x tile: 1536 / 1280 / 1152
     constexpr int NXT = (NX + 255) / 256;                                        // per thread: 6 / 5 / 5 (the last partly)
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bands = H / R;
-    const int64_t items = (int64_t)B * bands;
+    const int64_t items = IPB == 1 ? (int64_t)B * bands : (int64_t)((B + IPB - 1) / IPB);
 
     f32x16 acc[9];
 #pragma unroll
@@ -346,19 +347,19 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
     u32x4 xr[NXT], zr[4 * MW];
     unsigned xe[NXT];                                                            // neighbour pixels: low half = the one before the piece, high half = after
     auto load_item = [&](int64_t it) {
-        const int bg = (int)(it / bands), band = (int)(it % bands);
-        const int piece = bg / pieces.maps_per_piece, b = bg - piece * pieces.maps_per_piece;
+        const int bg = IPB == 1 ? (int)(it / bands) : (int)it * IPB, band = IPB == 1 ? (int)(it % bands) : 0;       // first map of the item
+        const int piece = bg / pieces.maps_per_piece, b = bg - piece * pieces.maps_per_piece;                             // (an item never straddles pieces)
         const unsigned short* X = pieces.x[piece];
         const unsigned short* DZ = pieces.dz[piece];
 #pragma unroll
         for (int r = 0; r < NXT; ++r) {
             const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
-            const int y = band * R + rr - 1, c = ct * 32 + cl;
+            const int im = rr / RPI, y = band * R + rr % RPI - 1, c = ct * 32 + cl;
             // every load is unconditional and the SELECT sits on the address (a block of zeros for what lies outside): a conditional load
             // makes the compiler wait for each one where the two paths merge -- ten serial round trips per band
-            const bool ok = u < NX && y >= 0 && y < H && c < Cin;
+            const bool ok = u < NX && y >= 0 && y < H && c < Cin && bg + im < B;
             const unsigned short* zero = reinterpret_cast<const unsigned short*>(vs_glds_zero);
-            const unsigned short* src = ok ? X + (((int64_t)b * Cin + c) * H + y) * W + pc * 8 : zero;
+            const unsigned short* src = ok ? X + (((int64_t)(b + im) * Cin + c) * H + y) * W + pc * 8 : zero;
             const unsigned short* pb = (ok && pc > 0) ? src - 1 : zero;
             const unsigned short* pa = (ok && pc + 1 < PW) ? src + 8 : zero;
             xr[r] = *reinterpret_cast<const u32x4*>(src);
@@ -367,8 +368,9 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
 #pragma unroll
         for (int r = 0; r < 4 * MW; ++r) {
             const int u = r * 256 + tid, ml = u >> 5, pc = u & 31, m = mt * (32 * MW) + ml;
-            const unsigned short* src = m < Cout ? DZ + (((int64_t)b * Cout + m) * H + band * R) * W + pc * 8
-                                                 : reinterpret_cast<const unsigned short*>(vs_glds_zero);
+            const int im = IPB == 1 ? 0 : pc / (R * PW), pcm = IPB == 1 ? pc : pc % (R * PW);                          // map of the item, piece inside it
+            const unsigned short* src = (m < Cout && bg + im < B) ? DZ + (((int64_t)(b + im) * Cout + m) * H + band * R) * W + pcm * 8
+                                                                  : reinterpret_cast<const unsigned short*>(vs_glds_zero);
             zr[r] = *reinterpret_cast<const u32x4*>(src);
         }
     };
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
         if (it + ksplit < items) load_item(it + ksplit);                         // travels during the MFMA phase
 #pragma unroll 4
         for (int tt = 0; tt < KSTEPS; ++tt) {
-            const int t = kpart * KSTEPS + tt, p0 = t * 16, row = p0 / W, x0 = p0 % W;
+            const int t = kpart * KSTEPS + tt, p0 = t * 16, row = (p0 / (R * W)) * RPI + (p0 % (R * W)) / W, x0 = p0 % W;
             const u32x4 af = *reinterpret_cast<const u32x4*>(zs + (msub * 32 + rl) * ZPITCH + p0 + 8 * h);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -636,7 +638,8 @@ extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, c
 
 // ---- weight gradient on row bands: x [B][Cin][H][W], dz [B][Cout][H][W] (16-bit) -> fp32 slabs [vs_conv3_wgrad_band_slabs][Cout][Cin][3][3] ----
 extern "C" int vs_conv3_wgrad_band_supported(int compute, int B, int Cin, int H, int W, int Cout) {
-    if (!vs_is16(compute) || (W != 16 && W != 32 && W != 64) || B < 1 || Cout < 8 || Cin < 8) return 0;
+    if (!vs_is16(compute) || (W != 8 && W != 16 && W != 32 && W != 64) || B < 1 || Cout < 8 || Cin < 8) return 0;
+    if (W == 8) return H == 8;                                                   // whole 8 x 8 maps, four per item
     const int R = 256 / W;
     if (H < R || H % R != 0) return 0;
     return 1;
@@ -646,7 +649,7 @@ static int wgrad_band_mw(int Cout) { return Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
 
 static int wgrad_band_ksplit(int B, int Cin, int H, int W, int Cout) {
     const int mw = wgrad_band_mw(Cout);
-    const int64_t tiles = vs_cdiv(Cout, 32 * mw) * vs_cdiv(Cin, 32), items = (int64_t)B * (H / (256 / W));
+    const int64_t tiles = vs_cdiv(Cout, 32 * mw) * vs_cdiv(Cin, 32), items = W == 8 ? vs_cdiv(B, 4) : (int64_t)B * (H / (256 / W));
     int64_t ks = vs_cdiv(512, tiles);                                           // ~2 rounds of workgroups over the launch
     if (ks > items) ks = items;
     const int64_t slab_bytes = (int64_t)Cout * Cin * 9 * 4;
@@ -660,8 +663,8 @@ extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout)
 
 template <int W, int MW>
 static void launch_wgrad_band(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
-    constexpr int R = 256 / W;
-    const size_t lds = (size_t)(3 * 32 * ((R + 2) * W + 8) + 32 * MW * 264) * 2;
+    constexpr int RPT = W == 8 ? 4 * 10 : 256 / W + 2;
+    const size_t lds = (size_t)(3 * 32 * (RPT * W + 8) + 32 * MW * 264) * 2;
     auto kb = wgrad3_band_kernel<VS_BF16, W, MW>;
     auto kh = wgrad3_band_kernel<VS_F16, W, MW>;
     static bool attr_set = false;
@@ -690,7 +693,8 @@ static int wgrad_band_go(int compute, const WgradPieces& pieces, float* slabs, i
     const int ks = wgrad_band_ksplit(B, Cin, H, W, Cout);
     if (W == 64) launch_wgrad_band_w<64>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     else if (W == 32) launch_wgrad_band_w<32>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
-    else launch_wgrad_band_w<16>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    else if (W == 16) launch_wgrad_band_w<16>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    else launch_wgrad_band_w<8>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     VS_CHECK_LAUNCH("vs_conv3_wgrad_band");
     return VS_OK;
 }
@@ -713,6 +717,7 @@ extern "C" int vs_conv3_wgrad_band_pieces(int compute, int npieces, const void* 
     VS_CHECK_ARG(x && dz && slabs && npieces >= 1 && npieces <= WG_MAX_PIECES && maps_per_piece >= 1, "vs_conv3_wgrad_band_pieces: bad argument");
     const int B = npieces * maps_per_piece;
     VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_wgrad_band_pieces: unsupported geometry");
+    VS_CHECK_ARG(W != 8 || npieces == 1 || maps_per_piece % 4 == 0, "vs_conv3_wgrad_band_pieces: 8 x 8 maps go four at a time: maps_per_piece must be a multiple of 4");
     WgradPieces pieces = {};
     for (int i = 0; i < npieces; ++i) {
         VS_CHECK_ARG(x[i] && dz[i] && ((uintptr_t)x[i] | (uintptr_t)dz[i]) % 16 == 0, "vs_conv3_wgrad_band_pieces: every piece must be a 16-byte aligned tensor");

@@ -491,8 +491,10 @@ def conv3_wgrad_band_supported(x, Cout, dtype_code_of=None):
     B, Cin, H, W = x.shape
     if (Cin * Cout * 9) % 4 != 0:
         return False
-    if W == 16 and Cin < 128 and os.environ.get('VS_CONV_WGRAD_BAND') != '2':
-        return False        # few input channels on 16-wide maps: the column matrix is small and the GEMM wins (123 vs 180 us at 64 -> 512 x 312 maps)
+    if ((W == 16 and Cin < 128) or W == 8) and os.environ.get('VS_CONV_WGRAD_BAND') != '2':
+        # few input channels on 16-wide maps: the column matrix is small and the GEMM wins (123 vs 180 us at 64 -> 512 x 312 maps); 8 x 8 maps
+        # (served, four per item): the TaxiBJ step is 14.3 instead of 13.4 ms with them on the band kernel
+        return False
     return bool(_lib.load_library().vs_conv3_wgrad_band_supported(dtype_code_of if dtype_code_of is not None else dtype_code(x), B, Cin, H, W, Cout))
 
 
@@ -517,7 +519,7 @@ def conv3_wgrad_band_pieces(pairs, w_shape, into=None):
     n = len(pairs)
     mp, Cin, H, W = x0.shape
     Cout = w_shape[0]
-    if n > 64 or any(p[0].shape != dz0.shape or p[1].shape != x0.shape or not p[0].is_contiguous() or not p[1].is_contiguous()
+    if (W == 8 and mp % 4 != 0) or n > 64 or any(p[0].shape != dz0.shape or p[1].shape != x0.shape or not p[0].is_contiguous() or not p[1].is_contiguous()
                      or p[0].dtype != x0.dtype or p[1].dtype != x0.dtype for p in pairs):
         return None
     if not conv3_wgrad_band_supported(torch.empty((n * mp, Cin, H, W), dtype=x0.dtype, device='meta'), Cout, dtype_code_of=dtype_code(x0)):

@@ -541,6 +541,8 @@ def test_conv3_band_forward_and_input_gradient(dtype, geom):
     (2, 40, 8, 64, 33),       # ragged both ways, H != W
     (40, 64, 32, 32, 64),     # several bands per workgroup share
     (312, 64, 16, 16, 512),   # the SST integrator's batched call (39 x 8 maps)
+    (10, 128, 8, 8, 72),      # 8 x 8 maps, four per item: two full items + two maps
+    (9, 40, 8, 8, 256),
 ])
 def test_conv3_wgrad_band_matches_fp64(dtype, geom, monkeypatch):
     """Weight gradient of Conv2d k3 s1 p1 through vs_conv3_wgrad_band + vs_slab_sum (ops.conv_wgrad picks it) against fp64 autograd on the
