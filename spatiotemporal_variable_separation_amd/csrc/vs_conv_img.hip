@@ -13,7 +13,7 @@
 //     three kx taps, and out[y][x] = G_0[x - 1] + G_1[x] + G_2[x + 1] is two DPP row shifts per accumulator register in the
 //     epilogue (a 16-lane DPP row IS an image row of the MFMA result; shifted-in lanes read 0 = the zero padding).
 //   * the weights never touch LDS: they are pre-packed in MFMA fragment order (vs_conv3_img16_pack_weight), every lane loads
-//     its 16 bytes of a fragment straight from global memory, twelve (chunk, ky) groups = 36 fragments ahead of their use
+//     its 16 bytes of a fragment straight from global memory, twelve (chunk, ky) groups = 36 fragments ahead of their use (four in the two-workgroups-per-CU form)
 //     (the four waves of a workgroup read the same fragments: L1 hits).
 //   * split partial sums go to fp32 slabs [split][B][Cout][256]; the consumer adds them: vs_bn_train_fwd_small_slabs (bias +
 //     16-bit rounding + BatchNorm statistics + running update + affine + activation in one launch, vs_norm.hip) or vs_slab_sum.
@@ -23,7 +23,6 @@
 namespace {
 
 constexpr int IMG_CPITCH = 288;          // LDS elements per channel: 18 rows x 16 pixels
-constexpr int IMG_AHEAD = 12;            // (chunk, ky) groups of weight fragments in flight = 4 chunks of 16 channels
 
 __device__ __forceinline__ float dpp_row_shr1(float v) {      // lane i <- lane i - 1 inside its 16-lane row, 0 into lane 0
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
@@ -37,22 +36,19 @@ __device__ __forceinline__ float lane_gather(int byte_index, float v) {       //
 }
 
 // Weight fragments: three 1 KiB wave loads (the kx taps of one (chunk, ky) group) written as asm so that they STAY where they are
-// issued -- twelve groups ahead of their use; left to the compiler the loads sink to just in front of the MFMAs that read them and
-// every group waits for a full L2 round trip.  The loads are invisible to the compiler's counter tracking, so the matching wait is
-// written out too: at the use of a group exactly (IMG_AHEAD - 1) * 3 = 33 younger fragment loads are outstanding.  The wait names
-// the registers as in/out operands: the MFMAs that read them cannot be scheduled above it.
+// issued -- AHEAD (12 or 4) groups ahead of their use; left to the compiler the loads sink to just in front of the MFMAs that read them
+// and every group waits for a full L2 round trip.  The loads are invisible to the compiler's counter tracking, so the matching wait is
+// written out too: at the use of a group exactly N = (AHEAD - 1) * 3 younger fragment loads are outstanding (33 or 9).  The wait names
+// the registers as in/out operands: the MFMAs that read them cannot be scheduled above it.  Loads still in flight when the loop ends
+// MUST be drained before the epilogue: their destination registers are dead to the compiler, which re-uses them (for store addresses).
 __device__ __forceinline__ void img_load3(u32x4& a0, u32x4& a1, u32x4& a2, const void* sbase, unsigned voff) {
     asm volatile("global_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:1024\n\tglobal_load_dwordx4 %2, %3, %4 offset:2048"
                  : "=&v"(a0), "=&v"(a1), "=&v"(a2)
                  : "v"(voff), "s"(sbase)
                  : "memory");
 }
-__device__ __forceinline__ void img_wait3(u32x4& a0, u32x4& a1, u32x4& a2) {
-    asm volatile("s_waitcnt vmcnt(33)" : "+v"(a0), "+v"(a1), "+v"(a2) : : "memory");
-}
-
 template <int N>
-__device__ __forceinline__ void img_wait3n(u32x4& a0, u32x4& a1, u32x4& a2) {   // as img_wait3 with N younger loads allowed in flight
+__device__ __forceinline__ void img_wait3n(u32x4& a0, u32x4& a1, u32x4& a2) {   // N younger loads may stay in flight
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a0), "+v"(a1), "+v"(a2) : "n"(N) : "memory");
 }
 
