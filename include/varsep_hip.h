@@ -112,6 +112,11 @@ int vs_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
  * a captured hipGraph stays valid when the random window moves.                                      */
 int vs_copy2d(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd,
               int64_t rows, int64_t cols, const int32_t* col_offset_dev, int64_t col_offset_scale, void* stream);
+/* Two windows of one [rows, lds] source stacked into a [2 rows, ldd] operand in one launch (the E_t input [random window; conditioning
+ * window] of train.py:45-88): rows [0, rows) from src + elem_offset_a + *col_offset_dev * col_offset_scale, rows [rows, 2 rows) from
+ * src + elem_offset_b (offsets in elements; the device offset may be NULL).  Converts between the three element types.             */
+int vs_copy2d_pair(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd, int64_t rows, int64_t cols,
+                   const int32_t* col_offset_dev, int64_t col_offset_scale, int64_t elem_offset_a, int64_t elem_offset_b, void* stream);
 
 /* out[n] (+)= sum_m X[m*ldx + n]  (fp32 out).  Bias gradient of nn.Linear / conv (autograd of
  * mlp.py:40).  `accumulate` = 0 overwrites.  Internally zeroes/accumulates with float atomics over row

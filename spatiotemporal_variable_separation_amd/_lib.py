@@ -88,6 +88,7 @@ SIGNATURES = {
                        _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     'vs_cast': (_i32, [_vp, _i32, _vp, _i32, _i64, _vp]),
     'vs_copy2d': (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp]),
+    'vs_copy2d_pair': (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp]),
     'vs_colsum': (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     'vs_colsum_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     'vs_adam_multi': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,

@@ -67,6 +67,31 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const void* src, int sd, in
     }
 }
 
+// Two windows of the same [rows, lds] source stacked into one [2 rows, ldd] operand in ONE launch: destination rows [0, rows) come from
+// src + elem_a + *off_dev * off_scale (a window that moves on the device), rows [rows, 2 rows) from src + elem_b (a fixed one).  The E_t
+// input of the recorded MLP step ([random window; conditioning window], train.py:45-88 of the reference) -- two copy launches in front of
+// the critical path before.  VEC: four elements per thread (everything a multiple of 4 elements).
+template <bool VEC>
+__global__ __launch_bounds__(256) void copy2d_pair_kernel(const void* src, int sd, int64_t lds, void* dst, int dd, int64_t ldd, int64_t rows, int64_t cols,
+                                                          const int32_t* off_dev, int64_t off_scale, int64_t elem_a, int64_t elem_b) {
+    const int64_t off_a = elem_a + (off_dev ? (int64_t)(*off_dev) * off_scale : 0);
+    constexpr int V = VEC ? 4 : 1;
+    const int64_t cv = cols / V, total = 2 * rows * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / cv, c = (idx - r * cv) * V;
+        const int64_t s = (r < rows ? r * lds + off_a : (r - rows) * lds + elem_b) + c;
+        if (VEC) {
+            float v[4];
+            if (sd == VS_F32) { const f32x4 t = *reinterpret_cast<const f32x4*>((const float*)src + s); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+            else { const u16x4 t = *reinterpret_cast<const u16x4*>((const unsigned short*)src + s); for (int j = 0; j < 4; ++j) v[j] = vs_h2f(t[j], sd); }
+            if (dd == VS_F32) *reinterpret_cast<f32x4*>((float*)dst + r * ldd + c) = f32x4{v[0], v[1], v[2], v[3]};
+            else *reinterpret_cast<u16x4*>((unsigned short*)dst + r * ldd + c) = u16x4{vs_f2h(v[0], dd), vs_f2h(v[1], dd), vs_f2h(v[2], dd), vs_f2h(v[3], dd)};
+        } else {
+            vs_st(dst, dd, r * ldd + c, vs_ld(src, sd, s));
+        }
+    }
+}
+
 // column sums: block (bx, by) reduces rows [by*RB, by*RB+RB) of columns [bx*64, bx*64+64) and adds with one atomic per column
 constexpr int CS_ROWS = 256;
 __global__ __launch_bounds__(256) void colsum_kernel(const void* X, int xd, int64_t ldx, int64_t M, int64_t N, float* out) {
@@ -705,6 +730,23 @@ extern "C" int vs_copy2d(const void* src, int sd, int64_t lds, void* dst, int dd
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, src, sd, lds, dst, dd, ldd,
                        rows, cols, col_offset_dev, col_offset_scale);
     VS_CHECK_LAUNCH("vs_copy2d");
+    return VS_OK;
+}
+
+extern "C" int vs_copy2d_pair(const void* src, int sd, int64_t lds, void* dst, int dd, int64_t ldd, int64_t rows, int64_t cols,
+                              const int32_t* col_offset_dev, int64_t col_offset_scale, int64_t elem_offset_a, int64_t elem_offset_b, void* stream) {
+    VS_CHECK_ARG(src && dst && rows >= 0 && cols >= 0 && vs_dtype_ok(sd) && vs_dtype_ok(dd), "vs_copy2d_pair: bad argument");
+    if (rows * cols == 0) return VS_OK;
+    const int se = vs_esize(sd), de = vs_esize(dd);
+    const bool vec = cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && col_offset_scale % 4 == 0 && elem_offset_a % 4 == 0 && elem_offset_b % 4 == 0 &&
+                     (uintptr_t)src % (4 * se) == 0 && (uintptr_t)dst % (4 * de) == 0;
+    if (vec)
+        hipLaunchKernelGGL(copy2d_pair_kernel<true>, dim3(grid_for(2 * rows * cols / 4)), dim3(256), 0, (hipStream_t)stream, src, sd, lds, dst, dd, ldd, rows, cols,
+                           col_offset_dev, col_offset_scale, elem_offset_a, elem_offset_b);
+    else
+        hipLaunchKernelGGL(copy2d_pair_kernel<false>, dim3(grid_for(2 * rows * cols)), dim3(256), 0, (hipStream_t)stream, src, sd, lds, dst, dd, ldd, rows, cols,
+                           col_offset_dev, col_offset_scale, elem_offset_a, elem_offset_b);
+    VS_CHECK_LAUNCH("vs_copy2d_pair");
     return VS_OK;
 }
 

@@ -29,6 +29,13 @@ class MLPResnet(nn.Module):
             residuals.append(res)
         return (x, residuals) if return_res else x
 
+    def prepack(self):
+        """Bring the integrator kernels' weight packs (forward and transposed) up to date now -- one launch on the current stream -- so
+        that `rollout` finds them ready: the training step calls this on the integrator's stream BEFORE the encoders, where it runs
+        beside E_t's first layers instead of between E_t and the recurrence."""
+        ws = [lin.weight for blk in self.blocks for lin in blk.mlp.linears()]
+        VF.prepack_weights([(w, tr) for w in ws for tr in (False, True)], VF.compute_dtype())
+
     def rollout(self, x0, n_steps):
         """Fused form of `for t in 1..n_steps-1: x, res = self(x)` (model.py:78-83): one persistent kernel.
 

@@ -169,6 +169,15 @@ def copy2d(src, rows, cols, lds, out, ldd, col_offset_dev=None, col_offset_scale
     return out
 
 
+def copy2d_pair(src, rows, cols, lds, out, ldd, col_offset_dev, col_offset_scale, elem_offset_a, elem_offset_b):
+    """out[0:rows] = window of `src` rows at elem_offset_a + *col_offset_dev * col_offset_scale, out[rows:2 rows] = the window at
+    elem_offset_b, one launch (with the element-type conversion)."""
+    require_cuda(src, out)
+    check(_lib.load_library().vs_copy2d_pair(src.data_ptr(), dtype_code(src), lds, out.data_ptr(), dtype_code(out), ldd, rows, cols,
+                                             _ptr(col_offset_dev), col_offset_scale, elem_offset_a, elem_offset_b, stream_ptr()), 'vs_copy2d_pair')
+    return out
+
+
 def colsum(x, M, N, out=None, accumulate=False):
     require_cuda(x)
     if out is None:

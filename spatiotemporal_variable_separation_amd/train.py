@@ -132,12 +132,18 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
         s_both = sep_net.Es.mlp(torch.cat([window(nt_cond), window(T)], dim=0))
         return s_both.view(2, B, -1).unbind(0)       # unbind: its gradient is ONE stack kernel (two slices: fill+copy each, then add)
 
+    if (VF.side_streams_enabled() and torch.is_grad_enabled() and VF.compute_dtype() != torch.float32
+            and os.environ.get('VARSEP_PREPACK_EARLY', '0') == '1' and hasattr(sep_net.t_resnet, 'prepack')):
+        # the integrator's weight packs depend on the weights only: on the integrator's stream, ahead of everything.  Measured and NOT the
+        # default: 1.451-1.459 vs 1.450 ms (the 8 us launch leaves the critical path, the replayed step does not get shorter)
+        main, side = torch.cuda.current_stream(), VF._side_stream('rollout')
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            sep_net.t_resnet.prepack()
     if on_device:
         # rows [0, B): full[:, t - nt_cond : t] cut out by a kernel that reads t on the device; rows [B, 2B): the conditioning window
         x_et = torch.empty((2 * B, nt_cond * D), dtype=VF.compute_dtype(), device=flat.device)
-        ops.copy2d(flat, B, nt_cond * D, T * D, x_et, nt_cond * D, col_offset_dev=t_random, col_offset_scale=D,
-                   src_elem_offset=-nt_cond * D)
-        ops.copy2d(flat, B, nt_cond * D, T * D, x_et[B:], nt_cond * D)
+        ops.copy2d_pair(flat, B, nt_cond * D, T * D, x_et, nt_cond * D, t_random, D, -nt_cond * D, 0)
     else:
         x_et = torch.cat([window(t_random), window(nt_cond)], dim=0)
     t_both = sep_net.Et.mlp(x_et)

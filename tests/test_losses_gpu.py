@@ -97,3 +97,21 @@ def test_loss_gradient_handoff_equals_two_pass_backward(precision, extra_consume
             torch.testing.assert_close(a, b, rtol=2e-2 if precision == 'bf16' else 1e-5, atol=1e-4 if precision == 'bf16' else 1e-7)
         else:
             assert torch.equal(a, b)                     # same arithmetic, same rounding point
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('D', [4096, 30])            # vectorised (multiples of 4) and scalar paths
+def test_copy2d_pair_builds_the_two_encoder_windows_in_one_launch(out_dtype, D):
+    """vs_copy2d_pair: rows [0, B) = the window that ends at the device-side t, rows [B, 2B) = the conditioning window (train.py:45-88)."""
+    import torch
+    from spatiotemporal_variable_separation_amd import ops
+    B, T, nc = 6, 11, 3
+    g = torch.Generator().manual_seed(9)
+    full = torch.rand((B, T, D), generator=g).cuda()
+    for t in (3, 7, 11):
+        tdev = torch.tensor([t], dtype=torch.int32, device='cuda')
+        out = torch.empty((2 * B, nc * D), dtype=out_dtype, device='cuda')
+        ops.copy2d_pair(full.view(B, T * D), B, nc * D, T * D, out, nc * D, tdev, D, -nc * D, 0)
+        want = torch.cat([full[:, t - nc:t].reshape(B, -1), full[:, :nc].reshape(B, -1)], dim=0).to(out_dtype)
+        assert torch.equal(out, want), (t, D, out_dtype)
