@@ -191,12 +191,13 @@ int vs_conv3_band(int compute, const void* x, const void* w_packed, const float*
                   int Cout, void* stream);
 /* Weight gradient of the same convolution without a column matrix (the backward of every Conv2d(k=3, s=1, p=1) above): workgroup = (32 output
  * channels, 32 input channels, a share of the batch's row bands); dz and three column-shifted copies of the x band in LDS, nine 32x32
- * accumulators (one per tap) per wave.  Leaves vs_conv3_wgrad_band_slabs(...) fp32 partial gradients [Cout][Cin][3][3]; vs_slab_sum adds
- * them (addend = the pending gradient for an accumulating call).  W in {16, 32, 64} with H a multiple of 256 / W, or 8 x 8 maps.    */
+ * accumulators (one per tap) per wave.  Leaves vs_conv3_wgrad_band_slabs(...) fp32 partial gradients laid out [tap][Cout][Cin] (coalesced
+ * stores); vs_conv3_wgrad_band_finish adds them into [Cout][Cin][3][3] (addend = the pending gradient for an accumulating call).  W in {16, 32, 64} with H a multiple of 256 / W, or 8 x 8 maps.    */
 /* ... over a batch lying in npieces (<= 64) separate tensors of maps_per_piece maps each (the remembered (dz, x) pairs of a convolution applied
  * once per predicted frame): the gradient over their concatenation without building it; slabs as for B = npieces * maps_per_piece.   */
 int vs_conv3_wgrad_band_pieces(int compute, int npieces, const void* const* x, const void* const* dz, int maps_per_piece, float* slabs, int Cin,
                                int H, int W, int Cout, void* stream);
+int vs_conv3_wgrad_band_finish(const float* slabs, int nslabs, const float* addend, float* out, int Cout, int Cin, void* stream);
 int vs_slab_sum_grouped(const float* slabs, int nslabs, int groups, float* partial, int64_t total, void* stream);   /* first pass over many slabs */
 int vs_conv3_wgrad_band_supported(int compute, int B, int Cin, int H, int W, int Cout);
 int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout);

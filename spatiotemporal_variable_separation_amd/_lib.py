@@ -147,6 +147,7 @@ SIGNATURES = {
     'vs_conv3_wgrad_band_slabs': (_i32, [_i32] * 5),
     'vs_conv3_wgrad_band': (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vs_conv3_wgrad_band_pieces': (_i32, [_i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'vs_conv3_wgrad_band_finish': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     'vs_slab_sum_grouped': (_i32, [_vp, _i32, _i32, _vp, _i64, _vp]),
     'vs_slab_sum': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     'vs_bn_train_fwd_small_slabs': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,

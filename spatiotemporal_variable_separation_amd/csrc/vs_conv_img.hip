@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
 // fragment read is an aligned ds_read_b128 (an unaligned one is replayed at 64 cycles).  The band's 16 k-steps of 16 pixels are split
 // over the four waves; a k-step is one dz fragment and nine x fragments (copy kx, row + ky) -> nine MFMAs into nine 32x32 accumulators.
 // The next band's global loads are issued before the MFMA phase of the current one.  Each wave leaves its nine accumulators in an fp32
-// slab of the weight's shape ([ksplit x 4][Cout][Cin][9]); vs_slab_sum adds the slabs (and the pending gradient, if any).
+// slab ([ksplit x 4 / MW][9][Cout][Cin]); vs_conv3_wgrad_band_finish adds the slabs (and the pending gradient, if any) into [Cout][Cin][3][3].
 // MW = 32-row output-channel sub-tiles per workgroup (4, 2 or 1): wave w owns sub-tile w % MW and the k-steps of part w / MW of 4 / MW.
 // With MW = 4 every wave walks all 16 k-steps of a band for its own 32 rows (144 MFMAs per staged band, one slab per workgroup share).
 // The batch may come in up to 64 equal pieces (the remembered (dz, x) pairs of a convolution that is applied once per predicted frame:
@@ -422,7 +422,9 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
         }
     }
 
-    // ---- this wave's nine 32 x 32 partial sums -> slab (ks, kpart): dW[m][c][tap] ---------------------------------------------------------
+    // ---- this wave's nine 32 x 32 partial sums -> slab (ks, kpart), laid out [tap][m][c]: the lanes of a store are 32 consecutive c (128-byte
+    // runs).  In the weight's own [m][c][tap] order a wave store is 64 words 36 bytes apart, every one a sector of its own: the PMC write
+    // counter showed 415-545 MB per launch for 37 MB of slabs; vs_conv3_wgrad_band_finish transposes once while it adds the slabs.
     float* out = slabs + ((int64_t)ks * KW + kpart) * ((int64_t)Cout * Cin * 9);
     const int c = ct * 32 + rl;
 #pragma unroll
@@ -430,8 +432,24 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int m = mt * (32 * MW) + msub * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-            if (m < Cout && c < Cin) out[((int64_t)m * Cin + c) * 9 + t] = acc[t][v];
+            if (m < Cout && c < Cin) out[((int64_t)t * Cout + m) * Cin + c] = acc[t][v];
         }
+}
+
+// dW[m][c][tap] = sum over the n slabs [tap][m][c] (+ the pending gradient): coalesced reads along c, nine consecutive words written per thread
+__global__ __launch_bounds__(256) void wgrad_slab_finish_kernel(const float* __restrict__ src, int n, int Cout, int Cin, const float* __restrict__ addend,
+                                                                float* __restrict__ out) {
+    const int64_t mc = (int64_t)Cout * Cin, total = mc * 9;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mc; i += (int64_t)gridDim.x * 256) {
+        float s[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s[t] = addend ? addend[i * 9 + t] : 0.f;
+        for (int k = 0; k < n; ++k)                                                // fixed order: reproducible
+#pragma unroll
+            for (int t = 0; t < 9; ++t) s[t] += src[(int64_t)k * total + (int64_t)t * mc + i];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) out[i * 9 + t] = s[t];
+    }
 }
 
 // Wp[mt][chunk][ky][kx][lane][8]: lane (r = lane & 31, h = lane >> 5) holds W[m = 32 mt + r][c = 16 chunk + 8 h .. + 7][ky][kx]
@@ -735,5 +753,16 @@ extern "C" int vs_slab_sum_grouped(const float* slabs, int nslabs, int groups, f
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(slab_sum_grouped_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, per, total, partial);
     VS_CHECK_LAUNCH("vs_slab_sum_grouped");
+    return VS_OK;
+}
+
+// dW [Cout][Cin][3][3] = sum of the nslabs partial gradients vs_conv3_wgrad_band left ([tap][Cout][Cin] each; for many slabs of a small weight
+// run vs_slab_sum_grouped over them first: it is layout-blind) + addend (the pending gradient, or NULL); out may be addend.
+extern "C" int vs_conv3_wgrad_band_finish(const float* slabs, int nslabs, const float* addend, float* out, int Cout, int Cin, void* stream) {
+    VS_CHECK_ARG(slabs && out && nslabs >= 1 && Cout > 0 && Cin > 0, "vs_conv3_wgrad_band_finish: bad argument");
+    int64_t blocks = vs_cdiv((int64_t)Cout * Cin, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_slab_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, Cout, Cin, addend, out);
+    VS_CHECK_LAUNCH("vs_conv3_wgrad_band_finish");
     return VS_OK;
 }

@@ -516,7 +516,8 @@ def _slab_reduce(slabs, nslabs, w_shape, into, dw):
         src = torch.empty((16,) + tuple(w_shape), dtype=torch.float32, device=slabs.device)
         check(lib.vs_slab_sum_grouped(slabs.data_ptr(), nslabs, 16, src.data_ptr(), dw.numel(), stream_ptr()), 'vs_slab_sum_grouped')
         n = -(-nslabs // (-(-nslabs // 16)))          # groups that received slabs: ceil(nslabs / per)
-    check(lib.vs_slab_sum(src.data_ptr(), n, None, _ptr(into), dw.data_ptr(), F32, 1, 1, dw.numel(), stream_ptr()), 'vs_slab_sum')
+    # the slabs are laid out [tap][Cout][Cin] (coalesced stores in the kernel): the last pass transposes into the weight's [Cout][Cin][3][3]
+    check(lib.vs_conv3_wgrad_band_finish(src.data_ptr(), n, _ptr(into), dw.data_ptr(), w_shape[0], w_shape[1], stream_ptr()), 'vs_conv3_wgrad_band_finish')
 
 
 def conv3_wgrad_band_pieces(pairs, w_shape, into=None):

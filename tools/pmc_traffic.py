@@ -28,6 +28,7 @@ FAMILIES = [
     (r'splitk_reduce_kernel', 'splitk_reduce'),
     (r'mix_codes_fwd_kernel', 'vs_mix_codes_fwd'),
     (r'mix_codes_bwd_kernel', 'vs_mix_codes_bwd'),
+    (r'wgrad3_band_kernel', 'vs_conv3_wgrad_band<bf16> (row-band 3x3 weight gradient)'),
     (r'conv3_band_kernel', 'vs_conv3_band<bf16> (row-band 3x3)'),
     (r'conv3_img16_kernel', 'vs_conv3_img16<bf16> (few-maps 3x3)'),
     (r'bn_fwd_small_kernel', 'vs_bn_train_fwd_small(_slabs)'),
