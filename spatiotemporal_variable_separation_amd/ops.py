@@ -500,10 +500,6 @@ def conv3_wgrad_band_supported(x, Cout, dtype_code_of=None):
     B, Cin, H, W = x.shape
     if (Cin * Cout * 9) % 4 != 0:
         return False
-    if ((W == 16 and Cin < 128) or W == 8) and os.environ.get('VS_CONV_WGRAD_BAND') != '2':
-        # few input channels on 16-wide maps: the column matrix is small and the GEMM wins (123 vs 180 us at 64 -> 512 x 312 maps); 8 x 8 maps
-        # (served, four per item): the TaxiBJ step is 14.3 instead of 13.4 ms with them on the band kernel
-        return False
     return bool(_lib.load_library().vs_conv3_wgrad_band_supported(dtype_code_of if dtype_code_of is not None else dtype_code(x), B, Cin, H, W, Cout))
 
 

@@ -548,7 +548,7 @@ def test_conv3_wgrad_band_matches_fp64(dtype, geom, monkeypatch):
     """Weight gradient of Conv2d k3 s1 p1 through vs_conv3_wgrad_band + vs_slab_sum (ops.conv_wgrad picks it) against fp64 autograd on the
     same 16-bit operands, fresh and accumulated into a pending gradient; equal to the column-matrix path up to summation order."""
     from spatiotemporal_variable_separation_amd import ops
-    monkeypatch.setenv('VS_CONV_WGRAD_BAND', '2')            # also where the plan prefers the column matrix
+    monkeypatch.setenv('VS_CONV_WGRAD_BAND', '1')
     B, Cin, H, W, Cout = geom
     x = _rand((B, Cin, H, W), 101).to(dtype)
     dz = _rand((B, Cout, H, W), 102).to(dtype)
