@@ -26,9 +26,9 @@ for w in waveeq mnist_b128 taxibj sst; do
   fi
 done
 rm -rf $out/p
-# (WaveEq and TaxiBJ; not SST: under --pmc the eager SST step aborted with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT and rocprofv3 hung while finalizing;
+# (WaveEq, TaxiBJ, Moving-MNIST; not SST: under --pmc the eager SST step aborted with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT and rocprofv3 hung while finalizing;
 #  every profiler call is wrapped in `timeout` since)
-for w in waveeq taxibj; do
+for w in waveeq taxibj mnist_b128; do
   rm -rf $out/f $out/w
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/f -o p -- python3 bench.py --config $w --no_graph --steps 6 --warmup 2 --repeats 1 --no_cpu_baseline --extra_configs none > $out/pmc_f_$w.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/w -o p -- python3 bench.py --config $w --no_graph --steps 6 --warmup 2 --repeats 1 --no_cpu_baseline --extra_configs none > $out/pmc_w_$w.log 2>&1
