@@ -26,13 +26,16 @@ for w in waveeq mnist_b128 taxibj sst; do
   fi
 done
 rm -rf $out/p
-# (WaveEq, TaxiBJ, Moving-MNIST; not SST: under --pmc the eager SST step aborted with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT and rocprofv3 hung while finalizing;
-#  every profiler call is wrapped in `timeout` since)
-for w in waveeq taxibj mnist_b128; do
+# (every profiler call is wrapped in `timeout`: once the eager SST step aborted under --pmc with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT and
+#  rocprofv3 hung while finalizing.  The PMC dispatch path rejects the 144 KiB-LDS launch of the default few-maps kernel, so the SST passes
+#  run with VS_CONV_IMG_PAIR=1: 72 KiB per workgroup, twice the slabs)
+for w in waveeq taxibj mnist_b128 sst; do
   rm -rf $out/f $out/w
+  if [ $w = sst ]; then export VS_CONV_IMG_PAIR=1; fi
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/f -o p -- python3 bench.py --config $w --no_graph --steps 6 --warmup 2 --repeats 1 --no_cpu_baseline --extra_configs none > $out/pmc_f_$w.log 2>&1
   timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/w -o p -- python3 bench.py --config $w --no_graph --steps 6 --warmup 2 --repeats 1 --no_cpu_baseline --extra_configs none > $out/pmc_w_$w.log 2>&1
   python3 tools/pmc_traffic.py $(find $out/f -name "*counter_collection.csv" | head -1) $(find $out/w -name "*counter_collection.csv" | head -1) $out/${tag}_${w}_bf16_traffic.json $out/${tag}_${w}_bf16_hbm_traffic.md $w
+  unset VS_CONV_IMG_PAIR
 done
 rm -rf $out/f $out/w
 ls -la $out
