@@ -10,14 +10,21 @@ configs[1] (WaveEq MLP, bf16), the configuration the metric is quoted on that fi
 Ranks: under `torch.distributed.run` (RANK / WORLD_SIZE in the environment) this process IS one rank.  Started plainly with
 `--gpus N` (N > 1) it launches N rank processes itself -- before anything touches the GPU -- one per device over RCCL, and
 rank 0 prints the JSON line.  VARSEP_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and exchanges gradients over gloo (the
-one-GPU test of the N > 1 path, tests/test_bench_gpu.py).
+one-GPU test of the N > 1 path, tests/test_safety_gpu.py::test_bench_spawns_its_own_ranks).
 
 Timing: W warm-up steps, then `--repeats` (default 5) timed regions of EXACTLY K steps each, every region bracketed by
 barrier + torch.cuda.synchronize() on both sides and reduced with MAX over ranks; the reported ms_per_step is the median region
 (all of them are listed in `ms_per_step_all`).
 
-At N = 1 the line also carries `configs`: the other single-GPU BASELINE workloads (Moving-MNIST DCGAN B=128, TaxiBJ VGG B=100,
-SST nt_pred 40 B=8) timed the same way with fewer steps, each with the roofline position of its dominant kernel family.
+The line also carries `configs`: further BASELINE workloads timed the same way with fewer steps, each with the roofline position of its
+dominant kernel group -- at N = 1 Moving-MNIST DCGAN B=128, TaxiBJ VGG B=100, SST nt_pred 40 B=8 in bf16 and SST in fp16 (the dtype
+BASELINE.json configs[4] states); at N > 1 TaxiBJ and SST (configs[3], configs[4]: the two workloads stated at 8 GPUs), data-parallel
+over the same ranks.
+
+`roofline`: kernel GROUPS (spatiotemporal_variable_separation_amd/profiling.py).  Algorithmic FLOPs / bytes per step are accounted live;
+the duration of a group inside the REPLAYED step comes from the committed rocprofv3 kernel statistics of this very command
+(profiles/r<NN>_<workload>_<dtype>_replay.json, tools/replay_stats.py) because HIP events cannot be recorded inside a hipGraph replay
+(tools/graph_event_probe.py: they read 4.7 us around a 4096^3 GEMM); the live eager-event figure is printed beside it (`eager_events`).
 """
 import argparse
 import json
@@ -30,13 +37,24 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import spatiotemporal_variable_separation_amd  # noqa: E402,F401  (sets the HIP runtime's queue knobs before torch initialises HIP)
+import spatiotemporal_variable_separation_amd  # noqa: E402
+
+spatiotemporal_variable_separation_amd.configure_single_gpu_queues()   # HIP runtime queue knobs: before anything initialises HIP
 
 import numpy as np          # noqa: E402
 import torch                # noqa: E402
 
-EXTRA_DEFAULT = 'mnist_b128,taxibj,sst'
-EXTRA_STEPS = {'mnist_b128': (10, 3), 'taxibj': (8, 3), 'sst': (3, 2), 'mnist_b16': (10, 3), 'chairs': (6, 2), 'waveeq': (20, 5)}
+EXTRA_DEFAULT = 'mnist_b128,taxibj,sst,sst_fp16'
+EXTRA_DEFAULT_DIST = 'taxibj,sst'          # N > 1: the two workloads BASELINE.json states at 8 GPUs (configs[3], configs[4])
+EXTRA_STEPS = {'mnist_b128': (10, 3), 'taxibj': (8, 3), 'sst': (3, 2), 'sst_fp16': (3, 2), 'mnist_b16': (10, 3), 'chairs': (6, 2), 'waveeq': (20, 5)}
+
+
+def split_workload(name, default_precision):
+    """'sst_fp16' -> ('sst', 'fp16'): a workload name may carry the compute type BASELINE.json states for it (configs[4]: SST in fp16)."""
+    for suffix in ('fp16', 'bf16', 'fp32'):
+        if name.endswith('_' + suffix):
+            return name[:-len(suffix) - 1], suffix
+    return name, default_precision
 
 
 def parse():
@@ -120,6 +138,9 @@ def cpu_baseline(cfg, steps):
     torch.set_num_threads(default_threads)
     nthr, dt = min(tried.items(), key=lambda kv: kv[1])
     return {'value': round(cfg['batch'] * cfg['nt_pred'] / dt, 1), 'unit': 'frames/s', 'cores': nthr,
+            'threads_8': {'value': round(cfg['batch'] * cfg['nt_pred'] / tried[8], 1), 'ms_per_step': round(tried[8] * 1e3, 1),
+                          'note': 'torch.set_num_threads(8): comparable with the survey container figures of BASELINE.md section 2'},
+            'by_threads_ms_per_step': {str(k): round(v * 1e3, 1) for k, v in tried.items()}, 'logical_cpus': os.cpu_count(),
             'kind': 'port', 'sample': f'{steps} full training steps of the same workload (batch {cfg["batch"]}, fp32, CPU '
             f'oracle = plain-PyTorch restatement of the reference) after 1 warm-up, best of thread counts '
             f'{ {k: round(v * 1e3) for k, v in tried.items()} } ms/step on {os.cpu_count()} logical CPUs',
@@ -169,8 +190,9 @@ class Ranks:
             torch.distributed.destroy_process_group()
 
 
-def run_workload(name, args, rk, steps, warmup, repeats, batch=None):
+def run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=None):
     """Build the workload `name`, warm up, time `repeats` regions of `steps` steps; returns timings + per-kernel event profile."""
+    precision = precision or args.precision
     from spatiotemporal_variable_separation_amd import functional as VF, ops
     from spatiotemporal_variable_separation_amd.configs import BASELINE_CONFIGS
     from spatiotemporal_variable_separation_amd.data.synthetic import synthetic_batch
@@ -190,18 +212,18 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None):
     if rk.ddp:
         broadcast_module_state(net)
     # 16-bit modes: gradients travel as bf16 (VARSEP_GRAD_COMM=fp32 keeps fp32 on the wire); reported in config.grad_allreduce
-    comm_bf16 = args.precision == 'bf16' and os.environ.get('VARSEP_GRAD_COMM', 'bf16') == 'bf16'
+    comm_bf16 = precision == 'bf16' and os.environ.get('VARSEP_GRAD_COMM', 'bf16') == 'bf16'
     direct = chain_weight_parameters(net) if (comm_bf16 and os.environ.get('VARSEP_GRAD_DIRECT_LOWP', '1') == '1') else None
     sync = GradAllReducer(net.parameters(), force=(rk.world == 1), comm_dtype=torch.bfloat16 if comm_bf16 else torch.float32,
                           lowp_direct=direct) if rk.ddp else None
     use_graph = (not args.no_graph) and os.environ.get('VARSEP_BENCH_GRAPH_ALL', '1') == '1'
     opt = Adam(net.parameters(), lr=4e-4, betas=(0.9, 0.99))
-    enable_update_in_backward(opt, net, sync)
     cond, target = synthetic_batch(cfg['data'], cfg['batch'], cfg['nt_cond'], cfg['nt_pred'], device=dev, seed=1234 + rk.rank)
     lam = cfg['lambdas']
-    VF.set_precision(args.precision)
-    scaler = make_loss_scaler(dev) if args.precision == 'fp16' else None     # reference train.py:96-97: GradScaler with fp16 autocast
-    if args.precision != 'fp32':
+    VF.set_precision(precision)
+    scaler = make_loss_scaler(dev) if precision == 'fp16' else None     # reference train.py:96-97: GradScaler with fp16 autocast
+    enable_update_in_backward(opt, net, sync, scaler=scaler)
+    if precision != 'fp32':
         enable_fused_update(opt, net, sync, scaler)      # (GraphedStep does the same; here for --no_graph and the instrumented eager steps)
     VF.fold_repeated_gradients(sync is None and os.environ.get('VARSEP_FOLD_GRADS', '1') == '1')
 
@@ -275,41 +297,102 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None):
     if err:
         raise RuntimeError('the rollout kernels reported an inter-workgroup exchange time-out (code %d): results are invalid' % err)
     final_loss = float(loss.item())
+    n_all = sum(p.numel() for p in net.parameters())
+    n_fused = sum(p.numel() for p in getattr(opt, '_fused', []))
+    if n_fused:
+        opt_text = ('Adam: %.1f M of %.1f M parameters updated in the epilogue of their weight-gradient GEMM (vs_gemm_adam), the rest by '
+                    'one vs_adam_multi launch' % (n_fused / 1e6, n_all / 1e6))
+    else:
+        opt_text = 'Adam: vs_adam_multi (one HIP launch per 64 tensors%s)' % ('; one recording per all-reduce bucket' if sync is not None else '')
     out = {'cfg': cfg, 'ms': statistics.median(regions) / steps * 1e3, 'ms_all': [round(r / steps * 1e3, 4) for r in regions],
            'prof': prof, 'sampled': sampled, 'loss': final_loss, 'comm_bf16': comm_bf16, 'use_graph': use_graph,
-           'scaler': None if scaler is None else scaler.describe()}
+           'scaler': None if scaler is None else scaler.describe(), 'optimizer': opt_text, 'precision': precision,
+           'full_size': batch is None and not rk.ddp}
     VF.fold_repeated_gradients(False)
     del graphed, net, opt, sync
     torch.cuda.empty_cache()
     return out
 
 
-def rooflines(res, precision, traffic=None, top=6):
-    """Roofline position of every instrumented kernel family, largest summed event time first."""
-    prof, ms, sampled = res['prof'], res['ms'], res['sampled']
-    traffic = traffic or {}
+def _latest_profile(workload, precision, kind):
+    """Newest committed profiles/r<NN>_<workload>_<precision>_<kind>.json (static evidence collected by tools/collect_profiles.sh)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s_%s_%s.json' % (workload, precision, kind))))
+    if not hits:
+        return None, None
+    try:
+        return json.load(open(hits[-1])), 'profiles/' + os.path.basename(hits[-1])
+    except (OSError, ValueError):
+        return None, None
 
-    def roof_of(name, rec):
-        base = {'kernel': name, 'launches_per_step': round(rec['n'] / sampled, 2), 'avg_launch_us': round(rec['ms'] * 1e3 / rec['n'], 2),
-                'share_of_step': round(rec['ms'] / (ms * sampled), 3), 'traffic': None}
-        if rec['flops'] > 0 and not name.startswith('vs_gemm_adam'):     # (the fused weight-gradient + Adam launch is HBM-bound:
-            peak = 157.3 if precision == 'fp32' else 2500.0              # 26 B per parameter against 2 K flop, K = 256)
-            ach = rec['flops'] / (rec['ms'] * 1e-3) / 1e12
-            base.update({'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4)})
-        else:
-            ach = rec['bytes'] / (rec['ms'] * 1e-3) / 1e9
-            base.update({'bound': 'hbm', 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(ach / 8000.0, 4)})
-        if name in traffic:
-            base['traffic'] = round(traffic[name]['bytes_per_launch'])
-            base['traffic_source'] = traffic.get('_source', 'static')
-        if 'rollout' in name:
-            base['note'] = ('sequential recurrence: (n-1)*n_blocks*3 dependent 16-row GEMMs per slab, bound by per-CU L2 '
-                            'weight streaming and barrier latency, not by MFMA rate (SURVEY.md H3)')
-        return base
+
+def rooflines(res, workload, precision, top=6):
+    """Roofline position of every kernel GROUP (spatiotemporal_variable_separation_amd/profiling.py), largest time per step first.
+
+    Algorithmic FLOPs / bytes per step: the live accounting of this run (ops.profile_collect over the instrumented steps).  Duration:
+    (1) `eager`: live HIP events around every launch of the instrumented eager steps; (2) when profiles/ holds the rocprofv3 kernel
+    statistics of this command's REPLAYED step (tools/replay_stats.py), the group's time per step from there -- inside the replayed
+    hipGraph launches overlap and run slower than alone, and events cannot be recorded inside a replay, so the static table is the
+    only per-kernel clock of the timed region; `achieved` / `frac` then follow from it (reproducible from the committed CSV) and the
+    eager figure is printed beside it."""
+    from spatiotemporal_variable_separation_amd.profiling import bound_of, group_of_family
+    prof, ms, sampled = res['prof'], res['ms'], res['sampled']
     if not prof:
         return None, []
-    ranked = sorted(prof.items(), key=lambda kv: -kv[1]['ms'])
-    return roof_of(*ranked[0]), [roof_of(*kv) for kv in ranked[1:top]]
+    replay, replay_src = (None, None)
+    traffic, traffic_src = (None, None)
+    if res.get('full_size', True):
+        replay, replay_src = _latest_profile(workload, precision, 'replay')
+        traffic, traffic_src = _latest_profile(workload, precision, 'traffic')
+    groups = {}
+    for name, rec in prof.items():
+        g = group_of_family(name) or name
+        e = groups.setdefault(g, {'ms': 0.0, 'n': 0, 'flops': 0.0, 'bytes': 0.0, 'families': []})
+        for k in ('ms', 'n', 'flops', 'bytes'):
+            e[k] += rec[k]
+        e['families'].append(name)
+    peak_mfma = 157.3 if precision == 'fp32' else 2500.0
+
+    def roof_of(g, e):
+        bound = bound_of(g) if e['flops'] > 0 or bound_of(g) == 'hbm' else 'hbm'
+        work = (e['flops'] if bound == 'mfma' else e['bytes']) / sampled              # algorithmic FLOPs or bytes per step
+        peak, unit, scale = (peak_mfma, 'TFLOP/s', 1e12) if bound == 'mfma' else (8000.0, 'GB/s', 1e9)
+        eager_us = e['ms'] * 1e3 / sampled
+        eager = {'us_per_step': round(eager_us, 1), 'avg_launch_us': round(e['ms'] * 1e3 / e['n'], 2),
+                 'achieved': round(work / (eager_us * 1e-6) / scale, 2), 'frac': round(work / (eager_us * 1e-6) / scale / peak, 4)}
+        out = {'kernel': g, 'families': sorted(e['families']), 'bound': bound, 'peak': peak, 'unit': unit,
+               'algorithmic_per_step': round(work), 'algorithmic_bytes_per_step': round(e['bytes'] / sampled)}
+        rp = (replay or {}).get('groups', {}).get(g)
+        if rp:
+            us = rp['us_per_step']
+            out.update({'achieved': round(work / (us * 1e-6) / scale, 2), 'frac': round(work / (us * 1e-6) / scale / peak, 4),
+                        'launches_per_step': rp['launches_per_step'], 'avg_launch_us': rp['avg_launch_us'], 'us_per_step': round(us, 1),
+                        'share_of_step': round(us * 1e-3 / ms, 3),
+                        'timing': 'replayed step: %s (rocprofv3 --kernel-trace --stats of this command; sum of TotalDurationNs over the '
+                                  'group\'s kernel symbols / steps)' % replay_src, 'eager_events': eager})
+        else:
+            out.update({'achieved': eager['achieved'], 'frac': eager['frac'], 'launches_per_step': round(e['n'] / sampled, 2),
+                        'avg_launch_us': eager['avg_launch_us'], 'us_per_step': eager['us_per_step'], 'share_of_step': round(eager_us * 1e-3 / ms, 3),
+                        'timing': 'live HIP events around every launch of %d eager steps (no rocprofv3 table of this workload under profiles/)' % sampled})
+        tr = (traffic or {}).get('groups', {}).get(g)
+        out['traffic'] = None
+        if tr:
+            out['traffic'] = round(tr['bytes_per_launch'])
+            out['traffic_per_step'] = round(tr['bytes_per_step'])
+            out['traffic_source'] = '%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes over eager steps of this command)' % traffic_src
+        if 'rollout' in g:
+            out['note'] = ('sequential recurrence: (n-1)*n_blocks*3 dependent 16-row GEMMs per slab, bound by the inter-workgroup exchange '
+                           'latency, not by MFMA rate (SURVEY.md H3)')
+        return out
+    roofs = [roof_of(g, e) for g, e in groups.items()]
+    roofs.sort(key=lambda r: -r['us_per_step'])
+    return roofs[0], roofs[1:top]
+
+
+def allreduce_text(rk, res):
+    if not rk.ddp:
+        return 'none (1 rank)'
+    return '%s buckets over %s' % ('bf16' if res['comm_bf16'] else 'fp32', 'RCCL' if rk.backend == 'nccl' else 'gloo (ranks share one GPU: test mode)')
 
 
 def workload_text(name, cfg):
@@ -328,25 +411,44 @@ def main():
     os.dup2(2, 1)
     rk = Ranks(args)
     res = run_workload(args.config, args, rk, args.steps, args.warmup, args.repeats, batch=args.batch)
+
+    # further workloads under "configs".  Every rank runs them (they contain the same barriers / all-reduces); rank 0 reports.
+    extra = args.extra_configs
+    if extra is None:
+        if args.config == 'waveeq' and args.batch is None and args.precision == 'bf16':
+            extra = EXTRA_DEFAULT if (rk.world == 1 and not rk.ddp) else EXTRA_DEFAULT_DIST
+        else:
+            extra = 'none'
+    configs = None
+    if extra != 'none':
+        configs = {}
+        for name in [e for e in extra.split(',') if e]:
+            st, wu = EXTRA_STEPS.get(name, (5, 2))
+            wname, prec = split_workload(name, args.precision)
+            try:
+                r = run_workload(wname, args, rk, st, wu, 3, precision=prec)
+            except Exception as e:          # one workload failing must not take the headline line down; it is reported
+                if rk.ddp:
+                    raise                    # (with several ranks a rank that skips a workload would leave the others in its collectives)
+                configs[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+                continue
+            c = r['cfg']
+            rf, oth = rooflines(r, wname, prec, top=4)
+            configs[name] = {'workload': workload_text(wname, c), 'ms_per_step': round(r['ms'], 4), 'n_gpus': rk.world,
+                             'value': round(rk.world * c['batch'] * c['nt_pred'] / (r['ms'] * 1e-3), 1), 'unit': 'frames/s',
+                             'steps': st, 'warmup': wu, 'ms_per_step_all': r['ms_all'], 'dtype': prec,
+                             'grad_allreduce': allreduce_text(rk, r), 'optimizer': r['optimizer'], 'final_loss': round(r['loss'], 5),
+                             'roofline': rf, 'roofline_others': oth}
+            if r['scaler']:
+                configs[name]['loss_scaling'] = r['scaler']
     if rk.rank != 0:
         rk.close()
         return
     cfg, ms = res['cfg'], res['ms']
     frames = rk.world * cfg['batch'] * cfg['nt_pred']
-
-    # HBM-side traffic per launch from the committed rocprofv3 --pmc passes (collected in their own runs: PMC passes cannot run
-    # inside the timed region); static data, only attached for the workload they were measured on
-    traffic = {}
-    for tname in ('r02_waveeq_bf16_traffic.json', 'r01_waveeq_bf16_traffic.json'):
-        tpath = os.path.join(ROOT, 'profiles', tname)
-        if args.config == 'waveeq' and args.precision == 'bf16' and cfg['batch'] == 128 and os.path.exists(tpath):
-            traffic = json.load(open(tpath))
-            traffic['_source'] = ('static: profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch, collected in '
-                                  'separate profiling runs of this command)' % tname)
-            break
-    roof, others = rooflines(res, args.precision, traffic)
-    launch = ('hipGraph replay (per-kernel roofline timings: HIP events around every launch of %d EAGER steps run after the timed '
-              'regions; they cannot be recorded inside a replay)' % res['sampled']) if res['use_graph'] else 'eager'
+    roof, others = rooflines(res, args.config, args.precision)
+    launch = ('hipGraph replay; per-kernel durations: see roofline.timing (events cannot be recorded inside a replay: live HIP events '
+              'bracket every launch of %d EAGER steps run after the timed regions)' % res['sampled']) if res['use_graph'] else 'eager'
     out = {
         'metric': 'training frames/sec (seq x nt_pred)', 'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s',
         'n_gpus': rk.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
@@ -354,34 +456,15 @@ def main():
         'repeats': len(res['ms_all']), 'ms_per_step_all': res['ms_all'],
         'config': {'workload': workload_text(args.config, cfg),
                    'global_batch': rk.world * cfg['batch'], 'parallelism': f'dp{rk.world}',
-                   'grad_allreduce': ('none (1 rank)' if not rk.ddp else
-                                      ('%s buckets over %s' % ('bf16' if res['comm_bf16'] else 'fp32',
-                                                               'RCCL' if rk.backend == 'nccl' else 'gloo (ranks share one GPU: test mode)'))),
-                   'optimizer': 'Adam (vs_adam_multi, one HIP launch)', 'launch': launch,
+                   'grad_allreduce': allreduce_text(rk, res), 'optimizer': res['optimizer'], 'launch': launch,
                    'timing': 'median of %d regions of %d steps' % (len(res['ms_all']), args.steps),
                    'final_loss': round(res['loss'], 5)},
         'roofline': roof, 'roofline_others': others,
     }
     if res['scaler']:
         out['config']['loss_scaling'] = res['scaler']
-    extra = args.extra_configs
-    if extra is None:
-        extra = EXTRA_DEFAULT if (rk.world == 1 and args.config == 'waveeq' and not rk.ddp and args.batch is None) else 'none'
-    if extra != 'none' and rk.world == 1:
-        out['configs'] = {}
-        for name in [e for e in extra.split(',') if e]:
-            st, wu = EXTRA_STEPS.get(name, (5, 2))
-            try:
-                r = run_workload(name, args, rk, st, wu, 3)
-            except Exception as e:          # one workload failing must not take the headline line down; it is reported
-                out['configs'][name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
-                continue
-            c = r['cfg']
-            rf, oth = rooflines(r, args.precision, top=4)
-            out['configs'][name] = {'workload': workload_text(name, c), 'ms_per_step': round(r['ms'], 4),
-                                    'value': round(c['batch'] * c['nt_pred'] / (r['ms'] * 1e-3), 1), 'unit': 'frames/s',
-                                    'steps': st, 'warmup': wu, 'ms_per_step_all': r['ms_all'], 'dtype': args.precision,
-                                    'final_loss': round(r['loss'], 5), 'roofline': rf, 'roofline_others': oth}
+    if configs is not None:
+        out['configs'] = configs
     if rk.world == 1 and not args.no_cpu_baseline:
         steps = args.cpu_steps or (5 if args.config in ('waveeq', 'mnist_b16') else 2)
         out['cpu_baseline'] = cpu_baseline(cfg, steps)

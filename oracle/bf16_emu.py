@@ -98,41 +98,35 @@ def _mlp_decoder_forward(self, z1, z2, skip=None):
     return _mlp_forward(self.mlp, z, out_act=name).view([-1] + self.output_shape)
 
 
-class emulate_bf16:
-    """Context manager: inside it, the oracle's MLP-family modules round like the product's bf16 mode (or, with
-    dtype=torch.float16, like its fp16 mode)."""
-
-    def __init__(self, dtype=torch.bfloat16):
-        self.dtype = dtype
-
-    def __enter__(self):
-        self._lowp_saved = dict(_LOWP)
-        _LOWP['dtype'], _LOWP['precision'] = self.dtype, 'fp16' if self.dtype == torch.float16 else 'bf16'
-        self._saved = (cpu_ref.MLP.forward, cpu_ref.MLPDecoder.forward)
-        cpu_ref.MLP.forward = _mlp_forward
-        cpu_ref.MLPDecoder.forward = _mlp_decoder_forward
-        return self
-
-    def __exit__(self, *exc):
-        cpu_ref.MLP.forward, cpu_ref.MLPDecoder.forward = self._saved
-        _LOWP.update(self._lowp_saved)
-        return False
-
-
 # ======================================================================================================================
-# Convolution families: the product's OWN module tree and host logic (networks/*.py, train.compute_losses) run on the CPU
-# with every functional entry point they use replaced by a plain-torch emulation that rounds to bfloat16 exactly where the
-# HIP kernels do.  What this checks is the bf16 ARITHMETIC of the kernels (conv / BatchNorm / pool / upsample / Linear
-# chains / integrator), layer by layer through a whole training step; the structure of the networks is pinned separately,
-# in fp32, against the independent oracle above.  Rounding points of a conv block (functional.ConvBlock):
-#   forward : block input -> bf16; weights -> bf16; conv accumulates in fp32; with BatchNorm the conv output z is STORED in
-#             bf16, statistics are taken from that stored z (fp64 sums), y = act(gamma * xhat + beta) is stored in bf16
-#             (fp32 for a module's final block); without BatchNorm the conv output is stored, then the activation is applied
-#             to the stored value and stored again.
-#   backward: the incoming gradient has the dtype of the block output; dz (BatchNorm / activation backward, fp32 math on the
-#             stored z) -> bf16; weight gradient fp32 from bf16 dz and bf16 input; input gradient in the input's dtype.
+# Convolution families on the ORACLE's module tree (independent of the product's host code).
+#
+# The classes of oracle/cpu_ref.py are plain nn.Sequential stacks of Conv2d / ConvTranspose2d / BatchNorm2d / activation / pool /
+# upsample / Linear modules in the reference's call structure (one decoder call per frame, one encoder call per window, one
+# ConvResBlock call per step and block).  `emulate_bf16` swaps their `forward` methods for interpreters of the SAME module lists that
+# round to the 16-bit type at the mode's rounding points and otherwise compute in fp32 with torch's CPU kernels.  Nothing of the
+# product (networks/*.py, functional.py, train.py) is imported or executed: layer grouping, skip wiring, per-call BatchNorm statistics
+# and the losses are the oracle's.
+#
+# Rounding points of the 16-bit modes, conv families (`lp` = the 16-bit type):
+#   conv block  = conv -> [BatchNorm2d] -> [activation]                                         (reference conv.py:41-60)
+#     forward : block input -> lp; weight -> lp; products exact, accumulation + bias in fp32;
+#               with BatchNorm: conv output z STORED in lp, batch statistics (fp64 sums) of the stored z, running statistics from
+#               them, y = act(gamma * xhat + beta) stored in lp -- in fp32 when the block is the last one of an encoder / decoder /
+#               residual branch (module outputs are fp32);
+#               without BatchNorm: conv output stored, activation applied to the stored value and stored again.
+#     backward: incoming gradient in the dtype of the block output; dz (BatchNorm / activation backward in fp32 on the stored z) -> lp;
+#               weight gradient fp32 from lp dz and lp input; bias gradient fp32 sum of the lp dz -- EXACTLY ZERO in front of a
+#               training-mode BatchNorm; d gamma / d beta fp32 (fp64 sums); input gradient in the dtype of the block input.
+#   max-pool / nearest up-sampling: on lp values (pooling is exact; the up-sampling gradient sums its four taps in fp32, then lp).
+#   skip tensors (encoder stage outputs) are lp; the codes leaving an encoder and the frames leaving a decoder are fp32.
+#   Linear layers: the chain rules of the first half (EmuChain).
+#   A tensor consumed by several calls (the spatial code and the skips of E_s across the n + 1 decoder calls): gradient contributions are
+#   summed in fp32 and rounded to the tensor's dtype once.
+import torch.nn as nn  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
+_ACT_MODULES = {'ReLU': 'relu', 'LeakyReLU': 'leaky_relu', 'ELU': 'elu', 'Sigmoid': 'sigmoid', 'Tanh': 'tanh'}
 
 
 def _conv(x32, w32, bias, stride, pad, transposed):
@@ -247,6 +241,23 @@ class _EmuPool(torch.autograd.Function):
         return F.max_unpool2d(dy.float(), idx, 2, 2, output_size=ctx.shape[-2:]).to(ctx.dt)
 
 
+class _EmuPool3s2(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) on 16-bit values (exact); overlapping windows: the gradient of an input sums its windows' (fp32, then 16 bits)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return F.max_pool2d(x.float(), 3, 2, 1).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        with torch.enable_grad():
+            xr = x.float().requires_grad_(True)
+            (g,) = torch.autograd.grad(F.max_pool2d(xr, 3, 2, 1), xr, dy.float())
+        return g.to(x.dtype)
+
+
 class _EmuUpsample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -273,6 +284,203 @@ class _EmuActivation(torch.autograd.Function):
         return (dy.float() * _act_grad(y.float(), ctx.act)).to(y.dtype), None
 
 
+
+class _SharedGrad(torch.autograd.Function):
+    """y = x.float() for a 16-bit tensor that several calls consume: the calls cast y back to 16 bits (an exact round trip), their
+    gradients meet on y in fp32 and are rounded to x's dtype ONCE here."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.dt = x.dtype
+        return x.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt)
+
+
+def _flat(module, out):
+    if isinstance(module, (nn.Sequential, nn.ModuleList)):
+        for m in module:
+            _flat(m, out)
+    elif not isinstance(module, nn.Identity):
+        out.append(module)
+    return out
+
+
+def _emu_layers(module, h, final_act='none', final_fp32=False):
+    """Interpret a (nested) Sequential of the oracle's layer objects with the mode's rounding points.  `final_act`: activation the
+    caller applies to the result (a decoder's `last_activation`), taken into the last block when that block has none of its own;
+    `final_fp32`: the last block writes fp32 (module outputs)."""
+    layers = _flat(module, [])
+    i, n = 0, len(layers)
+    while i < n:
+        m = layers[i]
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            bn = act = None
+            j = i + 1
+            if j < n and isinstance(layers[j], nn.BatchNorm2d):
+                bn, j = layers[j], j + 1
+            if j < n and type(layers[j]).__name__ in _ACT_MODULES:
+                act, j = _ACT_MODULES[type(layers[j]).__name__], j + 1
+            last = j >= n
+            act = act or 'none'
+            extra = None
+            if last and final_act not in ('none', None):
+                if act == 'none':
+                    act = final_act
+                else:
+                    extra = final_act
+            training = bn.training if bn is not None else False
+            if bn is not None and training:
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1
+            cfg = (isinstance(m, nn.ConvTranspose2d), m.stride[0], m.padding[0], bn is not None, act, training,
+                   bn.momentum if bn is not None else 0.1, bn.eps if bn is not None else 1e-5, bool(final_fp32 and last and extra is None), 1)
+            h = EmuConvBlock.apply(h, m.weight, m.bias, bn.weight if bn is not None else None, bn.bias if bn is not None else None,
+                                   bn.running_mean if bn is not None else None, bn.running_var if bn is not None else None, cfg)
+            if extra is not None:
+                h = _EmuActivation.apply(h.float() if final_fp32 else h, extra)
+            i = j
+            continue
+        if isinstance(m, nn.MaxPool2d):
+            assert m.kernel_size == 2 and m.stride == 2
+            h = _EmuPool.apply(h)
+        elif isinstance(m, nn.Upsample):
+            h = _EmuUpsample.apply(h)
+        elif isinstance(m, nn.Flatten):
+            h = h.reshape(h.shape[0], -1)
+        elif isinstance(m, nn.Linear):
+            last = i == n - 1
+            h = EmuChain.apply(h.float(), (final_act if (last and final_act) else 'none',), m.weight, m.bias)
+        else:
+            raise NotImplementedError(type(m).__name__)
+        i += 1
+    if final_fp32 and h.dtype != torch.float32:
+        h = h.float()
+    return h
+
+
+def _last_act_name(module):
+    return {'Sigmoid': 'sigmoid', 'Tanh': 'tanh', 'ReLU': 'relu', 'LeakyReLU': 'leaky_relu', 'ELU': 'elu', 'Identity': 'none'}[type(module).__name__]
+
+
+def _share(t):
+    """Mark a (possibly 16-bit) tensor that several calls will consume (see _SharedGrad); idempotent per tensor object."""
+    if t.dtype == torch.float32:
+        return t
+    return _SharedGrad.apply(t)
+
+
+def _flat_encoder_forward(self, x, return_skip=False):                         # cpu_ref._FlatEncoder (conv.py:81-99)
+    h = x.reshape(x.size(0), -1, x.size(3), x.size(4))
+    skips = []
+    for stage in self.conv:
+        h = _emu_layers(stage, h)
+        skips.append(h)
+    code = _emu_layers(self.last_op, h, final_fp32=True).view(-1, self.nh)
+    if return_skip:
+        return code, [_share(s) for s in skips[::-1]]
+    return code
+
+
+def _sst_encoder_forward(self, x, return_skip=False):                          # cpu_ref.EncoderSST (conv.py:346-356)
+    h1 = _emu_layers(self.conv1, x.reshape(x.size(0), -1, x.size(3), x.size(4)))
+    h2 = _emu_layers(self.conv2, h1)
+    h3 = _emu_layers(self.conv3, h2)
+    h4 = _emu_layers(self.conv4, h3, final_fp32=True)
+    if return_skip:
+        return h4, [_share(h3), _share(h2), _share(h1)]
+    return h4
+
+
+def _flat_decoder_forward(self, z1, z2, skip=None):                            # cpu_ref._FlatDecoder (conv.py:207-230)
+    assert skip is None and not self.skip or self.skip and skip is not None
+    z = torch.cat([z1, z2], dim=1) if self.mixing == 'concat' else z1 * z2
+    h = _emu_layers(self.first_upconv, z.view(*z.shape, 1, 1))
+    n_stage = len(self.conv)
+    for i, stage in enumerate(self.conv):
+        if skip is not None:
+            h = torch.cat([h, skip[i].to(h.dtype)], 1)
+        if i == n_stage - 1:
+            h = _emu_layers(stage, h, final_act=_last_act_name(self.last_activation), final_fp32=True)
+        else:
+            h = _emu_layers(stage, h)
+    return h
+
+
+def _sst_skip_decoder_forward(self, s_code, t_code, skip):                     # cpu_ref.DecoderSST_Skip (conv.py:385-396)
+    h3, h2, h1 = skip
+    out = _emu_layers(self.conv1, torch.cat([s_code, t_code], dim=1))
+    out = _emu_layers(self.conv2, torch.cat([h3.to(out.dtype), out], dim=1))
+    out = _emu_layers(self.conv3, torch.cat([h2.to(out.dtype), out], dim=1))
+    return _emu_layers(self.conv4, torch.cat([h1.to(out.dtype), out], dim=1), final_act=_last_act_name(self.out_f), final_fp32=True)
+
+
+def _sst_decoder_forward(self, s_code, t_code, skip=None):                     # cpu_ref.DecoderSST (conv.py:419-426)
+    x = _emu_layers(self.conv1, torch.cat([s_code, t_code], dim=1))
+    x = _emu_layers(self.conv2, x)
+    return _emu_layers(self.conv3, x, final_act=_last_act_name(self.out_f), final_fp32=True)
+
+
+def _conv_res_block_forward(self, x):                                          # cpu_ref.ConvResBlock (resnet.py:53-70)
+    r = _emu_layers(self.conv, x, final_fp32=True)
+    skip = x if isinstance(self.up, nn.Identity) else _emu_layers(self.up, x, final_fp32=True)
+    return skip + r, r
+
+
+def _basic_block_forward(self, x):                                             # cpu_ref.BasicBlock (conv.py:440-468)
+    out = _emu_layers(nn.Sequential(self.conv1, self.bn1, self.relu), x)
+    out = _emu_layers(nn.Sequential(self.conv2, self.bn2), out)
+    residual = x if self.downsample is None else _emu_layers(self.downsample, x)
+    if residual.dtype != out.dtype:
+        residual = residual.to(out.dtype)
+    return _EmuActivation.apply(out + residual, 'relu')
+
+
+def _resnet18_forward(self, x, return_skip=False):                             # cpu_ref.ResNet18 (conv.py:546-564)
+    h = x.reshape(x.size(0), -1, x.size(3), x.size(4))
+    h = _emu_layers(nn.Sequential(self.conv1, self.bn1, self.relu), h)
+    h = _EmuPool3s2.apply(h)
+    for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+        for block in stage:
+            h = _basic_block_forward(block, h)
+    h = _emu_layers(nn.Sequential(self.conv_out), h, final_act=_last_act_name(self.out_function), final_fp32=True)
+    return h.reshape(len(h), -1)
+
+
+class emulate_bf16:
+    """Context manager: inside it, the oracle's modules round like the product's bf16 mode (or, with dtype=torch.float16, like its fp16
+    mode): Linear chains through EmuChain, convolution blocks / pooling / up-sampling through the interpreter above."""
+
+    _PATCHES = (('MLP', _mlp_forward), ('MLPDecoder', _mlp_decoder_forward), ('_FlatEncoder', _flat_encoder_forward),
+                ('EncoderSST', _sst_encoder_forward), ('_FlatDecoder', _flat_decoder_forward), ('DecoderSST_Skip', _sst_skip_decoder_forward),
+                ('DecoderSST', _sst_decoder_forward), ('ConvResBlock', _conv_res_block_forward), ('ResNet18', _resnet18_forward))
+
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self._lowp_saved = dict(_LOWP)
+        _LOWP['dtype'], _LOWP['precision'] = self.dtype, 'fp16' if self.dtype == torch.float16 else 'bf16'
+        self._saved = [(name, getattr(cpu_ref, name).forward) for name, _ in self._PATCHES]
+        for name, fn in self._PATCHES:
+            getattr(cpu_ref, name).forward = fn
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved:
+            getattr(cpu_ref, name).forward = fn
+        _LOWP.update(self._lowp_saved)
+        return False
+
+
+# ======================================================================================================================
+# The product's OWN module tree and host logic (networks/*.py, train.compute_losses) on the CPU with every functional entry point
+# replaced by the emulation classes above (`emulate_product_bf16`).  This checks the product's HOST code (launch structure: grouped
+# BatchNorm over stacked calls, batched decoding, fused blocks) against the same rounding rules; it is NOT independent of the product
+# and is used only (a) block by block in tests/test_conv_gpu.py and (b) here on the CPU, where tests/test_oracle_golden.py checks that it
+# agrees with the independent emulation above.
 def _emu_mlp_chain(x, linears, hidden_act='relu', out_act='none'):
     params = []
     for lin in linears:

@@ -408,6 +408,20 @@ def refresh_shadows(params, dtype=None):
             _shadow[key] = (p._version, ent[1], p)
 
 
+def invalidate_shadows(params):
+    """Mark the operand copies (and every weight pre-pack) of `params` stale: their next use re-casts / re-packs into the same storage.  A
+    recorded step whose optimizer does not maintain the copies itself calls this right before the capture, so that the recording contains
+    the casts."""
+    for p in params:
+        ent = _shadow.get(id(p))
+        if ent is not None and ent[2] is p:
+            _shadow[id(p)] = (-1, ent[1], p)
+        for cache in (_packed, _packed_conv, _packed_tap, _packed_k3, _packed_img):
+            for key, e in list(cache.items()):
+                if e[2] is p:
+                    cache[key] = (-1, e[1], p)
+
+
 def to_compute(x, dtype):
     x = x.detach()
     if x.dtype == dtype:
@@ -501,10 +515,22 @@ class MLPChain(torch.autograd.Function):
             W, b = params[2 * l], params[2 * l + 1]
             N, K = W.shape
             h_in = saved[l]
+
+            def input_gradient(dz=dz, W=W, h_in=h_in, l=l, K=K, N=N):
+                masked = acts[l - 1] not in ('none', None)
+                return ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=cdt, mask=h_in if masked else None,
+                                mask_act=acts[l - 1] if masked else 'none')
+            dz_next = None
             if W.requires_grad:               # dW = dz^T h_in (fp32); off the critical path -> wgrad stream when enabled
                 dst = grad_output(W)
                 fused = fused_optimizer(W) if dst is None else None
                 if fused is not None and cdt != torch.float32 and fused.can_fuse(W, dz, h_in):
+                    # the fused launch REWRITES W and its 16-bit copy: the input gradient of this layer reads that copy, so it is
+                    # launched first; the update (run now, on a lane behind the current stream, or held) is ordered after it
+                    if l > 0:
+                        dz_next = input_gradient()
+                    elif ctx.x_needs_grad:
+                        dx = ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=torch.float32)
                     # the weight-gradient GEMM's epilogue IS this weight's optimizer step; nothing is stored, autograd gets nothing
                     run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, W=W, fused=fused: fused.fused_update(W, dz, S, h_in, S, N, K, M),
                                  dz, h_in, outs=(), lane=lane)
@@ -522,10 +548,8 @@ class MLPChain(torch.autograd.Function):
             if b is not None and b.requires_grad:
                 bias_jobs.append((2 * l + 1, dz, grad_output(b)))
             if l > 0:
-                masked = acts[l - 1] not in ('none', None)
-                dz = ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=cdt, mask=h_in if masked else None,
-                              mask_act=acts[l - 1] if masked else 'none')
-            elif ctx.x_needs_grad:
+                dz = dz_next if dz_next is not None else input_gradient()
+            elif ctx.x_needs_grad and dx is None:
                 dx = ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=torch.float32)
         direct = [j for j in bias_jobs if j[2] is not None]
         bias_jobs = [j for j in bias_jobs if j[2] is None]
@@ -882,7 +906,7 @@ class ConvResBlockFn(torch.autograd.Function):
             dw = _conv_weight_grad(w, dz, h, 1, 1, False) if w.requires_grad else None
             grads[4 * li:4 * li + 4] = _fold_param_grads(((w, dw), (b, db), (gm, dgamma), (bt, dbeta)))
             if li > 0 or ctx.x_needs_grad:
-                slabs = ops.conv3_img16(dz, packed_img_weight(w, cdt, True), w.shape[1], name='vs_conv_dgrad')
+                slabs = ops.conv3_img16(dz, packed_img_weight(w, cdt, True), w.shape[1], role='dgrad')
         dx = None
         if ctx.x_needs_grad:
             dx = ops.slab_sum(slabs, None, torch.float32, addend=g_new.contiguous().float() if g_new is not None else None)
@@ -1032,17 +1056,17 @@ class ConvBlock(torch.autograd.Function):
             # read as [in, out, 4, 4]): on 4x4 / 8x8 / 16x16 gradient maps it takes the LDS-staged tap kernel (no column matrix)
             if (not transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4 and ctx.x_dtype == dz.dtype
                     and xc.shape[2] == 2 * dz.shape[2] and xc.shape[3] == 2 * dz.shape[3] and ops.convt_tap_supported(dz, w.shape[1], 1)):
-                dx, _ = ops.convt_tap_fwd(dz, packed_tap_weight(w, cdt), None, w.shape[1], groups=1, want_sums=False, name='vs_conv_dgrad')
+                dx, _ = ops.convt_tap_fwd(dz, packed_tap_weight(w, cdt), None, w.shape[1], groups=1, want_sums=False, role='dgrad')
             elif (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3 and groups == 1
                   and ops.conv3_img16_supported(dz, w.shape[1])):
                 # few 16x16 maps: the same one-launch kernel on dz with the weight packed transposed and flipped
-                dx = ops.slab_sum(ops.conv3_img16(dz, packed_img_weight(w, cdt, True), w.shape[1], name='vs_conv_dgrad'), None, ctx.x_dtype)
+                dx = ops.slab_sum(ops.conv3_img16(dz, packed_img_weight(w, cdt, True), w.shape[1], role='dgrad'), None, ctx.x_dtype)
             elif band_ok(dz, w, transposed, stride, pad, dgrad=True):
-                dx = ops.conv3_band(dz, packed_img_weight(w, cdt, True), None, w.shape[1], ctx.x_dtype, name='vs_conv_dgrad')
+                dx = ops.conv3_band(dz, packed_img_weight(w, cdt, True), None, w.shape[1], ctx.x_dtype, role='dgrad')
             elif (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
                   and ops.conv_k3_tap_supported(dz, w.shape[1], 1)):
                 # Conv2d k3 s1 p1: the input gradient is the same convolution of dz with the weight transposed and flipped
-                dx, _ = ops.conv_k3_tap_fwd(dz, packed_k3_weight(w, cdt, True), None, w.shape[1], ctx.x_dtype, groups=1, name='vs_conv_dgrad')
+                dx, _ = ops.conv_k3_tap_fwd(dz, packed_k3_weight(w, cdt, True), None, w.shape[1], ctx.x_dtype, groups=1, role='dgrad')
             else:
                 wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
                 dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,

@@ -45,6 +45,9 @@ def load_dataset(args, device=None):
 def main(argv=None):
     args = parser.parse_args(argv)
     os.environ['OMP_NUM_THREADS'] = str(args.num_workers)
+    if not args.ddp:
+        from . import configure_single_gpu_queues
+        configure_single_gpu_queues()      # before the first HIP call of the process; data-parallel ranks keep the runtime's defaults
 
     # one process per GPU; under torchrun LOCAL_RANK selects the device
     rank, world = 0, 1
@@ -128,8 +131,6 @@ def main(argv=None):
     # same constructor call as the reference (main.py:133); the update runs as one multi-tensor HIP launch (optim.py)
     from .optim import Adam
     optimizer = Adam(sep_net.parameters(), lr=args.lr, betas=(args.beta1, args.beta2))
-    from .train import enable_update_in_backward
-    enable_update_in_backward(optimizer, sep_net, grad_sync)
     scheduler = lr_scheduler.MultiStepLR(optimizer, args.scheduler_milestones, gamma=args.scheduler_decay) \
         if args.scheduler else None
 
@@ -140,6 +141,8 @@ def main(argv=None):
         print('compute precision: %s%s' % (precision, ' + dynamic loss scaling' if precision == 'fp16' else ''))
     from .train import make_loss_scaler
     scaler = make_loss_scaler(device) if precision == 'fp16' else None
+    from .train import enable_update_in_backward
+    enable_update_in_backward(optimizer, sep_net, grad_sync, scaler=scaler)
     train(args.xp_dir, train_loader, device, sep_net, optimizer, scheduler, args.apex_amp, False, args.epochs, args.lamb_ae,
           args.lamb_s, args.lamb_t, args.lamb_pred, args.offset, args.nt_cond, args.nt_pred, args.no_s, args.skipco,
           args.chkpt_interval, args.architecture == 'encoderSST', grad_sync=grad_sync, log_interval=args.log_interval,

@@ -26,5 +26,15 @@ class MLP(nn.Module):
     def linears(self):
         return [blk[-1] for blk in self.module]
 
+    def hidden_activation(self):
+        """Name of the activation between the layers; read off the module tree when the object was restored from a reference
+        checkpoint (whole-module pickle of `var_sep.networks.mlp.MLP`, which keeps no such attribute)."""
+        act = self.__dict__.get('activation')
+        if act is None:
+            from .utils import activation_name
+            act = activation_name(self.module[1][0]) if len(self.module) > 1 else 'relu'
+            self.activation = act
+        return act
+
     def forward(self, x, out_act='none'):
-        return VF.mlp_chain(x, self.linears(), hidden_act=self.activation, out_act=out_act)
+        return VF.mlp_chain(x, self.linears(), hidden_act=self.hidden_activation(), out_act=out_act)

@@ -49,7 +49,7 @@ class MLPDecoder(nn.Module):
         from .. import functional as VF
         B, n = t_codes.shape[0], t_codes.shape[1]
         z, z_lowp = VF.MixCodes.apply(z1.float().contiguous(), t_first.float().contiguous(), t_codes.float().contiguous(), self.mixing)
-        x = VF.mlp_chain(z.reshape(B * (n + 1), -1), self.mlp.linears(), hidden_act=self.mlp.activation,
+        x = VF.mlp_chain(z.reshape(B * (n + 1), -1), self.mlp.linears(), hidden_act=self.mlp.hidden_activation(),
                          out_act=activation_name(self.last_activation),
                          x_lowp=None if z_lowp is None else z_lowp.reshape(B * (n + 1), -1), handoff=handoff)
         return x.view([B, n + 1] + self.output_shape)

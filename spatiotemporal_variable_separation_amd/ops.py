@@ -456,7 +456,7 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     e0 = _pb()
     check(fn(dtype_code(x), x.data_ptr(), w_arg.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W, Cout, k, k,
              stride, pad, _ptr(ws), ws.numel() if ws is not None else 0, stream_ptr()), 'vs_conv_fwd')
-    _pe(e0, 'vs_conv%s_fwd<%s>' % ('T' if transposed else '', _DT[dtype_code(x)]),
+    _pe(e0, 'vs_conv%s_cols:fwd<%s>' % ('T' if transposed else '', _DT[dtype_code(x)]),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
         nbytes=float(x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()))
     return y
@@ -485,7 +485,7 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     check(fn(dtype_code(dy), dy.data_ptr(), w_arg.data_ptr(), dx.data_ptr(), dtype_code(dx), B, Cin, H, W, Cout, k, k, stride, pad,
              _ptr(ws), ws.numel() if ws is not None else 0, *extra, stream_ptr()), 'vs_conv_dgrad')
     OH, OW = dy.shape[2], dy.shape[3]
-    _pe(e0, 'vs_conv%s_dgrad<%s>' % ('T' if transposed else '', _DT[dtype_code(dy)]),
+    _pe(e0, 'vs_conv%s_cols:dgrad<%s>' % ('T' if transposed else '', _DT[dtype_code(dy)]),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
         nbytes=float(dy.numel() * dy.element_size() + w.numel() * w.element_size() + dx.numel() * dx.element_size()))
     return dx
@@ -540,7 +540,7 @@ def conv3_wgrad_band_pieces(pairs, w_shape, into=None):
     e0 = _pb()
     check(lib.vs_conv3_wgrad_band_pieces(dtype_code(x0), n, xs, dzs, mp, slabs.data_ptr(), Cin, H, W, Cout, stream_ptr()), 'vs_conv3_wgrad_band_pieces')
     _slab_reduce(slabs, nslabs, w_shape, into, dw)
-    _pe(e0, 'vs_conv_wgrad<%s>' % _DT[dtype_code(x0)], flops=2.0 * B * Cout * H * W * Cin * 9,
+    _pe(e0, 'vs_conv3_wgrad_band<%s>' % _DT[dtype_code(x0)], flops=2.0 * B * Cout * H * W * Cin * 9,
         nbytes=float(n * (dz0.numel() + x0.numel()) * x0.element_size() + slabs.numel() * 8))
     return dw
 
@@ -567,7 +567,7 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
         e0 = _pb()
         check(lib.vs_conv3_wgrad_band(dtype_code(x), x.data_ptr(), dy.data_ptr(), slabs.data_ptr(), B, Cin, H, W, Cout, stream_ptr()), 'vs_conv3_wgrad_band')
         _slab_reduce(slabs, nslabs, w_shape, into, dw)
-        _pe(e0, 'vs_conv_wgrad<%s>' % _DT[dtype_code(x)], flops=2.0 * B * Cout * OH * OW * Cin * 9,
+        _pe(e0, 'vs_conv3_wgrad_band<%s>' % _DT[dtype_code(x)], flops=2.0 * B * Cout * OH * OW * Cin * 9,
             nbytes=float(dy.numel() * dy.element_size() + x.numel() * x.element_size() + slabs.numel() * 8))
         return dw
     pix_h, pix_w = (H, W) if transposed else (OH, OW)
@@ -579,7 +579,7 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
     e0 = _pb()
     check(fn(dtype_code(x), dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Cin, H, W, Cout, k, k, stride, pad, _ptr(ws),
              ws.numel() if ws is not None else 0, 1 if into is not None else 0, stream_ptr()), 'vs_conv_wgrad')
-    _pe(e0, 'vs_conv%s_wgrad<%s>' % ('T' if transposed else '', _DT[dtype_code(x)]),
+    _pe(e0, 'vs_conv%s_cols:wgrad<%s>' % ('T' if transposed else '', _DT[dtype_code(x)]),
         flops=2.0 * B * Cout * OH * OW * Cin * k * k if not transposed else 2.0 * B * Cin * H * W * Cout * k * k,
         nbytes=float(dy.numel() * dy.element_size() + x.numel() * x.element_size() + dw.numel() * 4))
     return dw
@@ -606,7 +606,7 @@ def convt_tap_pack_weight(w_master, dtype, out=None):
     return out
 
 
-def convt_tap_fwd(x, w_tap, bias, Cout, groups=1, want_sums=True, name='vs_convT_fwd'):
+def convt_tap_fwd(x, w_tap, bias, Cout, groups=1, want_sums=True, role='fwd'):
     """-> (y [B, Cout, 2H, 2W] in x's dtype, fp64 sums [groups, Cout, 2] of the stored outputs or None)."""
     require_cuda(x, w_tap, bias)
     assert x.is_contiguous() and x.dtype == w_tap.dtype
@@ -616,7 +616,7 @@ def convt_tap_fwd(x, w_tap, bias, Cout, groups=1, want_sums=True, name='vs_convT
     e0 = _pb()
     check(_lib.load_library().vs_convt_k4s2_tap_fwd(dtype_code(x), x.data_ptr(), w_tap.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(sums), B, Cin, H, W,
                                                     Cout, groups, stream_ptr()), 'vs_convt_k4s2_tap_fwd')
-    _pe(e0, '%s<%s>' % (name, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 16,
+    _pe(e0, 'vs_convT_tap:%s<%s>' % (role, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 16,
         nbytes=float(x.numel() * x.element_size() + w_tap.numel() * 2 + y.numel() * y.element_size()))
     return y, sums
 
@@ -663,7 +663,7 @@ def conv3_img16_pack_weight(w_master, dtype, flip, out=None):
     return out
 
 
-def conv3_img16(x, w_packed, Cout, name='vs_conv_fwd'):
+def conv3_img16(x, w_packed, Cout, role='fwd'):
     """Conv2d k3 s1 p1 of x [B, Cin, 16, 16] -> fp32 split slabs [S, B, Cout, 16, 16] WITHOUT bias (S = vs_conv3_img16_splits); consumers:
     `bn_train_fwd_small_slabs`, `slab_sum`."""
     require_cuda(x, w_packed)
@@ -674,7 +674,7 @@ def conv3_img16(x, w_packed, Cout, name='vs_conv_fwd'):
     slabs = torch.empty((S, B, Cout, H, W), dtype=torch.float32, device=x.device)
     e0 = _pb()
     check(lib.vs_conv3_img16(dtype_code(x), x.data_ptr(), w_packed.data_ptr(), slabs.data_ptr(), B, Cin, Cout, stream_ptr()), 'vs_conv3_img16')
-    _pe(e0, '%s<%s>' % (name, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
+    _pe(e0, 'vs_conv3_img16:%s<%s>' % (role, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
         nbytes=float(x.numel() * x.element_size() + w_packed.numel() * 2 + slabs.numel() * 4))
     return slabs
 
@@ -689,7 +689,7 @@ def conv3_band_supported(x, Cout):
     return bool(_lib.load_library().vs_conv3_band_supported(dtype_code(x), B, Cin, H, W, Cout))
 
 
-def conv3_band(x, w_packed, bias, Cout, out_dtype, name='vs_conv_fwd'):
+def conv3_band(x, w_packed, bias, Cout, out_dtype, role='fwd'):
     """Conv2d k3 s1 p1 of x [B, Cin, H, W] (16-bit) with the `conv3_img16_pack_weight` pre-pack -> y [B, Cout, H, W] in out_dtype (+ bias)."""
     require_cuda(x, w_packed, bias)
     assert x.is_contiguous() and x.dtype == w_packed.dtype
@@ -698,7 +698,7 @@ def conv3_band(x, w_packed, bias, Cout, out_dtype, name='vs_conv_fwd'):
     e0 = _pb()
     check(_lib.load_library().vs_conv3_band(dtype_code(x), x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W,
                                             Cout, stream_ptr()), 'vs_conv3_band')
-    _pe(e0, '%s<%s>' % (name, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
+    _pe(e0, 'vs_conv3_band:%s<%s>' % (role, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
         nbytes=float(x.numel() * x.element_size() + w_packed.numel() * 2 + y.numel() * y.element_size()))
     return y
 
@@ -732,7 +732,7 @@ def conv_k3_tap_pack_weight(w_master, dtype, flip, out=None):
     return out
 
 
-def conv_k3_tap_fwd(x, w_tap, bias, Cout, out_dtype, groups=1, want_sums=False, name='vs_conv_fwd'):
+def conv_k3_tap_fwd(x, w_tap, bias, Cout, out_dtype, groups=1, want_sums=False, role='fwd'):
     """-> (y [B, Cout, H, W] in out_dtype, fp64 sums [groups, Cout, 2] of the stored outputs or None)."""
     require_cuda(x, w_tap, bias)
     assert x.is_contiguous() and x.dtype == w_tap.dtype
@@ -742,7 +742,7 @@ def conv_k3_tap_fwd(x, w_tap, bias, Cout, out_dtype, groups=1, want_sums=False, 
     e0 = _pb()
     check(_lib.load_library().vs_conv_k3s1_tap_fwd(dtype_code(x), x.data_ptr(), w_tap.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), _ptr(sums),
                                                    B, Cin, H, W, Cout, groups, stream_ptr()), 'vs_conv_k3s1_tap_fwd')
-    _pe(e0, '%s<%s>' % (name, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
+    _pe(e0, 'vs_conv3_tap:%s<%s>' % (role, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
         nbytes=float(x.numel() * x.element_size() + w_tap.numel() * 2 + y.numel() * y.element_size()))
     return y, sums
 
@@ -799,7 +799,7 @@ def bn_train_fwd_small(x, gamma, beta, act, out_dtype, running_mean=None, runnin
     check(_lib.load_library().vs_bn_train_fwd_small(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), gamma.data_ptr(), beta.data_ptr(),
                                                     ACT[act], mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
                                                     float(momentum), float(eps), B, C, HW, stream_ptr()), 'vs_bn_train_fwd_small')
-    _pe(e0, 'vs_bn_act_fwd', nbytes=float(x.numel() * (x.element_size() + y.element_size())))
+    _pe(e0, 'vs_bn_fwd_small', nbytes=float(x.numel() * (x.element_size() + y.element_size())))
     return y, mean, invstd
 
 
@@ -825,7 +825,7 @@ def bn_train_fwd_small_slabs(slabs, bias, z_dtype, gamma, beta, act, out_dtype, 
                                                           gamma.data_ptr(), beta.data_ptr(), ACT[act], mean.data_ptr(), invstd.data_ptr(),
                                                           _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(skip),
                                                           _ptr(xnew), _ptr(xnew16), B, C, HW, stream_ptr()), 'vs_bn_train_fwd_small_slabs')
-    _pe(e0, 'vs_bn_act_fwd', nbytes=float(slabs.numel() * 4 + z.numel() * (z.element_size() + y.element_size())))
+    _pe(e0, 'vs_bn_fwd_small_slabs', nbytes=float(slabs.numel() * 4 + z.numel() * (z.element_size() + y.element_size())))
     if skip is not None:
         return y, z, mean, invstd, xnew, xnew16
     return y, z, mean, invstd
@@ -856,7 +856,7 @@ def bn_act_bwd_small_ex(z, mean, invstd, gamma, beta, act, dx_dtype, dy_a=None, 
                                                      invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], dgamma.data_ptr(),
                                                      dbeta.data_ptr(), int(acc is not None), dx.data_ptr(), dtype_code(dx), B, C, HW, stream_ptr()),
           'vs_bn_act_bwd_small_ex')
-    _pe(e0, 'vs_bn_act_bwd', nbytes=float(z.numel() * (z.element_size() + dx.element_size() + 4)))
+    _pe(e0, 'vs_bn_bwd_small_ex', nbytes=float(z.numel() * (z.element_size() + dx.element_size() + 4)))
     if acc is not None:
         return dx, None, None
     return dx, dgamma, dbeta

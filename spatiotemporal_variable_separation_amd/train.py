@@ -223,7 +223,7 @@ class GraphedStep:
             from . import functional as VF
             grad_sync.direct_lowp = True
             VF.set_lowp_gradients({p: grad_sync.lowp_views[id(p)] for p in grad_sync.params if id(p) in grad_sync.lowp_views})
-        enable_update_in_backward(optimizer, sep_net, grad_sync)
+        enable_update_in_backward(optimizer, sep_net, grad_sync, scaler=scaler)
         enable_fused_update(optimizer, sep_net, grad_sync, scaler)
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
         # static inputs of the recording: one [B, T, ...] buffer, cond / target are views of it (no concatenation per step)
@@ -249,11 +249,19 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         if snap is not None:
             snap.restore()
+        from . import functional as VF
+        from .optim import Adam as HipAdam
+        if isinstance(optimizer, HipAdam):
             # the restore bumped every parameter's version counter: bring the 16-bit operand copies up to date NOW, or the
-            # recording would contain a cast of every weight (the optimizer kernel keeps them current from then on): measured
-            # +90 us per replayed WaveEq step
-            from . import functional as VF
-            VF.refresh_shadows(list(sep_net.parameters()))
+            # recording would contain a cast of every weight: measured +90 us per replayed WaveEq step.  ONLY valid because the HIP
+            # Adam kernel rewrites the copies in the pass that updates the masters, so they stay current from then on
+            if snap is not None:
+                VF.refresh_shadows(list(sep_net.parameters()))
+        else:
+            # any other optimizer (torch.optim.Adam(capturable=True)) updates the fp32 masters only: the recording must CONTAIN the
+            # casts, or every replay would read the weights frozen at capture time.  Mark every copy stale so that its first use
+            # inside the capture records the cast (replayed at the start of every step, i.e. after the previous step's update)
+            VF.invalidate_shadows(list(sep_net.parameters()))
         self._capture()
 
     def _capture(self):
@@ -377,7 +385,7 @@ def chain_weight_parameters(sep_net):
     return out
 
 
-def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False):
+def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False, scaler=None):
     """With the HIP Adam and no gradient all-reduce: update decoder + integrator + E_s on a side stream as soon as the last
     of their gradients is final, i.e. while backward is still in E_t (optim.Adam.overlap_with_backward).  One bucket on
     purpose: the update streams HBM at >5 TB/s and, launched earlier, would run beside the integrator's backward kernel,
@@ -386,6 +394,10 @@ def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False):
     # (98 MB of fp32 weight gradient per encoder) compete for the same HBM bandwidth, both just run slower side by side.
     from .optim import Adam as HipAdam
     if not force and os.environ.get('VARSEP_ADAM_OVERLAP') != '1':
+        return
+    if scaler is not None:
+        # fp16 loss scaling: the update needs 1 / scale and the finite check of ALL gradients, which exist only after backward
+        # (LossScaler.step); an update from a backward hook would apply scaled gradients and could not be skipped on overflow
         return
     if isinstance(optimizer, HipAdam) and grad_sync is None and not optimizer._buckets and len(optimizer.param_groups) == 1:
         owned = {id(p) for p in optimizer.param_groups[0]['params']}
@@ -499,6 +511,9 @@ class LossScaler:
         from .optim import Adam as HipAdam
         if not isinstance(optimizer, HipAdam):
             raise ValueError('fp16 loss scaling is implemented by spatiotemporal_variable_separation_amd.optim.Adam (device-side skip)')
+        if optimizer._buckets or optimizer._fused:
+            raise ValueError('fp16 loss scaling cannot be combined with Adam updates issued during backward (overlap_with_backward / '
+                             'fuse_into_wgrad): they would apply still-scaled gradients and could not be skipped on overflow')
         grads = []
         for group in optimizer.param_groups:
             for p in group['params']:
@@ -630,16 +645,37 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
     # add per block; only valid without gradient hooks (the bucketed all-reduce counts hook calls)
     VF.fold_repeated_gradients(os.environ.get('VARSEP_FOLD_GRADS', '1') == '1' and grad_sync is None)
 
-    def checkpoint(epoch_number=None):
+    def checkpoint(epoch_number=None, collective=True):
         # data parallel: replicas hold identical parameters; BatchNorm buffers are per replica (no SyncBN), rank 0's are the ones
-        # kept and broadcast so that every replica continues from what was saved; only rank 0 writes
-        check_rollout_exchange(device)
-        if grad_sync is not None and world > 1:
+        # kept and broadcast so that every replica continues from what was saved; only rank 0 writes.
+        # The model is saved FIRST: a (sticky) exchange time-out flag of the integrator raises afterwards, so that hours of training
+        # are not discarded with it -- the files are then written under a `suspect_` name.  With several ranks the error word is
+        # MAX-reduced, so every rank takes the same branch (a raise on one rank would leave the others in the next collective);
+        # `collective=False` (after Ctrl-C, which may have hit one rank only) skips every collective.
+        from . import ops
+        err = int(ops.rollout_exchange_error(device)) if torch.device(device).type == 'cuda' else 0
+        if grad_sync is not None and world > 1 and collective:
+            import torch.distributed as dist
             from .parallel import broadcast_buffers
+            word = torch.tensor([err], dtype=torch.int32, device=device if grad_sync.backend == 'nccl' else 'cpu')
+            dist.all_reduce(word, op=dist.ReduceOp.MAX, group=grad_sync.group)
+            err = int(word.item())
             broadcast_buffers(sep_net, process_group=grad_sync.group)
         if rank == 0:
-            save(xp_dir, sep_net, epoch_number=epoch_number)
+            if err:
+                # same four files, in a sub-directory that marks them: helper.save keeps the reference's file names (helper.py:22-33)
+                suspect = os.path.join(xp_dir, 'suspect_exchange_timeout')
+                os.makedirs(suspect, exist_ok=True)
+                save(suspect, sep_net, epoch_number=epoch_number)
+            else:
+                save(xp_dir, sep_net, epoch_number=epoch_number)
+        if err:
+            from ._lib import VarsepHipError
+            raise VarsepHipError('rollout kernel: inter-workgroup exchange timed out (code %d) since the last check -- the integrator '
+                                 'results of at least one step are invalid; the model was saved under %s/suspect_exchange_timeout'
+                                 % (err, xp_dir))
 
+    interrupted = False
     try:
         for epoch in range(epochs):
             sep_net.train()
@@ -708,7 +744,7 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
             if chkpt_interval is not None and (epoch + 1) % chkpt_interval == 0:
                 checkpoint(epoch + 1)
     except KeyboardInterrupt:
-        pass
+        interrupted = True
     finally:
         VF.fold_repeated_gradients(False)
-    checkpoint()
+    checkpoint(collective=not interrupted)

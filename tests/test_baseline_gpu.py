@@ -23,7 +23,7 @@ from oracle import cpu_ref
 from oracle.detdata import det_fill
 from oracle.golden_configs import FULL_CONFIGS, fill_net, make_batch
 from golden_util import check_tensor, load_golden, rel_err
-from step_util import grad_err, grad_floor, hip_step, oracle_step
+from step_util import grad_err, grad_floor, hip_step, lowp_noise_floor, noise_bound, oracle_step
 
 pytestmark = pytest.mark.gpu
 
@@ -161,3 +161,126 @@ def test_full_size_waveeq_lowp_matches_rounding_point_emulation(precision):
     assert worst <= 2e-2, f'gradients: HIP {precision} vs emulation {worst:.3e}'
     errs['grad_worst'] = worst
     print('full_waveeq', precision, 'vs emulation:', {k: '%.1e' % v for k, v in errs.items()})
+
+
+# ---- the 16-bit modes at BASELINE size: the kernels bench.py times ---------------------------------------------------------------
+# (name, precision, kernel families that must have run, loss scale).  Every convolution kernel of the 16-bit path -- the row-band
+# forward / input-gradient / weight-gradient kernels, the few-maps kernel of the SST integrator and its one-launch BatchNorm forms, the
+# tap kernel of the stride-2 transposed convolutions, the column-matrix GEMM routes behind the ring tiles -- refuses fp32 tensors, so
+# the fp32 tests above never reach them; these do, at the sizes of BASELINE.json configs[2..4] and in the dtype configs[4] states.
+LOWP_FULL = [
+    ('full_mnist_b128', 'bf16', ('vs_convT_tap:fwd', 'vs_convT_tap:dgrad', 'vs_conv_cols:fwd', 'vs_conv_cols:wgrad', 'vs_convT_cols:wgrad',
+                                 'vs_mlp_rollout_fwd', 'vs_mlp_rollout_bwd'), None),
+    ('full_taxibj', 'bf16', ('vs_conv3_band:fwd', 'vs_conv3_band:dgrad', 'vs_conv3_wgrad_band', 'vs_convT_cols:fwd', 'vs_mlp_rollout_fwd'), None),
+    ('full_sst', 'fp16', ('vs_conv3_img16:fwd', 'vs_conv3_img16:dgrad', 'vs_conv3_band:fwd', 'vs_conv3_band:dgrad', 'vs_conv3_wgrad_band',
+                          'vs_bn_fwd_small_slabs', 'vs_bn_bwd_small_ex'), 1024.0),
+    ('full_sst', 'bf16', ('vs_conv3_img16:fwd', 'vs_conv3_img16:dgrad', 'vs_conv3_band:fwd', 'vs_conv3_wgrad_band'), None),
+]
+# Bounds (relative L2).
+#  vs the rounding-point emulation (same rounding rules, independent implementation: oracle/bf16_emu.py on the oracle's module tree):
+#     max(the floor below, 3 x the emulation's own distance to a second evaluation of itself under fp32-summation-order-sized noise) --
+#     step_util.lowp_noise_floor: a 16-bit step is discontinuous in its fp32 intermediates and the VGG / SST stacks amplify one-ulp flips
+#     to 3e-2 ... 5e-2 on the forecasts and 0.3 on the encoder gradients, for ANY two implementations (the DCGAN step: 5e-4 / 6e-3).
+#     The chaos-free statement -- stored values equal element for element except isolated one-ulp flips, block gradients to 2 % -- is
+#     test_full_size_lowp_blocks_match_emulation_elementwise below.
+#  vs the reference's fp32 fixture: the cost of the 16-bit operands themselves -- for outputs a stated bound per mode; for gradients the
+#     kernels may not be further from the reference than the mode's definition is: e(HIP, reference) <= 1.5 e(emulation, reference) + 0.03.
+_EMU_OUT = {'bf16': 5e-3, 'fp16': 2e-3}
+_EMU_GRAD = 5e-2
+_REF_OUT = {'bf16': 5e-2, 'fp16': 1e-2}
+
+
+@pytest.mark.parametrize('name,precision,families,loss_scale', LOWP_FULL, ids=[f'{n}-{p}' for n, p, _, _ in LOWP_FULL])
+def test_full_size_lowp_step_matches_emulation_and_reference(name, precision, families, loss_scale):
+    """One whole 16-bit training step at BASELINE size (the launch structure of the training loop: gradients folded, the integrator's
+    weight gradients batched) against (i) the fp32 fixture recorded from the reference's own train() at a stated 16-bit bound and (ii) the
+    independent rounding-point emulation evaluated on this host, element-wise; plus the check that the 16-bit kernel routes were taken."""
+    from step_util import emulated_bf16_step
+    cfg = FULL_CONFIGS[name]
+    gold = _fixture(name)
+    t_random = int(gold['t_random'])
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    o_net0 = fill_net(cpu_ref.build_sep_net(cfg), cfg)
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision, loss_scale=loss_scale, profile=True, fold=True)
+    from spatiotemporal_variable_separation_amd import ops
+    assert ops.rollout_exchange_error(torch.device('cuda', torch.cuda.current_device())) == 0
+    ran = set(h_net.kernel_families)
+    tag = {'bf16': '<bf16>', 'fp16': '<fp16>'}[precision]
+    fails = []
+
+    def expect(ok, msg):
+        if not ok:
+            fails.append(msg)
+    for fam in families:
+        expect(any(k.startswith(fam) and (tag in k or '<' not in k) for k in ran), f'{name} {precision}: kernel family {fam} did not run; ran {sorted(ran)}')
+    grads = {k: p.grad.detach().float().cpu() for k, p in h_net.named_parameters() if p.grad is not None}
+    assert all(torch.isfinite(g).all() for g in grads.values()), 'non-finite gradient'
+
+    # (i) the reference's fp32 step (fixture) at the mode's bound
+    tol = _REF_OUT[precision]
+    ref_total = float(gold['total'])
+    worst = {'ref:total': abs(h_total.item() - ref_total) / abs(ref_total)}
+    expect(worst['ref:total'] <= tol, f'total {h_total.item()} vs reference {ref_total}')
+    for k, v in h_terms.items():
+        ref = float(gold['loss:' + k])
+        e = abs(v.item() - ref) / max(abs(ref), 1e-6)
+        worst['ref:loss:' + k] = e
+        expect(e <= tol or abs(v.item() - ref) <= 1e-3 * abs(ref_total), f'loss {k}: {v.item()} vs reference {ref}')
+    worst['ref:forecasts'] = check_tensor(gold, 'forecasts', h_fore, float('inf'))
+    worst['ref:t_codes'] = check_tensor(gold, 't_codes', h_tc, float('inf'))
+    expect(worst['ref:forecasts'] <= tol and worst['ref:t_codes'] <= tol, f'forecasts / t_codes vs reference: {worst}')
+    total_norm = np.sqrt(sum(float(gold[k][1]) ** 2 if k.startswith('cs:grad:') else float((gold[k].astype(np.float64) ** 2).sum())
+                             for k in gold if k.startswith('cs:grad:') or k.startswith('grad:')))
+    hip_ref = {}
+    for k, g in grads.items():
+        key = 'grad:' + k
+        ref_norm = float(gold['cs:' + key][1]) if 'cs:' + key in gold else float(np.linalg.norm(gold[key].astype(np.float64)))
+        if ref_norm < 1e-3 * total_norm:
+            expect(g.double().norm().item() <= 5e-3 * total_norm, f'{key}: should be small on the scale of the whole gradient')
+            continue
+        hip_ref[k] = check_tensor(gold, key, g, float('inf'))
+    worst['ref:grad'] = max(hip_ref.values())
+
+    # (ii) the rounding-point emulation, element-wise
+    emu = emulated_bf16_step(cfg, t_random, precision, loss_scale=loss_scale)
+    e_net, e_total, e_terms, e_fore, e_tc = emu
+    noise = lowp_noise_floor(cfg, t_random, precision, loss_scale=loss_scale, base=emu)
+    tol = _EMU_OUT[precision]
+    errs = {'emu:forecasts': rel_err(h_fore.detach().float().cpu(), e_fore.detach().float()),
+            'emu:t_codes': rel_err(h_tc.detach().float().cpu(), e_tc.detach().float()),
+            'emu:total': abs(h_total.item() - e_total.item()) / abs(e_total.item())}
+    for k in e_terms:
+        errs['emu:loss:' + k] = abs(h_terms[k].item() - e_terms[k].item()) / max(abs(e_terms[k].item()), 1e-3 * abs(e_total.item()))
+    for k, v in errs.items():
+        b = noise_bound(noise, k[4:], tol)
+        expect(v <= b, f'{k}: HIP {precision} vs rounding-point emulation {v:.3e} > {b:.1e}')
+    floor = 10 * grad_floor(e_net)                   # 1e-3 of the whole gradient's norm
+    eg = dict(e_net.named_parameters())
+    per = {k: grad_err(g, eg[k].grad, floor) for k, g in grads.items()}
+    over = {k: v / noise_bound(noise, 'grad:' + k.split('.')[0], _EMU_GRAD) for k, v in per.items()}
+    kw = max(over, key=over.get)
+    errs['emu:grad_worst'] = max(per.values())
+    errs['emu:grad_worst_over_bound'] = over[kw]
+    expect(over[kw] <= 1.0, f'gradient {kw}: HIP {precision} vs rounding-point emulation {per[kw]:.3e}, {over[kw]:.2f} x its bound')
+    # gradients vs the reference, relative to the mode's own distance from it
+    ratio = 0.0
+    for k, e_hip in hip_ref.items():
+        e_emu = check_tensor(gold, 'grad:' + k, eg[k].grad, float('inf'))
+        bound = 1.5 * e_emu + 0.03
+        ratio = max(ratio, e_hip / bound)
+        expect(e_hip <= bound, f'gradient {k}: HIP {precision} vs reference {e_hip:.3e}, emulation vs reference {e_emu:.3e}')
+    errs['ref:grad_over_mode_bound'] = ratio
+    esd = e_net.state_dict()
+    bn = 0.0
+    for k, v in h_net.state_dict().items():
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            bn = max(bn, rel_err(v.detach().float().cpu(), esd[k].float()))
+        elif k.endswith('num_batches_tracked'):
+            expect(int(v) == int(esd[k]), k)
+    errs['emu:bn_running'] = bn
+    expect(bn <= noise_bound(noise, 'bn_running', tol), f'BatchNorm running statistics: {bn:.3e}')
+    worst.update(errs)
+    top = sorted(per.items(), key=lambda kv: -kv[1])[:4]
+    print(name, precision, {k: '%.1e' % v for k, v in worst.items()}, 'largest gradient distances to the emulation:',
+          [(k, '%.1e' % v) for k, v in top], '| emulation self-distance', {k: '%.1e' % v for k, v in noise.items() if not k.startswith('loss')})
+    assert not fails, '\n'.join(fails)

@@ -1,0 +1,236 @@
+"""GPU: every convolution block of the BASELINE-size networks in the 16-bit modes, block by block on IDENTICAL inputs, against the
+independent rounding-point emulation (oracle/bf16_emu.py: `_emu_layers` on the ORACLE's modules).
+
+Why block by block: a 16-bit training step is a discontinuous function of its fp32 intermediates (a conv output next to a rounding
+boundary is stored one ulp up or down depending on the fp32 summation order) and the per-call BatchNorm stacks amplify such flips, so
+two equally valid evaluations of a WHOLE step lie up to 5e-2 (forecasts) / 0.3 (encoder gradients) apart (step_util.lowp_noise_floor;
+test_baseline_gpu.test_full_size_lowp_step_* bounds the step at 3x that self-distance).  Fed the same 16-bit input, a single block has no
+such freedom: its stored output must equal the emulation's ELEMENT FOR ELEMENT except isolated one-ulp flips, and its input / parameter
+gradients for a fixed upstream gradient must agree to rounding noise.  This is the sharp statement about the kernels the bench times, at
+the shapes the bench runs them: the encoders' blocks on the two stacked calls of a step (`groups=2`), the decoder's on all n frames of a
+rollout (`groups=n`, per-call BatchNorm statistics), the SST integrator's ConvResBlock on its 8 maps -- row-band forward / input-gradient /
+weight-gradient kernels, the few-maps kernel with its one-launch BatchNorm forms, the tap kernel of the stride-2 transposed convolutions,
+the column-matrix GEMM routes on the ring tiles, pooling / up-sampling, the grouped BatchNorm kernels."""
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import cpu_ref
+from oracle.detdata import det_uniform
+from oracle.golden_configs import FULL_CONFIGS, fill_net, make_batch
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+_ACTS = ('ReLU', 'LeakyReLU', 'ELU', 'Sigmoid', 'Tanh')
+_LOWP = {'bf16': torch.bfloat16, 'fp16': torch.float16}
+# one ulp of the largest stored magnitudes, relative: 2^-8 (bf16: 8 significand bits), 2^-11 (fp16); a flipped z moves a block output by
+# ulp(z) * gamma * invstd, i.e. a few ulps of the largest outputs at most
+_MAX_FLIP = {'bf16': 2.0 ** -5, 'fp16': 2.0 ** -8}
+_FLIP_FRACTION = 0.01
+_GRAD_TOL = {'bf16': 2e-2, 'fp16': 4e-3}
+
+
+def _flatten(module, out):
+    if isinstance(module, (nn.Sequential, nn.ModuleList)):
+        for m in module:
+            _flatten(m, out)
+    elif not isinstance(module, nn.Identity):
+        out.append(module)
+    return out
+
+
+def _units(stage):
+    """[conv, (BatchNorm), (activation)] groups, [Flatten, Linear] pairs and single pool / up-sampling layers of a stage, in order."""
+    layers = _flatten(stage, [])
+    out, i = [], 0
+    while i < len(layers):
+        m = layers[i]
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            j = i + 1
+            if j < len(layers) and isinstance(layers[j], nn.BatchNorm2d):
+                j += 1
+            if j < len(layers) and type(layers[j]).__name__ in _ACTS:
+                j += 1
+        elif isinstance(m, nn.Flatten):
+            j = i + 2
+        else:
+            j = i + 1
+        out.append(nn.Sequential(*layers[i:j]))
+        i = j
+    return out
+
+
+class _Report:
+    def __init__(self, tag):
+        self.tag, self.rows, self.fails = tag, [], []
+
+    def expect(self, ok, msg):
+        if not ok:
+            self.fails.append(msg)
+
+
+def _compare_unit(rep, label, unit_h, unit_o, x, groups, precision, final_act='none', final_fp32=False, seed=0):
+    """Run one unit on the HIP path (all `groups` calls stacked) and in the emulation (call by call) on the same input; compare the stored
+    outputs element-wise, then the input / parameter gradients for one fixed upstream gradient.  Returns the emulated output (detached)."""
+    from oracle.bf16_emu import _emu_layers, emulate_bf16
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.conv import run_layers
+    lp = _LOWP[precision]
+    xg = x.cuda().requires_grad_(True)
+    xe = x.clone().requires_grad_(True)
+    with VF.precision(precision):
+        yg = run_layers(unit_h, xg, final_act=final_act, final_fp32=final_fp32, groups=groups)
+    with emulate_bf16(lp):
+        ye = torch.cat([_emu_layers(unit_o, c, final_act=final_act, final_fp32=final_fp32) for c in xe.chunk(groups, dim=0)], dim=0)
+    assert yg.dtype == ye.dtype and tuple(yg.shape) == tuple(ye.shape), (label, yg.dtype, ye.dtype, tuple(yg.shape), tuple(ye.shape))
+    a, b = yg.detach().cpu().float(), ye.detach().float()
+    diff = (a - b).abs()
+    row = {'unit': label, 'shape': tuple(ye.shape)}
+    if ye.dtype == lp:
+        n_bad = int((diff > 0).sum())
+        row['flipped'] = n_bad / a.numel()
+        row['max_flip'] = diff.max().item() / max(b.abs().max().item(), 1e-30)
+        rep.expect(n_bad <= max(3, int(_FLIP_FRACTION * a.numel())), f'{label}: {n_bad} of {a.numel()} stored values differ')
+        rep.expect(row['max_flip'] <= _MAX_FLIP[precision], f'{label}: largest difference {row["max_flip"]:.2e} of the output range')
+    else:
+        row['out_rel'] = rel_err(a, b)
+        rep.expect(row['out_rel'] <= (1e-3 if precision == 'bf16' else 2e-4), f'{label}: fp32 output {row["out_rel"]:.2e}')
+    dy = (det_uniform(tuple(ye.shape), 900 + seed) - 0.5).to(ye.dtype)
+    yg.backward(dy.cuda())
+    ye.backward(dy)
+    tol = _GRAD_TOL[precision]
+    if xe.grad is not None:
+        row['dx'] = rel_err(xg.grad.cpu().float(), xe.grad.float())
+        rep.expect(row['dx'] <= tol, f'{label}: input gradient {row["dx"]:.2e}')
+    worst = 0.0
+    pe_all = [q.grad for q in unit_o.parameters() if q.grad is not None]
+    scale_floor = 1e-3 * max([g.norm().item() for g in pe_all] or [0.0])
+    for (k, pg), (_, pe) in zip(unit_h.named_parameters(), unit_o.named_parameters()):
+        if pe.grad is None:
+            continue
+        e = ((pg.grad.cpu().float() - pe.grad.float()).norm() / max(pe.grad.float().norm().item(), scale_floor, 1e-30)).item()
+        worst = max(worst, e)
+        rep.expect(e <= tol, f'{label}: gradient of {k} {e:.2e}')
+        pg.grad = None
+        pe.grad = None
+    row['dparam'] = worst
+    # BatchNorm running statistics: `groups` sequential updates on both sides
+    for mh, mo in zip(unit_h.modules(), unit_o.modules()):
+        if isinstance(mo, nn.BatchNorm2d):
+            e = max(rel_err(mh.running_mean.cpu(), mo.running_mean), rel_err(mh.running_var.cpu(), mo.running_var))
+            row['bn_running'] = e
+            rep.expect(e <= 1e-4, f'{label}: running statistics {e:.2e}')
+    rep.rows.append(row)
+    return ye.detach()
+
+
+def _walk(rep, name, stage_h, stage_o, x, groups, precision, final_act='none', final_fp32=False, seed=0):
+    units_h, units_o = _units(stage_h), _units(stage_o)
+    assert len(units_h) == len(units_o)
+    h = x
+    for i, (uh, uo) in enumerate(zip(units_h, units_o)):
+        last = i == len(units_h) - 1
+        h = _compare_unit(rep, f'{name}.{i}:{type(uo[0]).__name__}', uh, uo, h, groups, precision,
+                          final_act=final_act if last else 'none', final_fp32=final_fp32 and last, seed=seed + i)
+    return h
+
+
+def _encoder_stages(enc):
+    if hasattr(enc, 'conv'):
+        return [('conv%d' % i, st) for i, st in enumerate(enc.conv)] + [('last_op', enc.last_op)]
+    return [(n, getattr(enc, n)) for n in ('conv1', 'conv2', 'conv3', 'conv4')]
+
+
+def _act_name(m):
+    return {'Sigmoid': 'sigmoid', 'Tanh': 'tanh', 'ReLU': 'relu', 'LeakyReLU': 'leaky_relu', 'ELU': 'elu', 'Identity': 'none'}[type(m).__name__]
+
+
+@pytest.mark.parametrize('name,precision', [('full_mnist_b128', 'bf16'), ('full_taxibj', 'bf16'), ('full_sst', 'fp16'), ('full_sst', 'bf16')])
+def test_full_size_lowp_blocks_match_emulation_elementwise(name, precision):
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    cfg = FULL_CONFIGS[name]
+    lp = _LOWP[precision]
+    o_net = fill_net(cpu_ref.build_sep_net(cfg), cfg).train()
+    h_net = build_sep_net(cfg)
+    h_net.load_state_dict(o_net.state_dict(), strict=True)
+    h_net = h_net.cuda().train()
+    cond, target = make_batch(cfg)
+    full = torch.cat([cond, target], dim=1)
+    B, nt = cfg['B'], cfg['nt_cond']
+    n = cfg['nt_pred'] + cfg['offset']
+    rep = _Report(f'{name} {precision}')
+
+    # ---- encoders: the two calls of a step stacked (first / last window), every BatchNorm with per-call statistics ------------------
+    pair = torch.cat([full[:, :nt], full[:, -nt:]], dim=0)
+    x0 = pair.reshape(2 * B, -1, pair.shape[-2], pair.shape[-1]).to(lp)
+    enc_out = {}
+    for en in ('Es', 'Et'):
+        h, outs = x0, []
+        stages_h, stages_o = _encoder_stages(getattr(h_net, en)), _encoder_stages(getattr(o_net, en))
+        for si, ((sn, sh), (_, so)) in enumerate(zip(stages_h, stages_o)):
+            h = _walk(rep, f'{en}.{sn}', sh, so, h, 2, precision, final_fp32=(si == len(stages_h) - 1), seed=10 * si)
+            outs.append(h)
+        enc_out[en] = outs
+    s_stages, t_stages = enc_out['Es'], enc_out['Et']
+    s_code, t_code = s_stages[-1][:B].float(), t_stages[-1][:B].float()
+
+    # ---- the SST integrator: whole ConvResBlocks (fused 6 + 7 launch form) on the 8 maps of one step ------------------------------
+    if cfg['architecture'] == 'encoderSST':
+        from oracle.bf16_emu import _conv_res_block_forward, emulate_bf16
+        x = t_code.reshape(B, cfg['code_size_t'], 16, 16).contiguous()
+        for bi, (bh, bo) in enumerate(zip(h_net.t_resnet.resblock_modules, o_net.t_resnet.resblock_modules)):
+            xg, xe = x.cuda().requires_grad_(True), x.clone().requires_grad_(True)
+            with VF.precision(precision):
+                yg, rg = bh(xg)
+            with emulate_bf16(lp):
+                ye, re_ = _conv_res_block_forward(bo, xe)
+            row = {'unit': f't_resnet.block{bi}', 'shape': tuple(ye.shape), 'out_rel': rel_err(yg.detach().cpu(), ye.detach()),
+                   'res_rel': rel_err(rg.detach().cpu(), re_.detach())}
+            tol3 = 6e-3 if precision == 'bf16' else 1e-3          # three chained conv + BatchNorm layers between input and output
+            rep.expect(row['out_rel'] <= tol3 and row['res_rel'] <= tol3, f'block {bi}: output {row["out_rel"]:.2e} residual {row["res_rel"]:.2e}')
+            dy = (det_uniform(tuple(ye.shape), 77 + bi) - 0.5)
+            (yg * dy.cuda()).sum().backward()
+            (ye * dy).sum().backward()
+            row['dx'] = rel_err(xg.grad.cpu(), xe.grad)
+            rep.expect(row['dx'] <= 5 * _GRAD_TOL[precision], f'block {bi}: input gradient {row["dx"]:.2e}')
+            worst = 0.0
+            for (k, pg), (_, pe) in zip(bh.named_parameters(), bo.named_parameters()):
+                if pe.grad is None or pe.grad.norm().item() == 0.0:
+                    continue
+                e = rel_err(pg.grad.cpu(), pe.grad)
+                worst = max(worst, e)
+                rep.expect(e <= 5 * _GRAD_TOL[precision], f'block {bi}: gradient of {k} {e:.2e}')
+                pg.grad = None
+                pe.grad = None
+            row['dparam'] = worst
+            rep.rows.append(row)
+            x = ye.detach()
+
+    # ---- decoder: all n frames of a rollout as one batch of n calls ------------------------------------------------------------------
+    dec_h, dec_o = h_net.decoder, o_net.decoder
+    if cfg['architecture'] == 'encoderSST':
+        z = torch.cat([s_code.reshape(B, -1, 16, 16), t_code.reshape(B, -1, 16, 16)], dim=1).repeat(n, 1, 1, 1)
+        h3, h2, h1 = (s_stages[2][:B].repeat(n, 1, 1, 1), s_stages[1][:B].repeat(n, 1, 1, 1), s_stages[0][:B].repeat(n, 1, 1, 1))
+        out = _walk(rep, 'decoder.conv1', dec_h.conv1, dec_o.conv1, z, n, precision, seed=100)
+        out = _walk(rep, 'decoder.conv2', dec_h.conv2, dec_o.conv2, torch.cat([h3, out], dim=1), n, precision, seed=110)
+        out = _walk(rep, 'decoder.conv3', dec_h.conv3, dec_o.conv3, torch.cat([h2, out], dim=1), n, precision, seed=120)
+        _walk(rep, 'decoder.conv4', dec_h.conv4, dec_o.conv4, torch.cat([h1, out], dim=1), n, precision, final_act=_act_name(dec_o.out_f),
+              final_fp32=True, seed=130)
+    else:
+        z = torch.cat([s_code, t_code], dim=1).repeat(n, 1)
+        h = _walk(rep, 'decoder.first_upconv', dec_h.first_upconv, dec_o.first_upconv, z.view(*z.shape, 1, 1), n, precision, seed=100)
+        for i, (sh, so) in enumerate(zip(dec_h.conv, dec_o.conv)):
+            last = i == len(dec_h.conv) - 1
+            h = _walk(rep, f'decoder.conv{i}', sh, so, h, n, precision, final_act=_act_name(dec_o.last_activation) if last else 'none',
+                      final_fp32=last, seed=110 + 10 * i)
+
+    keys = ('flipped', 'max_flip', 'out_rel', 'res_rel', 'dx', 'dparam', 'bn_running')
+    for row in rep.rows:
+        print(rep.tag, row['unit'], row['shape'], {k: '%.1e' % row[k] for k in keys if k in row})
+    print(rep.tag, 'worst over %d units:' % len(rep.rows), {k: '%.1e' % max(r[k] for r in rep.rows if k in r) for k in keys if any(k in r for r in rep.rows)})
+    assert not rep.fails, '\n'.join(rep.fails)

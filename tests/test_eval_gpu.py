@@ -99,3 +99,42 @@ def test_eval_forecast_matches_reference_fixture(name, precision):
             's_code': check_tensor(gold, 's_code', s[0] if isinstance(s, (tuple, list)) else s, tol),
             'swap': check_tensor(gold, 'swap_forecasts', swap, tol)}
     print(name, precision, 'eval vs reference fixture:', {k: '%.1e' % v for k, v in errs.items()})
+
+
+CKPT_NAMES = ['mlp_mul', 'dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny']
+
+
+@pytest.mark.parametrize('name', CKPT_NAMES)
+def test_reference_written_checkpoint_runs_on_the_hip_path(name):
+    """tests/golden/ckpt_<name>/*.pt were written by the REFERENCE's `save` (utils/helper.py:22-33: whole-module pickles naming
+    `var_sep.networks.*` classes; oracle/make_golden_ckpt.py).  Here -- where the reference package does not exist -- they are loaded the
+    way its evaluation scripts do (test/utils.py:8-16), straight into a SeparableNetwork of this package's classes, and must reproduce
+    the eval-mode forecasts the reference itself recorded for those weights (tests/golden/eval_<name>.npz)."""
+    import os
+    import sys
+    from golden_util import GOLDEN_DIR, check_tensor, load_golden
+    from spatiotemporal_variable_separation_amd.utils.helper import load_model, load_sep_net
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    assert not any(m == 'var_sep' or m.startswith('var_sep.') for m in sys.modules), 'the reference package must not be importable here'
+    cfg = CONFIGS[name]
+    gold = load_golden('eval_' + name)
+    ckpt = os.path.join(GOLDEN_DIR, 'ckpt_' + name)
+    cond, _ = make_batch(cfg)
+    skip = bool(cfg.get('skipco', False))
+    # (a) the reference's load_model: the module trees come out of the pickles
+    net = load_sep_net(ckpt, cfg['nt_cond'], skip).cuda()
+    assert not net.training and type(net.Et).__module__.startswith('spatiotemporal_variable_separation_amd.')
+    # (b) load_model into a freshly built (randomly initialised) network of the same architecture
+    fresh = build_sep_net(cfg)
+    load_model(ckpt, fresh)
+    fresh = fresh.cuda().eval()
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, fresh.state_dict()[k]), k
+    for model in (net, fresh):
+        with torch.no_grad():
+            fore, codes, s_code, _ = model.get_forecast(cond.cuda(), int(gold['horizon']))
+            swap = model.get_forecast(cond.cuda(), int(gold['swap_horizon']), init_s_code=model.Es(cond.flip(0).cuda(), return_skip=skip))[0]
+        check_tensor(gold, 'forecasts', fore, 1e-3)
+        check_tensor(gold, 't_codes', codes, 1e-3)
+        check_tensor(gold, 's_code', s_code[0] if isinstance(s_code, (tuple, list)) else s_code, 1e-3)
+        check_tensor(gold, 'swap_forecasts', swap, 1e-3)

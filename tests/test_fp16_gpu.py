@@ -25,12 +25,11 @@ def test_step_fp16_mlp_matches_rounding_point_emulation(name):
 
 @pytest.mark.parametrize('name', ['dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'sst_skip'])
 def test_step_fp16_conv_matches_rounding_point_emulation(name):
-    tight = name.startswith('dcgan')
-    # gradients: one stored fp16 value landing on the other side of a rounding boundary (the MFMA and the CPU convolution sum in
-    # different orders) is amplified by the per-call BatchNorm over 2-3 samples; measured 7e-2 ... 1.7e-1 on single small tensors
-    errs = compare_step_bf16_conv(CONFIGS[name], int(load_golden(name)['t_random']), tol_out=2e-3 if tight else 8e-2,
-                                  tol_grad=3e-1 if tight else float('inf'), precision='fp16')
-    print(name, 'fp16 vs emulation', {k: f'{v:.1e}' for k, v in errs.items()})
+    """fp16 mode of the conv families against the independent rounding-point emulation, with a loss scale as in training (the scale keeps
+    the 16-bit gradients out of the subnormal range; both sides divide it out again).  VGG / SST at batch 16 (see test_step_gpu.LOWP_BATCH)."""
+    from test_step_gpu import LOWP_BATCH
+    cfg = dict(CONFIGS[name], B=LOWP_BATCH.get(name, CONFIGS[name]['B']))
+    compare_step_bf16_conv(cfg, int(load_golden(name)['t_random']), tol_out=2e-3, tol_grad=5e-2, precision='fp16', loss_scale=256.0)
 
 
 def _net_and_batch(name='mlp_mul', B=8):

@@ -94,3 +94,32 @@ def test_init_net_statistics():
     assert torch.allclose(w.t() @ w, 1.41 ** 2 * torch.eye(8), atol=1e-4)
     e = get_encoder('mlp', [1, 8, 8], 4, 256, 3, 2, 'normal', 0.02)
     assert abs(e.mlp.module[1][1].weight.std().item() - 0.02) < 2e-3 and e.mlp.module[1][1].bias.abs().max() == 0
+
+
+def test_reference_written_checkpoints_load_without_the_reference_package():
+    """The four files the REFERENCE's `save` wrote (tests/golden/ckpt_*: whole-module pickles of var_sep.networks.* classes,
+    oracle/make_golden_ckpt.py) unpickle into this package's classes with `var_sep` absent, and carry the weights they were saved with."""
+    import os
+    import sys
+    import torch
+    from oracle import cpu_ref
+    from oracle.golden_configs import CONFIGS, fill_net
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.utils.helper import load_model, load_sep_net
+    assert not any(m == 'var_sep' or m.startswith('var_sep.') for m in sys.modules)
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    for name in ('mlp_mul', 'dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny'):
+        cfg = CONFIGS[name]
+        blob = open(os.path.join(root, 'ckpt_' + name, 'ov_Et.pt'), 'rb').read()
+        assert b'var_sep.networks' in blob                      # really a reference pickle
+        want = fill_net(cpu_ref.build_sep_net(cfg), cfg).state_dict()
+        net = load_model(os.path.join(root, 'ckpt_' + name), build_sep_net(cfg))
+        got = net.state_dict()
+        assert set(got) == set(want)
+        assert all(torch.equal(got[k], want[k]) for k in want), name
+        whole = load_sep_net(os.path.join(root, 'ckpt_' + name), cfg['nt_cond'], bool(cfg.get('skipco', False)))
+        assert not whole.training
+        for part in (whole.Es, whole.Et, whole.decoder, whole.t_resnet):
+            assert type(part).__module__.startswith('spatiotemporal_variable_separation_amd.networks.')
+        assert all(torch.equal(v, want[k]) for k, v in whole.state_dict().items())
+    assert not any(m == 'var_sep' or m.startswith('var_sep.') for m in sys.modules)

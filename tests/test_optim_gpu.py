@@ -292,3 +292,116 @@ def test_fused_update_in_the_recorded_step_equals_the_plain_step(name='mlp_mul')
     for k in sa:
         # Adam normalises: a near-zero gradient that differs in its last bits moves a weight by up to lr in either direction
         assert torch.allclose(sa[k], sb[k], rtol=2e-3, atol=2.5e-3), f'{k}: {(sa[k] - sb[k]).abs().max().item():.3e}'
+
+
+def test_fused_update_leaves_the_input_gradients_of_its_layer_untouched():
+    """A fused weight-gradient + Adam launch rewrites W and its 16-bit copy; the input gradient of the same layer reads that copy and must
+    see W_t, not W_{t+1} (round-2 advice: with side streams off -- the eager loop, `bench.py --no_graph`, the ragged last batch of
+    `train()` -- the update used to run first).  Every gradient that flows THROUGH a fused layer (biases below it, the integrator, the
+    encoders) must therefore equal the unfused step's bit for bit: the same kernels compute them from the same operands."""
+    from oracle import cpu_ref
+    from oracle.detdata import det_fill
+    from oracle.golden_configs import CONFIGS, make_batch
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.train import chain_weight_parameters, compute_losses
+    cfg = dict(CONFIGS['mlp_mul'], B=8)
+    lam = cfg['lambdas']
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    o_net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    grads = []
+    for fused in (True, False):
+        net = build_sep_net(cfg)
+        net.load_state_dict(o_net.state_dict())
+        net = net.cuda().train()
+        with VF.precision('bf16'):
+            opt = Adam(net.parameters(), lr=1e-2, betas=(0.9, 0.99))      # a large step: W_{t+1} is far from W_t
+            try:
+                if fused:
+                    opt.fuse_into_wgrad(chain_weight_parameters(net))
+                    assert len(opt._fused) >= 6
+                total = compute_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], False, lam['ae'], lam['s'], lam['t'],
+                                       lam['pred'], t_random=4)[0]
+                total.backward()
+                torch.cuda.synchronize()
+                grads.append({k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+                opt.step()
+            finally:
+                opt.unfuse()
+    ga, gb = grads
+    assert len(ga) < len(gb) and len(ga) > 0             # the fused weights have no stored gradient
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), f'{k}: differs by {(ga[k] - gb[k]).abs().max().item():.3e} (input gradient read an updated weight?)'
+
+
+def test_recorded_step_with_torch_adam_reads_current_weights():
+    """GraphedStep with torch.optim.Adam(capturable=True) in bf16 mode: torch's optimizer updates the fp32 masters only, so the recording
+    must contain the casts to the 16-bit operand copies -- otherwise every replay trains on the weights frozen at capture time (round-2
+    advice).  The loss sequence and the parameters must follow the eager loop with the same optimizer."""
+    import numpy as np
+    from oracle import cpu_ref
+    from oracle.detdata import det_fill
+    from oracle.golden_configs import CONFIGS, make_batch
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.train import GraphedStep, compute_losses
+    cfg = dict(CONFIGS['mlp_mul'], B=8)
+    lam = cfg['lambdas']
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    o_net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+    n_steps = 6
+    out = []
+    for graph in (True, False):
+        net = build_sep_net(cfg)
+        net.load_state_dict(o_net.state_dict())
+        net = net.cuda().train()
+        with VF.precision('bf16'):
+            opt = torch.optim.Adam(net.parameters(), lr=5e-3, betas=(0.9, 0.99), capturable=True)
+            np.random.seed(11)
+            hi = cond.shape[1] + target.shape[1] + (0 if cfg['offset'] == 0 else 1)
+            if graph:
+                g = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], (lam['ae'], lam['s'], lam['t'], lam['pred']),
+                                warmup=2)
+                losses = [g.step().item() for _ in range(n_steps)]
+            else:
+                np.random.randint(cfg['nt_cond'], hi)       # the recording itself consumes one draw of the t_random stream
+                losses = []
+                for _ in range(n_steps):
+                    opt.zero_grad(set_to_none=True)
+                    t_random = int(np.random.randint(cfg['nt_cond'], hi))
+                    total = compute_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], False, lam['ae'], lam['s'], lam['t'],
+                                           lam['pred'], t_random=t_random)[0]
+                    total.backward()
+                    opt.step()
+                    losses.append(total.item())
+        torch.cuda.synchronize()
+        out.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    (lg, sg), (le, se) = out
+    assert lg[0] != lg[-1]
+    # stale weights would leave the recorded loss sequence flat / drifting: the eager loop moves the loss by >10 % over these steps
+    assert abs(le[0] - le[-1]) > 0.05 * abs(le[0]), le
+    assert np.allclose(lg, le, rtol=5e-3), (lg, le)
+    for k in sg:
+        assert torch.allclose(sg[k], se[k], rtol=5e-3, atol=3 * 5e-3), f'{k}: {(sg[k] - se[k]).abs().max().item():.3e}'
+
+
+def test_loss_scaling_refuses_updates_issued_during_backward():
+    """fp16 loss scaling needs every gradient before any update (finite check, 1 / scale): it refuses optimizers that update from backward."""
+    from oracle.detdata import det_fill
+    from oracle.golden_configs import CONFIGS
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.train import LossScaler, enable_update_in_backward
+    cfg = CONFIGS['mlp_mul']
+    net = det_fill(build_sep_net(cfg), salt=cfg['salt']).cuda().train()
+    opt = Adam(net.parameters(), lr=1e-3)
+    scaler = LossScaler(torch.device('cuda'))
+    enable_update_in_backward(opt, net, force=True, scaler=scaler)
+    assert not opt._buckets                                 # declined
+    enable_update_in_backward(opt, net, force=True)
+    assert opt._buckets
+    with pytest.raises(ValueError):
+        scaler.step(opt)

@@ -96,3 +96,34 @@ def test_oracle_frame_metrics_match_reference_fixture():
         assert torch.allclose(o['ssim_plane'], torch.from_numpy(gold[name + ':ssim']), rtol=1e-6, atol=1e-7), name
         assert torch.allclose(o['mse_plane'], torch.from_numpy(gold[name + ':mse']), rtol=1e-6, atol=1e-9), name
         assert torch.allclose(o['psnr'], torch.from_numpy(gold[name + ':psnr']), rtol=1e-6), name
+
+
+@pytest.mark.parametrize('name', ['dcgan_skip_mul', 'vgg32_tiny', 'sst_skip'])
+def test_independent_lowp_emulation_agrees_with_the_product_host_code_on_cpu(name):
+    """oracle/bf16_emu.py holds two CPU emulations of the 16-bit modes: `emulate_bf16` interprets the ORACLE's module tree (independent of
+    the product; the checker of the GPU parity tests) and `emulate_product_bf16` runs the PRODUCT's host code (networks/*.py,
+    train.compute_losses) with its functional entry points replaced by the same rounding rules.  One training step through both must give
+    the same forward results exactly (same CPU kernels, same rounding points, same per-call structure) and the same gradients up to the one
+    stated difference: gradients of a skip tensor shared by several decoder calls are summed in fp32 and rounded once in the former, added
+    one by one in 16 bits by autograd in the latter."""
+    import torch
+    from oracle.golden_configs import CONFIGS
+    from golden_util import load_golden, rel_err
+    from step_util import emulated_bf16_step, emulated_product_step, grad_err, grad_floor
+    torch.set_num_threads(8)
+    cfg = CONFIGS[name]
+    t = int(load_golden(name)['t_random'])
+    a = emulated_bf16_step(cfg, t, 'bf16')
+    b = emulated_product_step(cfg, t, 'bf16')
+    assert rel_err(a[3].detach().float(), b[3].detach().float()) <= 1e-6 and rel_err(a[4].detach().float(), b[4].detach().float()) <= 1e-6
+    assert abs(a[1].item() - b[1].item()) <= 1e-6 * abs(b[1].item())
+    bg, floor = dict(b[0].named_parameters()), grad_floor(b[0])
+    for k, p in a[0].named_parameters():
+        if p.grad is not None:
+            assert grad_err(p.grad, bg[k].grad, floor) <= 2e-2, k
+    sa, sb = a[0].state_dict(), b[0].state_dict()
+    for k in sa:
+        if 'running' in k:
+            assert rel_err(sa[k], sb[k]) <= 1e-6, k
+        if k.endswith('num_batches_tracked'):
+            assert int(sa[k]) == int(sb[k]), k

@@ -43,26 +43,27 @@ def test_step_fp32_matches_oracle(name):
 def test_step_bf16_within_stated_bound(name):
     if not _available(name):
         pytest.skip('conv family not built yet')
-    cfg = CONFIGS[name]
+    cfg = dict(CONFIGS[name], B=LOWP_BATCH.get(name, CONFIGS[name]['B']))
     vs_emu, vs_fp32 = compare_step_bf16(cfg, int(load_golden(name)['t_random']), emulate=name in MLP_CONFIGS)
     print(name, 'vs bf16 emulation', {k: f'{v:.1e}' for k, v in vs_emu.items()}, 'vs fp32 oracle',
           {k: f'{v:.1e}' for k, v in vs_fp32.items()})
 
 
+# per-call BatchNorm over 2-3 samples amplifies ONE stored value that lands on the other side of a 16-bit rounding boundary (the MFMA and
+# the CPU convolution sum in different orders) into a 1e-2 drift of the whole step -- chaos, not arithmetic (two HIP runs with different
+# summation orders drift alike, tools/bf16_noise.py).  The deep VGG / SST stacks therefore run this comparison at batch 16, where the
+# statistics are conditioned like a real batch and every bound is finite.
+LOWP_BATCH = {'vgg32_tiny': 16, 'vgg64_skip': 16, 'sst_skip': 16, 'sst_noskip': 16}
+
+
 @pytest.mark.parametrize('name', CONV_CONFIGS)
 def test_step_bf16_conv_matches_bf16_emulation(name):
-    """bf16 mode of the conv families against the product-on-CPU emulation with the kernels' rounding points
-    (oracle/bf16_emu.py): outputs, losses, BatchNorm running statistics and gradients of one whole training step.
-    The DCGAN stacks agree to 1e-4; in the deeper VGG / SST stacks ONE stored value that lands on the other side of a bf16
-    rounding boundary (fp32 accumulation order differs between MFMA and the CPU convolution) is amplified by the per-call
-    BatchNorm over 2-3 samples to 1e-2 -- the same drift two HIP runs with different summation orders show
-    (tools/bf16_noise.py) -- so the whole-step bound is loose there and the sharp statement is the stage-wise test below."""
+    """bf16 mode of the conv families against the independent rounding-point emulation (oracle/bf16_emu.emulate_bf16: the ORACLE's module
+    tree and per-call structure with the mode's rounding points): outputs, losses, BatchNorm running statistics and every gradient
+    tensor of one whole training step, finite bounds throughout."""
     from step_util import compare_step_bf16_conv
-    cfg = CONFIGS[name]
-    tight = name.startswith('dcgan')
-    errs = compare_step_bf16_conv(cfg, int(load_golden(name)['t_random']), tol_out=2e-3 if tight else 8e-2,
-                                  tol_grad=5e-2 if tight else float('inf'))
-    print(name, {k: f'{v:.1e}' for k, v in errs.items()})
+    cfg = dict(CONFIGS[name], B=LOWP_BATCH.get(name, CONFIGS[name]['B']))
+    compare_step_bf16_conv(cfg, int(load_golden(name)['t_random']), tol_out=5e-3, tol_grad=5e-2)
 
 
 @pytest.mark.parametrize('name', CONV_CONFIGS)
