@@ -225,11 +225,15 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=N
     enable_update_in_backward(opt, net, sync, scaler=scaler)
     if precision != 'fp32':
         enable_fused_update(opt, net, sync, scaler)      # (GraphedStep does the same; here for --no_graph and the instrumented eager steps)
-    VF.fold_repeated_gradients(sync is None and os.environ.get('VARSEP_FOLD_GRADS', '1') == '1')
+    # conv families under a reducer: convolution / BatchNorm gradients accumulate straight into the bucket views, folding stays on
+    from spatiotemporal_variable_separation_amd.train import _mlp_family, conv_gradient_sinks
+    conv_sinks = conv_gradient_sinks(net, sync) if (sync is not None and not _mlp_family(net)) else None
+    VF.fold_repeated_gradients(os.environ.get('VARSEP_FOLD_GRADS', '1') == '1' and (sync is None or bool(conv_sinks)))
 
     def step():
         if sync is not None:
             sync.zero_grad()
+            VF.set_conv_grad_outputs(conv_sinks)
         else:
             opt.zero_grad(set_to_none=True)
         total, _, _, _ = compute_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'],
@@ -239,6 +243,7 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=N
             scaler.backward(total)
         else:
             total.backward()
+        VF.set_conv_grad_outputs(None)
         if sync is not None:
             sync.all_reduce()
         if scaler is not None:

@@ -63,12 +63,17 @@ class EmuChain(torch.autograd.Function):
             saved.append(h)
         ctx.save_for_backward(*saved)
         ctx.params, ctx.acts = params, acts
+        ctx.lp = _lowp()
         return saved[-1]
 
     @staticmethod
     def backward(ctx, dy):
         saved, params, acts = ctx.saved_tensors, ctx.params, ctx.acts
         L = len(params) // 2
+        lp = ctx.lp
+
+        def bf(t):                                    # the 16-bit type of THIS chain's forward pass
+            return t.to(lp).float()
         dz = bf(dy * _act_grad_from_out(saved[L], acts[L - 1]))
         grads = [None] * (2 * L)
         dx = None
@@ -178,12 +183,14 @@ class EmuConvBlock(torch.autograd.Function):
             ctx.save_for_backward(xc, y)
         ctx.cfg, ctx.w, ctx.b, ctx.gamma, ctx.beta = cfg, w, b, gamma, beta
         ctx.x_dtype, ctx.x_needs_grad = x.dtype, x.requires_grad
+        ctx.lp = _lowp()                              # backward rounds to the type of ITS forward pass, whatever context it runs in
         return y
 
     @staticmethod
     def backward(ctx, dy):
         transposed, stride, pad, has_bn, act, training, momentum, eps, out_fp32, groups = ctx.cfg
         w, b = ctx.w, ctx.b
+        lp = ctx.lp
         dgamma = dbeta = None
         dyf = dy.float()
         if has_bn:
@@ -211,16 +218,16 @@ class EmuConvBlock(torch.autograd.Function):
                 dz[sl] = d.float()
                 dgamma += sg.float()
                 dbeta += sb.float()
-            dz = dz.to(_lowp())
+            dz = dz.to(lp)
         else:
             xc, y = ctx.saved_tensors
-            dz = (dyf * _act_grad(y.float(), act)).to(_lowp()) if act not in ('none', None) else dy.to(_lowp())
+            dz = (dyf * _act_grad(y.float(), act)).to(lp) if act not in ('none', None) else dy.to(lp)
         db = None
         if b is not None and b.requires_grad:
             db = torch.zeros_like(b) if (has_bn and training) else dz.float().sum(dim=(0, 2, 3))
         with torch.enable_grad():
             xr = xc.float().requires_grad_(True)
-            wr = w.detach().to(_lowp()).float().requires_grad_(True)
+            wr = w.detach().to(lp).float().requires_grad_(True)
             zz = _conv(xr, wr, None, stride, pad, transposed)
             gx, gw = torch.autograd.grad(zz, (xr, wr), dz.float())
         dx = gx.to(ctx.x_dtype) if ctx.x_needs_grad else None

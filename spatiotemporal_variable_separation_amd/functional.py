@@ -39,14 +39,18 @@ def precision(p):
         _STATE['precision'] = old
 
 
-def fold_repeated_gradients(flag):
+def folding_repeated_gradients():
+    return bool(_STATE.get('fold_grads'))
+
+
+def fold_repeated_gradients(flag, flush=True):
     """Modules called many times per step (the integrator's convolutions: once per rollout step) produce one weight, bias, gamma
     and beta gradient PER CALL, and autograd adds each of them to `.grad` with its own 3-4 us launch (SST, 40 predicted frames:
     ~1200 such adds per step).  With this switch on, a block whose parameters already hold a gradient adds all of its
     contributions with ONE multi-tensor launch, into the tensor autograd holds as the parameter's pending gradient, and returns
     nothing to autograd for them.  Only valid without gradient hooks
     (the bucketed all-reduce counts hook calls), so `train()` / `bench.py` turn it on for single-process runs only."""
-    if not flag:
+    if not flag and flush:
         flush_bn_call_counts()
     _STATE['fold_grads'] = bool(flag)
 
@@ -299,6 +303,41 @@ def set_grad_outputs(mapping):
 
 def grad_output(prm):
     return _GRAD_OUT.get(id(prm)) if _GRAD_OUT else None
+
+
+# Convolution families under a gradient reducer.  A convolution / BatchNorm parameter receives several contributions per step (the decoder
+# runs for the auto-encoding pair and for the rollout, the SST integrator's blocks once per predicted frame), so its destination is
+# ACCUMULATED into: the reducer zeroes its flat buckets at the start of a step, every contribution -- the first one included -- is added
+# to the parameter's bucket view (weight gradients in the epilogue of their kernel, the small vectors by one multi-tensor add per
+# block, the batched weight gradients of repeatedly applied convolutions by the end-of-backward flush) and autograd is handed nothing
+# for such a parameter: no AccumulateGrad launch, no per-call adds, and the step under a reducer runs the same kernels as without one.
+_CONV_GRAD_OUT = {}
+
+
+def set_conv_grad_outputs(mapping):
+    """mapping: {conv / BatchNorm parameter: zero-initialised fp32 tensor of its shape that accumulates its gradient} or None to clear."""
+    _CONV_GRAD_OUT.clear()
+    if mapping:
+        for prm, view in mapping.items():
+            assert view.shape == prm.shape and view.dtype == torch.float32 and view.is_contiguous()
+            _CONV_GRAD_OUT[id(prm)] = (prm, view)
+
+
+def conv_grad_output(prm):
+    if not _CONV_GRAD_OUT or prm is None:
+        return None
+    ent = _CONV_GRAD_OUT.get(id(prm))
+    return ent[1] if ent is not None and ent[0] is prm else None
+
+
+def conv_parameters(net):
+    """The parameters of `net` whose gradients are produced by ConvBlock / ConvResBlockFn (Conv2d, ConvTranspose2d, BatchNorm2d)."""
+    import torch.nn as nn
+    out = []
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, nn.BatchNorm2d)):
+            out += [p for p in m.parameters(recurse=False) if p.requires_grad]
+    return out
 
 
 # A gradient destination may be a bf16 tensor (the reducer's wire image): the weight-gradient GEMM rounds once in its epilogue,
@@ -746,7 +785,8 @@ def _conv_weight_grad(w, dz, xc, stride, pad, transposed):
     # a weight that already holds a gradient from an earlier call of this pass (the integrator's blocks: one call per predicted
     # frame) gets this call's contribution ADDED in the weight-gradient GEMM's epilogue -- no temporary, no add launch
     dw = None
-    first_w = _fold_slots().get(id(w)) if _STATE.get('fold_grads') else None
+    dst = conv_grad_output(w)
+    first_w = dst if dst is not None else (_fold_slots().get(id(w)) if _STATE.get('fold_grads') else None)
     if _defer_wgrad_ok(dz, transposed, stride):
         slot = _DEFER_W['slots'].get(id(w))
         if slot is None:
@@ -777,12 +817,20 @@ def _fold_param_grads(pairs):
     gradient); later contributions of the pass are added INTO it with one multi-tensor launch per block and autograd gets nothing for
     them (otherwise: one add launch per parameter and contribution)."""
     out = [g for _, g in pairs]
-    if not _STATE.get('fold_grads'):
+    if not _STATE.get('fold_grads') and not _CONV_GRAD_OUT:
         return out
-    acc = _fold_slots()
+    acc = _fold_slots() if _STATE.get('fold_grads') else {}
     into, what = [], []
     for i, (prm, g) in enumerate(pairs):
         if g is None or prm is None:
+            continue
+        dst = conv_grad_output(prm)
+        if dst is not None:                          # a registered destination accumulates EVERY contribution; autograd gets nothing
+            into.append(dst)
+            what.append(g)
+            out[i] = None
+            continue
+        if not _STATE.get('fold_grads'):
             continue
         first = acc.get(id(prm))
         if first is None:
@@ -891,7 +939,10 @@ class ConvResBlockFn(torch.autograd.Function):
             w, b, gm, bt = prm[4 * li:4 * li + 4]
             h, z, mean, invstd = saved[4 * li:4 * li + 4]
             acc = None
-            if fold:
+            dg_dst, db_dst = conv_grad_output(gm), conv_grad_output(bt)
+            if dg_dst is not None and db_dst is not None:
+                acc = (dg_dst, db_dst)
+            elif fold:
                 fg, fb = _fold_slots().get(id(gm)), _fold_slots().get(id(bt))
                 if fg is not None and fb is not None and fg.dtype == torch.float32 and fb.dtype == torch.float32 and fg.is_contiguous() and fb.is_contiguous():
                     acc = (fg, fb)
@@ -902,7 +953,7 @@ class ConvResBlockFn(torch.autograd.Function):
             db = None
             if b is not None and b.requires_grad:
                 # exactly zero in front of a training-mode BatchNorm (see ConvBlock.backward)
-                db = None if (fold and id(b) in _fold_slots()) else torch.zeros_like(b)
+                db = None if ((fold and id(b) in _fold_slots()) or conv_grad_output(b) is not None) else torch.zeros_like(b)
             dw = _conv_weight_grad(w, dz, h, 1, 1, False) if w.requires_grad else None
             grads[4 * li:4 * li + 4] = _fold_param_grads(((w, dw), (b, db), (gm, dgamma), (bt, dbeta)))
             if li > 0 or ctx.x_needs_grad:
@@ -1046,7 +1097,7 @@ class ConvBlock(torch.autograd.Function):
             # the reference returns fp32 summation noise there, we return the exact value without a reduction pass
             if has_bn and training:
                 # exactly zero: nothing to add once the parameter has a pending gradient in this pass
-                db = None if (_STATE.get('fold_grads') and id(b) in _fold_slots()) else torch.zeros_like(b)
+                db = None if ((_STATE.get('fold_grads') and id(b) in _fold_slots()) or conv_grad_output(b) is not None) else torch.zeros_like(b)
             else:
                 db = ops.chan_sum(dz)
         dw = _conv_weight_grad(w, dz, xc, stride, pad, transposed) if w.requires_grad else None

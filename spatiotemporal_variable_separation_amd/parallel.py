@@ -42,6 +42,7 @@ class GradAllReducer:
         self.direct_lowp = False
         self._build(bucket_bytes)
         self._comm_stream = None
+        self._held = set()               # buckets that hooks must not launch (hold_params)
         self._overlap = overlap and (self.world_size > 1 or force)
         if self._overlap:
             self._install_hooks()
@@ -98,8 +99,18 @@ class GradAllReducer:
             return
         left -= 1
         self._pending[bi] = left
-        if left == 0:
+        if left == 0 and bi not in self._held:
             self._launch(bi)
+
+    def hold_params(self, params):
+        """The buckets of `params` are reduced by `all_reduce()` only, never from a gradient hook: for parameters whose gradient is
+        completed AFTER autograd has visited them -- the batched weight gradients of repeatedly applied stride-1 convolutions are
+        computed by an end-of-backward callback and added straight into the bucket (functional.set_conv_grad_outputs), while the
+        post-accumulate hooks of such parameters fire earlier (autograd calls them even when it was handed no gradient)."""
+        ids = {id(p) for p in params}
+        for bi, (_, plist) in enumerate(self.buckets):
+            if any(id(p) in ids for p in plist):
+                self._held.add(bi)
 
     def _launch(self, bi):
         flat = self.buckets[bi][0]

@@ -217,6 +217,10 @@ class GraphedStep:
         self.side_streams = side_streams and self.mlp and os.environ.get('VARSEP_GRAPH_SIDE', '1') == '1'
         check_optimizer(optimizer, for_graph=True)
         self.net, self.opt, self.sync, self.scaler = sep_net, optimizer, grad_sync, scaler
+        # conv families under a reducer: convolution / BatchNorm gradients accumulate straight into the reducer's bucket views
+        # (functional.set_conv_grad_outputs), so gradient folding and the batched weight gradients stay on and the data-parallel
+        # step runs the kernels of the single-GPU step
+        self._conv_sinks = conv_gradient_sinks(sep_net, grad_sync) if (grad_sync is not None and not self.mlp) else None
         self._one = torch.ones((), dtype=torch.float32, device=cond.device)
         if grad_sync is not None and self.mlp and getattr(grad_sync, 'lowp_views', None) and hasattr(optimizer, 'step_subset'):
             # the chains' weight gradients are produced, averaged and consumed as bf16 wire images (parallel.GradAllReducer)
@@ -284,8 +288,14 @@ class GraphedStep:
             # data parallel: losses + backward into the reducer's flat gradient buckets in one graph, the bucket
             # all-reduces issued eagerly in between (4 RCCL calls at WaveEq size; no collective inside a capture), Adam in
             # a second graph
-            with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
-                self.loss = self._fwd_bwd()
+            from . import functional as VF
+            VF.bn_counts_flushed_in_capture(True)
+            try:
+                with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
+                    self.loss = self._fwd_bwd()
+                    VF.flush_bn_call_counts()
+            finally:
+                VF.bn_counts_flushed_in_capture(False)
             self._reduce()
             if self.scaler is None and hasattr(self.opt, 'step_subset') and os.environ.get('VARSEP_ADAM_PER_BUCKET', '1') == '1':
                 # one Adam recording per all-reduce bucket: the update of bucket i runs while buckets i+1.. are still on the wire
@@ -323,11 +333,15 @@ class GraphedStep:
     def _fwd_bwd(self):
         nt_cond, nt_pred, offset, l_ae, l_s, l_t, l_pred, avg = self.args
         from . import functional as VF
+        fold_was = VF.folding_repeated_gradients()
         if self.sync is not None:
             self.sync.zero_buffers()
             if self.mlp:
                 lowp = self.sync.lowp_views if self.sync.direct_lowp else {}
                 VF.set_grad_outputs({p: lowp.get(id(p), p.grad) for p in self.sync.params})
+            elif self._conv_sinks:
+                VF.set_conv_grad_outputs(self._conv_sinks)
+                VF.fold_repeated_gradients(True, flush=False)
         else:
             self.opt.zero_grad(set_to_none=True)
         VF.enable_side_streams(self.side_streams)
@@ -347,6 +361,9 @@ class GraphedStep:
             VF.promise_loss_gradient(None)
             VF.enable_side_streams(False)
             VF.set_grad_outputs(None)
+            if self._conv_sinks:
+                VF.set_conv_grad_outputs(None)
+                VF.fold_repeated_gradients(fold_was, flush=False)
         return total.detach()
 
     def step(self, cond=None, target=None):
@@ -370,6 +387,19 @@ class GraphedStep:
             self._reduce()
             self.graph_opt.replay()
         return self.loss
+
+
+def conv_gradient_sinks(sep_net, grad_sync):
+    """{convolution / BatchNorm parameter: its view in the reducer's flat gradient buckets} for functional.set_conv_grad_outputs."""
+    import torch.nn as nn
+    from . import functional as VF
+    owned = {id(p) for p in grad_sync.params}
+    # weights whose gradient may be completed by the end-of-backward flush of the batched weight gradients (functional._DEFER_W:
+    # stride-1 Conv2d): their buckets are not reduced from gradient hooks
+    late = [m.weight for m in sep_net.modules() if isinstance(m, nn.Conv2d) and tuple(m.stride) == (1, 1) and id(m.weight) in owned]
+    if late and hasattr(grad_sync, 'hold_params'):
+        grad_sync.hold_params(late)
+    return {p: p.grad for p in VF.conv_parameters(sep_net) if id(p) in owned and p.grad is not None}
 
 
 def chain_weight_parameters(sep_net):
@@ -642,8 +672,10 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
     rank = grad_sync.rank if grad_sync is not None else 0
     world = grad_sync.world_size if grad_sync is not None else 1
     # folding repeated gradients (VF.fold_repeated_gradients) replaces ~1000 tiny add launches per SST step by one multi-tensor
-    # add per block; only valid without gradient hooks (the bucketed all-reduce counts hook calls)
-    VF.fold_repeated_gradients(os.environ.get('VARSEP_FOLD_GRADS', '1') == '1' and grad_sync is None)
+    # add per block.  Under a reducer the convolution / BatchNorm gradients of a conv family accumulate straight into its bucket views
+    # (conv_gradient_sinks): the same kernels as on one GPU; the MLP family under a reducer has one gradient per parameter anyway
+    conv_sinks = conv_gradient_sinks(sep_net, grad_sync) if (grad_sync is not None and not _mlp_family(sep_net)) else None
+    VF.fold_repeated_gradients(os.environ.get('VARSEP_FOLD_GRADS', '1') == '1' and (grad_sync is None or bool(conv_sinks)))
 
     def checkpoint(epoch_number=None, collective=True):
         # data parallel: replicas hold identical parameters; BatchNorm buffers are per replica (no SyncBN), rank 0's are the ones
@@ -710,6 +742,8 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                 try:
                     if grad_sync is not None:
                         grad_sync.zero_grad()            # gradients are views into flat all-reduce buckets
+                        if conv_sinks:
+                            VF.set_conv_grad_outputs(conv_sinks)
                     else:
                         optimizer.zero_grad()
                     total_loss, terms, _, _ = compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco,
@@ -725,6 +759,7 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                     else:
                         optimizer.step()
                 finally:
+                    VF.set_conv_grad_outputs(None)
                     if lowp_saved is not None:
                         grad_sync.direct_lowp = True
                         VF._LOWP_GRAD.update(lowp_saved)

@@ -30,7 +30,7 @@ _LOWP = {'bf16': torch.bfloat16, 'fp16': torch.float16}
 # ulp(z) * gamma * invstd, i.e. a few ulps of the largest outputs at most
 _MAX_FLIP = {'bf16': 2.0 ** -5, 'fp16': 2.0 ** -8}
 _FLIP_FRACTION = 0.01
-_GRAD_TOL = {'bf16': 2e-2, 'fp16': 4e-3}
+_GRAD_TOL = {'bf16': 5e-3, 'fp16': 3e-3}
 
 
 def _flatten(module, out):
@@ -100,7 +100,8 @@ def _compare_unit(rep, label, unit_h, unit_o, x, groups, precision, final_act='n
         rep.expect(row['out_rel'] <= (1e-3 if precision == 'bf16' else 2e-4), f'{label}: fp32 output {row["out_rel"]:.2e}')
     dy = (det_uniform(tuple(ye.shape), 900 + seed) - 0.5).to(ye.dtype)
     yg.backward(dy.cuda())
-    ye.backward(dy)
+    with emulate_bf16(lp):
+        ye.backward(dy)
     tol = _GRAD_TOL[precision]
     if xe.grad is not None:
         row['dx'] = rel_err(xg.grad.cpu().float(), xe.grad.float())
@@ -195,7 +196,8 @@ def test_full_size_lowp_blocks_match_emulation_elementwise(name, precision):
             rep.expect(row['out_rel'] <= tol3 and row['res_rel'] <= tol3, f'block {bi}: output {row["out_rel"]:.2e} residual {row["res_rel"]:.2e}')
             dy = (det_uniform(tuple(ye.shape), 77 + bi) - 0.5)
             (yg * dy.cuda()).sum().backward()
-            (ye * dy).sum().backward()
+            with emulate_bf16(lp):
+                (ye * dy).sum().backward()
             row['dx'] = rel_err(xg.grad.cpu(), xe.grad)
             rep.expect(row['dx'] <= 5 * _GRAD_TOL[precision], f'block {bi}: input gradient {row["dx"]:.2e}')
             worst = 0.0
@@ -222,7 +224,7 @@ def test_full_size_lowp_blocks_match_emulation_elementwise(name, precision):
         _walk(rep, 'decoder.conv4', dec_h.conv4, dec_o.conv4, torch.cat([h1, out], dim=1), n, precision, final_act=_act_name(dec_o.out_f),
               final_fp32=True, seed=130)
     else:
-        z = torch.cat([s_code, t_code], dim=1).repeat(n, 1)
+        z = torch.cat([s_code.reshape(B, -1), t_code.reshape(B, -1)], dim=1).repeat(n, 1)
         h = _walk(rep, 'decoder.first_upconv', dec_h.first_upconv, dec_o.first_upconv, z.view(*z.shape, 1, 1), n, precision, seed=100)
         for i, (sh, so) in enumerate(zip(dec_h.conv, dec_o.conv)):
             last = i == len(dec_h.conv) - 1
