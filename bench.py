@@ -66,6 +66,10 @@ def parse():
     p.add_argument('--config', default='waveeq')
     p.add_argument('--precision', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     p.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
+    p.add_argument('--eval', action='store_true', dest='eval_mode',
+                   help='time the inference path instead of the training step: `sep_net.eval(); get_forecast(cond, nt_cond + --horizon)` under '
+                        'no_grad, BatchNorm folded into the convolutions (what the reference\'s test/*/test.py run)')
+    p.add_argument('--horizon', type=int, default=95, help='--eval: predicted frames beyond the conditioning window (README.md:116: 95)')
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_graph', action='store_true', help='issue every kernel from Python instead of replaying a hipGraph')
     p.add_argument('--cpu_steps', type=int, default=None)
@@ -319,6 +323,43 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=N
     return out
 
 
+def run_eval(name, args, rk):
+    """Inference throughput of workload `name`: frames emitted per second by eval-mode `get_forecast` over nt_cond + horizon frames."""
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.configs import BASELINE_CONFIGS
+    from spatiotemporal_variable_separation_amd.data.synthetic import synthetic_batch
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    cfg = dict(BASELINE_CONFIGS[name])
+    if args.batch:
+        cfg['batch'] = args.batch
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    net = build_sep_net(cfg).to(rk.dev).eval()
+    cond, _ = synthetic_batch(cfg['data'], cfg['batch'], cfg['nt_cond'], cfg['nt_pred'], device=rk.dev, seed=1234 + rk.rank)
+    n = cfg['nt_cond'] + args.horizon
+    VF.set_precision(args.precision)
+    regions = []
+    with torch.no_grad():
+        for _ in range(max(1, args.warmup)):
+            out = net.get_forecast(cond, n)[0]
+        for _ in range(max(1, args.repeats)):
+            rk.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = net.get_forecast(cond, n)[0]
+            rk.barrier()
+            regions.append(rk.max_over_ranks(time.perf_counter() - t0))
+    ms = statistics.median(regions) / args.steps * 1e3
+    frames = rk.world * cfg['batch'] * n
+    return {'metric': 'inference frames/sec (eval-mode get_forecast, frames emitted)', 'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s',
+            'n_gpus': rk.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic', 'ms_per_step_all': [round(r / args.steps * 1e3, 4) for r in regions],
+            'config': {'workload': workload_text(name, cfg) + ', horizon %d (frames per call: %d)' % (args.horizon, n), 'global_batch': rk.world * cfg['batch'],
+                       'parallelism': f'dp{rk.world} (independent replicas: inference has no exchange step)',
+                       'mode': 'sep_net.eval(), torch.no_grad(), BatchNorm folded into the convolution weights, eager launches',
+                       'output_checksum': round(float(out.float().mean().item()), 6)}}
+
+
 def _latest_profile(workload, precision, kind):
     """Newest committed profiles/r<NN>_<workload>_<precision>_<kind>.json (static evidence collected by tools/collect_profiles.sh)."""
     import glob
@@ -415,6 +456,12 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
     rk = Ranks(args)
+    if args.eval_mode:
+        line = run_eval(args.config, args, rk)
+        if rk.rank == 0:
+            os.write(result_fd, (json.dumps(line) + '\n').encode())
+        rk.close()
+        return
     res = run_workload(args.config, args, rk, args.steps, args.warmup, args.repeats, batch=args.batch)
 
     # further workloads under "configs".  Every rank runs them (they contain the same barriers / all-reduces); rank 0 reports.

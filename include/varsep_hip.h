@@ -200,6 +200,25 @@ int vs_conv3_wgrad_band_pieces(int compute, int npieces, const void* const* x, c
 int vs_conv3_wgrad_band_finish(const float* slabs, int nslabs, const float* addend, float* out, int Cout, int Cin, void* stream);
 int vs_slab_sum_grouped(const float* slabs, int nslabs, int groups, float* partial, int64_t total, void* stream);   /* first pass over many slabs */
 int vs_conv3_wgrad_band_supported(int compute, int B, int Cin, int H, int W, int Cout);
+
+/* ---- 4x4 stride-2 pad-1 convolutions without a column matrix (csrc/vs_conv_k4s2.hip).  Replaces, for the DCGAN stride-2 layers, the
+ * nn.Conv2d(c, 2c, 4, 2, 1) forward / weight gradient of reference networks/conv.py:119-122 and the input / weight gradient of
+ * nn.ConvTranspose2d(2c, c, 4, 2, 1) of conv.py:260-263.  A stride-2 tap never mixes the parities of the input grid, so on the four
+ * parity planes of the input ("space to depth": planes [B][4 C][H/2][W/2], channel = (row parity * 2 + column parity) * C + c) the 4x4
+ * window is a 3x3 stride-1 pad-1 window over 4 C channels with 2x2 non-zero taps per plane, and the row-band kernels above
+ * (vs_conv3_band, vs_conv3_wgrad_band) carry it.
+ *   vs_space_to_depth2          x [B][C][H][W] (16-bit, H even, W a multiple of 16) -> planes
+ *   vs_conv_k4s2_pack_weight    fp32 w [M][K][4][4] -> the vs_conv3_band pre-pack over 4 K plane channels (vs_conv_k4s2_packed_elems elements):
+ *                               Conv2d weight [Cout][Cin][4][4] for its forward; ConvTranspose2d weight [Cin][Cout][4][4] (M = Cin, K = Cout)
+ *                               for its input gradient -- the same index order, no flip
+ *   vs_conv_k4s2_wgrad_finish   slabs [nslabs][9][M][4 K] of vs_conv3_wgrad_band(x = planes of the LARGE map, dz = the SMALL map with M
+ *                               channels) -> dW [M][K][4][4] (+ addend): Conv2d: M = Cout, K = Cin, large = input, small = dz;
+ *                               ConvTranspose2d: M = Cin, K = Cout, large = the output gradient, small = the input                      */
+int vs_space_to_depth2_supported(int compute, int B, int C, int H, int W);
+int vs_space_to_depth2(int compute, const void* x, void* planes, int B, int C, int H, int W, void* stream);
+size_t vs_conv_k4s2_packed_elems(int K, int M);
+int vs_conv_k4s2_pack_weight(int compute, const float* w, int K, int M, void* dst, void* stream);
+int vs_conv_k4s2_wgrad_finish(const float* slabs, int nslabs, const float* addend, float* out, int M, int K, void* stream);
 int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout);
 int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int W, int Cout, void* stream);
 int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,

@@ -66,6 +66,41 @@ def run(name, cfg, mods):
     print(f'eval_{name:22s} forecasts {tuple(r_fore.shape)}  oracle_vs_ref relmax={worst:.1e}  -> {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+# long-term prediction as in the paper's Moving-MNIST evaluation (README.md:116: `--nt_pred 95`; test/mnist/test.py:101,120:
+# get_forecast(x_cond, nt_cond + 95)).  The integrator's weights are scaled by 0.3 (golden_configs.fill_net, `res_scale`): with det_fill's
+# gain the latent code would double at every block and overflow long before frame 95.
+LONG_PRED = 95
+LONG_CONFIGS = ['mlp_mul', 'dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'sst_skip']
+
+
+def long_cfg(name):
+    return dict(CONFIGS[name], res_scale=0.3)
+
+
+def run_long(name, mods):
+    rf, rm, ru, rt = mods
+    cfg = long_cfg(name)
+    cond, _ = make_batch(cfg)
+    horizon = cfg['nt_cond'] + LONG_PRED
+    ref = fill_net(build_reference(cfg, rf, rm, ru), cfg).eval()
+    orc = fill_net(cpu_ref.build_sep_net(dict(cfg)), cfg).eval()
+    with torch.no_grad():
+        r_fore, r_codes, r_s, _ = ref.get_forecast(cond, horizon)
+        o_fore, o_codes, o_s, _ = orc.get_forecast(cond, horizon)
+    assert torch.isfinite(r_fore).all() and torch.isfinite(r_codes).all(), name
+    worst = max(((a - b).abs().max() / (b.abs().max() + 1e-30)).item() for a, b in ((o_fore, r_fore), (o_codes, r_codes)))
+    assert worst < 1e-6, (name, worst)
+    out = {'horizon': np.int64(horizon), 'nt_pred': np.int64(LONG_PRED)}
+    pack(out, 'forecasts', r_fore)
+    pack(out, 't_codes', r_codes)
+    pack(out, 'last_frame', r_fore[:, -1])                             # the frame 95 steps after the conditioning window, in full where small
+    pack(out, 'last_code', r_codes[:, -1])
+    path = os.path.join(ROOT, 'tests', 'golden', 'eval_long_' + name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'eval_long_{name:17s} forecasts {tuple(r_fore.shape)}  |code| first / last {r_codes[:, 0].norm():.3g} / {r_codes[:, -1].norm():.3g}  '
+          f'oracle_vs_ref relmax={worst:.1e}  -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def main():
     torch.set_num_threads(8)
     mods = _reference_modules()
@@ -73,6 +108,9 @@ def main():
     for name in EVAL_CONFIGS:
         if name in CONFIGS and (not only or name in only):
             run(name, CONFIGS[name], mods)
+    for name in LONG_CONFIGS:
+        if not only or name in only or 'long' in only:
+            run_long(name, mods)
 
 
 if __name__ == '__main__':

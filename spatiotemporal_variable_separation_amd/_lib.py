@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvarsep_hip.so')
-SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip', 'vs_conv_tap.hip', 'vs_metrics.hip', 'vs_conv_img.hip']
+SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip', 'vs_conv_tap.hip', 'vs_metrics.hip', 'vs_conv_img.hip', 'vs_conv_k4s2.hip']
 
 F32, BF16, F16 = 0, 1, 2
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
@@ -141,6 +141,11 @@ SIGNATURES = {
     'vs_conv3_img16_packed_elems': (_sz, [_i32, _i32]),
     'vs_conv3_img16_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     'vs_conv3_img16': (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'vs_space_to_depth2_supported': (_i32, [_i32] * 5),
+    'vs_space_to_depth2': (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'vs_conv_k4s2_packed_elems': (_sz, [_i32, _i32]),
+    'vs_conv_k4s2_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _vp, _vp]),
+    'vs_conv_k4s2_wgrad_finish': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     'vs_conv3_band_supported': (_i32, [_i32] * 6),
     'vs_conv3_band': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vs_conv3_wgrad_band_supported': (_i32, [_i32] * 6),

@@ -210,7 +210,7 @@ def _record_on(ws, inputs, outs):
             t.record_stream(ws)
 
 
-def run_deferred(fn, *inputs, outs=None, lane=0):
+def run_deferred(fn, *inputs, outs=None, lane=0, late=False):
     """Run `fn()` (weight-gradient launches) on a gradient stream behind everything queued so far on the current stream.
     `outs`: the tensors `fn` writes, allocated by the caller -- required for the work to be holdable (hold_deferred); they are
     returned in place of fn's result."""
@@ -218,7 +218,7 @@ def run_deferred(fn, *inputs, outs=None, lane=0):
         out = fn()
         return out if outs is None else outs
     if _SIDE['hold'] and outs is not None:
-        _SIDE['held'].append((fn, inputs, outs, lane))
+        _SIDE['held'].append((fn, inputs, outs, ('late', lane) if late else lane))
         return outs
     main, ws = torch.cuda.current_stream(), _lane_stream(lane)
     ws.wait_stream(main)
@@ -253,7 +253,7 @@ def defer_call(fn):
     return True
 
 
-def release_deferred(after=None):
+def release_deferred(after=None, late_after=None):
     """Launch everything collected since hold_deferred() on the gradient streams, in order, behind the work queued so far on the
     stream the hold was declared on (the producer of every input of the held closures) and behind the event `after`."""
     held, _SIDE['held'] = _SIDE['held'], []
@@ -263,13 +263,24 @@ def release_deferred(after=None):
     main = _SIDE['hold_main'] if (was and _SIDE['hold_main'] is not None) else torch.cuda.current_stream()
     started = set()
     for fn, inputs, outs, lane in held:
+        if isinstance(lane, tuple):            # ('late', lane): behind the event `late_after` (recorded after the integrator's kernel), own stream
+            ws = _lane_stream(N_LANES)
+            if 'late' not in started:
+                ws.wait_stream(main)
+                if late_after is not None:
+                    ws.wait_event(late_after)
+                started.add('late')
+            with torch.cuda.stream(ws):
+                fn()
+            _record_on(ws, inputs, outs)
+            continue
         if lane is None:                       # consumes everything released so far: lane 0 behind the other lanes
             ws = _lane_stream(0)
             if 0 not in started:
                 ws.wait_stream(main)
                 started.add(0)
             for l in started:
-                if l != 0:
+                if l != 0 and l != 'late':
                     ws.wait_stream(_lane_stream(l))
         else:
             ws = _lane_stream(lane)
@@ -455,7 +466,7 @@ def invalidate_shadows(params):
         ent = _shadow.get(id(p))
         if ent is not None and ent[2] is p:
             _shadow[id(p)] = (-1, ent[1], p)
-        for cache in (_packed, _packed_conv, _packed_tap, _packed_k3, _packed_img):
+        for cache in (_packed, _packed_conv, _packed_tap, _packed_k3, _packed_img, _packed_k4s2):
             for key, e in list(cache.items()):
                 if e[2] is p:
                     cache[key] = (-1, e[1], p)
@@ -572,7 +583,7 @@ class MLPChain(torch.autograd.Function):
                         dx = ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=torch.float32)
                     # the weight-gradient GEMM's epilogue IS this weight's optimizer step; nothing is stored, autograd gets nothing
                     run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, W=W, fused=fused: fused.fused_update(W, dz, S, h_in, S, N, K, M),
-                                 dz, h_in, outs=(), lane=lane)
+                                 dz, h_in, outs=(), lane=lane, late=(l == 0 and os.environ.get('VARSEP_FUSED_AFTER_ROLLOUT') == '1'))
                 elif dst is not None:           # straight into the all-reduce bucket; autograd gets nothing for this parameter
                     # (holdable like the single-GPU path: the destination exists already)
                     run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, dst=dst: ops.gemm(dz, S, h_in, S, N, K, M, out=dst), dz, h_in,
@@ -689,7 +700,11 @@ class MLPRollout(torch.autograd.Function):
             ready = torch.cuda.Event()
             ready.record()
         dx0, dr, dh2, dh1 = ops.mlp_rollout_bwd(g_codes, wts, h1, h2, m1, m2, n_steps)
-        release_deferred(after=ready)
+        done = None
+        if ready is not None and os.environ.get('VARSEP_FUSED_AFTER_ROLLOUT') == '1':
+            done = torch.cuda.Event()
+            done.record()
+        release_deferred(after=ready, late_after=done)
         B, C = dx0.shape
         H = h1.shape[-1]
         rows = (n_steps - 1) * B
@@ -779,14 +794,35 @@ def packed_k3_weight(p, dtype, flip):
     return ent[1]
 
 
-def _conv_weight_grad(w, dz, xc, stride, pad, transposed):
+_packed_k4s2 = {}
+
+
+def packed_k4s2_weight(p, dtype):
+    """Row-band pre-pack of a k4 s2 p1 weight over the parity planes of its gather operand (ops.conv_k4s2_pack_weight): a Conv2d weight
+    [Cout, Cin, 4, 4] for its forward, a ConvTranspose2d weight [Cin, Cout, 4, 4] for its input gradient; cached per parameter version."""
+    key = (id(p), dtype)
+    ent = _packed_k4s2.get(key)
+    if ent is None or ent[0] != p._version or ent[2] is not p:
+        buf = ent[1] if ent is not None and ent[2] is p else None
+        buf = ops.conv_k4s2_pack_weight(p.detach().contiguous(), dtype, out=buf)
+        _packed_k4s2[key] = (p._version, buf, p)
+        return buf
+    return ent[1]
+
+
+def _conv_weight_grad(w, dz, xc, stride, pad, transposed, k4s2=None):
     """Weight gradient of one convolution call for autograd, or None when it was added to / will be batched into the tensor autograd
-    already holds."""
+    already holds.  `k4s2` = (small map, parity planes of the large map): the k4 s2 p1 family on the row-band kernels (ops.conv_k4s2_wgrad)."""
     # a weight that already holds a gradient from an earlier call of this pass (the integrator's blocks: one call per predicted
     # frame) gets this call's contribution ADDED in the weight-gradient GEMM's epilogue -- no temporary, no add launch
     dw = None
     dst = conv_grad_output(w)
     first_w = dst if dst is not None else (_fold_slots().get(id(w)) if _STATE.get('fold_grads') else None)
+    if k4s2 is not None:
+        if first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
+            ops.conv_k4s2_wgrad(k4s2[0], k4s2[1], w.shape, into=first_w)
+            return None
+        return ops.conv_k4s2_wgrad(k4s2[0], k4s2[1], w.shape)
     if _defer_wgrad_ok(dz, transposed, stride):
         slot = _DEFER_W['slots'].get(id(w))
         if slot is None:
@@ -964,6 +1000,42 @@ class ConvResBlockFn(torch.autograd.Function):
         return (dx, None) + tuple(grads) + (None,)
 
 
+# ---- inference: BatchNorm folded into the convolution ---------------------------------------------------------------------------------
+# In `.eval()` a BatchNorm2d normalises with its RUNNING statistics, i.e. it is a fixed per-channel affine map of the convolution's
+# output: act(gamma (conv(x) + b - mean) / sqrt(var + eps) + beta) = act(conv'(x) + b') with W' = W s, b' = (b - mean) s + beta,
+# s = gamma / sqrt(var + eps).  The folded block is ONE kernel (the activation sits in the convolution's epilogue or in the pass that
+# follows it) instead of convolution + BatchNorm pass; SURVEY section 8f rank 1.  Only without autograd (`torch.no_grad()`: the way the
+# reference's evaluation scripts run, test/mnist/test.py:99) -- with gradients enabled the unfolded block is kept so that d gamma / d beta
+# exist.  In the 16-bit modes the rounding points move with it: the folded weight is rounded once (instead of the weight), the convolution
+# output is not stored before the affine map.
+_folded = {}
+
+
+def folded_conv_bn(conv, bn):
+    """(W', b') fp32 tensors of the eval-mode conv -> BatchNorm pair, cached until any of the six tensors involved changes.  The tensors
+    keep their identity across refreshes (in-place update), so the operand copies / weight pre-packs keyed on them refresh themselves."""
+    srcs = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = id(conv.weight)
+    vers = tuple(-1 if t is None else t._version for t in srcs) + tuple(0 if t is None else t.data_ptr() for t in srcs)
+    ent = _folded.get(key)
+    if ent is not None and ent[0] == vers and ent[3] is conv.weight:
+        return ent[1], ent[2]
+    with torch.no_grad():
+        s = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        shape = (1, -1, 1, 1) if isinstance(conv, torch.nn.ConvTranspose2d) else (-1, 1, 1, 1)
+        wf = conv.weight.detach().float() * s.view(shape)
+        b0 = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(s)
+        bf = (b0 - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+        if ent is not None and ent[3] is conv.weight and ent[1].shape == wf.shape:
+            ent[1].copy_(wf)
+            ent[2].copy_(bf)
+            wf, bf = ent[1], ent[2]
+        else:
+            wf, bf = wf.contiguous(), bf.contiguous()
+    _folded[key] = (vers, wf, bf, conv.weight)
+    return wf, bf
+
+
 def band_ok(x, w, transposed, stride, pad, dgrad=False):
     """Conv2d k3 s1 p1 of `x` with weight `w` ([Cout, Cin, 3, 3]) -- or, dgrad=True, its input gradient from x = dz -- on the row-band kernel."""
     return (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
@@ -988,15 +1060,39 @@ class ConvBlock(torch.autograd.Function):
         bias = b.detach() if b is not None else None
         # ConvTranspose2d k4 s2 p1 on 4x4 / 8x8 / 16x16 maps (the DCGAN decoder's middle layers): LDS-staged tap GEMM with the
         # col2im and the BatchNorm sums in its epilogue -- no column matrix, no separate statistics pass
-        tap = (transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4 and has_bn
-               and ops.convt_tap_supported(xc, w.shape[1], groups))
+        tap_geom = (transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4
+                    and ops.convt_tap_supported(xc, w.shape[1], groups))
+        tap = tap_geom and has_bn
         k3 = (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
               and ops.conv_k3_tap_supported(xc, w.shape[0], groups))
         # Conv2d k3 s1 p1 on a few 16x16 maps (the SST ConvResnet integrator, resnet.py:53-88): one chip-filling launch that leaves
         # split partial sums; the slab sum, the bias and the whole BatchNorm forward are the next (single) launch
         img = (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3 and groups == 1
                and ops.conv3_img16_supported(xc, w.shape[0]))
-        if img:
+        # Conv2d k4 s2 p1 (the DCGAN encoder's stride-2 layers): on the four parity planes of the input the 4x4 stride-2 window is a 3x3
+        # stride-1 window, so the row-band kernel carries it -- no column matrix; the planes are what the weight gradient needs, too
+        k4 = (not transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4 and ops.conv_k4s2_supported(xc, w.shape[0]))
+        ctx.k4_planes = False
+        if k4:
+            planes = ops.space_to_depth2(xc)
+            wpk = packed_k4s2_weight(w, cdt)
+            ctx.k4_planes = True
+            if has_bn:
+                z = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], cdt)
+                if training:
+                    mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
+                else:
+                    mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
+                    invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
+                y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
+                ctx.save_for_backward(planes, z, mean, invstd)
+            else:
+                y = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], out_dt)
+                if act not in ('none', None):
+                    ops.act_fwd(y, act, out=y)
+                ctx.save_for_backward(planes, y)
+            ctx.x_shape = tuple(xc.shape)
+        elif img:
             slabs = ops.conv3_img16(xc, packed_img_weight(w, cdt, False), w.shape[0])
             if has_bn:
                 if training and ops.bn_small_supported_shape(cdt, xc.shape[0], w.shape[0], 256):
@@ -1067,6 +1163,9 @@ class ConvBlock(torch.autograd.Function):
         else:
             if k3:
                 y, _ = ops.conv_k3_tap_fwd(xc, packed_k3_weight(w, cdt, False), bias, w.shape[0], out_dt, groups=1)
+            elif tap_geom and out_dt == cdt:
+                # (inference with the BatchNorm folded into the weight: the tap kernel without its statistics epilogue)
+                y, _ = ops.convt_tap_fwd(xc, packed_tap_weight(w, cdt), bias, w.shape[1], groups=groups, want_sums=False)
             else:
                 wc = shadow(w, cdt)
                 wp = packed_conv_weight(w, cdt, stride, pad) if transposed else None
@@ -1077,6 +1176,8 @@ class ConvBlock(torch.autograd.Function):
         ctx.cfg, ctx.cdt = cfg, cdt
         ctx.w, ctx.b, ctx.gamma, ctx.beta = w, b, gamma, beta
         ctx.x_dtype, ctx.x_needs_grad = x.dtype, x.requires_grad
+        if not ctx.k4_planes:
+            ctx.x_shape = tuple(xc.shape)
         return y
 
     @staticmethod
@@ -1100,13 +1201,27 @@ class ConvBlock(torch.autograd.Function):
                 db = None if ((_STATE.get('fold_grads') and id(b) in _fold_slots()) or conv_grad_output(b) is not None) else torch.zeros_like(b)
             else:
                 db = ops.chan_sum(dz)
-        dw = _conv_weight_grad(w, dz, xc, stride, pad, transposed) if w.requires_grad else None
+        x_shape = ctx.x_shape
+        dz_planes = None
+        if ctx.k4_planes:
+            # forward kept the parity planes of the input: they are the large operand of the weight gradient
+            dw = _conv_weight_grad(w, dz, None, stride, pad, transposed, k4s2=(dz, xc)) if w.requires_grad else None
+        elif (transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4 and dz.dtype == xc.dtype
+              and ops.conv_k4s2_supported(dz, w.shape[0])):
+            # ConvTranspose2d k4 s2 p1 (the DCGAN decoder): the parity planes of the output gradient serve the weight gradient (small map
+            # = the layer input) AND the input gradient (a k4 s2 p1 gather of dz with the weight read as [out = Cin][in = Cout])
+            dz_planes = ops.space_to_depth2(dz)
+            dw = _conv_weight_grad(w, dz, xc, stride, pad, transposed, k4s2=(xc, dz_planes)) if w.requires_grad else None
+        else:
+            dw = _conv_weight_grad(w, dz, xc, stride, pad, transposed) if w.requires_grad else None
         dx = None
-        if ctx.x_needs_grad:
+        if ctx.x_needs_grad and dz_planes is not None:
+            dx = ops.conv_k4s2_gather(dz_planes, packed_k4s2_weight(w, cdt), None, w.shape[0], ctx.x_dtype, role='dgrad')
+        elif ctx.x_needs_grad:
             # the input gradient of Conv2d k4 s2 p1 IS a ConvTranspose2d k4 s2 p1 of dz with the same weight tensor ([Cout, Cin, 4, 4]
             # read as [in, out, 4, 4]): on 4x4 / 8x8 / 16x16 gradient maps it takes the LDS-staged tap kernel (no column matrix)
             if (not transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4 and ctx.x_dtype == dz.dtype
-                    and xc.shape[2] == 2 * dz.shape[2] and xc.shape[3] == 2 * dz.shape[3] and ops.convt_tap_supported(dz, w.shape[1], 1)):
+                    and x_shape[2] == 2 * dz.shape[2] and x_shape[3] == 2 * dz.shape[3] and ops.convt_tap_supported(dz, w.shape[1], 1)):
                 dx, _ = ops.convt_tap_fwd(dz, packed_tap_weight(w, cdt), None, w.shape[1], groups=1, want_sums=False, role='dgrad')
             elif (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3 and groups == 1
                   and ops.conv3_img16_supported(dz, w.shape[1])):
@@ -1120,7 +1235,7 @@ class ConvBlock(torch.autograd.Function):
                 dx, _ = ops.conv_k3_tap_fwd(dz, packed_k3_weight(w, cdt, True), None, w.shape[1], ctx.x_dtype, groups=1, role='dgrad')
             else:
                 wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
-                dx = ops.conv_dgrad(dz, shadow(w, cdt), xc.shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
+                dx = ops.conv_dgrad(dz, shadow(w, cdt), x_shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
                                     cols_from_wgrad=transposed and bool(w.requires_grad))
         dw, db, dgamma, dbeta = _fold_param_grads(((w, dw), (b, db), (ctx.gamma, dgamma), (ctx.beta, dbeta)))
         return dx, dw, db, dgamma, dbeta, None, None, None

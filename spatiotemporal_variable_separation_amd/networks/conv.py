@@ -4,6 +4,8 @@ The module trees are the reference's (so `state_dict` keys match and `init_net`'
 the containers are only parameter holders: `run_layers` walks them and issues one fused HIP block per
 conv -> [BatchNorm2d] -> [activation] group, plus pool / upsample / flatten+linear ops.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -73,12 +75,20 @@ def run_layers(module, h, final_act='none', final_fp32=False, groups=1):
             training = bn.training if bn is not None else False
             if bn is not None and training:
                 VF.count_bn_calls(bn, groups)          # += groups: one per call, like nn.BatchNorm2d
-            cfg = (isinstance(m, nn.ConvTranspose2d), m.stride[0], m.padding[0], bn is not None, act_name, training,
-                   bn.momentum if bn is not None else 0.1, bn.eps if bn is not None else 1e-5,
-                   bool(final_fp32 and last and extra is None), groups)
-            h = VF.ConvBlock.apply(h, m.weight, m.bias, bn.weight if bn is not None else None,
-                                   bn.bias if bn is not None else None, bn.running_mean if bn is not None else None,
-                                   bn.running_var if bn is not None else None, cfg)
+            if (bn is not None and not training and not torch.is_grad_enabled() and bn.track_running_stats and bn.affine
+                    and os.environ.get('VARSEP_FOLD_BN_EVAL', '1') == '1'):
+                # inference: the BatchNorm is a fixed affine map of the convolution's output -> folded into weight and bias, one kernel
+                wf, bf = VF.folded_conv_bn(m, bn)
+                cfg = (isinstance(m, nn.ConvTranspose2d), m.stride[0], m.padding[0], False, act_name, False, 0.1, 1e-5,
+                       bool(final_fp32 and last and extra is None), groups)
+                h = VF.ConvBlock.apply(h, wf, bf, None, None, None, None, cfg)
+            else:
+                cfg = (isinstance(m, nn.ConvTranspose2d), m.stride[0], m.padding[0], bn is not None, act_name, training,
+                       bn.momentum if bn is not None else 0.1, bn.eps if bn is not None else 1e-5,
+                       bool(final_fp32 and last and extra is None), groups)
+                h = VF.ConvBlock.apply(h, m.weight, m.bias, bn.weight if bn is not None else None,
+                                       bn.bias if bn is not None else None, bn.running_mean if bn is not None else None,
+                                       bn.running_var if bn is not None else None, cfg)
             if extra is not None:
                 h = VF.Activation.apply(h.float() if final_fp32 else h, extra)
         elif isinstance(m, nn.MaxPool2d):

@@ -585,6 +585,90 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
     return dw
 
 
+# ---- 4x4 stride-2 pad-1 convolutions on the parity planes of their input (csrc/vs_conv_k4s2.hip) --------------------------------
+def conv_k4s2_supported(big, M):
+    """Whether the gather-type operations of a k4 s2 p1 (transposed) convolution on the LARGE map `big` [B, C, H, W] -- Conv2d forward /
+    weight gradient (big = the input, M = Cout), ConvTranspose2d input / weight gradient (big = the output gradient, M = Cin) -- run on
+    the parity planes of `big` with the row-band kernels (no column matrix).  VS_CONV_K4S2=0: never."""
+    import os
+    if os.environ.get('VS_CONV_K4S2') == '0' or big.dtype == torch.float32 or big.dim() != 4:
+        return False
+    B, C, H, W = big.shape
+    lib = _lib.load_library()
+    code = dtype_code(big)
+    if not lib.vs_space_to_depth2_supported(code, B, C, H, W):
+        return False
+    return bool(lib.vs_conv3_band_supported(code, B, 4 * C, H // 2, W // 2, M)) and bool(lib.vs_conv3_wgrad_band_supported(code, B, 4 * C, H // 2, W // 2, M))
+
+
+def space_to_depth2(x):
+    """x [B, C, H, W] (16-bit) -> its four parity planes [B, 4 C, H/2, W/2], channel = (row parity * 2 + column parity) * C + c."""
+    require_cuda(x)
+    assert x.is_contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, 4 * C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_space_to_depth2(dtype_code(x), x.data_ptr(), y.data_ptr(), B, C, H, W, stream_ptr()), 'vs_space_to_depth2')
+    _pe(e0, 'vs_space_to_depth2', nbytes=float(2 * x.numel() * x.element_size()))
+    return y
+
+
+def conv_k4s2_pack_weight(w_master, dtype, out=None):
+    """fp32 [M, K, 4, 4] -> the row-band kernels' pre-pack over the 4 K plane channels (vs_conv_k4s2_pack_weight)."""
+    require_cuda(w_master)
+    assert w_master.dtype == torch.float32 and w_master.is_contiguous() and tuple(w_master.shape[2:]) == (4, 4)
+    M, K = w_master.shape[0], w_master.shape[1]
+    lib = _lib.load_library()
+    if out is None:
+        out = torch.empty((lib.vs_conv_k4s2_packed_elems(K, M),), dtype=dtype, device=w_master.device)
+    check(lib.vs_conv_k4s2_pack_weight(code_of(dtype), w_master.data_ptr(), K, M, out.data_ptr(), stream_ptr()), 'vs_conv_k4s2_pack_weight')
+    return out
+
+
+def conv_k4s2_gather(planes, w_packed, bias, M, out_dtype, role='fwd'):
+    """out [B, M, h, w] = k4 s2 p1 gather of the large map whose parity planes are `planes` [B, 4 K, h, w] with the packed weight
+    (Conv2d forward: role 'fwd'; ConvTranspose2d input gradient: role 'dgrad')."""
+    require_cuda(planes, w_packed, bias)
+    assert planes.is_contiguous() and planes.dtype == w_packed.dtype
+    B, C4, H, W = planes.shape
+    y = torch.empty((B, M, H, W), dtype=out_dtype, device=planes.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_conv3_band(dtype_code(planes), planes.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, C4, H, W,
+                                            M, stream_ptr()), 'vs_conv3_band (k4 s2 planes)')
+    # algorithmic work of the 4x4 window: 16 taps x K channels (the zero taps of the 3x3 form are not counted)
+    _pe(e0, 'vs_conv_k4s2:%s<%s>' % (role, _DT[dtype_code(planes)]), flops=2.0 * B * H * W * M * (C4 // 4) * 16,
+        nbytes=float(planes.numel() * planes.element_size() + M * (C4 // 4) * 16 * 2 + y.numel() * y.element_size()))
+    return y
+
+
+def conv_k4s2_wgrad(small, planes, w_shape, into=None, out=None):
+    """dW [M, K, 4, 4] (fp32) of a k4 s2 p1 (transposed) convolution from the SMALL map `small` [B, M, h, w] and the parity planes of the
+    large one [B, 4 K, h, w]; `into`: ADDED to this pending gradient, `out`: written there."""
+    require_cuda(small, planes)
+    assert small.is_contiguous() and planes.is_contiguous() and small.dtype == planes.dtype
+    B, M, H, W = small.shape
+    K = planes.shape[1] // 4
+    assert tuple(w_shape) == (M, K, 4, 4), (tuple(w_shape), M, K)
+    lib = _lib.load_library()
+    dw = into if into is not None else (out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=small.device))
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and tuple(dw.shape) == tuple(w_shape)
+    nslabs = lib.vs_conv3_wgrad_band_slabs(B, 4 * K, H, W, M)
+    n3 = M * 4 * K * 9
+    slabs = torch.empty((nslabs, n3), dtype=torch.float32, device=small.device)
+    e0 = _pb()
+    check(lib.vs_conv3_wgrad_band(dtype_code(planes), planes.data_ptr(), small.data_ptr(), slabs.data_ptr(), B, 4 * K, H, W, M, stream_ptr()),
+          'vs_conv3_wgrad_band (k4 s2 planes)')
+    src, n = slabs, nslabs
+    if nslabs > 24:
+        src = torch.empty((16, n3), dtype=torch.float32, device=small.device)
+        check(lib.vs_slab_sum_grouped(slabs.data_ptr(), nslabs, 16, src.data_ptr(), n3, stream_ptr()), 'vs_slab_sum_grouped')
+        n = -(-nslabs // (-(-nslabs // 16)))
+    check(lib.vs_conv_k4s2_wgrad_finish(src.data_ptr(), n, _ptr(into), dw.data_ptr(), M, K, stream_ptr()), 'vs_conv_k4s2_wgrad_finish')
+    _pe(e0, 'vs_conv_k4s2:wgrad<%s>' % _DT[dtype_code(planes)], flops=2.0 * B * H * W * M * K * 16,
+        nbytes=float(small.numel() * small.element_size() + planes.numel() * planes.element_size() + slabs.numel() * 8))
+    return dw
+
+
 # ---- ConvTranspose2d k4 s2 p1 forward as tap GEMM + col2im epilogue (csrc/vs_conv_tap.hip) -------------------------------------
 def convt_tap_supported(x, Cout, groups):
     import os

@@ -227,8 +227,8 @@ class GraphedStep:
             from . import functional as VF
             grad_sync.direct_lowp = True
             VF.set_lowp_gradients({p: grad_sync.lowp_views[id(p)] for p in grad_sync.params if id(p) in grad_sync.lowp_views})
-        enable_update_in_backward(optimizer, sep_net, grad_sync, scaler=scaler)
         enable_fused_update(optimizer, sep_net, grad_sync, scaler)
+        enable_update_in_backward(optimizer, sep_net, grad_sync, scaler=scaler)
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
         # static inputs of the recording: one [B, T, ...] buffer, cond / target are views of it (no concatenation per step)
         self.full = torch.cat([cond, target], dim=1).contiguous()
@@ -423,7 +423,8 @@ def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False, s
     # Opt-in (VARSEP_ADAM_OVERLAP=1): on the WaveEq step it is a wash (1.898 vs 1.891 ms) -- the update and E_t's backward
     # (98 MB of fp32 weight gradient per encoder) compete for the same HBM bandwidth, both just run slower side by side.
     from .optim import Adam as HipAdam
-    if not force and os.environ.get('VARSEP_ADAM_OVERLAP') != '1':
+    early_only = os.environ.get('VARSEP_ADAM_EARLY_BUCKET') == '1'
+    if not force and os.environ.get('VARSEP_ADAM_OVERLAP') != '1' and not early_only:
         return
     if scaler is not None:
         # fp16 loss scaling: the update needs 1 / scale and the finite check of ALL gradients, which exist only after backward
@@ -431,10 +432,18 @@ def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False, s
         return
     if isinstance(optimizer, HipAdam) and grad_sync is None and not optimizer._buckets and len(optimizer.param_groups) == 1:
         owned = {id(p) for p in optimizer.param_groups[0]['params']}
-        early = [p for m in (sep_net.decoder, sep_net.Es) for p in m.parameters() if id(p) in owned]
-        buckets = [early, [p for p in sep_net.t_resnet.parameters() if id(p) in owned],
-                   [p for p in sep_net.Et.parameters() if id(p) in owned]]
-        if sum(len(b) for b in buckets) == len(owned):
+        fused = {id(p) for p in getattr(optimizer, '_fused', [])}        # updated inside their weight-gradient GEMMs: in no bucket
+        early = [p for m in (sep_net.decoder, sep_net.Es) for p in m.parameters() if id(p) in owned and id(p) not in fused]
+        if early_only and not force:
+            # decoder + E_s only: their gradients are complete once the held weight gradients have run (under the integrator's
+            # backward kernel), the update joins that queue; the optimizer launch at the end of the step shrinks to E_t + integrator.
+            # (The integrator's own gradients are recorded at the very end of backward -- functional.run_late -- after its hooks.)
+            if early:
+                optimizer.overlap_with_backward([early])
+            return
+        buckets = [early, [p for p in sep_net.t_resnet.parameters() if id(p) in owned and id(p) not in fused],
+                   [p for p in sep_net.Et.parameters() if id(p) in owned and id(p) not in fused]]
+        if sum(len(b) for b in buckets) + len(fused) == len(owned):
             optimizer.overlap_with_backward(buckets)
 
 

@@ -584,3 +584,51 @@ def test_conv3_wgrad_band_over_separate_pieces_equals_the_concatenated_batch():
     torch.cuda.synchronize()
     assert got is not None and torch.equal(got, want) and torch.equal(acc_got, acc_want)
     assert ops.conv3_wgrad_band_pieces(pairs * 13, shape) is None            # more than 64 pieces: the caller concatenates
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom', [
+    (6, 64, 32, 32, 128),     # DCGAN encoder layer 2 (nf = 64): planes [6, 256, 16, 16]
+    (5, 128, 16, 16, 256),    # layer 3: planes [5, 512, 8, 8] (8 x 8 maps, four per workgroup; 5 = one full group + 1)
+    (3, 16, 64, 64, 40),      # planes [3, 64, 32, 32]: one 64-channel phase, ragged output-channel tile
+    (2, 32, 128, 128, 32),    # planes [2, 128, 64, 64]
+])
+def test_conv_k4s2_on_parity_planes_matches_fp64(dtype, geom):
+    """The k4 s2 p1 family without a column matrix (csrc/vs_conv_k4s2.hip: parity planes + row-band kernels) against fp64 torch on the
+    same 16-bit operands: Conv2d forward and weight gradient, ConvTranspose2d input gradient and weight gradient."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, C, H, W, M = geom
+    x = _rand((B, C, H, W), 301).to(dtype)
+    assert ops.conv_k4s2_supported(x.cuda(), M)
+    planes = ops.space_to_depth2(x.cuda())
+    # planes: channel (py * 2 + px) * C + c = x[c][2 y + py][2 x + px]
+    want = torch.stack([x[:, :, py::2, px::2] for py in (0, 1) for px in (0, 1)], dim=1).reshape(B, 4 * C, H // 2, W // 2)
+    assert torch.equal(planes.cpu(), want)
+    # Conv2d(C, M, 4, 2, 1): forward + weight gradient
+    w = _rand((M, C, 4, 4), 302, 0.3).to(dtype)
+    bias = _rand((M,), 303)
+    wp = ops.conv_k4s2_pack_weight(w.float().cuda(), dtype)
+    y = ops.conv_k4s2_gather(planes, wp, bias.cuda(), M, torch.float32)
+    w64 = w.double().requires_grad_(True)
+    ref = F.conv2d(x.double(), w64, bias.double(), stride=2, padding=1)
+    assert ((y.cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max()).item() < 1e-5
+    dz = _rand(tuple(ref.shape), 304).to(dtype)
+    ref.backward(dz.double())
+    dw = ops.conv_k4s2_wgrad(dz.cuda(), planes, (M, C, 4, 4))
+    pend = _rand((M, C, 4, 4), 305).cuda()
+    acc = ops.conv_k4s2_wgrad(dz.cuda(), planes, (M, C, 4, 4), into=pend.clone())
+    torch.cuda.synchronize()
+    scale = w64.grad.abs().max()
+    assert ((dw.cpu().double() - w64.grad).abs().max() / scale).item() < 2e-6
+    assert ((acc.cpu().double() - (w64.grad + pend.cpu().double())).abs().max() / scale).item() < 2e-6
+    # ConvTranspose2d(M, C, 4, 2, 1) with output gradient x [B, C, H, W]: input gradient [B, M, H/2, W/2] and weight gradient [M, C, 4, 4]
+    wt = _rand((M, C, 4, 4), 306, 0.3).to(dtype)
+    inp = _rand((B, M, H // 2, W // 2), 307).to(dtype)
+    i64, wt64 = inp.double().requires_grad_(True), wt.double().requires_grad_(True)
+    F.conv_transpose2d(i64, wt64, None, stride=2, padding=1).backward(x.double())
+    dx = ops.conv_k4s2_gather(planes, ops.conv_k4s2_pack_weight(wt.float().cuda(), dtype), None, M, torch.float32, role='dgrad')
+    dwt = ops.conv_k4s2_wgrad(inp.cuda(), planes, (M, C, 4, 4))
+    torch.cuda.synchronize()
+    assert ((dx.cpu().double() - i64.grad).abs().max() / i64.grad.abs().max()).item() < 1e-5
+    assert ((dwt.cpu().double() - wt64.grad).abs().max() / wt64.grad.abs().max()).item() < 2e-6

@@ -138,3 +138,69 @@ def test_reference_written_checkpoint_runs_on_the_hip_path(name):
         check_tensor(gold, 't_codes', codes, 1e-3)
         check_tensor(gold, 's_code', s_code[0] if isinstance(s_code, (tuple, list)) else s_code, 1e-3)
         check_tensor(gold, 'swap_forecasts', swap, 1e-3)
+
+
+LONG_NAMES = ['mlp_mul', 'dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'sst_skip']
+
+
+@pytest.mark.parametrize('name', LONG_NAMES)
+def test_long_horizon_forecast_matches_reference_fixture(name):
+    """The paper's long-term evaluation (README.md:116 `--nt_pred 95`; test/mnist/test.py:101,120: `get_forecast(x_cond, nt_cond + 95)`
+    in `.eval()` under no_grad) against vectors recorded from the reference (tests/golden/eval_long_<name>.npz,
+    oracle/make_golden_eval.py): ~97 integrator steps, the decoder over all frames in one batch, BatchNorm on its running statistics
+    FOLDED into the convolution weights (functional.folded_conv_bn) -- and the same forecast with the folding switched off."""
+    import os
+    from golden_util import check_tensor, load_golden
+    from oracle.golden_configs import fill_net
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    cfg = dict(CONFIGS[name], res_scale=0.3)
+    gold = load_golden('eval_long_' + name)
+    o_net = fill_net(cpu_ref.build_sep_net(dict(cfg)), cfg)
+    h_net = build_sep_net(cfg)
+    h_net.load_state_dict(o_net.state_dict(), strict=True)
+    h_net = h_net.cuda().eval()
+    cond, _ = make_batch(cfg)
+    horizon = int(gold['horizon'])
+    assert horizon == cfg['nt_cond'] + 95
+    out = {}
+    for fold in ('1', '0'):
+        os.environ['VARSEP_FOLD_BN_EVAL'] = fold
+        try:
+            with torch.no_grad(), VF.precision('fp32'):
+                fore, codes, _, _ = h_net.get_forecast(cond.cuda(), horizon)
+        finally:
+            del os.environ['VARSEP_FOLD_BN_EVAL']
+        torch.cuda.synchronize()
+        errs = {k: check_tensor(gold, k, t, 1e-3) for k, t in (('forecasts', fore), ('t_codes', codes), ('last_frame', fore[:, -1]),
+                                                              ('last_code', codes[:, -1]))}
+        out[fold] = fore
+        print(name, 'horizon', horizon, 'BatchNorm folded' if fold == '1' else 'BatchNorm as a pass', {k: '%.1e' % v for k, v in errs.items()})
+    assert rel_err(out['1'].cpu(), out['0'].cpu()) < 1e-4
+    # eval mode leaves the running statistics alone
+    osd = o_net.state_dict()
+    for k, v in h_net.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            assert torch.equal(v.cpu(), osd[k]), k
+
+
+def test_folded_batchnorm_follows_parameter_updates():
+    """The folded weights are cached per (weight, bias, gamma, beta, running statistics) versions: after the parameters or the statistics
+    change, the next eval forecast uses the new ones."""
+    from spatiotemporal_variable_separation_amd import functional as VF
+    cfg, o_net, h_net = _pair('dcgan_tiny')
+    cond, _ = make_batch(cfg)
+    with torch.no_grad():
+        a = h_net.get_forecast(cond.cuda(), 6)[0].clone()
+        for m in h_net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.mul_(1.7)
+                m.weight.add_(0.05)
+        for m in o_net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_var.mul_(1.7)
+                m.weight.add_(0.05)
+        b = h_net.get_forecast(cond.cuda(), 6)[0]
+        want = o_net.get_forecast(cond, 6)[0]
+    assert rel_err(b.cpu(), want) < 1e-3
+    assert rel_err(b.cpu(), a.cpu()) > 1e-3                 # (the change is visible in the output at all)
