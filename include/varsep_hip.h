@@ -181,6 +181,10 @@ int vs_conv3_img16_supported(int compute, int B, int Cin, int H, int W, int Cout
 int vs_conv3_img16_splits(int B, int Cin, int Cout);
 size_t vs_conv3_img16_packed_elems(int Cin, int Cout);
 int vs_conv3_img16_pack_weight(int compute, const float* w, int Cin, int Cout, int flip, void* dst, void* stream);
+/* Up to 96 such pre-packs in ONE launch (every weight changes once per optimizer step, so all packs of a network are stale together:
+ * 36-67 launches of ~5 us per TaxiBJ / SST step otherwise): job j = vs_conv3_img16_pack_weight(compute, w[j], K[j], M[j], flip[j], dst[j]).  */
+int vs_conv3_img16_pack_weights(int compute, int n_jobs, const float* const* w, const int* K, const int* M, const int* flip, void* const* dst,
+                                void* stream);
 int vs_conv3_img16(int compute, const void* x, const void* w_packed, float* slabs, int B, int Cin, int Cout, void* stream);
 /* The same contraction for MANY maps of width 16 / 32 / 64 (every 3x3 block of EncoderSST / DecoderSST(_Skip) conv.py:323-426 and of the VGG
  * encoders / decoders conv.py:127-171, 267-320 on whole batches): workgroup = 256 consecutive pixels of one map (256 / W rows) x 32 output
@@ -219,6 +223,14 @@ int vs_space_to_depth2(int compute, const void* x, void* planes, int B, int C, i
 size_t vs_conv_k4s2_packed_elems(int K, int M);
 int vs_conv_k4s2_pack_weight(int compute, const float* w, int K, int M, void* dst, void* stream);
 int vs_conv_k4s2_wgrad_finish(const float* slabs, int nslabs, const float* addend, float* out, int M, int K, void* stream);
+/*   vs_conv_k4s2_band           the gather on the planes [B][4 K][H][W] -> y [B][M][H][W] (+ bias), vs_conv3_band's arguments with K in place of
+ *                               Cin; K a multiple of 64 (vs_conv_k4s2_skip_form): the kernel form that streams and multiplies only the 2 x 2
+ *                               taps a plane sees (the pack has the matching form), otherwise the plain 3 x 3 kernel on a zero-padded pack
+ *   vs_conv_k4s2_wgrad_band     slabs [vs_conv3_wgrad_band_slabs(B, 4 K, H, W, M)][9][M][4 K] from the planes and the small map [B][M][H][W]  */
+int vs_conv_k4s2_skip_form(int K);
+int vs_conv_k4s2_band(int compute, const void* planes, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int K, int H, int W, int M,
+                      void* stream);
+int vs_conv_k4s2_wgrad_band(int compute, const void* planes, const void* small_map, float* slabs, int B, int K, int H, int W, int M, void* stream);
 int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout);
 int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int W, int Cout, void* stream);
 int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,
@@ -511,6 +523,12 @@ int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float*
 int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, int act, int training, int groups, float* dgamma, float* dbeta, void* dx, int dx_dtype, int B,
                   int C, int64_t HW, void* stream);
+/* vs_bn_act_bwd that additionally returns the PARAMETER gradients, i.e. dgamma / dbeta summed over the call groups ([C] each; with the
+ * n + 1 decoder calls of a step stacked, nn.BatchNorm2d's weight receives the sum of n + 1 per-call gradients, conv.py:41-60): written
+ * by workgroup 0 of the apply pass (or one small launch behind the one-launch form) instead of two reduction launches by the caller.   */
+int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, int act, int training, int groups, float* dgamma, float* dbeta, void* dx, int dx_dtype, int B,
+                       int C, int64_t HW, float* dgamma_sum, float* dbeta_sum, void* stream);
 int vs_chan_sum(const void* x, int x_dtype, int B, int C, int64_t HW, float* out, void* stream);
 int vs_maxpool2_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t planes, int H, int W, void* stream);
 int vs_maxpool2_bwd(const void* x, int x_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype, int64_t planes, int H, int W,

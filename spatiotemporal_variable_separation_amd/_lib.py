@@ -140,12 +140,16 @@ SIGNATURES = {
     'vs_conv3_img16_splits': (_i32, [_i32] * 3),
     'vs_conv3_img16_packed_elems': (_sz, [_i32, _i32]),
     'vs_conv3_img16_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'vs_conv3_img16_pack_weights': (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'vs_conv3_img16': (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'vs_space_to_depth2_supported': (_i32, [_i32] * 5),
     'vs_space_to_depth2': (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     'vs_conv_k4s2_packed_elems': (_sz, [_i32, _i32]),
     'vs_conv_k4s2_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _vp, _vp]),
     'vs_conv_k4s2_wgrad_finish': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp]),
+    'vs_conv_k4s2_skip_form': (_i32, [_i32]),
+    'vs_conv_k4s2_band': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'vs_conv_k4s2_wgrad_band': (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vs_conv3_band_supported': (_i32, [_i32] * 6),
     'vs_conv3_band': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vs_conv3_wgrad_band_supported': (_i32, [_i32] * 6),
@@ -168,6 +172,7 @@ SIGNATURES = {
     'vs_bn_stats': (_i32, [_vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp]),
     'vs_bn_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     'vs_bn_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    'vs_bn_act_bwd_gsum': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp]),
     'vs_chan_sum': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     'vs_maxpool2_fwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
     'vs_maxpool2_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),

@@ -51,6 +51,14 @@ template <int N>
 __device__ __forceinline__ void img_wait3n(u32x4& a0, u32x4& a1, u32x4& a2) {   // N younger loads may stay in flight
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a0), "+v"(a1), "+v"(a2) : "n"(N) : "memory");
 }
+// the same for groups of TWO fragments (the k4 s2 p1 form on parity planes: a plane sees two of the three column taps)
+__device__ __forceinline__ void img_load2(u32x4& a0, u32x4& a1, const void* sbase, unsigned voff) {
+    asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024" : "=&v"(a0), "=&v"(a1) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void img_wait2n(u32x4& a0, u32x4& a1) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a0), "+v"(a1) : "n"(N) : "memory");
+}
 
 // NP 16-byte pieces per thread of the staged image: piece u = channel (u >> 5), 8 pixels (u & 31) -> the channel's rows 1 .. 16 in LDS
 template <int NP>
@@ -168,9 +176,16 @@ __global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned s
 //   * two forms: AHEAD = 12 fragment groups in flight and one workgroup per CU (the registers of 36 fragments), or AHEAD = 4 and TWO
 //     workgroups per CU where their LDS fits (one 64-channel phase, or W = 16): a workgroup's launch, first DMA and epilogue are then
 //     covered by its neighbour's MFMA phase instead of by a deep prefetch.
-template <int CT, int W, int AHEAD, int MINB>
+// K4 = 1: the k4 s2 p1 convolution family on the four parity planes of its large operand (csrc/vs_conv_k4s2.hip): X holds [4 planes][K]
+// channels (plane = row parity * 2 + column parity, K a multiple of 64, so a 64-channel phase lies in ONE plane) and a plane sees only 2 x 2
+// of the 3 x 3 taps -- rows {-1, 0} and columns {-1, 0} for the odd planes, {0, +1} for the even ones.  The fragment stream then holds
+// 4 chunks x 2 tap rows x 2 tap columns per phase (vs_conv_k4s2_pack_weight, skip form) and the zero taps cost neither fragment loads nor
+// MFMAs: 32 instead of 72 MFMAs per phase and wave.
+template <int CT, int W, int AHEAD, int MINB, int K4 = 0>
 __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
                                                          void* __restrict__ Y, int yd, int B, int Cin, int H, int Cout, int mtiles, int bands) {
+    constexpr int NKY = K4 ? 2 : 3, NF = K4 ? 2 : 3, GPP = 4 * NKY;              // tap rows and fragments per group, groups per 64-channel phase
+    static_assert(GPP % AHEAD == 0, "the fragment ring must divide the groups of a phase");
     // W >= 16: the tile is R = 256 / W rows of ONE map (`band` = which rows); W = 8: FOUR whole 8 x 8 maps (`band` = which four, b = 0)
     constexpr int IPB = W == 8 ? 4 : 1, RI = W == 8 ? 8 : 256 / W, RPI = RI + 2, RP = IPB * RPI, PW = W / 8;
     constexpr int NP = 64 * RP * PW / 256;                                       // 16-byte pieces per thread and phase: 12 / 10 / 9 / 10
@@ -202,11 +217,14 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
     dma(0);
 
     const int chunks_total = Cin >> 4;
-    const char* wbase = reinterpret_cast<const char*>(Wp + ((int64_t)mt * chunks_total * 3) * 192);
+    const char* wbase = reinterpret_cast<const char*>(Wp + ((int64_t)mt * chunks_total * NKY) * (NF * 64));
     const unsigned voff = lane * 16;
-    u32x4 a[AHEAD][3];
+    u32x4 a[AHEAD][3];                                                            // (K4: the third slot is unused)
 #pragma unroll
-    for (int gg = 0; gg < AHEAD; ++gg) img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + gg * 3072, voff);
+    for (int gg = 0; gg < AHEAD; ++gg) {
+        if constexpr (K4) img_load2(a[gg][0], a[gg][1], wbase + gg * (NF * 1024), voff);
+        else img_load3(a[gg][0], a[gg][1], a[gg][2], wbase + gg * 3072, voff);
+    }
 
     f32x16 acc[3][2];
 #pragma unroll
@@ -223,29 +241,51 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
         const int q0 = wave * 64 + j * 32 + 16 * cb + 4 * p, qi = q0 % (RI * W);
         lofs[j] = ((8 * h + q) * RP + (q0 / (RI * W)) * RPI + qi / W) * W + qi % W;
     }
-    const int ngroups = chunks_total * 3;
+    const int ngroups = chunks_total * NKY;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // phase 0 (and the first fragments) have landed
     __builtin_amdgcn_s_barrier();
 
     for (int ph = 0; ph < nph; ++ph) {
         if (ph + 1 < nph) dma(ph + 1);
         const unsigned short* buf = xs + (ph & 1) * BUF;
-        const int g0 = ph * 12;
+        const int g0 = ph * GPP;
+        // K4: the plane of this phase (wave-uniform): odd rows (plane >> 1) see tap rows {0, 1}, even rows {1, 2}; likewise the columns
+        const int plane = K4 ? ph / (nph >> 2) : 0;
+        const int ky0 = K4 ? ((plane >> 1) ? 0 : 1) : 0;
+        const bool odd_cols = K4 && (plane & 1);
 #pragma unroll
-        for (int gg = 0; gg < 12; ++gg) {
-            const int ch = gg / 3, ky = gg % 3;
+        for (int gg = 0; gg < GPP; ++gg) {
+            const int ch = gg / NKY, ky = ky0 + gg % NKY;
             u32x4 bf[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = vs_tr16_pair(buf + lofs[j] + (ch * 16 * RP + ky) * W, 4 * RP * W);
-            const int sl = gg % AHEAD;                                           // register set of this group (12 % AHEAD == 0; a constant once unrolled)
-            img_wait3n<(AHEAD - 1) * 3>(a[sl][0], a[sl][1], a[sl][2]);
+            const int sl = gg % AHEAD;                                           // register set of this group (GPP % AHEAD == 0; a constant once unrolled)
+            if constexpr (K4) {
+                img_wait2n<(AHEAD - 1) * 2>(a[sl][0], a[sl][1]);
+                if (odd_cols) {                                                  // column taps {0, 1}: x[col - 1], x[col]
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+                    for (int j = 0; j < 2; ++j) {
+                        acc[0][j] = mfma16_32<CT>(a[sl][0], bf[j], acc[0][j]);
+                        acc[1][j] = mfma16_32<CT>(a[sl][1], bf[j], acc[1][j]);
+                    }
+                } else {                                                         // column taps {1, 2}: x[col], x[col + 1]
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[kx][j] = mfma16_32<CT>(a[sl][kx], bf[j], acc[kx][j]);
+                    for (int j = 0; j < 2; ++j) {
+                        acc[1][j] = mfma16_32<CT>(a[sl][0], bf[j], acc[1][j]);
+                        acc[2][j] = mfma16_32<CT>(a[sl][1], bf[j], acc[2][j]);
+                    }
+                }
+            } else {
+                img_wait3n<(AHEAD - 1) * 3>(a[sl][0], a[sl][1], a[sl][2]);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[kx][j] = mfma16_32<CT>(a[sl][kx], bf[j], acc[kx][j]);
+            }
             int gn = g0 + AHEAD + gg;
             if (gn > ngroups - 1) gn = ngroups - 1;
-            img_load3(a[sl][0], a[sl][1], a[sl][2], wbase + (int64_t)gn * 3072, voff);
+            if constexpr (K4) img_load2(a[sl][0], a[sl][1], wbase + (int64_t)gn * (NF * 1024), voff);
+            else img_load3(a[sl][0], a[sl][1], a[sl][2], wbase + (int64_t)gn * 3072, voff);
         }
         // the last wait of the phase left <= (AHEAD - 1) * 3 loads outstanding, all younger than the DMA of the next phase: it has landed for this
         // wave; behind the barrier for all of them, and nobody reads this phase's buffer any more
@@ -314,7 +354,10 @@ struct WgradPieces {
     int maps_per_piece;
 };
 
-template <int CT, int W, int MW>
+// K4 = 1: the weight gradient of a k4 s2 p1 (transposed) convolution on the parity planes of its large operand (csrc/vs_conv_k4s2.hip): Cin = 4 K
+// plane channels, K a multiple of 32, so the 32 channels of a workgroup lie in ONE plane, which sees 2 x 2 of the 3 x 3 taps: the other five
+// MFMAs per k-step (and their slab stores: vs_conv_k4s2_wgrad_finish never reads them) are skipped.
+template <int CT, int W, int MW, int K4 = 0>
 __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, float* __restrict__ slabs, int B, int Cin, int H, int Cout, int ctiles, int ksplit) {
     // W >= 16: an item is a band of R = 256 / W rows of one map; W = 8: FOUR whole 8 x 8 maps (rows of one 16-byte piece, no column neighbours)
     constexpr int IPB = W == 8 ? 4 : 1, R = W == 8 ? 8 : 256 / W, RPI = R + 2, RP = IPB * RPI, PW = W / 8;
@@ -401,6 +444,9 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
 
     const int rl = lane & 31, h = lane >> 5;
     const int msub = wave % MW, kpart = wave / MW;
+    // K4: first tap row / column this plane sees (odd planes: {0, 1}, even planes: {1, 2}); wave-uniform
+    const int plane = K4 ? (ct * 32) / (Cin >> 2) : 0;
+    const int ky_lo = K4 ? ((plane >> 1) ? 0 : 1) : 0, kx_lo = K4 ? ((plane & 1) ? 0 : 1) : 0;
     int64_t it = ks;
     if (it < items) load_item(it);
     for (; it < items; it += ksplit) {
@@ -416,6 +462,7 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
+                    if (K4 && ((unsigned)(ky - ky_lo) > 1u || (unsigned)(kx - kx_lo) > 1u)) continue;      // not a tap of this plane
                     const u32x4 bf = *reinterpret_cast<const u32x4*>(xs + (kx * 32 + rl) * CPITCH + (row + ky) * W + x0 + 8 * h);
                     acc[ky * 3 + kx] = mfma16_32<CT>(af, bf, acc[ky * 3 + kx]);
                 }
@@ -428,12 +475,14 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
     float* out = slabs + ((int64_t)ks * KW + kpart) * ((int64_t)Cout * Cin * 9);
     const int c = ct * 32 + rl;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t) {
+        if (K4 && ((unsigned)(t / 3 - ky_lo) > 1u || (unsigned)(t % 3 - kx_lo) > 1u)) continue;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int m = mt * (32 * MW) + msub * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
             if (m < Cout && c < Cin) out[((int64_t)t * Cout + m) * Cin + c] = acc[t][v];
         }
+    }
 }
 
 // dW[m][c][tap] = sum over the n slabs [tap][m][c] (+ the pending gradient): coalesced reads along c, nine consecutive words written per thread
@@ -468,6 +517,47 @@ __global__ __launch_bounds__(256) void conv3_img16_pack_kernel(const float* __re
         if (m < M)
             v = flip ? w[(((int64_t)c * M + m) * 3 + (2 - ky)) * 3 + (2 - kx)] : w[(((int64_t)m * K + c) * 3 + ky) * 3 + kx];
         dst[e] = vs_f2h(v, CT);
+    }
+}
+
+// All the pre-packs of a step in ONE launch (every weight changes once per optimizer step, so every pack is stale once per step: 36-67
+// launches of ~5 us at TaxiBJ / SST size otherwise).  A job = (w, dst, M, K, flip); 16-byte units (8 packed elements) are numbered across jobs.
+constexpr int IPK_MAXJ = 96;
+struct ImgPackJobs {
+    const float* w[IPK_MAXJ];
+    unsigned short* dst[IPK_MAXJ];
+    int M[IPK_MAXJ], K[IPK_MAXJ], flip[IPK_MAXJ];
+    long long unit_off[IPK_MAXJ + 1];
+    int nj;
+};
+template <int CT>
+__global__ __launch_bounds__(256) void conv3_img16_pack_multi_kernel(ImgPackJobs J) {
+    const long long total = J.unit_off[J.nj];
+    for (long long gu = (long long)blockIdx.x * 256 + threadIdx.x; gu < total; gu += (long long)gridDim.x * 256) {
+        int lo = 0, hi = J.nj;                                                      // job of this unit: unit_off[lo] <= gu < unit_off[lo + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (J.unit_off[mid] <= gu) lo = mid; else hi = mid;
+        }
+        const int j = lo;
+        const long long u = gu - J.unit_off[j];
+        const int M = J.M[j], K = J.K[j], flip = J.flip[j], chunks = K >> 4;
+        const float* w = J.w[j];
+        const int lane = (int)(u & 63);
+        long long t = u >> 6;
+        const int kx = (int)(t % 3); t /= 3;
+        const int ky = (int)(t % 3); t /= 3;
+        const int chunk = (int)(t % chunks), mt = (int)(t / chunks);
+        const int m = mt * 32 + (lane & 31), c0 = chunk * 16 + 8 * (lane >> 5);
+        unsigned short o[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int c = c0 + jj;
+            float v = 0.f;
+            if (m < M) v = flip ? w[(((int64_t)c * M + m) * 3 + (2 - ky)) * 3 + (2 - kx)] : w[(((int64_t)m * K + c) * 3 + ky) * 3 + kx];
+            o[jj] = vs_f2h(v, CT);
+        }
+        *reinterpret_cast<u32x4*>(J.dst[j] + u * 8) = *reinterpret_cast<const u32x4*>(o);
     }
 }
 
@@ -550,6 +640,27 @@ extern "C" int vs_conv3_img16_pack_weight(int compute, const float* w, int Cin, 
     return VS_OK;
 }
 
+// n_jobs (<= 96) pre-packs at once: job j = vs_conv3_img16_pack_weight(compute, w[j], K[j], M[j], flip[j], dst[j]) (K = contraction channels, M = rows)
+extern "C" int vs_conv3_img16_pack_weights(int compute, int n_jobs, const float* const* w, const int* K, const int* M, const int* flip, void* const* dst,
+                                           void* stream) {
+    VS_CHECK_ARG(vs_is16(compute) && n_jobs >= 1 && n_jobs <= IPK_MAXJ && w && K && M && flip && dst, "vs_conv3_img16_pack_weights: bad argument (1..%d jobs)",
+                 IPK_MAXJ);
+    ImgPackJobs J;
+    J.nj = n_jobs;
+    J.unit_off[0] = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        VS_CHECK_ARG(w[j] && dst[j] && M[j] > 0 && K[j] >= 16 && K[j] % 16 == 0 && (uintptr_t)dst[j] % 16 == 0, "vs_conv3_img16_pack_weights: bad job %d", j);
+        J.w[j] = w[j]; J.dst[j] = (unsigned short*)dst[j]; J.M[j] = M[j]; J.K[j] = K[j]; J.flip[j] = flip[j];
+        J.unit_off[j + 1] = J.unit_off[j] + (long long)(vs_conv3_img16_packed_elems(K[j], M[j]) / 8);
+    }
+    long long blocks = (J.unit_off[n_jobs] + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (compute == VS_BF16) hipLaunchKernelGGL(conv3_img16_pack_multi_kernel<VS_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
+    else hipLaunchKernelGGL(conv3_img16_pack_multi_kernel<VS_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
+    VS_CHECK_LAUNCH("vs_conv3_img16_pack_weights");
+    return VS_OK;
+}
+
 // x [B][Cin][16][16] (16-bit), w_packed from vs_conv3_img16_pack_weight -> slabs [vs_conv3_img16_splits][B][Cout][256] fp32 (no bias)
 extern "C" int vs_conv3_img16(int compute, const void* x, const void* w_packed, float* slabs, int B, int Cin, int Cout, void* stream) {
     VS_CHECK_ARG(x && w_packed && slabs, "vs_conv3_img16: bad argument");
@@ -599,13 +710,13 @@ extern "C" int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W
     return 1;
 }
 
-template <int W, int AHEAD, int MINB>
+template <int W, int AHEAD, int MINB, int K4 = 0>
 static int launch_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
                        hipStream_t stream) {
     constexpr int R = W == 8 ? 8 : 256 / W, RPT = (W == 8 ? 4 : 1) * (R + 2);
     const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * 64 * RPT * W * 2;            // one buffer when there is a single 64-channel phase
-    auto kb = conv3_band_kernel<VS_BF16, W, AHEAD, MINB>;
-    auto kh = conv3_band_kernel<VS_F16, W, AHEAD, MINB>;
+    auto kb = conv3_band_kernel<VS_BF16, W, AHEAD, MINB, K4>;
+    auto kh = conv3_band_kernel<VS_F16, W, AHEAD, MINB, K4>;
     static bool attr_set = false;
     if (!attr_set) {
         const int most = 2 * 64 * RPT * W * 2;
@@ -621,6 +732,17 @@ static int launch_band(int compute, const void* x, const void* w_packed, const f
     else
         hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands);
     return VS_OK;
+}
+
+// k4 s2 p1 on parity planes (K4 form of the kernel): 8 fragment groups per phase -> rings of 4 (two workgroups per CU) or 8
+template <int W>
+static int launch_band_k4_w(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
+                            hipStream_t stream) {
+    static const int pair_mode = getenv("VS_CONV_BAND_PAIR") ? atoi(getenv("VS_CONV_BAND_PAIR")) : 1;
+    constexpr int R = W == 8 ? 8 : 256 / W, RPT = (W == 8 ? 4 : 1) * (R + 2);
+    const size_t lds = (size_t)2 * 64 * RPT * W * 2;                             // Cin = 4 K >= 256: always two buffers
+    if (pair_mode && 2 * lds <= 160 * 1024) return launch_band<W, 4, 2, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
+    return launch_band<W, 8, 1, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
 }
 
 template <int W>
@@ -675,12 +797,12 @@ extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout)
     return (4 / wgrad_band_mw(Cout)) * wgrad_band_ksplit(B, Cin, H, W, Cout);
 }
 
-template <int W, int MW>
+template <int W, int MW, int K4 = 0>
 static void launch_wgrad_band(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
     constexpr int RPT = W == 8 ? 4 * 10 : 256 / W + 2;
     const size_t lds = (size_t)(3 * 32 * (RPT * W + 8) + 32 * MW * 264) * 2;
-    auto kb = wgrad3_band_kernel<VS_BF16, W, MW>;
-    auto kh = wgrad3_band_kernel<VS_F16, W, MW>;
+    auto kb = wgrad3_band_kernel<VS_BF16, W, MW, K4>;
+    auto kh = wgrad3_band_kernel<VS_F16, W, MW, K4>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -695,20 +817,21 @@ static void launch_wgrad_band(int compute, const WgradPieces& pieces, float* sla
         hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, pieces, slabs, B, Cin, H, Cout, ctiles, ksplit);
 }
 
-template <int W>
+template <int W, int K4 = 0>
 static void launch_wgrad_band_w(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
     const int mw = wgrad_band_mw(Cout);
-    if (mw == 4) launch_wgrad_band<W, 4>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
-    else if (mw == 2) launch_wgrad_band<W, 2>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
-    else launch_wgrad_band<W, 1>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
+    if (mw == 4) launch_wgrad_band<W, 4, K4>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
+    else if (mw == 2) launch_wgrad_band<W, 2, K4>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
+    else launch_wgrad_band<W, 1, K4>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
 }
 
+template <int K4 = 0>
 static int wgrad_band_go(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int W, int Cout, hipStream_t stream) {
     const int ks = wgrad_band_ksplit(B, Cin, H, W, Cout);
-    if (W == 64) launch_wgrad_band_w<64>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
-    else if (W == 32) launch_wgrad_band_w<32>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
-    else if (W == 16) launch_wgrad_band_w<16>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
-    else launch_wgrad_band_w<8>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    if (W == 64) launch_wgrad_band_w<64, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    else if (W == 32) launch_wgrad_band_w<32, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    else if (W == 16) launch_wgrad_band_w<16, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    else launch_wgrad_band_w<8, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     VS_CHECK_LAUNCH("vs_conv3_wgrad_band");
     return VS_OK;
 }
@@ -721,7 +844,40 @@ extern "C" int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, f
     pieces.x[0] = (const unsigned short*)x;
     pieces.dz[0] = (const unsigned short*)dz;
     pieces.maps_per_piece = B;
-    return wgrad_band_go(compute, pieces, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
+    return wgrad_band_go<0>(compute, pieces, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
+}
+
+// ---- k4 s2 p1 on parity planes (csrc/vs_conv_k4s2.hip): planes [B][4 K][H][W] ----------------------------------------------------------
+// K a multiple of 64: the forms of the kernels that skip the five zero taps of every plane (weights packed by vs_conv_k4s2_pack_weight in
+// the matching 2 x 2 form); otherwise the plain 3 x 3 kernels on a zero-padded 3 x 3 pack.
+extern "C" int vs_conv_k4s2_skip_form(int K) { return K >= 64 && K % 64 == 0; }
+
+extern "C" int vs_conv_k4s2_band(int compute, const void* planes, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int K, int H, int W,
+                                 int M, void* stream) {
+    VS_CHECK_ARG(planes && w_packed && y && vs_dtype_ok(y_dtype), "vs_conv_k4s2_band: bad argument");
+    VS_CHECK_ARG(vs_conv3_band_supported(compute, B, 4 * K, H, W, M), "vs_conv_k4s2_band: unsupported geometry (query vs_conv3_band_supported on the planes)");
+    VS_CHECK_ARG(((uintptr_t)planes | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0, "vs_conv_k4s2_band: operands must be 16-byte aligned");
+    if (!vs_conv_k4s2_skip_form(K)) return vs_conv3_band(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, W, M, stream);
+    int rc;
+    if (W == 64) rc = launch_band_k4_w<64>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
+    else if (W == 32) rc = launch_band_k4_w<32>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
+    else if (W == 16) rc = launch_band_k4_w<16>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
+    else rc = launch_band_k4_w<8>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
+    if (rc != VS_OK) return rc;
+    VS_CHECK_LAUNCH("vs_conv_k4s2_band");
+    return VS_OK;
+}
+
+extern "C" int vs_conv_k4s2_wgrad_band(int compute, const void* planes, const void* small, float* slabs, int B, int K, int H, int W, int M, void* stream) {
+    VS_CHECK_ARG(planes && small && slabs, "vs_conv_k4s2_wgrad_band: bad argument");
+    VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, 4 * K, H, W, M), "vs_conv_k4s2_wgrad_band: unsupported geometry");
+    VS_CHECK_ARG(((uintptr_t)planes | (uintptr_t)small | (uintptr_t)slabs) % 16 == 0, "vs_conv_k4s2_wgrad_band: operands must be 16-byte aligned");
+    WgradPieces pieces = {};
+    pieces.x[0] = (const unsigned short*)planes;
+    pieces.dz[0] = (const unsigned short*)small;
+    pieces.maps_per_piece = B;
+    if (vs_conv_k4s2_skip_form(K)) return wgrad_band_go<1>(compute, pieces, slabs, B, 4 * K, H, W, M, (hipStream_t)stream);
+    return wgrad_band_go<0>(compute, pieces, slabs, B, 4 * K, H, W, M, (hipStream_t)stream);
 }
 
 // The same over a batch that lies in `npieces` (<= 64) separate tensors of `maps_per_piece` maps each (x[i] [maps][Cin][H][W], dz[i]
@@ -740,7 +896,7 @@ extern "C" int vs_conv3_wgrad_band_pieces(int compute, int npieces, const void* 
     }
     pieces.maps_per_piece = maps_per_piece;
     VS_CHECK_ARG((uintptr_t)slabs % 16 == 0, "vs_conv3_wgrad_band_pieces: slabs must be 16-byte aligned");
-    return wgrad_band_go(compute, pieces, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
+    return wgrad_band_go<0>(compute, pieces, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
 }
 
 // partial[g][i] = sum over the slabs g * per .. g * per + per - 1 (per = ceil(nslabs / groups)) of slabs[s][i], i < total (a multiple of 4):

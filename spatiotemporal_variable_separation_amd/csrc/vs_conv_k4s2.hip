@@ -94,6 +94,30 @@ __global__ __launch_bounds__(256) void k4s2_pack_kernel(const float* __restrict_
     }
 }
 
+// the same for K a multiple of 64 (vs_conv_k4s2_skip_form): only the 2 x 2 taps a plane sees, Wp[mt][chunk][kyi][kxi][lane][8] with
+// ky3 = ky0(plane) + kyi, kx3 = kx0(plane) + kxi (ky0 = 0 for the odd-row planes, 1 for the even ones; likewise kx0) -- the order the K4 form of
+// conv3_band_kernel streams
+template <int CT>
+__global__ __launch_bounds__(256) void k4s2_pack_skip_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int M, int K, int64_t total) {
+    const int chunks = (4 * K) >> 4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int jj = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        int64_t t = e >> 9;
+        const int kxi = (int)(t & 1);
+        t >>= 1;
+        const int kyi = (int)(t & 1);
+        t >>= 1;
+        const int chunk = (int)(t % chunks), mt = (int)(t / chunks);
+        const int m = mt * 32 + (lane & 31), cp = chunk * 16 + 8 * (lane >> 5) + jj;
+        const int plane = cp / K, c = cp - plane * K;
+        const int py = plane >> 1, px = plane & 1;
+        const int ky = k4_tap4(py, (py ? 0 : 1) + kyi), kx = k4_tap4(px, (px ? 0 : 1) + kxi);
+        float v = 0.f;
+        if (m < M) v = w[(((int64_t)m * K + c) * 4 + ky) * 4 + kx];
+        dst[e] = vs_f2h(v, CT);
+    }
+}
+
 // dW[m][c][ky][kx] = sum over the n slabs [tap3][m][c'] (+ the pending gradient); one thread per (m, c): 16 coalesced reads per slab along c
 __global__ __launch_bounds__(256) void k4s2_wgrad_finish_kernel(const float* __restrict__ src, int n, int M, int K, const float* __restrict__ addend,
                                                                 float* __restrict__ out) {
@@ -134,14 +158,21 @@ extern "C" int vs_space_to_depth2(int compute, const void* x, void* y, int B, in
     return VS_OK;
 }
 
-extern "C" size_t vs_conv_k4s2_packed_elems(int K, int M) { return (size_t)vs_cdiv(M, 32) * 32 * (size_t)(4 * K) * 9; }
+extern "C" int vs_conv_k4s2_skip_form(int K);          // vs_conv_img.hip
+
+extern "C" size_t vs_conv_k4s2_packed_elems(int K, int M) { return (size_t)vs_cdiv(M, 32) * 32 * (size_t)(4 * K) * (vs_conv_k4s2_skip_form(K) ? 4 : 9); }
 
 extern "C" int vs_conv_k4s2_pack_weight(int compute, const float* w, int K, int M, void* dst, void* stream) {
     VS_CHECK_ARG(w && dst && vs_is16(compute) && K > 0 && M > 0 && (4 * K) % 16 == 0, "vs_conv_k4s2_pack_weight: bad argument (16-bit, K a multiple of 4)");
     const int64_t total = (int64_t)vs_conv_k4s2_packed_elems(K, M);
     int64_t blocks = vs_cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
-    if (compute == VS_BF16)
+    if (vs_conv_k4s2_skip_form(K)) {
+        if (compute == VS_BF16)
+            hipLaunchKernelGGL(k4s2_pack_skip_kernel<VS_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)dst, M, K, total);
+        else
+            hipLaunchKernelGGL(k4s2_pack_skip_kernel<VS_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)dst, M, K, total);
+    } else if (compute == VS_BF16)
         hipLaunchKernelGGL(k4s2_pack_kernel<VS_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)dst, M, K, total);
     else
         hipLaunchKernelGGL(k4s2_pack_kernel<VS_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)dst, M, K, total);

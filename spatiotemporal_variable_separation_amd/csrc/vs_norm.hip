@@ -406,7 +406,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const void* dy, int
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int dyd, const void* x, int xd, const float* mean,
                                                            const float* invstd, const float* gamma, const float* beta, int act,
                                                            const float* sum_dz, const float* sum_dz_xhat, void* dx, int dxd, int Bg, int C,
-                                                           int64_t HW, int64_t total, int training, int vec) {
+                                                           int64_t HW, int64_t total, int training, int vec, float* gsum_dbeta, float* gsum_dgamma,
+                                                           int groups) {
+    if (gsum_dbeta && blockIdx.x == 0) {
+        // d beta / d gamma of the PARAMETER = the per-call-group sums added up (fixed order); a by-product of workgroup 0
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f, b = 0.f;
+            for (int g = 0; g < groups; ++g) { a += sum_dz[g * C + c]; b += sum_dz_xhat[g * C + c]; }
+            gsum_dbeta[c] = a;
+            gsum_dgamma[c] = b;
+        }
+    }
     const float inv_n = 1.f / (float)((int64_t)Bg * HW);
     const int64_t group_elems = (int64_t)Bg * C * HW;
     if (vec == 2) {
@@ -477,6 +487,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* dy, int d
 // step): reduce AND apply in one launch.  A 256-thread workgroup owns the slab, keeps dz and x-hat of its <= 32 elements per thread in
 // registers between the two phases (same-dtype 16-byte vector path only), so dy and x are read once and the second launch
 // (8-9 us each at these sizes, pure launch latency) disappears.
+// out_a[c] = sum_g a[g][c], out_b[c] = sum_g b[g][c] (the per-call-group d beta / d gamma of the one-launch form, added up)
+__global__ __launch_bounds__(256) void group_sum2_kernel(const float* a, const float* b, int groups, int C, float* out_a, float* out_b) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        float sa = 0.f, sb = 0.f;
+        for (int g = 0; g < groups; ++g) { sa += a[g * C + c]; sb += b[g * C + c]; }
+        out_a[c] = sa;
+        out_b[c] = sb;
+    }
+}
+
 template <int NV>                    // 16-byte vectors per thread
 __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const void* dy, const void* x, int xd, const float* mean, const float* invstd,
                                                           const float* gamma, const float* beta, int act, float* sum_dz, float* sum_dz_xhat,
@@ -929,9 +949,22 @@ extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, c
     return VS_OK;
 }
 
+// dgamma_sum / dbeta_sum (both or neither; [C]): additionally the parameter gradients summed over the call groups
+extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, int act, int training, int groups, float* dgamma, float* dbeta, void* dx,
+                                  int dx_dtype, int B, int C, int64_t HW, float* dgamma_sum, float* dbeta_sum, void* stream);
+
 extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd,
                              const float* gamma, const float* beta, int act, int training, int groups, float* dgamma, float* dbeta, void* dx,
                              int dx_dtype, int B, int C, int64_t HW, void* stream) {
+    return vs_bn_act_bwd_gsum(dy, dy_dtype, x, x_dtype, mean, invstd, gamma, beta, act, training, groups, dgamma, dbeta, dx, dx_dtype, B, C, HW, nullptr,
+                              nullptr, stream);
+}
+
+extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, int act, int training, int groups, float* dgamma, float* dbeta, void* dx,
+                                  int dx_dtype, int B, int C, int64_t HW, float* dgamma_sum, float* dbeta_sum, void* stream) {
+    VS_CHECK_ARG((dgamma_sum == nullptr) == (dbeta_sum == nullptr), "vs_bn_act_bwd_gsum: pass both sums or neither");
     VS_CHECK_ARG(dy && x && mean && invstd && gamma && beta && dgamma && dbeta && dx && B > 0 && C > 0 && HW > 0 && groups >= 1 &&
                      B % groups == 0, "vs_bn_act_bwd: bad argument");
     const int w_ = x_dtype == VS_F32 ? 4 : 8;
@@ -957,6 +990,11 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
             else VS_BN_SMALL(8);
 #undef VS_BN_SMALL
             VS_CHECK_LAUNCH("vs_bn_act_bwd (small slabs)");
+            if (dbeta_sum) {
+                hipLaunchKernelGGL(group_sum2_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dbeta, dgamma, groups, C, dbeta_sum,
+                                   dgamma_sum);
+                VS_CHECK_LAUNCH("vs_bn_act_bwd (group sums)");
+            }
             return VS_OK;
         }
     }
@@ -966,7 +1004,7 @@ extern "C" int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_
     VS_CHECK_LAUNCH("vs_bn_act_bwd reduce");
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(vec == 1 && x_dtype == dy_dtype ? total / 8 : total / 4)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, x_dtype, mean, invstd,
-                       gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, HW, total, training, vec);
+                       gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, HW, total, training, vec, dbeta_sum, dgamma_sum, groups);
     VS_CHECK_LAUNCH("vs_bn_act_bwd apply");
     return VS_OK;
 }

@@ -67,9 +67,18 @@ _FOLD = {'task': None, 'acc': {}}
 _DEFER_W = {'slots': {}, 'queued': False}
 
 
-def _defer_wgrad_ok(dz, transposed, stride):
+def mark_repeated(weights):
+    """Tell the weight-gradient machinery that these convolution weights are applied MANY times per step (the integrator's blocks:
+    once per predicted frame): only such weights have their (dz, x) pairs remembered and their gradient computed once per step."""
+    for w in weights:
+        w._vs_repeated = True
+
+
+def _defer_wgrad_ok(w, dz, transposed, stride):
+    # (a weight that is used once or twice per step -- encoder / decoder layers -- gains nothing from the batching and would pay a
+    # zero-filled buffer and, for calls of different batch sizes, a concatenation)
     return (_STATE.get('fold_grads') and os.environ.get('VARSEP_DEFER_WGRADS', '1') == '1' and not transposed and stride == 1
-            and dz.shape[0] * dz.shape[2] * dz.shape[3] <= 16384 and not torch.is_grad_enabled())
+            and getattr(w, '_vs_repeated', False) and dz.shape[0] * dz.shape[2] * dz.shape[3] <= 16384 and not torch.is_grad_enabled())
 
 
 def flush_deferred_wgrads():
@@ -89,6 +98,32 @@ def flush_deferred_wgrads():
                 dz = torch.cat([p[0] for p in pairs], dim=0)
                 xc = torch.cat([p[1] for p in pairs], dim=0)
             ops.conv_wgrad(dz, xc, slot['shape'], slot['stride'], slot['pad'], False, into=slot['g'])
+
+
+# Exactly-zero gradients (a convolution bias in front of a training-mode BatchNorm: the batch mean removes it) still have to be handed to
+# autograd as tensors.  One `zeros_like` each is a 4 us fill launch per convolution and step (TaxiBJ: 67 per step); here they are
+# slices of ONE zero-filled pool per backward pass (sized from the previous pass), each slice a tensor of its own, so autograd keeps it
+# as the parameter's gradient without cloning.  Nothing ever writes into such a gradient (later contributions of the pass are dropped
+# as exact zeros too, and optimizers only read gradients).
+_ZERO_POOL = {'task': None, 'buf': None, 'off': 0, 'need': 0, 'last': 0}
+
+
+def zero_grad_like(p):
+    task = torch._C._current_graph_task_id()
+    zp = _ZERO_POOL
+    n = p.numel()
+    if zp['task'] != task:
+        zp['last'] = max(zp['last'], zp['need'])
+        zp.update(task=task, buf=None, off=0, need=0)
+    zp['need'] += n
+    if p.dtype != torch.float32 or task == -1:
+        return torch.zeros_like(p)
+    if zp['buf'] is None or zp['buf'].device != p.device or zp['off'] + n > zp['buf'].numel():
+        zp['buf'] = torch.zeros(max(zp['last'], 4 * n, 1024), dtype=torch.float32, device=p.device)
+        zp['off'] = 0
+    out = zp['buf'][zp['off']:zp['off'] + n].view(p.shape)
+    zp['off'] += n
+    return out
 
 
 def _fold_slots():
@@ -823,7 +858,7 @@ def _conv_weight_grad(w, dz, xc, stride, pad, transposed, k4s2=None):
             ops.conv_k4s2_wgrad(k4s2[0], k4s2[1], w.shape, into=first_w)
             return None
         return ops.conv_k4s2_wgrad(k4s2[0], k4s2[1], w.shape)
-    if _defer_wgrad_ok(dz, transposed, stride):
+    if _defer_wgrad_ok(w, dz, transposed, stride):
         slot = _DEFER_W['slots'].get(id(w))
         if slot is None:
             if first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
@@ -895,6 +930,37 @@ def packed_img_weight(p, dtype, flip):
         _packed_img[key] = (p._version, buf, p)
         return buf
     return ent[1]
+
+
+def prepack_conv3_weights(net, dtype=None):
+    """Bring the row-band / few-maps pre-packs (forward and flipped) of every 3x3 stride-1 pad-1 convolution of `net` up to date with ONE
+    launch per 96 packs (instead of one launch per pack at its first use: 36-67 launches per TaxiBJ / SST step, every step, because the
+    optimizer changes every weight).  Called by the training step right before the forward pass; what is not stale is skipped, and a
+    weight the kernels cannot take (input channels not a multiple of 16) is left to its own route."""
+    import torch.nn as nn
+    dtype = dtype or compute_dtype()
+    if dtype == torch.float32:
+        return 0
+    stale = []
+    for m in net.modules():
+        if not (isinstance(m, nn.Conv2d) and tuple(m.kernel_size) == (3, 3) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (1, 1) and m.groups == 1):
+            continue
+        p = m.weight
+        if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+            continue
+        for flip in (False, True):
+            K = p.shape[0] if flip else p.shape[1]
+            if K < 16 or K % 16 != 0:
+                continue
+            key = (id(p), dtype, flip)
+            ent = _packed_img.get(key)
+            if ent is None or ent[0] != p._version or ent[2] is not p:
+                stale.append((key, p, flip, ent[1] if ent is not None and ent[2] is p else None))
+    if stale:
+        bufs = ops.conv3_img16_pack_weights([(p.detach(), flip, buf) for _, p, flip, buf in stale], dtype)
+        for (key, p, _, _), buf in zip(stale, bufs):
+            _packed_img[key] = (p._version, buf, p)
+    return len(stale)
 
 
 def conv_res_block_fusable(x, convs, bns, cdt=None):
@@ -989,7 +1055,7 @@ class ConvResBlockFn(torch.autograd.Function):
             db = None
             if b is not None and b.requires_grad:
                 # exactly zero in front of a training-mode BatchNorm (see ConvBlock.backward)
-                db = None if ((fold and id(b) in _fold_slots()) or conv_grad_output(b) is not None) else torch.zeros_like(b)
+                db = None if ((fold and id(b) in _fold_slots()) or conv_grad_output(b) is not None) else zero_grad_like(b)
             dw = _conv_weight_grad(w, dz, h, 1, 1, False) if w.requires_grad else None
             grads[4 * li:4 * li + 4] = _fold_param_grads(((w, dw), (b, db), (gm, dgamma), (bt, dbeta)))
             if li > 0 or ctx.x_needs_grad:
@@ -1198,7 +1264,7 @@ class ConvBlock(torch.autograd.Function):
             # the reference returns fp32 summation noise there, we return the exact value without a reduction pass
             if has_bn and training:
                 # exactly zero: nothing to add once the parameter has a pending gradient in this pass
-                db = None if ((_STATE.get('fold_grads') and id(b) in _fold_slots()) or conv_grad_output(b) is not None) else torch.zeros_like(b)
+                db = None if ((_STATE.get('fold_grads') and id(b) in _fold_slots()) or conv_grad_output(b) is not None) else zero_grad_like(b)
             else:
                 db = ops.chan_sum(dz)
         x_shape = ctx.x_shape

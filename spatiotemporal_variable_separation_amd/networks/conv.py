@@ -326,6 +326,10 @@ class ConvResBlock(nn.Module):
         self.up = _c3(in_c, out_c, activation='none') if in_c != out_c else nn.Identity()
 
     def forward(self, x):
+        if not getattr(self, '_marked', False):
+            # the integrator applies this block once per predicted frame: its weight gradients are batched over the step's calls
+            VF.mark_repeated([m.weight for m in self.modules() if isinstance(m, nn.Conv2d)])
+            self._marked = True
         if isinstance(self.up, nn.Identity) and torch.is_grad_enabled():
             # a few 16x16 maps in a 16-bit compute type (the SST integrator): the whole block as 6 launches forward / 7 backward
             layers = [m for m in _flatten_modules(self.conv, []) if not isinstance(m, nn.Identity)]

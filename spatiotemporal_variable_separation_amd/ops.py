@@ -633,8 +633,8 @@ def conv_k4s2_gather(planes, w_packed, bias, M, out_dtype, role='fwd'):
     B, C4, H, W = planes.shape
     y = torch.empty((B, M, H, W), dtype=out_dtype, device=planes.device)
     e0 = _pb()
-    check(_lib.load_library().vs_conv3_band(dtype_code(planes), planes.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, C4, H, W,
-                                            M, stream_ptr()), 'vs_conv3_band (k4 s2 planes)')
+    check(_lib.load_library().vs_conv_k4s2_band(dtype_code(planes), planes.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, C4 // 4,
+                                                H, W, M, stream_ptr()), 'vs_conv_k4s2_band')
     # algorithmic work of the 4x4 window: 16 taps x K channels (the zero taps of the 3x3 form are not counted)
     _pe(e0, 'vs_conv_k4s2:%s<%s>' % (role, _DT[dtype_code(planes)]), flops=2.0 * B * H * W * M * (C4 // 4) * 16,
         nbytes=float(planes.numel() * planes.element_size() + M * (C4 // 4) * 16 * 2 + y.numel() * y.element_size()))
@@ -656,8 +656,8 @@ def conv_k4s2_wgrad(small, planes, w_shape, into=None, out=None):
     n3 = M * 4 * K * 9
     slabs = torch.empty((nslabs, n3), dtype=torch.float32, device=small.device)
     e0 = _pb()
-    check(lib.vs_conv3_wgrad_band(dtype_code(planes), planes.data_ptr(), small.data_ptr(), slabs.data_ptr(), B, 4 * K, H, W, M, stream_ptr()),
-          'vs_conv3_wgrad_band (k4 s2 planes)')
+    check(lib.vs_conv_k4s2_wgrad_band(dtype_code(planes), planes.data_ptr(), small.data_ptr(), slabs.data_ptr(), B, K, H, W, M, stream_ptr()),
+          'vs_conv_k4s2_wgrad_band')
     src, n = slabs, nslabs
     if nslabs > 24:
         src = torch.empty((16, n3), dtype=torch.float32, device=small.device)
@@ -745,6 +745,27 @@ def conv3_img16_pack_weight(w_master, dtype, flip, out=None):
     check(lib.vs_conv3_img16_pack_weight(code_of(dtype), w_master.data_ptr(), K, M, int(bool(flip)), out.data_ptr(), stream_ptr()),
           'vs_conv3_img16_pack_weight')
     return out
+
+
+def conv3_img16_pack_weights(jobs, dtype):
+    """jobs = [(w_master fp32 [Cout, Cin, 3, 3] contiguous, flip, out buffer or None)] -> list of packed buffers, ONE launch per 96 jobs."""
+    import ctypes
+    lib = _lib.load_library()
+    outs = []
+    for w, flip, buf in jobs:
+        Cout, Cin = w.shape[0], w.shape[1]
+        M, K = (Cin, Cout) if flip else (Cout, Cin)
+        if buf is None:
+            buf = torch.empty((lib.vs_conv3_img16_packed_elems(K, M),), dtype=dtype, device=w.device)
+        outs.append((w, int(bool(flip)), buf, M, K))
+    for i in range(0, len(outs), 96):
+        chunk = outs[i:i + 96]
+        n = len(chunk)
+        VP, I32 = ctypes.c_void_p * n, ctypes.c_int32 * n
+        check(lib.vs_conv3_img16_pack_weights(code_of(dtype), n, VP(*[c[0].data_ptr() for c in chunk]), I32(*[c[4] for c in chunk]),
+                                              I32(*[c[3] for c in chunk]), I32(*[c[1] for c in chunk]), VP(*[c[2].data_ptr() for c in chunk]),
+                                              stream_ptr()), 'vs_conv3_img16_pack_weights')
+    return [c[2] for c in outs]
 
 
 def conv3_img16(x, w_packed, Cout, role='fwd'):
@@ -960,23 +981,25 @@ def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype, groups=1):
 
 
 def bn_act_bwd(dy, x, mean, invstd, gamma, beta, act, training, out_dtype, groups=1):
-    """Returns (dx, dgamma [C], dbeta [C]) -- per-group sums are reduced over the groups here."""
+    """Returns (dx, dgamma [C], dbeta [C]) -- the per-call-group sums are added up by the kernel itself (vs_bn_act_bwd_gsum)."""
     require_cuda(dy, x)
     dy = dy.contiguous()
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
-    dgamma = torch.empty((groups, C), dtype=torch.float32, device=x.device)
-    dbeta = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+    per_group = torch.empty((2, groups, C), dtype=torch.float32, device=x.device)
+    dgamma, dbeta = per_group[0], per_group[1]
+    sums = torch.empty((2, C), dtype=torch.float32, device=x.device) if groups > 1 else None
     dx = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     e0 = _pb()
-    check(_lib.load_library().vs_bn_act_bwd(dy.data_ptr(), dtype_code(dy), x.data_ptr(), dtype_code(x), mean.data_ptr(),
-                                            invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], int(bool(training)),
-                                            groups, dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), dtype_code(dx), B, C, HW,
-                                            stream_ptr()), 'vs_bn_act_bwd')
+    check(_lib.load_library().vs_bn_act_bwd_gsum(dy.data_ptr(), dtype_code(dy), x.data_ptr(), dtype_code(x), mean.data_ptr(),
+                                                 invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], int(bool(training)),
+                                                 groups, dgamma.data_ptr(), dbeta.data_ptr(), dx.data_ptr(), dtype_code(dx), B, C, HW,
+                                                 _ptr(sums[0]) if sums is not None else 0, _ptr(sums[1]) if sums is not None else 0,
+                                                 stream_ptr()), 'vs_bn_act_bwd')
     _pe(e0, 'vs_bn_act_bwd', nbytes=float(x.numel() * (2 * x.element_size() + 2 * dy.element_size() + dx.element_size())))
     if groups == 1:
         return dx, dgamma[0], dbeta[0]
-    return dx, dgamma.sum(0), dbeta.sum(0)
+    return dx, sums[0], sums[1]
 
 
 def chan_sum(x):

@@ -396,7 +396,13 @@ def conv_gradient_sinks(sep_net, grad_sync):
     owned = {id(p) for p in grad_sync.params}
     # weights whose gradient may be completed by the end-of-backward flush of the batched weight gradients (functional._DEFER_W:
     # stride-1 Conv2d): their buckets are not reduced from gradient hooks
-    late = [m.weight for m in sep_net.modules() if isinstance(m, nn.Conv2d) and tuple(m.stride) == (1, 1) and id(m.weight) in owned]
+    from .networks.conv import ConvResBlock
+    for blk in sep_net.modules():
+        if isinstance(blk, ConvResBlock):
+            VF.mark_repeated([m.weight for m in blk.modules() if isinstance(m, nn.Conv2d)])
+            blk._marked = True
+    late = [m.weight for m in sep_net.modules() if isinstance(m, nn.Conv2d) and tuple(m.stride) == (1, 1) and id(m.weight) in owned
+            and getattr(m.weight, '_vs_repeated', False)]
     if late and hasattr(grad_sync, 'hold_params'):
         grad_sync.hold_params(late)
     return {p: p.grad for p in VF.conv_parameters(sep_net) if id(p) in owned and p.grad is not None}
@@ -457,6 +463,7 @@ def enable_fused_update(optimizer, sep_net, grad_sync=None, scaler=None, min_num
         return False
     if grad_sync is not None or scaler is not None or not _mlp_family(sep_net) or len(optimizer.param_groups) != 1 or optimizer._buckets:
         return False
+    min_numel = int(os.environ.get('VARSEP_FUSE_ADAM_MIN', min_numel))
     big = [p for p in chain_weight_parameters(sep_net) if p.numel() >= min_numel]
     if not big:
         return False
@@ -595,6 +602,9 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
     if cond.is_cuda and _mlp_family(sep_net):
         return _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset, lamb_ae, lamb_s, lamb_t,
                                            lamb_pred, average_tloss, t_random)
+    if cond.is_cuda and torch.is_grad_enabled() and os.environ.get('VARSEP_PREPACK_CONV', '1') == '1':
+        from . import functional as VF
+        VF.prepack_conv3_weights(sep_net)            # every stale 3x3 weight pre-pack of the step in one launch
     full_data = torch.cat([cond, target], dim=1)
     pairs = (cond.is_cuda and getattr(sep_net, 'fused', False) and getattr(sep_net.Es, 'call_groups', False)
              and getattr(sep_net.Et, 'call_groups', False) and os.environ.get('VARSEP_ENCODER_PAIRS', '1') == '1')

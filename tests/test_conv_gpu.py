@@ -632,3 +632,26 @@ def test_conv_k4s2_on_parity_planes_matches_fp64(dtype, geom):
     torch.cuda.synchronize()
     assert ((dx.cpu().double() - i64.grad).abs().max() / i64.grad.abs().max()).item() < 1e-5
     assert ((dwt.cpu().double() - wt64.grad).abs().max() / wt64.grad.abs().max()).item() < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_conv3_pack_weights_in_one_launch_equals_single_packs(dtype):
+    """vs_conv3_img16_pack_weights (all the stale pre-packs of a step in one launch) == vs_conv3_img16_pack_weight job by job, bit for bit,
+    forward and flipped, ragged row tiles included."""
+    from spatiotemporal_variable_separation_amd import ops
+    shapes = [(64, 64), (40, 128), (196, 256), (512, 64), (33, 16), (128, 192)]
+    ws = [_rand((co, ci, 3, 3), 400 + i, 0.3).cuda() for i, (co, ci) in enumerate(shapes)]
+    jobs, want = [], []
+    for w in ws:
+        for flip in (False, True):
+            K = w.shape[0] if flip else w.shape[1]
+            if K % 16:
+                continue
+            jobs.append((w, flip, None))
+            want.append(ops.conv3_img16_pack_weight(w, dtype, flip))
+    got = ops.conv3_img16_pack_weights(jobs, dtype)
+    torch.cuda.synchronize()
+    assert len(got) == len(want) >= 9
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a.view(torch.int16), b.view(torch.int16))

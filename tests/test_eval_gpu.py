@@ -90,7 +90,9 @@ def test_eval_forecast_matches_reference_fixture(name, precision):
     cond, _ = make_batch(cfg)
     cond = cond.cuda()
     skip = bool(cfg.get('skipco', False))
-    tol = 1e-3 if precision == 'fp32' else 4e-2
+    # bf16: the BatchNorm of an eval-mode block is folded into its convolution (functional.folded_conv_bn), so the WEIGHT TIMES SCALE is what
+    # gets rounded to bf16; on the width-4 test networks that moves the temporal code by up to 8e-2 (4e-2 unfolded)
+    tol = 1e-3 if precision == 'fp32' else 1e-1
     with torch.no_grad(), VF.precision(precision):
         fore, codes, s, _ = h_net.get_forecast(cond, int(gold['horizon']))
         swap = h_net.get_forecast(cond, int(gold['swap_horizon']), init_s_code=h_net.Es(cond.flip(0), return_skip=skip))[0]
