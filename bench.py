@@ -477,12 +477,19 @@ def main():
         for name in [e for e in extra.split(',') if e]:
             st, wu = EXTRA_STEPS.get(name, (5, 2))
             wname, prec = split_workload(name, args.precision)
+            err = None
             try:
                 r = run_workload(wname, args, rk, st, wu, 3, precision=prec)
             except Exception as e:          # one workload failing must not take the headline line down; it is reported
-                if rk.ddp:
-                    raise                    # (with several ranks a rank that skips a workload would leave the others in its collectives)
-                configs[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+                err = '%s: %s' % (type(e).__name__, str(e)[:300])
+            if rk.ddp:
+                # every rank reaches this point (a failure that is deterministic in the code path hits all of them alike); the workload
+                # counts only if it succeeded everywhere
+                bad = rk.max_over_ranks(1.0 if err else 0.0)
+                if bad and not err:
+                    err = 'failed on another rank'
+            if err:
+                configs[name] = {'error': err}
                 continue
             c = r['cfg']
             rf, oth = rooflines(r, wname, prec, top=4)
