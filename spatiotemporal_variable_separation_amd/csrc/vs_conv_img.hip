@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned s
 // MFMAs: 32 instead of 72 MFMAs per phase and wave.
 template <int CT, int W, int AHEAD, int MINB, int K4 = 0>
 __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
-                                                         void* __restrict__ Y, int yd, int B, int Cin, int H, int Cout, int mtiles, int bands) {
+                                                         void* __restrict__ Y, int yd, int B, int Cin, int H, int Cout, int mtiles, int bands,
+                                                         int band_xcd_remap) {
     constexpr int NKY = K4 ? 2 : 3, NF = K4 ? 2 : 3, GPP = 4 * NKY;              // tap rows and fragments per group, groups per 64-channel phase
     static_assert(GPP % AHEAD == 0, "the fragment ring must divide the groups of a phase");
     // W >= 16: the tile is R = 256 / W rows of ONE map (`band` = which rows); W = 8: FOUR whole 8 x 8 maps (`band` = which four, b = 0)
@@ -192,6 +193,12 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
     constexpr int BUF = 64 * RP * W;                                             // elements per buffer
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [2][64 channels][IPB maps][RPI rows][W]
     int id = blockIdx.x;
+    if (band_xcd_remap) {
+        // the output-channel tiles of one band stage the SAME input rows: blocks are dealt round-robin over the 8 XCDs (observed, speed
+        // only), so give every XCD a contiguous range of logical ids (bijective for any grid) and the tiles of a band meet in one L2
+        const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
     const int mt = id % mtiles;
     id /= mtiles;
     const int band = id % bands, b = id / bands;
@@ -727,10 +734,14 @@ static int launch_band(int compute, const void* x, const void* w_packed, const f
     }
     const int mtiles = (int)vs_cdiv(Cout, 32), bands = W == 8 ? (int)vs_cdiv(B, 4) : H / R;
     const dim3 grid((unsigned)((int64_t)(W == 8 ? 1 : B) * bands * mtiles));
+    static const int xcd_remap = getenv("VS_BAND_XCD") ? atoi(getenv("VS_BAND_XCD")) : 1;
+    const int remap = xcd_remap && mtiles > 1 && grid.x >= 64;
     if (compute == VS_BF16)
-        hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands);
+        hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands,
+                           remap);
     else
-        hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands);
+        hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands,
+                           remap);
     return VS_OK;
 }
 
