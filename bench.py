@@ -215,8 +215,13 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=N
     net.train()
     if rk.ddp:
         broadcast_module_state(net)
-    # 16-bit modes: gradients travel as bf16 (VARSEP_GRAD_COMM=fp32 keeps fp32 on the wire); reported in config.grad_allreduce
-    comm_bf16 = precision == 'bf16' and os.environ.get('VARSEP_GRAD_COMM', 'bf16') == 'bf16'
+    # Wire format of the gradient all-reduce (reported in config.grad_allreduce; VARSEP_GRAD_COMM=fp32 | bf16 overrides).  SURVEY 8e's
+    # contract is fp32 buckets (N replicas == the single-process step on the concatenated batch); the conv families keep it -- 102 / 63 MB
+    # per step against 12 / 23 ms of compute.  The WaveEq MLP's 243 MB would cost more on the wire than its 1.4 ms step, so in bf16 mode
+    # its gradients travel as bf16 (a stated deviation: the chains' weight-gradient GEMMs write the wire image themselves).
+    from spatiotemporal_variable_separation_amd.train import _mlp_family as _is_mlp
+    comm_default = 'bf16' if (precision == 'bf16' and _is_mlp(net)) else 'fp32'
+    comm_bf16 = precision == 'bf16' and os.environ.get('VARSEP_GRAD_COMM', comm_default) == 'bf16'
     direct = chain_weight_parameters(net) if (comm_bf16 and os.environ.get('VARSEP_GRAD_DIRECT_LOWP', '1') == '1') else None
     sync = GradAllReducer(net.parameters(), force=(rk.world == 1), comm_dtype=torch.bfloat16 if comm_bf16 else torch.float32,
                           lowp_direct=direct) if rk.ddp else None
