@@ -245,6 +245,19 @@ def _record_on(ws, inputs, outs):
             t.record_stream(ws)
 
 
+def _late_mode():
+    """VARSEP_FUSED_AFTER_ROLLOUT: '2' (default) = a held fused first-layer update (E_s's 20480 x 1200 weight-gradient + Adam launch: 640 MB
+    of HBM traffic) waits ON ITS OWN LANE for the integrator's backward kernel to finish and then runs beside E_t's input-gradient chain, which
+    leaves HBM idle (WaveEq step, same box: 1.4505 -> 1.4045 ms); '3' = every held fused update; '1' = on a stream of its own (2.95 ms: a
+    fourth gradient stream collides with the integrator's queue); '0' = released with the other held work under the integrator's kernel."""
+    return os.environ.get('VARSEP_FUSED_AFTER_ROLLOUT', '2')
+
+
+def _late_fused(layer):
+    m = _late_mode()
+    return (m in ('1', '2') and layer == 0) or m == '3'
+
+
 def run_deferred(fn, *inputs, outs=None, lane=0, late=False):
     """Run `fn()` (weight-gradient launches) on a gradient stream behind everything queued so far on the current stream.
     `outs`: the tensors `fn` writes, allocated by the caller -- required for the work to be holdable (hold_deferred); they are
@@ -280,11 +293,12 @@ def run_late(fn, *inputs, outs, lane=0):
     return outs
 
 
-def defer_call(fn):
-    """Queue `fn` (launches that consume held gradients, e.g. an optimizer bucket) behind ALL the held work; False if nothing is held."""
+def defer_call(fn, late=False):
+    """Queue `fn` (launches that consume held gradients, e.g. an optimizer bucket) behind ALL the held work; False if nothing is held.
+    `late`: additionally behind the event recorded after the integrator's backward kernel (release_deferred(late_after=...))."""
     if not deferred_held():
         return False
-    _SIDE['held'].append((fn, (), (), None))
+    _SIDE['held'].append((fn, (), (), 'all-late' if late else None))
     return True
 
 
@@ -298,18 +312,22 @@ def release_deferred(after=None, late_after=None):
     main = _SIDE['hold_main'] if (was and _SIDE['hold_main'] is not None) else torch.cuda.current_stream()
     started = set()
     for fn, inputs, outs, lane in held:
-        if isinstance(lane, tuple):            # ('late', lane): behind the event `late_after` (recorded after the integrator's kernel), own stream
-            ws = _lane_stream(N_LANES)
-            if 'late' not in started:
+        if isinstance(lane, tuple):            # ('late', lane): behind the event `late_after` (recorded after the integrator's kernel)
+            own = _late_mode() == '1'          # '1': a stream of its own; '2': the closure's own lane
+            key = 'late' if own else lane[1]
+            ws = _lane_stream(N_LANES) if own else _lane_stream(lane[1])
+            if key not in started:
                 ws.wait_stream(main)
-                if late_after is not None:
-                    ws.wait_event(late_after)
-                started.add('late')
+                if after is not None and not own:
+                    ws.wait_event(after)
+                started.add(key)
+            if late_after is not None:
+                ws.wait_event(late_after)
             with torch.cuda.stream(ws):
                 fn()
             _record_on(ws, inputs, outs)
             continue
-        if lane is None:                       # consumes everything released so far: lane 0 behind the other lanes
+        if lane is None or lane == 'all-late':  # consumes everything released so far: lane 0 behind the other lanes
             ws = _lane_stream(0)
             if 0 not in started:
                 ws.wait_stream(main)
@@ -317,6 +335,8 @@ def release_deferred(after=None, late_after=None):
             for l in started:
                 if l != 0 and l != 'late':
                     ws.wait_stream(_lane_stream(l))
+            if lane == 'all-late' and late_after is not None:
+                ws.wait_event(late_after)
         else:
             ws = _lane_stream(lane)
             if lane not in started:
@@ -618,7 +638,7 @@ class MLPChain(torch.autograd.Function):
                         dx = ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=torch.float32)
                     # the weight-gradient GEMM's epilogue IS this weight's optimizer step; nothing is stored, autograd gets nothing
                     run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, W=W, fused=fused: fused.fused_update(W, dz, S, h_in, S, N, K, M),
-                                 dz, h_in, outs=(), lane=lane, late=(l == 0 and os.environ.get('VARSEP_FUSED_AFTER_ROLLOUT') == '1'))
+                                 dz, h_in, outs=(), lane=lane, late=_late_fused(l))
                 elif dst is not None:           # straight into the all-reduce bucket; autograd gets nothing for this parameter
                     # (holdable like the single-GPU path: the destination exists already)
                     run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, dst=dst: ops.gemm(dz, S, h_in, S, N, K, M, out=dst), dz, h_in,
@@ -736,7 +756,7 @@ class MLPRollout(torch.autograd.Function):
             ready.record()
         dx0, dr, dh2, dh1 = ops.mlp_rollout_bwd(g_codes, wts, h1, h2, m1, m2, n_steps)
         done = None
-        if ready is not None and os.environ.get('VARSEP_FUSED_AFTER_ROLLOUT') == '1':
+        if ready is not None and (_late_mode() in ('1', '2', '3') or os.environ.get('VARSEP_ADAM_EARLY_BUCKET') == '2'):
             done = torch.cuda.Event()
             done.record()
         release_deferred(after=ready, late_after=done)

@@ -94,7 +94,7 @@ class Adam(torch.optim.Optimizer):
         self._init_group(0, group)
         from . import functional as VF
         bg = int(os.environ.get('VARSEP_ADAM_BG_BLOCKS', '512'))
-        if VF.defer_call(lambda: self._update(0, group, self._buckets[bi], max_blocks=bg)):
+        if VF.defer_call(lambda: self._update(0, group, self._buckets[bi], max_blocks=bg), late=os.environ.get('VARSEP_ADAM_EARLY_BUCKET') == '2'):
             # the bucket's weight gradients are being held back (functional.hold_deferred): the update joins that queue and runs
             # on the gradient stream right behind them; step() joins that stream like any deferred gradient work
             self._launched.add(bi)

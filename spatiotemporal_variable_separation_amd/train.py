@@ -429,7 +429,7 @@ def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False, s
     # Opt-in (VARSEP_ADAM_OVERLAP=1): on the WaveEq step it is a wash (1.898 vs 1.891 ms) -- the update and E_t's backward
     # (98 MB of fp32 weight gradient per encoder) compete for the same HBM bandwidth, both just run slower side by side.
     from .optim import Adam as HipAdam
-    early_only = os.environ.get('VARSEP_ADAM_EARLY_BUCKET') == '1'
+    early_only = os.environ.get('VARSEP_ADAM_EARLY_BUCKET') in ('1', '2')
     if not force and os.environ.get('VARSEP_ADAM_OVERLAP') != '1' and not early_only:
         return
     if scaler is not None:
