@@ -194,8 +194,24 @@ N_LANES = max(1, int(os.environ.get('VARSEP_WGRAD_LANES', '3')))
 def enable_side_streams(flag):
     _SIDE['on'] = bool(flag)
     _SIDE['next_lane'] = 0
+    _SIDE['markers'] = {}
     if not flag:
         _SIDE['hold'], _SIDE['held'], _SIDE['late'] = False, [], []
+
+
+def tail_fused_updates():
+    """Default (VARSEP_ADAM_UNDER_FUSED=0 disables; WaveEq step, same box: 1.406-1.415 -> 1.378 ms): a chain's fused first-layer update (the 640 MB weight-gradient + Adam launches of the WaveEq encoders) is
+    issued LAST on its lane, behind the chain's bias sums and a marker event; the optimizer launch for the remaining parameters then waits
+    for the markers only and runs beside the fused updates (disjoint parameters; the step counter is advanced after the full join)."""
+    return os.environ.get('VARSEP_ADAM_UNDER_FUSED', '1') == '1'
+
+
+def _lane_marker(lane):
+    def fn():
+        ev = torch.cuda.Event()
+        ev.record()
+        _SIDE['markers'][lane] = ev
+    return fn
 
 
 def side_streams_enabled():
@@ -449,10 +465,19 @@ def side_streams_in_use():
     return (list(_SIDE['lanes']) + ([_SIDE['rollout']] if _SIDE['rollout'] is not None else [])) if _SIDE['on'] else []
 
 
-def join_side_streams():
-    """Make the current stream wait for all deferred gradient work (call before the optimizer step)."""
+def finish_join(pending):
+    """Second half of join_side_streams(partial=True): wait for the lanes whose fused updates were still running."""
+    cur = torch.cuda.current_stream()
+    for ws in pending or ():
+        cur.wait_stream(ws)
+
+
+def join_side_streams(partial=False):
+    """Make the current stream wait for all deferred gradient work (call before the optimizer step).  `partial`: on lanes that recorded a
+    marker in front of a trailing fused update (tail_fused_updates) wait for the marker only and return those lanes: the caller runs the
+    optimizer launch for the other parameters and then calls finish_join()."""
     if not _SIDE['on']:
-        return          # nothing was deferred; waiting on a stream outside the running capture would break the capture
+        return []       # nothing was deferred; waiting on a stream outside the running capture would break the capture
     release_deferred()  # (a step without the integrator's backward never reached the release point)
     late, _SIDE['late'] = _SIDE['late'], []
     for fn, inputs, outs, lane, producer in late:
@@ -462,10 +487,19 @@ def join_side_streams():
             fn()
         _record_on(ws, inputs, outs)
     cur = torch.cuda.current_stream()
-    for ws in _SIDE['lanes']:
-        cur.wait_stream(ws)
+    pending = []
+    markers = _SIDE.get('markers') or {}
+    for i, ws in enumerate(_SIDE['lanes']):
+        ev = markers.get(i) if partial else None
+        if ev is not None:
+            cur.wait_event(ev)
+            pending.append(ws)
+        else:
+            cur.wait_stream(ws)
+    _SIDE['markers'] = {}
     if _SIDE['rollout'] is not None:
         cur.wait_stream(_SIDE['rollout'])
+    return pending
 
 
 # ------------------------------------------------------------------------------------------------ weight shadows
@@ -616,6 +650,7 @@ class MLPChain(torch.autograd.Function):
         dx = None
         lane = next_lane()                   # this chain's weight / bias gradients: one gradient stream, in order
         bias_jobs = []                       # (slot, dz): all bias gradients of the chain in one launch at the end
+        tail_job = None
         for l in range(L - 1, -1, -1):
             W, b = params[2 * l], params[2 * l + 1]
             N, K = W.shape
@@ -637,8 +672,11 @@ class MLPChain(torch.autograd.Function):
                     elif ctx.x_needs_grad:
                         dx = ops.gemm(dz, R, shadow(W, cdt), S, M, K, N, out_dtype=torch.float32)
                     # the weight-gradient GEMM's epilogue IS this weight's optimizer step; nothing is stored, autograd gets nothing
-                    run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, W=W, fused=fused: fused.fused_update(W, dz, S, h_in, S, N, K, M),
-                                 dz, h_in, outs=(), lane=lane, late=_late_fused(l))
+                    job = (lambda dz=dz, h_in=h_in, N=N, K=K, W=W, fused=fused: fused.fused_update(W, dz, S, h_in, S, N, K, M), (dz, h_in))
+                    if l == 0 and _SIDE['on'] and tail_fused_updates():
+                        tail_job = job                   # issued behind the chain's bias sums and a marker (see tail_fused_updates)
+                    else:
+                        run_deferred(job[0], *job[1], outs=(), lane=lane, late=_late_fused(l))
                 elif dst is not None:           # straight into the all-reduce bucket; autograd gets nothing for this parameter
                     # (holdable like the single-GPU path: the destination exists already)
                     run_deferred(lambda dz=dz, h_in=h_in, N=N, K=K, dst=dst: ops.gemm(dz, S, h_in, S, N, K, M, out=dst), dz, h_in,
@@ -668,6 +706,9 @@ class MLPChain(torch.autograd.Function):
                 grads[slot] = db
             views = ops.colsum_alloc(dzs, flat)[1]       # the closure's own views (see the weight gradients above)
             run_deferred(lambda views=views: ops.colsum_multi(dzs, outs=views, zero_flat=flat), *dzs, outs=flat, lane=lane)
+        if tail_job is not None:
+            run_deferred(_lane_marker(lane), outs=(), lane=lane)
+            run_deferred(tail_job[0], *tail_job[1], outs=(), lane=lane, late=_late_fused(0))
         return (dx, None, None, None) + tuple(grads)
 
 

@@ -151,14 +151,18 @@ class Adam(torch.optim.Optimizer):
         return tab
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale_state=None):
+    def step(self, closure=None, grad_scale_state=None, defer_increment=False):
         """`grad_scale_state` (train.LossScaler.state, fp32 [scale, found_inf, ...] on the device): gradients are used as g / scale and
         the whole step -- parameters, moments, step count -- is skipped when found_inf is set (GradScaler.step semantics)."""
         self._scale_state = grad_scale_state
+        # defer_increment: the caller advances the step counter itself with finish_step() -- updates fused into weight-gradient GEMMs that are
+        # still running read the counter, so it may only move once they are done
+        self._defer_increment = bool(defer_increment) and grad_scale_state is None
         try:
             return self._step(closure)
         finally:
             self._scale_state = None
+            self._defer_increment = False
 
     def _step(self, closure=None):
         loss = None
@@ -186,7 +190,7 @@ class Adam(torch.optim.Optimizer):
             if getattr(self, '_scale_state', None) is not None:
                 _lib.check(lib.vs_adam_step_increment_scaled(group['step_dev'].data_ptr(), self._scale_state.data_ptr(), main.cuda_stream),
                            'vs_adam_step_increment_scaled')
-            else:
+            elif not getattr(self, '_defer_increment', False):
                 _lib.check(lib.vs_adam_step_increment(group['step_dev'].data_ptr(), main.cuda_stream), 'vs_adam_step_increment')
         if self._buckets:
             self._left = [len(b) for b in self._buckets]

@@ -315,8 +315,16 @@ class GraphedStep:
                     self._opt_step()
 
     def _opt_step(self):
+        from . import functional as VF
+        pending, self._pending_join = getattr(self, '_pending_join', None), None
         if self.scaler is not None:
             self.scaler.step(self.opt)               # finite check, unscale inside the update, skip on overflow, scale update
+        elif pending:
+            # the trailing fused updates (vs_gemm_adam of the encoders' first layers) are still running on their lanes: the launch for
+            # the remaining parameters runs beside them (disjoint parameters), the step counter both read moves after the full join
+            self.opt.step(defer_increment=True)
+            VF.finish_join(pending)
+            self.opt.finish_step()
         else:
             self.opt.step()
 
@@ -356,7 +364,10 @@ class GraphedStep:
                                                 l_t, l_pred, avg, t_random=self.t_dev)
             # a resident 1.0 (no ones_like fill per step), or the loss scale of fp16 training (train.py:152 scaler.scale(loss))
             total.backward(up)
-            VF.join_side_streams()
+            from .optim import Adam as HipAdam
+            partial = (self.sync is None and self.scaler is None and isinstance(self.opt, HipAdam)
+                       and bool(getattr(self.opt, '_fused', None)) and VF.tail_fused_updates())
+            self._pending_join = VF.join_side_streams(partial=partial)
         finally:
             VF.promise_loss_gradient(None)
             VF.enable_side_streams(False)
