@@ -238,6 +238,31 @@ int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* 
 int vs_bn_stats_from_sums(const double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* var_scratch,
                           float* running_mean, float* running_var, float momentum, float eps, void* stream);
 
+/* ---- convolutions between a map with many channels and the image side with 1..8 (csrc/vs_conv_thin.hip).  Replaces, for the first encoder
+ * layer and the last decoder layer of every convolutional family -- nn.Conv2d(nc, 64, 4, 2, 1) (reference networks/conv.py:119),
+ * nn.ConvTranspose2d(64, nc, 4, 2, 1) (conv.py:264-267), nn.Conv2d(nc, 64, 3, 1, 1) (conv.py:130-133, 345-350), nn.ConvTranspose2d(64, nc, 3, 1, 1)
+ * (conv.py:300-303), nn.Conv2d(64, nc, 3, 1, 1) (conv.py:420-426) -- the forward, input-gradient and weight-gradient calls whose GEMM form has a
+ * dimension of 1..8.  big [B][C][H][W], thin [B][M][S H][S W], (k, S) = (3, 1) or (4, 2), pad 1; a big pixel p = (y, x) meets the thin pixels
+ * S p + t - 1 = (S y + ty - 1, S x + tx - 1).  Weights are read from the caller's 16-bit tensor: element (c, m, t) at w[c w_sc + m w_sm + t'],
+ * t' = t, or k^2 - 1 - t with `flip` (a stride-1 Conv2d seen from its output side).
+ *   vs_conv_thin_expand   out_big[c][p] = bias[c] + sum_{m,t} thin[m][S p + t - 1] w(c, m, t)      Conv2d forward with few input channels (w_sc = M k^2,
+ *                         w_sm = k^2); ConvTranspose2d input gradient with few output channels (same strides); Conv2d k3 s1 input gradient with
+ *                         few output channels (w_sc = k^2, w_sm = C k^2, flip)
+ *   vs_conv_thin_reduce   out_thin[m][q] = bias[m] + sum_{c,t: S p + t - 1 = q} big[c][p] w(c, m, t)  ConvTranspose2d forward with few output channels
+ *                         (w_sc = M k^2, w_sm = k^2); Conv2d k3 s1 forward with few output channels (w_sc = k^2, w_sm = C k^2, flip); M <= 4 (k 3) / 2 (k 4)
+ *   vs_conv_thin_wgrad    out[c o_sc + m o_sm + t'] = (addend ? addend[..] : 0) + sum_{maps,p} big[c][p] thin[m][S p + t - 1]: both weight gradients
+ *                         (Conv2d few inputs: big = dz, o_sc = M k^2, o_sm = k^2; ConvTranspose2d few outputs: big = x, same strides; Conv2d k3 s1 few
+ *                         outputs: big = x, thin = dz, o_sc = k^2, o_sm = C k^2, flip); fp32 partials in `ws`, summed in a fixed order
+ * C a multiple of 32, W in {8, .., 128} dividing 512, H W a multiple of 512, 16-bit operands, 16-byte aligned.                            */
+int vs_conv_thin_supported(int compute, int B, int C, int H, int W, int M, int k, int stride, int pad);
+int vs_conv_thin_expand(int compute, const void* thin, const void* w, int64_t w_sc, int64_t w_sm, int flip, const float* bias, void* out, int out_dtype,
+                        int B, int C, int H, int W, int M, int k, int stride, void* stream);
+int vs_conv_thin_reduce(int compute, const void* big, const void* w, int64_t w_sc, int64_t w_sm, int flip, const float* bias, void* out, int out_dtype,
+                        int B, int C, int H, int W, int M, int k, int stride, void* stream);
+size_t vs_conv_thin_wgrad_workspace_bytes(int B, int C, int H, int W, int M, int k);
+int vs_conv_thin_wgrad(int compute, const void* big, const void* thin, float* ws, size_t ws_bytes, const float* addend, float* out, int64_t o_sc,
+                       int64_t o_sm, int flip, int B, int C, int H, int W, int M, int k, int stride, void* stream);
+
 /* Frame metrics of the evaluation scripts (test/mnist/test.py:136-142): for every plane pair (pred, target) [planes, H, W] fp32
  * mse[plane] = mean squared error (PSNR = 10 log10(1 / mse) follows on the host as in the reference) and ssim[plane] = mean over the
  * (H - 10) x (W - 10) "valid" window positions of the SSIM index of utils/ssim.py:81-111 (11 x 11 Gaussian window of the given
@@ -530,6 +555,10 @@ int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, int x_dtype,
                        const float* beta, int act, int training, int groups, float* dgamma, float* dbeta, void* dx, int dx_dtype, int B,
                        int C, int64_t HW, float* dgamma_sum, float* dbeta_sum, void* stream);
 int vs_chan_sum(const void* x, int x_dtype, int B, int C, int64_t HW, float* out, void* stream);
+/* the same sum with per-chunk partial sums in a workspace of vs_chan_sum_workspace_bytes: no atomics (a 1-channel map serialises 1024 of them on
+ * one address), fixed summation order */
+size_t vs_chan_sum_workspace_bytes(int B, int C, int64_t HW);
+int vs_chan_sum_ws(const void* x, int x_dtype, int B, int C, int64_t HW, void* ws, size_t ws_bytes, float* out, void* stream);
 int vs_maxpool2_fwd(const void* x, int x_dtype, void* y, int y_dtype, int64_t planes, int H, int W, void* stream);
 int vs_maxpool2_bwd(const void* x, int x_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype, int64_t planes, int H, int W,
                     void* stream);

@@ -14,7 +14,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvarsep_hip.so')
-SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip', 'vs_conv_tap.hip', 'vs_metrics.hip', 'vs_conv_img.hip', 'vs_conv_k4s2.hip']
+SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip', 'vs_conv_tap.hip', 'vs_metrics.hip', 'vs_conv_img.hip', 'vs_conv_k4s2.hip',
+           'vs_conv_thin.hip']
 
 F32, BF16, F16 = 0, 1, 2
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
@@ -150,6 +151,11 @@ SIGNATURES = {
     'vs_conv_k4s2_skip_form': (_i32, [_i32]),
     'vs_conv_k4s2_band': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vs_conv_k4s2_wgrad_band': (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'vs_conv_thin_supported': (_i32, [_i32] * 9),
+    'vs_conv_thin_expand': (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32] + [_i32] * 7 + [_vp]),
+    'vs_conv_thin_reduce': (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32] + [_i32] * 7 + [_vp]),
+    'vs_conv_thin_wgrad_workspace_bytes': (_sz, [_i32] * 6),
+    'vs_conv_thin_wgrad': (_i32, [_i32, _vp, _vp, _vp, _sz, _vp, _vp, _i64, _i64, _i32] + [_i32] * 7 + [_vp]),
     'vs_conv3_band_supported': (_i32, [_i32] * 6),
     'vs_conv3_band': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vs_conv3_wgrad_band_supported': (_i32, [_i32] * 6),
@@ -174,6 +180,8 @@ SIGNATURES = {
     'vs_bn_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     'vs_bn_act_bwd_gsum': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp]),
     'vs_chan_sum': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    'vs_chan_sum_workspace_bytes': (_sz, [_i32, _i32, _i64]),
+    'vs_chan_sum_ws': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _sz, _vp, _vp]),
     'vs_maxpool2_fwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
     'vs_maxpool2_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
     'vs_maxpool3s2_fwd': (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),

@@ -187,10 +187,13 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
                                                          int band_xcd_remap) {
     constexpr int NKY = K4 ? 2 : 3, NF = K4 ? 2 : 3, GPP = 4 * NKY;              // tap rows and fragments per group, groups per 64-channel phase
     static_assert(GPP % AHEAD == 0, "the fragment ring must divide the groups of a phase");
-    // W >= 16: the tile is R = 256 / W rows of ONE map (`band` = which rows); W = 8: FOUR whole 8 x 8 maps (`band` = which four, b = 0)
-    constexpr int IPB = W == 8 ? 4 : 1, RI = W == 8 ? 8 : 256 / W, RPI = RI + 2, RP = IPB * RPI, PW = W / 8;
-    constexpr int NP = 64 * RP * PW / 256;                                       // 16-byte pieces per thread and phase: 12 / 10 / 9 / 10
-    constexpr int BUF = 64 * RP * W;                                             // elements per buffer
+    // W >= 16: the tile is R = 256 / W rows of ONE map (`band` = which rows); W = 8: FOUR whole 8 x 8 maps (`band` = which four, b = 0);
+    // W = 4: SIXTEEN whole 4 x 4 maps.  A 16-byte piece then holds two rows, so a map is laid out as [2 zero rows][4 rows] (three pieces):
+    // the row above a map is its own zero piece, the row below it the zero piece of the NEXT map (one more zero piece closes each buffer)
+    constexpr int IPB = W == 8 ? 4 : (W == 4 ? 16 : 1), RI = W == 8 ? 8 : (W == 4 ? 4 : 256 / W), RPI = RI + 2, RP = IPB * RPI;
+    constexpr int ROW0 = W == 4 ? 1 : 0;                                         // rows between the start of a map's block and its row -1
+    constexpr int NP = 64 * RP * W / 8 / 256;                                    // 16-byte pieces per thread and phase: 12 / 12 / 10 / 9 / 10
+    constexpr int BUF = 64 * RP * W + (W == 4 ? 8 : 0);                          // elements per buffer
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [2][64 channels][IPB maps][RPI rows][W]
     int id = blockIdx.x;
     if (band_xcd_remap) {
@@ -210,17 +213,28 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
         char* dst = reinterpret_cast<char*>(xs + (ph & 1) * BUF);
 #pragma unroll
         for (int r = 0; r < NP; ++r) {
-            const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
-            const int y = (IPB == 1 ? band * RI : 0) + rr % RPI - 1;
-            const int img = IPB == 1 ? b : band * IPB + rr / RPI;
-            const void* g = (y >= 0 && y < H && img < B) ? (const void*)(X + ((((int64_t)img * Cin + ph * 64 + cl) * H + y) * W + pc * 8))
-                                                        : (const void*)vs_glds_zero;
+            const void* g;
+            if constexpr (W == 4) {
+                const int u = r * 256 + tid, pp = u % 3, mp = (u / 3) % IPB, cl = u / (3 * IPB);     // piece 0 of a map: its two zero rows
+                const int img = band * IPB + mp;
+                g = (pp != 0 && img < B) ? (const void*)(X + (((int64_t)img * Cin + ph * 64 + cl) * 16 + (pp - 1) * 8)) : (const void*)vs_glds_zero;
+            } else {
+                constexpr int PW = W / 8;
+                const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
+                const int y = (IPB == 1 ? band * RI : 0) + rr % RPI - 1;
+                const int img = IPB == 1 ? b : band * IPB + rr / RPI;
+                g = (y >= 0 && y < H && img < B) ? (const void*)(X + ((((int64_t)img * Cin + ph * 64 + cl) * H + y) * W + pc * 8))
+                                                 : (const void*)vs_glds_zero;
+            }
             // asm: the compiler orders a builtin LDS-DMA against every later LDS read with s_waitcnt vmcnt(0), which would also drain the
             // weight stream at every phase; the DMA is covered by the counted waits below instead (M0 has this one writer)
             const uint32_t d = (uint32_t)(uintptr_t)(dst + (r * 256 + wave * 64) * 16);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(g) : "memory", "m0");
         }
     };
+    if constexpr (W == 4) {
+        if (tid < (nph > 1 ? 2 : 1)) *reinterpret_cast<u32x4*>(xs + tid * BUF + 64 * RP * W) = u32x4{0u, 0u, 0u, 0u};     // the closing zero piece of each buffer
+    }
     dma(0);
 
     const int chunks_total = Cin >> 4;
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q0 = wave * 64 + j * 32 + 16 * cb + 4 * p, qi = q0 % (RI * W);
-        lofs[j] = ((8 * h + q) * RP + (q0 / (RI * W)) * RPI + qi / W) * W + qi % W;
+        lofs[j] = ((8 * h + q) * RP + (q0 / (RI * W)) * RPI + qi / W + ROW0) * W + qi % W;
     }
     const int ngroups = chunks_total * NKY;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // phase 0 (and the first fragments) have landed
@@ -307,8 +321,10 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
     const int l31 = lane & 31;
     const int idx_l = ((lane & 32) | ((lane - 1) & 31)) * 4, idx_r = ((lane & 32) | ((lane + 1) & 31)) * 4;
     const int mrow = mt * 32 + 4 * (lane >> 5);
-    const int oimg = IPB == 1 ? b : band * IPB + wave;                            // W = 8: wave w owns map w of the four
-    const int64_t obase = (int64_t)oimg * Cout * H * W + (IPB == 1 ? band * RI * W + wave * 64 : 0) + l31;
+    // W = 8: wave w owns map w of the four; W = 4: maps 4 w .. 4 w + 3 of the sixteen -- tile j holds two of them, lanes 0-15 / 16-31 one each
+    const int oimg = IPB == 1 ? b : (W == 4 ? band * IPB + wave * 4 + (l31 >> 4) : band * IPB + wave);
+    const int64_t obase = W == 4 ? (int64_t)oimg * Cout * 16 + (l31 & 15)
+                                 : (int64_t)oimg * Cout * H * W + (IPB == 1 ? band * RI * W + wave * 64 : 0) + l31;
     const int col0 = (wave * 64 + l31) % W, col1 = (wave * 64 + 32 + l31) % W;
     float bvs[16];
 #pragma unroll
@@ -330,7 +346,12 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
         const float left1 = col1 == 0 ? 0.f : (l31 != 0 ? rl[1] : rl[0]);
         const float right0 = col0 == W - 1 ? 0.f : (l31 != 31 ? rr[0] : rr[1]);
         const float right1 = (l31 != 31 && col1 != W - 1) ? rr[1] : 0.f;
-        if (m < Cout && oimg < B) {
+        if constexpr (W == 4) {
+            const float bv = bvs[v];
+            const int64_t o = obase + (int64_t)m * 16;
+            if (m < Cout && oimg < B) vs_st(Y, yd, o, acc[1][0][v] + left0 + right0 + bv);
+            if (m < Cout && oimg + 2 < B) vs_st(Y, yd, o + (int64_t)2 * Cout * 16, acc[1][1][v] + left1 + right1 + bv);
+        } else if (m < Cout && oimg < B) {
             const float bv = bvs[v];
             const int64_t o = obase + (int64_t)m * H * W;
             vs_st(Y, yd, o, acc[1][0][v] + left0 + right0 + bv);
@@ -707,9 +728,10 @@ extern "C" int vs_slab_sum(const float* slabs, int nslabs, const float* bias, co
     return VS_OK;
 }
 
-// ---- row-band form: many maps, W in {16, 32, 64} with H a multiple of 256 / W, or 8 x 8 maps; Cin a multiple of 64; y in any type, bias added --
+// ---- row-band form: many maps, W in {16, 32, 64} with H a multiple of 256 / W, or 8 x 8 / 4 x 4 maps; Cin a multiple of 64; y in any type, bias added --
 extern "C" int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W, int Cout) {
-    if (!vs_is16(compute) || (W != 8 && W != 16 && W != 32 && W != 64) || B < 1 || Cout < 1 || Cin < 64 || Cin % 64 != 0) return 0;
+    if (!vs_is16(compute) || (W != 4 && W != 8 && W != 16 && W != 32 && W != 64) || B < 1 || Cout < 1 || Cin < 64 || Cin % 64 != 0) return 0;
+    if (W == 4) return H == 4 && (int64_t)vs_cdiv(B, 16) * vs_cdiv(Cout, 32) < (1ll << 31);      // whole 4 x 4 maps, sixteen per workgroup
     if (W == 8) return H == 8 && (int64_t)vs_cdiv(B, 4) * vs_cdiv(Cout, 32) < (1ll << 31);       // whole 8 x 8 maps, four per workgroup
     const int R = 256 / W;
     if (H < R || H % R != 0) return 0;
@@ -717,23 +739,30 @@ extern "C" int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W
     return 1;
 }
 
+// bytes of one staged 64-channel phase (conv3_band_kernel's BUF)
+template <int W>
+constexpr size_t band_buf_bytes() {
+    constexpr int IPB = W == 8 ? 4 : (W == 4 ? 16 : 1), RI = W == 8 ? 8 : (W == 4 ? 4 : 256 / W);
+    return (size_t)(64 * IPB * (RI + 2) * W + (W == 4 ? 8 : 0)) * 2;
+}
+
 template <int W, int AHEAD, int MINB, int K4 = 0>
 static int launch_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
                        hipStream_t stream) {
-    constexpr int R = W == 8 ? 8 : 256 / W, RPT = (W == 8 ? 4 : 1) * (R + 2);
-    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * 64 * RPT * W * 2;            // one buffer when there is a single 64-channel phase
+    constexpr int R = W == 8 ? 8 : (W == 4 ? 4 : 256 / W), IPB = W == 8 ? 4 : (W == 4 ? 16 : 1);
+    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * band_buf_bytes<W>();         // one buffer when there is a single 64-channel phase
     auto kb = conv3_band_kernel<VS_BF16, W, AHEAD, MINB, K4>;
     auto kh = conv3_band_kernel<VS_F16, W, AHEAD, MINB, K4>;
     static bool attr_set = false;
     if (!attr_set) {
-        const int most = 2 * 64 * RPT * W * 2;
+        const int most = (int)(2 * band_buf_bytes<W>());
         if (hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess ||
             hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess)
             return vs_fail(VS_ERR_LAUNCH, "vs_conv3_band: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    const int mtiles = (int)vs_cdiv(Cout, 32), bands = W == 8 ? (int)vs_cdiv(B, 4) : H / R;
-    const dim3 grid((unsigned)((int64_t)(W == 8 ? 1 : B) * bands * mtiles));
+    const int mtiles = (int)vs_cdiv(Cout, 32), bands = IPB > 1 ? (int)vs_cdiv(B, IPB) : H / R;
+    const dim3 grid((unsigned)((int64_t)(IPB > 1 ? 1 : B) * bands * mtiles));
     static const int xcd_remap = getenv("VS_BAND_XCD") ? atoi(getenv("VS_BAND_XCD")) : 1;
     const int remap = xcd_remap && mtiles > 1 && grid.x >= 64;
     if (compute == VS_BF16)
@@ -750,8 +779,7 @@ template <int W>
 static int launch_band_k4_w(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
                             hipStream_t stream) {
     static const int pair_mode = getenv("VS_CONV_BAND_PAIR") ? atoi(getenv("VS_CONV_BAND_PAIR")) : 1;
-    constexpr int R = W == 8 ? 8 : 256 / W, RPT = (W == 8 ? 4 : 1) * (R + 2);
-    const size_t lds = (size_t)2 * 64 * RPT * W * 2;                             // Cin = 4 K >= 256: always two buffers
+    const size_t lds = 2 * band_buf_bytes<W>();                                  // Cin = 4 K >= 256: always two buffers
     if (pair_mode && 2 * lds <= 160 * 1024) return launch_band<W, 4, 2, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
     return launch_band<W, 8, 1, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
 }
@@ -761,8 +789,7 @@ static int launch_band_w(int compute, const void* x, const void* w_packed, const
                          hipStream_t stream) {
     // two workgroups per CU where 2 x LDS fits (VS_CONV_BAND_PAIR=0: always the deep-prefetch form)
     static const int pair_mode = getenv("VS_CONV_BAND_PAIR") ? atoi(getenv("VS_CONV_BAND_PAIR")) : 1;
-    constexpr int R = W == 8 ? 8 : 256 / W, RPT = (W == 8 ? 4 : 1) * (R + 2);
-    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * 64 * RPT * W * 2;
+    const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * band_buf_bytes<W>();
     if (pair_mode && 2 * lds <= 160 * 1024) return launch_band<W, 4, 2>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
     return launch_band<W, 12, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
 }
@@ -777,7 +804,8 @@ extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, c
     if (W == 64) rc = launch_band_w<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
     else if (W == 32) rc = launch_band_w<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
     else if (W == 16) rc = launch_band_w<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
-    else rc = launch_band_w<8>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    else if (W == 8) rc = launch_band_w<8>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    else rc = launch_band_w<4>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
     if (rc != VS_OK) return rc;
     VS_CHECK_LAUNCH("vs_conv3_band");
     return VS_OK;
@@ -873,7 +901,8 @@ extern "C" int vs_conv_k4s2_band(int compute, const void* planes, const void* w_
     if (W == 64) rc = launch_band_k4_w<64>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
     else if (W == 32) rc = launch_band_k4_w<32>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
     else if (W == 16) rc = launch_band_k4_w<16>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
-    else rc = launch_band_k4_w<8>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
+    else if (W == 8) rc = launch_band_k4_w<8>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
+    else rc = launch_band_k4_w<4>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
     if (rc != VS_OK) return rc;
     VS_CHECK_LAUNCH("vs_conv_k4s2_band");
     return VS_OK;

@@ -434,6 +434,90 @@ def _conv_workspace(x_dtype_code, B, Cin, H, W, Cout, k, stride, pad, device):
     return _workspace(nbytes, device) if nbytes else None
 
 
+# ---- convolutions with 1..8 channels on the image side (csrc/vs_conv_thin.hip): dispatched from conv_fwd / conv_dgrad / conv_wgrad ----------
+def _thin_plan(op, code, B, Cin, H, W, Cout, OH, OW, k, stride, pad, transposed, wgrad_max_m=2):
+    """Whether this convolution call is one of the thin forms; returns (kind, C, Hb, Wb, M, sc, sm, flip) -- the many-channel map's channels and
+    size, the thin channel count and how element (c, m, t) of the kernel's weight view is found in the weight tensor -- or None.
+    VS_CONV_THIN=0: never.  The weight gradient takes its thin kernel only up to `wgrad_max_m` thin channels (measured: with 4 / 5 / 8 -- the first
+    encoder layers -- the column-matrix GEMM is faster, 57-72 us against 78-129 us: the VALU form re-reads the map per pair of thin channels)."""
+    import os
+    if os.environ.get('VS_CONV_THIN') == '0' or code == F32 or pad != 1 or (k, stride) not in ((3, 1), (4, 2)):
+        return None
+    k2 = k * k
+    plan = None
+    if op == 'fwd':
+        if not transposed and Cin <= 8 and (H, W) == (stride * OH, stride * OW):
+            plan = ('expand', Cout, OH, OW, Cin, Cin * k2, k2, 0)
+        elif not transposed and stride == 1 and Cout <= 4:
+            plan = ('reduce', Cin, H, W, Cout, k2, Cin * k2, 1)
+        elif transposed and Cout <= (4 if k == 3 else 2) and (OH, OW) == (stride * H, stride * W):
+            plan = ('reduce', Cin, H, W, Cout, Cout * k2, k2, 0)
+    elif op == 'dgrad':
+        if transposed and Cout <= 8 and (OH, OW) == (stride * H, stride * W):
+            plan = ('expand', Cin, H, W, Cout, Cout * k2, k2, 0)
+        elif not transposed and stride == 1 and Cout <= 8:
+            plan = ('expand', Cin, H, W, Cout, k2, Cin * k2, 1)
+    else:
+        if not transposed and Cin <= wgrad_max_m and (H, W) == (stride * OH, stride * OW):
+            plan = ('wgrad_big_dy', Cout, OH, OW, Cin, Cin * k2, k2, 0)
+        elif not transposed and stride == 1 and Cout <= wgrad_max_m:
+            plan = ('wgrad_big_x', Cin, H, W, Cout, k2, Cin * k2, 1)
+        elif transposed and Cout <= wgrad_max_m and (OH, OW) == (stride * H, stride * W):
+            plan = ('wgrad_big_x', Cin, H, W, Cout, Cout * k2, k2, 0)
+    if plan is None or not _lib.load_library().vs_conv_thin_supported(code, B, plan[1], plan[2], plan[3], plan[4], k, stride, pad):
+        return None
+    return plan
+
+
+def conv_thin_expand(thin, w, bias, out_shape, out_dtype, k, stride, sc, sm, flip, role='fwd'):
+    """out [B, C, H, W] = bias[c] + sum_{m, t} thin[B, M, S H, S W][m][S p + t - 1] * w(c, m, t)  (vs_conv_thin_expand)."""
+    require_cuda(thin, w, bias)
+    B, C, H, W = out_shape
+    out = torch.empty(tuple(out_shape), dtype=out_dtype, device=thin.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_conv_thin_expand(dtype_code(thin), thin.data_ptr(), w.data_ptr(), sc, sm, flip, _ptr(bias), out.data_ptr(), dtype_code(out),
+                                                  B, C, H, W, thin.shape[1], k, stride, stream_ptr()), 'vs_conv_thin_expand')
+    _pe(e0, 'vs_conv_thin:%s<%s>' % (role, _DT[dtype_code(thin)]), flops=2.0 * B * C * H * W * thin.shape[1] * k * k,
+        nbytes=float(thin.numel() * thin.element_size() + out.numel() * out.element_size()))
+    return out
+
+
+def conv_thin_reduce(big, w, bias, M, out_dtype, k, stride, sc, sm, flip, role='fwd'):
+    """out [B, M, S H, S W] = bias[m] + sum over the pixels / taps of big [B, C, H, W] that meet each output pixel  (vs_conv_thin_reduce)."""
+    require_cuda(big, w, bias)
+    B, C, H, W = big.shape
+    out = torch.empty((B, M, stride * H, stride * W), dtype=out_dtype, device=big.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_conv_thin_reduce(dtype_code(big), big.data_ptr(), w.data_ptr(), sc, sm, flip, _ptr(bias), out.data_ptr(), dtype_code(out),
+                                                  B, C, H, W, M, k, stride, stream_ptr()), 'vs_conv_thin_reduce')
+    _pe(e0, 'vs_conv_thin:%s<%s>' % (role, _DT[dtype_code(big)]), flops=2.0 * B * C * H * W * M * k * k,
+        nbytes=float(big.numel() * big.element_size() + out.numel() * out.element_size()))
+    return out
+
+
+def conv_thin_wgrad(big, thin, w_shape, k, stride, sc, sm, flip, into=None, out=None):
+    """dW (the weight's own layout, fp32) (+= into) = sum_{maps, p} big[c][p] * thin[m][S p + t - 1]  (vs_conv_thin_wgrad)."""
+    require_cuda(big, thin)
+    B, C, H, W = big.shape
+    M = thin.shape[1]
+    lib = _lib.load_library()
+    dw = into if into is not None else (out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=big.device))
+    ws = _workspace(lib.vs_conv_thin_wgrad_workspace_bytes(B, C, H, W, M, k), big.device)
+    e0 = _pb()
+    check(lib.vs_conv_thin_wgrad(dtype_code(big), big.data_ptr(), thin.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(into), dw.data_ptr(), sc, sm, flip,
+                                 B, C, H, W, M, k, stride, stream_ptr()), 'vs_conv_thin_wgrad')
+    _pe(e0, 'vs_conv_thin:wgrad<%s>' % _DT[dtype_code(big)], flops=2.0 * B * C * H * W * M * k * k,
+        nbytes=float(big.numel() * big.element_size() + thin.numel() * thin.element_size() + dw.numel() * 4))
+    return dw
+
+
+# ---- ConvTranspose2d on a 1x1 map (the decoders' first_upconv, reference conv.py:258, 295: [B, C, 1, 1] -> [B, Cout, k, k]) IS a dense GEMM with
+# the weight [Cin][Cout k k] as it lies in memory: no column matrix, no scatter ------------------------------------------------------------------
+def _convt_1x1(x_shape, k, stride, pad, transposed):
+    import os
+    return (transposed and x_shape[2] == 1 and x_shape[3] == 1 and pad == 0 and stride == 1 and os.environ.get('VS_CONVT_1X1_GEMM', '1') == '1')
+
+
 def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     """x [B,Cin,H,W], w Conv2d [Cout,Cin,k,k] / ConvTranspose2d [Cin,Cout,k,k] in the same (compute) dtype.
     The transposed form consumes `w_packed` (conv_pack_weight); it is built on the fly from `w` when not given."""
@@ -449,6 +533,17 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     k = w.shape[2]
     Cout = w.shape[1] if transposed else w.shape[0]
     OH, OW = _conv_out_hw(H, W, k, stride, pad, transposed)
+    if _convt_1x1(x.shape, k, stride, pad, transposed):
+        # y[b][(co, ky, kx)] = sum_ci x[b][ci] w[ci][(co, ky, kx)] + bias[co]
+        n = Cout * k * w.shape[3]
+        brep = bias.repeat_interleave(k * w.shape[3]) if bias is not None else None
+        y = gemm(x.view(B, Cin), LAYOUT_R, w.view(Cin, n), LAYOUT_S, B, n, Cin, out_dtype=out_dtype, bias=brep)
+        return y.view(B, Cout, k, w.shape[3])
+    thin = _thin_plan('fwd', dtype_code(x), B, Cin, H, W, Cout, OH, OW, k, stride, pad, transposed) if w.shape[2] == w.shape[3] else None
+    if thin is not None:
+        if thin[0] == 'expand':
+            return conv_thin_expand(x, w, bias, (B, Cout, OH, OW), out_dtype, k, stride, *thin[5:])
+        return conv_thin_reduce(x, w, bias, Cout, out_dtype, k, stride, *thin[5:])
     y = torch.empty((B, Cout, OH, OW), dtype=out_dtype, device=x.device)
     lib = _lib.load_library()
     fn = lib.vs_conv_transpose2d_fwd if transposed else lib.vs_conv2d_fwd
@@ -476,6 +571,14 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     B, Cin, H, W = x_shape
     k = w.shape[2]
     Cout = w.shape[1] if transposed else w.shape[0]
+    if _convt_1x1(x_shape, k, stride, pad, transposed):
+        # dx[b][ci] = sum_j dy[b][j] w[ci][j], j = (co, ky, kx)
+        n = Cout * k * w.shape[3]
+        return gemm(dy.view(B, n), LAYOUT_R, w.view(Cin, n), LAYOUT_R, B, Cin, n, out_dtype=out_dtype).view(B, Cin, 1, 1)
+    thin = (_thin_plan('dgrad', dtype_code(dy), B, Cin, H, W, Cout, dy.shape[2], dy.shape[3], k, stride, pad, transposed)
+            if w.shape[2] == w.shape[3] else None)
+    if thin is not None:
+        return conv_thin_expand(dy, w, None, (B, Cin, H, W), out_dtype, k, stride, *thin[5:], role='dgrad')
     dx = torch.empty((B, Cin, H, W), dtype=out_dtype, device=dy.device)
     lib = _lib.load_library()
     fn = lib.vs_conv_transpose2d_dgrad if transposed else lib.vs_conv2d_dgrad
@@ -558,6 +661,16 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
         assert into.dtype == torch.float32 and into.is_contiguous() and tuple(into.shape) == tuple(w_shape)
     if out is not None:
         assert into is None and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(w_shape)
+    if _convt_1x1(x.shape, k, stride, pad, transposed):
+        # dW[ci][j] (+)= sum_b x[b][ci] dy[b][j]
+        n = Cout * k * w_shape[3]
+        dw = into if into is not None else (out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device))
+        gemm(x.view(B, Cin), LAYOUT_S, dy.view(B, n), LAYOUT_S, Cin, n, B, out=dw.view(Cin, n), accumulate=into is not None)
+        return dw
+    thin = _thin_plan('wgrad', dtype_code(x), B, Cin, H, W, Cout, OH, OW, k, stride, pad, transposed) if w_shape[2] == w_shape[3] else None
+    if thin is not None:
+        big, small = (dy, x) if thin[0] == 'wgrad_big_dy' else (x, dy)
+        return conv_thin_wgrad(big, small, w_shape, k, stride, *thin[5:], into=into, out=out)
     dw = into if into is not None else (out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device))
     lib = _lib.load_library()
     if not transposed and k == 3 and stride == 1 and pad == 1 and conv3_wgrad_band_supported(x, Cout):
@@ -1007,7 +1120,11 @@ def chan_sum(x):
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     out = torch.empty((C,), dtype=torch.float32, device=x.device)
-    check(_lib.load_library().vs_chan_sum(x.data_ptr(), dtype_code(x), B, C, HW, out.data_ptr(), stream_ptr()), 'vs_chan_sum')
+    lib = _lib.load_library()
+    ws = _workspace(lib.vs_chan_sum_workspace_bytes(B, C, HW), x.device)
+    e0 = _pb()
+    check(lib.vs_chan_sum_ws(x.data_ptr(), dtype_code(x), B, C, HW, ws.data_ptr(), ws.numel(), out.data_ptr(), stream_ptr()), 'vs_chan_sum_ws')
+    _pe(e0, 'vs_chan_sum<%s>' % _DT[dtype_code(x)], nbytes=float(x.numel() * x.element_size()))
     return out
 
 

@@ -26,7 +26,9 @@ GROUPS = [
     ('vs_gemm+cols', r'^vs_gemm<|^vs_conv_cols:|^vs_convT_cols:', r'gemm_kernel<|gemm_glds_kernel<|gemm_big_kernel<|gemm_mid_kernel<\d, \d, \d, \w+, \d+, false>|'
      r'splitk_reduce_kernel|im2col_|convt_k4s2_small_kernel|gather_small_s1_kernel|gather_rowdot_kernel', 'mfma'),
     ('vs_bn_small', r'^vs_bn_fwd_small|^vs_bn_bwd_small', r'bn_fwd_small|bn_bwd_small', 'hbm'),
-    ('vs_bn', r'^vs_bn_stats|^vs_bn_act_fwd|^vs_bn_act_bwd', r'bn_stats_kernel|bn_act_fwd_kernel|bn_bwd_reduce|bn_bwd_apply|bn_running|bn_from_sums|chan_sum', 'hbm'),
+    # first / last layers (1..8 channels on the image side): one VALU pass over the many-channel map, no column matrix
+    ('vs_conv_thin', r'^vs_conv_thin:', r'thin_\w+_kernel', 'hbm'),
+    ('vs_bn', r'^vs_bn_stats|^vs_bn_act_fwd|^vs_bn_act_bwd|^vs_chan_sum', r'bn_stats_kernel|bn_act_fwd_kernel|bn_bwd_reduce|bn_bwd_apply|bn_running|bn_from_sums|chan_sum', 'hbm'),
     ('vs_adam_multi', r'^vs_adam_multi', r'adam_multi_kernel', 'hbm'),
     ('vs_train_losses', r'^vs_train_losses|^vs_frames_sse', r'train_losses_\w+_kernel|frames_sse', 'hbm'),
     ('vs_colsum_multi', r'^vs_colsum_multi', r'colsum_multi_kernel', 'hbm'),

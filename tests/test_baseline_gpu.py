@@ -170,11 +170,12 @@ def test_full_size_waveeq_lowp_matches_rounding_point_emulation(precision):
 # the fp32 tests above never reach them; these do, at the sizes of BASELINE.json configs[2..4] and in the dtype configs[4] states.
 LOWP_FULL = [
     ('full_mnist_b128', 'bf16', ('vs_convT_tap:fwd', 'vs_convT_tap:dgrad', 'vs_conv_cols:fwd', 'vs_conv_cols:wgrad', 'vs_convT_cols:wgrad',
-                                 'vs_mlp_rollout_fwd', 'vs_mlp_rollout_bwd'), None),
-    ('full_taxibj', 'bf16', ('vs_conv3_band:fwd', 'vs_conv3_band:dgrad', 'vs_conv3_wgrad_band', 'vs_convT_cols:fwd', 'vs_mlp_rollout_fwd'), None),
+                                 'vs_conv_thin:fwd', 'vs_conv_thin:dgrad', 'vs_conv_thin:wgrad', 'vs_mlp_rollout_fwd', 'vs_mlp_rollout_bwd'), None),
+    ('full_taxibj', 'bf16', ('vs_conv3_band:fwd', 'vs_conv3_band:dgrad', 'vs_conv3_wgrad_band', 'vs_conv_thin:fwd', 'vs_conv_thin:dgrad',
+                             'vs_conv_thin:wgrad', 'vs_mlp_rollout_fwd'), None),
     ('full_sst', 'fp16', ('vs_conv3_img16:fwd', 'vs_conv3_img16:dgrad', 'vs_conv3_band:fwd', 'vs_conv3_band:dgrad', 'vs_conv3_wgrad_band',
-                          'vs_bn_fwd_small_slabs', 'vs_bn_bwd_small_ex'), 1024.0),
-    ('full_sst', 'bf16', ('vs_conv3_img16:fwd', 'vs_conv3_img16:dgrad', 'vs_conv3_band:fwd', 'vs_conv3_wgrad_band'), None),
+                          'vs_conv_thin:fwd', 'vs_conv_thin:dgrad', 'vs_conv_thin:wgrad', 'vs_bn_fwd_small_slabs', 'vs_bn_bwd_small_ex'), 1024.0),
+    ('full_sst', 'bf16', ('vs_conv3_img16:fwd', 'vs_conv3_img16:dgrad', 'vs_conv3_band:fwd', 'vs_conv3_wgrad_band', 'vs_conv_thin:wgrad'), None),
 ]
 # Bounds (relative L2).
 #  vs the rounding-point emulation (same rounding rules, independent implementation: oracle/bf16_emu.py on the oracle's module tree):

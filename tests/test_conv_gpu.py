@@ -503,6 +503,9 @@ def test_fused_conv_res_block_equals_layer_by_layer(precision, monkeypatch):
     (9, 128, 64, 64, 32),
     (10, 128, 8, 8, 72),      # 8 x 8 maps, four per workgroup: 10 = 2 full groups + 2 maps
     (3, 256, 8, 8, 256),
+    (37, 128, 4, 4, 72),      # 4 x 4 maps, sixteen per workgroup: 37 = 2 full groups + 5 maps; ragged output-channel tile
+    (16, 64, 4, 4, 64),       # one phase, one buffer
+    (200, 512, 4, 4, 512),    # the VGG encoder's 512-channel layers at TaxiBJ size (conv.py:147-160)
 ])
 def test_conv3_band_forward_and_input_gradient(dtype, geom):
     """Conv2d k3 s1 p1 on many maps through vs_conv3_band (row bands in LDS, no column matrix) against fp64 conv2d on the same 16-bit
@@ -655,3 +658,68 @@ def test_conv3_pack_weights_in_one_launch_equals_single_packs(dtype):
     assert len(got) == len(want) >= 9
     for a, b in zip(got, want):
         assert a.shape == b.shape and torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+THIN_GEOMS = [
+    # (B, Cin, H, W, Cout, k, stride, pad, transposed)
+    (3, 5, 64, 64, 64, 4, 2, 1, False),     # DCGAN encoder c1 at width (conv.py:119): forward = expand (5 thin channels), weight gradient
+    (2, 8, 32, 32, 64, 3, 1, 1, False),     # VGG encoder first layer on 8 stacked frames (conv.py:130)
+    (2, 4, 64, 64, 64, 3, 1, 1, False),     # SST encoder first layer (conv.py:345)
+    (3, 1, 64, 32, 32, 4, 2, 1, False),     # one thin channel, rows of 16 pixels
+    (3, 64, 32, 32, 1, 4, 2, 1, True),      # DCGAN decoder upc5 (conv.py:264): forward = reduce over four output parities
+    (2, 64, 32, 32, 2, 3, 1, 1, True),      # VGG decoder last layer (conv.py:300)
+    (2, 64, 64, 64, 1, 3, 1, 1, False),     # SST decoder last layer (conv.py:420): Conv2d seen from its output (flipped taps)
+    (2, 32, 16, 32, 3, 3, 1, 1, False),     # three thin channels (a masked fourth), rows of 32 on 16 x 32 maps
+    (2, 64, 8, 64, 2, 4, 2, 1, True),       # k4 s2 with two thin channels
+    (5, 96, 16, 32, 3, 3, 1, 1, True),      # 96 channels, an odd batch
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom', THIN_GEOMS)
+def test_conv_thin_kernels_match_fp64(dtype, geom):
+    """The first / last layers (1..8 channels on the image side) through csrc/vs_conv_thin.hip -- expand, reduce and the weight gradient --
+    against fp64 on the same 16-bit operands; the dispatch inside ops.conv_fwd / conv_dgrad / conv_wgrad must pick them."""
+    from spatiotemporal_variable_separation_amd import ops
+    from spatiotemporal_variable_separation_amd._lib import dtype_code
+    B, Cin, H, W, Cout, k, s, p, tr = geom
+    x = _rand((B, Cin, H, W), 41).to(dtype)
+    wshape = (Cin, Cout, k, k) if tr else (Cout, Cin, k, k)
+    w = _rand(wshape, 42, 0.3).to(dtype)
+    bias = _rand((Cout,), 43)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    fn = F.conv_transpose2d if tr else F.conv2d
+    y64 = fn(x64, w64, bias.double(), stride=s, padding=p)
+    OH, OW = y64.shape[2], y64.shape[3]
+    dy = _rand(tuple(y64.shape), 44).to(dtype)
+    y64.backward(dy.double())
+    code = dtype_code(x.cuda())
+    plans = {op: ops._thin_plan(op, code, B, Cin, H, W, Cout, OH, OW, k, s, p, tr, wgrad_max_m=8) for op in ('fwd', 'dgrad', 'wgrad')}
+    assert plans['fwd'] is not None and plans['wgrad'] is not None, plans
+    if Cout <= 8:
+        assert plans['dgrad'] is not None, plans
+
+    def rel(a, b):
+        return ((a.cpu().double() - b).norm() / (b.norm() + 1e-30)).item()
+    y = ops.conv_fwd(x.cuda(), w.cuda(), bias.cuda(), s, p, tr, torch.float32)
+    assert tuple(y.shape) == tuple(y64.shape)
+    assert rel(y, y64.detach()) < 1e-5, f'fwd {geom} {dtype}'
+    y16 = ops.conv_fwd(x.cuda(), w.cuda(), bias.cuda(), s, p, tr, dtype)
+    assert torch.equal(y16.cpu(), y.cpu().to(dtype)), 'typed store = rounding of the fp32 result'
+    # (the dispatch in ops.conv_wgrad takes the thin kernel up to two thin channels; the kernel itself serves up to eight)
+    big, small = (dy.cuda(), x.cuda()) if plans['wgrad'][0] == 'wgrad_big_dy' else (x.cuda(), dy.cuda())
+    dw = ops.conv_thin_wgrad(big, small, wshape, k, s, *plans['wgrad'][5:])
+    assert rel(dw, w64.grad) < 1e-5, f'wgrad {geom} {dtype}'
+    base = _rand(wshape, 45).cuda()
+    acc = base.clone()
+    ops.conv_thin_wgrad(big, small, wshape, k, s, *plans['wgrad'][5:], into=acc)
+    assert rel(acc, base.cpu().double() + w64.grad) < 1e-5, 'accumulating form'
+    dw2 = ops.conv_thin_wgrad(big, small, wshape, k, s, *plans['wgrad'][5:])
+    assert torch.equal(dw, dw2), 'fixed summation order: bit-reproducible'
+    assert rel(ops.conv_wgrad(dy.cuda(), x.cuda(), wshape, s, p, tr), w64.grad) < 1e-5, 'through the dispatch'
+    dx = ops.conv_dgrad(dy.cuda(), w.cuda(), x.shape, s, p, tr, torch.float32, cols_from_wgrad=tr)
+    assert rel(dx, x64.grad) < 1e-5, f'dgrad {geom} {dtype}'
+    if plans['dgrad'] is not None:
+        dx16 = ops.conv_dgrad(dy.cuda(), w.cuda(), x.shape, s, p, tr, dtype)
+        assert torch.equal(dx16.cpu(), dx.cpu().to(dtype))
