@@ -825,7 +825,11 @@ static int wgrad_band_mw(int Cout) { return Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
 static int wgrad_band_ksplit(int B, int Cin, int H, int W, int Cout) {
     const int mw = wgrad_band_mw(Cout);
     const int64_t tiles = vs_cdiv(Cout, 32 * mw) * vs_cdiv(Cin, 32), items = W == 8 ? vs_cdiv(B, 4) : (int64_t)B * (H / (256 / W));
-    int64_t ks = vs_cdiv(512, tiles);                                           // ~2 rounds of workgroups over the launch
+    // ONE round of workgroups (a workgroup's LDS fills a CU): every share of the bands costs a slab of the weight's size, written and read
+    // again by the finish pass -- with two rounds (512) the slabs of a TaxiBJ step were 3.9 GB of traffic: 9.80 -> 9.37 ms with 256; 128, 192
+    // and 384 are slower (idle CUs / a partial second round)
+    static const int target_wgs = getenv("VS_WGRAD_BAND_WGS") ? atoi(getenv("VS_WGRAD_BAND_WGS")) : 256;
+    int64_t ks = vs_cdiv(target_wgs, tiles);
     if (ks > items) ks = items;
     const int64_t slab_bytes = (int64_t)Cout * Cin * 9 * 4;
     while (ks > 1 && ks * (4 / mw) * slab_bytes > ((int64_t)96 << 20)) --ks;    // at most 96 MiB of slabs
