@@ -853,6 +853,16 @@ inline bool wgrad_uses_cols(int64_t M, int64_t N, int64_t K, const void* ws, siz
     return ws && ws_bytes >= cols_bytes + vs_gemm_workspace_bytes(M, N, K) && cols_worthwhile(M, K, N);
 }
 
+// R [B][M][hw] (16-bit) -> dense rows [M][B hw]: the channel-rows operand of a weight gradient on maps of fewer than 32 pixels (4 x 4), where a
+// 32-wide K tile of the LDS-DMA ring kernel would straddle two maps; one 16-byte piece per thread and step
+__global__ __launch_bounds__(256) void chan_rows_to_dense_kernel(const unsigned short* __restrict__ r, unsigned short* __restrict__ d, int M, int hw8, int64_t K8,
+                                                                 int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / K8, k8 = i - m * K8, b = k8 / hw8, p8 = k8 - b * hw8;
+        *reinterpret_cast<u32x4*>(d + i * 8) = *reinterpret_cast<const u32x4*>(r + ((b * M + m) * hw8 + p8) * 8);
+    }
+}
+
 // weight gradient: dW[m][(c,t)] = sum_pix R[b,m,pix] * G[b,c,py*s-p+ky,px*s-p+kx]; R has Cr channels on the (PH,PW) pixel
 // grid, G has Cg channels of size (GH,GW)
 template <int CT>
@@ -882,8 +892,11 @@ int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH
             // DCGAN / VGG weight gradients (K = 10^4 .. 10^5, 16-64 output tiles)
             static const int mid_mode = getenv("VS_CONV_WGRAD_MID") ? atoi(getenv("VS_CONV_WGRAD_MID")) : 1;
             const int64_t kt = K / BIG_BK, tiles = vs_cdiv(M, 128) * vs_cdiv(N, 128);
-            if (mid_mode && hw % BIG_BK == 0 && K % BIG_BK == 0 && M % 8 == 0 && N % 8 == 0 && (uintptr_t)r % 16 == 0 && hw < (1ll << 23) &&
-                ld < (1ll << 23) && kt >= 32 && tiles <= 512 && (M >= 64 || mid_mode == 2)) {
+            // maps of 8 / 16 pixels (hw not a multiple of the K tile): the same kernel on a dense [M][K] copy of R (one small transposing pass)
+            const bool via_dense = hw % BIG_BK != 0 && hw % 8 == 0;
+            const size_t dense_bytes = via_dense ? (size_t)M * (size_t)K * sizeof(T) : 0;
+            if (mid_mode && (hw % BIG_BK == 0 || via_dense) && K % BIG_BK == 0 && M % 8 == 0 && N % 8 == 0 && (uintptr_t)r % 16 == 0 && hw < (1ll << 23) &&
+                ld < (1ll << 23) && K < (1ll << 23) && kt >= 32 && tiles <= 512 && (M >= 64 || mid_mode == 2)) {
                 int splits = 1;
                 if (tiles < 448) {
                     splits = (int)(448 / tiles);
@@ -896,10 +909,21 @@ int wgrad_form(const void* r, const void* gsrc, float* dw, int B, int Cr, int PH
                 splits = (int)vs_cdiv(kt, ktps);
                 float* slabs = nullptr;
                 const size_t need = splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
-                if (need <= ws_bytes - cols_bytes) {
+                if (need + dense_bytes <= ws_bytes - cols_bytes) {
                     if (splits > 1) slabs = (float*)((char*)ws + cols_bytes);
                     const int stages = tiles * splits <= 256 ? 10 : 5;
-                    int rc2 = mid_launch<CT, LR, LR>(r, hw, ws, ld, M, N, K, splits, ktps, stages, 1, e, slabs, st, hw);
+                    const void* a_ptr = r;
+                    if (via_dense) {
+                        unsigned short* dense = (unsigned short*)((char*)ws + cols_bytes + need);
+                        const int64_t total = M * K / 8;
+                        int64_t blocks = vs_cdiv(total, 256);
+                        if (blocks > 4096) blocks = 4096;
+                        hipLaunchKernelGGL(chan_rows_to_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)r, dense, (int)M,
+                                           (int)(hw / 8), K / 8, total);
+                        VS_CHECK_LAUNCH(what);
+                        a_ptr = dense;
+                    }
+                    int rc2 = mid_launch<CT, LR, LR>(a_ptr, via_dense ? K : hw, ws, ld, M, N, K, splits, ktps, stages, 1, e, slabs, st, via_dense ? 0 : hw);
                     if (rc2 != VS_OK) return rc2;
                     VS_CHECK_LAUNCH(what);
                     if (slabs) {
@@ -1004,13 +1028,13 @@ extern "C" size_t vs_conv_workspace_bytes(int compute, int B, int Cin, int H, in
         take(cols(B * OHc * OWc, Cin * khw), Cout, B * OHc * OWc, Cin * khw);                         // conv forward
         if (stride == 2) take(cols(B * OHc * OWc, Cout * tt), Cin, B * OHc * OWc, Cout * tt);        // conv dgrad: per phase on dy's grid
         else take(cols((int64_t)B * H * W, Cout * khw), Cin, (int64_t)B * H * W, Cout * khw);         //   stride 1: on dx's grid
-        take(cols(B * OHc * OWc, Cin * khw), Cout, Cin * khw, B * OHc * OWc);                         // conv wgrad
+        take(cols(B * OHc * OWc, Cin * khw) + (size_t)(Cout * B * OHc * OWc * e), Cout, Cin * khw, B * OHc * OWc);   // conv wgrad (+ a dense copy of dy)
     }
     if (OHt > 0 && OWt > 0) {
         if (stride == 2) take(cols((int64_t)B * H * W, Cin * tt), Cout, (int64_t)B * H * W, Cin * tt); // convT forward: per phase on x's grid
         else take(cols(B * OHt * OWt, Cin * khw), Cout, B * OHt * OWt, Cin * khw);                     //   stride 1: on the output grid
         take(cols((int64_t)B * H * W, Cout * khw), Cin, (int64_t)B * H * W, Cout * khw);              // convT dgrad
-        take(cols((int64_t)B * H * W, Cout * khw), Cin, Cout * khw, (int64_t)B * H * W);              // convT wgrad
+        take(cols((int64_t)B * H * W, Cout * khw) + (size_t)((int64_t)Cin * B * H * W * e), Cin, Cout * khw, (int64_t)B * H * W);   // convT wgrad (+ a dense copy of x)
     }
     return worst;
 }
