@@ -521,6 +521,7 @@ __global__ __launch_bounds__(256) void wgrad_slab_finish_kernel(const float* __r
         float s[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) s[t] = addend ? addend[i * 9 + t] : 0.f;
+#pragma unroll 2
         for (int k = 0; k < n; ++k)                                                // fixed order: reproducible
 #pragma unroll
             for (int t = 0; t < 9; ++t) s[t] += src[(int64_t)k * total + (int64_t)t * mc + i];
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
                                                        const float* __restrict__ addend, int C, int HW, void* __restrict__ out, int od) {
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
         f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
+#pragma unroll 4
         for (int k = 1; k < nslabs; ++k) {                                         // fixed order: reproducible
             const f32x4 t = *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * total + i);
             s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
@@ -616,6 +618,7 @@ __global__ __launch_bounds__(256) void slab_sum_grouped_kernel(const float* __re
     const int g = blockIdx.y, s0 = g * per, s1 = s0 + per < nslabs ? s0 + per : nslabs;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
         for (int k = s0; k < s1; ++k) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * total + i);
             s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];

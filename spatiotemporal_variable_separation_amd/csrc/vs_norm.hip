@@ -573,6 +573,7 @@ __global__ __launch_bounds__(256) void bn_bwd_small_ex_kernel(const void* dy_a, 
             ld_vec(x, xd, idx, xv);
             if (slabs) {
                 f32x4 lo = *reinterpret_cast<const f32x4*>(slabs + idx), hi = *reinterpret_cast<const f32x4*>(slabs + idx + 4);
+#pragma unroll 4
                 for (int k = 1; k < nslabs; ++k) {
                     const f32x4 l2 = *reinterpret_cast<const f32x4*>(slabs + k * stride + idx), h2 = *reinterpret_cast<const f32x4*>(slabs + k * stride + idx + 4);
                     lo[0] += l2[0]; lo[1] += l2[1]; lo[2] += l2[2]; lo[3] += l2[3];
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd
                 // stored for backward and normalised here (xd is the 16-bit type of z: 8 elements per thread and round)
                 const int64_t stride = (int64_t)B * C * HW;
                 f32x4 lo = *reinterpret_cast<const f32x4*>(slabs + idx), hi = *reinterpret_cast<const f32x4*>(slabs + idx + 4);
+#pragma unroll 4
                 for (int k = 1; k < nslabs; ++k) {
                     const f32x4 l2 = *reinterpret_cast<const f32x4*>(slabs + k * stride + idx), h2 = *reinterpret_cast<const f32x4*>(slabs + k * stride + idx + 4);
                     lo[0] += l2[0]; lo[1] += l2[1]; lo[2] += l2[2]; lo[3] += l2[3];
