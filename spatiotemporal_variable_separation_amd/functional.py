@@ -98,6 +98,11 @@ def flush_deferred_wgrads():
                 dz = torch.cat([p[0] for p in pairs], dim=0)
                 xc = torch.cat([p[1] for p in pairs], dim=0)
             ops.conv_wgrad(dz, xc, slot['shape'], slot['stride'], slot['pad'], False, into=slot['g'])
+    # (the engine has already joined the streams of the pass with the caller's: work issued now on another stream is joined here)
+    cur = torch.cuda.current_stream()
+    for st in {slot['stream'] for slot in slots.values()}:
+        if st != cur:
+            cur.wait_stream(st)
 
 
 # Exactly-zero gradients (a convolution bias in front of a training-mode BatchNorm: the batch mean removes it) still have to be handed to
@@ -105,12 +110,15 @@ def flush_deferred_wgrads():
 # slices of ONE zero-filled pool per backward pass (sized from the previous pass), each slice a tensor of its own, so autograd keeps it
 # as the parameter's gradient without cloning.  Nothing ever writes into such a gradient (later contributions of the pass are dropped
 # as exact zeros too, and optimizers only read gradients).
-_ZERO_POOL = {'task': None, 'buf': None, 'off': 0, 'need': 0, 'last': 0}
+# One pool per STREAM: a slice handed out as a parameter's gradient is added to in place by autograd when the parameter is used again in the pass
+# (on the stream of ITS node); with a pool shared between streams that add could run before the pool's fill on the other stream.
+_ZERO_POOLS = {}
 
 
 def zero_grad_like(p):
     task = torch._C._current_graph_task_id()
-    zp = _ZERO_POOL
+    zp = _ZERO_POOLS.setdefault(torch.cuda.current_stream(p.device).cuda_stream if p.is_cuda else -1,
+                                {'task': None, 'buf': None, 'off': 0, 'need': 0, 'last': 0})
     n = p.numel()
     if zp['task'] != task:
         zp['last'] = max(zp['last'], zp['need'])
@@ -121,6 +129,9 @@ def zero_grad_like(p):
     if zp['buf'] is None or zp['buf'].device != p.device or zp['off'] + n > zp['buf'].numel():
         zp['buf'] = torch.zeros(max(zp['last'], 4 * n, 1024), dtype=torch.float32, device=p.device)
         zp['off'] = 0
+        main = _SIDE.get('main')
+        if main is not None and main != torch.cuda.current_stream():
+            zp['buf'].record_stream(main)            # allocated inside a side-stream node, read by the optimizer on the step's stream
     out = zp['buf'][zp['off']:zp['off'] + n].view(p.shape)
     zp['off'] += n
     return out
@@ -216,6 +227,12 @@ def _lane_marker(lane):
 
 def side_streams_enabled():
     return _SIDE['on']
+
+
+def note_main_stream(stream):
+    """The stream the step runs on while part of it is on a side stream: tensors of the backward pass that are allocated wherever they are first
+    needed but read by the optimizer afterwards (the pooled zero gradients) are recorded on it."""
+    _SIDE['main'] = stream
 
 
 def _side_stream(name):

@@ -25,7 +25,7 @@ class SeparableNetwork(nn.Module):
         assert isinstance(grad, bool)
         self._grad = grad
 
-    def get_forecast(self, cond, n_forecast, init_t_code=None, init_s_code=None):
+    def get_forecast(self, cond, n_forecast, init_t_code=None, init_s_code=None, rolled=None):
         """Encode once, decode frame 0, then roll the temporal code forward n_forecast-1 times (model.py:52-89).
 
         Returns (forecasts [B,n,C,H,W], t_codes [B,n,...], s_code, t_residuals) like the reference.
@@ -40,7 +40,9 @@ class SeparableNetwork(nn.Module):
         # recurrence in one persistent kernel, and the n decoder calls run as one batch over time -- for the conv
         # decoders with per-call BatchNorm statistics kept per step (grouped BatchNorm), so nothing changes numerically.
         if self.fused and hasattr(self.decoder, 'decode_sequence') and t_code.is_cuda:
-            if hasattr(self.t_resnet, 'rollout'):
+            if rolled is not None:
+                t_codes, t_residuals = rolled           # (the caller rolled the code forward already: train.compute_losses, on a side stream)
+            elif hasattr(self.t_resnet, 'rollout'):
                 t_codes, t_residuals = self.t_resnet.rollout(t_code, n_forecast)
             else:
                 codes, t_residuals = self._roll(t_code, n_forecast)

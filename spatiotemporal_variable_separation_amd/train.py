@@ -630,8 +630,29 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
             window, supervision_data = _device_window(full_data, t_random, nt_cond, offset)
         else:
             window, supervision_data = full_data[:, t_random - nt_cond:t_random], full_data[:, t_random - offset]
-        s_old, s_recent = _encode_pair(sep_net.Es, full_data[:, :nt_cond], full_data[:, -nt_cond:], skipco)
-        t_rand, t_cond = _encode_pair(sep_net.Et, window, cond, False)
+        # A convolutional integrator (SST's ConvResnet, resnet.py:53-88: ~470 small launches forward, as many backward, each on 8 maps) needs
+        # E_t's code only; E_s, the reconstruction decode and their backward passes are independent of it.  VARSEP_ROLLOUT_SIDE=1 runs it on a
+        # side stream (autograd replays the assignment in backward) between E_t and the forecast decode: same arithmetic, same per-module
+        # call order of every BatchNorm.  Measured and NOT the default: the replayed SST step goes from 21.0 to 55-58 ms with 8 hardware
+        # queues (every launch of two concurrently running chains of ~800 small kernels pays a cross-queue hand-over), and is unchanged
+        # (21.3 ms) with 4 or 2 queues, where the runtime maps both branches onto one queue.
+        rolled = None
+        side_roll = (cond.is_cuda and not hasattr(sep_net.t_resnet, 'rollout') and hasattr(sep_net.decoder, 'decode_sequence')
+                     and os.environ.get('VARSEP_ROLLOUT_SIDE', '0') == '1')
+        if side_roll:
+            from . import functional as VF
+            t_rand, t_cond = _encode_pair(sep_net.Et, window, cond, False)
+            main, side = torch.cuda.current_stream(), VF._side_stream('rollout')
+            VF.note_main_stream(main)
+            side.wait_stream(main)
+            t_cond.record_stream(side)
+            with torch.cuda.stream(side):
+                codes, t_residuals = sep_net._roll(t_cond, nt_pred + offset)
+                rolled = (torch.stack(codes, dim=1), t_residuals)
+            s_old, s_recent = _encode_pair(sep_net.Es, full_data[:, :nt_cond], full_data[:, -nt_cond:], skipco)
+        else:
+            s_old, s_recent = _encode_pair(sep_net.Es, full_data[:, :nt_cond], full_data[:, -nt_cond:], skipco)
+            t_rand, t_cond = _encode_pair(sep_net.Et, window, cond, False)
         if skipco:
             reconstruction = sep_net.decoder(s_old[0], t_rand, skip=s_old[1])
         else:
@@ -648,7 +669,12 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
         else:
             ae_loss_value = F.mse_loss(supervision_data, reconstruction, reduction='mean')
         spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
-        forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_t_code=t_cond, init_s_code=s_old)
+        if rolled is not None:
+            main.wait_stream(side)
+            rolled[0].record_stream(main)
+            forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_t_code=t_cond, init_s_code=s_old, rolled=rolled)
+        else:
+            forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_t_code=t_cond, init_s_code=s_old)
     else:
         ae_loss_value, s_recent, s_old = ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=t_random)
         spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
