@@ -530,6 +530,11 @@ int vs_bn_train_fwd_small_supported(int x_dtype, int B, int C, int64_t HW);
 int vs_bn_train_fwd_small(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int act, float* mean,
                           float* invstd, float* running_mean, float* running_var, float momentum, float eps, int B, int C, int64_t HW,
                           void* stream);
+/* the same for `groups` calls stacked along the batch axis (per-call statistics, mean / invstd [groups][C]); var_scratch [groups][C] is needed when
+ * running statistics are tracked (they are folded in call order by a second launch) */
+int vs_bn_train_fwd_small_groups(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int act, float* mean,
+                                 float* invstd, float* var_scratch, float* running_mean, float* running_var, float momentum, float eps, int B, int C,
+                                 int64_t HW, int groups, void* stream);
 /* vs_bn_train_fwd_small on the split slabs of vs_conv3_img16: z = round(sum of the slabs + bias[c]) in the 16-bit z_dtype is written
  * (vs_bn_act_bwd needs it), everything else as above.  skip / xnew (fp32, both or neither) and xnew16 (z_dtype, optional): the tail of
  * a residual block (ConvResBlock.forward resnet.py:66-70) -- xnew = skip + y and its 16-bit copy for the next block.           */

@@ -170,6 +170,8 @@ SIGNATURES = {
     'vs_bn_act_bwd_small_ex': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i64, _vp]),
     'vs_bn_train_fwd_small_supported': (_i32, [_i32, _i32, _i32, _i64]),
     'vs_bn_train_fwd_small': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32, _i32, _i64, _vp]),
+    'vs_bn_train_fwd_small_groups': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32, _i32, _i64, _i32,
+                                            _vp]),
     'vs_conv2d_wgrad_acc': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _i32, _vp]),
     'vs_conv_transpose2d_wgrad_acc': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _i32, _vp]),
     'vs_conv_transpose2d_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _vp]),

@@ -632,9 +632,15 @@ template <int NV>
 __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd, void* y, int yd, const float* gamma, const float* beta, int act,
                                                           float* mean, float* invstd, float* rmean, float* rvar, float momentum, float eps, int B,
                                                           int C, int HW, const float* slabs = nullptr, int nslabs = 0, const float* bias = nullptr,
-                                                          void* z = nullptr, const float* skip = nullptr, float* xnew = nullptr, void* xnew16 = nullptr) {
+                                                          void* z = nullptr, const float* skip = nullptr, float* xnew = nullptr, void* xnew16 = nullptr,
+                                                          float* ubvar = nullptr) {
+    // blockIdx.y = call group (B = the maps of ONE group; groups lie one after the other along the batch axis): statistics per group;
+    // with several groups the running estimates are folded in call order by bn_running_kernel from mean / ubvar (ubvar != NULL)
     __shared__ double red[16];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, grp = blockIdx.y;
+    const int64_t b0 = (int64_t)grp * B;
+    mean += grp * C;
+    invstd += grp * C;
     const int w = xd == VS_F32 ? 4 : 8;
     const int per = HW / w, nvec = B * per;
     const int64_t n = (int64_t)B * HW;
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd
         const int i = threadIdx.x + r * 256;
         if (i < nvec) {
             const int b = i / per, p = (i - b * per) * w;
-            const int64_t idx = ((int64_t)b * C + c) * (int64_t)HW + p;
+            const int64_t idx = ((b0 + b) * C + c) * (int64_t)HW + p;
             int cnt = 8;
             if (slabs) {
                 // the convolution left split partial sums (fp32 slabs of the whole tensor): z = round16(sum of the slabs in order + bias) is
@@ -695,7 +701,9 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd
     if (threadIdx.x == 0) {
         mean[c] = mu;
         invstd[c] = is;
-        if (rmean) {
+        if (ubvar) {
+            ubvar[grp * C + c] = (float)(n > 1 ? ss / (double)(n - 1) : var);
+        } else if (rmean) {
             const double ub = n > 1 ? ss / (double)(n - 1) : var;
             rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * (double)mu);
             rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * (double)(float)ub);
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = vs_act((xv[r][j] - mu) * is * g + bt, act);
-            const int64_t idx = ((int64_t)b * C + c) * (int64_t)HW + p;
+            const int64_t idx = ((b0 + b) * C + c) * (int64_t)HW + p;
             st_vec(y, yd, idx, o, w);
             if (skip) {
                 // residual block tail (resnet.py:66-70): the block output skip + y in fp32 and as the next block's 16-bit operand (w == 8)
@@ -948,6 +956,38 @@ extern "C" int vs_bn_train_fwd_small(const void* x, int x_dtype, void* y, int y_
     else VS_BN_SMALL(8);
 #undef VS_BN_SMALL
     VS_CHECK_LAUNCH("vs_bn_train_fwd_small");
+    return VS_OK;
+}
+
+// The same for `groups` reference calls stacked along the batch axis (B maps in all, B / groups per call, each normalised with its own
+// statistics): mean / invstd [groups][C]; the running estimates are folded in call order by a second (tiny) launch from mean and the
+// unbiased variances left in var_scratch [groups][C].  Served when one call's slab is (vs_bn_train_fwd_small_supported(x_dtype, B / groups, ..)).
+extern "C" int vs_bn_train_fwd_small_groups(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int act, float* mean,
+                                            float* invstd, float* var_scratch, float* running_mean, float* running_var, float momentum, float eps,
+                                            int B, int C, int64_t HW, int groups, void* stream) {
+    VS_CHECK_ARG(x && y && gamma && beta && mean && invstd && vs_dtype_ok(y_dtype) && groups >= 1 && B > 0 && B % groups == 0,
+                 "vs_bn_train_fwd_small_groups: bad argument");
+    VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && (!running_mean || var_scratch), "vs_bn_train_fwd_small_groups: running_mean / running_var / var_scratch come together");
+    const int Bg = B / groups;
+    if (!vs_bn_train_fwd_small_supported(x_dtype, Bg, C, HW) || ((uintptr_t)x | (uintptr_t)y) % 16 != 0)
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_bn_train_fwd_small_groups: tensor not served (use vs_bn_stats + vs_bn_act_fwd)");
+    const int64_t nvec = (int64_t)Bg * HW / (x_dtype == VS_F32 ? 4 : 8);
+    const dim3 grid(C, groups);
+#define VS_BN_SMALL(NV)                                                                                                                 \
+    hipLaunchKernelGGL(bn_fwd_small_kernel<NV>, grid, dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, gamma, beta, act, mean, invstd, \
+                       (float*)nullptr, (float*)nullptr, momentum, eps, Bg, C, (int)HW, (const float*)nullptr, 0, (const float*)nullptr, (void*)nullptr,  \
+                       (const float*)nullptr, (float*)nullptr, (void*)nullptr, running_mean ? var_scratch : (float*)nullptr)
+    if (nvec <= 256) VS_BN_SMALL(1);
+    else if (nvec <= 512) VS_BN_SMALL(2);
+    else if (nvec <= 1024) VS_BN_SMALL(4);
+    else VS_BN_SMALL(8);
+#undef VS_BN_SMALL
+    VS_CHECK_LAUNCH("vs_bn_train_fwd_small_groups");
+    if (running_mean) {
+        hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, var_scratch, groups, C, running_mean,
+                           running_var, momentum);
+        VS_CHECK_LAUNCH("vs_bn_train_fwd_small_groups running update");
+    }
     return VS_OK;
 }
 

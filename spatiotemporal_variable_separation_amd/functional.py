@@ -1261,8 +1261,8 @@ class ConvBlock(torch.autograd.Function):
             wpk = packed_img_weight(w, cdt, False)
             if has_bn:
                 z = ops.conv3_band(xc, wpk, bias, w.shape[0], cdt)
-                if training and groups == 1 and ops.bn_small_supported(z):
-                    y, mean, invstd = ops.bn_train_fwd_small(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps)
+                if training and ops.bn_small_supported(z, groups):
+                    y, mean, invstd = ops.bn_train_fwd_small(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps, groups=groups)
                 else:
                     if training:
                         mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
@@ -1293,9 +1293,9 @@ class ConvBlock(torch.autograd.Function):
             wc = shadow(w, cdt)
             wp = packed_conv_weight(w, cdt, stride, pad) if transposed else None
             z = ops.conv_fwd(xc, wc, bias, stride, pad, transposed, cdt, w_packed=wp)
-            if training and groups == 1 and ops.bn_small_supported(z):
+            if training and ops.bn_small_supported(z, groups):
                 # small maps (the SST integrator: 8 x 16 x 16 per channel): statistics, running update, affine + activation in one launch
-                y, mean, invstd = ops.bn_train_fwd_small(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps)
+                y, mean, invstd = ops.bn_train_fwd_small(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps, groups=groups)
             else:
                 if training:
                     mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)

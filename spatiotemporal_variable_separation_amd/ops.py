@@ -995,9 +995,15 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gro
     return mean, invstd
 
 
-def bn_small_supported(x):
+def bn_small_supported(x, groups=1):
     B, C = x.shape[0], x.shape[1]
-    return x.is_contiguous() and bool(_lib.load_library().vs_bn_train_fwd_small_supported(dtype_code(x), B, C, x.numel() // (B * C)))
+    if groups > 1:
+        # several calls stacked along the batch axis in one launch (vs_bn_train_fwd_small_groups): measured on the TaxiBJ step and NOT the
+        # default -- 8.95 ms with it, 8.93 without (the two-launch path's kernels overlap with their neighbours just as well)
+        import os
+        if os.environ.get('VS_BN_SMALL_GROUPS', '0') != '1' or B % groups != 0:
+            return False
+    return x.is_contiguous() and bool(_lib.load_library().vs_bn_train_fwd_small_supported(dtype_code(x), B // groups, C, x.numel() // (B * C)))
 
 
 def bn_small_supported_shape(dtype, B, C, HW):
@@ -1005,12 +1011,22 @@ def bn_small_supported_shape(dtype, B, C, HW):
     return bool(_lib.load_library().vs_bn_train_fwd_small_supported(code_of(dtype), B, C, HW))
 
 
-def bn_train_fwd_small(x, gamma, beta, act, out_dtype, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
-    """Training-mode BatchNorm + activation of one call in ONE launch (small tensors).  Returns (y, mean [1, C], invstd [1, C])."""
+def bn_train_fwd_small(x, gamma, beta, act, out_dtype, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, groups=1):
+    """Training-mode BatchNorm + activation of one call in ONE launch (small tensors).  Returns (y, mean [1, C], invstd [1, C]).
+    groups > 1: that many calls stacked along the batch axis, statistics per call ([groups, C]), running estimates folded in call order."""
     require_cuda(x)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    if groups > 1:
+        stats = torch.empty((3, groups, C), dtype=torch.float32, device=x.device)
+        e0 = _pb()
+        check(_lib.load_library().vs_bn_train_fwd_small_groups(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), gamma.data_ptr(), beta.data_ptr(),
+                                                               ACT[act], stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                                               _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), B, C, HW, groups,
+                                                               stream_ptr()), 'vs_bn_train_fwd_small_groups')
+        _pe(e0, 'vs_bn_fwd_small', nbytes=float(x.numel() * (x.element_size() + y.element_size())))
+        return y, stats[0], stats[1]
     mean = torch.empty((1, C), dtype=torch.float32, device=x.device)
     invstd = torch.empty((1, C), dtype=torch.float32, device=x.device)
     e0 = _pb()

@@ -723,3 +723,33 @@ def test_conv_thin_kernels_match_fp64(dtype, geom):
     if plans['dgrad'] is not None:
         dx16 = ops.conv_dgrad(dy.cuda(), w.cuda(), x.shape, s, p, tr, dtype)
         assert torch.equal(dx16.cpu(), dx.cpu().to(dtype))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape,groups', [((200, 64, 8, 8), 2), ((24, 512, 4, 4), 8), ((6, 40, 16, 16), 3)])
+def test_batchnorm_small_one_launch_with_call_groups_equals_one_call_per_group(dtype, shape, groups, monkeypatch):
+    """vs_bn_train_fwd_small_groups (several reference calls stacked along the batch axis, per-call statistics, running estimates folded in call
+    order) == the one-call launch applied to each group in turn, bit for bit (the VGG / DCGAN encoders' paired calls, the decoders'
+    per-frame calls, conv.py:41-60)."""
+    from spatiotemporal_variable_separation_amd import ops
+    monkeypatch.setenv('VS_BN_SMALL_GROUPS', '1')          # (not the default route: see ops.bn_small_supported)
+    B, C, H, W = shape
+    x = (_rand(shape, 71) * 3 + 0.5).to(dtype).cuda()
+    gamma, beta = (_rand((C,), 72) + 1.5).cuda(), _rand((C,), 73).cuda()
+    assert ops.bn_small_supported(x, groups)
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    y, mean, invstd = ops.bn_train_fwd_small(x, gamma, beta, 'leaky_relu', dtype, rm, rv, 0.1, 1e-5, groups=groups)
+    rm1, rv1 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    Bg = B // groups
+    for g in range(groups):
+        yg, mg, ig = ops.bn_train_fwd_small(x[g * Bg:(g + 1) * Bg].contiguous(), gamma, beta, 'leaky_relu', dtype, rm1, rv1, 0.1, 1e-5)
+        assert torch.equal(y[g * Bg:(g + 1) * Bg], yg) and torch.equal(mean[g], mg[0]) and torch.equal(invstd[g], ig[0])
+    assert torch.allclose(rm, rm1, rtol=1e-6, atol=1e-7) and torch.allclose(rv, rv1, rtol=1e-6, atol=1e-7)
+    # and against the two-launch path on the stacked tensor
+    rm2, rv2 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    m2, i2 = ops.bn_stats(x, rm2, rv2, 0.1, 1e-5, groups=groups)
+    y2 = ops.bn_act_fwd(x, m2, i2, gamma, beta, 'leaky_relu', dtype, groups=groups)
+    assert torch.allclose(mean, m2, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, i2, rtol=1e-5, atol=1e-6)
+    assert (y.float() - y2.float()).abs().max().item() <= (2e-2 if dtype != torch.float32 else 1e-5) * y2.float().abs().max().item()
+    assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5, atol=1e-6)
