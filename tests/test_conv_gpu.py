@@ -40,6 +40,8 @@ GEOMS = [
     (4, 24, 3, 3, 10, 3, 1, 0, False),      # conv_out: 3x3 valid -> 1x1
     (4, 64, 33, 33, 64, 3, 2, 1, False),    # 33 -> 17 with 64 channels: the column-matrix path on odd sizes
     (3, 8, 32, 32, 3, 4, 2, 1, True),       # DCGAN decoder last layer for 3-channel frames (chairs): one-pass kernel with 4 row slots
+    (64, 128, 4, 4, 64, 3, 1, 1, False),    # 3x3 on 4x4 maps at width (VGG encoder / decoder 512-channel layers): one-map-per-thread column gather,
+    (72, 64, 4, 4, 128, 3, 1, 1, True),     #   weight gradient through the dense transposed copy of the channel-rows operand
 ]
 
 
