@@ -540,6 +540,55 @@ __global__ __launch_bounds__(256) void im2col_s1_w4_kernel(TapGather<CT> gth, ty
     }
 }
 
+// k4 s2 p1 taps from 8 x 8 maps onto their 4 x 4 grid (the DCGAN encoder's c4 / decoder's upc2, conv.py:122, 260): one thread owns a map (eight
+// 16-byte rows), splits every row once into its even and odd columns (tap kx reads columns 2 gx - 1 + kx: odds shifted, evens, odds, evens
+// shifted) and writes the 16 grid pixels of each of the 16 taps as 32 contiguous bytes.
+template <int CT>
+__global__ __launch_bounds__(256) void im2col_k4s2_w8_kernel(TapGather<CT> gth, typename CTraits<CT>::T* cols, int64_t ld, int64_t maps) {
+    typedef typename CTraits<CT>::T T;
+    const TapGeo& g = gth.g;
+    const int c = blockIdx.y;
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < maps; b += (int64_t)gridDim.x * 256) {
+        const T* plane = gth.src + (b * g.C + c) * 64;
+        uint64_t ev[8], od[8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(plane + y * 8);       // dword j = columns (2 j, 2 j + 1)
+            ev[y] = (uint64_t)((v[0] & 0xffffu) | (v[1] << 16)) | ((uint64_t)((v[2] & 0xffffu) | (v[3] << 16)) << 32);
+            od[y] = (uint64_t)((v[0] >> 16) | (v[1] & 0xffff0000u)) | ((uint64_t)((v[2] >> 16) | (v[3] & 0xffff0000u)) << 32);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            uint64_t e4[4], o4[4];                                                // source rows 2 gy - 1 + ky, gy = 0 .. 3 (zeros outside)
+#pragma unroll
+            for (int gy = 0; gy < 4; ++gy) {
+                const int sy = 2 * gy - 1 + ky;                                    // compile-time after unrolling
+                e4[gy] = (sy >= 0 && sy < 8) ? ev[sy < 0 ? 0 : (sy > 7 ? 7 : sy)] : 0ull;
+                o4[gy] = (sy >= 0 && sy < 8) ? od[sy < 0 ? 0 : (sy > 7 ? 7 : sy)] : 0ull;
+            }
+            T* dst = cols + ((int64_t)c * 16 + ky * 4) * ld + b * 16;              // tap t = ky * 4 + kx (natural_taps order)
+            auto put = [&](T* d, const uint64_t* q) {
+                *reinterpret_cast<u32x4*>(d) = u32x4{(unsigned)q[0], (unsigned)(q[0] >> 32), (unsigned)q[1], (unsigned)(q[1] >> 32)};
+                *reinterpret_cast<u32x4*>(d + 8) = u32x4{(unsigned)q[2], (unsigned)(q[2] >> 32), (unsigned)q[3], (unsigned)(q[3] >> 32)};
+            };
+            uint64_t os[4], es[4];
+#pragma unroll
+            for (int gy = 0; gy < 4; ++gy) { os[gy] = o4[gy] << 16; es[gy] = e4[gy] >> 16; }
+            put(dst, os);                                                          // kx = 0: columns 2 gx - 1
+            put(dst + ld, e4);                                                     // kx = 1: columns 2 gx
+            put(dst + 2 * ld, o4);                                                 // kx = 2: columns 2 gx + 1
+            put(dst + 3 * ld, es);                                                 // kx = 3: columns 2 gx + 2
+        }
+    }
+}
+
+inline bool k4s2_w8_ok(const TapGeo& g, int64_t npix, const void* src) {
+    if (g.s != 2 || g.ntap != 16 || g.H != 8 || g.W != 8 || g.GH != 4 || g.GW != 4 || npix % 16 != 0 || (uintptr_t)src % 16 != 0) return false;
+    for (int t = 0; t < 16; ++t)
+        if (g.dy[t] != t / 4 - 1 || g.dx[t] != t % 4 - 1) return false;              // natural (unflipped) k4 p1 taps
+    return true;
+}
+
 inline bool s1_w4_ok(const TapGeo& g, int64_t npix, const void* src) {
     if (g.s != 1 || g.H != 4 || g.W != 4 || g.GH != 4 || g.GW != 4 || npix % 16 != 0 || (uintptr_t)src % 16 != 0) return false;
     for (int t = 0; t < g.ntap; ++t)
@@ -583,6 +632,14 @@ int materialise(const TapGather<CT>& gth, void* ws, hipStream_t st, const char* 
             int64_t bm = (maps + 255) / 256;
             if (bm > 1024) bm = 1024;
             hipLaunchKernelGGL(im2col_s1_w4_kernel<CT>, dim3((unsigned)bm, (unsigned)gth.g.C), dim3(256), 0, st, gth, (typename CTraits<CT>::T*)ws, ld, maps);
+            VS_CHECK_LAUNCH(what);
+            return VS_OK;
+        }
+        if (k4s2_w8_ok(gth.g, gth.npix, gth.src) && getenv("VS_IM2COL_W4") == nullptr) {
+            const int64_t maps = gth.npix / 16;
+            int64_t bm = (maps + 255) / 256;
+            if (bm > 1024) bm = 1024;
+            hipLaunchKernelGGL(im2col_k4s2_w8_kernel<CT>, dim3((unsigned)bm, (unsigned)gth.g.C), dim3(256), 0, st, gth, (typename CTraits<CT>::T*)ws, ld, maps);
             VS_CHECK_LAUNCH(what);
             return VS_OK;
         }

@@ -42,6 +42,7 @@ GEOMS = [
     (3, 8, 32, 32, 3, 4, 2, 1, True),       # DCGAN decoder last layer for 3-channel frames (chairs): one-pass kernel with 4 row slots
     (64, 128, 4, 4, 64, 3, 1, 1, False),    # 3x3 on 4x4 maps at width (VGG encoder / decoder 512-channel layers): one-map-per-thread column gather,
     (72, 64, 4, 4, 128, 3, 1, 1, True),     #   weight gradient through the dense transposed copy of the channel-rows operand
+    (64, 64, 8, 8, 128, 4, 2, 1, False),    # DCGAN encoder c4 geometry (8x8 -> 4x4): k4 s2 column gather with one 8x8 map per thread
 ]
 
 
