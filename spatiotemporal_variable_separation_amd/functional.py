@@ -923,6 +923,14 @@ def packed_k4s2_weight(p, dtype):
     return ent[1]
 
 
+def _conv_lane():
+    """Gradient stream of the next convolution weight gradient (VARSEP_CONV_WGRAD_LANES of them in turn, default 1)."""
+    n = max(1, int(os.environ.get('VARSEP_CONV_WGRAD_LANES', '1')))
+    i = _SIDE.get('conv_lane', 0)
+    _SIDE['conv_lane'] = (i + 1) % n
+    return i
+
+
 def _conv_weight_grad(w, dz, xc, stride, pad, transposed, k4s2=None):
     """Weight gradient of one convolution call for autograd, or None when it was added to / will be batched into the tensor autograd
     already holds.  `k4s2` = (small map, parity planes of the large map): the k4 s2 p1 family on the row-band kernels (ops.conv_k4s2_wgrad)."""
@@ -931,9 +939,18 @@ def _conv_weight_grad(w, dz, xc, stride, pad, transposed, k4s2=None):
     dw = None
     dst = conv_grad_output(w)
     first_w = dst if dst is not None else (_fold_slots().get(id(w)) if _STATE.get('fold_grads') else None)
+    _STATE['wgrad_on_lane'] = False
+    # a gradient that accumulates into a destination autograd never sees (dst) is nobody's input until the optimizer: with gradient streams on it
+    # runs on one of them, beside the input-gradient / BatchNorm chain (train.GraphedStep joins the streams before the optimizer step)
+    on_lane = (dst is not None and first_w is dst and _SIDE['on'] and not _defer_wgrad_ok(w, dz, transposed, stride)
+               and dst.dtype == torch.float32 and dst.is_contiguous())
     if k4s2 is not None:
         if first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
-            ops.conv_k4s2_wgrad(k4s2[0], k4s2[1], w.shape, into=first_w)
+            if on_lane:
+                run_deferred(lambda a=k4s2[0], b=k4s2[1]: ops.conv_k4s2_wgrad(a, b, w.shape, into=dst), k4s2[0], k4s2[1], outs=dst, lane=_conv_lane())
+                _STATE['wgrad_on_lane'] = True
+            else:
+                ops.conv_k4s2_wgrad(k4s2[0], k4s2[1], w.shape, into=first_w)
             return None
         return ops.conv_k4s2_wgrad(k4s2[0], k4s2[1], w.shape)
     if _defer_wgrad_ok(w, dz, transposed, stride):
@@ -954,7 +971,11 @@ def _conv_weight_grad(w, dz, xc, stride, pad, transposed, k4s2=None):
                 _DEFER_W['queued'] = True
         slot['pairs'].append((dz, xc))
     elif first_w is not None and first_w.dtype == torch.float32 and first_w.shape == w.shape and first_w.is_contiguous():
-        ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed, into=first_w)
+        if on_lane:
+            run_deferred(lambda: ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed, into=dst), dz, xc, outs=dst, lane=_conv_lane())
+            _STATE['wgrad_on_lane'] = True
+        else:
+            ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed, into=first_w)
     else:
         dw = ops.conv_wgrad(dz, xc, w.shape, stride, pad, transposed)
     return dw
@@ -1380,7 +1401,7 @@ class ConvBlock(torch.autograd.Function):
             else:
                 wp = None if transposed else packed_conv_weight(w, cdt, stride, pad)
                 dx = ops.conv_dgrad(dz, shadow(w, cdt), x_shape, stride, pad, transposed, ctx.x_dtype, w_packed=wp,
-                                    cols_from_wgrad=transposed and bool(w.requires_grad))
+                                    cols_from_wgrad=transposed and bool(w.requires_grad) and not _STATE.get('wgrad_on_lane'))
         dw, db, dgamma, dbeta = _fold_param_grads(((w, dw), (b, db), (ctx.gamma, dgamma), (ctx.beta, dbeta)))
         return dx, dw, db, dgamma, dbeta, None, None, None
 

@@ -221,6 +221,16 @@ class GraphedStep:
         # (functional.set_conv_grad_outputs), so gradient folding and the batched weight gradients stay on and the data-parallel
         # step runs the kernels of the single-GPU step
         self._conv_sinks = conv_gradient_sinks(sep_net, grad_sync) if (grad_sync is not None and not self.mlp) else None
+        # single process, conv family: the same destinations WITHOUT a reducer (one flat fp32 buffer, zeroed at the start of the step) --
+        # a weight gradient that accumulates into a tensor autograd never sees can run on a gradient stream beside the input-gradient /
+        # BatchNorm chain it does not feed (functional._conv_weight_grad); joined before the optimizer.  VARSEP_CONV_WGRAD_SIDE=1 turns it on;
+        # measured and NOT the default: with 8 hardware queues the replayed steps double (TaxiBJ 8.74 -> 17.2 ms, Moving-MNIST 7.0 -> 11.9, SST
+        # 21.0 -> 43: every launch of the ~700-kernel main chain slows down while a second queue is busy), with 4 / 2 queues nothing overlaps
+        # and the zero fill + accumulate cost 4 % (9.07 vs 8.74 ms).
+        self._local_flat = None
+        if grad_sync is None and not self.mlp and side_streams and os.environ.get('VARSEP_CONV_WGRAD_SIDE', '0') == '1':
+            self._local_flat, self._conv_sinks = local_conv_gradient_sinks(sep_net)
+            self.side_streams = True
         self._one = torch.ones((), dtype=torch.float32, device=cond.device)
         if grad_sync is not None and self.mlp and getattr(grad_sync, 'lowp_views', None) and hasattr(optimizer, 'step_subset'):
             # the chains' weight gradients are produced, averaged and consumed as bf16 wire images (parallel.GradAllReducer)
@@ -350,6 +360,17 @@ class GraphedStep:
             elif self._conv_sinks:
                 VF.set_conv_grad_outputs(self._conv_sinks)
                 VF.fold_repeated_gradients(True, flush=False)
+        elif self._local_flat is not None:
+            self._local_flat.zero_()
+            for prm, view in self._conv_sinks.items():
+                prm.grad = view
+            sinks = {id(p) for p in self._conv_sinks}
+            for group in self.opt.param_groups:
+                for prm in group['params']:
+                    if id(prm) not in sinks:
+                        prm.grad = None
+            VF.set_conv_grad_outputs(self._conv_sinks)
+            VF.fold_repeated_gradients(True, flush=False)
         else:
             self.opt.zero_grad(set_to_none=True)
         VF.enable_side_streams(self.side_streams)
@@ -398,6 +419,25 @@ class GraphedStep:
             self._reduce()
             self.graph_opt.replay()
         return self.loss
+
+
+def local_conv_gradient_sinks(sep_net):
+    """(flat fp32 buffer, {convolution / BatchNorm parameter: its view}) for functional.set_conv_grad_outputs in a single-process step: the
+    gradients accumulate into the views (`p.grad` of these parameters), the buffer is zeroed once per step."""
+    import torch.nn as nn
+    from . import functional as VF
+    from .networks.conv import ConvResBlock
+    for blk in sep_net.modules():
+        if isinstance(blk, ConvResBlock):
+            VF.mark_repeated([m.weight for m in blk.modules() if isinstance(m, nn.Conv2d)])
+            blk._marked = True
+    params = VF.conv_parameters(sep_net)
+    offs, n = [], 0
+    for prm in params:
+        offs.append(n)
+        n += (prm.numel() + 3) // 4 * 4                  # 16-byte aligned views
+    flat = torch.zeros((n,), dtype=torch.float32, device=params[0].device)
+    return flat, {prm: flat[o:o + prm.numel()].view(prm.shape) for prm, o in zip(params, offs)}
 
 
 def conv_gradient_sinks(sep_net, grad_sync):

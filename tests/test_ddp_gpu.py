@@ -273,3 +273,23 @@ def test_conv_family_two_ranks_equal_two_independent_halves(tmp_path, name, prec
         worst = max(worst, e)
         assert e <= tol, f'{k}: the update of the data-parallel run differs from the two-halves reference by {e:.3e} of its norm'
     print(name, precision, 'graph' if graph else 'eager', 'worst update distance %.2e' % worst, 'losses', r0['losses'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['vgg32_tiny', 'dcgan_tiny'])
+def test_recorded_conv_step_with_weight_gradients_on_a_gradient_stream(name, monkeypatch):
+    """VARSEP_CONV_WGRAD_SIDE=1 (optional route of train.GraphedStep: convolution / BatchNorm gradients accumulate into a local flat buffer,
+    weight gradients run on a gradient stream and are joined before the optimizer) computes what the plain recorded step computes."""
+    cfg = dict(CONFIGS[name])
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    runs = {}
+    for side in ('0', '1'):
+        monkeypatch.setenv('VARSEP_CONV_WGRAD_SIDE', side)
+        net = _build(cfg, salt=3)
+        runs[side] = (_run(net, cond, target, cfg, None, True, 3), {k: v.detach().float().cpu() for k, v in net.state_dict().items()})
+    assert np.allclose(runs['0'][0], runs['1'][0], rtol=2e-4), (runs['0'][0], runs['1'][0])
+    for k, v in runs['0'][1].items():
+        if v.dtype.is_floating_point and v.numel() > 1:
+            d = (runs['1'][1][k] - v).norm().item() / (v.norm().item() + 1e-12)
+            assert d < 2e-3, (k, d)
