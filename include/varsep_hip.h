@@ -231,6 +231,17 @@ int vs_conv_k4s2_skip_form(int K);
 int vs_conv_k4s2_band(int compute, const void* planes, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int K, int H, int W, int M,
                       void* stream);
 int vs_conv_k4s2_wgrad_band(int compute, const void* planes, const void* small_map, float* slabs, int B, int K, int H, int W, int M, void* stream);
+/* vs_conv3_band / vs_conv_k4s2_band with the BatchNorm statistics of the output taken in the epilogue (replaces the vs_bn_stats pass behind
+ * conv -> BatchNorm, reference conv.py:41-60): (sum, sum of squares) of the STORED values are added to bn_sums [groups][Cout][2] (fp64),
+ * group = map / (B / groups).  vs_bn_stats_from_sums_fold turns them into mean / invstd [groups][C], folds the running estimates in call order
+ * and (reset != 0) leaves the sums at zero for the next step -- one launch instead of vs_bn_stats_from_sums' two. */
+int vs_conv3_band_bn_supported(int compute, int B, int Cin, int H, int W, int Cout, int groups);
+int vs_conv3_band_bn(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W, int Cout,
+                     double* bn_sums, int groups, void* stream);
+int vs_conv_k4s2_band_bn(int compute, const void* planes, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int K, int H, int W, int M,
+                         double* bn_sums, int groups, void* stream);
+int vs_bn_stats_from_sums_fold(double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* running_mean, float* running_var,
+                               float momentum, float eps, int reset, void* stream);
 int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout);
 int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int W, int Cout, void* stream);
 int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,

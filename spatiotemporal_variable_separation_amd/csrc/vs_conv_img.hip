@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned s
 template <int CT, int W, int AHEAD, int MINB, int K4 = 0>
 __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
                                                          void* __restrict__ Y, int yd, int B, int Cin, int H, int Cout, int mtiles, int bands,
-                                                         int band_xcd_remap) {
+                                                         int band_xcd_remap, double* __restrict__ bn_sums, int maps_per_group) {
     constexpr int NKY = K4 ? 2 : 3, NF = K4 ? 2 : 3, GPP = 4 * NKY;              // tap rows and fragments per group, groups per 64-channel phase
     static_assert(GPP % AHEAD == 0, "the fragment ring must divide the groups of a phase");
     // W >= 16: the tile is R = 256 / W rows of ONE map (`band` = which rows); W = 8: FOUR whole 8 x 8 maps (`band` = which four, b = 0);
@@ -351,11 +351,29 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
             const int64_t o = obase + (int64_t)m * 16;
             if (m < Cout && oimg < B) vs_st(Y, yd, o, acc[1][0][v] + left0 + right0 + bv);
             if (m < Cout && oimg + 2 < B) vs_st(Y, yd, o + (int64_t)2 * Cout * 16, acc[1][1][v] + left1 + right1 + bv);
-        } else if (m < Cout && oimg < B) {
+        } else {
             const float bv = bvs[v];
-            const int64_t o = obase + (int64_t)m * H * W;
-            vs_st(Y, yd, o, acc[1][0][v] + left0 + right0 + bv);
-            vs_st(Y, yd, o + 32, acc[1][1][v] + left1 + right1 + bv);
+            const float o0 = acc[1][0][v] + left0 + right0 + bv, o1 = acc[1][1][v] + left1 + right1 + bv;
+            const bool live = m < Cout && oimg < B;
+            if (live) {
+                const int64_t o = obase + (int64_t)m * H * W;
+                vs_st(Y, yd, o, o0);
+                vs_st(Y, yd, o + 32, o1);
+            }
+            if (bn_sums) {
+                // sum and sum of squares of the STORED values (rounded as stored: what a statistics pass over y would read) of this wave's 64
+                // pixels of channel m -> the (call group, channel) slot the following BatchNorm reads: fp32 over the 32 lanes, fp64 atomics
+                // across waves and workgroups (all pixels of a wave lie in one map here: W >= 8)
+                const float r0 = yd == VS_F32 ? o0 : vs_h2f(vs_f2h(o0, yd), yd), r1 = yd == VS_F32 ? o1 : vs_h2f(vs_f2h(o1, yd), yd);
+                float s1 = live ? r0 + r1 : 0.f, s2 = live ? r0 * r0 + r1 * r1 : 0.f;
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+                if (l31 == 0 && live) {
+                    double* slot = bn_sums + ((int64_t)(oimg / maps_per_group) * Cout + m) * 2;
+                    atomicAdd(slot, (double)s1);
+                    atomicAdd(slot + 1, (double)s2);
+                }
+            }
         }
     }
 }
@@ -763,7 +781,7 @@ constexpr size_t band_buf_bytes() {
 
 template <int W, int AHEAD, int MINB, int K4 = 0>
 static int launch_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
-                       hipStream_t stream) {
+                       hipStream_t stream, double* bn_sums = nullptr, int maps_per_group = 1) {
     constexpr int R = W == 8 ? 8 : (W == 4 ? 4 : 256 / W), IPB = W == 8 ? 4 : (W == 4 ? 16 : 1);
     const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * band_buf_bytes<W>();         // one buffer when there is a single 64-channel phase
     auto kb = conv3_band_kernel<VS_BF16, W, AHEAD, MINB, K4>;
@@ -782,48 +800,62 @@ static int launch_band(int compute, const void* x, const void* w_packed, const f
     const int remap = xcd_remap && mtiles > 1 && grid.x >= 64;
     if (compute == VS_BF16)
         hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands,
-                           remap);
+                           remap, bn_sums, maps_per_group);
     else
         hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands,
-                           remap);
+                           remap, bn_sums, maps_per_group);
     return VS_OK;
 }
 
 // k4 s2 p1 on parity planes (K4 form of the kernel): 8 fragment groups per phase -> rings of 4 (two workgroups per CU) or 8
 template <int W>
 static int launch_band_k4_w(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
-                            hipStream_t stream) {
+                            hipStream_t stream, double* bn_sums = nullptr, int mpg = 1) {
     static const int pair_mode = getenv("VS_CONV_BAND_PAIR") ? atoi(getenv("VS_CONV_BAND_PAIR")) : 1;
     const size_t lds = 2 * band_buf_bytes<W>();                                  // Cin = 4 K >= 256: always two buffers
-    if (pair_mode && 2 * lds <= 160 * 1024) return launch_band<W, 4, 2, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
-    return launch_band<W, 8, 1, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
+    if (pair_mode && 2 * lds <= 160 * 1024) return launch_band<W, 4, 2, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream, bn_sums, mpg);
+    return launch_band<W, 8, 1, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream, bn_sums, mpg);
 }
 
 template <int W>
 static int launch_band_w(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int Cout,
-                         hipStream_t stream) {
+                         hipStream_t stream, double* bn_sums = nullptr, int mpg = 1) {
     // two workgroups per CU where 2 x LDS fits (VS_CONV_BAND_PAIR=0: always the deep-prefetch form)
     static const int pair_mode = getenv("VS_CONV_BAND_PAIR") ? atoi(getenv("VS_CONV_BAND_PAIR")) : 1;
     const size_t lds = (size_t)(Cin > 64 ? 2 : 1) * band_buf_bytes<W>();
-    if (pair_mode && 2 * lds <= 160 * 1024) return launch_band<W, 4, 2>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
-    return launch_band<W, 12, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream);
+    if (pair_mode && 2 * lds <= 160 * 1024) return launch_band<W, 4, 2>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream, bn_sums, mpg);
+    return launch_band<W, 12, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream, bn_sums, mpg);
 }
 
 // x [B][Cin][H][W] (16-bit), w_packed from vs_conv3_img16_pack_weight (same pre-pack) -> y [B][Cout][H][W] in y_dtype, bias added
-extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
-                             int Cout, void* stream) {
+// bn_sums != NULL: the (sum, sum of squares) of the stored outputs are ADDED to bn_sums[group][Cout][2] (fp64; group = map / (B / groups)) -- what the
+// BatchNorm behind the convolution needs (vs_bn_stats_from_sums_fold), without a statistics pass over y.  Maps of >= 8 x 8 pixels only
+// (vs_conv3_band_bn_supported).
+extern "C" int vs_conv3_band_bn_supported(int compute, int B, int Cin, int H, int W, int Cout, int groups) {
+    return vs_conv3_band_supported(compute, B, Cin, H, W, Cout) && W >= 8 && groups >= 1 && B % groups == 0;     // (a wave's 64 pixels lie in ONE map)
+}
+
+extern "C" int vs_conv3_band_bn(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
+                                int Cout, double* bn_sums, int groups, void* stream) {
     VS_CHECK_ARG(x && w_packed && y && vs_dtype_ok(y_dtype), "vs_conv3_band: bad argument");
     VS_CHECK_ARG(vs_conv3_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_band: unsupported geometry (query vs_conv3_band_supported)");
-    VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0, "vs_conv3_band: operands must be 16-byte aligned");
+    VS_CHECK_ARG(!bn_sums || vs_conv3_band_bn_supported(compute, B, Cin, H, W, Cout, groups), "vs_conv3_band_bn: statistics not served for this geometry");
+    VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0 && (uintptr_t)bn_sums % 8 == 0, "vs_conv3_band: operands must be 16-byte aligned");
+    const int mpg = bn_sums ? B / groups : 1;
     int rc;
-    if (W == 64) rc = launch_band_w<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
-    else if (W == 32) rc = launch_band_w<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
-    else if (W == 16) rc = launch_band_w<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
-    else if (W == 8) rc = launch_band_w<8>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
+    if (W == 64) rc = launch_band_w<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream, bn_sums, mpg);
+    else if (W == 32) rc = launch_band_w<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream, bn_sums, mpg);
+    else if (W == 16) rc = launch_band_w<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream, bn_sums, mpg);
+    else if (W == 8) rc = launch_band_w<8>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream, bn_sums, mpg);
     else rc = launch_band_w<4>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream);
     if (rc != VS_OK) return rc;
     VS_CHECK_LAUNCH("vs_conv3_band");
     return VS_OK;
+}
+
+extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
+                             int Cout, void* stream) {
+    return vs_conv3_band_bn(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, W, Cout, nullptr, 1, stream);
 }
 
 // ---- weight gradient on row bands: x [B][Cin][H][W], dz [B][Cout][H][W] (16-bit) -> fp32 slabs [vs_conv3_wgrad_band_slabs][Cout][Cin][3][3] ----
@@ -910,21 +942,28 @@ extern "C" int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, f
 // the matching 2 x 2 form); otherwise the plain 3 x 3 kernels on a zero-padded 3 x 3 pack.
 extern "C" int vs_conv_k4s2_skip_form(int K) { return K >= 64 && K % 64 == 0; }
 
-extern "C" int vs_conv_k4s2_band(int compute, const void* planes, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int K, int H, int W,
-                                 int M, void* stream) {
+extern "C" int vs_conv_k4s2_band_bn(int compute, const void* planes, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int K, int H, int W,
+                                    int M, double* bn_sums, int groups, void* stream) {
     VS_CHECK_ARG(planes && w_packed && y && vs_dtype_ok(y_dtype), "vs_conv_k4s2_band: bad argument");
     VS_CHECK_ARG(vs_conv3_band_supported(compute, B, 4 * K, H, W, M), "vs_conv_k4s2_band: unsupported geometry (query vs_conv3_band_supported on the planes)");
-    VS_CHECK_ARG(((uintptr_t)planes | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0, "vs_conv_k4s2_band: operands must be 16-byte aligned");
-    if (!vs_conv_k4s2_skip_form(K)) return vs_conv3_band(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, W, M, stream);
+    VS_CHECK_ARG(!bn_sums || vs_conv3_band_bn_supported(compute, B, 4 * K, H, W, M, groups), "vs_conv_k4s2_band_bn: statistics not served for this geometry");
+    VS_CHECK_ARG(((uintptr_t)planes | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0 && (uintptr_t)bn_sums % 8 == 0, "vs_conv_k4s2_band: operands must be 16-byte aligned");
+    if (!vs_conv_k4s2_skip_form(K)) return vs_conv3_band_bn(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, W, M, bn_sums, groups, stream);
+    const int mpg = bn_sums ? B / groups : 1;
     int rc;
-    if (W == 64) rc = launch_band_k4_w<64>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
-    else if (W == 32) rc = launch_band_k4_w<32>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
-    else if (W == 16) rc = launch_band_k4_w<16>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
-    else if (W == 8) rc = launch_band_k4_w<8>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
+    if (W == 64) rc = launch_band_k4_w<64>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream, bn_sums, mpg);
+    else if (W == 32) rc = launch_band_k4_w<32>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream, bn_sums, mpg);
+    else if (W == 16) rc = launch_band_k4_w<16>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream, bn_sums, mpg);
+    else if (W == 8) rc = launch_band_k4_w<8>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream, bn_sums, mpg);
     else rc = launch_band_k4_w<4>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream);
     if (rc != VS_OK) return rc;
     VS_CHECK_LAUNCH("vs_conv_k4s2_band");
     return VS_OK;
+}
+
+extern "C" int vs_conv_k4s2_band(int compute, const void* planes, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int K, int H, int W,
+                                 int M, void* stream) {
+    return vs_conv_k4s2_band_bn(compute, planes, w_packed, bias, y, y_dtype, B, K, H, W, M, nullptr, 1, stream);
 }
 
 extern "C" int vs_conv_k4s2_wgrad_band(int compute, const void* planes, const void* small, float* slabs, int B, int K, int H, int W, int M, void* stream) {

@@ -402,6 +402,30 @@ __global__ __launch_bounds__(256) void bn_running_from_groups_kernel(const float
     rvar[c] = (float)rv;
 }
 
+// mean / invstd of every (call group, channel) from the epilogue sums AND the running estimates folded in call order, one thread per channel;
+// reset: the sums are left at zero for the next step (a persistent buffer then needs no fill launch)
+__global__ __launch_bounds__(256) void bn_from_sums_fold_kernel(double* sums, int G, int C, double n, float eps, float* mean, float* invstd, float* rmean,
+                                                                float* rvar, float momentum, int reset) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double rm = rmean ? (double)rmean[c] : 0.0, rv = rvar ? (double)rvar[c] : 0.0;
+    for (int g = 0; g < G; ++g) {
+        const int i = g * C + c;
+        const double ts = sums[2 * i], tq = sums[2 * i + 1];
+        const double mu = ts / n;
+        double ss = tq - ts * mu;
+        if (ss < 0.0) ss = 0.0;
+        const double var = ss / n;
+        mean[i] = (float)mu;
+        invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+        const float ub = (float)(n > 1.0 ? ss / (n - 1.0) : var);
+        rm = (double)(float)((1.0 - momentum) * rm + momentum * (double)(float)mu);
+        rv = (double)(float)((1.0 - momentum) * rv + momentum * (double)ub);
+        if (reset) { sums[2 * i] = 0.0; sums[2 * i + 1] = 0.0; }
+    }
+    if (rmean) { rmean[c] = (float)rm; rvar[c] = (float)rv; }
+}
+
 }  // namespace
 
 extern "C" int vs_convt_tap_supported(int compute, int B, int Cin, int H, int W, int Cout, int groups) {
@@ -517,6 +541,18 @@ extern "C" int vs_conv_k3s1_tap_fwd(int compute, const void* x, const void* w_ta
         hipLaunchKernelGGL(kh, grid, dim3(512), BIG_STAGES * BIG_TILE_BYTES, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)w_tap, bias,
                            y, y_dtype, bn_sums, B, Cin, H, W, Cout, B / groups, tiles_m);
     VS_CHECK_LAUNCH("vs_conv_k3s1_tap_fwd");
+    return VS_OK;
+}
+
+// vs_bn_stats_from_sums in ONE launch (statistics of every call group and the running estimates folded in call order); reset != 0 leaves the
+// sums at zero, so a persistent sums buffer needs no fill launch before the next convolution adds into it
+extern "C" int vs_bn_stats_from_sums_fold(double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* running_mean,
+                                          float* running_var, float momentum, float eps, int reset, void* stream) {
+    VS_CHECK_ARG(sums && mean && invstd && groups >= 1 && C > 0 && n_per_group > 0, "vs_bn_stats_from_sums_fold: bad argument");
+    VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "vs_bn_stats_from_sums_fold: running_mean/var must come together");
+    hipLaunchKernelGGL(bn_from_sums_fold_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, groups, C, (double)n_per_group, eps,
+                       mean, invstd, running_mean, running_var, momentum, reset);
+    VS_CHECK_LAUNCH("vs_bn_stats_from_sums_fold");
     return VS_OK;
 }
 

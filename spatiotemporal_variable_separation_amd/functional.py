@@ -1243,12 +1243,19 @@ class ConvBlock(torch.autograd.Function):
             wpk = packed_k4s2_weight(w, cdt)
             ctx.k4_planes = True
             if has_bn:
-                z = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], cdt)
-                if training:
-                    mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
+                Bp, C4, Hp, Wp = planes.shape
+                if training and ops.conv_band_bn_supported(Bp, C4, Hp, Wp, w.shape[0], groups, cdt):
+                    # the BatchNorm sums are taken in the convolution's epilogue: no statistics pass over z
+                    sums = ops.bn_sums_buffer(gamma.data_ptr(), groups, w.shape[0], planes.device)
+                    z = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], cdt, bn_sums=sums, groups=groups)
+                    mean, invstd = ops.bn_stats_from_sums_fold(sums, (Bp // groups) * Hp * Wp, rmean, rvar, momentum, eps)
                 else:
-                    mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
-                    invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
+                    z = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], cdt)
+                    if training:
+                        mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
+                    else:
+                        mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
+                        invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
                 y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
                 ctx.save_for_backward(planes, z, mean, invstd)
             else:
@@ -1281,6 +1288,20 @@ class ConvBlock(torch.autograd.Function):
             # 3x3 on many maps of width 16 / 32 / 64: row bands through LDS, no column matrix; BatchNorm as for the column-matrix path
             wpk = packed_img_weight(w, cdt, False)
             if has_bn:
+                Bx, Cx, Hx, Wx = xc.shape
+                small = training and ops.bn_small_supported_shape(cdt, Bx, w.shape[0], Hx * Wx) and (groups == 1 or ops.bn_small_groups_enabled())
+                if training and not small and ops.conv_band_bn_supported(Bx, Cx, Hx, Wx, w.shape[0], groups, cdt):
+                    # the BatchNorm sums are taken in the convolution's epilogue: no statistics pass over z
+                    sums = ops.bn_sums_buffer(gamma.data_ptr(), groups, w.shape[0], xc.device)
+                    z = ops.conv3_band(xc, wpk, bias, w.shape[0], cdt, bn_sums=sums, groups=groups)
+                    mean, invstd = ops.bn_stats_from_sums_fold(sums, (Bx // groups) * Hx * Wx, rmean, rvar, momentum, eps)
+                    y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
+                    ctx.save_for_backward(xc, z, mean, invstd)
+                    ctx.cfg, ctx.cdt = cfg, cdt
+                    ctx.w, ctx.b, ctx.gamma, ctx.beta = w, b, gamma, beta
+                    ctx.x_dtype, ctx.x_needs_grad = x.dtype, x.requires_grad
+                    ctx.x_shape = tuple(xc.shape)
+                    return y
                 z = ops.conv3_band(xc, wpk, bias, w.shape[0], cdt)
                 if training and ops.bn_small_supported(z, groups):
                     y, mean, invstd = ops.bn_train_fwd_small(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps, groups=groups)
@@ -1304,7 +1325,7 @@ class ConvBlock(torch.autograd.Function):
                 z, sums = ops.conv_k3_tap_fwd(xc, packed_k3_weight(w, cdt, False), bias, w.shape[0], cdt, groups=groups, want_sums=training)
             if training:
                 n_per = (z.shape[0] // groups) * z.shape[2] * z.shape[3]
-                mean, invstd = ops.bn_stats_from_sums(sums, n_per, rmean, rvar, momentum, eps)
+                mean, invstd = ops.bn_stats_from_sums_fold(sums, n_per, rmean, rvar, momentum, eps, reset=False)     # (one launch: statistics + running fold)
             else:
                 mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
                 invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()

@@ -738,7 +738,7 @@ def conv_k4s2_pack_weight(w_master, dtype, out=None):
     return out
 
 
-def conv_k4s2_gather(planes, w_packed, bias, M, out_dtype, role='fwd'):
+def conv_k4s2_gather(planes, w_packed, bias, M, out_dtype, role='fwd', bn_sums=None, groups=1):
     """out [B, M, h, w] = k4 s2 p1 gather of the large map whose parity planes are `planes` [B, 4 K, h, w] with the packed weight
     (Conv2d forward: role 'fwd'; ConvTranspose2d input gradient: role 'dgrad')."""
     require_cuda(planes, w_packed, bias)
@@ -746,8 +746,8 @@ def conv_k4s2_gather(planes, w_packed, bias, M, out_dtype, role='fwd'):
     B, C4, H, W = planes.shape
     y = torch.empty((B, M, H, W), dtype=out_dtype, device=planes.device)
     e0 = _pb()
-    check(_lib.load_library().vs_conv_k4s2_band(dtype_code(planes), planes.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, C4 // 4,
-                                                H, W, M, stream_ptr()), 'vs_conv_k4s2_band')
+    check(_lib.load_library().vs_conv_k4s2_band_bn(dtype_code(planes), planes.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B,
+                                                   C4 // 4, H, W, M, _ptr(bn_sums), groups, stream_ptr()), 'vs_conv_k4s2_band')
     # algorithmic work of the 4x4 window: 16 taps x K channels (the zero taps of the 3x3 form are not counted)
     _pe(e0, 'vs_conv_k4s2:%s<%s>' % (role, _DT[dtype_code(planes)]), flops=2.0 * B * H * W * M * (C4 // 4) * 16,
         nbytes=float(planes.numel() * planes.element_size() + M * (C4 // 4) * 16 * 2 + y.numel() * y.element_size()))
@@ -907,15 +907,53 @@ def conv3_band_supported(x, Cout):
     return bool(_lib.load_library().vs_conv3_band_supported(dtype_code(x), B, Cin, H, W, Cout))
 
 
-def conv3_band(x, w_packed, bias, Cout, out_dtype, role='fwd'):
-    """Conv2d k3 s1 p1 of x [B, Cin, H, W] (16-bit) with the `conv3_img16_pack_weight` pre-pack -> y [B, Cout, H, W] in out_dtype (+ bias)."""
+# ---- BatchNorm sums taken in a convolution's epilogue: persistent fp64 buffers [groups, C, 2], zero between steps (vs_bn_stats_from_sums_fold
+# resets what it has read, so no fill launch is needed per convolution) ----------------------------------------------------------------------
+_BN_SUMS = {}
+
+
+def bn_sums_buffer(key, groups, C, device):
+    """The persistent sums buffer of one BatchNorm call site (`key`: e.g. the data pointer of its running mean), zero-filled when created."""
+    k = (device.index, key, groups, C)
+    buf = _BN_SUMS.get(k)
+    if buf is None:
+        buf = _BN_SUMS[k] = torch.zeros((groups, C, 2), dtype=torch.float64, device=device)
+    return buf
+
+
+def conv_band_bn_supported(B, Cin, H, W, Cout, groups, dtype):
+    """Whether vs_conv3_band (Cin = 4 K plane channels for the k4 s2 family) leaves the BatchNorm sums of its output.  Opt-in (VS_BAND_BN_SUMS=1):
+    measured slower -- a workgroup owns only 32 channels x 256 pixels, so a layer issues millions of fp64 atomics onto a few thousand
+    addresses (TaxiBJ 8.89 -> 10.7 ms, SST 21.2 -> 22.9); the statistics pass over y it replaces costs 11-80 us per layer."""
+    import os
+    if os.environ.get('VS_BAND_BN_SUMS', '0') != '1' or dtype == torch.float32:
+        return False
+    return bool(_lib.load_library().vs_conv3_band_bn_supported(code_of(dtype), B, Cin, H, W, Cout, groups))
+
+
+def bn_stats_from_sums_fold(sums, n_per_group, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, reset=True):
+    """(mean, invstd) [groups, C] from epilogue sums in ONE launch (running estimates folded in call order; the sums are zeroed for the next step)."""
+    require_cuda(sums)
+    groups, C = sums.shape[0], sums.shape[1]
+    stats = torch.empty((2, groups, C), dtype=torch.float32, device=sums.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_bn_stats_from_sums_fold(sums.data_ptr(), groups, C, int(n_per_group), stats[0].data_ptr(), stats[1].data_ptr(),
+                                                         _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), int(bool(reset)),
+                                                         stream_ptr()), 'vs_bn_stats_from_sums_fold')
+    _pe(e0, 'vs_bn_stats_from_sums', nbytes=float(sums.numel() * 8))
+    return stats[0], stats[1]
+
+
+def conv3_band(x, w_packed, bias, Cout, out_dtype, role='fwd', bn_sums=None, groups=1):
+    """Conv2d k3 s1 p1 of x [B, Cin, H, W] (16-bit) with the `conv3_img16_pack_weight` pre-pack -> y [B, Cout, H, W] in out_dtype (+ bias).
+    bn_sums [groups, Cout, 2] (fp64, see bn_sums_buffer): the sums of the stored outputs are added to it in the epilogue."""
     require_cuda(x, w_packed, bias)
     assert x.is_contiguous() and x.dtype == w_packed.dtype
     B, Cin, H, W = x.shape
     y = torch.empty((B, Cout, H, W), dtype=out_dtype, device=x.device)
     e0 = _pb()
-    check(_lib.load_library().vs_conv3_band(dtype_code(x), x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W,
-                                            Cout, stream_ptr()), 'vs_conv3_band')
+    check(_lib.load_library().vs_conv3_band_bn(dtype_code(x), x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W,
+                                               Cout, _ptr(bn_sums), groups, stream_ptr()), 'vs_conv3_band')
     _pe(e0, 'vs_conv3_band:%s<%s>' % (role, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
         nbytes=float(x.numel() * x.element_size() + w_packed.numel() * 2 + y.numel() * y.element_size()))
     return y
@@ -993,6 +1031,11 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gro
                                           stream_ptr()), 'vs_bn_stats')
     _pe(e0, 'vs_bn_stats', nbytes=float(x.numel() * x.element_size()))
     return mean, invstd
+
+
+def bn_small_groups_enabled():
+    import os
+    return os.environ.get('VS_BN_SMALL_GROUPS', '0') == '1'
 
 
 def bn_small_supported(x, groups=1):

@@ -756,3 +756,35 @@ def test_batchnorm_small_one_launch_with_call_groups_equals_one_call_per_group(d
     assert torch.allclose(mean, m2, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, i2, rtol=1e-5, atol=1e-6)
     assert (y.float() - y2.float()).abs().max().item() <= (2e-2 if dtype != torch.float32 else 1e-5) * y2.float().abs().max().item()
     assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom,groups', [((6, 64, 32, 32, 40), 2), ((12, 128, 8, 8, 64), 3), ((4, 64, 64, 64, 32), 1), ((9, 64, 16, 16, 96), 9)])
+def test_conv3_band_leaves_batchnorm_sums_of_its_stored_output(dtype, geom, groups, monkeypatch):
+    """vs_conv3_band_bn: (sum, sum of squares) per (call group, channel) of the values AS STORED, added to a persistent buffer in the epilogue;
+    vs_bn_stats_from_sums_fold = vs_bn_stats on the stored tensor (mean / invstd per group, running estimates folded in call order) and
+    leaves the buffer at zero."""
+    from spatiotemporal_variable_separation_amd import ops
+    monkeypatch.setenv('VS_BAND_BN_SUMS', '1')            # (an opt-in route: see ops.conv_band_bn_supported)
+    B, Cin, H, W, Cout = geom
+    x = _rand((B, Cin, H, W), 81).to(dtype).cuda()
+    w = _rand((Cout, Cin, 3, 3), 82, 0.3)
+    bias = _rand((Cout,), 83).cuda()
+    assert ops.conv_band_bn_supported(B, Cin, H, W, Cout, groups, dtype)
+    wp = ops.conv3_img16_pack_weight(w.cuda(), dtype, False)
+    sums = ops.bn_sums_buffer('test-%s-%s' % (geom, dtype), groups, Cout, x.device)
+    assert float(sums.abs().sum()) == 0.0
+    y = ops.conv3_band(x, wp, bias, Cout, dtype, bn_sums=sums, groups=groups)
+    y_plain = ops.conv3_band(x, wp, bias, Cout, dtype)
+    assert torch.equal(y, y_plain)
+    yg = y.double().view(groups, B // groups, Cout, H * W)
+    ref = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], dim=-1)
+    assert ((sums - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    rm, rv = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda')
+    mean, invstd = ops.bn_stats_from_sums_fold(sums, (B // groups) * H * W, rm, rv, 0.1, 1e-5)
+    assert float(sums.abs().sum()) == 0.0, 'left at zero for the next step'
+    rm2, rv2 = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda')
+    m2, i2 = ops.bn_stats(y, rm2, rv2, 0.1, 1e-5, groups=groups)
+    assert torch.allclose(mean, m2, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, i2, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5, atol=1e-6)
