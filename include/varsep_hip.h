@@ -570,6 +570,12 @@ int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, cons
 int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd, const float* gamma,
                        const float* beta, int act, int training, int groups, float* dgamma, float* dbeta, void* dx, int dx_dtype, int B,
                        int C, int64_t HW, float* dgamma_sum, float* dbeta_sum, void* stream);
+/* vs_bn_stats + vs_bn_act_fwd with the running-statistics fold moved INTO the apply pass (one launch less per BatchNorm call): vs_bn_stats_ub leaves the
+ * unbiased variances in ubvar [groups][C]; vs_bn_act_fwd_running applies mean / invstd and folds (mean, ubvar) into running_mean / running_var in call order */
+int vs_bn_stats_ub(const void* x, int x_dtype, int B, int C, int64_t HW, int groups, float* mean, float* invstd, float* ubvar, float eps, void* stream);
+int vs_bn_act_fwd_running(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                          int act, int B, int C, int64_t HW, int groups, const float* ubvar, float* running_mean, float* running_var, float momentum,
+                          void* stream);
 int vs_chan_sum(const void* x, int x_dtype, int B, int C, int64_t HW, float* out, void* stream);
 /* the same sum with per-chunk partial sums in a workspace of vs_chan_sum_workspace_bytes: no atomics (a 1-channel map serialises 1024 of them on
  * one address), fixed summation order */

@@ -185,6 +185,8 @@ SIGNATURES = {
     'vs_bn_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     'vs_bn_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     'vs_bn_act_bwd_gsum': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp]),
+    'vs_bn_stats_ub': (_i32, [_vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, ctypes.c_float, _vp]),
+    'vs_bn_act_fwd_running': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, ctypes.c_float, _vp]),
     'vs_chan_sum': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     'vs_chan_sum_workspace_bytes': (_sz, [_i32, _i32, _i64]),
     'vs_chan_sum_ws': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _sz, _vp, _vp]),

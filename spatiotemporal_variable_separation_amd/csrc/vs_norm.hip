@@ -299,7 +299,21 @@ __global__ __launch_bounds__(256) void bn_running_kernel(const float* mean, cons
 
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const void* x, int xd, void* y, int yd, const float* mean, const float* invstd,
                                                          const float* gamma, const float* beta, int act, int C, int64_t HW, int64_t total,
-                                                         int64_t group_elems, int vec) {
+                                                         int64_t group_elems, int vec, const float* ubvar = nullptr, float* rmean = nullptr,
+                                                         float* rvar = nullptr, float momentum = 0.f, int G = 1) {
+    if (rmean && blockIdx.x == gridDim.x - 1) {
+        // the running estimates of the statistics this pass applies, folded in call order (bn_running_kernel's arithmetic) by the last
+        // workgroup: one launch less per BatchNorm call (a one-workgroup kernel lasts ~5 us inside the replayed step)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            double rm = rmean[c], rv = rvar[c];
+            for (int g = 0; g < G; ++g) {
+                rm = (double)(float)((1.0 - momentum) * rm + momentum * (double)mean[g * C + c]);
+                rv = (double)(float)((1.0 - momentum) * rv + momentum * (double)ubvar[g * C + c]);
+            }
+            rmean[c] = (float)rm;
+            rvar[c] = (float)rv;
+        }
+    }
     if (vec == 2) {
         const int w = unit_width(xd, yd, VS_BF16);
         const uint32_t upp = (uint32_t)((HW + w - 1) / w);
@@ -929,6 +943,19 @@ extern "C" int vs_bn_stats(const void* x, int x_dtype, int B, int C, int64_t HW,
     return VS_OK;
 }
 
+// vs_bn_stats without the running update: the unbiased variances go to ubvar [groups][C] for vs_bn_act_fwd_running, which folds them
+extern "C" int vs_bn_stats_ub(const void* x, int x_dtype, int B, int C, int64_t HW, int groups, float* mean, float* invstd, float* ubvar, float eps,
+                              void* stream) {
+    VS_CHECK_ARG(x && mean && invstd && ubvar && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_stats_ub: bad argument");
+    const int w_ = x_dtype == VS_F32 ? 4 : 8;
+    int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0);
+    if (!vec && HW % w_ != 0 && HW >= w_ && (int64_t)B * C * HW < ((int64_t)1 << 31) && (uintptr_t)x % 16 == 0) vec = 2;
+    const unsigned nt_ = ((int64_t)C * groups <= 1024 && (int64_t)(B / groups) * HW >= 8192) ? 1024u : 256u;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, groups), dim3(nt_), 0, (hipStream_t)stream, x, x_dtype, B / groups, C, HW, mean, invstd, ubvar, eps, vec);
+    VS_CHECK_LAUNCH("vs_bn_stats_ub");
+    return VS_OK;
+}
+
 // 1 when vs_bn_train_fwd_small serves the tensor: one call group, slabs of <= 8192 elements, 16-byte vectors
 extern "C" int vs_bn_train_fwd_small_supported(int x_dtype, int B, int C, int64_t HW) {
     static const int small_mode = getenv("VS_BN_SMALL") ? atoi(getenv("VS_BN_SMALL")) : 1;
@@ -1028,6 +1055,21 @@ extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, c
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(vec == 1 ? total / 16 : total / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
                        gamma, beta, act, C, HW, total, (int64_t)(B / groups) * C * HW, vec);
     VS_CHECK_LAUNCH("vs_bn_act_fwd");
+    return VS_OK;
+}
+
+// vs_bn_act_fwd that also folds the running estimates (mean / ubvar [groups][C] from vs_bn_stats_ub) in call order: one launch less per call
+extern "C" int vs_bn_act_fwd_running(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
+                                     const float* beta, int act, int B, int C, int64_t HW, int groups, const float* ubvar, float* running_mean,
+                                     float* running_var, float momentum, void* stream) {
+    VS_CHECK_ARG(x && y && mean && invstd && gamma && beta && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_act_fwd_running: bad argument");
+    VS_CHECK_ARG(ubvar && running_mean && running_var, "vs_bn_act_fwd_running: ubvar / running_mean / running_var are required");
+    const int64_t total = (int64_t)B * C * HW;
+    int vec = (HW % 8 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    if (!vec && HW >= 8 && total < ((int64_t)1 << 31) && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0) vec = 2;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(vec == 1 ? total / 16 : total / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, mean, invstd,
+                       gamma, beta, act, C, HW, total, (int64_t)(B / groups) * C * HW, vec, ubvar, running_mean, running_var, momentum, groups);
+    VS_CHECK_LAUNCH("vs_bn_act_fwd_running");
     return VS_OK;
 }
 

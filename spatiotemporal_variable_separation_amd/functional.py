@@ -1201,6 +1201,21 @@ def folded_conv_bn(conv, bn):
     return wf, bf
 
 
+def _bn_apply(z, training, rmean, rvar, momentum, eps, groups, gamma, beta, act, out_dt):
+    """BatchNorm (+ activation) of a convolution output z on the two-launch path: (y, mean, invstd).  Training with tracked running estimates:
+    the fold of the running estimates rides in the apply launch (VS_BN_RUNNING_FUSED=0: the separate bn_running launch)."""
+    if training:
+        if rmean is not None and os.environ.get('VS_BN_RUNNING_FUSED', '1') == '1':
+            mean, invstd, ub = ops.bn_stats_ub(z, eps, groups=groups)
+            y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups, running=(ub, rmean, rvar, momentum))
+            return y, mean, invstd
+        mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
+    else:
+        mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
+        invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
+    return ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups), mean, invstd
+
+
 def band_ok(x, w, transposed, stride, pad, dgrad=False):
     """Conv2d k3 s1 p1 of `x` with weight `w` ([Cout, Cin, 3, 3]) -- or, dgrad=True, its input gradient from x = dz -- on the row-band kernel."""
     return (not transposed and stride == 1 and pad == 1 and w.shape[2] == 3 and w.shape[3] == 3
@@ -1249,14 +1264,10 @@ class ConvBlock(torch.autograd.Function):
                     sums = ops.bn_sums_buffer(gamma.data_ptr(), groups, w.shape[0], planes.device)
                     z = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], cdt, bn_sums=sums, groups=groups)
                     mean, invstd = ops.bn_stats_from_sums_fold(sums, (Bp // groups) * Hp * Wp, rmean, rvar, momentum, eps)
+                    y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
                 else:
                     z = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], cdt)
-                    if training:
-                        mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
-                    else:
-                        mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
-                        invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
-                y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
+                    y, mean, invstd = _bn_apply(z, training, rmean, rvar, momentum, eps, groups, gamma, beta, act, out_dt)
                 ctx.save_for_backward(planes, z, mean, invstd)
             else:
                 y = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], out_dt)
@@ -1272,12 +1283,7 @@ class ConvBlock(torch.autograd.Function):
                                                                       momentum, eps)
                 else:
                     z = ops.slab_sum(slabs, bias, cdt)
-                    if training:
-                        mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=1)
-                    else:
-                        mean = rmean.detach().unsqueeze(0).contiguous()
-                        invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).contiguous()
-                    y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=1)
+                    y, mean, invstd = _bn_apply(z, training, rmean, rvar, momentum, eps, 1, gamma, beta, act, out_dt)
                 ctx.save_for_backward(xc, z, mean, invstd)
             else:
                 y = ops.slab_sum(slabs, bias, out_dt)
@@ -1306,12 +1312,7 @@ class ConvBlock(torch.autograd.Function):
                 if training and ops.bn_small_supported(z, groups):
                     y, mean, invstd = ops.bn_train_fwd_small(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps, groups=groups)
                 else:
-                    if training:
-                        mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
-                    else:
-                        mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
-                        invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
-                    y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
+                    y, mean, invstd = _bn_apply(z, training, rmean, rvar, momentum, eps, groups, gamma, beta, act, out_dt)
                 ctx.save_for_backward(xc, z, mean, invstd)
             else:
                 y = ops.conv3_band(xc, wpk, bias, w.shape[0], out_dt)
@@ -1339,12 +1340,7 @@ class ConvBlock(torch.autograd.Function):
                 # small maps (the SST integrator: 8 x 16 x 16 per channel): statistics, running update, affine + activation in one launch
                 y, mean, invstd = ops.bn_train_fwd_small(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps, groups=groups)
             else:
-                if training:
-                    mean, invstd = ops.bn_stats(z, rmean, rvar, momentum, eps, groups=groups)
-                else:
-                    mean = rmean.detach().unsqueeze(0).expand(groups, -1).contiguous()
-                    invstd = torch.rsqrt(rvar.detach() + eps).unsqueeze(0).expand(groups, -1).contiguous()
-                y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
+                y, mean, invstd = _bn_apply(z, training, rmean, rvar, momentum, eps, groups, gamma, beta, act, out_dt)
             ctx.save_for_backward(xc, z, mean, invstd)
         else:
             if k3:

@@ -1033,6 +1033,19 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gro
     return mean, invstd
 
 
+def bn_stats_ub(x, eps=1e-5, groups=1):
+    """bn_stats without the running update: (mean, invstd, unbiased variance) [groups, C]; `bn_act_fwd(..., running=...)` folds the last one."""
+    require_cuda(x)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    stats = torch.empty((3, groups, C), dtype=torch.float32, device=x.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_bn_stats_ub(x.data_ptr(), dtype_code(x), B, C, HW, groups, stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(),
+                                             float(eps), stream_ptr()), 'vs_bn_stats_ub')
+    _pe(e0, 'vs_bn_stats', nbytes=float(x.numel() * x.element_size()))
+    return stats[0], stats[1], stats[2]
+
+
 def bn_small_groups_enabled():
     import os
     return os.environ.get('VS_BN_SMALL_GROUPS', '0') == '1'
@@ -1139,15 +1152,23 @@ def bn_act_bwd_small_ex(z, mean, invstd, gamma, beta, act, dx_dtype, dy_a=None, 
     return dx, dgamma, dbeta
 
 
-def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype, groups=1):
+def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype, groups=1, running=None):
+    """y = act(gamma * (x - mean) * invstd + beta) per (call group, channel).  running = (ubvar [groups, C], running_mean, running_var, momentum):
+    the running estimates are folded in call order by the same launch (bn_stats_ub produced ubvar)."""
     require_cuda(x)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     e0 = _pb()
-    check(_lib.load_library().vs_bn_act_fwd(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), mean.data_ptr(),
-                                            invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], B, C, HW, groups,
-                                            stream_ptr()), 'vs_bn_act_fwd')
+    if running is not None:
+        ub, rm, rv, momentum = running
+        check(_lib.load_library().vs_bn_act_fwd_running(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), mean.data_ptr(), invstd.data_ptr(),
+                                                        gamma.data_ptr(), beta.data_ptr(), ACT[act], B, C, HW, groups, ub.data_ptr(), rm.data_ptr(),
+                                                        rv.data_ptr(), float(momentum), stream_ptr()), 'vs_bn_act_fwd_running')
+    else:
+        check(_lib.load_library().vs_bn_act_fwd(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), mean.data_ptr(),
+                                                invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act], B, C, HW, groups,
+                                                stream_ptr()), 'vs_bn_act_fwd')
     _pe(e0, 'vs_bn_act_fwd', nbytes=float(x.numel() * (x.element_size() + y.element_size())))
     return y
 
