@@ -73,6 +73,25 @@ __global__ __launch_bounds__(256) void space_to_depth2_kernel(const unsigned sho
     }
 }
 
+// rows of 8 pixels (8 x 8 maps -> 4 x 4 planes): one thread = one input row (16 bytes) -> 4 even + 4 odd pixels, an 8-byte store into each of
+// the row parity's two planes
+__global__ __launch_bounds__(256) void space_to_depth2_w8_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int C, int H,
+                                                                 int64_t units) {
+    const int H2 = H >> 1;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+        const int r = (int)(u % H);
+        int64_t t = u / H;
+        const int c = (int)(t % C);
+        const int64_t b = t / C;
+        const k4_u32x4 a = *reinterpret_cast<const k4_u32x4*>(x + u * 8);
+        const u32x2 ev = {(a[0] & 0xffffu) | (a[1] << 16), (a[2] & 0xffffu) | (a[3] << 16)};
+        const u32x2 od = {(a[0] >> 16) | (a[1] & 0xffff0000u), (a[2] >> 16) | (a[3] & 0xffff0000u)};
+        const int py = r & 1, yy = r >> 1;
+        *reinterpret_cast<u32x2*>(y + (((b * 4 + (py * 2 + 0)) * C + c) * H2 + yy) * 4) = ev;
+        *reinterpret_cast<u32x2*>(y + (((b * 4 + (py * 2 + 1)) * C + c) * H2 + yy) * 4) = od;
+    }
+}
+
 // Wp[mt][chunk][ky3][kx3][lane][8] (the layout of conv3_img16_pack_kernel, flip = 0) over 4 K plane channels c' = plane K + c
 template <int CT>
 __global__ __launch_bounds__(256) void k4s2_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int M, int K, int64_t total) {
@@ -143,13 +162,21 @@ __global__ __launch_bounds__(256) void k4s2_wgrad_finish_kernel(const float* __r
 }  // namespace
 
 extern "C" int vs_space_to_depth2_supported(int compute, int B, int C, int H, int W) {
-    return vs_is16(compute) && B > 0 && C > 0 && H >= 2 && H % 2 == 0 && W >= 16 && W % 16 == 0 && (int64_t)B * C * H * W < ((int64_t)1 << 40);
+    return vs_is16(compute) && B > 0 && C > 0 && H >= 2 && H % 2 == 0 && ((W >= 16 && W % 16 == 0) || W == 8) && (int64_t)B * C * H * W < ((int64_t)1 << 40);
 }
 
 extern "C" int vs_space_to_depth2(int compute, const void* x, void* y, int B, int C, int H, int W, void* stream) {
     VS_CHECK_ARG(x && y, "vs_space_to_depth2: bad argument");
-    VS_CHECK_ARG(vs_space_to_depth2_supported(compute, B, C, H, W), "vs_space_to_depth2: 16-bit tensors with even H and W a multiple of 16 only");
+    VS_CHECK_ARG(vs_space_to_depth2_supported(compute, B, C, H, W), "vs_space_to_depth2: 16-bit tensors with even H and W = 8 or a multiple of 16 only");
     VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)y) % 16 == 0, "vs_space_to_depth2: operands must be 16-byte aligned");
+    if (W == 8) {
+        const int64_t rows = (int64_t)B * C * H;
+        int64_t blocks8 = vs_cdiv(rows, 256);
+        if (blocks8 > 16384) blocks8 = 16384;
+        hipLaunchKernelGGL(space_to_depth2_w8_kernel, dim3((unsigned)blocks8), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, C, H, rows);
+        VS_CHECK_LAUNCH("vs_space_to_depth2");
+        return VS_OK;
+    }
     const int64_t units = (int64_t)B * C * H * (W >> 4);
     int64_t blocks = vs_cdiv(units, 256);
     if (blocks > 16384) blocks = 16384;

@@ -1275,6 +1275,14 @@ class ConvBlock(torch.autograd.Function):
                     ops.act_fwd(y, act, out=y)
                 ctx.save_for_backward(planes, y)
             ctx.x_shape = tuple(xc.shape)
+        elif (has_bn and not transposed and stride == 2 and pad == 1 and w.shape[2] == 4 and w.shape[3] == 4
+              and ops.conv_k4s2_gather_supported(xc, w.shape[0])):
+            # 8 x 8 -> 4 x 4 (the DCGAN encoder's c4, conv.py:122): the forward on the parity planes; the weight gradient keeps the column matrix
+            # (the row-band weight gradient does not serve 4 x 4 planes), so backward gets x itself
+            planes = ops.space_to_depth2(xc)
+            z = ops.conv_k4s2_gather(planes, packed_k4s2_weight(w, cdt), bias, w.shape[0], cdt)
+            y, mean, invstd = _bn_apply(z, training, rmean, rvar, momentum, eps, groups, gamma, beta, act, out_dt)
+            ctx.save_for_backward(xc, z, mean, invstd)
         elif img:
             slabs = ops.conv3_img16(xc, packed_img_weight(w, cdt, False), w.shape[0])
             if has_bn:

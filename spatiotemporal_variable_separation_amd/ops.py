@@ -714,6 +714,18 @@ def conv_k4s2_supported(big, M):
     return bool(lib.vs_conv3_band_supported(code, B, 4 * C, H // 2, W // 2, M)) and bool(lib.vs_conv3_wgrad_band_supported(code, B, 4 * C, H // 2, W // 2, M))
 
 
+def conv_k4s2_gather_supported(big, M):
+    """`conv_k4s2_supported` for the GATHER alone (Conv2d forward / ConvTranspose2d input gradient on the parity planes): 8 x 8 maps have 4 x 4
+    planes, which the row-band forward kernel serves (sixteen maps per workgroup) but the row-band weight gradient does not."""
+    import os
+    if os.environ.get('VS_CONV_K4S2') == '0' or big.dtype == torch.float32 or big.dim() != 4:
+        return False
+    B, C, H, W = big.shape
+    lib = _lib.load_library()
+    code = dtype_code(big)
+    return bool(lib.vs_space_to_depth2_supported(code, B, C, H, W)) and bool(lib.vs_conv3_band_supported(code, B, 4 * C, H // 2, W // 2, M))
+
+
 def space_to_depth2(x):
     """x [B, C, H, W] (16-bit) -> its four parity planes [B, 4 C, H/2, W/2], channel = (row parity * 2 + column parity) * C + c."""
     require_cuda(x)

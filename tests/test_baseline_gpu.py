@@ -169,7 +169,7 @@ def test_full_size_waveeq_lowp_matches_rounding_point_emulation(precision):
 # tap kernel of the stride-2 transposed convolutions, the column-matrix GEMM routes behind the ring tiles -- refuses fp32 tensors, so
 # the fp32 tests above never reach them; these do, at the sizes of BASELINE.json configs[2..4] and in the dtype configs[4] states.
 LOWP_FULL = [
-    ('full_mnist_b128', 'bf16', ('vs_convT_tap:fwd', 'vs_convT_tap:dgrad', 'vs_conv_cols:fwd', 'vs_conv_cols:wgrad', 'vs_convT_cols:wgrad',
+    ('full_mnist_b128', 'bf16', ('vs_convT_tap:fwd', 'vs_convT_tap:dgrad', 'vs_conv_k4s2:fwd', 'vs_conv_k4s2:dgrad', 'vs_conv_cols:wgrad', 'vs_convT_cols:wgrad',
                                  'vs_conv_thin:fwd', 'vs_conv_thin:dgrad', 'vs_conv_thin:wgrad', 'vs_mlp_rollout_fwd', 'vs_mlp_rollout_bwd'), None),
     ('full_taxibj', 'bf16', ('vs_conv3_band:fwd', 'vs_conv3_band:dgrad', 'vs_conv3_wgrad_band', 'vs_conv_thin:fwd', 'vs_conv_thin:dgrad',
                              'vs_conv_thin:wgrad', 'vs_mlp_rollout_fwd'), None),

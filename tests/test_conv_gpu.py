@@ -788,3 +788,23 @@ def test_conv3_band_leaves_batchnorm_sums_of_its_stored_output(dtype, geom, grou
     m2, i2 = ops.bn_stats(y, rm2, rv2, 0.1, 1e-5, groups=groups)
     assert torch.allclose(mean, m2, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, i2, rtol=1e-5, atol=1e-6)
     assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom', [(21, 64, 8, 8, 96), (256, 256, 8, 8, 512)])
+def test_conv_k4s2_gather_on_4x4_planes_matches_fp64(dtype, geom):
+    """8 x 8 maps (the DCGAN encoder's c4, conv.py:122): parity planes of 4 x 4 pixels (8-byte rows) and the gather on them (sixteen maps per
+    workgroup of the row-band kernel); the weight gradient of such a layer stays on the column-matrix path."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, C, H, W, M = geom
+    x = _rand((B, C, H, W), 311).to(dtype)
+    assert ops.conv_k4s2_gather_supported(x.cuda(), M) and not ops.conv_k4s2_supported(x.cuda(), M)
+    planes = ops.space_to_depth2(x.cuda())
+    want = torch.stack([x[:, :, py::2, px::2] for py in (0, 1) for px in (0, 1)], dim=1).reshape(B, 4 * C, H // 2, W // 2)
+    assert torch.equal(planes.cpu(), want)
+    w = _rand((M, C, 4, 4), 312, 0.3).to(dtype)
+    bias = _rand((M,), 313)
+    y = ops.conv_k4s2_gather(planes, ops.conv_k4s2_pack_weight(w.float().cuda(), dtype), bias.cuda(), M, torch.float32)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=2, padding=1)
+    assert ((y.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
