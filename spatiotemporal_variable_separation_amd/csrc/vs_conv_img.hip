@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned s
 template <int CT, int W, int AHEAD, int MINB, int K4 = 0>
 __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, const float* __restrict__ bias,
                                                          void* __restrict__ Y, int yd, int B, int Cin, int H, int Cout, int mtiles, int bands,
-                                                         int band_xcd_remap, double* __restrict__ bn_sums, int maps_per_group) {
+                                                         int band_xcd_remap, double* __restrict__ bn_sums, int maps_per_group, int Creal) {
+    // Creal = the channels X really has (its per-map stride); the channels Creal .. Cin - 1 of the last phase are staged as zeros
     constexpr int NKY = K4 ? 2 : 3, NF = K4 ? 2 : 3, GPP = 4 * NKY;              // tap rows and fragments per group, groups per 64-channel phase
     static_assert(GPP % AHEAD == 0, "the fragment ring must divide the groups of a phase");
     // W >= 16: the tile is R = 256 / W rows of ONE map (`band` = which rows); W = 8: FOUR whole 8 x 8 maps (`band` = which four, b = 0);
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
     const int band = id % bands, b = id / bands;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nph = Cin >> 6;
+    const int nph = Cin >> 6;                                                    // (Cin = the channel count padded to whole 64-channel phases)
 
     auto dma = [&](int ph) {
         char* dst = reinterpret_cast<char*>(xs + (ph & 1) * BUF);
@@ -217,14 +218,15 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
             if constexpr (W == 4) {
                 const int u = r * 256 + tid, pp = u % 3, mp = (u / 3) % IPB, cl = u / (3 * IPB);     // piece 0 of a map: its two zero rows
                 const int img = band * IPB + mp;
-                g = (pp != 0 && img < B) ? (const void*)(X + (((int64_t)img * Cin + ph * 64 + cl) * 16 + (pp - 1) * 8)) : (const void*)vs_glds_zero;
+                g = (pp != 0 && img < B && ph * 64 + cl < Creal) ? (const void*)(X + (((int64_t)img * Creal + ph * 64 + cl) * 16 + (pp - 1) * 8))
+                                                               : (const void*)vs_glds_zero;
             } else {
                 constexpr int PW = W / 8;
                 const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
                 const int y = (IPB == 1 ? band * RI : 0) + rr % RPI - 1;
                 const int img = IPB == 1 ? b : band * IPB + rr / RPI;
-                g = (y >= 0 && y < H && img < B) ? (const void*)(X + ((((int64_t)img * Cin + ph * 64 + cl) * H + y) * W + pc * 8))
-                                                 : (const void*)vs_glds_zero;
+                g = (y >= 0 && y < H && img < B && ph * 64 + cl < Creal) ? (const void*)(X + ((((int64_t)img * Creal + ph * 64 + cl) * H + y) * W + pc * 8))
+                                                                       : (const void*)vs_glds_zero;
             }
             // asm: the compiler orders a builtin LDS-DMA against every later LDS read with s_waitcnt vmcnt(0), which would also drain the
             // weight stream at every phase; the DMA is covered by the counted waits below instead (M0 has this one writer)
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256) void wgrad_slab_finish_kernel(const float* __r
 // (flip = 0, w = [M][K][3][3]) or, for the input gradient (flip = 1, w = the conv's [K][M][3][3]), w[c][m][2 - ky][2 - kx]
 template <int CT>
 __global__ __launch_bounds__(256) void conv3_img16_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int M, int K, int flip, int64_t total) {
-    const int chunks = K >> 4;
+    const int chunks = ((K + 63) >> 6) * 4;                                         // contraction channels padded to whole 64-channel phases (zeros)
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int jj = (int)(e & 7), lane = (int)((e >> 3) & 63);
         int64_t t = e >> 9;
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(256) void conv3_img16_pack_kernel(const float* __re
         const int chunk = (int)(t % chunks), mt = (int)(t / chunks);
         const int m = mt * 32 + (lane & 31), c = chunk * 16 + 8 * (lane >> 5) + jj;
         float v = 0.f;
-        if (m < M)
+        if (m < M && c < K)
             v = flip ? w[(((int64_t)c * M + m) * 3 + (2 - ky)) * 3 + (2 - kx)] : w[(((int64_t)m * K + c) * 3 + ky) * 3 + kx];
         dst[e] = vs_f2h(v, CT);
     }
@@ -592,19 +594,19 @@ __global__ __launch_bounds__(256) void conv3_img16_pack_multi_kernel(ImgPackJobs
             if (J.unit_off[mid] <= gt) lo = mid; else hi = mid;
         }
         const int j = lo;
-        const int M = J.M[j], K = J.K[j], flip = J.flip[j], chunks = K >> 4;
+        const int M = J.M[j], K = J.K[j], flip = J.flip[j], chunks = ((K + 63) >> 6) * 4;
         const long long tl = gt - J.unit_off[j];
         const int chunk = (int)(tl % chunks), mt = (int)(tl / chunks);
         const float* w = J.w[j];
         if (!flip) {
             for (int idx = threadIdx.x; idx < 32 * 144; idx += 256) {
                 const int mi = idx / 144, r = idx - mi * 144, m = mt * 32 + mi;
-                tile[idx] = m < M ? w[((int64_t)m * K + chunk * 16) * 9 + r] : 0.f;
+                tile[idx] = (m < M && chunk * 16 + r / 9 < K) ? w[((int64_t)m * K + chunk * 16) * 9 + r] : 0.f;
             }
         } else {
             for (int idx = threadIdx.x; idx < 16 * 288; idx += 256) {
                 const int ci = idx / 288, r = idx - ci * 288, mi = r / 9, t = 8 - (r - mi * 9), m = mt * 32 + mi;
-                tile[(mi * 16 + ci) * 9 + t] = m < M ? w[((int64_t)(chunk * 16 + ci) * M + mt * 32) * 9 + r] : 0.f;
+                tile[(mi * 16 + ci) * 9 + t] = (m < M && chunk * 16 + ci < K) ? w[((int64_t)(chunk * 16 + ci) * M + mt * 32) * 9 + r] : 0.f;
             }
         }
         __syncthreads();
@@ -684,12 +686,13 @@ extern "C" int vs_conv3_img16_supported(int compute, int B, int Cin, int H, int 
 
 extern "C" int vs_conv3_img16_splits(int B, int Cin, int Cout) { return img16_splits(B, Cin, Cout); }
 
-extern "C" size_t vs_conv3_img16_packed_elems(int Cin, int Cout) { return (size_t)vs_cdiv(Cout, 32) * (size_t)(Cin / 16) * 9 * 512; }
+// (the contraction is padded to whole 64-channel phases with zeros: vs_conv3_band stages zeros for the channels a last phase lacks)
+extern "C" size_t vs_conv3_img16_packed_elems(int Cin, int Cout) { return (size_t)vs_cdiv(Cout, 32) * (size_t)(vs_cdiv(Cin, 64) * 4) * 9 * 512; }
 
 // flip = 0: w is the Conv2d weight [Cout][Cin][3][3].  flip = 1 (input gradient): pass the SAME tensor with Cin := the conv's Cout
 // (the contraction) and Cout := the conv's Cin (the rows).
 extern "C" int vs_conv3_img16_pack_weight(int compute, const float* w, int Cin, int Cout, int flip, void* dst, void* stream) {
-    VS_CHECK_ARG(vs_is16(compute) && w && dst && Cin >= 16 && Cin % 16 == 0 && Cout > 0, "vs_conv3_img16_pack_weight: bad argument");
+    VS_CHECK_ARG(vs_is16(compute) && w && dst && Cin >= 1 && Cout > 0, "vs_conv3_img16_pack_weight: bad argument");
     const int64_t total = (int64_t)vs_conv3_img16_packed_elems(Cin, Cout);
     int64_t blocks = vs_cdiv(total, 256);
     if (blocks > 2048) blocks = 2048;
@@ -710,7 +713,7 @@ extern "C" int vs_conv3_img16_pack_weights(int compute, int n_jobs, const float*
     J.nj = n_jobs;
     J.unit_off[0] = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        VS_CHECK_ARG(w[j] && dst[j] && M[j] > 0 && K[j] >= 16 && K[j] % 16 == 0 && (uintptr_t)dst[j] % 16 == 0, "vs_conv3_img16_pack_weights: bad job %d", j);
+        VS_CHECK_ARG(w[j] && dst[j] && M[j] > 0 && K[j] >= 1 && (uintptr_t)dst[j] % 16 == 0, "vs_conv3_img16_pack_weights: bad job %d", j);
         J.w[j] = w[j]; J.dst[j] = (unsigned short*)dst[j]; J.M[j] = M[j]; J.K[j] = K[j]; J.flip[j] = flip[j];
         J.unit_off[j + 1] = J.unit_off[j] + (long long)(vs_conv3_img16_packed_elems(K[j], M[j]) / 4608);       // tiles of (32 rows, 16 channels)
     }
@@ -763,7 +766,8 @@ extern "C" int vs_slab_sum(const float* slabs, int nslabs, const float* bias, co
 
 // ---- row-band form: many maps, W in {16, 32, 64} with H a multiple of 256 / W, or 8 x 8 / 4 x 4 maps; Cin a multiple of 64; y in any type, bias added --
 extern "C" int vs_conv3_band_supported(int compute, int B, int Cin, int H, int W, int Cout) {
-    if (!vs_is16(compute) || (W != 4 && W != 8 && W != 16 && W != 32 && W != 64) || B < 1 || Cout < 1 || Cin < 64 || Cin % 64 != 0) return 0;
+    // (Cin need not be a multiple of 64: the last phase stages zeros for the channels it lacks and the pre-pack holds zero weights there)
+    if (!vs_is16(compute) || (W != 4 && W != 8 && W != 16 && W != 32 && W != 64) || B < 1 || Cout < 1 || Cin < 1) return 0;
     if (W == 4) return H == 4 && (int64_t)vs_cdiv(B, 16) * vs_cdiv(Cout, 32) < (1ll << 31);      // whole 4 x 4 maps, sixteen per workgroup
     if (W == 8) return H == 8 && (int64_t)vs_cdiv(B, 4) * vs_cdiv(Cout, 32) < (1ll << 31);       // whole 8 x 8 maps, four per workgroup
     const int R = 256 / W;
@@ -794,16 +798,17 @@ static int launch_band(int compute, const void* x, const void* w_packed, const f
             return vs_fail(VS_ERR_LAUNCH, "vs_conv3_band: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
+    const int Cpad = (int)vs_cdiv(Cin, 64) * 64;                                    // the kernel walks whole 64-channel phases
     const int mtiles = (int)vs_cdiv(Cout, 32), bands = IPB > 1 ? (int)vs_cdiv(B, IPB) : H / R;
     const dim3 grid((unsigned)((int64_t)(IPB > 1 ? 1 : B) * bands * mtiles));
     static const int xcd_remap = getenv("VS_BAND_XCD") ? atoi(getenv("VS_BAND_XCD")) : 1;
     const int remap = xcd_remap && mtiles > 1 && grid.x >= 64;
     if (compute == VS_BF16)
-        hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands,
-                           remap, bn_sums, maps_per_group);
+        hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cpad, H, Cout, mtiles, bands,
+                           remap, bn_sums, maps_per_group, Cin);
     else
-        hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cin, H, Cout, mtiles, bands,
-                           remap, bn_sums, maps_per_group);
+        hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, (const unsigned short*)x, (const u32x4*)w_packed, bias, y, y_dtype, B, Cpad, H, Cout, mtiles, bands,
+                           remap, bn_sums, maps_per_group, Cin);
     return VS_OK;
 }
 

@@ -1034,8 +1034,7 @@ def packed_img_weight(p, dtype, flip):
 def prepack_conv3_weights(net, dtype=None):
     """Bring the row-band / few-maps pre-packs (forward and flipped) of every 3x3 stride-1 pad-1 convolution of `net` up to date with ONE
     launch per 96 packs (instead of one launch per pack at its first use: 36-67 launches per TaxiBJ / SST step, every step, because the
-    optimizer changes every weight).  Called by the training step right before the forward pass; what is not stale is skipped, and a
-    weight the kernels cannot take (input channels not a multiple of 16) is left to its own route."""
+    optimizer changes every weight).  Called by the training step right before the forward pass; what is not stale is skipped."""
     import torch.nn as nn
     dtype = dtype or compute_dtype()
     if dtype == torch.float32:
@@ -1048,9 +1047,7 @@ def prepack_conv3_weights(net, dtype=None):
         if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
             continue
         for flip in (False, True):
-            K = p.shape[0] if flip else p.shape[1]
-            if K < 16 or K % 16 != 0:
-                continue
+            K = p.shape[0] if flip else p.shape[1]          # (any K: the pack pads the contraction to whole 64-channel phases)
             key = (id(p), dtype, flip)
             ent = _packed_img.get(key)
             if ent is None or ent[0] != p._version or ent[2] is not p:

@@ -709,7 +709,7 @@ def conv_k4s2_supported(big, M):
     B, C, H, W = big.shape
     lib = _lib.load_library()
     code = dtype_code(big)
-    if not lib.vs_space_to_depth2_supported(code, B, C, H, W):
+    if C % 16 != 0 or not lib.vs_space_to_depth2_supported(code, B, C, H, W):       # (the plane pre-packs hold whole 64-channel phases)
         return False
     return bool(lib.vs_conv3_band_supported(code, B, 4 * C, H // 2, W // 2, M)) and bool(lib.vs_conv3_wgrad_band_supported(code, B, 4 * C, H // 2, W // 2, M))
 
@@ -723,7 +723,8 @@ def conv_k4s2_gather_supported(big, M):
     B, C, H, W = big.shape
     lib = _lib.load_library()
     code = dtype_code(big)
-    return bool(lib.vs_space_to_depth2_supported(code, B, C, H, W)) and bool(lib.vs_conv3_band_supported(code, B, 4 * C, H // 2, W // 2, M))
+    return (C % 16 == 0 and bool(lib.vs_space_to_depth2_supported(code, B, C, H, W))
+            and bool(lib.vs_conv3_band_supported(code, B, 4 * C, H // 2, W // 2, M)))
 
 
 def space_to_depth2(x):
@@ -910,12 +911,16 @@ def conv3_img16(x, w_packed, Cout, role='fwd'):
 
 
 def conv3_band_supported(x, Cout):
-    """Whether Conv2d k3 s1 p1 on `x` takes the row-band kernel (`conv3_band`: many maps of width 16 / 32 / 64, Cin a multiple of 64, no
-    column matrix).  VS_CONV_BAND=0: never."""
+    """Whether Conv2d k3 s1 p1 on `x` takes the row-band kernel (`conv3_band`: many maps of width 4 / 8 / 16 / 32 / 64, any channel count --
+    a last 64-channel phase is filled with zeros --, no column matrix).  VS_CONV_BAND=0: never.  Below 16 channels on either side the
+    thin-channel kernels (one VALU pass, no 32 x 64-wide MFMA tiles of padding) keep the layer: VS_CONV_BAND_MIN_C."""
     import os
     if os.environ.get('VS_CONV_BAND') == '0' or x.dtype == torch.float32 or x.dim() != 4:
         return False
     B, Cin, H, W = x.shape
+    min_c = int(os.environ.get('VS_CONV_BAND_MIN_C', '16'))
+    if Cin < min_c or Cout < min_c:
+        return False
     return bool(_lib.load_library().vs_conv3_band_supported(dtype_code(x), B, Cin, H, W, Cout))
 
 

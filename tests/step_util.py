@@ -181,7 +181,13 @@ def compare_step_bf16_conv(cfg, t_random, tol_out=2e-3, tol_grad=5e-2, precision
     eg = dict(e_net.named_parameters())
     floor = 10 * grad_floor(e_net)
     per = {k: grad_err(p.grad.detach().cpu(), eg[k].grad, floor) for k, p in h_net.named_parameters() if p.grad is not None}
-    over = {k: v / noise_bound(noise, 'grad:' + _part(k), tol_grad) for k, v in per.items()}
+    def grad_bound(k):
+        # where the emulation's OWN self-distance saturates the bound (two equally valid evaluations of the part's gradients are a third or more
+        # apart: tiny nets, 16-bit, per-call BatchNorm stacks) a single small tensor -- a BatchNorm bias of the first block -- of two valid
+        # evaluations is as good as uncorrelated (distance ~ sqrt 2): only "finite and of the right size" is left to check there
+        b = noise_bound(noise, 'grad:' + _part(k), tol_grad)
+        return 1.5 if b >= 1.0 else b
+    over = {k: v / grad_bound(k) for k, v in per.items()}
     kw = max(over, key=over.get)
     errs['grad_worst'] = max(per.values())
     errs['grad_worst_over_bound'] = over[kw]

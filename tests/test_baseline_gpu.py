@@ -185,7 +185,7 @@ LOWP_FULL = [
 #     The chaos-free statement -- stored values equal element for element except isolated one-ulp flips, block gradients to 2 % -- is
 #     test_full_size_lowp_blocks_match_emulation_elementwise below.
 #  vs the reference's fp32 fixture: the cost of the 16-bit operands themselves -- for outputs a stated bound per mode; for gradients the
-#     kernels may not be further from the reference than the mode's definition is: e(HIP, reference) <= 1.5 e(emulation, reference) + 0.03.
+#     kernels may not be further from the reference than the mode's definition is: e(HIP, reference) <= 1.5 e(emulation, reference) + max(0.03, the part's noise bound).
 _EMU_OUT = {'bf16': 5e-3, 'fp16': 2e-3}
 _EMU_GRAD = 5e-2
 _REF_OUT = {'bf16': 5e-2, 'fp16': 1e-2}
@@ -267,7 +267,9 @@ def test_full_size_lowp_step_matches_emulation_and_reference(name, precision, fa
     ratio = 0.0
     for k, e_hip in hip_ref.items():
         e_emu = check_tensor(gold, 'grad:' + k, eg[k].grad, float('inf'))
-        bound = 1.5 * e_emu + 0.03
+        # triangle inequality: e(HIP, ref) <= e(emu, ref) + d(HIP, emu), and two valid evaluations of a 16-bit step may lie d <= the noise bound of
+        # that part apart (step_util.noise_bound: >= 3 x the emulation's own distance to a perturbed evaluation of itself; 0.03 where the step is tame)
+        bound = 1.5 * e_emu + max(0.03, noise_bound(noise, 'grad:' + k.split('.')[0], 0.03))
         ratio = max(ratio, e_hip / bound)
         expect(e_hip <= bound, f'gradient {k}: HIP {precision} vs reference {e_hip:.3e}, emulation vs reference {e_emu:.3e}')
     errs['ref:grad_over_mode_bound'] = ratio

@@ -509,6 +509,14 @@ def test_fused_conv_res_block_equals_layer_by_layer(precision, monkeypatch):
     (37, 128, 4, 4, 72),      # 4 x 4 maps, sixteen per workgroup: 37 = 2 full groups + 5 maps; ragged output-channel tile
     (16, 64, 4, 4, 64),       # one phase, one buffer
     (200, 512, 4, 4, 512),    # the VGG encoder's 512-channel layers at TaxiBJ size (conv.py:147-160)
+    (6, 260, 16, 16, 256),    # channels not a multiple of 64 (SST decoder first layer, 256 + 4: conv.py:404): the last phase stages zeros
+    (5, 24, 32, 32, 64),      # fewer than 64 input channels: one partial phase
+    (3, 16, 64, 64, 48),      # (below 16 channels on either side the thin-channel kernels keep the layer: ops.conv3_band_supported)
+    (9, 100, 8, 8, 40),       # 8 x 8 maps, ragged channels both ways
+    (37, 40, 4, 4, 24),       # 4 x 4 maps, one partial phase
+    (20, 96, 4, 4, 32),       # 4 x 4 maps, two phases (the second half empty)
+    (7, 32, 8, 8, 16),
+    (4, 16, 16, 16, 16),
 ])
 def test_conv3_band_forward_and_input_gradient(dtype, geom):
     """Conv2d k3 s1 p1 on many maps through vs_conv3_band (row bands in LDS, no column matrix) against fp64 conv2d on the same 16-bit
