@@ -293,3 +293,22 @@ def test_recorded_conv_step_with_weight_gradients_on_a_gradient_stream(name, mon
         if v.dtype.is_floating_point and v.numel() > 1:
             d = (runs['1'][1][k] - v).norm().item() / (v.norm().item() + 1e-12)
             assert d < 2e-3, (k, d)
+
+
+@pytest.mark.gpu
+def test_recorded_sst_step_with_the_integrator_on_a_side_stream(monkeypatch):
+    """VARSEP_ROLLOUT_SIDE=1 (optional route of train.compute_losses: the convolutional integrator between E_t and the forecast decode on a side
+    stream, autograd replaying the assignment in backward) computes what the serial recorded step computes."""
+    cfg = dict(CONFIGS['sst_skip'])
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    runs = {}
+    for side in ('0', '1'):
+        monkeypatch.setenv('VARSEP_ROLLOUT_SIDE', side)
+        net = _build(cfg, salt=5)
+        runs[side] = (_run(net, cond, target, cfg, None, True, 3), {k: v.detach().float().cpu() for k, v in net.state_dict().items()})
+    assert np.allclose(runs['0'][0], runs['1'][0], rtol=2e-4), (runs['0'][0], runs['1'][0])
+    for k, v in runs['0'][1].items():
+        if v.dtype.is_floating_point and v.numel() > 1:
+            d = (runs['1'][1][k] - v).norm().item() / (v.norm().item() + 1e-12)
+            assert d < 2e-3, (k, d)
