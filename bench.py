@@ -21,10 +21,17 @@ dominant kernel group -- at N = 1 Moving-MNIST DCGAN B=128, TaxiBJ VGG B=100, SS
 BASELINE.json configs[4] states); at N > 1 TaxiBJ and SST (configs[3], configs[4]: the two workloads stated at 8 GPUs), data-parallel
 over the same ranks.
 
-`roofline`: kernel GROUPS (spatiotemporal_variable_separation_amd/profiling.py).  Algorithmic FLOPs / bytes per step are accounted live;
-the duration of a group inside the REPLAYED step comes from the committed rocprofv3 kernel statistics of this very command
-(profiles/r<NN>_<workload>_<dtype>_replay.json, tools/replay_stats.py) because HIP events cannot be recorded inside a hipGraph replay
-(tools/graph_event_probe.py: they read 4.7 us around a 4096^3 GEMM); the live eager-event figure is printed beside it (`eager_events`).
+`roofline`: kernel GROUPS (spatiotemporal_variable_separation_amd/profiling.py).  Algorithmic FLOPs / bytes per step are accounted live.
+The duration of a group inside the REPLAYED step is measured IN THIS RUN: before this process touches the GPU it runs the same command
+(same workload, steps, warm-up; VARSEP_BENCH_NO_EVENTS=1) as a child under `rocprofv3 --kernel-trace --stats` and reads the kernel
+statistics (`timing: "replay-live"`) -- HIP events cannot be recorded inside a hipGraph replay (tools/graph_event_probe.py: they read 4.7 us
+around a 4096^3 GEMM).  Fallbacks, in order: the committed table profiles/r<NN>_<workload>_<dtype>_replay.json when its `_source_sha` still
+equals profiling.source_sha() (`"replay-committed"`); live HIP events around every launch of three eager steps (`"eager"`, with
+`"stale": true` when a committed table exists but belongs to other sources).  VARSEP_BENCH_LIVE_PROFILE=0 | headline | all (default all).
+
+Output: stdout carries ONE JSON line of < 4 KB (headline, one roofline object, cpu_baseline, one short entry per further workload);
+everything else (all regions, every group's roofline, eager-event figures, traffic sources, prose) goes to `bench_detail.json` next to
+this file and to stderr.
 """
 import argparse
 import json
@@ -109,6 +116,22 @@ def spawn_ranks(args):
     sys.exit(max(abs(rc) for rc in rcs))
 
 
+def physical_cores():
+    """Physical cores of the host: distinct (package, core) pairs of /proc/cpuinfo, else half the logical CPUs when SMT siblings show."""
+    try:
+        seen, pkg = set(), None
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('physical id'):
+                pkg = ln.split(':')[1].strip()
+            elif ln.startswith('core id'):
+                seen.add((pkg, ln.split(':')[1].strip()))
+        if seen:
+            return max(1, len(seen))
+    except OSError:
+        pass
+    return max(1, os.cpu_count() or 1)
+
+
 def cpu_baseline(cfg, steps):
     """Time the CPU oracle (plain PyTorch fp32 restatement of the reference) on the host cores, same workload."""
     from oracle import cpu_ref
@@ -129,10 +152,10 @@ def cpu_baseline(cfg, steps):
                                                  average_tloss=bool(cfg.get('average_tloss')))
         total.backward()
         opt.step()
-    # thread counts: 8 (comparable with the survey container) and a quarter of the logical CPUs; best one is reported
+    # thread counts: 8 (comparable with the survey container) and all physical cores of the host; best one is reported
     default_threads = torch.get_num_threads()
     tried = {}
-    for nthr in sorted({8, max(8, min(64, (os.cpu_count() or 8) // 4))}):
+    for nthr in sorted({8, physical_cores()}):
         torch.set_num_threads(nthr)
         step()
         t0 = time.time()
@@ -145,9 +168,10 @@ def cpu_baseline(cfg, steps):
             'threads_8': {'value': round(cfg['batch'] * cfg['nt_pred'] / tried[8], 1), 'ms_per_step': round(tried[8] * 1e3, 1),
                           'note': 'torch.set_num_threads(8): comparable with the survey container figures of BASELINE.md section 2'},
             'by_threads_ms_per_step': {str(k): round(v * 1e3, 1) for k, v in tried.items()}, 'logical_cpus': os.cpu_count(),
+            'physical_cores': physical_cores(),
             'kind': 'port', 'sample': f'{steps} full training steps of the same workload (batch {cfg["batch"]}, fp32, CPU '
             f'oracle = plain-PyTorch restatement of the reference) after 1 warm-up, best of thread counts '
-            f'{ {k: round(v * 1e3) for k, v in tried.items()} } ms/step on {os.cpu_count()} logical CPUs',
+            f'{ {k: round(v * 1e3) for k, v in tried.items()} } ms/step on {physical_cores()} physical cores / {os.cpu_count()} logical CPUs',
             'ms_per_step': round(dt * 1e3, 1)}
 
 
@@ -366,35 +390,84 @@ def run_eval(name, args, rk):
 
 
 def _latest_profile(workload, precision, kind):
-    """Newest committed profiles/r<NN>_<workload>_<precision>_<kind>.json (static evidence collected by tools/collect_profiles.sh)."""
+    """Newest committed profiles/r<NN>_<workload>_<precision>_<kind>.json (static evidence collected by tools/collect_profiles.sh);
+    returns (table, path, fresh): `fresh` = its `_source_sha` equals the sources this run executes."""
     import glob
+    from spatiotemporal_variable_separation_amd.profiling import source_sha
     hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s_%s_%s.json' % (workload, precision, kind))))
     if not hits:
-        return None, None
+        return None, None, False
     try:
-        return json.load(open(hits[-1])), 'profiles/' + os.path.basename(hits[-1])
+        tab = json.load(open(hits[-1]))
     except (OSError, ValueError):
-        return None, None
+        return None, None, False
+    return tab, 'profiles/' + os.path.basename(hits[-1]), tab.get('_source_sha') == source_sha()
 
 
-def rooflines(res, workload, precision, top=6):
+def live_replay_table(workload, precision, steps, warmup, timeout_s=240):
+    """Per-group kernel time of the REPLAYED step, measured in this run: the same command as a child process under
+    `rocprofv3 --kernel-trace --stats` (VARSEP_BENCH_NO_EVENTS=1: no instrumented eager steps, so every launch in the table but the
+    recording's warm-up is a graph replay), kernel statistics read back through profiling.replay_table.  Called BEFORE this process touches
+    the GPU (the child owns the device meanwhile).  Returns {'groups', 'steps', 'unassigned_us_per_step'} or None (no rocprofv3, time-out,
+    failure: the caller falls back)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    from spatiotemporal_variable_separation_amd.profiling import replay_table
+    tool = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if tool is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix='varsep_prof_', dir='/tmp')
+    env = dict(os.environ, VARSEP_BENCH_NO_EVENTS='1', VARSEP_BENCH_LIVE_PROFILE='0', TMPDIR='/tmp')
+    cmd = [tool, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', tmp, '-o', 'p', '--', sys.executable, os.path.abspath(__file__),
+           '--config', workload, '--precision', precision, '--steps', str(steps), '--warmup', str(warmup), '--repeats', '2',
+           '--no_cpu_baseline', '--extra_configs', 'none']
+    try:
+        t0 = time.time()
+        r = subprocess.run(cmd, env=env, cwd='/tmp', stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        hits = glob.glob(os.path.join(tmp, '**', '*kernel_stats.csv'), recursive=True)
+        if r.returncode != 0 or not hits:
+            sys.stderr.write('bench.py: live rocprofv3 pass of %s failed (rc %s): %s\n' % (workload, r.returncode, r.stderr.decode(errors='replace')[-400:]))
+            return None
+        rows = list(csv.DictReader(open(hits[0])))
+        nsteps, table, rest = replay_table(rows)
+        child = None
+        for ln in r.stdout.decode(errors='replace').splitlines():
+            if ln.startswith('{'):
+                child = json.loads(ln)
+        return {'groups': table, 'steps': nsteps, 'unassigned_us_per_step': rest, 'seconds': round(time.time() - t0, 1),
+                'profiled_ms_per_step': None if child is None else child.get('ms_per_step')}
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        sys.stderr.write('bench.py: live rocprofv3 pass of %s: %s\n' % (workload, e))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def rooflines(res, workload, precision, top=6, live=None):
     """Roofline position of every kernel GROUP (spatiotemporal_variable_separation_amd/profiling.py), largest time per step first.
 
-    Algorithmic FLOPs / bytes per step: the live accounting of this run (ops.profile_collect over the instrumented steps).  Duration:
-    (1) `eager`: live HIP events around every launch of the instrumented eager steps; (2) when profiles/ holds the rocprofv3 kernel
-    statistics of this command's REPLAYED step (tools/replay_stats.py), the group's time per step from there -- inside the replayed
-    hipGraph launches overlap and run slower than alone, and events cannot be recorded inside a replay, so the static table is the
-    only per-kernel clock of the timed region; `achieved` / `frac` then follow from it (reproducible from the committed CSV) and the
-    eager figure is printed beside it."""
+    Algorithmic FLOPs / bytes per step: the live accounting of this run (ops.profile_collect over the instrumented steps).  Duration of a
+    group, in order of preference: (1) `replay-live`: kernel statistics of this run's own rocprofv3 child pass over the replayed step
+    (live_replay_table); (2) `replay-committed`: the committed table under profiles/ when its source hash still matches; (3) `eager`: HIP
+    events around every launch of the instrumented eager steps (always computed, printed beside the others in bench_detail.json)."""
     from spatiotemporal_variable_separation_amd.profiling import bound_of, group_of_family
     prof, ms, sampled = res['prof'], res['ms'], res['sampled']
     if not prof:
         return None, []
-    replay, replay_src = (None, None)
-    traffic, traffic_src = (None, None)
+    replay, replay_src, timing, stale = (None, None, 'eager', False)
+    traffic, traffic_src, traffic_fresh = (None, None, False)
     if res.get('full_size', True):
-        replay, replay_src = _latest_profile(workload, precision, 'replay')
-        traffic, traffic_src = _latest_profile(workload, precision, 'traffic')
+        traffic, traffic_src, traffic_fresh = _latest_profile(workload, precision, 'traffic')
+        if live is not None:
+            replay, replay_src, timing = live, 'rocprofv3 --kernel-trace --stats child pass of this run (%d steps)' % live['steps'], 'replay-live'
+        else:
+            tab, src, fresh = _latest_profile(workload, precision, 'replay')
+            if tab is not None and fresh:
+                replay, replay_src, timing = tab, src, 'replay-committed'
+            elif tab is not None:
+                stale = True
     groups = {}
     for name, rec in prof.items():
         g = group_of_family(name) or name
@@ -417,20 +490,22 @@ def rooflines(res, workload, precision, top=6):
         if rp:
             us = rp['us_per_step']
             out.update({'achieved': round(work / (us * 1e-6) / scale, 2), 'frac': round(work / (us * 1e-6) / scale / peak, 4),
-                        'launches_per_step': rp['launches_per_step'], 'avg_launch_us': rp['avg_launch_us'], 'us_per_step': round(us, 1),
-                        'share_of_step': round(us * 1e-3 / ms, 3),
-                        'timing': 'replayed step: %s (rocprofv3 --kernel-trace --stats of this command; sum of TotalDurationNs over the '
-                                  'group\'s kernel symbols / steps)' % replay_src, 'eager_events': eager})
+                        'launches_per_step': round(rp['launches_per_step'], 2), 'avg_launch_us': round(rp['avg_launch_us'], 3), 'us_per_step': round(us, 1),
+                        'share_of_step': round(us * 1e-3 / ms, 3), 'timing': timing, 'source': replay_src, 'eager_events': eager})
         else:
             out.update({'achieved': eager['achieved'], 'frac': eager['frac'], 'launches_per_step': round(e['n'] / sampled, 2),
                         'avg_launch_us': eager['avg_launch_us'], 'us_per_step': eager['us_per_step'], 'share_of_step': round(eager_us * 1e-3 / ms, 3),
-                        'timing': 'live HIP events around every launch of %d eager steps (no rocprofv3 table of this workload under profiles/)' % sampled})
+                        'timing': 'eager', 'source': 'live HIP events around every launch of %d eager steps' % sampled})
+            if stale:
+                out['stale'] = True           # a committed replay table exists but was collected on other kernel sources: not used
         tr = (traffic or {}).get('groups', {}).get(g)
         out['traffic'] = None
         if tr:
             out['traffic'] = round(tr['bytes_per_launch'])
             out['traffic_per_step'] = round(tr['bytes_per_step'])
-            out['traffic_source'] = '%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes over eager steps of this command)' % traffic_src
+            out['traffic_source'] = traffic_src
+            if not traffic_fresh:
+                out['traffic_stale'] = True   # PMC passes of an earlier source state (profiles/ names the round)
         if 'rollout' in g:
             out['note'] = ('sequential recurrence: (n-1)*n_blocks*3 dependent 16-row GEMMs per slab, bound by the inter-workgroup exchange '
                            'latency, not by MFMA rate (SURVEY.md H3)')
@@ -438,6 +513,46 @@ def rooflines(res, workload, precision, top=6):
     roofs = [roof_of(g, e) for g, e in groups.items()]
     roofs.sort(key=lambda r: -r['us_per_step'])
     return roofs[0], roofs[1:top]
+
+
+_ROOF_KEYS = ('kernel', 'bound', 'peak', 'unit', 'achieved', 'frac', 'us_per_step', 'launches_per_step', 'avg_launch_us', 'share_of_step',
+              'traffic', 'traffic_per_step', 'algorithmic_bytes_per_step', 'algorithmic_per_step', 'timing', 'source', 'stale', 'traffic_stale')
+
+
+def compact_line(full, limit=4000):
+    """The ONE stdout line (< 4 KB: the driver reads an 8 KB tail) from the full result: headline fields, the dominant group's roofline,
+    cpu_baseline and one short entry per further workload.  Everything dropped here is in bench_detail.json."""
+    out = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                'vs_baseline', 'dtype', 'data') if k in full}
+    cfg = full.get('config', {})
+    out['config'] = {k: cfg[k] for k in ('workload', 'global_batch', 'parallelism', 'grad_allreduce', 'launch') if k in cfg}
+    rf = full.get('roofline')
+    out['roofline'] = None if rf is None else {k: rf[k] for k in _ROOF_KEYS if k in rf}
+    cb = full.get('cpu_baseline')
+    if cb is not None:
+        out['cpu_baseline'] = {k: cb[k] for k in ('value', 'unit', 'cores', 'ms_per_step', 'kind', 'sample', 'by_threads_ms_per_step') if k in cb}
+    if full.get('configs'):
+        out['configs'] = {}
+        for name, c in full['configs'].items():
+            if 'error' in c:
+                out['configs'][name] = {'error': c['error'][:120]}
+                continue
+            r = c.get('roofline') or {}
+            out['configs'][name] = {'ms_per_step': c['ms_per_step'], 'value': c['value'], 'dtype': c['dtype'], 'n_gpus': c['n_gpus'],
+                                    'roofline': {k: r[k] for k in ('kernel', 'bound', 'frac', 'achieved', 'unit', 'timing') if k in r}}
+    out['detail'] = 'bench_detail.json'
+    line = json.dumps(out)
+    # belt and braces: shed optional fields until the line fits
+    for drop in (('cpu_baseline', 'sample'), ('cpu_baseline', 'by_threads_ms_per_step'), ('roofline', 'source'), ('config', 'launch'), ('configs', None)):
+        if len(line) <= limit:
+            break
+        if drop[1] is None:
+            out.pop(drop[0], None)
+        elif isinstance(out.get(drop[0]), dict):
+            out[drop[0]].pop(drop[1], None)
+        line = json.dumps(out)
+    assert len(line) <= limit, len(line)
+    return line
 
 
 def allreduce_text(rk, res):
@@ -460,6 +575,36 @@ def main():
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    force_dist = os.environ.get('VARSEP_BENCH_FORCE_DIST') == '1'
+    extra = args.extra_configs
+    if extra is None:
+        if args.config == 'waveeq' and args.batch is None and args.precision == 'bf16':
+            extra = EXTRA_DEFAULT if (world == 1 and not force_dist) else EXTRA_DEFAULT_DIST
+        else:
+            extra = 'none'
+    extra_names = [e for e in extra.split(',') if e and e != 'none']
+
+    # per-kernel clock of the replayed step, measured in this run: child passes under rocprofv3 BEFORE this process touches the GPU
+    live = {}
+    mode = os.environ.get('VARSEP_BENCH_LIVE_PROFILE', 'all')
+    if (mode != '0' and world == 1 and not force_dist and not args.eval_mode and not args.no_graph and args.batch is None
+            and os.environ.get('VARSEP_BENCH_NO_EVENTS') is None):
+        t_start = time.time()
+        todo = [(args.config, args.precision, args.steps, args.warmup)]
+        if mode == 'all':
+            for name in extra_names:
+                wname, prec = split_workload(name, args.precision)
+                st, wu = EXTRA_STEPS.get(name, (5, 2))
+                todo.append((wname, prec, st, wu))
+        for wname, prec, st, wu in todo:
+            if time.time() - t_start > 200:          # the default run has to finish within minutes: later workloads fall back
+                break
+            tab = live_replay_table(wname, prec, st, wu)
+            if tab is not None:
+                live[(wname, prec)] = tab
+                sys.stderr.write('bench.py: live replay table of %s/%s: %d steps, %.1f s\n' % (wname, prec, tab['steps'], tab['seconds']))
+
     rk = Ranks(args)
     if args.eval_mode:
         line = run_eval(args.config, args, rk)
@@ -470,16 +615,10 @@ def main():
     res = run_workload(args.config, args, rk, args.steps, args.warmup, args.repeats, batch=args.batch)
 
     # further workloads under "configs".  Every rank runs them (they contain the same barriers / all-reduces); rank 0 reports.
-    extra = args.extra_configs
-    if extra is None:
-        if args.config == 'waveeq' and args.batch is None and args.precision == 'bf16':
-            extra = EXTRA_DEFAULT if (rk.world == 1 and not rk.ddp) else EXTRA_DEFAULT_DIST
-        else:
-            extra = 'none'
     configs = None
-    if extra != 'none':
+    if extra_names:
         configs = {}
-        for name in [e for e in extra.split(',') if e]:
+        for name in extra_names:
             st, wu = EXTRA_STEPS.get(name, (5, 2))
             wname, prec = split_workload(name, args.precision)
             err = None
@@ -497,7 +636,7 @@ def main():
                 configs[name] = {'error': err}
                 continue
             c = r['cfg']
-            rf, oth = rooflines(r, wname, prec, top=4)
+            rf, oth = rooflines(r, wname, prec, top=4, live=live.get((wname, prec)))
             configs[name] = {'workload': workload_text(wname, c), 'ms_per_step': round(r['ms'], 4), 'n_gpus': rk.world,
                              'value': round(rk.world * c['batch'] * c['nt_pred'] / (r['ms'] * 1e-3), 1), 'unit': 'frames/s',
                              'steps': st, 'warmup': wu, 'ms_per_step_all': r['ms_all'], 'dtype': prec,
@@ -510,9 +649,8 @@ def main():
         return
     cfg, ms = res['cfg'], res['ms']
     frames = rk.world * cfg['batch'] * cfg['nt_pred']
-    roof, others = rooflines(res, args.config, args.precision)
-    launch = ('hipGraph replay; per-kernel durations: see roofline.timing (events cannot be recorded inside a replay: live HIP events '
-              'bracket every launch of %d EAGER steps run after the timed regions)' % res['sampled']) if res['use_graph'] else 'eager'
+    roof, others = rooflines(res, args.config, args.precision, live=live.get((args.config, args.precision)))
+    launch = 'hipGraph replay' if res['use_graph'] else 'eager'
     out = {
         'metric': 'training frames/sec (seq x nt_pred)', 'value': round(frames / (ms * 1e-3), 1), 'unit': 'frames/s',
         'n_gpus': rk.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
@@ -529,10 +667,23 @@ def main():
         out['config']['loss_scaling'] = res['scaler']
     if configs is not None:
         out['configs'] = configs
+    if live:
+        out['live_profile'] = {'%s/%s' % k: {kk: v[kk] for kk in ('steps', 'seconds', 'profiled_ms_per_step', 'unassigned_us_per_step')}
+                               for k, v in live.items()}
     if rk.world == 1 and not args.no_cpu_baseline:
         steps = args.cpu_steps or (5 if args.config in ('waveeq', 'mnist_b16') else 2)
         out['cpu_baseline'] = cpu_baseline(cfg, steps)
-    os.write(result_fd, (json.dumps(out) + '\n').encode())
+    from spatiotemporal_variable_separation_amd.profiling import source_sha
+    out['source_sha'] = source_sha()
+    detail = json.dumps(out, indent=1)
+    try:
+        with open(os.path.join(ROOT, 'bench_detail.json'), 'w') as f:
+            f.write(detail + '\n')
+    except OSError:
+        pass
+    sys.stderr.write(detail + '\n')
+    sys.stderr.flush()
+    os.write(result_fd, (compact_line(out) + '\n').encode())
     rk.close()
 
 

@@ -8,7 +8,24 @@ of `ops.profile_collect()` and its duration either from live HIP events (eager l
 table of the same command (the replayed hipGraph step: `tools/replay_stats.py` -> `profiles/<round>_<workload>_<dtype>_replay.json`);
 `tools/pmc_traffic.py` uses the same table for the PMC traffic per launch.  Everything is reproducible from the committed CSV: a group's
 time per step = sum of TotalDurationNs over the symbols matching its regex / steps executed (calls of `step_increment_kernel`)."""
+import hashlib
+import os
 import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+
+def source_sha():
+    """sha256 (first 16 hex digits) over the kernel sources and the two files that decide which kernel a call reaches (`csrc/*`,
+    `ops.py`, `functional.py`).  `tools/replay_stats.py` / `tools/pmc_traffic.py` store it in every table they write under `profiles/`;
+    `bench.py` uses a committed table only while it still matches and says `"stale": true` otherwise."""
+    h = hashlib.sha256()
+    files = sorted(os.path.join(_PKG, 'csrc', f) for f in os.listdir(os.path.join(_PKG, 'csrc')) if f.endswith(('.hip', '.h')))
+    for f in files + [os.path.join(_PKG, 'ops.py'), os.path.join(_PKG, 'functional.py')]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
 
 # (group, regex over ops.py family labels, regex over kernel symbols, bound)
 GROUPS = [

@@ -123,3 +123,46 @@ def test_reference_written_checkpoints_load_without_the_reference_package():
             assert type(part).__module__.startswith('spatiotemporal_variable_separation_amd.networks.')
         assert all(torch.equal(v, want[k]) for k, v in whole.state_dict().items())
     assert not any(m == 'var_sep' or m.startswith('var_sep.') for m in sys.modules)
+
+
+def test_bench_line_is_short_and_parses():
+    """The driver reads an 8 KB tail of stdout: the ONE result line must stay under 4 KB whatever the full result holds (round 3's
+    22.5 KB line went unparsed).  Canned full result = the round-3 line itself, every workload with five roofline groups and prose."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    saved = {k: os.environ.get(k) for k in ('GPU_MAX_HW_QUEUES', 'DEBUG_HIP_FORCE_GRAPH_QUEUES', 'VARSEP_PACKAGE_SET')}
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r03_bench_default.json')))
+    assert len(json.dumps(full)) > 20000
+    full['configs']['broken'] = {'error': 'RuntimeError: ' + 'x' * 300}
+    line = bench.compact_line(full)
+    assert len(line) < 4096 and '\n' not in line
+    back = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'):
+        assert back[k] == full[k], k
+    assert back['config']['workload'] == full['config']['workload']
+    for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert back['roofline'][k] == full['roofline'][k], k
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert back['cpu_baseline'][k] == full['cpu_baseline'][k], k
+    assert set(back['configs']) == set(full['configs'])
+    assert back['configs']['sst_fp16']['ms_per_step'] == full['configs']['sst_fp16']['ms_per_step']
+    assert back['configs']['sst']['roofline']['kernel'] == full['configs']['sst']['roofline']['kernel']
+    # a pathologically long result still fits (optional fields are shed)
+    full['cpu_baseline']['sample'] = 'y' * 5000
+    assert len(bench.compact_line(full)) < 4096
+
+
+def test_profile_tables_are_tied_to_the_sources():
+    from spatiotemporal_variable_separation_amd.profiling import source_sha
+    a = source_sha()
+    assert len(a) == 16 and a == source_sha()

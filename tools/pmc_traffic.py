@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
-from spatiotemporal_variable_separation_amd.profiling import group_of_kernel  # noqa: E402
+from spatiotemporal_variable_separation_amd.profiling import group_of_kernel, source_sha  # noqa: E402
 
 
 def family(name):
@@ -49,7 +49,7 @@ def main():
     groups = {name: {'bytes_per_launch': (v[0] + v[1]) / v[2], 'fetch_bytes_per_launch_x2': v[0] / v[2], 'write_bytes_per_launch': v[1] / v[2],
                      'launches': v[2], 'bytes_per_step': (v[0] + v[1]) / steps} for name, v in fam.items()}
     meta = {'_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --no_graph --steps 6 --warmup 2`; FETCH_SIZE x2 '
-                       '(gfx950); kernel groups: spatiotemporal_variable_separation_amd/profiling.py', '_steps': steps, 'groups': groups}
+                       '(gfx950); kernel groups: spatiotemporal_variable_separation_amd/profiling.py', '_source_sha': source_sha(), '_steps': steps, 'groups': groups}
     json.dump(meta, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
     out = groups
     with open(sys.argv[4], 'w') as md:

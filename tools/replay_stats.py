@@ -14,7 +14,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from spatiotemporal_variable_separation_amd.profiling import replay_table  # noqa: E402
+from spatiotemporal_variable_separation_amd.profiling import replay_table, source_sha  # noqa: E402
 
 
 def main():
@@ -22,7 +22,7 @@ def main():
     steps, table, rest = replay_table(rows)
     out = {'_source': 'rocprofv3 --kernel-trace --stats of `VARSEP_BENCH_NO_EVENTS=1 python3 bench.py ...` (%s): per group, sum of '
                       'TotalDurationNs over its kernel symbols / %d steps executed' % (sys.argv[3] if len(sys.argv) > 3 else os.path.basename(sys.argv[1]), steps),
-           '_steps': steps, '_unassigned_us_per_step': round(rest, 2), 'groups': {g: {k: round(v, 3) for k, v in e.items()} for g, e in table.items()}}
+           '_source_sha': source_sha(), '_steps': steps, '_unassigned_us_per_step': round(rest, 2), 'groups': {g: {k: round(v, 3) for k, v in e.items()} for g, e in table.items()}}
     json.dump(out, open(sys.argv[2], 'w'), indent=1, sort_keys=True)
     tot = sum(e['us_per_step'] for e in table.values()) + rest
     print('steps %d, kernel time per step %.1f us (unassigned %.1f us)' % (steps, tot, rest))
