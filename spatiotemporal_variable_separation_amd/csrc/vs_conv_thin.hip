@@ -382,6 +382,13 @@ bool thin_geo_ok(int compute, int B, int C, int H, int W, int M, int k, int stri
     if (W < 8 || W > 128 || TH_BAND % W != 0 || H < 1 || ((int64_t)H * W) % TH_BAND != 0) return false;
     if ((int64_t)B * C * H * W * stride * stride >= (1ll << 40)) return false;
     if ((int64_t)B * (H * W / TH_BAND) >= (1ll << 30)) return false;
+    // LDS budgets of the expand / reduce launches (their weight tables are C x M x k^2 fp32: 512 x 8 x 16 would be 256 KiB): a geometry is
+    // "supported" only if every kernel of the family fits, so that the dispatcher's predicate and the launchers agree
+    const int NR = stride * (TH_BAND / W) + k - stride, pitch = stride * W + 2 * TH_PAD;
+    const size_t lds_expand = (((size_t)M * NR * pitch * 2 + 15) & ~(size_t)15) + (size_t)C * M * k * k * 4;
+    const int MT = M == 1 ? 1 : (M == 2 ? 2 : 4);
+    const size_t lds_reduce = (size_t)((C * MT * k * k + 3) & ~3) * 4 + (size_t)3 * MT * stride * stride * 8 * 64 * 4;
+    if (lds_expand > 160 * 1024 || lds_reduce > 160 * 1024) return false;
     return true;
 }
 

@@ -11,6 +11,7 @@ Precision policy (`set_precision` / `precision(...)`):
 """
 import contextlib
 import os
+import weakref
 
 import torch
 
@@ -152,6 +153,7 @@ def count_bn_calls(bn, calls):
     """`num_batches_tracked += calls` of a training-mode BatchNorm (one per reference call).  While gradients are folded (the
     training loop owns the step and calls `flush_bn_call_counts()` at its end) the increments are collected and applied by ONE
     multi-tensor launch per step instead of one launch per BatchNorm call (SST: ~300 per step)."""
+    _EPOCH['bn'] += 1                    # the call rewrites running_mean / running_var through raw pointers: eval-mode folds are outdated
     # a recording must contain the increment: either right here, or -- when the recorder has promised to call
     # flush_bn_call_counts() inside the capture (train.GraphedStep) -- in that one multi-tensor launch
     if not _STATE.get('fold_grads') or (torch.cuda.is_current_stream_capturing() and not _STATE.get('bn_counts_flushed_in_capture')):
@@ -222,7 +224,17 @@ def _lane_marker(lane):
         ev = torch.cuda.Event()
         ev.record()
         _SIDE['markers'][lane] = ev
+    fn._vs_marker = True
     return fn
+
+
+def _queued_on_lane(fn, lane):
+    """`fn` has just been issued on gradient lane `lane`.  A marker recorded earlier on that lane stands for "everything but the trailing
+    fused update of this lane is done" only while nothing else follows it: any other work queued behind it (a later chain when the lanes
+    wrap around, VARSEP_WGRAD_LANES < number of chains) withdraws the marker, and join_side_streams(partial=True) then waits for the
+    whole lane."""
+    if not (getattr(fn, '_vs_marker', False) or getattr(fn, '_vs_tail', False)):
+        (_SIDE.get('markers') or {}).pop(lane, None)
 
 
 def side_streams_enabled():
@@ -305,6 +317,7 @@ def run_deferred(fn, *inputs, outs=None, lane=0, late=False):
     ws.wait_stream(main)
     with torch.cuda.stream(ws):
         out = fn()
+    _queued_on_lane(fn, lane)
     if outs is not None:
         out = outs
     _record_on(ws, inputs, out if outs is not None else ())
@@ -358,6 +371,7 @@ def release_deferred(after=None, late_after=None):
                 ws.wait_event(late_after)
             with torch.cuda.stream(ws):
                 fn()
+            _queued_on_lane(fn, N_LANES if own else lane[1])
             _record_on(ws, inputs, outs)
             continue
         if lane is None or lane == 'all-late':  # consumes everything released so far: lane 0 behind the other lanes
@@ -379,6 +393,7 @@ def release_deferred(after=None, late_after=None):
                 started.add(lane)
         with torch.cuda.stream(ws):
             fn()
+        _queued_on_lane(fn, 0 if (lane is None or lane == 'all-late') else lane)
         _record_on(ws, inputs, outs)
 
 
@@ -502,6 +517,7 @@ def join_side_streams(partial=False):
         ws.wait_stream(producer)
         with torch.cuda.stream(ws):
             fn()
+        _queued_on_lane(fn, lane)
         _record_on(ws, inputs, outs)
     cur = torch.cuda.current_stream()
     pending = []
@@ -520,7 +536,29 @@ def join_side_streams(partial=False):
 
 
 # ------------------------------------------------------------------------------------------------ weight shadows
+# Every derived copy of a parameter (16-bit operand copy, MFMA pre-pack, eval-mode BatchNorm fold) is valid for one (version counter,
+# replay epoch) pair.  The version counter moves when torch or optim.Adam updates the parameter from Python; it does NOT move when a
+# recorded step is replayed (`increment_version` ran at capture time only) nor when a kernel writes BatchNorm running statistics through
+# raw pointers.  `note_replay()` (train.GraphedStep.step) and `count_bn_calls` (every training-mode BatchNorm call) advance the epochs
+# instead, so an eager use after replays -- evaluation between recorded training steps, a re-recording after a learning-rate change --
+# re-derives what the replays have outdated (into the same storage: recorded graphs keep addressing it).
+_EPOCH = {'replay': 0, 'bn': 0}
 _shadow = {}
+
+
+def _ver(p):
+    return (p._version, _EPOCH['replay'])
+
+
+def _wref(cache, key, p):
+    """Weak reference to the tensor a cache entry belongs to; the entry (and the device memory of its copy) goes when the tensor does."""
+    return weakref.ref(p, lambda _r: cache.pop(key, None))
+
+
+def note_replay():
+    """A recorded step has been replayed: parameters and BatchNorm statistics changed without moving any version counter."""
+    _EPOCH['replay'] += 1
+    _EPOCH['bn'] += 1
 
 
 def shadow(p, dtype):
@@ -529,10 +567,10 @@ def shadow(p, dtype):
         return p.detach()
     key = id(p)
     ent = _shadow.get(key)
-    if ent is None or ent[0] != p._version or ent[1].data_ptr() == 0 or ent[2] is not p or ent[1].dtype != dtype:
-        buf = ent[1] if ent is not None and ent[2] is p and ent[1].shape == p.shape and ent[1].dtype == dtype else None
+    if ent is None or ent[0] != _ver(p) or ent[1].data_ptr() == 0 or ent[2]() is not p or ent[1].dtype != dtype:
+        buf = ent[1] if ent is not None and ent[2]() is p and ent[1].shape == p.shape and ent[1].dtype == dtype else None
         buf = ops.cast(p.detach(), dtype, out=buf)
-        _shadow[key] = (p._version, buf, p)
+        _shadow[key] = (_ver(p), buf, _wref(_shadow, key, p))
         return buf
     return ent[1]
 
@@ -540,7 +578,7 @@ def shadow(p, dtype):
 def shadow_buffer_for_update(p):
     """The live bf16 operand copy of `p`, if one exists: the optimizer kernel rewrites it in the pass that updates `p`."""
     ent = _shadow.get(id(p))
-    if ent is not None and ent[2] is p and ent[1].shape == p.shape and ent[1].dtype in (torch.bfloat16, torch.float16) and ent[1].is_contiguous():
+    if ent is not None and ent[2]() is p and ent[1].shape == p.shape and ent[1].dtype in (torch.bfloat16, torch.float16) and ent[1].is_contiguous():
         return ent[1]
     return None
 
@@ -549,8 +587,8 @@ def shadows_written(params):
     """Called after an optimizer kernel refreshed the shadows of `params` in place: mark them current."""
     for p in params:
         ent = _shadow.get(id(p))
-        if ent is not None and ent[2] is p:
-            _shadow[id(p)] = (p._version, ent[1], p)
+        if ent is not None and ent[2]() is p:
+            _shadow[id(p)] = (_ver(p), ent[1], ent[2])
 
 
 def refresh_shadows(params, dtype=None):
@@ -559,9 +597,9 @@ def refresh_shadows(params, dtype=None):
     for p in params:
         key = id(p)
         ent = _shadow.get(key)
-        if ent is not None and ent[2] is p:
+        if ent is not None and ent[2]() is p:
             ops.cast(p.detach(), dtype, out=ent[1])
-            _shadow[key] = (p._version, ent[1], p)
+            _shadow[key] = (_ver(p), ent[1], ent[2])
 
 
 def invalidate_shadows(params):
@@ -570,12 +608,12 @@ def invalidate_shadows(params):
     the casts."""
     for p in params:
         ent = _shadow.get(id(p))
-        if ent is not None and ent[2] is p:
-            _shadow[id(p)] = (-1, ent[1], p)
+        if ent is not None and ent[2]() is p:
+            _shadow[id(p)] = ((-1, -1), ent[1], ent[2])
         for cache in (_packed, _packed_conv, _packed_tap, _packed_k3, _packed_img, _packed_k4s2):
             for key, e in list(cache.items()):
-                if e[2] is p:
-                    cache[key] = (-1, e[1], p)
+                if e[2]() is p:
+                    cache[key] = ((-1, -1), e[1], e[2])
 
 
 def to_compute(x, dtype):
@@ -724,6 +762,7 @@ class MLPChain(torch.autograd.Function):
             views = ops.colsum_alloc(dzs, flat)[1]       # the closure's own views (see the weight gradients above)
             run_deferred(lambda views=views: ops.colsum_multi(dzs, outs=views, zero_flat=flat), *dzs, outs=flat, lane=lane)
         if tail_job is not None:
+            tail_job[0]._vs_tail = True
             run_deferred(_lane_marker(lane), outs=(), lane=lane)
             run_deferred(tail_job[0], *tail_job[1], outs=(), lane=lane, late=_late_fused(0))
         return (dx, None, None, None) + tuple(grads)
@@ -746,10 +785,10 @@ def packed_weight(p, dtype, transpose):
     """Rollout pre-pack of a 2-D parameter (fragment order, compute dtype), cached per parameter version."""
     key = (id(p), bool(transpose), dtype)
     ent = _packed.get(key)
-    if ent is None or ent[0] != p._version or ent[2] is not p:
-        buf = ent[1] if ent is not None and ent[2] is p else None
+    if ent is None or ent[0] != _ver(p) or ent[2]() is not p:
+        buf = ent[1] if ent is not None and ent[2]() is p else None
         buf = ops.pack_rollout_weight(p.detach().contiguous(), dtype, transpose, out=buf)
-        _packed[key] = (p._version, buf, p)
+        _packed[key] = (_ver(p), buf, _wref(_packed, key, p))
         return buf
     return ent[1]
 
@@ -760,12 +799,12 @@ def prepack_weights(requests, dtype):
     for p, tr in requests:
         key = (id(p), bool(tr), dtype)
         ent = _packed.get(key)
-        if ent is None or ent[0] != p._version or ent[2] is not p:
-            stale.append((key, p, tr, ent[1] if ent is not None and ent[2] is p else None))
+        if ent is None or ent[0] != _ver(p) or ent[2]() is not p:
+            stale.append((key, p, tr, ent[1] if ent is not None and ent[2]() is p else None))
     if stale:
         bufs = ops.pack_rollout_weights([(p.detach().contiguous(), tr, buf) for _, p, tr, buf in stale], dtype)
         for (key, p, _, _), buf in zip(stale, bufs):
-            _packed[key] = (p._version, buf, p)
+            _packed[key] = (_ver(p), buf, _wref(_packed, key, p))
 
 
 class MLPRollout(torch.autograd.Function):
@@ -869,10 +908,10 @@ def packed_conv_weight(p, dtype, stride, pad):
     """Transposed-form pre-pack of a conv weight (ops.conv_pack_weight), cached per parameter version."""
     key = (id(p), dtype, stride, pad)
     ent = _packed_conv.get(key)
-    if ent is None or ent[0] != p._version or ent[2] is not p:
-        buf = ent[1] if ent is not None and ent[2] is p else None
+    if ent is None or ent[0] != _ver(p) or ent[2]() is not p:
+        buf = ent[1] if ent is not None and ent[2]() is p else None
         buf = ops.conv_pack_weight(p.detach().contiguous(), dtype, stride, pad, out=buf)
-        _packed_conv[key] = (p._version, buf, p)
+        _packed_conv[key] = (_ver(p), buf, _wref(_packed_conv, key, p))
         return buf
     return ent[1]
 
@@ -884,10 +923,10 @@ def packed_tap_weight(p, dtype):
     """Tap-GEMM pre-pack of a ConvTranspose2d k4 s2 p1 weight (ops.convt_tap_pack_weight), cached per parameter version."""
     key = (id(p), dtype)
     ent = _packed_tap.get(key)
-    if ent is None or ent[0] != p._version or ent[2] is not p:
-        buf = ent[1] if ent is not None and ent[2] is p else None
+    if ent is None or ent[0] != _ver(p) or ent[2]() is not p:
+        buf = ent[1] if ent is not None and ent[2]() is p else None
         buf = ops.convt_tap_pack_weight(p.detach().contiguous(), dtype, out=buf)
-        _packed_tap[key] = (p._version, buf, p)
+        _packed_tap[key] = (_ver(p), buf, _wref(_packed_tap, key, p))
         return buf
     return ent[1]
 
@@ -899,10 +938,10 @@ def packed_k3_weight(p, dtype, flip):
     """Tap-GEMM pre-pack of a Conv2d k3 s1 p1 weight (forward, or flipped / transposed for the input gradient)."""
     key = (id(p), dtype, bool(flip))
     ent = _packed_k3.get(key)
-    if ent is None or ent[0] != p._version or ent[2] is not p:
-        buf = ent[1] if ent is not None and ent[2] is p else None
+    if ent is None or ent[0] != _ver(p) or ent[2]() is not p:
+        buf = ent[1] if ent is not None and ent[2]() is p else None
         buf = ops.conv_k3_tap_pack_weight(p.detach().contiguous(), dtype, flip, out=buf)
-        _packed_k3[key] = (p._version, buf, p)
+        _packed_k3[key] = (_ver(p), buf, _wref(_packed_k3, key, p))
         return buf
     return ent[1]
 
@@ -915,10 +954,10 @@ def packed_k4s2_weight(p, dtype):
     [Cout, Cin, 4, 4] for its forward, a ConvTranspose2d weight [Cin, Cout, 4, 4] for its input gradient; cached per parameter version."""
     key = (id(p), dtype)
     ent = _packed_k4s2.get(key)
-    if ent is None or ent[0] != p._version or ent[2] is not p:
-        buf = ent[1] if ent is not None and ent[2] is p else None
+    if ent is None or ent[0] != _ver(p) or ent[2]() is not p:
+        buf = ent[1] if ent is not None and ent[2]() is p else None
         buf = ops.conv_k4s2_pack_weight(p.detach().contiguous(), dtype, out=buf)
-        _packed_k4s2[key] = (p._version, buf, p)
+        _packed_k4s2[key] = (_ver(p), buf, _wref(_packed_k4s2, key, p))
         return buf
     return ent[1]
 
@@ -1023,10 +1062,10 @@ def packed_img_weight(p, dtype, flip):
     """MFMA-fragment pre-pack of a Conv2d k3 s1 p1 weight for `ops.conv3_img16` (forward, or flipped / transposed: input gradient)."""
     key = (id(p), dtype, bool(flip))
     ent = _packed_img.get(key)
-    if ent is None or ent[0] != p._version or ent[2] is not p:
-        buf = ent[1] if ent is not None and ent[2] is p else None
+    if ent is None or ent[0] != _ver(p) or ent[2]() is not p:
+        buf = ent[1] if ent is not None and ent[2]() is p else None
         buf = ops.conv3_img16_pack_weight(p.detach().contiguous(), dtype, flip, out=buf)
-        _packed_img[key] = (p._version, buf, p)
+        _packed_img[key] = (_ver(p), buf, _wref(_packed_img, key, p))
         return buf
     return ent[1]
 
@@ -1050,12 +1089,12 @@ def prepack_conv3_weights(net, dtype=None):
             K = p.shape[0] if flip else p.shape[1]          # (any K: the pack pads the contraction to whole 64-channel phases)
             key = (id(p), dtype, flip)
             ent = _packed_img.get(key)
-            if ent is None or ent[0] != p._version or ent[2] is not p:
-                stale.append((key, p, flip, ent[1] if ent is not None and ent[2] is p else None))
+            if ent is None or ent[0] != _ver(p) or ent[2]() is not p:
+                stale.append((key, p, flip, ent[1] if ent is not None and ent[2]() is p else None))
     if stale:
         bufs = ops.conv3_img16_pack_weights([(p.detach(), flip, buf) for _, p, flip, buf in stale], dtype)
         for (key, p, _, _), buf in zip(stale, bufs):
-            _packed_img[key] = (p._version, buf, p)
+            _packed_img[key] = (_ver(p), buf, _wref(_packed_img, key, p))
     return len(stale)
 
 
@@ -1178,9 +1217,10 @@ def folded_conv_bn(conv, bn):
     keep their identity across refreshes (in-place update), so the operand copies / weight pre-packs keyed on them refresh themselves."""
     srcs = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
     key = id(conv.weight)
-    vers = tuple(-1 if t is None else t._version for t in srcs) + tuple(0 if t is None else t.data_ptr() for t in srcs)
+    vers = (tuple(-1 if t is None else t._version for t in srcs) + tuple(0 if t is None else t.data_ptr() for t in srcs)
+            + (_EPOCH['replay'], _EPOCH['bn']))
     ent = _folded.get(key)
-    if ent is not None and ent[0] == vers and ent[3] is conv.weight:
+    if ent is not None and ent[0] == vers and ent[3]() is conv.weight:
         return ent[1], ent[2]
     with torch.no_grad():
         s = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
@@ -1188,14 +1228,26 @@ def folded_conv_bn(conv, bn):
         wf = conv.weight.detach().float() * s.view(shape)
         b0 = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(s)
         bf = (b0 - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
-        if ent is not None and ent[3] is conv.weight and ent[1].shape == wf.shape:
+        if ent is not None and ent[3]() is conv.weight and ent[1].shape == wf.shape:
             ent[1].copy_(wf)
             ent[2].copy_(bf)
             wf, bf = ent[1], ent[2]
         else:
             wf, bf = wf.contiguous(), bf.contiguous()
-    _folded[key] = (vers, wf, bf, conv.weight)
+    if ent is None or ent[3]() is not conv.weight:
+        # the entry dies with the weight it belongs to (models built and evaluated repeatedly in one process: tests, sweeps)
+        _folded[key] = (vers, wf, bf, weakref.ref(conv.weight, lambda _r, k=key: _drop_folded(k)))
+    else:
+        _folded[key] = (vers, wf, bf, ent[3])
     return wf, bf
+
+
+def _drop_folded(key):
+    ent = _folded.pop(key, None)
+    if ent is not None:
+        for cache in (_shadow, _packed, _packed_conv, _packed_tap, _packed_k3, _packed_img, _packed_k4s2):
+            for k in [k for k, e in cache.items() if e[2]() is ent[1] or e[2]() is ent[2]]:
+                cache.pop(k, None)
 
 
 def _bn_apply(z, training, rmean, rvar, momentum, eps, groups, gamma, beta, act, out_dt):

@@ -126,7 +126,7 @@ def main(argv=None):
         lowp = getattr(args, 'grad_comm', 'fp32') == 'bf16'
         from .train import chain_weight_parameters
         grad_sync = GradAllReducer(sep_net.parameters(), comm_dtype=torch.bfloat16 if lowp else torch.float32,
-                                   lowp_direct=chain_weight_parameters(sep_net) if (lowp and getattr(args, 'hip_graph', False)) else None)
+                                   lowp_direct=chain_weight_parameters(sep_net) if (lowp and not getattr(args, 'no_hip_graph', False)) else None)
 
     # same constructor call as the reference (main.py:133); the update runs as one multi-tensor HIP launch (optim.py)
     from .optim import Adam
@@ -137,8 +137,14 @@ def main(argv=None):
     # --torch_amp keeps the reference's meaning (fp16 autocast + GradScaler, train.py:96-97); --precision names a mode explicitly
     precision = args.precision or ('fp16' if args.torch_amp else 'fp32')
     VF.set_precision(precision)
+    # the recorded step (train.GraphedStep) is the default: main always builds the HIP Adam (recordable, maintains the 16-bit operand
+    # copies inside the recording) and its loaders yield one batch shape per epoch but for a ragged last batch, which runs eagerly
+    hip_graph = not getattr(args, 'no_hip_graph', False)
     if rank == 0:
-        print('compute precision: %s%s' % (precision, ' + dynamic loss scaling' if precision == 'fp16' else ''))
+        print('compute precision: %s%s' % (precision, ' + dynamic loss scaling' if precision == 'fp16' else
+                                            (' (the reference\'s default arithmetic; --precision bf16 selects the 16-bit MFMA kernels bench.py times)'
+                                             if precision == 'fp32' else '')))
+        print('step launch: %s' % ('recorded hipGraph, replayed per batch (--no_hip_graph: eager launches)' if hip_graph else 'eager launches from Python'))
     from .train import make_loss_scaler
     scaler = make_loss_scaler(device) if precision == 'fp16' else None
     from .train import enable_update_in_backward
@@ -146,7 +152,7 @@ def main(argv=None):
     train(args.xp_dir, train_loader, device, sep_net, optimizer, scheduler, args.apex_amp, False, args.epochs, args.lamb_ae,
           args.lamb_s, args.lamb_t, args.lamb_pred, args.offset, args.nt_cond, args.nt_pred, args.no_s, args.skipco,
           args.chkpt_interval, args.architecture == 'encoderSST', grad_sync=grad_sync, log_interval=args.log_interval,
-          hip_graph=args.hip_graph, scaler=scaler)
+          hip_graph=hip_graph, scaler=scaler)
 
 
 if __name__ == "__main__":

@@ -108,7 +108,12 @@ def _build():
                    help='Wire format of the gradient all-reduce with --ddp (bf16 halves the xGMI bytes; fp32 keeps N replicas '
                         'bit-compatible with the single-process step).')
     g.add_argument('--hip_graph', action='store_true',
-                   help='Record the whole training step into a hipGraph and replay it (every architecture; the MLP family gains most).')
+                   help='(default since round 4; kept so that older command lines still parse) record the whole training step into a '
+                        'hipGraph and replay it.')
+    g.add_argument('--no_hip_graph', action='store_true',
+                   help='Issue every kernel of the step from Python instead of replaying the recorded hipGraph (the WaveEq MLP step is then '
+                        'host-bound: ~3.9 ms instead of ~1.4 ms).  The recorded step is what bench.py times; batches of another shape '
+                        '(a ragged last batch) run eagerly either way.')
     g.add_argument('--log_interval', type=int, default=None, help='Print losses and frames/s every N steps.')
     g.add_argument('--synthetic_len', type=int, default=2048, help='Sequences per epoch of the synthetic dataset.')
     return p

@@ -263,22 +263,24 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         if snap is not None:
             snap.restore()
+        self._capture()
+
+    def _capture(self):
         from . import functional as VF
         from .optim import Adam as HipAdam
-        if isinstance(optimizer, HipAdam):
-            # the restore bumped every parameter's version counter: bring the 16-bit operand copies up to date NOW, or the
-            # recording would contain a cast of every weight: measured +90 us per replayed WaveEq step.  ONLY valid because the HIP
-            # Adam kernel rewrites the copies in the pass that updates the masters, so they stay current from then on
-            if snap is not None:
-                VF.refresh_shadows(list(sep_net.parameters()))
+        params = list(self.net.parameters())
+        if isinstance(self.opt, HipAdam):
+            # restoring the warm-up snapshot bumped every parameter's version counter (and, for a re-recording after a learning-rate
+            # change, the replays since the last recording moved the replay epoch): bring the 16-bit operand copies up to date NOW, or
+            # the recording would contain a cast of every weight: measured +90 us per replayed WaveEq step.  ONLY valid because the HIP
+            # Adam kernel rewrites the copies in the pass that updates the masters, so they stay current from then on.  Weight
+            # pre-packs are NOT refreshed here: they are stale at this point, so the recording contains them, once per step.
+            VF.refresh_shadows(params)
         else:
             # any other optimizer (torch.optim.Adam(capturable=True)) updates the fp32 masters only: the recording must CONTAIN the
             # casts, or every replay would read the weights frozen at capture time.  Mark every copy stale so that its first use
             # inside the capture records the cast (replayed at the start of every step, i.e. after the previous step's update)
-            VF.invalidate_shadows(list(sep_net.parameters()))
-        self._capture()
-
-    def _capture(self):
+            VF.invalidate_shadows(params)
         grad_sync = self.sync
         self._lrs = [g['lr'] for g in self.opt.param_groups]
         self._draw()
@@ -418,6 +420,10 @@ class GraphedStep:
         elif self.graph_opt is not None:
             self._reduce()
             self.graph_opt.replay()
+        # the replay changed parameters and BatchNorm statistics without moving a version counter: whatever eager code derives from them
+        # next (evaluation between training steps, instrumented eager steps, a re-recording) must re-derive it
+        from . import functional as VF
+        VF.note_replay()
         return self.loss
 
 

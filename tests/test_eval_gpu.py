@@ -206,3 +206,45 @@ def test_folded_batchnorm_follows_parameter_updates():
         want = o_net.get_forecast(cond, 6)[0]
     assert rel_err(b.cpu(), want) < 1e-3
     assert rel_err(b.cpu(), a.cpu()) > 1e-3                 # (the change is visible in the output at all)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_eval_between_replayed_training_steps_sees_the_current_state(precision):
+    """Replays of a recorded step change parameters and BatchNorm running statistics without moving a version counter (round-3 advisor
+    finding: the folded-BatchNorm cache and the version-keyed weight pre-packs then served the state of the FIRST evaluation).  Sequence:
+    replay, eval, replay, eval -- every eval with the fold must equal the eval that reads the running statistics directly
+    (VARSEP_FOLD_BN_EVAL=0), and the second must differ from the first."""
+    import os
+    import numpy as np
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.train import GraphedStep
+    cfg, o_net, h_net = _pair('dcgan_tiny')
+    lam = cfg['lambdas']
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    np.random.seed(3)
+    with VF.precision(precision):
+        h_net.train()
+        opt = Adam(h_net.parameters(), lr=2e-3, betas=(0.9, 0.99))
+        g = GraphedStep(h_net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], (lam['ae'], lam['s'], lam['t'], lam['pred']),
+                        average_tloss=bool(cfg.get('average_tloss')), warmup=2)
+        seen = []
+        for rnd in range(2):
+            for _ in range(3):
+                g.step()
+            h_net.eval()
+            outs = {}
+            for fold in ('1', '0'):
+                os.environ['VARSEP_FOLD_BN_EVAL'] = fold
+                try:
+                    with torch.no_grad():
+                        outs[fold] = h_net.get_forecast(cond, 6)[0].float().clone()
+                finally:
+                    del os.environ['VARSEP_FOLD_BN_EVAL']
+            h_net.train()
+            torch.cuda.synchronize()
+            tol = 1e-4 if precision == 'fp32' else 3e-2
+            assert rel_err(outs['1'].cpu(), outs['0'].cpu()) < tol, (rnd, rel_err(outs['1'].cpu(), outs['0'].cpu()))
+            seen.append(outs['1'])
+        assert rel_err(seen[1].cpu(), seen[0].cpu()) > 1e-3       # three more training steps are visible in the forecast

@@ -31,3 +31,42 @@ def test_main_trains_and_checkpoints(tmp_path, extra):
     for stem in ('ov_Et', 'ov_Es', 'decoder', 't_resnet'):
         assert (tmp_path / f'{stem}.pt').exists() and (tmp_path / f'{stem}_1.pt').exists()
     assert (tmp_path / 'params.json').exists()
+
+
+def test_main_runs_the_step_bench_times(tmp_path):
+    """What `python -m ...main` runs by default IS what bench.py times (round-3 review: the recorded step and the 16-bit kernels were two
+    opt-in flags away).  `main --data wave --precision bf16` on a WaveEq set of BASELINE size resident in HBM (64 simulations of 60 frames
+    of 64x64, the README.md:90 architecture, batch 128) logs its frames/s per 20 replayed steps; the best logged interval must be within
+    15 % of bench.py's ms/step for the same workload on the same box."""
+    import json
+    import re
+    import shutil
+    import torch
+    d = '/tmp/varsep_wave_fullsize/' + ''.join(chr(ord('a') + (os.getpid() // 26 ** k) % 26) for k in range(6))
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(os.path.join(d, 'data'))
+    try:
+        g = torch.Generator().manual_seed(11)
+        for i in range(64):
+            torch.save({'simul': torch.rand((60, 64, 64), generator=g)}, os.path.join(d, 'data', 'wave_%d.pt' % i))
+        env = dict(os.environ, VARSEP_BENCH_LIVE_PROFILE='0')
+        cmd = [sys.executable, '-m', 'spatiotemporal_variable_separation_amd.main', '--xp_dir', str(tmp_path), '--data_dir', d, '--data', 'wave',
+               '--architecture', 'mlp', '--device', '0', '--nt_cond', '5', '--nt_pred', '20', '--offset', '5', '--downsample', '1',
+               '--batch_size', '128', '--epochs', '12', '--enc_hidden_size', '1200', '--dec_hidden_size', '1200', '--enc_n_layers', '3',
+               '--dec_n_layers', '4', '--res_hidden_size', '512', '--n_blocks', '3', '--code_size_t', '32', '--code_size_s', '32',
+               '--mixing', 'mul', '--gain_resnet', '0.71', '--lamb_ae', '1', '--precision', 'bf16', '--seed', '5', '--num_workers', '1',
+               '--log_interval', '20']
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert 'recorded hipGraph' in r.stdout and 'compute precision: bf16' in r.stdout
+        fps = [float(m) for m in re.findall(r'\| (\d+) frames/s \(hipGraph\)', r.stdout)]
+        assert len(fps) >= 4, r.stdout[-2000:]
+        main_ms = 128 * 20 / max(fps[1:]) * 1e3          # (the first interval contains the recording)
+        b = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', 'waveeq', '--no_cpu_baseline', '--extra_configs', 'none'],
+                           cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert b.returncode == 0, b.stderr[-4000:]
+        bench_ms = json.loads(b.stdout.strip().splitlines()[-1])['ms_per_step']
+        print('main %.3f ms/step (best of %d logged intervals of 20 steps), bench.py %.3f ms/step' % (main_ms, len(fps) - 1, bench_ms))
+        assert main_ms <= 1.15 * bench_ms, (main_ms, bench_ms, fps)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
