@@ -35,8 +35,8 @@ def test_main_trains_and_checkpoints(tmp_path, extra):
 
 def test_main_runs_the_step_bench_times(tmp_path):
     """What `python -m ...main` runs by default IS what bench.py times (round-3 review: the recorded step and the 16-bit kernels were two
-    opt-in flags away).  `main --data wave --precision bf16` on a WaveEq set of BASELINE size resident in HBM (64 simulations of 60 frames
-    of 64x64, the README.md:90 architecture, batch 128) logs its frames/s per 20 replayed steps; the best logged interval must be within
+    opt-in flags away).  `main --data wave --precision bf16` on a WaveEq set of BASELINE size resident in HBM (64 simulations of 64 frames
+    of 64x64 -- as many frames as rows, so that the reference's `__len__` quirk, wave_eq.py:62-65, stays inside the set --, the README.md:90 architecture, batch 128) logs its frames/s per 20 replayed steps; the best logged interval must be within
     15 % of bench.py's ms/step for the same workload on the same box."""
     import json
     import re
@@ -48,7 +48,7 @@ def test_main_runs_the_step_bench_times(tmp_path):
     try:
         g = torch.Generator().manual_seed(11)
         for i in range(64):
-            torch.save({'simul': torch.rand((60, 64, 64), generator=g)}, os.path.join(d, 'data', 'wave_%d.pt' % i))
+            torch.save({'simul': torch.rand((64, 64, 64), generator=g)}, os.path.join(d, 'data', 'wave_%d.pt' % i))
         env = dict(os.environ, VARSEP_BENCH_LIVE_PROFILE='0')
         cmd = [sys.executable, '-m', 'spatiotemporal_variable_separation_amd.main', '--xp_dir', str(tmp_path), '--data_dir', d, '--data', 'wave',
                '--architecture', 'mlp', '--device', '0', '--nt_cond', '5', '--nt_pred', '20', '--offset', '5', '--downsample', '1',
