@@ -247,8 +247,11 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=N
     comm_default = 'bf16' if (precision == 'bf16' and _is_mlp(net)) else 'fp32'
     comm_bf16 = precision == 'bf16' and os.environ.get('VARSEP_GRAD_COMM', comm_default) == 'bf16'
     direct = chain_weight_parameters(net) if (comm_bf16 and os.environ.get('VARSEP_GRAD_DIRECT_LOWP', '1') == '1') else None
+    # conv families: the decoder's gradients (complete first in backward) in leading buckets of their own -- the recorded step is split
+    # there and their all-reduce travels beside the integrator's / encoders' backward kernels (train.GraphedStep.segmented)
+    early = None if _is_mlp(net) else list(net.decoder.parameters())
     sync = GradAllReducer(net.parameters(), force=(rk.world == 1), comm_dtype=torch.bfloat16 if comm_bf16 else torch.float32,
-                          lowp_direct=direct) if rk.ddp else None
+                          lowp_direct=direct, early=early) if rk.ddp else None
     use_graph = (not args.no_graph) and os.environ.get('VARSEP_BENCH_GRAPH_ALL', '1') == '1'
     opt = Adam(net.parameters(), lr=4e-4, betas=(0.9, 0.99))
     cond, target = synthetic_batch(cfg['data'], cfg['batch'], cfg['nt_cond'], cfg['nt_pred'], device=dev, seed=1234 + rk.rank)

@@ -405,14 +405,22 @@ struct WgradPieces {
 // K4 = 1: the weight gradient of a k4 s2 p1 (transposed) convolution on the parity planes of its large operand (csrc/vs_conv_k4s2.hip): Cin = 4 K
 // plane channels, K a multiple of 32, so the 32 channels of a workgroup lie in ONE plane, which sees 2 x 2 of the 3 x 3 taps: the other five
 // MFMAs per k-step (and their slab stores: vs_conv_k4s2_wgrad_finish never reads them) are skipped.
+template <int W>
+constexpr int wgrad_cpitch() { return W == 4 ? 388 : (W == 8 ? 4 * 10 : 256 / W + 2) * W + 8; }
+
 template <int CT, int W, int MW, int K4 = 0>
 __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, float* __restrict__ slabs, int B, int Cin, int H, int Cout, int ctiles, int ksplit) {
-    // W >= 16: an item is a band of R = 256 / W rows of one map; W = 8: FOUR whole 8 x 8 maps (rows of one 16-byte piece, no column neighbours)
-    constexpr int IPB = W == 8 ? 4 : 1, R = W == 8 ? 8 : 256 / W, RPI = R + 2, RP = IPB * RPI, PW = W / 8;
-    constexpr int CPITCH = RP * W + 8;                                           // 392 / 328 / 296 / 328 elements: (CPITCH / 8) odd
+    // W >= 16: an item is a band of R = 256 / W rows of one map; W = 8: FOUR whole 8 x 8 maps (rows of one 16-byte piece, no column neighbours);
+    // W = 4: SIXTEEN whole 4 x 4 maps (the 512-channel layers of the VGG encoders / decoders, the parity planes of 8 x 8 maps): a 16-byte
+    // piece is TWO rows, a k-step of 16 pixels is one map; a fragment (8 pixels = two rows, shifted by ky rows = 8 bytes) is read as two
+    // aligned ds_read_b64, the channel pitch of 388 elements (194 words = 2 mod 64) keeps the 32 rows of such a read on 64 different banks;
+    // the zero rows above / below every map are written once at kernel start
+    constexpr int IPB = W == 8 ? 4 : (W == 4 ? 16 : 1), R = W == 8 ? 8 : (W == 4 ? 4 : 256 / W), RPI = R + 2, RP = IPB * RPI, PW = W >= 8 ? W / 8 : 1;
+    constexpr int PPM = R * W / 8;                                               // 16-byte pieces of one map of a multi-map item
+    constexpr int CPITCH = wgrad_cpitch<W>();                                    // 392 / 328 / 296 / 328 elements: (CPITCH / 8) odd; W = 4: 388
     constexpr int ZPITCH = 264;
-    constexpr int NX = 32 * RP * PW;                                             // 16-byte pieces of the x tile: 1536 / 1280 / 1152
-    constexpr int NXT = (NX + 255) / 256;                                        // per thread: 6 / 5 / 5 (the last partly)
+    constexpr int NX = W == 4 ? 32 * IPB * PPM : 32 * RP * PW;                   // 16-byte pieces of the x tile: 1536 / 1280 / 1152; W = 4: 1024
+    constexpr int NXT = (NX + 255) / 256;                                        // per thread: 6 / 5 / 5 (the last partly) / 4
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [3][32][CPITCH] then dz [32 MW][ZPITCH]
     constexpr int KW = 4 / MW, KSTEPS = 16 / KW;                                 // k parts per band, k-steps per wave and band
     unsigned short* zs = xs + 3 * 32 * CPITCH;
@@ -438,6 +446,14 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
         const int piece = bg / pieces.maps_per_piece, b = bg - piece * pieces.maps_per_piece;                             // (an item never straddles pieces)
         const unsigned short* X = pieces.x[piece];
         const unsigned short* DZ = pieces.dz[piece];
+        if constexpr (W == 4) {
+#pragma unroll
+            for (int r = 0; r < NXT; ++r) {
+                const int u = r * 256 + tid, hf = u & 1, im = (u >> 1) & 15, c = ct * 32 + (u >> 5);
+                const bool ok = c < Cin && bg + im < B;
+                xr[r] = *reinterpret_cast<const u32x4*>(ok ? X + ((int64_t)(b + im) * Cin + c) * 16 + hf * 8 : reinterpret_cast<const unsigned short*>(vs_glds_zero));
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < NXT; ++r) {
             const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
@@ -455,13 +471,33 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
 #pragma unroll
         for (int r = 0; r < 4 * MW; ++r) {
             const int u = r * 256 + tid, ml = u >> 5, pc = u & 31, m = mt * (32 * MW) + ml;
-            const int im = IPB == 1 ? 0 : pc / (R * PW), pcm = IPB == 1 ? pc : pc % (R * PW);                          // map of the item, piece inside it
+            const int im = IPB == 1 ? 0 : pc / PPM, pcm = IPB == 1 ? pc : pc % PPM;                                    // map of the item, piece inside it
             const unsigned short* src = (m < Cout && bg + im < B) ? DZ + (((int64_t)(b + im) * Cout + m) * H + band * R) * W + pcm * 8
                                                                   : reinterpret_cast<const unsigned short*>(vs_glds_zero);
             zr[r] = *reinterpret_cast<const u32x4*>(src);
         }
     };
     auto store_item = [&]() {
+        if constexpr (W == 4) {
+#pragma unroll
+            for (int r = 0; r < NXT; ++r) {
+                const int u = r * 256 + tid, hf = u & 1, im = (u >> 1) & 15, cl = u >> 5;
+                unsigned short* dst = xs + cl * CPITCH + im * (RPI * 4) + 4 + hf * 8;      // rows 1 + 2 hf, 2 + 2 hf of the map's six
+                const u32x4 d = xr[r];                                                   // (d0 d1) = one row of four pixels, (d2 d3) the next
+                u32x2 a, bb;
+                a[0] = __builtin_amdgcn_alignbyte(d[0], 0u, 2);  a[1] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);
+                bb[0] = __builtin_amdgcn_alignbyte(d[2], 0u, 2); bb[1] = __builtin_amdgcn_alignbyte(d[3], d[2], 2);
+                *reinterpret_cast<u32x2*>(dst) = a;                                      // copy 0: x[col - 1]
+                *reinterpret_cast<u32x2*>(dst + 4) = bb;
+                a[0] = d[0]; a[1] = d[1]; bb[0] = d[2]; bb[1] = d[3];
+                *reinterpret_cast<u32x2*>(dst + 32 * CPITCH) = a;                        // copy 1: x[col]
+                *reinterpret_cast<u32x2*>(dst + 32 * CPITCH + 4) = bb;
+                a[0] = __builtin_amdgcn_alignbyte(d[1], d[0], 2);  a[1] = __builtin_amdgcn_alignbyte(0u, d[1], 2);
+                bb[0] = __builtin_amdgcn_alignbyte(d[3], d[2], 2); bb[1] = __builtin_amdgcn_alignbyte(0u, d[3], 2);
+                *reinterpret_cast<u32x2*>(dst + 64 * CPITCH) = a;                        // copy 2: x[col + 1]
+                *reinterpret_cast<u32x2*>(dst + 64 * CPITCH + 4) = bb;
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < NXT; ++r) {
             const int u = r * 256 + tid, pc = u % PW, rr = (u / PW) % RP, cl = u / (PW * RP);
@@ -495,6 +531,9 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
     // K4: first tap row / column this plane sees (odd planes: {0, 1}, even planes: {1, 2}); wave-uniform
     const int plane = K4 ? (ct * 32) / (Cin >> 2) : 0;
     const int ky_lo = K4 ? ((plane >> 1) ? 0 : 1) : 0, kx_lo = K4 ? ((plane & 1) ? 0 : 1) : 0;
+    if constexpr (W == 4) {                                                      // the zero rows (and the pad) of the x image: written once
+        for (int i = tid; i < 3 * 32 * CPITCH / 2; i += 256) reinterpret_cast<unsigned*>(xs)[i] = 0u;
+    }
     int64_t it = ks;
     if (it < items) load_item(it);
     for (; it < items; it += ksplit) {
@@ -511,7 +550,14 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     if (K4 && ((unsigned)(ky - ky_lo) > 1u || (unsigned)(kx - kx_lo) > 1u)) continue;      // not a tap of this plane
-                    const u32x4 bf = *reinterpret_cast<const u32x4*>(xs + (kx * 32 + rl) * CPITCH + (row + ky) * W + x0 + 8 * h);
+                    u32x4 bf;
+                    if constexpr (W == 4) {
+                        const unsigned short* src = xs + (kx * 32 + rl) * CPITCH + (row + ky) * W + 8 * h;
+                        const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 4);
+                        bf[0] = lo[0]; bf[1] = lo[1]; bf[2] = hi[0]; bf[3] = hi[1];
+                    } else {
+                        bf = *reinterpret_cast<const u32x4*>(xs + (kx * 32 + rl) * CPITCH + (row + ky) * W + x0 + 8 * h);
+                    }
                     acc[ky * 3 + kx] = mfma16_32<CT>(af, bf, acc[ky * 3 + kx]);
                 }
         }
@@ -865,7 +911,8 @@ extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, c
 
 // ---- weight gradient on row bands: x [B][Cin][H][W], dz [B][Cout][H][W] (16-bit) -> fp32 slabs [vs_conv3_wgrad_band_slabs][Cout][Cin][3][3] ----
 extern "C" int vs_conv3_wgrad_band_supported(int compute, int B, int Cin, int H, int W, int Cout) {
-    if (!vs_is16(compute) || (W != 8 && W != 16 && W != 32 && W != 64) || B < 1 || Cout < 8 || Cin < 8) return 0;
+    if (!vs_is16(compute) || (W != 4 && W != 8 && W != 16 && W != 32 && W != 64) || B < 1 || Cout < 8 || Cin < 8) return 0;
+    if (W == 4) return H == 4;                                                   // whole 4 x 4 maps, sixteen per item
     if (W == 8) return H == 8;                                                   // whole 8 x 8 maps, four per item
     const int R = 256 / W;
     if (H < R || H % R != 0) return 0;
@@ -876,7 +923,7 @@ static int wgrad_band_mw(int Cout) { return Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
 
 static int wgrad_band_ksplit(int B, int Cin, int H, int W, int Cout) {
     const int mw = wgrad_band_mw(Cout);
-    const int64_t tiles = vs_cdiv(Cout, 32 * mw) * vs_cdiv(Cin, 32), items = W == 8 ? vs_cdiv(B, 4) : (int64_t)B * (H / (256 / W));
+    const int64_t tiles = vs_cdiv(Cout, 32 * mw) * vs_cdiv(Cin, 32), items = W == 8 ? vs_cdiv(B, 4) : (W == 4 ? vs_cdiv(B, 16) : (int64_t)B * (H / (256 / W)));
     // ONE round of workgroups (a workgroup's LDS fills a CU): every share of the bands costs a slab of the weight's size, written and read
     // again by the finish pass -- with two rounds (512) the slabs of a TaxiBJ step were 3.9 GB of traffic: 9.80 -> 9.37 ms with 256; 128, 192
     // and 384 are slower (idle CUs / a partial second round)
@@ -894,8 +941,7 @@ extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout)
 
 template <int W, int MW, int K4 = 0>
 static void launch_wgrad_band(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
-    constexpr int RPT = W == 8 ? 4 * 10 : 256 / W + 2;
-    const size_t lds = (size_t)(3 * 32 * (RPT * W + 8) + 32 * MW * 264) * 2;
+    const size_t lds = (size_t)(3 * 32 * wgrad_cpitch<W>() + 32 * MW * 264) * 2;
     auto kb = wgrad3_band_kernel<VS_BF16, W, MW, K4>;
     auto kh = wgrad3_band_kernel<VS_F16, W, MW, K4>;
     static bool attr_set = false;
@@ -926,7 +972,8 @@ static int wgrad_band_go(int compute, const WgradPieces& pieces, float* slabs, i
     if (W == 64) launch_wgrad_band_w<64, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     else if (W == 32) launch_wgrad_band_w<32, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     else if (W == 16) launch_wgrad_band_w<16, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
-    else launch_wgrad_band_w<8, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    else if (W == 8) launch_wgrad_band_w<8, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
+    else launch_wgrad_band_w<4, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     VS_CHECK_LAUNCH("vs_conv3_wgrad_band");
     return VS_OK;
 }
@@ -991,6 +1038,7 @@ extern "C" int vs_conv3_wgrad_band_pieces(int compute, int npieces, const void* 
     const int B = npieces * maps_per_piece;
     VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_wgrad_band_pieces: unsupported geometry");
     VS_CHECK_ARG(W != 8 || npieces == 1 || maps_per_piece % 4 == 0, "vs_conv3_wgrad_band_pieces: 8 x 8 maps go four at a time: maps_per_piece must be a multiple of 4");
+    VS_CHECK_ARG(W != 4 || npieces == 1 || maps_per_piece % 16 == 0, "vs_conv3_wgrad_band_pieces: 4 x 4 maps go sixteen at a time: maps_per_piece must be a multiple of 16");
     WgradPieces pieces = {};
     for (int i = 0; i < npieces; ++i) {
         VS_CHECK_ARG(x[i] && dz[i] && ((uintptr_t)x[i] | (uintptr_t)dz[i]) % 16 == 0, "vs_conv3_wgrad_band_pieces: every piece must be a 16-byte aligned tensor");

@@ -179,6 +179,37 @@ def flush_bn_call_counts():
         torch._foreach_add_(bufs, incs)
 
 
+# ---- backward in two segments (train.GraphedStep under a reducer) --------------------------------------------------------------------
+# The decoder is the LAST thing the forward pass runs and the FIRST thing backward finishes: once its parameters' gradients are complete the
+# all-reduce of their bucket can travel while the integrator's and the encoders' backward passes still run.  A recorded step cannot fire
+# hooks, so the recording is split there: segment 1 = forward + the part of backward that ends at the decoder's inputs
+# (`torch.autograd.backward(total, inputs=decoder parameters + the tensors noted here)`), segment 2 = the rest, started from those tensors'
+# gradients.  `cut(x)` notes a tensor that enters the decoder (called by SeparableNetwork.get_forecast and train.compute_losses); it returns x
+# itself -- no node is added to the autograd graph.
+_CUTS = {'on': False, 'tensors': {}}
+
+
+def collect_cuts(flag):
+    _CUTS['on'] = bool(flag)
+    _CUTS['tensors'] = {}
+
+
+def cut(x):
+    if not _CUTS['on'] or x is None:
+        return x
+    if isinstance(x, (list, tuple)):
+        for t in x:
+            cut(t)
+        return x
+    if isinstance(x, torch.Tensor) and x.requires_grad and x.grad_fn is not None:
+        _CUTS['tensors'].setdefault(id(x), x)
+    return x
+
+
+def cut_tensors():
+    return list(_CUTS['tensors'].values())
+
+
 def promise_loss_gradient(t):
     """`t` (one fp32 element on the device, or None) is the tensor the caller WILL pass as the gradient of the total loss
     (`total.backward(t)`): TrainLosses then writes its gradients in the forward pass (one read of the frame stack per step instead of

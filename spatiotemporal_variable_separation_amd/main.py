@@ -124,8 +124,9 @@ def main(argv=None):
     if world > 1:
         broadcast_module_state(sep_net)
         lowp = getattr(args, 'grad_comm', 'fp32') == 'bf16'
-        from .train import chain_weight_parameters
+        from .train import _mlp_family, chain_weight_parameters
         grad_sync = GradAllReducer(sep_net.parameters(), comm_dtype=torch.bfloat16 if lowp else torch.float32,
+                                   early=None if _mlp_family(sep_net) else list(decoder.parameters()),
                                    lowp_direct=chain_weight_parameters(sep_net) if (lowp and not getattr(args, 'no_hip_graph', False)) else None)
 
     # same constructor call as the reference (main.py:133); the update runs as one multi-tensor HIP launch (optim.py)

@@ -47,6 +47,8 @@ class SeparableNetwork(nn.Module):
             else:
                 codes, t_residuals = self._roll(t_code, n_forecast)
                 t_codes = torch.stack(codes, dim=1)
+            from .. import functional as VF
+            VF.cut((s_code, t_codes, s_skipco))        # (a recorded data-parallel step splits its backward pass at the decoder's inputs)
             forecasts = self.decoder.decode_sequence(s_code, t_codes, skip=s_skipco)
             return forecasts, t_codes, s_code, t_residuals
 

@@ -628,7 +628,7 @@ def conv3_wgrad_band_pieces(pairs, w_shape, into=None):
     n = len(pairs)
     mp, Cin, H, W = x0.shape
     Cout = w_shape[0]
-    if (W == 8 and mp % 4 != 0) or n > 64 or any(p[0].shape != dz0.shape or p[1].shape != x0.shape or not p[0].is_contiguous() or not p[1].is_contiguous()
+    if (W == 8 and mp % 4 != 0) or (W == 4 and mp % 16 != 0) or n > 64 or any(p[0].shape != dz0.shape or p[1].shape != x0.shape or not p[0].is_contiguous() or not p[1].is_contiguous()
                      or p[0].dtype != x0.dtype or p[1].dtype != x0.dtype for p in pairs):
         return None
     if not conv3_wgrad_band_supported(torch.empty((n * mp, Cin, H, W), dtype=x0.dtype, device='meta'), Cout, dtype_code_of=dtype_code(x0)):

@@ -16,8 +16,13 @@ import torch.distributed as dist
 
 class GradAllReducer:
     def __init__(self, params, bucket_bytes=64 << 20, process_group=None, overlap=True, force=False, comm_dtype=torch.float32,
-                 lowp_direct=None):
+                 lowp_direct=None, early=None):
         self.params = [p for p in params if p.requires_grad]
+        # `early`: parameters whose gradients are complete long before the end of backward (the decoder's: it is the first thing backward
+        # finishes).  They get leading buckets of their own (`early_buckets`), so that their all-reduce can start -- from the hook of the last
+        # of them in the eager loop, between the two segments of a recorded step (train.GraphedStep) -- while the rest of backward runs.
+        self._early_ids = {id(p) for p in (early or [])}
+        self.early_buckets = []
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -48,17 +53,22 @@ class GradAllReducer:
             self._install_hooks()
 
     def _build(self, bucket_bytes):
-        cur, cur_bytes = [], 0
-        for p in reversed(self.params):                  # reverse order = order gradients become final
-            cur.append(p)
-            cur_bytes += p.numel() * 4
-            if cur_bytes >= bucket_bytes:
-                self._finish_bucket(cur)
-                cur, cur_bytes = [], 0
-        if cur:
-            self._finish_bucket(cur)
+        order = list(reversed(self.params))              # reverse order = order gradients become final
+        groups = [[p for p in order if id(p) in self._early_ids], [p for p in order if id(p) not in self._early_ids]]
+        for gi, group in enumerate(groups):
+            cur, cur_bytes = [], 0
+            for p in group:
+                cur.append(p)
+                cur_bytes += p.numel() * 4
+                if cur_bytes >= bucket_bytes:
+                    self._finish_bucket(cur, early=gi == 0)
+                    cur, cur_bytes = [], 0
+            if cur:
+                self._finish_bucket(cur, early=gi == 0)
 
-    def _finish_bucket(self, plist):
+    def _finish_bucket(self, plist, early=False):
+        if early:
+            self.early_buckets.append(len(self.buckets))
         plist = [p for p in plist if id(p) in self._direct_ids] + [p for p in plist if id(p) not in self._direct_ids]
         total = sum(p.numel() for p in plist)
         flat = torch.zeros(total, dtype=torch.float32, device=plist[0].device)

@@ -221,6 +221,13 @@ class GraphedStep:
         # (functional.set_conv_grad_outputs), so gradient folding and the batched weight gradients stay on and the data-parallel
         # step runs the kernels of the single-GPU step
         self._conv_sinks = conv_gradient_sinks(sep_net, grad_sync) if (grad_sync is not None and not self.mlp) else None
+        # ... and its backward pass is recorded in TWO segments split at the decoder's inputs when the reducer keeps the decoder's gradients
+        # in buckets of their own (GradAllReducer(early=decoder parameters)): their all-reduce is issued between the two replays and travels
+        # on the comm stream while the integrator's / encoders' backward kernels run (VARSEP_GRAPH_SEGMENTS=0: one segment, as in round 3)
+        self.segmented = (grad_sync is not None and not self.mlp and bool(getattr(grad_sync, 'early_buckets', None))
+                          and getattr(sep_net, 'fused', False) and getattr(sep_net.Es, 'call_groups', False) and getattr(sep_net.Et, 'call_groups', False)
+                          and hasattr(sep_net.decoder, 'decode_sequence') and os.environ.get('VARSEP_GRAPH_SEGMENTS', '1') == '1'
+                          and os.environ.get('VARSEP_ENCODER_PAIRS', '1') == '1')
         # single process, conv family: the same destinations WITHOUT a reducer (one flat fp32 buffer, zeroed at the start of the step) --
         # a weight gradient that accumulates into a tensor autograd never sees can run on a gradient stream beside the input-gradient /
         # BatchNorm chain it does not feed (functional._conv_weight_grad); joined before the optimizer.  VARSEP_CONV_WGRAD_SIDE=1 turns it on;
@@ -302,10 +309,20 @@ class GraphedStep:
             # a second graph
             from . import functional as VF
             VF.bn_counts_flushed_in_capture(True)
+            self.graph2 = None
             try:
-                with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
-                    self.loss = self._fwd_bwd()
-                    VF.flush_bn_call_counts()
+                if self.segmented:
+                    with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
+                        self.loss = self._fwd_bwd(segment=1)
+                    # same memory pool: the second segment reads what the first one saved for it
+                    self.graph2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=_CAPTURE_MODE):
+                        self._fwd_bwd(segment=2)
+                        VF.flush_bn_call_counts()
+                else:
+                    with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
+                        self.loss = self._fwd_bwd()
+                        VF.flush_bn_call_counts()
             finally:
                 VF.bn_counts_flushed_in_capture(False)
             self._reduce()
@@ -350,10 +367,24 @@ class GraphedStep:
         if self.sync is not None:
             self.sync.reduce_all()
 
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, segment=None):
+        """Losses + backward.  `segment` (conv family under a reducer with early buckets): 1 = forward and the part of backward that ends at
+        the decoder's inputs (the decoder's gradients are complete afterwards), 2 = the rest of backward from those tensors' gradients."""
         nt_cond, nt_pred, offset, l_ae, l_s, l_t, l_pred, avg = self.args
         from . import functional as VF
         fold_was = VF.folding_repeated_gradients()
+        if segment == 2:
+            cuts, self._cuts = self._cuts, None
+            VF.set_conv_grad_outputs(self._conv_sinks)
+            VF.fold_repeated_gradients(True, flush=False)
+            try:
+                torch.autograd.backward(cuts, [c.grad for c in cuts])
+            finally:
+                for c in cuts:
+                    c.grad = None
+                VF.set_conv_grad_outputs(None)
+                VF.fold_repeated_gradients(fold_was, flush=False)
+            return None
         if self.sync is not None:
             self.sync.zero_buffers()
             if self.mlp:
@@ -376,6 +407,7 @@ class GraphedStep:
         else:
             self.opt.zero_grad(set_to_none=True)
         VF.enable_side_streams(self.side_streams)
+        VF.collect_cuts(segment == 1)
         up = self._one if self.scaler is None else self.scaler.scale_tensor()
         VF.promise_loss_gradient(up if (self.mlp and os.environ.get('VARSEP_LOSS_ONE_PASS', '1') == '1') else None)
         try:
@@ -386,12 +418,20 @@ class GraphedStep:
                 total, _, _, _ = compute_losses(self.cond, self.target, self.net, nt_cond, nt_pred, offset, self.skipco, l_ae, l_s,
                                                 l_t, l_pred, avg, t_random=self.t_dev)
             # a resident 1.0 (no ones_like fill per step), or the loss scale of fp16 training (train.py:152 scaler.scale(loss))
-            total.backward(up)
+            if segment == 1:
+                cuts = VF.cut_tensors()
+                assert cuts, 'segmented backward: no tensor was noted at the decoder\'s inputs'
+                heads = [p for p in self.net.decoder.parameters() if p.requires_grad]
+                torch.autograd.backward(total, up, inputs=heads + cuts, retain_graph=True)
+                self._cuts = cuts
+            else:
+                total.backward(up)
             from .optim import Adam as HipAdam
             partial = (self.sync is None and self.scaler is None and isinstance(self.opt, HipAdam)
                        and bool(getattr(self.opt, '_fused', None)) and VF.tail_fused_updates())
             self._pending_join = VF.join_side_streams(partial=partial)
         finally:
+            VF.collect_cuts(False)
             VF.promise_loss_gradient(None)
             VF.enable_side_streams(False)
             VF.set_grad_outputs(None)
@@ -409,8 +449,13 @@ class GraphedStep:
             self._capture()                          # a scheduler moved the learning rate: it is a launch argument of the recording
         self._draw()
         self.graph.replay()
+        early = {}
+        if getattr(self, 'graph2', None) is not None:
+            # the decoder's buckets go on the wire now; the second segment (integrator + encoders backward) runs beside them
+            early = {bi: self.sync.reduce_bucket(bi) for bi in self.sync.early_buckets}
+            self.graph2.replay()
         if isinstance(self.graph_opt, list):
-            events = [self.sync.reduce_bucket(bi) for bi in range(len(self.sync.buckets))]
+            events = [early[bi] if bi in early else self.sync.reduce_bucket(bi) for bi in range(len(self.sync.buckets))]
             main = torch.cuda.current_stream()
             for ev, g in zip(events, self.graph_opt):
                 if ev is not None:
@@ -418,7 +463,11 @@ class GraphedStep:
                 g.replay()
             self.graph_opt[-1].replay()              # step counter
         elif self.graph_opt is not None:
-            self._reduce()
+            for bi in range(len(self.sync.buckets)):
+                if bi not in early:
+                    self.sync.reduce_bucket(bi)
+            if self.sync._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.sync._comm_stream)
             self.graph_opt.replay()
         # the replay changed parameters and BatchNorm statistics without moving a version counter: whatever eager code derives from them
         # next (evaluation between training steps, instrumented eager steps, a re-recording) must re-derive it
@@ -699,6 +748,9 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
         else:
             s_old, s_recent = _encode_pair(sep_net.Es, full_data[:, :nt_cond], full_data[:, -nt_cond:], skipco)
             t_rand, t_cond = _encode_pair(sep_net.Et, window, cond, False)
+        if cond.is_cuda:
+            from . import functional as VF
+            VF.cut((s_old, s_recent, t_rand))      # every tensor through which the losses reach the encoders / the integrator
         if skipco:
             reconstruction = sep_net.decoder(s_old[0], t_rand, skip=s_old[1])
         else:

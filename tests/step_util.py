@@ -132,14 +132,76 @@ def lowp_noise_floor(cfg, t_random, precision, loss_scale=None, base=None, pertu
         if p.grad is not None:
             key = 'grad:' + _part(k)
             out[key] = max(out.get(key, 0.0), grad_err(bg[k].grad, p.grad, floor))
+    out.update(part_grad_distance({k: v.grad for k, v in bg.items() if v.grad is not None},
+                                  {k: p.grad for k, p in a[0].named_parameters() if p.grad is not None}))
     sa, sb = a[0].state_dict(), b[0].state_dict()
     out['bn_running'] = max([rel_err(sb[k].float(), sa[k].float()) for k in sa if k.endswith('running_mean') or k.endswith('running_var')] or [0.0])
     return out
 
 
-def noise_bound(noise, key, floor_tol, cap=1.0):
-    """max(stated floor, 3 x the emulation's self-distance), never above `cap` (a result must stay correlated with the emulation)."""
+NOISE_CAP = 0.5
+
+
+def part_grad_distance(got, ref):
+    """{'gradall:<part>': relative L2 distance over ALL gradient tensors of the sub-network taken as one vector}: dominated by the large
+    convolution weights, it stays meaningful where a single small tensor (a BatchNorm bias of the first block) of two valid 16-bit
+    evaluations is as good as uncorrelated."""
+    num, den = {}, {}
+    for k, r in ref.items():
+        part = _part(k)
+        d = (got[k].detach().double().cpu().flatten() - r.detach().double().cpu().flatten())
+        num[part] = num.get(part, 0.0) + float((d * d).sum())
+        den[part] = den.get(part, 0.0) + float((r.detach().double() ** 2).sum())
+    return {'gradall:' + p: (num[p] / max(den[p], 1e-300)) ** 0.5 for p in num}
+
+
+def noise_bound(noise, key, floor_tol, cap=NOISE_CAP):
+    """max(stated floor, 3 x the emulation's COMMITTED self-distance), never above 0.5: where two valid evaluations of a part's gradients lie
+    further apart than a sixth, the bound does not follow them -- a result at distance > 0.5 fails."""
     return min(cap, max(floor_tol, 3.0 * noise.get(key, 0.0)))
+
+
+def check_gradients(per, per_part, noise, tol_grad, fails, precision):
+    """Gradient bounds of a 16-bit step against the emulation.  Per TENSOR (error on the scale max(its norm, 1e-3 of the whole gradient))
+    wherever the committed bound of its sub-network, max(tol_grad, 3 x self-distance), is below the cap of 0.5; for a sub-network whose
+    single tensors are chaotic beyond that (tiny hash-filled nets: two valid evaluations of one BatchNorm bias are uncorrelated) the
+    sub-network's gradient as ONE vector instead, bounded by max(tol_grad, 3 x its committed self-distance) and never above 0.5 -- nothing is
+    relaxed past 0.5.  Appends to `fails`; returns (worst error / bound, its key)."""
+    worst, kw = 0.0, None
+    for k, v in per.items():
+        b = max(tol_grad, 3.0 * noise.get('grad:' + _part(k), 0.0))
+        if b > NOISE_CAP:
+            continue                                  # judged as part of the whole sub-network below
+        if v / b > worst:
+            worst, kw = v / b, k
+        if not v <= b:
+            fails.append(f'gradient {k}: HIP {precision} vs emulation {v:.3e} > {b:.1e}')
+    for key, v in per_part.items():
+        b = noise_bound(noise, key, tol_grad)
+        if v / b > worst:
+            worst, kw = v / b, key
+        if not v <= b:
+            fails.append(f'{key} (all gradients of the sub-network as one vector): HIP {precision} vs emulation {v:.3e} > {b:.1e}')
+    return worst, kw
+
+
+def lowp_case_key(name, cfg, precision, loss_scale):
+    return '%s|B%d|%s|ls%s' % (name, cfg['B'], precision, 'none' if not loss_scale else '%g' % loss_scale)
+
+
+_COMMITTED = {}
+
+
+def committed_noise(name, cfg, precision, loss_scale):
+    """The emulation's self-distances of this test case from tests/golden/lowp_bounds.json (written by tests/make_lowp_bounds.py on the
+    CPU, committed): constants, so that a drift of the kernels cannot move its own bound."""
+    import json
+    import os
+    if not _COMMITTED:
+        _COMMITTED.update(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lowp_bounds.json'))))
+    key = lowp_case_key(name, cfg, precision, loss_scale)
+    assert key in _COMMITTED, 'no committed noise constants for %s: run `python tests/make_lowp_bounds.py`' % key
+    return _COMMITTED[key]
 
 
 def emulated_product_step(cfg, t_random, precision='bf16'):
@@ -163,16 +225,16 @@ def emulated_product_step(cfg, t_random, precision='bf16'):
     return net, total, terms, forecasts, t_codes
 
 
-def compare_step_bf16_conv(cfg, t_random, tol_out=2e-3, tol_grad=5e-2, precision='bf16', loss_scale=None):
+def compare_step_bf16_conv(name, cfg, t_random, tol_out=2e-3, tol_grad=5e-2, precision='bf16', loss_scale=None):
     """HIP 16-bit step of a conv family against the INDEPENDENT rounding-point emulation (oracle/bf16_emu.emulate_bf16: the oracle's
     module tree and call structure with the mode's rounding points).  Bounds: max(tol, 3 x the emulation's own sensitivity to fp32
-    summation-order noise) -- see lowp_noise_floor -- per output and per sub-network for the gradients (on the scale of
-    max(a tensor's norm, 1e-3 of the whole gradient))."""
+    summation-order noise -- lowp_noise_floor, COMMITTED per case in tests/golden/lowp_bounds.json) and never above 0.5, per output and
+    per sub-network for the gradients (on the scale of max(a tensor's norm, 1e-3 of the whole gradient))."""
     o_net0 = fill_net(cpu_ref.build_sep_net(cfg), cfg)
     h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, t_random, o_net0, precision, loss_scale=loss_scale)
     emu = emulated_bf16_step(cfg, t_random, precision, loss_scale=loss_scale)
     e_net, e_total, e_terms, e_fore, e_tc = emu
-    noise = lowp_noise_floor(cfg, t_random, precision, loss_scale=loss_scale, base=emu)
+    noise = committed_noise(name, cfg, precision, loss_scale)
     errs = {'forecasts': rel_err(h_fore.detach().cpu().float(), e_fore.detach().float()),
             't_codes': rel_err(h_tc.detach().cpu().float(), e_tc.detach().float()),
             'total': abs(h_total.item() - e_total.item()) / abs(e_total.item())}
@@ -181,18 +243,10 @@ def compare_step_bf16_conv(cfg, t_random, tol_out=2e-3, tol_grad=5e-2, precision
     eg = dict(e_net.named_parameters())
     floor = 10 * grad_floor(e_net)
     per = {k: grad_err(p.grad.detach().cpu(), eg[k].grad, floor) for k, p in h_net.named_parameters() if p.grad is not None}
-    def grad_bound(k):
-        # where the emulation's OWN self-distance saturates the bound (two equally valid evaluations of the part's gradients are a third or more
-        # apart: tiny nets, 16-bit, per-call BatchNorm stacks) a single small tensor -- a BatchNorm bias of the first block -- of two valid
-        # evaluations is as good as uncorrelated (distance ~ sqrt 2): only "finite and of the right size" is left to check there
-        b = noise_bound(noise, 'grad:' + _part(k), tol_grad)
-        return 1.5 if b >= 1.0 else b
-    over = {k: v / grad_bound(k) for k, v in per.items()}
-    kw = max(over, key=over.get)
+    over, kw = check_gradients(per, part_grad_distance({k: p.grad for k, p in h_net.named_parameters() if p.grad is not None},
+                                                       {k: p.grad for k, p in eg.items() if p.grad is not None}), noise, tol_grad, fails, precision)
     errs['grad_worst'] = max(per.values())
-    errs['grad_worst_over_bound'] = over[kw]
-    if not over[kw] <= 1.0:
-        fails.append(f'gradient {kw}: HIP {precision} vs emulation {per[kw]:.3e} > {noise_bound(noise, "grad:" + _part(kw), tol_grad):.1e}')
+    errs['grad_worst_over_bound'] = over
     # BatchNorm running statistics after the step
     esd = e_net.state_dict()
     bn = 0.0

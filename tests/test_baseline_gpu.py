@@ -23,7 +23,7 @@ from oracle import cpu_ref
 from oracle.detdata import det_fill
 from oracle.golden_configs import FULL_CONFIGS, fill_net, make_batch
 from golden_util import check_tensor, load_golden, rel_err
-from step_util import grad_err, grad_floor, hip_step, lowp_noise_floor, noise_bound, oracle_step
+from step_util import committed_noise, grad_err, grad_floor, hip_step, noise_bound, oracle_step
 
 pytestmark = pytest.mark.gpu
 
@@ -245,7 +245,7 @@ def test_full_size_lowp_step_matches_emulation_and_reference(name, precision, fa
     # (ii) the rounding-point emulation, element-wise
     emu = emulated_bf16_step(cfg, t_random, precision, loss_scale=loss_scale)
     e_net, e_total, e_terms, e_fore, e_tc = emu
-    noise = lowp_noise_floor(cfg, t_random, precision, loss_scale=loss_scale, base=emu)
+    noise = committed_noise(name, cfg, precision, loss_scale)
     tol = _EMU_OUT[precision]
     errs = {'emu:forecasts': rel_err(h_fore.detach().float().cpu(), e_fore.detach().float()),
             'emu:t_codes': rel_err(h_tc.detach().float().cpu(), e_tc.detach().float()),
@@ -258,11 +258,10 @@ def test_full_size_lowp_step_matches_emulation_and_reference(name, precision, fa
     floor = 10 * grad_floor(e_net)                   # 1e-3 of the whole gradient's norm
     eg = dict(e_net.named_parameters())
     per = {k: grad_err(g, eg[k].grad, floor) for k, g in grads.items()}
-    over = {k: v / noise_bound(noise, 'grad:' + k.split('.')[0], _EMU_GRAD) for k, v in per.items()}
-    kw = max(over, key=over.get)
+    from step_util import check_gradients, part_grad_distance
+    over, kw = check_gradients(per, part_grad_distance(grads, {k: p.grad for k, p in eg.items() if p.grad is not None}), noise, _EMU_GRAD, fails, precision)
     errs['emu:grad_worst'] = max(per.values())
-    errs['emu:grad_worst_over_bound'] = over[kw]
-    expect(over[kw] <= 1.0, f'gradient {kw}: HIP {precision} vs rounding-point emulation {per[kw]:.3e}, {over[kw]:.2f} x its bound')
+    errs['emu:grad_worst_over_bound'] = over
     # gradients vs the reference, relative to the mode's own distance from it
     ratio = 0.0
     for k, e_hip in hip_ref.items():
@@ -283,7 +282,17 @@ def test_full_size_lowp_step_matches_emulation_and_reference(name, precision, fa
     errs['emu:bn_running'] = bn
     expect(bn <= noise_bound(noise, 'bn_running', tol), f'BatchNorm running statistics: {bn:.3e}')
     worst.update(errs)
+    # the measured distances of this run, kept round to round under profiles/ (copied from gpurun_out/ by hand): a drift is visible there
+    try:
+        import json
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'lowp_errors_%s_%s.json' % (name, precision)), 'w') as f:
+            json.dump({'case': name, 'precision': precision, 'errors': {k: float(v) for k, v in worst.items()},
+                       'hip_vs_reference_fixture_gradients': {k: float(v) for k, v in hip_ref.items()},
+                       'hip_vs_emulation_gradients': {k: float(v) for k, v in per.items()}}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
     top = sorted(per.items(), key=lambda kv: -kv[1])[:4]
-    print(name, precision, {k: '%.1e' % v for k, v in worst.items()}, 'largest gradient distances to the emulation:',
-          [(k, '%.1e' % v) for k, v in top], '| emulation self-distance', {k: '%.1e' % v for k, v in noise.items() if not k.startswith('loss')})
+    print(name, precision, {k: '%.1e' % v for k, v in worst.items()}, 'worst gradient / bound at', kw, 'largest gradient distances to the emulation:',
+          [(k, '%.1e' % v) for k, v in top], '| committed emulation self-distance', {k: '%.1e' % v for k, v in noise.items() if not k.startswith('loss')})
     assert not fails, '\n'.join(fails)

@@ -557,6 +557,9 @@ def test_conv3_band_forward_and_input_gradient(dtype, geom):
     (312, 64, 16, 16, 512),   # the SST integrator's batched call (39 x 8 maps)
     (10, 128, 8, 8, 72),      # 8 x 8 maps, four per item: two full items + two maps
     (9, 40, 8, 8, 256),
+    (200, 512, 4, 4, 512),    # 4 x 4 maps, sixteen per item (the VGG encoders' 512-channel layers on the two stacked calls): 12 items + 8 maps
+    (37, 40, 4, 4, 72),       # 4 x 4 maps, ragged channels both ways, a partial last item
+    (5, 64, 4, 4, 24),        # fewer maps than one item
 ])
 def test_conv3_wgrad_band_matches_fp64(dtype, geom, monkeypatch):
     """Weight gradient of Conv2d k3 s1 p1 through vs_conv3_wgrad_band + vs_slab_sum (ops.conv_wgrad picks it) against fp64 autograd on the
@@ -601,12 +604,31 @@ def test_conv3_wgrad_band_over_separate_pieces_equals_the_concatenated_batch():
 
 
 @pytest.mark.gpu
+def test_conv3_wgrad_band_pieces_on_4x4_maps():
+    """The pieces form on 4 x 4 maps (sixteen per item: pieces of a multiple of 16 maps) == the concatenated batch, bit for bit; other piece
+    sizes are refused (the caller concatenates)."""
+    from spatiotemporal_variable_separation_amd import ops
+    dtype = torch.bfloat16
+    pairs = [(_rand((32, 96, 4, 4), 500 + i).to(dtype).cuda(), _rand((32, 64, 4, 4), 600 + i).to(dtype).cuda()) for i in range(3)]
+    shape = (96, 64, 3, 3)
+    dz, x = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
+    want = ops.conv_wgrad(dz, x, shape, 1, 1, False)
+    got = ops.conv3_wgrad_band_pieces(pairs, shape)
+    torch.cuda.synchronize()
+    assert got is not None and torch.equal(got, want)
+    odd = [(p[0][:8].contiguous(), p[1][:8].contiguous()) for p in pairs]
+    assert ops.conv3_wgrad_band_pieces(odd, shape) is None
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('geom', [
     (6, 64, 32, 32, 128),     # DCGAN encoder layer 2 (nf = 64): planes [6, 256, 16, 16]
     (5, 128, 16, 16, 256),    # layer 3: planes [5, 512, 8, 8] (8 x 8 maps, four per workgroup; 5 = one full group + 1)
     (3, 16, 64, 64, 40),      # planes [3, 64, 32, 32]: one 64-channel phase, ragged output-channel tile
     (2, 32, 128, 128, 32),    # planes [2, 128, 64, 64]
+    (37, 256, 8, 8, 512),     # DCGAN encoder layer 4 / decoder layer 1 (conv.py:122, 260): planes [37, 1024, 4, 4], sixteen maps per item
+    (16, 64, 8, 8, 40),       # 4 x 4 planes, ragged output-channel tile
 ])
 def test_conv_k4s2_on_parity_planes_matches_fp64(dtype, geom):
     """The k4 s2 p1 family without a column matrix (csrc/vs_conv_k4s2.hip: parity planes + row-band kernels) against fp64 torch on the

@@ -29,7 +29,7 @@ def _losses(net, cond, target, cfg, t_random):
                                    lam['s'], lam['t'], lam['pred'], t_random=t_random)[0]
 
 
-def _worker(rank, world, port, overlap, bucket_bytes, out_dir):
+def _worker(rank, world, port, overlap, bucket_bytes, out_dir, early=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -39,7 +39,13 @@ def _worker(rank, world, port, overlap, bucket_bytes, out_dir):
     cond, target = make_batch(cfg)
     net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'] + rank)       # ranks start DIFFERENT ...
     broadcast_module_state(net)                                               # ... and are made equal to rank 0
-    sync = GradAllReducer(net.parameters(), bucket_bytes=bucket_bytes, overlap=overlap)
+    sync = GradAllReducer(net.parameters(), bucket_bytes=bucket_bytes, overlap=overlap, early=list(net.decoder.parameters()) if early else None)
+    if early:
+        # the decoder's gradients (complete first in backward) lead, in buckets of their own
+        dec = {id(p) for p in net.decoder.parameters()}
+        assert sync.early_buckets and sync.early_buckets == list(range(len(sync.early_buckets)))
+        for bi, (_, plist) in enumerate(sync.buckets):
+            assert all((id(p) in dec) == (bi in sync.early_buckets) for p in plist)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     shard = slice(rank * 4, rank * 4 + 4)
     for step in range(2):
@@ -52,10 +58,10 @@ def _worker(rank, world, port, overlap, bucket_bytes, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('overlap,bucket_bytes', [(True, 16 << 10), (False, 64 << 20)])
-def test_two_replicas_equal_single_process(tmp_path, overlap, bucket_bytes):
+@pytest.mark.parametrize('overlap,bucket_bytes,early', [(True, 16 << 10, False), (False, 64 << 20, False), (True, 16 << 10, True)])
+def test_two_replicas_equal_single_process(tmp_path, overlap, bucket_bytes, early):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, overlap, bucket_bytes, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, overlap, bucket_bytes, str(tmp_path), early), nprocs=2, join=True)
     # single process on the concatenated batch (mean losses => averaged shard gradients are the same gradient)
     cfg = dict(CONFIGS['mlp_mul'], B=8)
     cond, target = make_batch(cfg)

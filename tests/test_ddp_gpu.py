@@ -148,7 +148,7 @@ def test_graphed_step_with_directly_written_wire_gradients(tmp_path, world, back
 
 
 # ---- convolution families (BatchNorm per replica, the decoder's grouped calls, folded / batched weight gradients) -----------------------
-def _conv_worker(rank, world, port, name, graph, precision, out_dir):
+def _conv_worker(rank, world, port, name, graph, precision, out_dir, segmented=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -165,7 +165,7 @@ def _conv_worker(rank, world, port, name, graph, precision, out_dir):
     cond, target = cond[rank * per:(rank + 1) * per].cuda().contiguous(), target[rank * per:(rank + 1) * per].cuda().contiguous()
     net = _build(cfg, cfg['salt'] + rank)
     broadcast_module_state(net)
-    sync = GradAllReducer(net.parameters(), bucket_bytes=256 << 10)
+    sync = GradAllReducer(net.parameters(), bucket_bytes=256 << 10, early=list(net.decoder.parameters()) if segmented else None)
     opt = Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.99))
     np.random.seed(7)
     hi = cond.shape[1] + target.shape[1] + (cfg['offset'] != 0)
@@ -175,6 +175,7 @@ def _conv_worker(rank, world, port, name, graph, precision, out_dir):
             gs = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], (lam['ae'], lam['s'], lam['t'], lam['pred']),
                              bool(cfg.get('average_tloss')), warmup=1, grad_sync=sync)
             assert gs._conv_sinks, 'the convolution gradients must go straight into the reducer\'s buckets'
+            assert gs.segmented == segmented and (gs.graph2 is not None) == segmented
             for _ in range(3):
                 losses.append(gs.step().item())
         else:
@@ -273,6 +274,39 @@ def test_conv_family_two_ranks_equal_two_independent_halves(tmp_path, name, prec
         worst = max(worst, e)
         assert e <= tol, f'{k}: the update of the data-parallel run differs from the two-halves reference by {e:.3e} of its norm'
     print(name, precision, 'graph' if graph else 'eager', 'worst update distance %.2e' % worst, 'losses', r0['losses'])
+
+
+@pytest.mark.parametrize('name,precision', [('vgg32_tiny', 'fp32'), ('sst_skip', 'fp32'), ('sst_skip', 'bf16'), ('dcgan_skip_mul', 'fp32')])
+def test_recorded_step_in_two_segments_equals_one_segment(tmp_path, name, precision):
+    """The recorded data-parallel step of a conv family with the decoder's gradients in leading buckets of their own: backward recorded in TWO
+    segments split at the decoder's inputs, the decoder buckets' all-reduce issued between the two replays (train.GraphedStep.segmented).
+    Two ranks on one GPU over gloo: same losses as the one-segment recording, replicas bit-identical, parameters within the noise of two
+    runs whose float-atomic sums differ in the last bit."""
+    a, b = tmp_path / 'seg', tmp_path / 'one'
+    a.mkdir(), b.mkdir()
+    mp.spawn(_conv_worker, args=(2, _free_port(), name, True, precision, str(a), True), nprocs=2, join=True)
+    mp.spawn(_conv_worker, args=(2, _free_port(), name, True, precision, str(b), False), nprocs=2, join=True)
+    s0, s1 = torch.load(os.path.join(a, 'rank0.pt')), torch.load(os.path.join(a, 'rank1.pt'))
+    o0 = torch.load(os.path.join(b, 'rank0.pt'))
+    assert np.allclose(s0['losses'], o0['losses'], rtol=1e-5 if precision == 'fp32' else 2e-2), (s0['losses'], o0['losses'])
+    cfg = dict(CONFIGS[name], B=8)
+    init = {k: v.detach().cpu() for k, v in _build(cfg, cfg['salt']).state_dict().items()}
+    worst = 0.0
+    for k, v in o0['state'].items():
+        x = s0['state'][k]
+        if k.endswith('num_batches_tracked'):
+            assert int(x) == int(v), k
+            continue
+        if 'running' not in k:
+            assert torch.equal(x, s1['state'][k]), f'replicas diverged at {k}'
+        du, dv = (x - init[k]).double(), (v - init[k]).double()
+        if dv.norm().item() == 0.0:
+            assert du.norm().item() == 0.0, k
+            continue
+        e = ((du - dv).norm() / dv.norm()).item()
+        worst = max(worst, e)
+        assert e <= (3e-2 if precision == 'fp32' else 0.6), f'{k}: update differs by {e:.3e} of its norm between the two recordings'
+    print(name, precision, 'two segments vs one: worst update distance %.2e' % worst)
 
 
 @pytest.mark.gpu

@@ -29,7 +29,7 @@ def test_step_fp16_conv_matches_rounding_point_emulation(name):
     the 16-bit gradients out of the subnormal range; both sides divide it out again).  VGG / SST at batch 16 (see test_step_gpu.LOWP_BATCH)."""
     from test_step_gpu import LOWP_BATCH
     cfg = dict(CONFIGS[name], B=LOWP_BATCH.get(name, CONFIGS[name]['B']))
-    compare_step_bf16_conv(cfg, int(load_golden(name)['t_random']), tol_out=2e-3, tol_grad=5e-2, precision='fp16', loss_scale=256.0)
+    compare_step_bf16_conv(name, cfg, int(load_golden(name)['t_random']), tol_out=2e-3, tol_grad=5e-2, precision='fp16', loss_scale=256.0)
 
 
 def _net_and_batch(name='mlp_mul', B=8):

@@ -63,7 +63,7 @@ def test_step_bf16_conv_matches_bf16_emulation(name):
     tensor of one whole training step, finite bounds throughout."""
     from step_util import compare_step_bf16_conv
     cfg = dict(CONFIGS[name], B=LOWP_BATCH.get(name, CONFIGS[name]['B']))
-    compare_step_bf16_conv(cfg, int(load_golden(name)['t_random']), tol_out=5e-3, tol_grad=5e-2)
+    compare_step_bf16_conv(name, cfg, int(load_golden(name)['t_random']), tol_out=5e-3, tol_grad=5e-2)
 
 
 @pytest.mark.parametrize('name', CONV_CONFIGS)
