@@ -528,7 +528,7 @@ def compact_line(full, limit=4000):
     out = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                                 'vs_baseline', 'dtype', 'data') if k in full}
     cfg = full.get('config', {})
-    out['config'] = {k: cfg[k] for k in ('workload', 'global_batch', 'parallelism', 'grad_allreduce', 'launch') if k in cfg}
+    out['config'] = {k: cfg[k] for k in ('workload', 'global_batch', 'parallelism', 'grad_allreduce', 'launch', 'final_loss') if k in cfg}
     rf = full.get('roofline')
     out['roofline'] = None if rf is None else {k: rf[k] for k in _ROOF_KEYS if k in rf}
     cb = full.get('cpu_baseline')

@@ -370,10 +370,42 @@ __global__ __launch_bounds__(256, MINB) void conv3_band_kernel(const unsigned sh
                 float s1 = live ? r0 + r1 : 0.f, s2 = live ? r0 * r0 + r1 * r1 : 0.f;
 #pragma unroll
                 for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-                if (l31 == 0 && live) {
-                    double* slot = bn_sums + ((int64_t)(oimg / maps_per_group) * Cout + m) * 2;
-                    atomicAdd(slot, (double)s1);
-                    atomicAdd(slot + 1, (double)s2);
+                if (maps_per_group > 0) {
+                    if (l31 == 0 && live) {
+                        double* slot = bn_sums + ((int64_t)(oimg / maps_per_group) * Cout + m) * 2;
+                        atomicAdd(slot, (double)s1);
+                        atomicAdd(slot + 1, (double)s2);
+                    }
+                } else if (IPB == 1) {
+                    // partial-table form (maps_per_group == 0, bn_sums = float parts[B * bands][Cout][2]): no atomics -- the four waves' sums of
+                    // this channel meet in LDS (free by now: everybody is past the last phase's barrier) and ONE thread per channel writes the
+                    // workgroup's (sum, sum of squares) to its own row of the table; vs_bn_stats_from_parts_fold adds the rows in a fixed order
+                    if (l31 == 0) {
+                        float* red = reinterpret_cast<float*>(xs);
+                        const int cl = 4 * (lane >> 5) + (v & 3) + 8 * (v >> 2);
+                        red[(wave * 32 + cl) * 2] = s1;
+                        red[(wave * 32 + cl) * 2 + 1] = s2;
+                    }
+                } else if (l31 == 0 && live) {                                       // W = 8: a wave's 64 pixels ARE one map -> row = the map
+                    float* slot = reinterpret_cast<float*>(bn_sums) + ((int64_t)oimg * Cout + m) * 2;
+                    slot[0] = s1;
+                    slot[1] = s2;
+                }
+            }
+        }
+    }
+    if constexpr (W != 4 && IPB == 1) {
+        if (bn_sums && maps_per_group == 0) {
+            __syncthreads();
+            if (tid < 32) {
+                const float* red = reinterpret_cast<const float*>(xs);
+                const int m = mt * 32 + tid;
+                const float s1 = (red[tid * 2] + red[(32 + tid) * 2]) + (red[(64 + tid) * 2] + red[(96 + tid) * 2]);
+                const float s2 = (red[tid * 2 + 1] + red[(32 + tid) * 2 + 1]) + (red[(64 + tid) * 2 + 1] + red[(96 + tid) * 2 + 1]);
+                if (m < Cout) {
+                    float* slot = reinterpret_cast<float*>(bn_sums) + (((int64_t)b * bands + band) * Cout + m) * 2;
+                    slot[0] = s1;
+                    slot[1] = s2;
                 }
             }
         }
@@ -907,6 +939,42 @@ extern "C" int vs_conv3_band_bn(int compute, const void* x, const void* w_packed
 extern "C" int vs_conv3_band(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
                              int Cout, void* stream) {
     return vs_conv3_band_bn(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, W, Cout, nullptr, 1, stream);
+}
+
+// The same statistics WITHOUT atomics: every workgroup (W >= 16: one row band of one map; W = 8: every map) writes the (sum, sum of squares) of
+// the stored values of its 32 channels to its own row of parts [vs_conv3_band_bn_parts_rows(B, H, W)][Cout][2] (fp32; row = map * bands + band,
+// so the rows of a BatchNorm call group are consecutive); vs_bn_stats_from_parts_fold adds a group's rows in a fixed order (fp64) and does what
+// vs_bn_stats_from_sums_fold does.  Reproducible launch to launch, no zero fill.  k4 != 0: x are parity planes [B][4 K][H][W], Cin = 4 K, the
+// pack of vs_conv_k4s2_pack_weight (the gather of csrc/vs_conv_k4s2.hip).
+extern "C" int vs_conv3_band_bn_parts_rows(int B, int H, int W) {
+    if (W == 8) return B;
+    if (W != 16 && W != 32 && W != 64) return 0;
+    return B * (H / (256 / W));
+}
+
+extern "C" int vs_conv3_band_bn_parts(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W,
+                                      int Cout, float* parts, int k4, void* stream) {
+    VS_CHECK_ARG(x && w_packed && y && parts && vs_dtype_ok(y_dtype), "vs_conv3_band_bn_parts: bad argument");
+    VS_CHECK_ARG(vs_conv3_band_bn_supported(compute, B, Cin, H, W, Cout, 1), "vs_conv3_band_bn_parts: statistics not served for this geometry");
+    VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0 && (uintptr_t)parts % 8 == 0, "vs_conv3_band_bn_parts: operands must be 16-byte aligned");
+    VS_CHECK_ARG(!k4 || Cin % 4 == 0, "vs_conv3_band_bn_parts: the planes form needs Cin = 4 K");
+    double* tag = reinterpret_cast<double*>(parts);                               // (maps_per_group = 0 selects the table form in the kernel)
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (k4 && vs_conv_k4s2_skip_form(Cin / 4)) {
+        if (W == 64) rc = launch_band_k4_w<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, st, tag, 0);
+        else if (W == 32) rc = launch_band_k4_w<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, st, tag, 0);
+        else if (W == 16) rc = launch_band_k4_w<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, st, tag, 0);
+        else rc = launch_band_k4_w<8>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, st, tag, 0);
+    } else {
+        if (W == 64) rc = launch_band_w<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, st, tag, 0);
+        else if (W == 32) rc = launch_band_w<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, st, tag, 0);
+        else if (W == 16) rc = launch_band_w<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, st, tag, 0);
+        else rc = launch_band_w<8>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, st, tag, 0);
+    }
+    if (rc != VS_OK) return rc;
+    VS_CHECK_LAUNCH("vs_conv3_band_bn_parts");
+    return VS_OK;
 }
 
 // ---- weight gradient on row bands: x [B][Cin][H][W], dz [B][Cout][H][W] (16-bit) -> fp32 slabs [vs_conv3_wgrad_band_slabs][Cout][Cin][3][3] ----

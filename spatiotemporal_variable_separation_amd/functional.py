@@ -1341,9 +1341,13 @@ class ConvBlock(torch.autograd.Function):
                 Bp, C4, Hp, Wp = planes.shape
                 if training and ops.conv_band_bn_supported(Bp, C4, Hp, Wp, w.shape[0], groups, cdt):
                     # the BatchNorm sums are taken in the convolution's epilogue: no statistics pass over z
-                    sums = ops.bn_sums_buffer(gamma.data_ptr(), groups, w.shape[0], planes.device)
-                    z = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], cdt, bn_sums=sums, groups=groups)
-                    mean, invstd = ops.bn_stats_from_sums_fold(sums, (Bp // groups) * Hp * Wp, rmean, rvar, momentum, eps)
+                    if ops.band_bn_mode() == '1':
+                        sums = ops.bn_sums_buffer(gamma.data_ptr(), groups, w.shape[0], planes.device)
+                        z = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], cdt, bn_sums=sums, groups=groups)
+                        mean, invstd = ops.bn_stats_from_sums_fold(sums, (Bp // groups) * Hp * Wp, rmean, rvar, momentum, eps)
+                    else:                            # per-workgroup partial sums + one fold launch (no atomics)
+                        z, parts = ops.conv3_band_parts(planes, wpk, bias, w.shape[0], cdt, k4=True)
+                        mean, invstd = ops.bn_stats_from_parts_fold(parts, groups, (Bp // groups) * Hp * Wp, rmean, rvar, momentum, eps)
                     y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
                 else:
                     z = ops.conv_k4s2_gather(planes, wpk, bias, w.shape[0], cdt)
@@ -1386,9 +1390,13 @@ class ConvBlock(torch.autograd.Function):
                 small = training and ops.bn_small_supported_shape(cdt, Bx, w.shape[0], Hx * Wx) and (groups == 1 or ops.bn_small_groups_enabled())
                 if training and not small and ops.conv_band_bn_supported(Bx, Cx, Hx, Wx, w.shape[0], groups, cdt):
                     # the BatchNorm sums are taken in the convolution's epilogue: no statistics pass over z
-                    sums = ops.bn_sums_buffer(gamma.data_ptr(), groups, w.shape[0], xc.device)
-                    z = ops.conv3_band(xc, wpk, bias, w.shape[0], cdt, bn_sums=sums, groups=groups)
-                    mean, invstd = ops.bn_stats_from_sums_fold(sums, (Bx // groups) * Hx * Wx, rmean, rvar, momentum, eps)
+                    if ops.band_bn_mode() == '1':
+                        sums = ops.bn_sums_buffer(gamma.data_ptr(), groups, w.shape[0], xc.device)
+                        z = ops.conv3_band(xc, wpk, bias, w.shape[0], cdt, bn_sums=sums, groups=groups)
+                        mean, invstd = ops.bn_stats_from_sums_fold(sums, (Bx // groups) * Hx * Wx, rmean, rvar, momentum, eps)
+                    else:                            # per-workgroup partial sums + one fold launch (no atomics)
+                        z, parts = ops.conv3_band_parts(xc, wpk, bias, w.shape[0], cdt)
+                        mean, invstd = ops.bn_stats_from_parts_fold(parts, groups, (Bx // groups) * Hx * Wx, rmean, rvar, momentum, eps)
                     y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups)
                     ctx.save_for_backward(xc, z, mean, invstd)
                     ctx.cfg, ctx.cdt = cfg, cdt

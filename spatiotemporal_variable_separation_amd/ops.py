@@ -518,6 +518,13 @@ def _convt_1x1(x_shape, k, stride, pad, transposed):
     return (transposed and x_shape[2] == 1 and x_shape[3] == 1 and pad == 0 and stride == 1 and os.environ.get('VS_CONVT_1X1_GEMM', '1') == '1')
 
 
+def _conv_full(x_shape, k, stride, pad, transposed):
+    """Conv2d whose window is the whole (unpadded) map -- the encoders' `last_op` (reference conv.py:123, 169: Conv2d(8 nf, nh, 4, 1, 0) on a
+    4 x 4 map -> 1 x 1): a Linear layer on the map as it lies in memory, y[b][co] = sum_j x[b][j] w[co][j], j = (ci, ky, kx).  No gather."""
+    import os
+    return (not transposed and pad == 0 and x_shape[2] == k and x_shape[3] == k and os.environ.get('VS_CONV_FULL_GEMM', '1') == '1')
+
+
 def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     """x [B,Cin,H,W], w Conv2d [Cout,Cin,k,k] / ConvTranspose2d [Cin,Cout,k,k] in the same (compute) dtype.
     The transposed form consumes `w_packed` (conv_pack_weight); it is built on the fly from `w` when not given."""
@@ -539,6 +546,9 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
         brep = bias.repeat_interleave(k * w.shape[3]) if bias is not None else None
         y = gemm(x.view(B, Cin), LAYOUT_R, w.view(Cin, n), LAYOUT_S, B, n, Cin, out_dtype=out_dtype, bias=brep)
         return y.view(B, Cout, k, w.shape[3])
+    if _conv_full(x.shape, k, stride, pad, transposed) and w.shape[3] == k:
+        n = Cin * k * k
+        return gemm(x.view(B, n), LAYOUT_R, w.view(Cout, n), LAYOUT_R, B, Cout, n, out_dtype=out_dtype, bias=bias).view(B, Cout, 1, 1)
     thin = _thin_plan('fwd', dtype_code(x), B, Cin, H, W, Cout, OH, OW, k, stride, pad, transposed) if w.shape[2] == w.shape[3] else None
     if thin is not None:
         if thin[0] == 'expand':
@@ -575,6 +585,10 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
         # dx[b][ci] = sum_j dy[b][j] w[ci][j], j = (co, ky, kx)
         n = Cout * k * w.shape[3]
         return gemm(dy.view(B, n), LAYOUT_R, w.view(Cin, n), LAYOUT_R, B, Cin, n, out_dtype=out_dtype).view(B, Cin, 1, 1)
+    if _conv_full(x_shape, k, stride, pad, transposed) and w.shape[3] == k:
+        # dx[b][j] = sum_co dy[b][co] w[co][j]
+        n = Cin * k * k
+        return gemm(dy.view(B, Cout), LAYOUT_R, w.view(Cout, n), LAYOUT_S, B, n, Cout, out_dtype=out_dtype).view(B, Cin, k, k)
     thin = (_thin_plan('dgrad', dtype_code(dy), B, Cin, H, W, Cout, dy.shape[2], dy.shape[3], k, stride, pad, transposed)
             if w.shape[2] == w.shape[3] else None)
     if thin is not None:
@@ -666,6 +680,12 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
         n = Cout * k * w_shape[3]
         dw = into if into is not None else (out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device))
         gemm(x.view(B, Cin), LAYOUT_S, dy.view(B, n), LAYOUT_S, Cin, n, B, out=dw.view(Cin, n), accumulate=into is not None)
+        return dw
+    if _conv_full(x.shape, k, stride, pad, transposed) and w_shape[3] == k:
+        # dW[co][j] (+)= sum_b dy[b][co] x[b][j]
+        n = Cin * k * k
+        dw = into if into is not None else (out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device))
+        gemm(dy.view(B, Cout), LAYOUT_S, x.view(B, n), LAYOUT_S, Cout, n, B, out=dw.view(Cout, n), accumulate=into is not None)
         return dw
     thin = _thin_plan('wgrad', dtype_code(x), B, Cin, H, W, Cout, OH, OW, k, stride, pad, transposed) if w_shape[2] == w_shape[3] else None
     if thin is not None:
@@ -938,14 +958,58 @@ def bn_sums_buffer(key, groups, C, device):
     return buf
 
 
-def conv_band_bn_supported(B, Cin, H, W, Cout, groups, dtype):
-    """Whether vs_conv3_band (Cin = 4 K plane channels for the k4 s2 family) leaves the BatchNorm sums of its output.  Opt-in (VS_BAND_BN_SUMS=1):
-    measured slower -- a workgroup owns only 32 channels x 256 pixels, so a layer issues millions of fp64 atomics onto a few thousand
-    addresses (TaxiBJ 8.89 -> 10.7 ms, SST 21.2 -> 22.9); the statistics pass over y it replaces costs 11-80 us per layer."""
+def band_bn_mode():
+    """How the row-band kernels leave the BatchNorm statistics of their output (VS_BAND_BN_SUMS): 'parts' (default since round 4: per-workgroup
+    partial sums in a table + one fold launch, no atomics), '1' (fp64 atomics: round 3, measured SLOWER than a statistics pass -- a workgroup
+    owns 32 channels x 256 pixels, so a layer issues millions of atomics onto a few thousand addresses: TaxiBJ 8.89 -> 10.7 ms), '0' (a
+    statistics pass over the stored output)."""
     import os
-    if os.environ.get('VS_BAND_BN_SUMS', '0') != '1' or dtype == torch.float32:
+    return os.environ.get('VS_BAND_BN_SUMS', 'parts')
+
+
+def conv_band_bn_supported(B, Cin, H, W, Cout, groups, dtype):
+    """Whether vs_conv3_band (Cin = 4 K plane channels for the k4 s2 family) leaves the BatchNorm sums of its output (band_bn_mode)."""
+    if band_bn_mode() == '0' or dtype == torch.float32:
         return False
     return bool(_lib.load_library().vs_conv3_band_bn_supported(code_of(dtype), B, Cin, H, W, Cout, groups))
+
+
+def conv3_band_parts(x, w_packed, bias, Cout, out_dtype, role='fwd', k4=False):
+    """vs_conv3_band / the k4 s2 gather on planes with the per-workgroup (sum, sum of squares) of the stored output written to a table:
+    (y, parts [rows, Cout, 2] fp32); bn_stats_from_parts_fold finishes.  No atomics, no zero fill, reproducible."""
+    require_cuda(x, w_packed, bias)
+    assert x.is_contiguous() and x.dtype == w_packed.dtype
+    B, Cin, H, W = x.shape
+    lib = _lib.load_library()
+    rows = lib.vs_conv3_band_bn_parts_rows(B, H, W)
+    assert rows > 0
+    y = torch.empty((B, Cout, H, W), dtype=out_dtype, device=x.device)
+    parts = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
+    e0 = _pb()
+    check(lib.vs_conv3_band_bn_parts(dtype_code(x), x.data_ptr(), w_packed.data_ptr(), _ptr(bias), y.data_ptr(), dtype_code(y), B, Cin, H, W, Cout,
+                                     parts.data_ptr(), 1 if k4 else 0, stream_ptr()), 'vs_conv3_band_bn_parts')
+    if k4:
+        _pe(e0, 'vs_conv_k4s2:%s<%s>' % (role, _DT[dtype_code(x)]), flops=2.0 * B * H * W * Cout * (Cin // 4) * 16,
+            nbytes=float(x.numel() * x.element_size() + Cout * (Cin // 4) * 16 * 2 + y.numel() * y.element_size()))
+    else:
+        _pe(e0, 'vs_conv3_band:%s<%s>' % (role, _DT[dtype_code(x)]), flops=2.0 * B * Cin * H * W * Cout * 9,
+            nbytes=float(x.numel() * x.element_size() + w_packed.numel() * 2 + y.numel() * y.element_size()))
+    return y, parts
+
+
+def bn_stats_from_parts_fold(parts, groups, n_per_group, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """(mean, invstd) [groups, C] from the partial-sum table of conv3_band_parts (rows of a call group consecutive) in ONE launch; the running
+    estimates are folded in call order."""
+    require_cuda(parts)
+    rows, C = parts.shape[0], parts.shape[1]
+    assert rows % groups == 0
+    stats = torch.empty((2, groups, C), dtype=torch.float32, device=parts.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_bn_stats_from_parts_fold(parts.data_ptr(), rows // groups, groups, C, int(n_per_group), stats[0].data_ptr(),
+                                                          stats[1].data_ptr(), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+                                                          stream_ptr()), 'vs_bn_stats_from_parts_fold')
+    _pe(e0, 'vs_bn_stats_from_sums', nbytes=float(parts.numel() * 4))
+    return stats[0], stats[1]
 
 
 def bn_stats_from_sums_fold(sums, n_per_group, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, reset=True):

@@ -822,14 +822,70 @@ def test_conv3_band_leaves_batchnorm_sums_of_its_stored_output(dtype, geom, grou
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom,groups', [((6, 64, 32, 32, 40), 2), ((12, 128, 8, 8, 64), 3), ((4, 64, 64, 64, 32), 1), ((9, 64, 16, 16, 96), 9),
+                                         ((200, 16, 16, 16, 72), 2)])
+def test_conv3_band_partial_sum_table_gives_the_batchnorm_statistics(dtype, geom, groups):
+    """vs_conv3_band_bn_parts (round 4, the default route of conv -> BatchNorm on row bands): every workgroup writes the (sum, sum of squares)
+    of its 32 channels x 256 stored values to its own table row, no atomics; the table's column sums are the sums of the stored tensor, the
+    output equals the plain kernel's, vs_bn_stats_from_parts_fold == vs_bn_stats on the stored tensor (mean / invstd per call group, running
+    estimates folded in call order), launch-to-launch bit-reproducible."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, Cin, H, W, Cout = geom
+    x = _rand((B, Cin, H, W), 81).to(dtype).cuda()
+    w = _rand((Cout, Cin, 3, 3), 82, 0.3)
+    bias = _rand((Cout,), 83).cuda()
+    assert ops.band_bn_mode() == 'parts' and ops.conv_band_bn_supported(B, Cin, H, W, Cout, groups, dtype)
+    wp = ops.conv3_img16_pack_weight(w.cuda(), dtype, False)
+    y, parts = ops.conv3_band_parts(x, wp, bias, Cout, dtype)
+    y2, parts2 = ops.conv3_band_parts(x, wp, bias, Cout, dtype)
+    assert torch.equal(y, ops.conv3_band(x, wp, bias, Cout, dtype)) and torch.equal(parts, parts2)
+    rows = parts.shape[0]
+    assert rows % groups == 0
+    yg = y.double().view(groups, B // groups, Cout, H * W)
+    ref = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], dim=-1)
+    got = parts.double().view(groups, rows // groups, Cout, 2).sum(dim=1)
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    rm, rv = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda')
+    mean, invstd = ops.bn_stats_from_parts_fold(parts, groups, (B // groups) * H * W, rm, rv, 0.1, 1e-5)
+    rm2, rv2 = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda')
+    m2, i2 = ops.bn_stats(y, rm2, rv2, 0.1, 1e-5, groups=groups)
+    assert torch.allclose(mean, m2, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, i2, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_conv_k4s2_planes_partial_sum_table(dtype):
+    """The same table from the k4 s2 p1 gather on parity planes (the DCGAN encoder's conv -> BatchNorm layers, conv.py:119-122)."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, C, H, W, M, groups = 6, 64, 32, 32, 128, 2
+    x = _rand((B, C, H, W), 91).to(dtype).cuda()
+    planes = ops.space_to_depth2(x)
+    w = _rand((M, C, 4, 4), 92, 0.3)
+    bias = _rand((M,), 93).cuda()
+    wp = ops.conv_k4s2_pack_weight(w.cuda(), dtype)
+    y, parts = ops.conv3_band_parts(planes, wp, bias, M, dtype, k4=True)
+    assert torch.equal(y, ops.conv_k4s2_gather(planes, wp, bias, M, dtype))
+    yg = y.double().view(groups, B // groups, M, (H // 2) * (W // 2))
+    ref = torch.stack([yg.sum(dim=(1, 3)), (yg * yg).sum(dim=(1, 3))], dim=-1)
+    got = parts.double().view(groups, parts.shape[0] // groups, M, 2).sum(dim=1)
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    mean, invstd = ops.bn_stats_from_parts_fold(parts, groups, (B // groups) * (H // 2) * (W // 2))
+    m2, i2 = ops.bn_stats(y, None, None, 0.1, 1e-5, groups=groups)
+    assert torch.allclose(mean, m2, rtol=1e-5, atol=1e-6) and torch.allclose(invstd, i2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('geom', [(21, 64, 8, 8, 96), (256, 256, 8, 8, 512)])
 def test_conv_k4s2_gather_on_4x4_planes_matches_fp64(dtype, geom):
     """8 x 8 maps (the DCGAN encoder's c4, conv.py:122): parity planes of 4 x 4 pixels (8-byte rows) and the gather on them (sixteen maps per
-    workgroup of the row-band kernel); the weight gradient of such a layer stays on the column-matrix path."""
+    workgroup of the row-band kernel); since round 4 the weight gradient of such a layer runs on the planes as well
+    (test_conv_k4s2_on_parity_planes_matches_fp64 has the 4 x 4 plane geometries)."""
     from spatiotemporal_variable_separation_amd import ops
     B, C, H, W, M = geom
     x = _rand((B, C, H, W), 311).to(dtype)
-    assert ops.conv_k4s2_gather_supported(x.cuda(), M) and not ops.conv_k4s2_supported(x.cuda(), M)
+    assert ops.conv_k4s2_gather_supported(x.cuda(), M) and ops.conv_k4s2_supported(x.cuda(), M)
     planes = ops.space_to_depth2(x.cuda())
     want = torch.stack([x[:, :, py::2, px::2] for py in (0, 1) for px in (0, 1)], dim=1).reshape(B, 4 * C, H // 2, W // 2)
     assert torch.equal(planes.cpu(), want)
