@@ -246,12 +246,13 @@ int vs_bn_stats_from_sums_fold(double* sums, int groups, int C, int64_t n_per_gr
  * workgroup writes the (sum, sum of squares) of the stored values of its 32 channels to its own row of parts [vs_conv3_band_bn_parts_rows(B, H,
  * W)][Cout][2] (fp32; row = map * bands + band, the rows of a call group are consecutive); k4 != 0: x are the parity planes [B][4 K][H][W] of a
  * k4 s2 p1 convolution (Cin = 4 K, pack of vs_conv_k4s2_pack_weight).  vs_bn_stats_from_parts_fold adds the rows of every call group in a fixed
- * order (fp64) -> mean / invstd [groups][C] and folds the running estimates in call order.  No zero fill, reproducible launch to launch. */
+ * order (fp64) -> mean / invstd [groups][C] and (running_mean != NULL; var_scratch [groups][C] then required) folds the running estimates in call
+ * order with a second small launch.  No zero fill, reproducible launch to launch. */
 int vs_conv3_band_bn_parts_rows(int B, int H, int W);
 int vs_conv3_band_bn_parts(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W, int Cout,
                            float* parts, int k4, void* stream);
 int vs_bn_stats_from_parts_fold(const float* parts, int rows_per_group, int groups, int C, int64_t n_per_group, float* mean, float* invstd,
-                                float* running_mean, float* running_var, float momentum, float eps, void* stream);
+                                float* var_scratch, float* running_mean, float* running_var, float momentum, float eps, void* stream);
 int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout);
 int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int W, int Cout, void* stream);
 int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,

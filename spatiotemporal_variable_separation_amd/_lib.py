@@ -163,7 +163,7 @@ SIGNATURES = {
     'vs_bn_stats_from_sums_fold': (_i32, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32, _vp]),
     'vs_conv3_band_bn_parts_rows': (_i32, [_i32, _i32, _i32]),
     'vs_conv3_band_bn_parts': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
-    'vs_bn_stats_from_parts_fold': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp]),
+    'vs_bn_stats_from_parts_fold': (_i32, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp]),
     'vs_conv3_band': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vs_conv3_wgrad_band_supported': (_i32, [_i32] * 6),
     'vs_conv3_wgrad_band_slabs': (_i32, [_i32] * 5),

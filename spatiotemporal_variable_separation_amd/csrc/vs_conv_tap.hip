@@ -426,55 +426,66 @@ __global__ __launch_bounds__(256) void bn_from_sums_fold_kernel(double* sums, in
     if (rmean) { rmean[c] = (float)rm; rvar[c] = (float)rv; }
 }
 
-// The same from a table of per-workgroup partial sums parts[rows][C][2] (fp32; the rows of call group g are g * rpg .. (g + 1) * rpg - 1): block =
-// 32 channels x 8 row lanes; a lane adds every 8th row of the group in fp64, the 8 lanes of a channel meet in LDS in a fixed order (reproducible),
-// lane 0 finishes the group and carries the running estimates to the next one (call order).
-__global__ __launch_bounds__(256) void bn_from_parts_fold_kernel(const float* __restrict__ parts, int rpg, int G, int C, double n, float eps, float* mean,
-                                                                 float* invstd, float* rmean, float* rvar, float momentum) {
-    __shared__ double red[8][32][2];
-    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
-    double rm = (rmean && c < C) ? (double)rmean[c] : 0.0, rv = (rvar && c < C) ? (double)rvar[c] : 0.0;
-    for (int g = 0; g < G; ++g) {
-        double ts = 0.0, tq = 0.0;
-        if (c < C) {
-            const float* p = parts + ((int64_t)g * rpg * C + c) * 2;
-            for (int r = rl; r < rpg; r += 8) {
-                const float2 v = *reinterpret_cast<const float2*>(p + (int64_t)r * C * 2);
-                ts += (double)v.x;
-                tq += (double)v.y;
-            }
+// The same from a table of per-workgroup partial sums parts[rows][C][2] (fp32; the rows of call group g are g * rpg .. (g + 1) * rpg - 1).  Grid =
+// (channel octets, call groups), block = 8 channels x 32 row lanes: a lane adds every 32nd row of its group in fp64, the 32 lanes of a channel
+// meet in LDS in a fixed order (reproducible launch to launch); mean / invstd / the unbiased variance per (group, channel).  The running
+// estimates are folded in call order by bn_running_fold_kernel behind it (a first form with ONE block per 32 channels that walked the groups
+// itself left the chip to 2-16 workgroups: 15 us per layer, TaxiBJ 8.1 -> 8.7 ms).
+__global__ __launch_bounds__(256) void bn_from_parts_kernel(const float* __restrict__ parts, int rpg, int C, double n, float eps, float* __restrict__ mean,
+                                                            float* __restrict__ invstd, float* __restrict__ ubvar) {
+    __shared__ double red[32][8][2];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3, c = blockIdx.x * 8 + cl, g = blockIdx.y;
+    double ts = 0.0, tq = 0.0;
+    if (c < C) {
+        const float* p = parts + ((int64_t)g * rpg * C + c) * 2;
+        for (int r = rl; r < rpg; r += 32) {
+            const float2 v = *reinterpret_cast<const float2*>(p + (int64_t)r * C * 2);
+            ts += (double)v.x;
+            tq += (double)v.y;
         }
-        red[rl][cl][0] = ts;
-        red[rl][cl][1] = tq;
-        __syncthreads();
-        if (rl == 0 && c < C) {
-#pragma unroll
-            for (int k = 1; k < 8; ++k) { ts += red[k][cl][0]; tq += red[k][cl][1]; }
-            const int i = g * C + c;
-            const double mu = ts / n;
-            double ss = tq - ts * mu;
-            if (ss < 0.0) ss = 0.0;
-            const double var = ss / n;
-            mean[i] = (float)mu;
-            invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-            const float ub = (float)(n > 1.0 ? ss / (n - 1.0) : var);
-            rm = (double)(float)((1.0 - momentum) * rm + momentum * (double)(float)mu);
-            rv = (double)(float)((1.0 - momentum) * rv + momentum * (double)ub);
-        }
-        __syncthreads();
     }
-    if (rl == 0 && c < C && rmean) { rmean[c] = (float)rm; rvar[c] = (float)rv; }
+    red[rl][cl][0] = ts;
+    red[rl][cl][1] = tq;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int k = 1; k < 32; ++k) { ts += red[k][cl][0]; tq += red[k][cl][1]; }
+        const int i = g * C + c;
+        const double mu = ts / n;
+        double ss = tq - ts * mu;
+        if (ss < 0.0) ss = 0.0;
+        const double var = ss / n;
+        mean[i] = (float)mu;
+        invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+        if (ubvar) ubvar[i] = (float)(n > 1.0 ? ss / (n - 1.0) : var);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_running_fold_kernel(const float* __restrict__ mean, const float* __restrict__ ubvar, int G, int C, float* rmean,
+                                                              float* rvar, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double rm = rmean[c], rv = rvar[c];
+    for (int g = 0; g < G; ++g) {                       // sequential, in call order; fp32 rounding after every call like the reference
+        rm = (double)(float)((1.0 - momentum) * rm + momentum * (double)mean[g * C + c]);
+        rv = (double)(float)((1.0 - momentum) * rv + momentum * (double)ubvar[g * C + c]);
+    }
+    rmean[c] = (float)rm;
+    rvar[c] = (float)rv;
 }
 
 }  // namespace
 
 extern "C" int vs_bn_stats_from_parts_fold(const float* parts, int rows_per_group, int groups, int C, int64_t n_per_group, float* mean, float* invstd,
-                                           float* running_mean, float* running_var, float momentum, float eps, void* stream) {
+                                           float* var_scratch, float* running_mean, float* running_var, float momentum, float eps, void* stream) {
     VS_CHECK_ARG(parts && mean && invstd && groups >= 1 && rows_per_group >= 1 && C > 0 && n_per_group > 0, "vs_bn_stats_from_parts_fold: bad argument");
     VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "vs_bn_stats_from_parts_fold: running_mean/var must come together");
+    VS_CHECK_ARG(!running_mean || var_scratch, "vs_bn_stats_from_parts_fold: the running update needs var_scratch [groups][C]");
     VS_CHECK_ARG((uintptr_t)parts % 8 == 0, "vs_bn_stats_from_parts_fold: the table must be 8-byte aligned");
-    hipLaunchKernelGGL(bn_from_parts_fold_kernel, dim3((unsigned)vs_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, parts, rows_per_group, groups, C,
-                       (double)n_per_group, eps, mean, invstd, running_mean, running_var, momentum);
+    hipLaunchKernelGGL(bn_from_parts_kernel, dim3((unsigned)vs_cdiv(C, 8), (unsigned)groups), dim3(256), 0, (hipStream_t)stream, parts, rows_per_group, C,
+                       (double)n_per_group, eps, mean, invstd, running_mean ? var_scratch : nullptr);
+    if (running_mean)
+        hipLaunchKernelGGL(bn_running_fold_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, var_scratch, groups, C,
+                           running_mean, running_var, momentum);
     VS_CHECK_LAUNCH("vs_bn_stats_from_parts_fold");
     return VS_OK;
 }

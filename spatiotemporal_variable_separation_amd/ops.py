@@ -1003,11 +1003,11 @@ def bn_stats_from_parts_fold(parts, groups, n_per_group, running_mean=None, runn
     require_cuda(parts)
     rows, C = parts.shape[0], parts.shape[1]
     assert rows % groups == 0
-    stats = torch.empty((2, groups, C), dtype=torch.float32, device=parts.device)
+    stats = torch.empty((3, groups, C), dtype=torch.float32, device=parts.device)
     e0 = _pb()
     check(_lib.load_library().vs_bn_stats_from_parts_fold(parts.data_ptr(), rows // groups, groups, C, int(n_per_group), stats[0].data_ptr(),
-                                                          stats[1].data_ptr(), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
-                                                          stream_ptr()), 'vs_bn_stats_from_parts_fold')
+                                                          stats[1].data_ptr(), stats[2].data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                                          float(momentum), float(eps), stream_ptr()), 'vs_bn_stats_from_parts_fold')
     _pe(e0, 'vs_bn_stats_from_sums', nbytes=float(parts.numel() * 4))
     return stats[0], stats[1]
 
