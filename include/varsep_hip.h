@@ -226,11 +226,12 @@ int vs_conv_k4s2_wgrad_finish(const float* slabs, int nslabs, const float* adden
 /*   vs_conv_k4s2_band           the gather on the planes [B][4 K][H][W] -> y [B][M][H][W] (+ bias), vs_conv3_band's arguments with K in place of
  *                               Cin; K a multiple of 64 (vs_conv_k4s2_skip_form): the kernel form that streams and multiplies only the 2 x 2
  *                               taps a plane sees (the pack has the matching form), otherwise the plain 3 x 3 kernel on a zero-padded pack
- *   vs_conv_k4s2_wgrad_band     slabs [vs_conv3_wgrad_band_slabs(B, 4 K, H, W, M)][9][M][4 K] from the planes and the small map [B][M][H][W]  */
+ *   vs_conv_k4s2_wgrad_band     slabs [vs_conv_k4s2_wgrad_band_slabs(B, K, H, W, M)][9][M][4 K] from the planes and the small map [B][M][H][W]  */
 int vs_conv_k4s2_skip_form(int K);
 int vs_conv_k4s2_band(int compute, const void* planes, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int K, int H, int W, int M,
                       void* stream);
 int vs_conv_k4s2_wgrad_band(int compute, const void* planes, const void* small_map, float* slabs, int B, int K, int H, int W, int M, void* stream);
+int vs_conv_k4s2_wgrad_band_slabs(int B, int K, int H, int W, int M);    /* slabs the call above writes (round 4: not vs_conv3_wgrad_band_slabs' count) */
 /* vs_conv3_band / vs_conv_k4s2_band with the BatchNorm statistics of the output taken in the epilogue (replaces the vs_bn_stats pass behind
  * conv -> BatchNorm, reference conv.py:41-60): (sum, sum of squares) of the STORED values are added to bn_sums [groups][Cout][2] (fp64),
  * group = map / (B / groups).  vs_bn_stats_from_sums_fold turns them into mean / invstd [groups][C], folds the running estimates in call order

@@ -151,6 +151,7 @@ SIGNATURES = {
     'vs_conv_k4s2_skip_form': (_i32, [_i32]),
     'vs_conv_k4s2_band': (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'vs_conv_k4s2_wgrad_band': (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'vs_conv_k4s2_wgrad_band_slabs': (_i32, [_i32, _i32, _i32, _i32, _i32]),
     'vs_conv_thin_supported': (_i32, [_i32] * 9),
     'vs_conv_thin_expand': (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32] + [_i32] * 7 + [_vp]),
     'vs_conv_thin_reduce': (_i32, [_i32, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32] + [_i32] * 7 + [_vp]),

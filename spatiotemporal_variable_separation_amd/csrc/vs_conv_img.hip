@@ -440,7 +440,10 @@ struct WgradPieces {
 template <int W>
 constexpr int wgrad_cpitch() { return W == 4 ? 388 : (W == 8 ? 4 * 10 : 256 / W + 2) * W + 8; }
 
-template <int CT, int W, int MW, int K4 = 0>
+// CTW (K4 form only) = 32-channel tiles of ONE plane a workgroup walks per item, one after the other against the SAME staged dz tile: the dz
+// tile [32 MW][256 px] is what every channel tile of a layer re-reads (L2 -> LDS: 1.07 GB per launch on the Moving-MNIST 8 x 8 <-> 4 x 4 layers,
+// 9 TB/s -- the kernel was L2-bound), and with four accumulators per tile instead of nine two tiles fit the register file.
+template <int CT, int W, int MW, int K4 = 0, int CTW = 1>
 __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, float* __restrict__ slabs, int B, int Cin, int H, int Cout, int ctiles, int ksplit) {
     // W >= 16: an item is a band of R = 256 / W rows of one map; W = 8: FOUR whole 8 x 8 maps (rows of one 16-byte piece, no column neighbours);
     // W = 4: SIXTEEN whole 4 x 4 maps (the 512-channel layers of the VGG encoders / decoders, the parity planes of 8 x 8 maps): a 16-byte
@@ -459,25 +462,29 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
     int id = blockIdx.x;
     const int ks = id % ksplit;
     id /= ksplit;
-    const int ct = id % ctiles, mt = id / ctiles;
+    const int ct0 = (id % ctiles) * CTW, mt = id / ctiles;                          // ctiles = groups of CTW channel tiles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bands = H / R;
     const int64_t items = IPB == 1 ? (int64_t)B * bands : (int64_t)((B + IPB - 1) / IPB);
 
-    f32x16 acc[9];
+    static_assert(CTW == 1 || K4, "several channel tiles per workgroup: K4 form only (four accumulators per tile)");
+    constexpr int NT = K4 ? 4 : 9;                                               // accumulators per channel tile: the taps a plane sees / all nine
+    f32x16 acc[CTW][NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int s2 = 0; s2 < CTW; ++s2)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[s2][t][v] = 0.f;
 
     u32x4 xr[NXT], zr[4 * MW];
     unsigned xe[NXT];                                                            // neighbour pixels: low half = the one before the piece, high half = after
-    auto load_item = [&](int64_t it) {
+    auto load_x = [&](int64_t it, int sub) {
+        const int ct = ct0 + sub;
         const int bg = IPB == 1 ? (int)(it / bands) : (int)it * IPB, band = IPB == 1 ? (int)(it % bands) : 0;       // first map of the item
         const int piece = bg / pieces.maps_per_piece, b = bg - piece * pieces.maps_per_piece;                             // (an item never straddles pieces)
         const unsigned short* X = pieces.x[piece];
-        const unsigned short* DZ = pieces.dz[piece];
         if constexpr (W == 4) {
 #pragma unroll
             for (int r = 0; r < NXT; ++r) {
@@ -500,6 +507,11 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
             xr[r] = *reinterpret_cast<const u32x4*>(src);
             xe[r] = (unsigned)*pb | ((unsigned)*pa << 16);
         }
+    };
+    auto load_z = [&](int64_t it) {
+        const int bg = IPB == 1 ? (int)(it / bands) : (int)it * IPB, band = IPB == 1 ? (int)(it % bands) : 0;
+        const int piece = bg / pieces.maps_per_piece, b = bg - piece * pieces.maps_per_piece;
+        const unsigned short* DZ = pieces.dz[piece];
 #pragma unroll
         for (int r = 0; r < 4 * MW; ++r) {
             const int u = r * 256 + tid, ml = u >> 5, pc = u & 31, m = mt * (32 * MW) + ml;
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
             zr[r] = *reinterpret_cast<const u32x4*>(src);
         }
     };
-    auto store_item = [&]() {
+    auto store_x = [&]() {
         if constexpr (W == 4) {
 #pragma unroll
             for (int r = 0; r < NXT; ++r) {
@@ -551,6 +563,8 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
                 *reinterpret_cast<u32x4*>(dst + 64 * CPITCH) = rgt;                    // copy 2: x[col + 1]
             }
         }
+    };
+    auto store_z = [&]() {
 #pragma unroll
         for (int r = 0; r < 4 * MW; ++r) {
             const int u = r * 256 + tid, ml = u >> 5, pc = u & 31;
@@ -560,28 +574,31 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
 
     const int rl = lane & 31, h = lane >> 5;
     const int msub = wave % MW, kpart = wave / MW;
-    // K4: first tap row / column this plane sees (odd planes: {0, 1}, even planes: {1, 2}); wave-uniform
-    const int plane = K4 ? (ct * 32) / (Cin >> 2) : 0;
+    // K4: first tap row / column this plane sees (odd planes: {0, 1}, even planes: {1, 2}); wave-uniform (the CTW tiles lie in one plane)
+    const int plane = K4 ? (ct0 * 32) / (Cin >> 2) : 0;
     const int ky_lo = K4 ? ((plane >> 1) ? 0 : 1) : 0, kx_lo = K4 ? ((plane & 1) ? 0 : 1) : 0;
     if constexpr (W == 4) {                                                      // the zero rows (and the pad) of the x image: written once
         for (int i = tid; i < 3 * 32 * CPITCH / 2; i += 256) reinterpret_cast<unsigned*>(xs)[i] = 0u;
     }
     int64_t it = ks;
-    if (it < items) load_item(it);
+    if (it < items) { load_z(it); load_x(it, 0); }
     for (; it < items; it += ksplit) {
-        __syncthreads();                                                         // the previous band's fragments have been read
-        store_item();
-        __syncthreads();
-        if (it + ksplit < items) load_item(it + ksplit);                         // travels during the MFMA phase
+#pragma unroll
+        for (int sub = 0; sub < CTW; ++sub) {
+            __syncthreads();                                                     // the previous stage's fragments have been read
+            if (sub == 0) store_z();                                             // (the dz tile stays for all CTW channel tiles of the item)
+            store_x();
+            __syncthreads();
+            // the next stage's global loads travel during this MFMA phase
+            if (sub + 1 < CTW) load_x(it, sub + 1);
+            else if (it + ksplit < items) { load_z(it + ksplit); load_x(it + ksplit, 0); }
 #pragma unroll 4
-        for (int tt = 0; tt < KSTEPS; ++tt) {
-            const int t = kpart * KSTEPS + tt, p0 = t * 16, row = (p0 / (R * W)) * RPI + (p0 % (R * W)) / W, x0 = p0 % W;
-            const u32x4 af = *reinterpret_cast<const u32x4*>(zs + (msub * 32 + rl) * ZPITCH + p0 + 8 * h);
+            for (int tt = 0; tt < KSTEPS; ++tt) {
+                const int t = kpart * KSTEPS + tt, p0 = t * 16, row = (p0 / (R * W)) * RPI + (p0 % (R * W)) / W, x0 = p0 % W;
+                const u32x4 af = *reinterpret_cast<const u32x4*>(zs + (msub * 32 + rl) * ZPITCH + p0 + 8 * h);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    if (K4 && ((unsigned)(ky - ky_lo) > 1u || (unsigned)(kx - kx_lo) > 1u)) continue;      // not a tap of this plane
+                for (int ti = 0; ti < NT; ++ti) {
+                    const int ky = K4 ? ky_lo + (ti >> 1) : ti / 3, kx = K4 ? kx_lo + (ti & 1) : ti % 3;
                     u32x4 bf;
                     if constexpr (W == 4) {
                         const unsigned short* src = xs + (kx * 32 + rl) * CPITCH + (row + ky) * W + 8 * h;
@@ -590,8 +607,9 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
                     } else {
                         bf = *reinterpret_cast<const u32x4*>(xs + (kx * 32 + rl) * CPITCH + (row + ky) * W + x0 + 8 * h);
                     }
-                    acc[ky * 3 + kx] = mfma16_32<CT>(af, bf, acc[ky * 3 + kx]);
+                    acc[sub][ti] = mfma16_32<CT>(af, bf, acc[sub][ti]);
                 }
+            }
         }
     }
 
@@ -599,14 +617,17 @@ __global__ __launch_bounds__(256) void wgrad3_band_kernel(WgradPieces pieces, fl
     // runs).  In the weight's own [m][c][tap] order a wave store is 64 words 36 bytes apart, every one a sector of its own: the PMC write
     // counter showed 415-545 MB per launch for 37 MB of slabs; vs_conv3_wgrad_band_finish transposes once while it adds the slabs.
     float* out = slabs + ((int64_t)ks * KW + kpart) * ((int64_t)Cout * Cin * 9);
-    const int c = ct * 32 + rl;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        if (K4 && ((unsigned)(t / 3 - ky_lo) > 1u || (unsigned)(t % 3 - kx_lo) > 1u)) continue;
+    for (int sub = 0; sub < CTW; ++sub) {
+        const int c = (ct0 + sub) * 32 + rl;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int m = mt * (32 * MW) + msub * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-            if (m < Cout && c < Cin) out[((int64_t)t * Cout + m) * Cin + c] = acc[t][v];
+        for (int ti = 0; ti < NT; ++ti) {
+            const int t = K4 ? (ky_lo + (ti >> 1)) * 3 + kx_lo + (ti & 1) : ti;     // slab position [tap of the 3 x 3 form][m][c]
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = mt * (32 * MW) + msub * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m < Cout && c < Cin) out[((int64_t)t * Cout + m) * Cin + c] = acc[sub][ti][v];
+            }
         }
     }
 }
@@ -989,9 +1010,9 @@ extern "C" int vs_conv3_wgrad_band_supported(int compute, int B, int Cin, int H,
 
 static int wgrad_band_mw(int Cout) { return Cout > 64 ? 4 : (Cout > 32 ? 2 : 1); }      // 32-row sub-tiles per workgroup
 
-static int wgrad_band_ksplit(int B, int Cin, int H, int W, int Cout) {
+static int wgrad_band_ksplit(int B, int Cin, int H, int W, int Cout, int ctw = 1) {
     const int mw = wgrad_band_mw(Cout);
-    const int64_t tiles = vs_cdiv(Cout, 32 * mw) * vs_cdiv(Cin, 32), items = W == 8 ? vs_cdiv(B, 4) : (W == 4 ? vs_cdiv(B, 16) : (int64_t)B * (H / (256 / W)));
+    const int64_t tiles = vs_cdiv(Cout, 32 * mw) * vs_cdiv(Cin, 32 * ctw), items = W == 8 ? vs_cdiv(B, 4) : (W == 4 ? vs_cdiv(B, 16) : (int64_t)B * (H / (256 / W)));
     // ONE round of workgroups (a workgroup's LDS fills a CU): every share of the bands costs a slab of the weight's size, written and read
     // again by the finish pass -- with two rounds (512) the slabs of a TaxiBJ step were 3.9 GB of traffic: 9.80 -> 9.37 ms with 256; 128, 192
     // and 384 are slower (idle CUs / a partial second round)
@@ -1007,18 +1028,22 @@ extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout)
     return (4 / wgrad_band_mw(Cout)) * wgrad_band_ksplit(B, Cin, H, W, Cout);
 }
 
+// K4 form: two 32-channel tiles of a plane per workgroup against one staged dz tile (planes hold K >= 64 channels, a multiple of 64)
+constexpr int WGRAD_K4_CTW = 2;
+
 template <int W, int MW, int K4 = 0>
 static void launch_wgrad_band(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
+    constexpr int CTW = K4 ? WGRAD_K4_CTW : 1;
     const size_t lds = (size_t)(3 * 32 * wgrad_cpitch<W>() + 32 * MW * 264) * 2;
-    auto kb = wgrad3_band_kernel<VS_BF16, W, MW, K4>;
-    auto kh = wgrad3_band_kernel<VS_F16, W, MW, K4>;
+    auto kb = wgrad3_band_kernel<VS_BF16, W, MW, K4, CTW>;
+    auto kh = wgrad3_band_kernel<VS_F16, W, MW, K4, CTW>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)kh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int mtiles = (int)vs_cdiv(Cout, 32 * MW), ctiles = (int)vs_cdiv(Cin, 32);
+    const int mtiles = (int)vs_cdiv(Cout, 32 * MW), ctiles = (int)vs_cdiv(Cin, 32 * CTW);
     const dim3 grid((unsigned)((int64_t)mtiles * ctiles * ksplit));
     if (compute == VS_BF16)
         hipLaunchKernelGGL(kb, grid, dim3(256), lds, stream, pieces, slabs, B, Cin, H, Cout, ctiles, ksplit);
@@ -1036,7 +1061,7 @@ static void launch_wgrad_band_w(int compute, const WgradPieces& pieces, float* s
 
 template <int K4 = 0>
 static int wgrad_band_go(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int W, int Cout, hipStream_t stream) {
-    const int ks = wgrad_band_ksplit(B, Cin, H, W, Cout);
+    const int ks = wgrad_band_ksplit(B, Cin, H, W, Cout, K4 ? WGRAD_K4_CTW : 1);
     if (W == 64) launch_wgrad_band_w<64, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     else if (W == 32) launch_wgrad_band_w<32, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     else if (W == 16) launch_wgrad_band_w<16, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
@@ -1084,6 +1109,11 @@ extern "C" int vs_conv_k4s2_band_bn(int compute, const void* planes, const void*
 extern "C" int vs_conv_k4s2_band(int compute, const void* planes, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int K, int H, int W,
                                  int M, void* stream) {
     return vs_conv_k4s2_band_bn(compute, planes, w_packed, bias, y, y_dtype, B, K, H, W, M, nullptr, 1, stream);
+}
+
+// slabs vs_conv_k4s2_wgrad_band writes (the skip form shares the batch among fewer, heavier workgroups than vs_conv3_wgrad_band on the same planes)
+extern "C" int vs_conv_k4s2_wgrad_band_slabs(int B, int K, int H, int W, int M) {
+    return (4 / wgrad_band_mw(M)) * wgrad_band_ksplit(B, 4 * K, H, W, M, vs_conv_k4s2_skip_form(K) ? WGRAD_K4_CTW : 1);
 }
 
 extern "C" int vs_conv_k4s2_wgrad_band(int compute, const void* planes, const void* small, float* slabs, int B, int K, int H, int W, int M, void* stream) {

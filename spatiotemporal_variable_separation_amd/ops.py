@@ -435,12 +435,16 @@ def _conv_workspace(x_dtype_code, B, Cin, H, W, Cout, k, stride, pad, device):
 
 
 # ---- convolutions with 1..8 channels on the image side (csrc/vs_conv_thin.hip): dispatched from conv_fwd / conv_dgrad / conv_wgrad ----------
-def _thin_plan(op, code, B, Cin, H, W, Cout, OH, OW, k, stride, pad, transposed, wgrad_max_m=2):
+def _thin_plan(op, code, B, Cin, H, W, Cout, OH, OW, k, stride, pad, transposed, wgrad_max_m=None):
     """Whether this convolution call is one of the thin forms; returns (kind, C, Hb, Wb, M, sc, sm, flip) -- the many-channel map's channels and
     size, the thin channel count and how element (c, m, t) of the kernel's weight view is found in the weight tensor -- or None.
-    VS_CONV_THIN=0: never.  The weight gradient takes its thin kernel only up to `wgrad_max_m` thin channels (measured: with 4 / 5 / 8 -- the first
-    encoder layers -- the column-matrix GEMM is faster, 57-72 us against 78-129 us: the VALU form re-reads the map per pair of thin channels)."""
+    VS_CONV_THIN=0: never.  The weight gradient takes its thin kernel up to `wgrad_max_m` thin channels (VS_CONV_THIN_WGRAD_MAX_M, default 8 since
+    round 4: no convolution of the BASELINE steps builds a column matrix any more.  With 4 / 5 / 8 thin channels -- the first encoder layers --
+    the column-matrix GEMM was the faster form, 57-72 us against 78-129 us: the VALU form re-reads the map per pair of thin channels; 2
+    restores that choice)."""
     import os
+    if wgrad_max_m is None:
+        wgrad_max_m = int(os.environ.get('VS_CONV_THIN_WGRAD_MAX_M', '8'))
     if os.environ.get('VS_CONV_THIN') == '0' or code == F32 or pad != 1 or (k, stride) not in ((3, 1), (4, 2)):
         return None
     k2 = k * k
@@ -798,7 +802,7 @@ def conv_k4s2_wgrad(small, planes, w_shape, into=None, out=None):
     lib = _lib.load_library()
     dw = into if into is not None else (out if out is not None else torch.empty(tuple(w_shape), dtype=torch.float32, device=small.device))
     assert dw.dtype == torch.float32 and dw.is_contiguous() and tuple(dw.shape) == tuple(w_shape)
-    nslabs = lib.vs_conv3_wgrad_band_slabs(B, 4 * K, H, W, M)
+    nslabs = lib.vs_conv_k4s2_wgrad_band_slabs(B, K, H, W, M)
     n3 = M * 4 * K * 9
     slabs = torch.empty((nslabs, n3), dtype=torch.float32, device=small.device)
     e0 = _pb()
@@ -959,12 +963,14 @@ def bn_sums_buffer(key, groups, C, device):
 
 
 def band_bn_mode():
-    """How the row-band kernels leave the BatchNorm statistics of their output (VS_BAND_BN_SUMS): 'parts' (default since round 4: per-workgroup
-    partial sums in a table + one fold launch, no atomics), '1' (fp64 atomics: round 3, measured SLOWER than a statistics pass -- a workgroup
-    owns 32 channels x 256 pixels, so a layer issues millions of atomics onto a few thousand addresses: TaxiBJ 8.89 -> 10.7 ms), '0' (a
-    statistics pass over the stored output)."""
+    """How the row-band kernels leave the BatchNorm statistics of their output (VS_BAND_BN_SUMS): '0' (default: a statistics pass over the
+    stored output), 'parts' (round 4: per-workgroup partial sums in a table + a fold launch, no atomics, reproducible), '1' (round 3: fp64
+    atomics).  Both epilogue forms are MEASURED SLOWER than the pass they replace and stay opt-in: the pass reads the 16-bit tensor once at
+    HBM rate (11-80 us per layer), while the epilogue reduction (32 lanes x 16 channels x 2 sums per wave through cross-lane moves, behind the
+    x shift of the result) lengthens every convolution launch -- same-box A/B of the replayed steps: TaxiBJ 8.13 (pass) / 8.33 (table) /
+    10.7 ms (atomics), SST 20.22 / 20.67 / 22.9, Moving-MNIST 7.07 / 7.09."""
     import os
-    return os.environ.get('VS_BAND_BN_SUMS', 'parts')
+    return os.environ.get('VS_BAND_BN_SUMS', '0')
 
 
 def conv_band_bn_supported(B, Cin, H, W, Cout, groups, dtype):

@@ -824,12 +824,13 @@ def test_conv3_band_leaves_batchnorm_sums_of_its_stored_output(dtype, geom, grou
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('geom,groups', [((6, 64, 32, 32, 40), 2), ((12, 128, 8, 8, 64), 3), ((4, 64, 64, 64, 32), 1), ((9, 64, 16, 16, 96), 9),
                                          ((200, 16, 16, 16, 72), 2)])
-def test_conv3_band_partial_sum_table_gives_the_batchnorm_statistics(dtype, geom, groups):
-    """vs_conv3_band_bn_parts (round 4, the default route of conv -> BatchNorm on row bands): every workgroup writes the (sum, sum of squares)
+def test_conv3_band_partial_sum_table_gives_the_batchnorm_statistics(dtype, geom, groups, monkeypatch):
+    """vs_conv3_band_bn_parts (round 4; opt-in, VS_BAND_BN_SUMS=parts: measured slower than the statistics pass it replaces): every workgroup writes the (sum, sum of squares)
     of its 32 channels x 256 stored values to its own table row, no atomics; the table's column sums are the sums of the stored tensor, the
     output equals the plain kernel's, vs_bn_stats_from_parts_fold == vs_bn_stats on the stored tensor (mean / invstd per call group, running
     estimates folded in call order), launch-to-launch bit-reproducible."""
     from spatiotemporal_variable_separation_amd import ops
+    monkeypatch.setenv('VS_BAND_BN_SUMS', 'parts')
     B, Cin, H, W, Cout = geom
     x = _rand((B, Cin, H, W), 81).to(dtype).cuda()
     w = _rand((Cout, Cin, 3, 3), 82, 0.3)
