@@ -256,6 +256,26 @@ int vs_bn_stats_from_parts_fold(const float* parts, int rows_per_group, int grou
                                 float* var_scratch, float* running_mean, float* running_var, float momentum, float eps, void* stream);
 int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout);
 int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, float* slabs, int B, int Cin, int H, int W, int Cout, void* stream);
+/* Round 4: a layer of the ConvResnet integrator (reference resnet.py:53-70: Conv2d k3 s1 p1 -> BatchNorm2d (training mode) [-> LeakyReLU]; 78 block
+ * calls each way per SST step) in ONE launch instead of vs_conv3_img16 + vs_bn_train_fwd_small_slabs: the other input-channel splits' partial sums
+ * and the other maps' BatchNorm statistics are exchanged inside the launch through epoch-tagged 8-byte granules (the MLP integrator's mechanism),
+ * so every workgroup of the launch must be resident (vs_conv3_img16_bn_supported checks: <= 256 workgroups, splits 1 / 2 / 8).
+ *   ws          vs_conv3_img16_bn_workspace_bytes() bytes, zero-filled ONCE by the caller and kept (per stream); word 0 = epoch base, word 1 =
+ *               sticky error flag (a partner did not answer: results invalid), the rest exchange areas
+ *   call_idx    1 .. 65535, distinct for every launch on this workspace since the last vs_exchange_epoch_advance (base += 65536; recordable)
+ *   _fwd        z [B][Cout][256] (16-bit pre-BatchNorm output = round16(conv + bias), bit-identical to the two-launch path), y = act(BN(z)) in
+ *               y_dtype, mean / invstd [Cout], running estimates updated; skip != NULL: xnew = skip + y (fp32) and its 16-bit copy xnew16
+ *   _bwd        dz = BatchNorm + activation backward of this layer applied to dy = input gradient of the FOLLOWING layer's convolution of dz_next
+ *               (w_packed: that layer's weight, flip = 1; Cin = its output channels); d gamma / d beta written or ADDED (accumulate) */
+size_t vs_conv3_img16_bn_workspace_bytes(void);
+int vs_conv3_img16_bn_supported(int compute, int B, int Cin, int Cout);
+int vs_exchange_epoch_advance(void* ws, void* stream);
+int vs_conv3_img16_bn_fwd(int compute, const void* x, const void* w_packed, void* ws, unsigned call_idx, const float* bias, const float* gamma,
+                          const float* beta, int act, float* running_mean, float* running_var, float momentum, float eps, void* z, void* y, int y_dtype,
+                          float* mean, float* invstd, const float* skip, float* xnew, void* xnew16, int B, int Cin, int Cout, void* stream);
+int vs_conv3_img16_bn_bwd(int compute, const void* dz_next, const void* w_packed, void* ws, unsigned call_idx, const void* z, const float* mean,
+                          const float* invstd, const float* gamma, const float* beta, int act, void* dz, float* dgamma, float* dbeta, int accumulate,
+                          int B, int Cin, int Cout, void* stream);
 int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,
                 void* stream);
 int vs_bn_stats_from_sums(const double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* var_scratch,

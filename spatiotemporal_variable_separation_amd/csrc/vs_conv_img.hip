@@ -31,6 +31,18 @@ __device__ __forceinline__ float dpp_row_shl1(float v) {      // lane i <- lane 
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
 }
 
+// derivative of the activation from its PRE-activation input (as vs_norm.hip's BatchNorm backward kernels take it)
+__device__ __forceinline__ float img_act_grad(float z, int act) {
+    switch (act) {
+        case VS_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case VS_ACT_LEAKY: return z > 0.f ? 1.f : 0.2f;
+        case VS_ACT_SIGMOID: { const float sg = 1.f / (1.f + expf(-z)); return sg * (1.f - sg); }
+        case VS_ACT_TANH: { const float t = tanhf(z); return 1.f - t * t; }
+        case VS_ACT_ELU: return z > 0.f ? 1.f : expf(z);
+        default: return 1.f;
+    }
+}
+
 __device__ __forceinline__ float lane_gather(int byte_index, float v) {       // value of lane byte_index / 4
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_index, __builtin_bit_cast(int, v)));
 }
@@ -75,14 +87,12 @@ __device__ __forceinline__ void img_stage(unsigned short* xs, const unsigned sho
 
 // AHEAD = 12, MINB = 1: the deep prefetch, one workgroup per CU.  AHEAD = 4, MINB = 2: two workgroups per CU (splits of <= 128 channels =
 // 72 KiB of LDS each) that cover each other's staging and epilogue -- taken when that doubles the number of resident workgroups.
-template <int CT, int AHEAD, int MINB>
-__global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, float* __restrict__ slabs,
-                                                          int B, int Cin, int Cout, int cs, int splits, int mtiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [cs][18][16]
-    int id = blockIdx.x;
-    const int split = id % splits;
-    id /= splits;
-    const int mt = id % mtiles, b = id / mtiles;
+// The tile of one workgroup -- image b, output channels 32 mt .., input channels c0 .. c0 + cs - 1 -- up to the x shift on the result:
+// o[j][v] = partial sum (over this split's channels) of output channel 32 mt + (v & 3) + 8 (v >> 2) + 4 (lane >> 5) at pixel
+// (4 wave + 2 j) * 16 + (lane & 31).  The two kernels below differ in what they do with it.
+template <int CT, int AHEAD>
+__device__ __forceinline__ void img16_tile(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, int Cin, int cs, int mt, int b, int split,
+                                           unsigned short* xs, float (&o)[2][16]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c0 = split * cs;
@@ -146,7 +156,29 @@ __global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned s
     // they must land before it re-uses those registers (for the store addresses below)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- out[y][x] = G_1[x] + G_0[x - 1] + G_2[x + 1], fp32 slab of this split ------------------------------------------
+    // ---- out[y][x] = G_1[x] + G_0[x - 1] + G_2[x + 1] ------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[j][v] = acc[1][j][v] + dpp_row_shr1(acc[0][j][v]) + dpp_row_shl1(acc[2][j][v]);
+}
+
+// AHEAD = 12, MINB = 1: the deep prefetch, one workgroup per CU.  AHEAD = 4, MINB = 2: two workgroups per CU (splits of <= 128 channels =
+// 72 KiB of LDS each) that cover each other's staging and epilogue -- taken when that doubles the number of resident workgroups.
+template <int CT, int AHEAD, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, float* __restrict__ slabs,
+                                                          int B, int Cin, int Cout, int cs, int splits, int mtiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [cs][18][16]
+    int id = blockIdx.x;
+    const int split = id % splits;
+    id /= splits;
+    const int mt = id % mtiles, b = id / mtiles;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float o[2][16];
+    img16_tile<CT, AHEAD>(X, Wp, Cin, cs, mt, b, split, xs, o);
+
+    // ---- fp32 slab of this split ----------------------------------------------------------------------------------------------------
     float* out = slabs + (((int64_t)split * B + b) * Cout) * 256;
     const int mrow = mt * 32 + 4 * (lane >> 5);
 #pragma unroll
@@ -154,12 +186,316 @@ __global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned s
         const int pix = (4 * wave + 2 * j) * 16 + (lane & 31);
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const float o = acc[1][j][v] + dpp_row_shr1(acc[0][j][v]) + dpp_row_shl1(acc[2][j][v]);
             const int m = mrow + (v & 3) + 8 * (v >> 2);
-            if (m < Cout) out[(int64_t)m * 256 + pix] = o;
+            if (m < Cout) out[(int64_t)m * 256 + pix] = o[j][v];
         }
     }
 }
+
+// ---- convolution + BatchNorm of one residual-block layer in ONE launch ---------------------------------------------------------------
+// The ConvResnet integrator (resnet.py:53-88) is 78 block calls each way per SST step, every layer of a block a convolution launch
+// (conv3_img16_kernel, split partial sums to fp32 slabs) and a BatchNorm launch (slab sum + statistics over the 8 maps + affine): 936
+// launches of 6-14 us that sit at the kernel-boundary floor.  Here the BatchNorm of a layer rides in the epilogue of its convolution; what
+// the second launch got from the kernel boundary -- the other splits' partial sums, the other maps' statistics -- is exchanged INSIDE the
+// launch through epoch-tagged 8-byte granules {epoch, fp32} (the mechanism of the MLP integrator, vs_rollout.hip: relaxed agent-scope
+// 8-byte stores / loads, the data is the flag, no fence, bounded spins):
+//   1. the tile's partial sums go to LDS as [32 channels][256 pixels]; thread t then works on PIXEL t;
+//   2. reduce-scatter over the S input-channel splits of (image, channel tile): split s keeps the channels 32 s / S .. and receives their
+//      partial sums from the other S - 1 workgroups (area A: [workgroup][source split][32 / S channels][256 px]), added in split order --
+//      the slab order of the two-launch path, so z = round16(sum + bias) is bit-identical to it;
+//   3. per-channel statistics of the workgroup's image (sum, centred sum of squares: two LDS rounds), all-gather over the B images of
+//      (channel tile, split) through area B ([channel][image][2]), combined with the parallel-variance formula in fp64 and image order;
+//   4. affine + activation (+ the block's skip), stores of z, y (and x + r, its 16-bit copy), running estimates by the image-0 workgroups.
+// MODE 1 is the backward layer: the convolution is the input-gradient of the FOLLOWING layer (flipped pack), the epilogue the BatchNorm
+// backward of this one -- dy' = dy act'(.), (sum dy', sum dy' xhat) over all images by the same all-gather, dz = gamma invstd (dy' - k1 - xhat k2).
+// Every workgroup of the launch must be resident (grid <= one per CU: the launcher checks); a partner that does not answer within
+// spin_limit polls raises the sticky error word instead of hanging.  epoch = *epoch_base + call_idx: the base is a device word advanced
+// once per training step by vs_exchange_epoch_advance (recordable), call_idx the launch's number within the step (a launch argument).
+typedef unsigned long long xg64;
+
+struct ImgBnArgs {
+    const unsigned short* X;
+    const u32x4* Wp;
+    int B, Cin, Cout, cs, splits, mtiles;
+    xg64* xa;
+    xg64* xb;
+    const unsigned* epoch_base;
+    unsigned call_idx, spin_limit;
+    unsigned* xerr;
+    const float* bias;
+    const float* gamma;
+    const float* beta;
+    int act;
+    float eps, momentum;
+    float* rmean;
+    float* rvar;
+    float* mean;
+    float* invstd;
+    unsigned short* z;          // MODE 0: out, MODE 1: in
+    void* y;
+    int yd;
+    const float* skip;
+    float* xnew;
+    unsigned short* xnew16;
+    unsigned short* dz;         // MODE 1: out
+    float* dgamma;
+    float* dbeta;
+    int accumulate;
+};
+
+__device__ __forceinline__ xg64 xg_load(const xg64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xg_store(xg64* p, xg64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ xg64 xg_pack(unsigned epoch, float v) { return ((xg64)epoch << 32) | (xg64)__float_as_uint(v); }
+__device__ __forceinline__ float xg_val(xg64 g) { return __uint_as_float((unsigned)g); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 64 lanes of a wave, in every lane: four DPP steps inside the 16-lane rows, two cross-row exchanges
+__device__ __forceinline__ float wave_sum64(float v) {
+    v += dpp_get<0xB1>(v);          // quad_perm [1, 0, 3, 2]
+    v += dpp_get<0x4E>(v);          // quad_perm [2, 3, 0, 1]
+    v += dpp_get<0x141>(v);         // row_half_mirror
+    v += dpp_get<0x140>(v);         // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int CT, int S, int MODE>
+__global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
+    constexpr int N = 32 / S;                                                    // channels this workgroup owns after the reduce-scatter
+    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [cs][18][16], then the partial-sum tile + reduction rows
+    int id = blockIdx.x;
+    const int me = id;
+    const int split = id % S;
+    id /= S;
+    const int mt = id % p.mtiles, b = id / p.mtiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned epoch = *p.epoch_base + p.call_idx;
+
+    float o[2][16];
+    img16_tile<CT, 12>(p.X, p.Wp, p.Cin, p.cs, mt, b, split, xs, o);
+
+    // ---- 1. partial sums -> LDS [32 channels][256 pixels] -------------------------------------------------------------------------------
+    float* P = reinterpret_cast<float*>(xs);
+    float* redA = P + 32 * 256;                                                  // [4 waves][32]
+    float* redB = redA + 128;
+    float* st = redB + 128;                                                      // [32][2]
+    __syncthreads();                                                             // everybody has read its last fragments of the image
+    {
+        const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) P[((v & 3) + 8 * (v >> 2) + 4 * h) * 256 + wave * 64 + j * 32 + l31] = o[j][v];
+    }
+    __syncthreads();
+
+    // ---- 2. reduce-scatter over the splits ----------------------------------------------------------------------------------------------
+    float R[N];
+    bool timed_out = false;
+    if constexpr (S == 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) R[i] = P[i * 256 + tid];
+    } else {
+        const int wg0 = me - split;                                              // workgroup of split 0 of this (image, channel tile)
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc) {
+            const int owner = cc / N;
+            if (owner != split) xg_store(p.xa + (((int64_t)(wg0 + owner) * S + split) * N + (cc % N)) * 256 + tid, xg_pack(epoch, P[cc * 256 + tid]));
+        }
+        xg64 got[(S - 1) * N];
+        const xg64* mine = p.xa + ((int64_t)me * S) * N * 256 + tid;
+#pragma unroll
+        for (int k = 0; k < S - 1; ++k) {
+            const int src = k < split ? k : k + 1;
+#pragma unroll
+            for (int i = 0; i < N; ++i) got[k * N + i] = xg_load(mine + ((int64_t)src * N + i) * 256);
+        }
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < S - 1; ++k) {
+                const int src = k < split ? k : k + 1;
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+                    if ((unsigned)(got[k * N + i] >> 32) != epoch) {
+                        got[k * N + i] = xg_load(mine + ((int64_t)src * N + i) * 256);
+                        ok = false;
+                    }
+            }
+            if (ok) break;
+            if (++spins > p.spin_limit) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float own = P[(split * N + i) * 256 + tid];
+            float acc = 0.f;
+#pragma unroll
+            for (int src = 0; src < S; ++src) {                                  // split order = the slab order of the two-launch path
+                // got[] holds the sources in order without this split: source src sits at row src (src < split) or src - 1 (src > split);
+                // both candidates are named with compile-time indices (a run-time index would send the array to scratch)
+                const float lo = xg_val(got[(src < S - 1 ? src : 0) * N + i]), hi = xg_val(got[(src > 0 ? src - 1 : 0) * N + i]);
+                const float v = src == split ? own : (src < split ? lo : hi);
+                acc = src == 0 ? v : acc + v;
+            }
+            R[i] = acc;
+        }
+    }
+
+    // ---- 3. / 4. the BatchNorm of the layer over the B images ---------------------------------------------------------------------------
+    const int m0 = mt * 32 + split * N;                                          // first channel this workgroup owns
+    const int64_t pix0 = ((int64_t)b * p.Cout + m0) * 256 + tid;
+    float e1[N], e2[N];                                                          // MODE 0: (z, -)   MODE 1: (dy', xhat)
+    float s1[N], s2[N];
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const bool live = m0 + i < p.Cout;
+            const unsigned short zb = vs_f2h(R[i] + ((p.bias && live) ? p.bias[m0 + i] : 0.f), CT);
+            e1[i] = vs_h2f(zb, CT);
+            if (live) p.z[pix0 + (int64_t)i * 256] = zb;
+            s1[i] = wave_sum64(e1[i]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) redA[wave * 32 + i] = s1[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            s1[i] = ((redA[i] + redA[32 + i]) + redA[64 + i]) + redA[96 + i];   // sum over this image's 256 pixels (every thread the same)
+            const float d = e1[i] - s1[i] * (1.f / 256.f);
+            s2[i] = wave_sum64(d * d);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) redB[wave * 32 + i] = s2[i];
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const bool live = m0 + i < p.Cout;
+            const int m = live ? m0 + i : 0;
+            const float xv = live ? vs_h2f(p.z[pix0 + (int64_t)i * 256], CT) : 0.f;
+            const float xh = (xv - p.mean[m]) * p.invstd[m];
+            const float dzp = live ? R[i] * img_act_grad(xh * p.gamma[m] + p.beta[m], p.act) : 0.f;
+            e1[i] = dzp;
+            e2[i] = xh;
+            s1[i] = wave_sum64(dzp);
+            s2[i] = wave_sum64(dzp * xh);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { redA[wave * 32 + i] = s1[i]; redB[wave * 32 + i] = s2[i]; }
+        }
+        __syncthreads();
+    }
+    // all-gather over the images: thread i < N publishes its channel's two numbers for image b and reads those of all B images
+    if (tid < N) {
+        const int i = tid;
+        const float a = ((redA[i] + redA[32 + i]) + redA[64 + i]) + redA[96 + i];
+        const float q = ((redB[i] + redB[32 + i]) + redB[64 + i]) + redB[96 + i];
+        xg64* row = p.xb + ((int64_t)(m0 + i) * p.B) * 2;
+        xg_store(row + 2 * b, xg_pack(epoch, a));
+        xg_store(row + 2 * b + 1, xg_pack(epoch, q));
+        double t1 = 0.0, t2 = 0.0;
+        unsigned spins = 0;
+        bool bad = false;
+        if constexpr (MODE == 0) {
+            // first the mean over all images, then the centred sums: M2 = sum_b [M2_b + 256 (mean_b - mean)^2]
+            double tot = 0.0;
+            for (int bb = 0; bb < p.B; ++bb) {
+                xg64 g = xg_load(row + 2 * bb);
+                while ((unsigned)(g >> 32) != epoch) {
+                    if (++spins > p.spin_limit) { bad = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    g = xg_load(row + 2 * bb);
+                }
+                tot += (double)xg_val(g);
+            }
+            const double n = 256.0 * (double)p.B, mu = tot / n;
+            double m2 = 0.0;
+            for (int bb = 0; bb < p.B; ++bb) {
+                xg64 g = xg_load(row + 2 * bb), g2 = xg_load(row + 2 * bb + 1);
+                while ((unsigned)(g2 >> 32) != epoch || (unsigned)(g >> 32) != epoch) {
+                    if (++spins > p.spin_limit) { bad = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    g = xg_load(row + 2 * bb);
+                    g2 = xg_load(row + 2 * bb + 1);
+                }
+                const double d = (double)xg_val(g) * (1.0 / 256.0) - mu;
+                m2 += (double)xg_val(g2) + 256.0 * d * d;
+            }
+            const double var = m2 / n;
+            const float muf = (float)mu, is = (float)(1.0 / sqrt(var + (double)p.eps));
+            st[2 * i] = muf;
+            st[2 * i + 1] = is;
+            if (b == 0 && m0 + i < p.Cout) {
+                p.mean[m0 + i] = muf;
+                p.invstd[m0 + i] = is;
+                if (p.rmean) {
+                    const double ub = n > 1.0 ? m2 / (n - 1.0) : var;
+                    p.rmean[m0 + i] = (float)((1.0 - p.momentum) * (double)p.rmean[m0 + i] + p.momentum * (double)muf);
+                    p.rvar[m0 + i] = (float)((1.0 - p.momentum) * (double)p.rvar[m0 + i] + p.momentum * (double)(float)ub);
+                }
+            }
+        } else {
+            for (int bb = 0; bb < p.B; ++bb) {
+                xg64 g = xg_load(row + 2 * bb), g2 = xg_load(row + 2 * bb + 1);
+                while ((unsigned)(g2 >> 32) != epoch || (unsigned)(g >> 32) != epoch) {
+                    if (++spins > p.spin_limit) { bad = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    g = xg_load(row + 2 * bb);
+                    g2 = xg_load(row + 2 * bb + 1);
+                }
+                t1 += (double)xg_val(g);
+                t2 += (double)xg_val(g2);
+            }
+            const float inv_n = 1.f / (256.f * (float)p.B);
+            st[2 * i] = (float)t1 * inv_n;
+            st[2 * i + 1] = (float)t2 * inv_n;
+            if (b == 0 && m0 + i < p.Cout) {
+                if (p.accumulate) { p.dbeta[m0 + i] += (float)t1; p.dgamma[m0 + i] += (float)t2; }
+                else { p.dbeta[m0 + i] = (float)t1; p.dgamma[m0 + i] = (float)t2; }
+            }
+        }
+        if (bad) timed_out = true;
+    }
+    __syncthreads();
+    if (timed_out) atomicOr(p.xerr, 1u);
+
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (m0 + i >= p.Cout) continue;
+            const int64_t idx = pix0 + (int64_t)i * 256;
+            const float yv = vs_act((e1[i] - st[2 * i]) * st[2 * i + 1] * p.gamma[m0 + i] + p.beta[m0 + i], p.act);
+            vs_st(p.y, p.yd, idx, yv);
+            if (p.skip) {                                                        // block tail (resnet.py:66-70): x + r in fp32 and as the next operand
+                const float xn = p.skip[idx] + yv;
+                p.xnew[idx] = xn;
+                if (p.xnew16) p.xnew16[idx] = vs_f2h(xn, CT);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (m0 + i >= p.Cout) continue;
+            const float g = p.gamma[m0 + i], is = p.invstd[m0 + i];
+            p.dz[pix0 + (int64_t)i * 256] = vs_f2h(g * is * (e1[i] - st[2 * i] - e2[i] * st[2 * i + 1]), CT);
+        }
+    }
+}
+
+// base += 65536: one training step's worth of launch numbers (the caller's call_idx restarts at 1)
+__global__ void exchange_epoch_advance_kernel(unsigned* base) { *base += 65536u; }
 
 // ---- many maps of 16 / 32 / 64 pixels width: the same contraction on row BANDS -------------------------------------------------
 // Every 3x3 block of the SST / VGG encoders and decoders (conv.py:127-171, 267-426 of the reference) on hundreds of maps: as "column
@@ -848,6 +1184,106 @@ extern "C" int vs_conv3_img16(int compute, const void* x, const void* w_packed, 
         hipLaunchKernelGGL(kh, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)x, (const u32x4*)w_packed, slabs, B, Cin, Cout, cs, splits, mtiles);
     VS_CHECK_LAUNCH("vs_conv3_img16");
     return VS_OK;
+}
+
+// ---- the fused layer (conv3_img16_bn_kernel): workspace = [epoch word][error word] .. 256 | area B (1 MiB) | area A (16 MiB), zero-filled by the caller
+// once and kept; one workspace per stream (launches on a stream follow each other, so they can share the areas)
+constexpr size_t IMGBN_B_OFF = 256, IMGBN_B_BYTES = (size_t)1 << 20, IMGBN_A_OFF = IMGBN_B_OFF + IMGBN_B_BYTES, IMGBN_A_BYTES = (size_t)16 << 20;
+
+extern "C" size_t vs_conv3_img16_bn_workspace_bytes(void) { return IMGBN_A_OFF + IMGBN_A_BYTES; }
+
+extern "C" int vs_conv3_img16_bn_supported(int compute, int B, int Cin, int Cout) {
+    if (!vs_conv3_img16_supported(compute, B, Cin, 16, 16, Cout)) return 0;
+    const int s = img16_splits(B, Cin, Cout), mtiles = (int)vs_cdiv(Cout, 32);
+    if (s != 1 && s != 2 && s != 8) return 0;
+    static const int cus = getenv("VS_IMG_BN_MAX_WGS") ? atoi(getenv("VS_IMG_BN_MAX_WGS")) : 256;       // every workgroup must be resident: one per CU
+    if ((int64_t)B * mtiles * s > cus) return 0;
+    if (B > 64 || (int64_t)mtiles * 32 * B * 16 > (int64_t)IMGBN_B_BYTES) return 0;
+    return 1;
+}
+
+extern "C" int vs_exchange_epoch_advance(void* ws, void* stream) {
+    VS_CHECK_ARG(ws && (uintptr_t)ws % 16 == 0, "vs_exchange_epoch_advance: bad argument");
+    hipLaunchKernelGGL(exchange_epoch_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned*)ws);
+    VS_CHECK_LAUNCH("vs_exchange_epoch_advance");
+    return VS_OK;
+}
+
+static int imgbn_launch(int compute, int mode, ImgBnArgs& a, void* ws, unsigned call_idx, hipStream_t stream) {
+    static const unsigned spin = getenv("VS_IMG_BN_SPIN") ? (unsigned)atol(getenv("VS_IMG_BN_SPIN")) : 2000000u;
+    a.splits = img16_splits(a.B, a.Cin, a.Cout);
+    a.cs = a.Cin / a.splits;
+    a.mtiles = (int)vs_cdiv(a.Cout, 32);
+    char* base = (char*)ws;
+    a.epoch_base = (const unsigned*)base;
+    a.xerr = (unsigned*)(base + 4);
+    a.xb = (xg64*)(base + IMGBN_B_OFF);
+    a.xa = (xg64*)(base + IMGBN_A_OFF);
+    a.call_idx = call_idx;
+    a.spin_limit = spin;
+    const size_t lds = (size_t)a.cs * IMG_CPITCH * 2;
+    const dim3 grid((unsigned)((int64_t)a.B * a.mtiles * a.splits));
+#define VS_IMGBN_GO(CTV, SV, MV)                                                                                                          \
+    do {                                                                                                                                  \
+        auto kern = conv3_img16_bn_kernel<CTV, SV, MV>;                                                                                   \
+        static bool attr_set = false;                                                                                                     \
+        if (!attr_set) {                                                                                                                  \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * IMG_CPITCH * 2) != hipSuccess)   \
+                return vs_fail(VS_ERR_LAUNCH, "vs_conv3_img16_bn: cannot raise the dynamic LDS limit");                                   \
+            attr_set = true;                                                                                                              \
+        }                                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);                                                                        \
+    } while (0)
+#define VS_IMGBN_S(CTV, MV)                                  \
+    do {                                                     \
+        if (a.splits == 1) VS_IMGBN_GO(CTV, 1, MV);          \
+        else if (a.splits == 2) VS_IMGBN_GO(CTV, 2, MV);     \
+        else VS_IMGBN_GO(CTV, 8, MV);                        \
+    } while (0)
+    if (compute == VS_BF16) { if (mode == 0) VS_IMGBN_S(VS_BF16, 0); else VS_IMGBN_S(VS_BF16, 1); }
+    else { if (mode == 0) VS_IMGBN_S(VS_F16, 0); else VS_IMGBN_S(VS_F16, 1); }
+#undef VS_IMGBN_S
+#undef VS_IMGBN_GO
+    VS_CHECK_LAUNCH("vs_conv3_img16_bn");
+    return VS_OK;
+}
+
+// y = act(BatchNorm_train(conv3x3(x) + bias)) of ONE reference call (all B maps are the call's batch) in one launch: z [B][Cout][256]
+// (the 16-bit pre-BatchNorm output, kept for backward), y in y_dtype, mean / invstd [Cout], running estimates updated; skip != NULL (the
+// block's last layer): xnew = skip + y (fp32) and its 16-bit copy xnew16.  call_idx: 1 .. 65535, distinct for every launch since the last
+// vs_exchange_epoch_advance on this workspace.
+extern "C" int vs_conv3_img16_bn_fwd(int compute, const void* x, const void* w_packed, void* ws, unsigned call_idx, const float* bias, const float* gamma,
+                                     const float* beta, int act, float* running_mean, float* running_var, float momentum, float eps, void* z, void* y,
+                                     int y_dtype, float* mean, float* invstd, const float* skip, float* xnew, void* xnew16, int B, int Cin, int Cout,
+                                     void* stream) {
+    VS_CHECK_ARG(x && w_packed && ws && gamma && beta && z && y && mean && invstd && vs_dtype_ok(y_dtype), "vs_conv3_img16_bn_fwd: bad argument");
+    VS_CHECK_ARG(vs_conv3_img16_bn_supported(compute, B, Cin, Cout), "vs_conv3_img16_bn_fwd: unsupported geometry (query vs_conv3_img16_bn_supported)");
+    VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && (!skip || xnew), "vs_conv3_img16_bn_fwd: running_mean/var, skip/xnew come together");
+    VS_CHECK_ARG(call_idx >= 1 && call_idx < 65536, "vs_conv3_img16_bn_fwd: call_idx out of range (advance the epoch base)");
+    VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)ws) % 16 == 0, "vs_conv3_img16_bn_fwd: operands must be 16-byte aligned");
+    ImgBnArgs a = {};
+    a.X = (const unsigned short*)x; a.Wp = (const u32x4*)w_packed; a.B = B; a.Cin = Cin; a.Cout = Cout;
+    a.bias = bias; a.gamma = gamma; a.beta = beta; a.act = act; a.eps = eps; a.momentum = momentum;
+    a.rmean = running_mean; a.rvar = running_var; a.mean = mean; a.invstd = invstd;
+    a.z = (unsigned short*)z; a.y = y; a.yd = y_dtype; a.skip = skip; a.xnew = xnew; a.xnew16 = (unsigned short*)xnew16;
+    return imgbn_launch(compute, 0, a, ws, call_idx, (hipStream_t)stream);
+}
+
+// The backward layer: dy = conv3x3_input_gradient(dz_next) (w_packed: the FOLLOWING layer's weight packed with flip = 1; Cin = its output
+// channels, Cout = this layer's channels), then this layer's BatchNorm + activation backward from the stored z, mean, invstd:
+// dz [B][Cout][256] (16-bit); d gamma / d beta written or (accumulate) ADDED to dgamma / dbeta.
+extern "C" int vs_conv3_img16_bn_bwd(int compute, const void* dz_next, const void* w_packed, void* ws, unsigned call_idx, const void* z, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, int act, void* dz, float* dgamma, float* dbeta,
+                                     int accumulate, int B, int Cin, int Cout, void* stream) {
+    VS_CHECK_ARG(dz_next && w_packed && ws && z && mean && invstd && gamma && beta && dz && dgamma && dbeta, "vs_conv3_img16_bn_bwd: bad argument");
+    VS_CHECK_ARG(vs_conv3_img16_bn_supported(compute, B, Cin, Cout), "vs_conv3_img16_bn_bwd: unsupported geometry (query vs_conv3_img16_bn_supported)");
+    VS_CHECK_ARG(call_idx >= 1 && call_idx < 65536, "vs_conv3_img16_bn_bwd: call_idx out of range (advance the epoch base)");
+    VS_CHECK_ARG(((uintptr_t)dz_next | (uintptr_t)w_packed | (uintptr_t)ws) % 16 == 0, "vs_conv3_img16_bn_bwd: operands must be 16-byte aligned");
+    ImgBnArgs a = {};
+    a.X = (const unsigned short*)dz_next; a.Wp = (const u32x4*)w_packed; a.B = B; a.Cin = Cin; a.Cout = Cout;
+    a.gamma = gamma; a.beta = beta; a.act = act; a.mean = (float*)mean; a.invstd = (float*)invstd;
+    a.z = (unsigned short*)z; a.dz = (unsigned short*)dz; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
+    return imgbn_launch(compute, 1, a, ws, call_idx, (hipStream_t)stream);
 }
 
 // out[b][c][p] = sum_s slabs[s][b][c][p] (+ bias[c]) (+ addend[b][c][p], fp32) in out_dtype; HW a multiple of 4

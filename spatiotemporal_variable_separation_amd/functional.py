@@ -1156,7 +1156,9 @@ def conv_res_block_fusable(x, convs, bns, cdt=None):
 
 class ConvResBlockFn(torch.autograd.Function):
     """One ConvResBlock (resnet.py:53-70) of the ConvResnet integrator on a few 16x16 maps: x -> (x + r, r), r = BN(conv(act(BN(conv(act(BN(conv
-    x))))))).  Forward = 6 launches (per layer: `ops.conv3_img16` into split slabs, then slab sum + bias + BatchNorm + activation in one;
+    x))))))).  Round 4 (VARSEP_FUSED_RESBLOCK=2, default): every layer ONE launch each way (`ops.conv3_img16_bn_fwd` / `_bwd`: convolution + BatchNorm,
+    the splits' partial sums and the maps' statistics exchanged inside the launch) -- forward 3 launches, backward 5 (the top BatchNorm backward, two
+    fused layers, the block input's gradient convolution + its slab sum).  VARSEP_FUSED_RESBLOCK=1, the round-3 form: forward = 6 launches (per layer: `ops.conv3_img16` into split slabs, then slab sum + bias + BatchNorm + activation in one;
     the last one also adds the skip and writes the 16-bit copy the next block's convolution reads), backward = 7 (per layer: BatchNorm
     backward that takes its upstream gradient straight from the slabs of the following input-gradient launch and adds d gamma / d beta to
     the pending gradients, then the input-gradient launch; the skip gradient joins in the last slab sum).  Weight gradients are batched
@@ -1171,11 +1173,24 @@ class ConvResBlockFn(torch.autograd.Function):
         cdt = compute_dtype()
         h = x16 if (x16 is not None and x16.dtype == cdt and x16.shape == x.shape) else to_compute(x, cdt)
         saved = []
+        one_launch = os.environ.get('VARSEP_FUSED_RESBLOCK', '2') == '2'       # '1': convolution and BatchNorm as two launches per layer (round 3)
         for li in range(3):
             w, b, gm, bt = prm[4 * li:4 * li + 4]
             rmean, rvar, momentum, eps, act = cfg[li]
-            slabs = ops.conv3_img16(h, packed_img_weight(w, cdt, False), w.shape[0])
             bias = b.detach() if b is not None else None
+            if one_launch and ops.conv3_img16_bn_supported(h.shape[0], h.shape[1], w.shape[0], cdt):
+                # convolution + BatchNorm of the layer in ONE launch: the splits' partial sums and the maps' statistics meet inside it
+                if li < 2:
+                    y, z, mean, invstd = ops.conv3_img16_bn_fwd(h, packed_img_weight(w, cdt, False), bias, gm.detach(), bt.detach(), act, cdt, w.shape[0],
+                                                                rmean, rvar, momentum, eps)
+                else:
+                    y, z, mean, invstd, xnew, xnew16 = ops.conv3_img16_bn_fwd(h, packed_img_weight(w, cdt, False), bias, gm.detach(), bt.detach(), act,
+                                                                              torch.float32, w.shape[0], rmean, rvar, momentum, eps, skip=x.detach(),
+                                                                              want16=True)
+                saved += [h, z, mean, invstd]
+                h = y
+                continue
+            slabs = ops.conv3_img16(h, packed_img_weight(w, cdt, False), w.shape[0])
             if li < 2:
                 y, z, mean, invstd = ops.bn_train_fwd_small_slabs(slabs, bias, cdt, gm.detach(), bt.detach(), act, cdt, rmean, rvar, momentum, eps)
             else:
@@ -1201,8 +1216,9 @@ class ConvResBlockFn(torch.autograd.Function):
         if dy_b is not None:
             dy_b = dy_b.contiguous().float()
         grads = [None] * 12
-        slabs = None
+        dz_up = None                                 # dz of the layer above (li + 1)
         fold = _STATE.get('fold_grads')
+        one_launch = os.environ.get('VARSEP_FUSED_RESBLOCK', '2') == '2'
         for li in (2, 1, 0):
             w, b, gm, bt = prm[4 * li:4 * li + 4]
             h, z, mean, invstd = saved[4 * li:4 * li + 4]
@@ -1214,18 +1230,24 @@ class ConvResBlockFn(torch.autograd.Function):
                 fg, fb = _fold_slots().get(id(gm)), _fold_slots().get(id(bt))
                 if fg is not None and fb is not None and fg.dtype == torch.float32 and fb.dtype == torch.float32 and fg.is_contiguous() and fb.is_contiguous():
                     acc = (fg, fb)
-            if slabs is not None:
-                dz, dgamma, dbeta = ops.bn_act_bwd_small_ex(z, mean, invstd, gm.detach(), bt.detach(), ctx.acts[li], cdt, slabs=slabs, acc=acc)
-            else:
+            if dz_up is None:
                 dz, dgamma, dbeta = ops.bn_act_bwd_small_ex(z, mean, invstd, gm.detach(), bt.detach(), ctx.acts[li], cdt, dy_a=dy_a, dy_b=dy_b, acc=acc)
+            else:
+                w_up = prm[4 * (li + 1)]              # the upstream gradient is the input gradient of the layer above
+                if one_launch and ops.conv3_img16_bn_supported(dz_up.shape[0], w_up.shape[0], w_up.shape[1], cdt):
+                    dz, dgamma, dbeta = ops.conv3_img16_bn_bwd(dz_up, packed_img_weight(w_up, cdt, True), w_up.shape[1], z, mean, invstd, gm.detach(),
+                                                               bt.detach(), ctx.acts[li], acc=acc)
+                else:
+                    slabs = ops.conv3_img16(dz_up, packed_img_weight(w_up, cdt, True), w_up.shape[1], role='dgrad')
+                    dz, dgamma, dbeta = ops.bn_act_bwd_small_ex(z, mean, invstd, gm.detach(), bt.detach(), ctx.acts[li], cdt, slabs=slabs, acc=acc)
             db = None
             if b is not None and b.requires_grad:
                 # exactly zero in front of a training-mode BatchNorm (see ConvBlock.backward)
                 db = None if ((fold and id(b) in _fold_slots()) or conv_grad_output(b) is not None) else zero_grad_like(b)
             dw = _conv_weight_grad(w, dz, h, 1, 1, False) if w.requires_grad else None
             grads[4 * li:4 * li + 4] = _fold_param_grads(((w, dw), (b, db), (gm, dgamma), (bt, dbeta)))
-            if li > 0 or ctx.x_needs_grad:
-                slabs = ops.conv3_img16(dz, packed_img_weight(w, cdt, True), w.shape[1], role='dgrad')
+            dz_up = dz
+        slabs = ops.conv3_img16(dz_up, packed_img_weight(prm[0], cdt, True), prm[0].shape[1], role='dgrad') if ctx.x_needs_grad else None
         dx = None
         if ctx.x_needs_grad:
             dx = ops.slab_sum(slabs, None, torch.float32, addend=g_new.contiguous().float() if g_new is not None else None)

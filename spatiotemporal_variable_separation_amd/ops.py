@@ -297,6 +297,13 @@ def rollout_exchange_error(device, reset=True):
         err |= int(word.item())
         if reset and err:
             word.zero_()
+    st = _IMGBN.get(index)                              # the fused ConvResBlock layers' exchange (conv3_img16_bn_*): word 1 of their workspace
+    if st is not None:
+        e2 = int(st['ws'][1].item())
+        if e2:
+            err |= 2
+            if reset:
+                st['ws'][1].zero_()
     return err
 
 
@@ -1237,6 +1244,108 @@ def bn_act_bwd_small_ex(z, mean, invstd, gamma, beta, act, dx_dtype, dy_a=None, 
     if acc is not None:
         return dx, None, None
     return dx, dgamma, dbeta
+
+
+# ---- a ConvResBlock layer in one launch (csrc/vs_conv_img.hip: conv3_img16_bn_kernel) -------------------------------------------------
+_IMGBN = {}          # device index -> {'ws': int32 workspace (word 0: epoch base, word 1: sticky error flag), 'idx': launches since the last advance}
+
+
+def _imgbn_state(device):
+    """The exchange workspace of the fused layers on `device` (one per device: the integrator's launches follow each other on one stream).
+    Created OUTSIDE a stream capture (GraphedStep's warm-up steps reach it first): a workspace created while capturing would be zero-filled
+    and re-initialised by every replay."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    st = _IMGBN.get(index)
+    if st is None:
+        nbytes = _lib.load_library().vs_conv3_img16_bn_workspace_bytes()
+        ws = torch.zeros((nbytes // 4,), dtype=torch.int32, device=device)
+        ws[0] = 65536                                    # epochs start above zero: a zero-filled granule never looks current
+        st = _IMGBN[index] = {'ws': ws, 'idx': 0}
+    return st
+
+
+def _imgbn_next_call(st):
+    st['idx'] += 1
+    if st['idx'] >= 65535:                               # (a step has ~1000 such launches; callers outside a training step never advance)
+        check(_lib.load_library().vs_exchange_epoch_advance(st['ws'].data_ptr(), stream_ptr()), 'vs_exchange_epoch_advance')
+        st['idx'] = 1
+    return st['idx']
+
+
+def exchange_epoch_advance(device=None):
+    """Start of a training step: the launch numbers of the fused layers restart at 1 under a new epoch base (one 1-thread launch, recordable:
+    a replayed step then tags its exchanges with epochs no earlier replay used).  No-op while no fused layer has run on the device."""
+    index = torch.cuda.current_device() if device is None or device.index is None else device.index
+    st = _IMGBN.get(index)
+    if st is None:
+        return
+    check(_lib.load_library().vs_exchange_epoch_advance(st['ws'].data_ptr(), stream_ptr()), 'vs_exchange_epoch_advance')
+    st['idx'] = 0
+
+
+def conv3_img16_bn_supported(B, Cin, Cout, dtype):
+    """Whether conv3_img16_bn_fwd / _bwd serve a Conv2d k3 s1 p1 (Cin -> Cout) -> BatchNorm layer on B maps of 16 x 16 (VS_IMG_BN_FUSED=0: never)."""
+    import os
+    if os.environ.get('VS_IMG_BN_FUSED', '1') == '0' or dtype == torch.float32:
+        return False
+    return bool(_lib.load_library().vs_conv3_img16_bn_supported(code_of(dtype), B, Cin, Cout))
+
+
+def conv3_img16_bn_fwd(x, w_packed, bias, gamma, beta, act, out_dtype, Cout, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, skip=None,
+                       want16=False):
+    """act(BatchNorm_train(conv3x3(x) + bias)) of ONE call in ONE launch: (y, z, mean [1, C], invstd [1, C]) like conv3_img16 +
+    bn_train_fwd_small_slabs; with `skip` additionally (skip + y in fp32, its 16-bit copy or None)."""
+    require_cuda(x, w_packed)
+    assert x.is_contiguous() and x.dtype == w_packed.dtype and tuple(x.shape[2:]) == (16, 16)
+    B, Cin = x.shape[0], x.shape[1]
+    st = _imgbn_state(x.device)
+    z = torch.empty((B, Cout, 16, 16), dtype=x.dtype, device=x.device)
+    y = torch.empty((B, Cout, 16, 16), dtype=out_dtype, device=x.device)
+    mean = torch.empty((1, Cout), dtype=torch.float32, device=x.device)
+    invstd = torch.empty((1, Cout), dtype=torch.float32, device=x.device)
+    xnew = xnew16 = None
+    if skip is not None:
+        assert skip.dtype == torch.float32 and skip.is_contiguous() and skip.numel() == y.numel()
+        xnew = torch.empty((B, Cout, 16, 16), dtype=torch.float32, device=x.device)
+        xnew16 = torch.empty((B, Cout, 16, 16), dtype=x.dtype, device=x.device) if want16 else None
+    e0 = _pb()
+    check(_lib.load_library().vs_conv3_img16_bn_fwd(dtype_code(x), x.data_ptr(), w_packed.data_ptr(), st['ws'].data_ptr(), _imgbn_next_call(st), _ptr(bias),
+                                                    gamma.data_ptr(), beta.data_ptr(), ACT[act], _ptr(running_mean), _ptr(running_var), float(momentum),
+                                                    float(eps), z.data_ptr(), y.data_ptr(), dtype_code(y), mean.data_ptr(), invstd.data_ptr(), _ptr(skip),
+                                                    _ptr(xnew), _ptr(xnew16), B, Cin, Cout, stream_ptr()), 'vs_conv3_img16_bn_fwd')
+    _pe(e0, 'vs_conv3_img16_bn:fwd<%s>' % _DT[dtype_code(x)], flops=2.0 * B * 256 * Cout * Cin * 9,
+        nbytes=float(x.numel() * x.element_size() + w_packed.numel() * 2 + z.numel() * (z.element_size() + y.element_size())))
+    if skip is not None:
+        return y, z, mean, invstd, xnew, xnew16
+    return y, z, mean, invstd
+
+
+def conv3_img16_bn_bwd(dz_next, w_packed_flipped, Cout, z, mean, invstd, gamma, beta, act, acc=None):
+    """The backward layer in ONE launch: dz = BatchNorm + activation backward (from the stored z, mean, invstd) of dy = the input gradient of the
+    FOLLOWING layer's convolution of dz_next (`w_packed_flipped`: that layer's weight, flip = 1).  `acc` = (dgamma, dbeta) the parameter
+    gradients are ADDED to (returns (dz, None, None)); otherwise fresh (dz, dgamma, dbeta)."""
+    require_cuda(dz_next, w_packed_flipped, z)
+    assert dz_next.is_contiguous() and z.is_contiguous() and dz_next.dtype == z.dtype == w_packed_flipped.dtype
+    B, Cin = dz_next.shape[0], dz_next.shape[1]
+    assert z.shape[0] == B and z.shape[1] == Cout
+    st = _imgbn_state(z.device)
+    dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    if acc is None:
+        dgamma = torch.empty((Cout,), dtype=torch.float32, device=z.device)
+        dbeta = torch.empty((Cout,), dtype=torch.float32, device=z.device)
+    else:
+        dgamma, dbeta = acc
+        assert dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32 and dgamma.numel() == Cout and dbeta.numel() == Cout
+    e0 = _pb()
+    check(_lib.load_library().vs_conv3_img16_bn_bwd(dtype_code(z), dz_next.data_ptr(), w_packed_flipped.data_ptr(), st['ws'].data_ptr(), _imgbn_next_call(st),
+                                                    z.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ACT[act],
+                                                    dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), int(acc is not None), B, Cin, Cout, stream_ptr()),
+          'vs_conv3_img16_bn_bwd')
+    _pe(e0, 'vs_conv3_img16_bn:bwd<%s>' % _DT[dtype_code(z)], flops=2.0 * B * 256 * Cout * Cin * 9,
+        nbytes=float(dz_next.numel() * 2 + w_packed_flipped.numel() * 2 + 2 * z.numel() * z.element_size()))
+    if acc is not None:
+        return dz, None, None
+    return dz, dgamma, dbeta
 
 
 def bn_act_fwd(x, mean, invstd, gamma, beta, act, out_dtype, groups=1, running=None):

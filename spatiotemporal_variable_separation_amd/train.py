@@ -708,6 +708,9 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
     if cond.is_cuda and _mlp_family(sep_net):
         return _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset, lamb_ae, lamb_s, lamb_t,
                                            lamb_pred, average_tloss, t_random)
+    if cond.is_cuda and torch.is_grad_enabled():
+        from . import ops
+        ops.exchange_epoch_advance(cond.device)      # the fused ConvResBlock layers number their launches from 1 under a new epoch base
     if cond.is_cuda and torch.is_grad_enabled() and os.environ.get('VARSEP_PREPACK_CONV', '1') == '1':
         from . import functional as VF
         VF.prepack_conv3_weights(sep_net)            # every stale 3x3 weight pre-pack of the step in one launch

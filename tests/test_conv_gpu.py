@@ -455,12 +455,75 @@ def test_batchnorm_small_from_split_slabs_equals_sum_then_batchnorm(dtype, shape
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('geom', [(8, 64, 512), (8, 512, 512), (8, 512, 64), (3, 128, 96), (5, 256, 40)])
+def test_conv3_img16_bn_one_launch_layer_matches_two_launches(dtype, geom):
+    """vs_conv3_img16_bn_fwd / _bwd (convolution + BatchNorm of a ConvResBlock layer in ONE launch; partial sums of the input-channel splits and
+    the per-map statistics exchanged inside the launch) against vs_conv3_img16 + vs_bn_train_fwd_small_slabs / vs_bn_act_bwd_small_ex: z bit for
+    bit (same sums in the same order), statistics to 2e-6, y / dz equal except isolated values on a rounding boundary, running estimates and
+    parameter gradients to 1e-5; the 64 -> 512, 512 -> 512 (two splits) and 512 -> 64 (eight splits) geometries of the SST integrator, ragged
+    channel tiles, a repeated launch (new epoch) bit-identical, no exchange time-out."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, Cin, Cout = geom
+    if not ops.conv3_img16_bn_supported(B, Cin, Cout, dtype):
+        pytest.skip('geometry not served by the one-launch layer')
+    x = _rand((B, Cin, 16, 16), 601).to(dtype).cuda()
+    w = _rand((Cout, Cin, 3, 3), 602, 0.2).cuda()
+    bias = _rand((Cout,), 603).cuda()
+    gamma, beta = (1 + _rand((Cout,), 604, 0.3)).cuda(), _rand((Cout,), 605, 0.2).cuda()
+    skip = _rand((B, Cout, 16, 16), 606).cuda()
+    wp = ops.conv3_img16_pack_weight(w, dtype, False)
+    rm1, rv1 = _rand((Cout,), 607, 0.1).cuda(), (1 + _rand((Cout,), 608, 0.2)).cuda()
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    slabs = ops.conv3_img16(x, wp, Cout)
+    y0, z0, m0, i0, xn0, xn16_0 = ops.bn_train_fwd_small_slabs(slabs, bias, dtype, gamma, beta, 'leaky_relu', torch.float32, rm1, rv1, 0.1, 1e-5, skip=skip, want16=True)
+    y1, z1, m1, i1, xn1, xn16_1 = ops.conv3_img16_bn_fwd(x, wp, bias, gamma, beta, 'leaky_relu', torch.float32, Cout, rm2, rv2, 0.1, 1e-5, skip=skip, want16=True)
+    rm3, rv3 = rm2.clone(), rv2.clone()
+    again = ops.conv3_img16_bn_fwd(x, wp, bias, gamma, beta, 'leaky_relu', torch.float32, Cout, rm3, rv3, 0.1, 1e-5, skip=skip, want16=True)
+    torch.cuda.synchronize()
+    assert ops.rollout_exchange_error(x.device) == 0
+    assert torch.equal(z1, z0)
+    assert torch.allclose(m1, m0, rtol=2e-6, atol=2e-7) and torch.allclose(i1, i0, rtol=2e-6, atol=0)
+    assert torch.allclose(y1, y0, rtol=1e-5, atol=1e-5) and torch.allclose(xn1, xn0, rtol=1e-5, atol=1e-5)
+    assert (xn16_1 != xn16_0).float().mean().item() < 1e-3
+    assert torch.allclose(rm2, rm1, rtol=1e-6, atol=1e-7) and torch.allclose(rv2, rv1, rtol=1e-5, atol=1e-7)
+    assert torch.equal(again[0], y1) and torch.equal(again[1], z1) and torch.equal(again[2], m1)          # reproducible, epochs move on
+    # 16-bit output of an inner layer
+    y16_0 = ops.bn_train_fwd_small_slabs(slabs, bias, dtype, gamma, beta, 'leaky_relu', dtype, None, None, 0.1, 1e-5)[0]
+    y16_1 = ops.conv3_img16_bn_fwd(x, wp, bias, gamma, beta, 'leaky_relu', dtype, Cout)[0]
+    assert (y16_1 != y16_0).float().mean().item() < 1e-3
+    # backward layer: dz_next has Cnext channels, the layer above maps Cout -> Cnext
+    Cnext = Cin                                               # (any supported pair: reuse the geometry mirrored)
+    if not ops.conv3_img16_bn_supported(B, Cnext, Cout, dtype):
+        return
+    w_up = _rand((Cnext, Cout, 3, 3), 609, 0.2).cuda()
+    wf = ops.conv3_img16_pack_weight(w_up, dtype, True)
+    dz_next = _rand((B, Cnext, 16, 16), 610).to(dtype).cuda()
+    sl = ops.conv3_img16(dz_next, wf, Cout, role='dgrad')
+    d0, dg0, db0 = ops.bn_act_bwd_small_ex(z0, m0, i0, gamma, beta, 'leaky_relu', dtype, slabs=sl)
+    d1, dg1, db1 = ops.conv3_img16_bn_bwd(dz_next, wf, Cout, z0, m0, i0, gamma, beta, 'leaky_relu')
+    pend_g, pend_b = _rand((Cout,), 611).cuda(), _rand((Cout,), 612).cuda()
+    acc_g, acc_b = pend_g.clone(), pend_b.clone()
+    d2, _, _ = ops.conv3_img16_bn_bwd(dz_next, wf, Cout, z0, m0, i0, gamma, beta, 'leaky_relu', acc=(acc_g, acc_b))
+    torch.cuda.synchronize()
+    assert ops.rollout_exchange_error(x.device) == 0
+    scale = d0.float().abs().max().item()
+    assert ((d1.float() - d0.float()).abs() > 1e-5 * scale).float().mean().item() < 2e-3
+    assert ((d1.float() - d0.float()).norm() / d0.float().norm()).item() < 1e-3
+    assert torch.allclose(dg1, dg0, rtol=1e-5, atol=1e-5 * dg0.abs().max().item()) and torch.allclose(db1, db0, rtol=1e-5, atol=1e-5 * db0.abs().max().item())
+    assert torch.equal(d2, d1) and torch.allclose(acc_g, pend_g + dg1, rtol=1e-6, atol=1e-6) and torch.allclose(acc_b, pend_b + db1, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['1', '2'])
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
-def test_fused_conv_res_block_equals_layer_by_layer(precision, monkeypatch):
-    """ConvResBlock (resnet.py:53-70) through functional.ConvResBlockFn (6 launches forward, 7 backward) against the same block run
-    layer by layer: forward outputs and running statistics bit for bit (same kernels), gradients to the tolerance of the one difference
-    -- the fused backward hands the inner BatchNorms the fp32 input gradient, the layered one a 16-bit rounding of it --, and a second
-    chained block re-uses the 16-bit copy of the first one's output."""
+def test_fused_conv_res_block_equals_layer_by_layer(precision, mode, monkeypatch):
+    """ConvResBlock (resnet.py:53-70) through functional.ConvResBlockFn against the same block run layer by layer.  mode 1 (round 3: 6 launches
+    forward, 7 backward, the same kernels as the layered path): forward outputs and running statistics bit for bit, gradients to the tolerance
+    of the one difference -- the fused backward hands the inner BatchNorms the fp32 input gradient, the layered one a 16-bit rounding of it.
+    mode 2 (round 4: ONE launch per layer, the statistics combined from per-map sums by the parallel-variance formula instead of one two-pass
+    reduction): the stored pre-BatchNorm values are the same bits, mean / invstd agree to ~1e-7, so outputs agree except where that moves a
+    value across a 16-bit rounding boundary (bounded below).  A second chained block re-uses the 16-bit copy of the first one's output."""
     import copy
     from spatiotemporal_variable_separation_amd import functional as VF
     from spatiotemporal_variable_separation_amd.networks.conv import ConvResnet
@@ -471,18 +534,29 @@ def test_fused_conv_res_block_equals_layer_by_layer(precision, monkeypatch):
         x0 = _rand((4, 64, 16, 16), 81).cuda()
         ga, gb = _rand((4, 64, 16, 16), 82).cuda(), _rand((4, 64, 16, 16), 83).cuda()
         outs = []
-        for fused, m in (('1', net), ('0', ref)):
+        for fused, m in ((mode, net), ('0', ref)):
             monkeypatch.setenv('VARSEP_FUSED_RESBLOCK', fused)
             x = x0.clone().requires_grad_(True)
             y, residuals = m(x)
-            assert hasattr(y, '_vs16') == (fused == '1')          # the fused path leaves the 16-bit copy of its output
+            assert hasattr(y, '_vs16') == (fused != '0')          # the fused path leaves the 16-bit copy of its output
             (y * ga).sum().add((residuals[0] * gb).sum()).add((residuals[1] * ga).sum()).backward()
             torch.cuda.synchronize()
             outs.append((y.detach(), [r.detach() for r in residuals], x.grad))
         (y1, r1, g1), (y2, r2, g2) = outs
-        assert torch.equal(y1, y2) and torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
-        for (n1, b1), (_, b2) in zip(net.named_buffers(), ref.named_buffers()):
-            assert torch.equal(b1, b2), n1
+        from spatiotemporal_variable_separation_amd import ops
+        assert ops.rollout_exchange_error(torch.device('cuda', torch.cuda.current_device())) == 0
+        if mode == '1':
+            assert torch.equal(y1, y2) and torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+            for (n1, b1), (_, b2) in zip(net.named_buffers(), ref.named_buffers()):
+                assert torch.equal(b1, b2), n1
+        else:
+            ulp = 2.0 ** -8 if precision == 'bf16' else 2.0 ** -11
+            for a, bb in ((y1, y2), (r1[0], r2[0]), (r1[1], r2[1])):
+                d = (a - bb).abs()
+                assert (d.norm() / bb.norm()).item() < 4 * ulp
+                assert (d > 1e-5 * bb.abs().max()).float().mean().item() < 0.05            # isolated flipped roundings of intermediate values
+            for (n1, b1), (_, b2) in zip(net.named_buffers(), ref.named_buffers()):
+                assert torch.allclose(b1.float(), b2.float(), rtol=2e-3, atol=1e-4), n1
         tol = 2e-2 if precision == 'bf16' else 3e-3
 
         def rel(a, b):
