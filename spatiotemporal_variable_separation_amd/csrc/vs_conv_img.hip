@@ -152,9 +152,19 @@ __device__ __forceinline__ void img16_tile(const unsigned short* __restrict__ X,
         }
     }
 
-    // the repeated fragment loads of the last groups are still in flight and their destination registers are dead to the compiler:
-    // they must land before it re-uses those registers (for the store addresses below)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the repeated fragment loads of the last groups are still in flight and their destination registers are dead to the compiler, which
+    // would re-use them for whatever it schedules next (round 4: the x-shift sums below, hoisted above a bare wait, came back with the
+    // values of three registers overwritten by a landing load).  The wait therefore NAMES every fragment register as an in/out operand:
+    // they stay allocated until the loads have landed, and nothing that follows can move above it.
+#pragma unroll
+    for (int gg = 0; gg < AHEAD; ++gg) {
+        if (gg == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[gg][0]), "+v"(a[gg][1]), "+v"(a[gg][2]) : : "memory");
+        else asm volatile("" : "+v"(a[gg][0]), "+v"(a[gg][1]), "+v"(a[gg][2]) : : "memory");
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[kx][j]));         // (the sums below are taken after the wait)
 
     // ---- out[y][x] = G_1[x] + G_0[x - 1] + G_2[x + 1] ------------------------------------------------------------------------------
 #pragma unroll
