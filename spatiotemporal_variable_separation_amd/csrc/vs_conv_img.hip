@@ -407,7 +407,10 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
         }
         __syncthreads();
     }
-    // all-gather over the images: thread i < N publishes its channel's two numbers for image b and reads those of all B images
+    // all-gather over the images: thread i < N publishes its channel's two numbers for image b; then thread (i, bb) fetches image bb's pair of
+    // channel i -- ONE round trip for the whole workgroup (a first form in which thread i polled the B images one after the other cost 2 B
+    // dependent round trips per layer: SST 20.0 -> 24.4 ms) -- and parks it in LDS, where thread i combines them in image order
+    float* gat = P;                                                              // [B][N][2]: the partial-sum tile is no longer needed
     if (tid < N) {
         const int i = tid;
         const float a = ((redA[i] + redA[32 + i]) + redA[64 + i]) + redA[96 + i];
@@ -415,33 +418,39 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
         xg64* row = p.xb + ((int64_t)(m0 + i) * p.B) * 2;
         xg_store(row + 2 * b, xg_pack(epoch, a));
         xg_store(row + 2 * b + 1, xg_pack(epoch, q));
-        double t1 = 0.0, t2 = 0.0;
-        unsigned spins = 0;
-        bool bad = false;
-        if constexpr (MODE == 0) {
-            // first the mean over all images, then the centred sums: M2 = sum_b [M2_b + 256 (mean_b - mean)^2]
-            double tot = 0.0;
-            for (int bb = 0; bb < p.B; ++bb) {
-                xg64 g = xg_load(row + 2 * bb);
-                while ((unsigned)(g >> 32) != epoch) {
-                    if (++spins > p.spin_limit) { bad = true; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                    g = xg_load(row + 2 * bb);
-                }
-                tot += (double)xg_val(g);
-            }
-            const double n = 256.0 * (double)p.B, mu = tot / n;
-            double m2 = 0.0;
-            for (int bb = 0; bb < p.B; ++bb) {
+    }
+    {
+        constexpr int PER = 256 / N;                                             // images fetched per round
+        const int i = tid % N;
+        const xg64* row = p.xb + ((int64_t)(m0 + i) * p.B) * 2;
+        for (int base = 0; base < p.B; base += PER) {
+            const int bb = base + tid / N;
+            if (bb < p.B) {
                 xg64 g = xg_load(row + 2 * bb), g2 = xg_load(row + 2 * bb + 1);
+                unsigned spins = 0;
                 while ((unsigned)(g2 >> 32) != epoch || (unsigned)(g >> 32) != epoch) {
-                    if (++spins > p.spin_limit) { bad = true; break; }
+                    if (++spins > p.spin_limit) { timed_out = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                     g = xg_load(row + 2 * bb);
                     g2 = xg_load(row + 2 * bb + 1);
                 }
-                const double d = (double)xg_val(g) * (1.0 / 256.0) - mu;
-                m2 += (double)xg_val(g2) + 256.0 * d * d;
+                gat[(bb * N + i) * 2] = xg_val(g);
+                gat[(bb * N + i) * 2 + 1] = xg_val(g2);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < N) {
+        const int i = tid;
+        if constexpr (MODE == 0) {
+            // first the mean over all images, then the centred sums: M2 = sum_b [M2_b + 256 (mean_b - mean)^2]
+            double tot = 0.0;
+            for (int bb = 0; bb < p.B; ++bb) tot += (double)gat[(bb * N + i) * 2];
+            const double n = 256.0 * (double)p.B, mu = tot / n;
+            double m2 = 0.0;
+            for (int bb = 0; bb < p.B; ++bb) {
+                const double d = (double)gat[(bb * N + i) * 2] * (1.0 / 256.0) - mu;
+                m2 += (double)gat[(bb * N + i) * 2 + 1] + 256.0 * d * d;
             }
             const double var = m2 / n;
             const float muf = (float)mu, is = (float)(1.0 / sqrt(var + (double)p.eps));
@@ -457,16 +466,10 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
                 }
             }
         } else {
+            double t1 = 0.0, t2 = 0.0;
             for (int bb = 0; bb < p.B; ++bb) {
-                xg64 g = xg_load(row + 2 * bb), g2 = xg_load(row + 2 * bb + 1);
-                while ((unsigned)(g2 >> 32) != epoch || (unsigned)(g >> 32) != epoch) {
-                    if (++spins > p.spin_limit) { bad = true; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                    g = xg_load(row + 2 * bb);
-                    g2 = xg_load(row + 2 * bb + 1);
-                }
-                t1 += (double)xg_val(g);
-                t2 += (double)xg_val(g2);
+                t1 += (double)gat[(bb * N + i) * 2];
+                t2 += (double)gat[(bb * N + i) * 2 + 1];
             }
             const float inv_n = 1.f / (256.f * (float)p.B);
             st[2 * i] = (float)t1 * inv_n;
@@ -476,7 +479,6 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
                 else { p.dbeta[m0 + i] = (float)t1; p.dgamma[m0 + i] = (float)t2; }
             }
         }
-        if (bad) timed_out = true;
     }
     __syncthreads();
     if (timed_out) atomicOr(p.xerr, 1u);

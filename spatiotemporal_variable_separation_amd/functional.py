@@ -1133,7 +1133,7 @@ def conv_res_block_fusable(x, convs, bns, cdt=None):
     """Whether `ConvResBlockFn` serves a ConvResBlock (resnet.py:53-70): three Conv2d k3 s1 p1 + training-mode BatchNorm on a few 16x16
     maps in a 16-bit compute type, identity skip."""
     cdt = cdt or compute_dtype()
-    if os.environ.get('VARSEP_FUSED_RESBLOCK', '1') != '1' or cdt == torch.float32 or not x.is_cuda or x.dim() != 4:
+    if os.environ.get('VARSEP_FUSED_RESBLOCK', '2') not in ('1', '2') or cdt == torch.float32 or not x.is_cuda or x.dim() != 4:
         return False
     if x.dtype != torch.float32 or not x.is_contiguous() or len(convs) != 3 or convs[2].out_channels != x.shape[1]:
         return False
