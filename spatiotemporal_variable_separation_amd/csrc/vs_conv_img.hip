@@ -294,7 +294,21 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
     float* redA = P + 32 * 256;                                                  // [4 waves][32]
     float* redB = redA + 128;
     float* st = redB + 128;                                                      // [32][2]
+    float* par = st + 64;                                                        // [5][32]: bias, gamma, beta, mean, invstd of the owned channels
     __syncthreads();                                                             // everybody has read its last fragments of the image
+    // the per-channel parameters of the channels this workgroup will own go to LDS once: read one by one inside the store loops below they
+    // cost a global-load latency per channel (the compiler keeps a load behind the stores it may alias): 28 us for a 7 us convolution
+    if (tid < N) {
+        const int m = mt * 32 + split * N + tid;
+        const bool live = m < p.Cout;
+        par[tid] = (live && p.bias) ? p.bias[m] : 0.f;
+        par[32 + tid] = live ? p.gamma[m] : 0.f;
+        par[64 + tid] = live ? p.beta[m] : 0.f;
+        if constexpr (MODE == 1) {
+            par[96 + tid] = live ? p.mean[m] : 0.f;
+            par[128 + tid] = live ? p.invstd[m] : 0.f;
+        }
+    }
     {
         const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const bool live = m0 + i < p.Cout;
-            const unsigned short zb = vs_f2h(R[i] + ((p.bias && live) ? p.bias[m0 + i] : 0.f), CT);
+            const unsigned short zb = vs_f2h(R[i] + par[i], CT);
             e1[i] = vs_h2f(zb, CT);
             if (live) p.z[pix0 + (int64_t)i * 256] = zb;
             s1[i] = wave_sum64(e1[i]);
@@ -389,13 +403,15 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
         }
         __syncthreads();
     } else {
+        unsigned short zin[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) zin[i] = m0 + i < p.Cout ? p.z[pix0 + (int64_t)i * 256] : (unsigned short)0;     // (all loads in flight together)
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const bool live = m0 + i < p.Cout;
-            const int m = live ? m0 + i : 0;
-            const float xv = live ? vs_h2f(p.z[pix0 + (int64_t)i * 256], CT) : 0.f;
-            const float xh = (xv - p.mean[m]) * p.invstd[m];
-            const float dzp = live ? R[i] * img_act_grad(xh * p.gamma[m] + p.beta[m], p.act) : 0.f;
+            const float xv = vs_h2f(zin[i], CT);
+            const float xh = (xv - par[96 + i]) * par[128 + i];
+            const float dzp = live ? R[i] * img_act_grad(xh * par[32 + i] + par[64 + i], p.act) : 0.f;
             e1[i] = dzp;
             e2[i] = xh;
             s1[i] = wave_sum64(dzp);
@@ -484,14 +500,19 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
     if (timed_out) atomicOr(p.xerr, 1u);
 
     if constexpr (MODE == 0) {
+        float sk[N];
+        if (p.skip) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) sk[i] = m0 + i < p.Cout ? p.skip[pix0 + (int64_t)i * 256] : 0.f;               // (in flight together, ahead of the stores)
+        }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             if (m0 + i >= p.Cout) continue;
             const int64_t idx = pix0 + (int64_t)i * 256;
-            const float yv = vs_act((e1[i] - st[2 * i]) * st[2 * i + 1] * p.gamma[m0 + i] + p.beta[m0 + i], p.act);
+            const float yv = vs_act((e1[i] - st[2 * i]) * st[2 * i + 1] * par[32 + i] + par[64 + i], p.act);
             vs_st(p.y, p.yd, idx, yv);
             if (p.skip) {                                                        // block tail (resnet.py:66-70): x + r in fp32 and as the next operand
-                const float xn = p.skip[idx] + yv;
+                const float xn = sk[i] + yv;
                 p.xnew[idx] = xn;
                 if (p.xnew16) p.xnew16[idx] = vs_f2h(xn, CT);
             }
@@ -500,8 +521,7 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             if (m0 + i >= p.Cout) continue;
-            const float g = p.gamma[m0 + i], is = p.invstd[m0 + i];
-            p.dz[pix0 + (int64_t)i * 256] = vs_f2h(g * is * (e1[i] - st[2 * i] - e2[i] * st[2 * i + 1]), CT);
+            p.dz[pix0 + (int64_t)i * 256] = vs_f2h(par[32 + i] * par[128 + i] * (e1[i] - st[2 * i] - e2[i] * st[2 * i + 1]), CT);
         }
     }
 }
