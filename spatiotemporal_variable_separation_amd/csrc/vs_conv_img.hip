@@ -376,7 +376,23 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
     const int m0 = mt * 32 + split * N;                                          // first channel this workgroup owns
     const int64_t pix0 = ((int64_t)b * p.Cout + m0) * 256 + tid;
     float e1[N], e2[N];                                                          // MODE 0: (z, -)   MODE 1: (dy', xhat)
-    float s1[N], s2[N];
+    // The two per-channel sums over the image's 256 pixels: the values go to LDS pixel-major [channel][256 + T] and T = 256 / N threads per
+    // channel add N pixels each (stride T: conflict-free with that pitch), then meet by 3 .. 6 butterfly steps inside their T lanes.  (A first
+    // form reduced every channel across the wave from the pixel-major registers: 2 N dependent cross-lane reductions per thread, 0.4 us per
+    // channel -- 18 us behind a 7 us convolution.)
+    constexpr int T = 256 / N, ZP = 256 + T;
+    float* Z1 = st + 64 + 160;                                                   // [N][ZP]
+    float* Z2 = Z1 + N * ZP;
+    const int zc = tid / T, zpart = tid % T;                                     // the channel / pixel residue this thread sums
+    auto group_sum = [&](float v) {                                              // sum over the T lanes of the channel, in every one of them
+        v += dpp_get<0xB1>(v);          // quad_perm [1, 0, 3, 2]
+        v += dpp_get<0x4E>(v);          // quad_perm [2, 3, 0, 1]
+        v += dpp_get<0x141>(v);         // row_half_mirror: 8 lanes
+        if constexpr (T >= 16) v += dpp_get<0x140>(v);                           // row_mirror: 16 lanes
+        if constexpr (T >= 64) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); }
+        return v;
+    };
+    float ga = 0.f, gq = 0.f;                                                    // the channel's two numbers for this image (in its T threads)
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -384,24 +400,19 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
             const unsigned short zb = vs_f2h(R[i] + par[i], CT);
             e1[i] = vs_h2f(zb, CT);
             if (live) p.z[pix0 + (int64_t)i * 256] = zb;
-            s1[i] = wave_sum64(e1[i]);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) redA[wave * 32 + i] = s1[i];
+            Z1[i * ZP + tid] = e1[i];
         }
         __syncthreads();
+        float zv[N];
+        float a = 0.f;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            s1[i] = ((redA[i] + redA[32 + i]) + redA[64 + i]) + redA[96 + i];   // sum over this image's 256 pixels (every thread the same)
-            const float d = e1[i] - s1[i] * (1.f / 256.f);
-            s2[i] = wave_sum64(d * d);
-        }
-        if (lane == 0) {
+        for (int k = 0; k < N; ++k) { zv[k] = Z1[zc * ZP + zpart + T * k]; a += zv[k]; }
+        ga = group_sum(a);                                                       // sum over this image's 256 pixels
+        const float mb = ga * (1.f / 256.f);
+        float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < N; ++i) redB[wave * 32 + i] = s2[i];
-        }
-        __syncthreads();
+        for (int k = 0; k < N; ++k) { const float d = zv[k] - mb; q += d * d; }
+        gq = group_sum(q);                                                       // centred sum of squares
     } else {
         unsigned short zin[N];
 #pragma unroll
@@ -414,26 +425,24 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
             const float dzp = live ? R[i] * img_act_grad(xh * par[32 + i] + par[64 + i], p.act) : 0.f;
             e1[i] = dzp;
             e2[i] = xh;
-            s1[i] = wave_sum64(dzp);
-            s2[i] = wave_sum64(dzp * xh);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) { redA[wave * 32 + i] = s1[i]; redB[wave * 32 + i] = s2[i]; }
+            Z1[i * ZP + tid] = dzp;
+            Z2[i * ZP + tid] = dzp * xh;
         }
         __syncthreads();
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) { a += Z1[zc * ZP + zpart + T * k]; q += Z2[zc * ZP + zpart + T * k]; }
+        ga = group_sum(a);
+        gq = group_sum(q);
     }
     // all-gather over the images: thread i < N publishes its channel's two numbers for image b; then thread (i, bb) fetches image bb's pair of
     // channel i -- ONE round trip for the whole workgroup (a first form in which thread i polled the B images one after the other cost 2 B
     // dependent round trips per layer: SST 20.0 -> 24.4 ms) -- and parks it in LDS, where thread i combines them in image order
     float* gat = P;                                                              // [B][N][2]: the partial-sum tile is no longer needed
-    if (tid < N) {
-        const int i = tid;
-        const float a = ((redA[i] + redA[32 + i]) + redA[64 + i]) + redA[96 + i];
-        const float q = ((redB[i] + redB[32 + i]) + redB[64 + i]) + redB[96 + i];
-        xg64* row = p.xb + ((int64_t)(m0 + i) * p.B) * 2;
-        xg_store(row + 2 * b, xg_pack(epoch, a));
-        xg_store(row + 2 * b + 1, xg_pack(epoch, q));
+    if (zpart == 0) {                                                            // the first of the channel's T threads publishes
+        xg64* row = p.xb + ((int64_t)(m0 + zc) * p.B) * 2;
+        xg_store(row + 2 * b, xg_pack(epoch, ga));
+        xg_store(row + 2 * b + 1, xg_pack(epoch, gq));
     }
     {
         constexpr int PER = 256 / N;                                             // images fetched per round
@@ -1253,7 +1262,10 @@ static int imgbn_launch(int compute, int mode, ImgBnArgs& a, void* ws, unsigned 
     a.xa = (xg64*)(base + IMGBN_A_OFF);
     a.call_idx = call_idx;
     a.spin_limit = spin;
-    const size_t lds = (size_t)a.cs * IMG_CPITCH * 2;
+    // the image (cs channels) or the epilogue's tiles -- partial sums [32][256], two pixel-major tiles of <= [32][264] and the small rows --
+    // whichever is larger
+    size_t lds = (size_t)a.cs * IMG_CPITCH * 2;
+    if (lds < (size_t)104 * 1024) lds = (size_t)104 * 1024;
     const dim3 grid((unsigned)((int64_t)a.B * a.mtiles * a.splits));
 #define VS_IMGBN_GO(CTV, SV, MV)                                                                                                          \
     do {                                                                                                                                  \
