@@ -269,6 +269,7 @@ int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, float* slabs
  *               (w_packed: that layer's weight, flip = 1; Cin = its output channels); d gamma / d beta written or ADDED (accumulate) */
 size_t vs_conv3_img16_bn_workspace_bytes(void);
 int vs_conv3_img16_bn_supported(int compute, int B, int Cin, int Cout);
+int vs_conv3_img16_bn_form_supported(int backward, int act, int y_dtype, int compute);   /* built: fwd LeakyReLU -> 16-bit y, fwd none -> fp32 y; bwd LeakyReLU / none */
 int vs_exchange_epoch_advance(void* ws, void* stream);
 int vs_conv3_img16_bn_fwd(int compute, const void* x, const void* w_packed, void* ws, unsigned call_idx, const float* bias, const float* gamma,
                           const float* beta, int act, float* running_mean, float* running_var, float momentum, float eps, void* z, void* y, int y_dtype,

@@ -175,6 +175,7 @@ SIGNATURES = {
     'vs_slab_sum': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     'vs_conv3_img16_bn_workspace_bytes': (ctypes.c_size_t, []),
     'vs_conv3_img16_bn_supported': (_i32, [_i32, _i32, _i32, _i32]),
+    'vs_conv3_img16_bn_form_supported': (_i32, [_i32, _i32, _i32, _i32]),
     'vs_exchange_epoch_advance': (_i32, [_vp, _vp]),
     'vs_conv3_img16_bn_fwd': (_i32, [_i32, _vp, _vp, _vp, ctypes.c_uint, _vp, _vp, _vp, _i32, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _i32,
                                      _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -273,7 +273,16 @@ __device__ __forceinline__ float wave_sum64(float v) {
     return v;
 }
 
-template <int CT, int S, int MODE>
+// -DVS_IMGBN_STAMP (tools/imgbn_timing.py): workgroup 0 leaves wall-clock stamps of its phases in the last 128 bytes of area B
+#ifdef VS_IMGBN_STAMP
+#define IMGBN_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.xa)[-16 + (k)] = wall_clock64(); } while (0)
+#else
+#define IMGBN_STAMP(k) do { } while (0)
+#endif
+
+// ACT (VS_ACT_NONE / VS_ACT_LEAKY: what the ConvResBlock uses) and YF (y in fp32) are compile-time: with the activation and the store type as
+// run-time switches every one of the N channel iterations of the store loops carried a ten-way branch -- 0.2 us per channel, 6.5 us of a 15 us launch.
+template <int CT, int S, int MODE, int ACT, int YF>
 __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
     constexpr int N = 32 / S;                                                    // channels this workgroup owns after the reduce-scatter
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [cs][18][16], then the partial-sum tile + reduction rows
@@ -286,8 +295,10 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned epoch = *p.epoch_base + p.call_idx;
 
+    IMGBN_STAMP(0);
     float o[2][16];
     img16_tile<CT, 12>(p.X, p.Wp, p.Cin, p.cs, mt, b, split, xs, o);
+    IMGBN_STAMP(1);
 
     // ---- 1. partial sums -> LDS [32 channels][256 pixels] -------------------------------------------------------------------------------
     float* P = reinterpret_cast<float*>(xs);
@@ -372,6 +383,7 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
         }
     }
 
+    IMGBN_STAMP(2);
     // ---- 3. / 4. the BatchNorm of the layer over the B images ---------------------------------------------------------------------------
     const int m0 = mt * 32 + split * N;                                          // first channel this workgroup owns
     const int64_t pix0 = ((int64_t)b * p.Cout + m0) * 256 + tid;
@@ -422,7 +434,8 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
             const bool live = m0 + i < p.Cout;
             const float xv = vs_h2f(zin[i], CT);
             const float xh = (xv - par[96 + i]) * par[128 + i];
-            const float dzp = live ? R[i] * img_act_grad(xh * par[32 + i] + par[64 + i], p.act) : 0.f;
+            const float pre = xh * par[32 + i] + par[64 + i];
+            const float dzp = live ? R[i] * (ACT == VS_ACT_LEAKY ? (pre > 0.f ? 1.f : 0.2f) : 1.f) : 0.f;
             e1[i] = dzp;
             e2[i] = xh;
             Z1[i * ZP + tid] = dzp;
@@ -438,6 +451,7 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
     // all-gather over the images: thread i < N publishes its channel's two numbers for image b; then thread (i, bb) fetches image bb's pair of
     // channel i -- ONE round trip for the whole workgroup (a first form in which thread i polled the B images one after the other cost 2 B
     // dependent round trips per layer: SST 20.0 -> 24.4 ms) -- and parks it in LDS, where thread i combines them in image order
+    IMGBN_STAMP(3);
     float* gat = P;                                                              // [B][N][2]: the partial-sum tile is no longer needed
     if (zpart == 0) {                                                            // the first of the channel's T threads publishes
         xg64* row = p.xb + ((int64_t)(m0 + zc) * p.B) * 2;
@@ -465,6 +479,7 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
         }
     }
     __syncthreads();
+    IMGBN_STAMP(4);
     if (tid < N) {
         const int i = tid;
         if constexpr (MODE == 0) {
@@ -506,6 +521,7 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
         }
     }
     __syncthreads();
+    IMGBN_STAMP(5);
     if (timed_out) atomicOr(p.xerr, 1u);
 
     if constexpr (MODE == 0) {
@@ -518,8 +534,10 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
         for (int i = 0; i < N; ++i) {
             if (m0 + i >= p.Cout) continue;
             const int64_t idx = pix0 + (int64_t)i * 256;
-            const float yv = vs_act((e1[i] - st[2 * i]) * st[2 * i + 1] * par[32 + i] + par[64 + i], p.act);
-            vs_st(p.y, p.yd, idx, yv);
+            const float pre = (e1[i] - st[2 * i]) * st[2 * i + 1] * par[32 + i] + par[64 + i];
+            const float yv = ACT == VS_ACT_LEAKY ? (pre > 0.f ? pre : 0.2f * pre) : pre;
+            if constexpr (YF) reinterpret_cast<float*>(p.y)[idx] = yv;
+            else reinterpret_cast<unsigned short*>(p.y)[idx] = vs_f2h(yv, CT);
             if (p.skip) {                                                        // block tail (resnet.py:66-70): x + r in fp32 and as the next operand
                 const float xn = sk[i] + yv;
                 p.xnew[idx] = xn;
@@ -533,6 +551,7 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
             p.dz[pix0 + (int64_t)i * 256] = vs_f2h(par[32 + i] * par[128 + i] * (e1[i] - st[2 * i] - e2[i] * st[2 * i + 1]), CT);
         }
     }
+    IMGBN_STAMP(6);
 }
 
 // base += 65536: one training step's worth of launch numbers (the caller's call_idx restarts at 1)
@@ -1243,6 +1262,14 @@ extern "C" int vs_conv3_img16_bn_supported(int compute, int B, int Cin, int Cout
     return 1;
 }
 
+// the (activation, y type) pairs the one-launch layer is built for: forward LeakyReLU with a 16-bit y, forward no activation with an fp32 y;
+// backward LeakyReLU or none
+extern "C" int vs_conv3_img16_bn_form_supported(int backward, int act, int y_dtype, int compute) {
+    if (act != VS_ACT_NONE && act != VS_ACT_LEAKY) return 0;
+    if (backward) return 1;
+    return (act == VS_ACT_LEAKY && y_dtype == compute) || (act == VS_ACT_NONE && y_dtype == VS_F32);
+}
+
 extern "C" int vs_exchange_epoch_advance(void* ws, void* stream) {
     VS_CHECK_ARG(ws && (uintptr_t)ws % 16 == 0, "vs_exchange_epoch_advance: bad argument");
     hipLaunchKernelGGL(exchange_epoch_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned*)ws);
@@ -1267,9 +1294,9 @@ static int imgbn_launch(int compute, int mode, ImgBnArgs& a, void* ws, unsigned 
     size_t lds = (size_t)a.cs * IMG_CPITCH * 2;
     if (lds < (size_t)104 * 1024) lds = (size_t)104 * 1024;
     const dim3 grid((unsigned)((int64_t)a.B * a.mtiles * a.splits));
-#define VS_IMGBN_GO(CTV, SV, MV)                                                                                                          \
+#define VS_IMGBN_GO(CTV, SV, MV, AV, YV)                                                                                                  \
     do {                                                                                                                                  \
-        auto kern = conv3_img16_bn_kernel<CTV, SV, MV>;                                                                                   \
+        auto kern = conv3_img16_bn_kernel<CTV, SV, MV, AV, YV>;                                                                           \
         static bool attr_set = false;                                                                                                     \
         if (!attr_set) {                                                                                                                  \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * IMG_CPITCH * 2) != hipSuccess)   \
@@ -1278,14 +1305,26 @@ static int imgbn_launch(int compute, int mode, ImgBnArgs& a, void* ws, unsigned 
         }                                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);                                                                        \
     } while (0)
-#define VS_IMGBN_S(CTV, MV)                                  \
-    do {                                                     \
-        if (a.splits == 1) VS_IMGBN_GO(CTV, 1, MV);          \
-        else if (a.splits == 2) VS_IMGBN_GO(CTV, 2, MV);     \
-        else VS_IMGBN_GO(CTV, 8, MV);                        \
+#define VS_IMGBN_S(CTV, MV, AV, YV)                                  \
+    do {                                                             \
+        if (a.splits == 1) VS_IMGBN_GO(CTV, 1, MV, AV, YV);          \
+        else if (a.splits == 2) VS_IMGBN_GO(CTV, 2, MV, AV, YV);     \
+        else VS_IMGBN_GO(CTV, 8, MV, AV, YV);                        \
     } while (0)
-    if (compute == VS_BF16) { if (mode == 0) VS_IMGBN_S(VS_BF16, 0); else VS_IMGBN_S(VS_BF16, 1); }
-    else { if (mode == 0) VS_IMGBN_S(VS_F16, 0); else VS_IMGBN_S(VS_F16, 1); }
+    // the forms the ConvResBlock needs: forward LeakyReLU -> 16-bit y (inner layers), forward no activation -> fp32 y (the block's last layer),
+    // backward through LeakyReLU / no activation
+    const bool leaky = a.act == VS_ACT_LEAKY, yf = a.yd == VS_F32;
+#define VS_IMGBN_CT(CTV)                                                                  \
+    do {                                                                                  \
+        if (mode == 0 && leaky && !yf) VS_IMGBN_S(CTV, 0, VS_ACT_LEAKY, 0);               \
+        else if (mode == 0 && !leaky && yf) VS_IMGBN_S(CTV, 0, VS_ACT_NONE, 1);           \
+        else if (mode == 1 && leaky) VS_IMGBN_S(CTV, 1, VS_ACT_LEAKY, 0);                 \
+        else if (mode == 1) VS_IMGBN_S(CTV, 1, VS_ACT_NONE, 0);                           \
+        else return vs_fail(VS_ERR_UNSUPPORTED, "vs_conv3_img16_bn: this (activation, output type) pair is not built (query vs_conv3_img16_bn_form_supported)"); \
+    } while (0)
+    if (compute == VS_BF16) VS_IMGBN_CT(VS_BF16);
+    else VS_IMGBN_CT(VS_F16);
+#undef VS_IMGBN_CT
 #undef VS_IMGBN_S
 #undef VS_IMGBN_GO
     VS_CHECK_LAUNCH("vs_conv3_img16_bn");
@@ -1303,6 +1342,7 @@ extern "C" int vs_conv3_img16_bn_fwd(int compute, const void* x, const void* w_p
     VS_CHECK_ARG(x && w_packed && ws && gamma && beta && z && y && mean && invstd && vs_dtype_ok(y_dtype), "vs_conv3_img16_bn_fwd: bad argument");
     VS_CHECK_ARG(vs_conv3_img16_bn_supported(compute, B, Cin, Cout), "vs_conv3_img16_bn_fwd: unsupported geometry (query vs_conv3_img16_bn_supported)");
     VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && (!skip || xnew), "vs_conv3_img16_bn_fwd: running_mean/var, skip/xnew come together");
+    VS_CHECK_ARG(vs_conv3_img16_bn_form_supported(0, act, y_dtype, compute), "vs_conv3_img16_bn_fwd: (activation, y type) not built (query vs_conv3_img16_bn_form_supported)");
     VS_CHECK_ARG(call_idx >= 1 && call_idx < 65536, "vs_conv3_img16_bn_fwd: call_idx out of range (advance the epoch base)");
     VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)ws) % 16 == 0, "vs_conv3_img16_bn_fwd: operands must be 16-byte aligned");
     ImgBnArgs a = {};
@@ -1322,6 +1362,7 @@ extern "C" int vs_conv3_img16_bn_bwd(int compute, const void* dz_next, const voi
     VS_CHECK_ARG(dz_next && w_packed && ws && z && mean && invstd && gamma && beta && dz && dgamma && dbeta, "vs_conv3_img16_bn_bwd: bad argument");
     VS_CHECK_ARG(vs_conv3_img16_bn_supported(compute, B, Cin, Cout), "vs_conv3_img16_bn_bwd: unsupported geometry (query vs_conv3_img16_bn_supported)");
     VS_CHECK_ARG(call_idx >= 1 && call_idx < 65536, "vs_conv3_img16_bn_bwd: call_idx out of range (advance the epoch base)");
+    VS_CHECK_ARG(vs_conv3_img16_bn_form_supported(1, act, 0, compute), "vs_conv3_img16_bn_bwd: activation not built (query vs_conv3_img16_bn_form_supported)");
     VS_CHECK_ARG(((uintptr_t)dz_next | (uintptr_t)w_packed | (uintptr_t)ws) % 16 == 0, "vs_conv3_img16_bn_bwd: operands must be 16-byte aligned");
     ImgBnArgs a = {};
     a.X = (const unsigned short*)dz_next; a.Wp = (const u32x4*)w_packed; a.B = B; a.Cin = Cin; a.Cout = Cout;

@@ -1178,7 +1178,7 @@ class ConvResBlockFn(torch.autograd.Function):
             w, b, gm, bt = prm[4 * li:4 * li + 4]
             rmean, rvar, momentum, eps, act = cfg[li]
             bias = b.detach() if b is not None else None
-            if one_launch and ops.conv3_img16_bn_supported(h.shape[0], h.shape[1], w.shape[0], cdt):
+            if one_launch and ops.conv3_img16_bn_supported(h.shape[0], h.shape[1], w.shape[0], cdt, act, cdt if li < 2 else torch.float32):
                 # convolution + BatchNorm of the layer in ONE launch: the splits' partial sums and the maps' statistics meet inside it
                 if li < 2:
                     y, z, mean, invstd = ops.conv3_img16_bn_fwd(h, packed_img_weight(w, cdt, False), bias, gm.detach(), bt.detach(), act, cdt, w.shape[0],
@@ -1234,7 +1234,7 @@ class ConvResBlockFn(torch.autograd.Function):
                 dz, dgamma, dbeta = ops.bn_act_bwd_small_ex(z, mean, invstd, gm.detach(), bt.detach(), ctx.acts[li], cdt, dy_a=dy_a, dy_b=dy_b, acc=acc)
             else:
                 w_up = prm[4 * (li + 1)]              # the upstream gradient is the input gradient of the layer above
-                if one_launch and ops.conv3_img16_bn_supported(dz_up.shape[0], w_up.shape[0], w_up.shape[1], cdt):
+                if one_launch and ops.conv3_img16_bn_supported(dz_up.shape[0], w_up.shape[0], w_up.shape[1], cdt, ctx.acts[li], backward=True):
                     dz, dgamma, dbeta = ops.conv3_img16_bn_bwd(dz_up, packed_img_weight(w_up, cdt, True), w_up.shape[1], z, mean, invstd, gm.detach(),
                                                                bt.detach(), ctx.acts[li], acc=acc)
                 else:

@@ -1283,12 +1283,20 @@ def exchange_epoch_advance(device=None):
     st['idx'] = 0
 
 
-def conv3_img16_bn_supported(B, Cin, Cout, dtype):
-    """Whether conv3_img16_bn_fwd / _bwd serve a Conv2d k3 s1 p1 (Cin -> Cout) -> BatchNorm layer on B maps of 16 x 16 (VS_IMG_BN_FUSED=0: never)."""
+def conv3_img16_bn_supported(B, Cin, Cout, dtype, act='leaky_relu', out_dtype=None, backward=False):
+    """Whether conv3_img16_bn_fwd / _bwd serve a Conv2d k3 s1 p1 (Cin -> Cout) -> BatchNorm -> `act` layer on B maps of 16 x 16 with output type
+    `out_dtype` (forward).  VS_IMG_BN_FUSED=0: never; VS_IMG_BN_SPLITS (default '1'): the input-channel split counts served -- with several
+    splits the partial sums cross the chip inside the launch, which costs what the kernel boundary it replaces costs (measured)."""
     import os
     if os.environ.get('VS_IMG_BN_FUSED', '1') == '0' or dtype == torch.float32:
         return False
-    return bool(_lib.load_library().vs_conv3_img16_bn_supported(code_of(dtype), B, Cin, Cout))
+    lib = _lib.load_library()
+    if not lib.vs_conv3_img16_bn_supported(code_of(dtype), B, Cin, Cout):
+        return False
+    if not lib.vs_conv3_img16_bn_form_supported(int(backward), ACT[act], code_of(out_dtype if out_dtype is not None else dtype), code_of(dtype)):
+        return False
+    allowed = os.environ.get('VS_IMG_BN_SPLITS', '1').split(',')
+    return str(lib.vs_conv3_img16_splits(B, Cin, Cout)) in allowed
 
 
 def conv3_img16_bn_fwd(x, w_packed, bias, gamma, beta, act, out_dtype, Cout, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, skip=None,

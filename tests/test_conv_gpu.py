@@ -457,13 +457,14 @@ def test_batchnorm_small_from_split_slabs_equals_sum_then_batchnorm(dtype, shape
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('geom', [(8, 64, 512), (8, 512, 512), (8, 512, 64), (3, 128, 96), (5, 256, 40)])
-def test_conv3_img16_bn_one_launch_layer_matches_two_launches(dtype, geom):
+def test_conv3_img16_bn_one_launch_layer_matches_two_launches(dtype, geom, monkeypatch):
     """vs_conv3_img16_bn_fwd / _bwd (convolution + BatchNorm of a ConvResBlock layer in ONE launch; partial sums of the input-channel splits and
     the per-map statistics exchanged inside the launch) against vs_conv3_img16 + vs_bn_train_fwd_small_slabs / vs_bn_act_bwd_small_ex: z bit for
     bit (same sums in the same order), statistics to 2e-6, y / dz equal except isolated values on a rounding boundary, running estimates and
     parameter gradients to 1e-5; the 64 -> 512, 512 -> 512 (two splits) and 512 -> 64 (eight splits) geometries of the SST integrator, ragged
     channel tiles, a repeated launch (new epoch) bit-identical, no exchange time-out."""
     from spatiotemporal_variable_separation_amd import ops
+    monkeypatch.setenv('VS_IMG_BN_SPLITS', '1,2,8')           # (the default serves unsplit layers only: see ops.conv3_img16_bn_supported)
     B, Cin, Cout = geom
     if not ops.conv3_img16_bn_supported(B, Cin, Cout, dtype):
         pytest.skip('geometry not served by the one-launch layer')
@@ -476,10 +477,11 @@ def test_conv3_img16_bn_one_launch_layer_matches_two_launches(dtype, geom):
     rm1, rv1 = _rand((Cout,), 607, 0.1).cuda(), (1 + _rand((Cout,), 608, 0.2)).cuda()
     rm2, rv2 = rm1.clone(), rv1.clone()
     slabs = ops.conv3_img16(x, wp, Cout)
-    y0, z0, m0, i0, xn0, xn16_0 = ops.bn_train_fwd_small_slabs(slabs, bias, dtype, gamma, beta, 'leaky_relu', torch.float32, rm1, rv1, 0.1, 1e-5, skip=skip, want16=True)
-    y1, z1, m1, i1, xn1, xn16_1 = ops.conv3_img16_bn_fwd(x, wp, bias, gamma, beta, 'leaky_relu', torch.float32, Cout, rm2, rv2, 0.1, 1e-5, skip=skip, want16=True)
+    # the block's last layer: no activation, fp32 output, skip added
+    y0, z0, m0, i0, xn0, xn16_0 = ops.bn_train_fwd_small_slabs(slabs, bias, dtype, gamma, beta, 'none', torch.float32, rm1, rv1, 0.1, 1e-5, skip=skip, want16=True)
+    y1, z1, m1, i1, xn1, xn16_1 = ops.conv3_img16_bn_fwd(x, wp, bias, gamma, beta, 'none', torch.float32, Cout, rm2, rv2, 0.1, 1e-5, skip=skip, want16=True)
     rm3, rv3 = rm2.clone(), rv2.clone()
-    again = ops.conv3_img16_bn_fwd(x, wp, bias, gamma, beta, 'leaky_relu', torch.float32, Cout, rm3, rv3, 0.1, 1e-5, skip=skip, want16=True)
+    again = ops.conv3_img16_bn_fwd(x, wp, bias, gamma, beta, 'none', torch.float32, Cout, rm3, rv3, 0.1, 1e-5, skip=skip, want16=True)
     torch.cuda.synchronize()
     assert ops.rollout_exchange_error(x.device) == 0
     assert torch.equal(z1, z0)
@@ -534,6 +536,7 @@ def test_fused_conv_res_block_equals_layer_by_layer(precision, mode, monkeypatch
         x0 = _rand((4, 64, 16, 16), 81).cuda()
         ga, gb = _rand((4, 64, 16, 16), 82).cuda(), _rand((4, 64, 16, 16), 83).cuda()
         outs = []
+        monkeypatch.setenv('VS_IMG_BN_SPLITS', '1,2,8')
         for fused, m in ((mode, net), ('0', ref)):
             monkeypatch.setenv('VARSEP_FUSED_RESBLOCK', fused)
             x = x0.clone().requires_grad_(True)
