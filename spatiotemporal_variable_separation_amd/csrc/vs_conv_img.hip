@@ -426,13 +426,15 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
         for (int k = 0; k < N; ++k) { const float d = zv[k] - mb; q += d * d; }
         gq = group_sum(q);                                                       // centred sum of squares
     } else {
-        unsigned short zin[N];
+        // (32-bit destinations: two 16-bit loads packed into one register are a d16 / d16_hi pair, the second of which MERGES into the
+        //  register the first one is still writing -- the compiler then waits for every load: 32 serial HBM round trips, 15 us)
+        unsigned zin[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) zin[i] = m0 + i < p.Cout ? p.z[pix0 + (int64_t)i * 256] : (unsigned short)0;     // (all loads in flight together)
+        for (int i = 0; i < N; ++i) zin[i] = m0 + i < p.Cout ? (unsigned)p.z[pix0 + (int64_t)i * 256] : 0u;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const bool live = m0 + i < p.Cout;
-            const float xv = vs_h2f(zin[i], CT);
+            const float xv = vs_h2f((unsigned short)zin[i], CT);
             const float xh = (xv - par[96 + i]) * par[128 + i];
             const float pre = xh * par[32 + i] + par[64 + i];
             const float dzp = live ? R[i] * (ACT == VS_ACT_LEAKY ? (pre > 0.f ? 1.f : 0.2f) : 1.f) : 0.f;

