@@ -182,32 +182,38 @@ def flush_bn_call_counts():
 # ---- backward in two segments (train.GraphedStep under a reducer) --------------------------------------------------------------------
 # The decoder is the LAST thing the forward pass runs and the FIRST thing backward finishes: once its parameters' gradients are complete the
 # all-reduce of their bucket can travel while the integrator's and the encoders' backward passes still run.  A recorded step cannot fire
-# hooks, so the recording is split there: segment 1 = forward + the part of backward that ends at the decoder's inputs
-# (`torch.autograd.backward(total, inputs=decoder parameters + the tensors noted here)`), segment 2 = the rest, started from those tensors'
-# gradients.  `cut(x)` notes a tensor that enters the decoder (called by SeparableNetwork.get_forecast and train.compute_losses); it returns x
-# itself -- no node is added to the autograd graph.
-_CUTS = {'on': False, 'tensors': {}}
+# hooks, so the recording is split there.  `cut(x)` (called on every tensor that enters the decoder: SeparableNetwork.get_forecast,
+# train.compute_losses) hands the decoder a DETACHED leaf of x and remembers the pair: the decoder's part of the autograd graph then hangs off
+# those leaves.  Segment 1 = forward + `backward(total, inputs=decoder parameters + leaves)` (the loss heads and the decoder);
+# segment 2 = `backward([total] + originals, [d total] + [leaf.grad ...], inputs=the other parameters)`: the leaves' gradients enter the
+# originals, and `total` contributes what reaches the encoders / the integrator without passing the decoder (the code regularisers).
+# (Passing the decoder inputs THEMSELVES as `inputs=` of the first call is wrong whenever one of them is an ancestor of another -- the skip
+# connections: h3 feeds the code -- because `inputs=` asks for total derivatives, and the second call would add the path through the
+# code a second time.  A true cut needs leaves.)
+_CUTS = {'on': False, 'pairs': {}}
 
 
 def collect_cuts(flag):
     _CUTS['on'] = bool(flag)
-    _CUTS['tensors'] = {}
+    _CUTS['pairs'] = {}
 
 
 def cut(x):
+    """x, or -- while a two-segment backward is being recorded -- a detached leaf standing in for it (tensors, lists / tuples of tensors)."""
     if not _CUTS['on'] or x is None:
         return x
     if isinstance(x, (list, tuple)):
-        for t in x:
-            cut(t)
-        return x
+        return type(x)(cut(t) for t in x)
     if isinstance(x, torch.Tensor) and x.requires_grad and x.grad_fn is not None:
-        _CUTS['tensors'].setdefault(id(x), x)
+        ent = _CUTS['pairs'].get(id(x))
+        if ent is None:
+            ent = _CUTS['pairs'][id(x)] = (x, x.detach().requires_grad_(True))
+        return ent[1]
     return x
 
 
-def cut_tensors():
-    return list(_CUTS['tensors'].values())
+def cut_pairs():
+    return list(_CUTS['pairs'].values())
 
 
 def promise_loss_gradient(t):

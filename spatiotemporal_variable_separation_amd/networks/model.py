@@ -48,8 +48,9 @@ class SeparableNetwork(nn.Module):
                 codes, t_residuals = self._roll(t_code, n_forecast)
                 t_codes = torch.stack(codes, dim=1)
             from .. import functional as VF
-            VF.cut((s_code, t_codes, s_skipco))        # (a recorded data-parallel step splits its backward pass at the decoder's inputs)
-            forecasts = self.decoder.decode_sequence(s_code, t_codes, skip=s_skipco)
+            # (a recorded data-parallel step splits its backward pass at the decoder's inputs: the decoder then sees detached leaves)
+            d_s, d_t, d_skip = VF.cut((s_code, t_codes, s_skipco))
+            forecasts = self.decoder.decode_sequence(d_s, d_t, skip=d_skip)
             return forecasts, t_codes, s_code, t_residuals
 
         # the reference's launch structure: one decoder call per code

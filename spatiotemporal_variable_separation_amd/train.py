@@ -374,14 +374,12 @@ class GraphedStep:
         from . import functional as VF
         fold_was = VF.folding_repeated_gradients()
         if segment == 2:
-            cuts, self._cuts = self._cuts, None
+            (pairs, total, up), self._cuts = self._cuts, None
             VF.set_conv_grad_outputs(self._conv_sinks)
             VF.fold_repeated_gradients(True, flush=False)
             try:
-                torch.autograd.backward(cuts, [c.grad for c in cuts])
+                backward_rest_segment(total, up, self.net, pairs)
             finally:
-                for c in cuts:
-                    c.grad = None
                 VF.set_conv_grad_outputs(None)
                 VF.fold_repeated_gradients(fold_was, flush=False)
             return None
@@ -419,11 +417,7 @@ class GraphedStep:
                                                 l_t, l_pred, avg, t_random=self.t_dev)
             # a resident 1.0 (no ones_like fill per step), or the loss scale of fp16 training (train.py:152 scaler.scale(loss))
             if segment == 1:
-                cuts = VF.cut_tensors()
-                assert cuts, 'segmented backward: no tensor was noted at the decoder\'s inputs'
-                heads = [p for p in self.net.decoder.parameters() if p.requires_grad]
-                torch.autograd.backward(total, up, inputs=heads + cuts, retain_graph=True)
-                self._cuts = cuts
+                self._cuts = (backward_decoder_segment(total, up, self.net), total, up)
             else:
                 total.backward(up)
             from .optim import Adam as HipAdam
@@ -474,6 +468,29 @@ class GraphedStep:
         from . import functional as VF
         VF.note_replay()
         return self.loss
+
+
+def backward_decoder_segment(total, up, sep_net):
+    """First segment of a two-segment backward pass (functional.cut / collect_cuts were on during the forward pass): the loss heads and the
+    decoder.  Afterwards the decoder's parameter gradients are complete and every leaf that stood in for a decoder input holds its gradient.
+    Returns the (original, leaf) pairs for `backward_rest_segment`."""
+    from . import functional as VF
+    pairs = VF.cut_pairs()
+    assert pairs, 'two-segment backward: no tensor was cut at the decoder\'s inputs'
+    heads = [p for p in sep_net.decoder.parameters() if p.requires_grad]
+    torch.autograd.backward(total, up, inputs=heads + [leaf for _, leaf in pairs], retain_graph=True)
+    return pairs
+
+
+def backward_rest_segment(total, up, sep_net, pairs):
+    """Second segment: the leaves' gradients enter the tensors they stood in for, and `total` contributes what reaches the encoders / the
+    integrator without passing the decoder (the code regularisers of train.py:120-149); accumulates into every parameter outside the decoder."""
+    dec = {id(p) for p in sep_net.decoder.parameters()}
+    rest = [p for p in sep_net.parameters() if p.requires_grad and id(p) not in dec]
+    live = [(o, leaf) for o, leaf in pairs if leaf.grad is not None]
+    torch.autograd.backward([total] + [o for o, _ in live], [up] + [leaf.grad for _, leaf in live], inputs=rest)
+    for _, leaf in pairs:
+        leaf.grad = None
 
 
 def local_conv_gradient_sinks(sep_net):
@@ -751,13 +768,14 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
         else:
             s_old, s_recent = _encode_pair(sep_net.Es, full_data[:, :nt_cond], full_data[:, -nt_cond:], skipco)
             t_rand, t_cond = _encode_pair(sep_net.Et, window, cond, False)
+        d_s, d_t = s_old, t_rand
         if cond.is_cuda:
             from . import functional as VF
-            VF.cut((s_old, s_recent, t_rand))      # every tensor through which the losses reach the encoders / the integrator
+            d_s, d_t = VF.cut((s_old, t_rand))     # (two-segment backward of a recorded data-parallel step: the decoder sees detached leaves)
         if skipco:
-            reconstruction = sep_net.decoder(s_old[0], t_rand, skip=s_old[1])
+            reconstruction = sep_net.decoder(d_s[0], d_t, skip=d_s[1])
         else:
-            reconstruction = sep_net.decoder(s_old, t_rand)
+            reconstruction = sep_net.decoder(d_s, d_t)
         fused_mse = os.environ.get('VARSEP_FUSED_FRAME_MSE', '1') == '1' and full_data.dtype == torch.float32
         if fused_mse:
             # both frame losses through the fused kernels (no supervision-frame copy, no slices of full_data)

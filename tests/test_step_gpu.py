@@ -252,3 +252,60 @@ def test_folded_repeated_gradients_equal_autograd_accumulation(name):
     sa, sb = net_a.state_dict(), net_b.state_dict()
     counters = [k for k in sa if k.endswith('num_batches_tracked')]
     assert counters and all(int(sa[k]) == int(sb[k]) for k in counters) and any(int(sb[k]) > 0 for k in counters)   # increments applied
+
+
+@pytest.mark.parametrize('name', ['dcgan_skip_mul', 'sst_skip', 'vgg64_skip', 'vgg32_tiny', 'dcgan_tiny'])
+def test_two_segment_backward_equals_one_backward(name):
+    """The backward pass split at the decoder's inputs (train.backward_decoder_segment / backward_rest_segment: what the recorded data-parallel
+    step replays as two graphs with the decoder buckets' all-reduce in between) against ONE backward call: after the first segment the
+    decoder's gradients are final, after the second every gradient equals the one-call gradient -- including the skip-connection nets, where a
+    decoder input (a skip) is an ancestor of another (the code): the cut is made with detached leaves, not by naming the inputs."""
+    import numpy as np
+    from oracle import cpu_ref
+    from oracle.detdata import det_fill
+    from oracle.golden_configs import make_batch
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.train import backward_decoder_segment, backward_rest_segment, compute_losses
+    cfg = CONFIGS[name]
+    lam, skipco = cfg['lambdas'], bool(cfg.get('skipco', False))
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    t_random = int(load_golden(name)['t_random'])
+    o_net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'])
+
+    def fresh():
+        net = build_sep_net(cfg)
+        net.load_state_dict(o_net.state_dict())
+        return net.cuda().train()
+
+    def losses(net):
+        return compute_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], skipco, lam['ae'], lam['s'], lam['t'], lam['pred'],
+                              average_tloss=bool(cfg.get('average_tloss')), t_random=t_random)[0]
+    with VF.precision('fp32'):
+        a = fresh()
+        losses(a).backward()
+        b = fresh()
+        VF.collect_cuts(True)
+        try:
+            total = losses(b)
+            up = torch.ones((), device='cuda')
+            pairs = backward_decoder_segment(total, up, b)
+        finally:
+            VF.collect_cuts(False)
+        ga = dict(a.named_parameters())
+        for k, p in b.named_parameters():           # decoder complete, nothing else touched yet
+            if k.startswith('decoder.'):
+                assert (p.grad is None) == (ga[k].grad is None), k
+                if p.grad is not None:
+                    torch.testing.assert_close(p.grad, ga[k].grad, rtol=2e-4, atol=1e-6, msg=k)
+            else:
+                assert p.grad is None, k
+        backward_rest_segment(total, up, b, pairs)
+    torch.cuda.synchronize()
+    for k, p in b.named_parameters():
+        if ga[k].grad is None:
+            assert p.grad is None, k
+            continue
+        scale = max(ga[k].grad.abs().max().item(), 1e-12)
+        assert p.grad is not None and ((p.grad - ga[k].grad).abs().max().item() <= 2e-4 * scale + 1e-7), (k, (p.grad - ga[k].grad).abs().max().item(), scale)
