@@ -32,7 +32,7 @@ GROUPS = [
     ('vs_gemm_adam', r'^vs_gemm_adam<', r'gemm_mid_kernel<\d, \d, \d, \w+, \d+, true>', 'hbm'),
     ('vs_mlp_rollout_fwd', r'^vs_mlp_rollout_fwd<', r'rollout_(ws|fwd)_kernel<\d+, true|rollout_fwd_kernel', 'mfma'),
     ('vs_mlp_rollout_bwd', r'^vs_mlp_rollout_bwd<', r'rollout_ws_kernel<\d+, false|rollout_bwd_kernel', 'mfma'),
-    ('vs_conv_k4s2', r'^vs_conv_k4s2:|^vs_space_to_depth2', r'conv3_band_kernel<\d, \d+, \d+, \d, 1>|wgrad3_band_kernel<\d, \d+, \d, 1>|space_to_depth2_kernel|'
+    ('vs_conv_k4s2', r'^vs_conv_k4s2:|^vs_space_to_depth2', r'conv3_band_kernel<\d, \d+, \d+, \d, 1>|wgrad3_band_kernel<\d, \d+, \d, 1(, \d)?>|space_to_depth2_kernel|'
      r'::k4s2_\w+_kernel', 'mfma'),
     ('vs_conv3_img16_bn', r'^vs_conv3_img16_bn:', r'conv3_img16_bn_kernel|exchange_epoch_advance', 'mfma'),
     ('vs_conv3_img16', r'^vs_conv3_img16:', r'conv3_img16_kernel|(?<!grouped_)slab_sum_kernel', 'mfma'),
