@@ -419,6 +419,20 @@ int vs_frames_sse_fwd(const float* frames, const float* full, const int32_t* idx
 int vs_frames_sse_bwd(const float* frames, const float* full, const int32_t* idx, int64_t B, int G, int T, int64_t D, const float* coef,
                       float* dframes, void* stream);
 
+/* Round 4: the conv families' code losses and the weighted total in one pass (reference train.py:38-42 zero_order_loss -- with skip connections
+ * over the code and every skip tensor --, :141-149 t_reg and total): pairs (a[j], b[j]) of count[j] elements (a multiple of 8, 16-byte aligned,
+ * fp32 or 16-bit: read where they lie, no concatenation), t0 [t_count] fp32, the raw sums of vs_frames_sse_fwd for the two frame terms.
+ *   _fwd   out[0..4] = total, ae, zero, pred, t_reg; partial: vs_code_losses_chunks() floats (per-chunk sums, finished in a fixed order)
+ *   _bwd   for the upstream gradient g[0] (device): da[j] / db[j] (NULL: not wanted) in dtype[j], dt0, and coefs[4] = the coefficient pairs
+ *          vs_frames_sse_bwd takes for the auto-encoding and the forecast frame stacks.  One launch. */
+int64_t vs_code_losses_chunks(int n_pairs, const int64_t* count, int64_t t_count);
+int vs_code_losses_fwd(int n_pairs, const void* const* a, const void* const* b, const int* dtype, const int64_t* count, const float* t0, int64_t t_count,
+                       const float* sse_ae, const float* sse_pred, float scale_ae, float scale_pred, float l_ae, float l_s, float l_pred, float l_t,
+                       float inv_s, float inv_t, float* partial, float* out, void* stream);
+int vs_code_losses_bwd(int n_pairs, const void* const* a, const void* const* b, void* const* da, void* const* db, const int* dtype, const int64_t* count,
+                       const float* t0, float* dt0, int64_t t_count, const float* g, float scale_ae, float scale_pred, float l_ae, float l_s, float l_pred,
+                       float l_t, float inv_s, float inv_t, float* coefs, void* stream);
+
 /* dz[i] = dy[i] * act'(y[i]) evaluated from the activation OUTPUT y (see vs_gemm mask semantics).
  * Backward of the trailing activation of a chain (mlp_encdec.py:49 last_activation, conv.py:230).  */
 int vs_act_bwd(const void* dy, int dy_dtype, const void* y, int y_dtype, void* dz, int dz_dtype, int act,

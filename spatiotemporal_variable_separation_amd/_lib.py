@@ -127,6 +127,9 @@ SIGNATURES = {
     'vs_pack_rollout_weights': (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'vs_frames_sse_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp]),
     'vs_frames_sse_bwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp]),
+    'vs_code_losses_chunks': (_i64, [_i32, _vp, _i64]),
+    'vs_code_losses_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
+    'vs_code_losses_bwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     'vs_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     'vs_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     'vs_conv_wgrad_workspace_bytes': (_sz, [_i32] * 7),

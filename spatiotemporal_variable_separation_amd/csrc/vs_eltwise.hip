@@ -675,6 +675,207 @@ extern "C" int vs_frames_sse_bwd(const float* frames, const float* full, const i
     return VS_OK;
 }
 
+// ---- the conv families' code losses and the weighted total in one pass (reference train.py:38-42, 141-149) ---------------------------------
+// zero-order loss mean((s_old - s_new)^2) -- with skip connections over the code AND every skip tensor (element-count weighted, i.e. one mean
+// over their concatenation) --, the temporal regulariser 0.5 sum t0^2 / N_t and total = l_ae ae + l_s zero + l_pred pred + l_t t_reg, with ae /
+// pred taken from the frame kernels' raw sums.  As torch ops that is two concatenations of all skips (SST: 2 x 16 MB), sub / pow / mean, a dozen
+// scalar launches and as many again backward -- ~45 launches of 4-50 us per step.  Here: the pairs are read where they lie (fp32 or 16-bit),
+// one workgroup per 4096-element chunk leaves a partial sum, a one-block launch finishes (fixed order: reproducible); backward is ONE launch
+// that writes d s_old / d s_new in their own types, d t0, and the two coefficients vs_frames_sse_bwd takes.
+namespace {
+constexpr int CL_MAX_PAIRS = 10, CL_CHUNK = 4096;
+struct CodeLossJobs {
+    const void* a[CL_MAX_PAIRS];
+    const void* b[CL_MAX_PAIRS];
+    void* da[CL_MAX_PAIRS];
+    void* db[CL_MAX_PAIRS];
+    int dtype[CL_MAX_PAIRS];
+    int64_t count[CL_MAX_PAIRS];
+    int first_chunk[CL_MAX_PAIRS + 1];          // chunks [first_chunk[j], first_chunk[j + 1]) belong to pair j
+    int n_pairs;
+    const float* t0;
+    float* dt0;
+    int64_t t_count;
+    int n_chunks;                               // pair chunks, then the chunks of t0
+};
+
+__device__ __forceinline__ void cl_load8(const void* p, int dtype, int64_t i, float (&v)[8]) {
+    if (dtype == VS_F32) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>((const float*)p + i), hi = *reinterpret_cast<const f32x4*>((const float*)p + i + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[j + 4] = hi[j]; }
+    } else {
+        const u16x8 r = *reinterpret_cast<const u16x8*>((const unsigned short*)p + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = vs_h2f(r[j], dtype);
+    }
+}
+__device__ __forceinline__ void cl_store8(void* p, int dtype, int64_t i, const float (&v)[8]) {
+    if (dtype == VS_F32) {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lo[j] = v[j]; hi[j] = v[j + 4]; }
+        *reinterpret_cast<f32x4*>((float*)p + i) = lo;
+        *reinterpret_cast<f32x4*>((float*)p + i + 4) = hi;
+    } else {
+        u16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = vs_f2h(v[j], dtype);
+        *reinterpret_cast<u16x8*>((unsigned short*)p + i) = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void code_losses_partial_kernel(CodeLossJobs J, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int chunk = blockIdx.x;
+    float s = 0.f;
+    if (chunk < J.first_chunk[J.n_pairs]) {
+        int j = 0;
+        while (chunk >= J.first_chunk[j + 1]) ++j;
+        const int64_t base = (int64_t)(chunk - J.first_chunk[j]) * CL_CHUNK;
+#pragma unroll
+        for (int r = 0; r < CL_CHUNK / (256 * 8); ++r) {
+            const int64_t i = base + (int64_t)(r * 256 + threadIdx.x) * 8;
+            if (i < J.count[j]) {                                            // (count is a multiple of 8)
+                float a[8], b[8];
+                cl_load8(J.a[j], J.dtype[j], i, a);
+                cl_load8(J.b[j], J.dtype[j], i, b);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = a[k] - b[k]; s += d * d; }
+            }
+        }
+    } else {
+        const int64_t base = (int64_t)(chunk - J.first_chunk[J.n_pairs]) * CL_CHUNK;
+        for (int e = threadIdx.x; e < CL_CHUNK; e += 256) {
+            const int64_t i = base + e;
+            if (i < J.t_count) { const float t = J.t0[i]; s += t * t; }
+        }
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) partial[chunk] = s;
+}
+
+struct CodeLossScal { float l_ae, l_s, l_pred, l_t, scale_ae, scale_pred, inv_s, inv_t; };
+
+// out[0..4] = total, ae, zero, pred, t_reg
+__global__ __launch_bounds__(256) void code_losses_finish_kernel(const float* __restrict__ partial, int n_pair_chunks, int n_chunks, const float* sse_ae,
+                                                                 const float* sse_pred, CodeLossScal c, float* __restrict__ out) {
+    __shared__ double red[2][256];
+    double z = 0.0, t = 0.0;
+    for (int i = threadIdx.x; i < n_pair_chunks; i += 256) z += (double)partial[i];
+    for (int i = n_pair_chunks + threadIdx.x; i < n_chunks; i += 256) t += (double)partial[i];
+    red[0][threadIdx.x] = z;
+    red[1][threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; ++i) { z += red[0][i]; t += red[1][i]; }     // fixed order
+        const float ae = (sse_ae[0] + sse_ae[1]) * c.scale_ae, pred = (sse_pred[0] + sse_pred[1]) * c.scale_pred;
+        const float zero = (float)(z * (double)c.inv_s), treg = (float)(0.5 * t * (double)c.inv_t);
+        out[0] = c.l_ae * ae + c.l_s * zero + c.l_pred * pred + c.l_t * treg;
+        out[1] = ae;
+        out[2] = zero;
+        out[3] = pred;
+        out[4] = treg;
+    }
+}
+
+// coefs[0..1] = g l_ae 2 scale_ae (the auto-encoding frame stack), coefs[2..3] = g l_pred 2 scale_pred: what vs_frames_sse_bwd multiplies (y - target) by
+__global__ __launch_bounds__(256) void code_losses_bwd_kernel(CodeLossJobs J, const float* __restrict__ g, CodeLossScal c, float* __restrict__ coefs) {
+    const int chunk = blockIdx.x;
+    const float up = g[0];
+    if (chunk == 0 && threadIdx.x == 0) {
+        coefs[0] = coefs[1] = up * c.l_ae * 2.f * c.scale_ae;
+        coefs[2] = coefs[3] = up * c.l_pred * 2.f * c.scale_pred;
+    }
+    if (chunk < J.first_chunk[J.n_pairs]) {
+        int j = 0;
+        while (chunk >= J.first_chunk[j + 1]) ++j;
+        const float k = up * c.l_s * 2.f * c.inv_s;
+        const int64_t base = (int64_t)(chunk - J.first_chunk[j]) * CL_CHUNK;
+#pragma unroll
+        for (int r = 0; r < CL_CHUNK / (256 * 8); ++r) {
+            const int64_t i = base + (int64_t)(r * 256 + threadIdx.x) * 8;
+            if (i < J.count[j]) {
+                float a[8], b[8], d[8], e[8];
+                cl_load8(J.a[j], J.dtype[j], i, a);
+                cl_load8(J.b[j], J.dtype[j], i, b);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { d[q] = k * (a[q] - b[q]); e[q] = -d[q]; }
+                if (J.da[j]) cl_store8(J.da[j], J.dtype[j], i, d);
+                if (J.db[j]) cl_store8(J.db[j], J.dtype[j], i, e);
+            }
+        }
+    } else if (J.dt0) {
+        const float k = up * c.l_t * c.inv_t;                                    // d/dt of 0.5 t^2 / N_t
+        const int64_t base = (int64_t)(chunk - J.first_chunk[J.n_pairs]) * CL_CHUNK;
+        for (int e = threadIdx.x; e < CL_CHUNK; e += 256) {
+            const int64_t i = base + e;
+            if (i < J.t_count) J.dt0[i] = k * J.t0[i];
+        }
+    }
+}
+
+int cl_fill(CodeLossJobs& J, int n_pairs, const void* const* a, const void* const* b, void* const* da, void* const* db, const int* dtype, const int64_t* count,
+            const float* t0, float* dt0, int64_t t_count) {
+    if (n_pairs < 0 || n_pairs > CL_MAX_PAIRS || t_count < 0 || (t_count > 0 && !t0)) return -1;
+    J.n_pairs = n_pairs;
+    int64_t chunks = 0;
+    for (int j = 0; j < n_pairs; ++j) {
+        if (!a[j] || !b[j] || !vs_dtype_ok(dtype[j]) || count[j] <= 0 || count[j] % 8 != 0 || ((uintptr_t)a[j] | (uintptr_t)b[j]) % 16 != 0) return -1;
+        if (da && da[j] && (uintptr_t)da[j] % 16 != 0) return -1;
+        if (db && db[j] && (uintptr_t)db[j] % 16 != 0) return -1;
+        J.a[j] = a[j]; J.b[j] = b[j]; J.da[j] = da ? da[j] : nullptr; J.db[j] = db ? db[j] : nullptr;
+        J.dtype[j] = dtype[j]; J.count[j] = count[j];
+        J.first_chunk[j] = (int)chunks;
+        chunks += vs_cdiv(count[j], CL_CHUNK);
+    }
+    J.first_chunk[n_pairs] = (int)chunks;
+    J.t0 = t0; J.dt0 = dt0; J.t_count = t_count;
+    chunks += vs_cdiv(t_count, CL_CHUNK);
+    if (chunks < 1 || chunks > (1 << 22)) return -1;
+    J.n_chunks = (int)chunks;
+    return 0;
+}
+}  // namespace
+
+// chunks = rows of `partial` vs_code_losses_fwd needs
+extern "C" int64_t vs_code_losses_chunks(int n_pairs, const int64_t* count, int64_t t_count) {
+    int64_t c = vs_cdiv(t_count > 0 ? t_count : 0, CL_CHUNK);
+    for (int j = 0; j < n_pairs; ++j) c += vs_cdiv(count[j], CL_CHUNK);
+    return c;
+}
+
+// out[0..4] = total, ae, zero, pred, t_reg.  Pairs (a[j], b[j]): count[j] elements (a multiple of 8) of dtype[j], 16-byte aligned; t0: t_count
+// fp32 elements; sse_ae / sse_pred: the [2] raw sums of vs_frames_sse_fwd; scale_* = 1 / elements of each frame mean; inv_s = 1 / sum of the
+// pair counts; inv_t = 1 / N_t (train.py:141-146: B x positions, or all elements with average_tloss).
+extern "C" int vs_code_losses_fwd(int n_pairs, const void* const* a, const void* const* b, const int* dtype, const int64_t* count, const float* t0,
+                                  int64_t t_count, const float* sse_ae, const float* sse_pred, float scale_ae, float scale_pred, float l_ae, float l_s,
+                                  float l_pred, float l_t, float inv_s, float inv_t, float* partial, float* out, void* stream) {
+    CodeLossJobs J = {};
+    VS_CHECK_ARG(sse_ae && sse_pred && partial && out && cl_fill(J, n_pairs, a, b, nullptr, nullptr, dtype, count, t0, nullptr, t_count) == 0,
+                 "vs_code_losses_fwd: bad argument (<= 10 pairs, counts multiples of 8, 16-byte aligned)");
+    const CodeLossScal c = {l_ae, l_s, l_pred, l_t, scale_ae, scale_pred, inv_s, inv_t};
+    hipLaunchKernelGGL(code_losses_partial_kernel, dim3((unsigned)J.n_chunks), dim3(256), 0, (hipStream_t)stream, J, partial);
+    hipLaunchKernelGGL(code_losses_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, J.first_chunk[n_pairs], J.n_chunks, sse_ae, sse_pred, c,
+                       out);
+    VS_CHECK_LAUNCH("vs_code_losses_fwd");
+    return VS_OK;
+}
+
+// Gradients of `total` for the upstream gradient g[0] (device): da[j] / db[j] (either may be NULL) in dtype[j], dt0 (fp32, may be NULL), and
+// coefs[4] = the coefficient pairs vs_frames_sse_bwd takes for the auto-encoding / forecast frame stacks.
+extern "C" int vs_code_losses_bwd(int n_pairs, const void* const* a, const void* const* b, void* const* da, void* const* db, const int* dtype,
+                                  const int64_t* count, const float* t0, float* dt0, int64_t t_count, const float* g, float scale_ae, float scale_pred,
+                                  float l_ae, float l_s, float l_pred, float l_t, float inv_s, float inv_t, float* coefs, void* stream) {
+    CodeLossJobs J = {};
+    VS_CHECK_ARG(g && coefs && cl_fill(J, n_pairs, a, b, da, db, dtype, count, t0, dt0, t_count) == 0,
+                 "vs_code_losses_bwd: bad argument (<= 10 pairs, counts multiples of 8, 16-byte aligned)");
+    const CodeLossScal c = {l_ae, l_s, l_pred, l_t, scale_ae, scale_pred, inv_s, inv_t};
+    hipLaunchKernelGGL(code_losses_bwd_kernel, dim3((unsigned)J.n_chunks), dim3(256), 0, (hipStream_t)stream, J, g, c, coefs);
+    VS_CHECK_LAUNCH("vs_code_losses_bwd");
+    return VS_OK;
+}
+
 extern "C" int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dtype, const int64_t* ldx, const int64_t* M, const int64_t* N,
                                float* const* out, float* zero_base, int64_t zero_count, void* stream) {
     VS_CHECK_ARG(n_jobs >= 1 && n_jobs <= CS_MAXJ && X && x_dtype && ldx && M && N && out, "vs_colsum_multi: bad argument (1..%d jobs)", CS_MAXJ);

@@ -1638,6 +1638,75 @@ def frames_mse(frames, full, idx):
     return FramesMSE.apply(frames.reshape(B, G, -1).contiguous().float(), flat.float(), idx)
 
 
+class ConvLosses(torch.autograd.Function):
+    """The four losses of a conv-family step and their weighted sum (train.py:85-86, 38-42, 139-149) in 4 launches forward (two frame-sum
+    kernels, the code-loss partials, a one-block finish) and 3 backward (one launch for every code gradient and the frame coefficients, the two
+    frame kernels) -- instead of frames_mse x 2 + zero_order_loss (two concatenations of every skip tensor with skip connections) + ~30
+    scalar / reduction launches each way.  apply(recon [B, 1, D], fore [B, G, D], full [B, T, D], ae_idx, f_idx, t0, meta, a_1, b_1, ..., a_k,
+    b_k) -> (total, ae, zero, pred, t_reg); meta = (lambdas (ae, s, t, pred), inv_t).  Only `total` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, recon, fore, full, ae_idx, f_idx, t0, meta, *flat):
+        lambdas, inv_t = meta
+        pairs = [(flat[2 * j].detach(), flat[2 * j + 1].detach()) for j in range(len(flat) // 2)]
+        sse_ae = ops.frames_sse_fwd(recon, full, ae_idx)
+        sse_pred = ops.frames_sse_fwd(fore, full, f_idx)
+        scale_ae, scale_pred = 1.0 / recon.numel(), 1.0 / fore.numel()
+        out = ops.code_losses_fwd(pairs, t0.detach(), sse_ae, sse_pred, scale_ae, scale_pred, lambdas, inv_t)
+        ctx.save_for_backward(recon, fore, full, ae_idx, f_idx, t0, *flat)
+        ctx.meta = (tuple(float(v) for v in lambdas), float(inv_t), scale_ae, scale_pred)
+        ctx.set_materialize_grads(False)
+        total, ae, zero, pred, treg = out[0], out[1], out[2], out[3], out[4]
+        ctx.mark_non_differentiable(ae, zero, pred, treg)
+        return total, ae, zero, pred, treg
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        recon, fore, full, ae_idx, f_idx, t0 = ctx.saved_tensors[:6]
+        flat = ctx.saved_tensors[6:]
+        lambdas, inv_t, scale_ae, scale_pred = ctx.meta
+        if g is None:
+            return (None,) * (7 + len(flat))
+        pairs = [(flat[2 * j].detach(), flat[2 * j + 1].detach()) for j in range(len(flat) // 2)]
+        need = [(ctx.needs_input_grad[7 + 2 * j], ctx.needs_input_grad[8 + 2 * j]) for j in range(len(pairs))]
+        da, db, dt0, coefs = ops.code_losses_bwd(pairs, need, t0.detach(), g.detach().float().reshape(1), scale_ae, scale_pred, lambdas, inv_t)
+        d_recon = ops.frames_sse_bwd(recon, full, ae_idx, coefs[0:2]) if ctx.needs_input_grad[0] else None
+        d_fore = ops.frames_sse_bwd(fore, full, f_idx, coefs[2:4]) if ctx.needs_input_grad[1] else None
+        grads = []
+        for j in range(len(pairs)):
+            grads += [da[j], db[j]]
+        return (d_recon, d_fore, None, None, None, dt0 if ctx.needs_input_grad[5] else None, None) + tuple(grads)
+
+
+def conv_losses(reconstruction, forecasts, full_data, ae_idx, f_idx, s_old, s_new, skipco, t0, lambdas, average_tloss):
+    """(total, {'ae', 'zero', 'pred', 't_reg'}) through ConvLosses, or None when the fused kernels do not take these tensors (the caller then
+    assembles the losses from torch ops as before).  lambdas = (ae, s, t, pred)."""
+    B, T = full_data.shape[0], full_data.shape[1]
+    flat = full_data.reshape(B, T, -1)
+    if not flat.is_contiguous():
+        flat = flat.contiguous()
+    if flat.dtype != torch.float32 or t0.dtype != torch.float32:
+        return None
+    if skipco:
+        olds, news = [s_old[0]] + list(s_old[1]), [s_new[0]] + list(s_new[1])
+    else:
+        olds, news = [s_old], [s_new]
+    pairs = [(a.contiguous(), b.contiguous()) for a, b in zip(olds, news)]
+    t0c = t0.contiguous()
+    if not ops.code_losses_supported([(a.detach(), b.detach()) for a, b in pairs], t0c.detach()):
+        return None
+    G = f_idx.numel()
+    recon = reconstruction.reshape(B, 1, -1).contiguous().float()
+    fore = forecasts.reshape(B, G, -1).contiguous().float()
+    # train.py:141-146: 0.5 * mean over all elements, or 0.5 * sum over dim 1, mean over the rest
+    inv_t = 1.0 / t0c.numel() if average_tloss else float(t0c.shape[1]) / t0c.numel()
+    flat_pairs = []
+    for a, b in pairs:
+        flat_pairs += [a, b]
+    total, ae, zero, pred, treg = ConvLosses.apply(recon, fore, flat, ae_idx, f_idx, t0c, (tuple(lambdas), inv_t), *flat_pairs)
+    return total, {'ae': ae, 'zero': zero, 'pred': pred, 't_reg': treg}
+
+
 # ------------------------------------------------------------------------------------------------ all training losses
 class TrainLosses(torch.autograd.Function):
     """total = l_ae*ae + l_s*zero + l_pred*pred + l_t*t_reg and the four terms (train.py:117-149) from the decoded frame stack

@@ -1621,6 +1621,63 @@ def frames_sse_bwd(frames, full, idx, coef):
     return out
 
 
+def _code_loss_tables(pairs):
+    import ctypes
+    n = len(pairs)
+    VP, I32, I64 = ctypes.c_void_p * max(n, 1), ctypes.c_int32 * max(n, 1), ctypes.c_int64 * max(n, 1)
+    return n, VP, I32(*([dtype_code(a) for a, _ in pairs] or [0])), I64(*([a.numel() for a, _ in pairs] or [0]))
+
+
+def code_losses_supported(pairs, t0):
+    """Whether the fused code-loss kernels take these (a, b) pairs: <= 10 of them, equal shapes / types, contiguous, element counts multiples of 8."""
+    if len(pairs) > 10 or t0 is None or t0.dtype != torch.float32 or not t0.is_contiguous() or not t0.is_cuda:
+        return False
+    for a, b in pairs:
+        if (a.shape != b.shape or a.dtype != b.dtype or not a.is_cuda or not a.is_contiguous() or not b.is_contiguous() or a.numel() % 8 != 0
+                or a.numel() == 0 or a.dtype not in (torch.float32, torch.bfloat16, torch.float16) or a.data_ptr() % 16 or b.data_ptr() % 16):
+            return False
+    return True
+
+
+def code_losses_fwd(pairs, t0, sse_ae, sse_pred, scale_ae, scale_pred, lambdas, inv_t):
+    """out [5] = (total, ae, zero, pred, t_reg) from the pairs of the zero-order loss, the initial temporal code and the raw frame sums
+    (vs_code_losses_fwd: a partial-sum launch over 4096-element chunks + a one-block finish)."""
+    require_cuda(t0, sse_ae, sse_pred)
+    lib = _lib.load_library()
+    n, VP, dts, cnts = _code_loss_tables(pairs)
+    total = sum(a.numel() for a, _ in pairs)
+    chunks = lib.vs_code_losses_chunks(n, cnts, t0.numel())
+    partial = torch.empty((max(int(chunks), 1),), dtype=torch.float32, device=t0.device)
+    out = torch.empty((5,), dtype=torch.float32, device=t0.device)
+    l_ae, l_s, l_t, l_pred = (float(v) for v in lambdas)
+    e0 = _pb()
+    check(lib.vs_code_losses_fwd(n, VP(*([a.data_ptr() for a, _ in pairs] or [0])), VP(*([b.data_ptr() for _, b in pairs] or [0])), dts, cnts, t0.data_ptr(),
+                                 t0.numel(), sse_ae.data_ptr(), sse_pred.data_ptr(), float(scale_ae), float(scale_pred), l_ae, l_s, l_pred, l_t,
+                                 1.0 / max(total, 1), float(inv_t), partial.data_ptr(), out.data_ptr(), stream_ptr()), 'vs_code_losses_fwd')
+    _pe(e0, 'vs_code_losses_fwd', nbytes=float(sum(2 * a.numel() * a.element_size() for a, _ in pairs) + t0.numel() * 4))
+    return out
+
+
+def code_losses_bwd(pairs, need, t0, g, scale_ae, scale_pred, lambdas, inv_t):
+    """(d a_j or None, d b_j or None per pair, d t0, coefs [4]) for the upstream gradient g (one fp32 element on the device); need[j] = (bool, bool)."""
+    require_cuda(t0, g)
+    lib = _lib.load_library()
+    n, VP, dts, cnts = _code_loss_tables(pairs)
+    total = sum(a.numel() for a, _ in pairs)
+    da = [torch.empty_like(a) if need[j][0] else None for j, (a, _) in enumerate(pairs)]
+    db = [torch.empty_like(b) if need[j][1] else None for j, (_, b) in enumerate(pairs)]
+    dt0 = torch.empty_like(t0)
+    coefs = torch.empty((4,), dtype=torch.float32, device=t0.device)
+    l_ae, l_s, l_t, l_pred = (float(v) for v in lambdas)
+    e0 = _pb()
+    check(lib.vs_code_losses_bwd(n, VP(*([a.data_ptr() for a, _ in pairs] or [0])), VP(*([b.data_ptr() for _, b in pairs] or [0])),
+                                 VP(*([_ptr(t) for t in da] or [0])), VP(*([_ptr(t) for t in db] or [0])), dts, cnts, t0.data_ptr(), dt0.data_ptr(), t0.numel(),
+                                 g.data_ptr(), float(scale_ae), float(scale_pred), l_ae, l_s, l_pred, l_t, 1.0 / max(total, 1), float(inv_t), coefs.data_ptr(),
+                                 stream_ptr()), 'vs_code_losses_bwd')
+    _pe(e0, 'vs_code_losses_bwd', nbytes=float(sum(4 * a.numel() * a.element_size() for a, _ in pairs) + t0.numel() * 8))
+    return da, db, dt0, coefs
+
+
 # ------------------------------------------------------------------------------------------------ fp16 loss scaling
 def check_finite_multi(grads, scale_state):
     """scale_state[1] (found_inf) = 1 when any gradient tensor holds an inf / NaN; one launch per 64 tensors."""

@@ -777,23 +777,35 @@ def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb
         else:
             reconstruction = sep_net.decoder(d_s, d_t)
         fused_mse = os.environ.get('VARSEP_FUSED_FRAME_MSE', '1') == '1' and full_data.dtype == torch.float32
+        ae_idx = None
         if fused_mse:
-            # both frame losses through the fused kernels (no supervision-frame copy, no slices of full_data)
             from . import functional as VF
             if isinstance(t_random, torch.Tensor):
                 ae_idx = (t_random.reshape(1) - offset).to(torch.int32)
             else:
                 ae_idx = _frame_index(int(t_random) - offset, 0, 0, full_data.device, full_data.size(1) + 1)[:1]
-            ae_loss_value = VF.frames_mse(reconstruction, full_data, ae_idx)
-        else:
-            ae_loss_value = F.mse_loss(supervision_data, reconstruction, reduction='mean')
-        spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
         if rolled is not None:
             main.wait_stream(side)
             rolled[0].record_stream(main)
             forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_t_code=t_cond, init_s_code=s_old, rolled=rolled)
         else:
             forecasts, t_codes, _, _ = sep_net.get_forecast(cond, nt_pred + offset, init_t_code=t_cond, init_s_code=s_old)
+        if fused_mse and os.environ.get('VARSEP_FUSED_CONV_LOSSES', '1') == '1':
+            # the four losses and their weighted sum in 4 launches (3 backward): no concatenation of the skip tensors, no scalar launches.
+            # t_codes[:, 0] IS t_cond (the first code of the rollout): the regulariser reads the encoder output directly, so its gradient
+            # does not travel through a zero-filled [B, n, ...] tensor
+            n_f = forecasts.shape[1]
+            f_idx = _frame_index(0, nt_cond if offset == 0 else 0, n_f, full_data.device, full_data.size(1) + 1)[1:]
+            fused = VF.conv_losses(reconstruction, forecasts, full_data, ae_idx, f_idx, s_old, s_recent, skipco, t_cond,
+                                   (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss)
+            if fused is not None:
+                return fused[0], fused[1], forecasts, t_codes
+        if fused_mse:
+            # both frame losses through the fused kernels (no supervision-frame copy, no slices of full_data)
+            ae_loss_value = VF.frames_mse(reconstruction, full_data, ae_idx)
+        else:
+            ae_loss_value = F.mse_loss(supervision_data, reconstruction, reduction='mean')
+        spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)
     else:
         ae_loss_value, s_recent, s_old = ae_loss(cond, target, sep_net, nt_cond, offset, skipco, t_random=t_random)
         spatial_ode_loss = zero_order_loss(s_old, s_recent, skipco)

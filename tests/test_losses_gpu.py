@@ -115,3 +115,67 @@ def test_copy2d_pair_builds_the_two_encoder_windows_in_one_launch(out_dtype, D):
         ops.copy2d_pair(full.view(B, T * D), B, nc * D, T * D, out, nc * D, tdev, D, -nc * D, 0)
         want = torch.cat([full[:, t - nc:t].reshape(B, -1), full[:, :nc].reshape(B, -1)], dim=0).to(out_dtype)
         assert torch.equal(out, want), (t, D, out_dtype)
+
+
+@pytest.mark.parametrize('skipco,average,spatial', [(False, False, False), (True, True, True), (True, False, False), (False, True, True)])
+def test_conv_losses_fused_equal_torch_assembly(skipco, average, spatial):
+    """functional.conv_losses (round 4: the conv families' four losses and their weighted sum in 4 launches forward / 3 backward, the zero-order
+    loss over the code AND every skip tensor read where they lie -- fp32 code, 16-bit skips -- without concatenation) against the torch
+    assembly of train.py:38-42, 85-86, 139-149: values to 1e-6, every gradient (frames, both codes, every skip in its own dtype, the initial
+    temporal code) to 1e-5 / the 16-bit rounding of the skip gradients."""
+    import torch.nn.functional as F
+    from spatiotemporal_variable_separation_amd import functional as VF
+    torch.manual_seed(3)
+    B, T, n_f, C, H, W = 4, 9, 5, 2, 16, 16
+    full = torch.rand(B, T, C, H, W, device='cuda')
+    recon = torch.rand(B, C, H, W, device='cuda', requires_grad=True)
+    fore = torch.rand(B, n_f, C, H, W, device='cuda', requires_grad=True)
+    ae_frame, first = 6, 4
+    ae_idx = torch.tensor([ae_frame], dtype=torch.int32, device='cuda')
+    f_idx = torch.arange(first, first + n_f, dtype=torch.int32, device='cuda')
+    code_shape = (B, 24, 8, 8) if spatial else (B, 40)
+    t0 = torch.randn(code_shape, device='cuda', requires_grad=True)
+
+    def make_s():
+        code = torch.randn(B, 40, device='cuda', requires_grad=True)
+        if not skipco:
+            return code
+        skips = [torch.randn(B, 16, 8, 8, device='cuda').bfloat16().requires_grad_(True), torch.randn(B, 8, 16, 16, device='cuda').bfloat16().requires_grad_(True)]
+        return (code, skips)
+    s_old, s_new = make_s(), make_s()
+    lam = (1.7, 45.0, 0.01, 30.0)                    # (ae, s, t, pred)
+
+    def leaves():
+        out = [recon, fore, t0]
+        for s in (s_old, s_new):
+            out += ([s[0]] + list(s[1])) if skipco else [s]
+        return out
+
+    def torch_total():
+        ae = F.mse_loss(full[:, ae_frame], recon)
+        pred = F.mse_loss(fore, full[:, first:first + n_f])
+        if skipco:
+            a = torch.cat([s_old[0].flatten().float()] + [x.flatten().float() for x in s_old[1]])
+            b = torch.cat([s_new[0].flatten().float()] + [x.flatten().float() for x in s_new[1]])
+        else:
+            a, b = s_old, s_new
+        zero = (a - b).pow(2).mean()
+        treg = 0.5 * (t0.pow(2).view(B, -1)).mean() if average else 0.5 * torch.sum(t0.pow(2), dim=1).mean()
+        return lam[0] * ae + lam[1] * zero + lam[3] * pred + lam[2] * treg, (ae, zero, pred, treg)
+    want, terms = torch_total()
+    (want * 3.0).backward()
+    ref = [x.grad.clone() for x in leaves()]
+    for x in leaves():
+        x.grad = None
+    got = VF.conv_losses(recon, fore, full, ae_idx, f_idx, s_old, s_new, skipco, t0, lam, average)
+    assert got is not None
+    total, d = got
+    (total * 3.0).backward()
+    torch.cuda.synchronize()
+    assert abs(total.item() - want.item()) <= 1e-5 * abs(want.item())
+    for k, v in zip(('ae', 'zero', 'pred', 't_reg'), terms):
+        assert abs(d[k].item() - v.item()) <= 1e-5 * abs(v.item()) + 1e-9, k
+    for x, r in zip(leaves(), ref):
+        assert x.grad is not None and x.grad.dtype == r.dtype
+        tol = 1e-5 if r.dtype == torch.float32 else 8e-3
+        assert ((x.grad.float() - r.float()).abs().max() <= tol * r.float().abs().max() + 1e-12), (tuple(x.shape), r.dtype)
