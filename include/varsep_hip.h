@@ -425,6 +425,12 @@ int vs_frames_sse_bwd(const float* frames, const float* full, const int32_t* idx
  *   _fwd   out[0..4] = total, ae, zero, pred, t_reg; partial: vs_code_losses_chunks() floats (per-chunk sums, finished in a fixed order)
  *   _bwd   for the upstream gradient g[0] (device): da[j] / db[j] (NULL: not wanted) in dtype[j], dt0, and coefs[4] = the coefficient pairs
  *          vs_frames_sse_bwd takes for the auto-encoding and the forecast frame stacks.  One launch. */
+/* Round 4: decoder inputs of a batched rollout (reference conv.py:228, 388-394: torch.cat([skip, out], 1) with the skip / spatial code of the B
+ * sequences shared by the n frame calls that run as one batch): out [n B][Ca + Cb][HW] = cat(a [B][Ca][HW] repeated over the frames, x [n B][Cb][HW])
+ * in out's type, one pass (no repeated copy of a); _bwd: da = sum over the frames of dout's first Ca channels (frame order), dx = the others.
+ * HW a multiple of 8, tensors 16-byte aligned; da or dx may be NULL. */
+int vs_cat_bcast_fwd(const void* a, int a_dtype, const void* x, int x_dtype, void* out, int out_dtype, int B, int n, int Ca, int Cb, int64_t HW, void* stream);
+int vs_cat_bcast_bwd(const void* dout, int dout_dtype, void* da, int a_dtype, void* dx, int x_dtype, int B, int n, int Ca, int Cb, int64_t HW, void* stream);
 int64_t vs_code_losses_chunks(int n_pairs, const int64_t* count, int64_t t_count);
 int vs_code_losses_fwd(int n_pairs, const void* const* a, const void* const* b, const int* dtype, const int64_t* count, const float* t0, int64_t t_count,
                        const float* sse_ae, const float* sse_pred, float scale_ae, float scale_pred, float l_ae, float l_s, float l_pred, float l_t,

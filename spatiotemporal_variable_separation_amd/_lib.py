@@ -127,6 +127,8 @@ SIGNATURES = {
     'vs_pack_rollout_weights': (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     'vs_frames_sse_fwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp]),
     'vs_frames_sse_bwd': (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp]),
+    'vs_cat_bcast_fwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _vp]),
+    'vs_cat_bcast_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _vp]),
     'vs_code_losses_chunks': (_i64, [_i32, _vp, _i64]),
     'vs_code_losses_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     'vs_code_losses_bwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]),

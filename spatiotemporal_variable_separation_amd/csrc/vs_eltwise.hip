@@ -838,6 +838,82 @@ int cl_fill(CodeLossJobs& J, int n_pairs, const void* const* a, const void* cons
 }
 }  // namespace
 
+// ---- decoder inputs of a batched rollout: cat([a repeated over the n frames, x], dim 1) in one pass (reference conv.py:228, 388-394) ----------
+// The SST decoder runs its n frame calls as one batch of n B maps; every skip tensor (and the spatial code) of the B sequences is the same for
+// all frames.  torch builds `a.repeat(n, 1, 1, 1)` (n copies written) and then `cat` (read again, written again): 0.6 GB per SST step.  Here
+// out[f B + b][c] = c < Ca ? a[b][c] : x[f B + b][c - Ca], converted to out's type, one write.  Backward: da[b][c] = sum over the frames of
+// dout[f B + b][c] (fp32 accumulation, frame order), dx = the other channels -- one pass over dout.
+namespace {
+__global__ __launch_bounds__(256) void cat_bcast_fwd_kernel(const void* __restrict__ a, int ad, const void* __restrict__ x, int xd, void* __restrict__ out,
+                                                            int od, int B, int Ca, int Cb, int64_t HW8, int64_t total8) {
+    // one 8-element piece per thread (HW a multiple of 8)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i % HW8, mc = i / HW8;
+        const int C = Ca + Cb;
+        const int c = (int)(mc % C);
+        const int64_t m = mc / C;                                                // map f B + b
+        float v[8];
+        if (c < Ca) cl_load8(a, ad, (((m % B) * Ca + c) * HW8 + p) * 8, v);
+        else cl_load8(x, xd, ((m * Cb + (c - Ca)) * HW8 + p) * 8, v);
+        cl_store8(out, od, i * 8, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void cat_bcast_bwd_kernel(const void* __restrict__ dout, int dd, void* __restrict__ da, int ad, void* __restrict__ dx, int xd,
+                                                            int B, int n, int Ca, int Cb, int64_t HW8, int64_t total8) {
+    // thread space: [x part: n B Cb HW8 pieces] then [a part: B Ca HW8 pieces]
+    const int C = Ca + Cb;
+    const int64_t x8 = (int64_t)n * B * Cb * HW8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        if (i < x8) {
+            if (!dx) continue;
+            const int64_t p = i % HW8, mc = i / HW8;
+            const int c = (int)(mc % Cb);
+            const int64_t m = mc / Cb;
+            cl_load8(dout, dd, ((m * C + Ca + c) * HW8 + p) * 8, v);
+            cl_store8(dx, xd, i * 8, v);
+        } else {
+            if (!da) continue;
+            const int64_t j = i - x8, p = j % HW8, bc = j / HW8;
+            const int c = (int)(bc % Ca);
+            const int64_t b = bc / Ca;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < n; ++f) {                                         // frame order: reproducible
+                cl_load8(dout, dd, ((((int64_t)f * B + b) * C + c) * HW8 + p) * 8, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            }
+            cl_store8(da, ad, j * 8, acc);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int vs_cat_bcast_fwd(const void* a, int a_dtype, const void* x, int x_dtype, void* out, int out_dtype, int B, int n, int Ca, int Cb, int64_t HW,
+                                void* stream) {
+    VS_CHECK_ARG(a && x && out && vs_dtype_ok(a_dtype) && vs_dtype_ok(x_dtype) && vs_dtype_ok(out_dtype) && B > 0 && n > 0 && Ca > 0 && Cb > 0 && HW > 0 &&
+                     HW % 8 == 0 && ((uintptr_t)a | (uintptr_t)x | (uintptr_t)out) % 16 == 0,
+                 "vs_cat_bcast_fwd: bad argument (planes of a multiple of 8 elements, 16-byte aligned tensors)");
+    const int64_t total8 = (int64_t)n * B * (Ca + Cb) * (HW / 8);
+    hipLaunchKernelGGL(cat_bcast_fwd_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, a, a_dtype, x, x_dtype, out, out_dtype, B, Ca, Cb, HW / 8,
+                       total8);
+    VS_CHECK_LAUNCH("vs_cat_bcast_fwd");
+    return VS_OK;
+}
+
+extern "C" int vs_cat_bcast_bwd(const void* dout, int dout_dtype, void* da, int a_dtype, void* dx, int x_dtype, int B, int n, int Ca, int Cb, int64_t HW,
+                                void* stream) {
+    VS_CHECK_ARG(dout && (da || dx) && vs_dtype_ok(dout_dtype) && vs_dtype_ok(a_dtype) && vs_dtype_ok(x_dtype) && B > 0 && n > 0 && Ca > 0 && Cb > 0 && HW > 0 &&
+                     HW % 8 == 0 && ((uintptr_t)dout | (uintptr_t)da | (uintptr_t)dx) % 16 == 0,
+                 "vs_cat_bcast_bwd: bad argument (planes of a multiple of 8 elements, 16-byte aligned tensors)");
+    const int64_t total8 = ((int64_t)n * B * Cb + (int64_t)B * Ca) * (HW / 8);
+    hipLaunchKernelGGL(cat_bcast_bwd_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, dout, dout_dtype, da, a_dtype, dx, x_dtype, B, n, Ca, Cb,
+                       HW / 8, total8);
+    VS_CHECK_LAUNCH("vs_cat_bcast_bwd");
+    return VS_OK;
+}
+
 // chunks = rows of `partial` vs_code_losses_fwd needs
 extern "C" int64_t vs_code_losses_chunks(int n_pairs, const int64_t* count, int64_t t_count) {
     int64_t c = vs_cdiv(t_count > 0 ? t_count : 0, CL_CHUNK);

@@ -1638,6 +1638,33 @@ def frames_mse(frames, full, idx):
     return FramesMSE.apply(frames.reshape(B, G, -1).contiguous().float(), flat.float(), idx)
 
 
+class CatBcast(torch.autograd.Function):
+    """cat([a.repeat(n, 1, 1, 1), x], dim=1) for the decoder inputs of a batched rollout (conv.py:228, 388-394: the skip tensors / the spatial
+    code of the B sequences are shared by the n frame calls): one pass forward (no repeated copy of `a`), one backward (d a = sum over the
+    frames, d x = the other channels)."""
+
+    @staticmethod
+    def forward(ctx, a, x, n, out_dtype):
+        ctx.meta = (a.shape[0], int(n), a.shape[1], a.dtype, x.dtype)
+        return ops.cat_bcast_fwd(a.detach().contiguous(), x.detach().contiguous(), int(n), out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, n, Ca, a_dtype, x_dtype = ctx.meta
+        da, dx = ops.cat_bcast_bwd(dout, B, n, Ca, a_dtype, x_dtype, need_a=ctx.needs_input_grad[0], need_x=ctx.needs_input_grad[1])
+        return da, dx, None, None
+
+
+def cat_bcast(a, x, n, out_dtype=None):
+    """cat([a repeated n times along the batch axis, x], dim=1) in `out_dtype` (default: x's); falls back to torch ops where the kernel does not
+    take the tensors (CPU, odd plane sizes) or VARSEP_CAT_BCAST=0."""
+    out_dtype = out_dtype or x.dtype
+    if (n > 1 and os.environ.get('VARSEP_CAT_BCAST', '1') == '1' and a.is_cuda and a.dim() == 4 and x.dim() == 4
+            and ops.cat_bcast_supported(a.detach().contiguous(), x.detach().contiguous(), n)):
+        return CatBcast.apply(a, x, n, out_dtype)
+    return torch.cat([a.repeat(n, 1, 1, 1).to(out_dtype), x.to(out_dtype)], dim=1)
+
+
 class ConvLosses(torch.autograd.Function):
     """The four losses of a conv-family step and their weighted sum (train.py:85-86, 38-42, 139-149) in 4 launches forward (two frame-sum
     kernels, the code-loss partials, a one-block finish) and 3 backward (one launch for every code gradient and the frame coefficients, the two

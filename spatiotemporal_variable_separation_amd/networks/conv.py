@@ -269,10 +269,17 @@ def _decode_sequence_spatial(dec, s_code, t_codes, skip):
     """decode_sequence for the SST decoders: s_code [B, Cs, h, w], t_codes [B, n, Ct, h, w] -> [B, n, C, H, W]."""
     B, n = t_codes.shape[0], t_codes.shape[1]
     z2 = t_codes.transpose(0, 1).reshape(n * B, *t_codes.shape[2:])
-    z1e = s_code.repeat(n, 1, 1, 1)
-    skips = None if skip is None else [s.repeat(n, 1, 1, 1) for s in skip]
-    out = dec.forward(z1e, z2, skips, groups=n)
+    # the spatial code and the skips of the B sequences are shared by the n frame calls: they are NOT repeated here -- the concatenations
+    # inside forward read them by sequence index (functional.cat_bcast)
+    out = dec.forward(s_code, z2, skip, groups=n, rep=n)
     return out.view(n, B, *out.shape[1:]).transpose(0, 1)
+
+
+def _cat_shared(a, x, rep, dtype=None):
+    """torch.cat([a, x], 1) where `a` belongs to B sequences and `x` to rep x B frame calls stacked frame-major (rep = 1: a plain cat)."""
+    if rep == 1:
+        return torch.cat([a if dtype is None else a.to(dtype), x], dim=1)
+    return VF.cat_bcast(a, x, rep, dtype or x.dtype)
 
 
 class DecoderSST_Skip(nn.Module):
@@ -286,12 +293,12 @@ class DecoderSST_Skip(nn.Module):
         self.conv4 = nn.Sequential(_c3(64 * 2, 64), _c3(64, 64), _c3(64, out_c))
         self.out_f = activation_factory(out_f)
 
-    def forward(self, s_code, t_code, skip, groups=1):
+    def forward(self, s_code, t_code, skip, groups=1, rep=1):
         h3, h2, h1 = skip
-        out = run_layers(self.conv1, torch.cat([s_code, t_code], dim=1), groups=groups)
-        out = run_layers(self.conv2, torch.cat([h3.to(out.dtype), out], dim=1), groups=groups)
-        out = run_layers(self.conv3, torch.cat([h2.to(out.dtype), out], dim=1), groups=groups)
-        return run_layers(self.conv4, torch.cat([h1.to(out.dtype), out], dim=1), final_act=activation_name(self.out_f),
+        out = run_layers(self.conv1, _cat_shared(s_code, t_code, rep), groups=groups)
+        out = run_layers(self.conv2, _cat_shared(h3, out, rep, out.dtype), groups=groups)
+        out = run_layers(self.conv3, _cat_shared(h2, out, rep, out.dtype), groups=groups)
+        return run_layers(self.conv4, _cat_shared(h1, out, rep, out.dtype), final_act=activation_name(self.out_f),
                           final_fp32=True, groups=groups)
 
     def decode_sequence(self, s_code, t_codes, skip):
@@ -308,8 +315,8 @@ class DecoderSST(nn.Module):
         self.conv3 = nn.Sequential(_c3(64, 64), _c3(64, out_c))
         self.out_f = activation_factory(out_f)
 
-    def forward(self, s_code, t_code, skip=None, groups=1):
-        x = run_layers(self.conv1, torch.cat([s_code, t_code], dim=1), groups=groups)
+    def forward(self, s_code, t_code, skip=None, groups=1, rep=1):
+        x = run_layers(self.conv1, _cat_shared(s_code, t_code, rep), groups=groups)
         x = run_layers(self.conv2, x, groups=groups)
         return run_layers(self.conv3, x, final_act=activation_name(self.out_f), final_fp32=True, groups=groups)
 

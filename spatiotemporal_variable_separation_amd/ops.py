@@ -1621,6 +1621,40 @@ def frames_sse_bwd(frames, full, idx, coef):
     return out
 
 
+def cat_bcast_supported(a, x, n):
+    return (a.is_cuda and x.is_cuda and a.dim() == 4 and x.dim() == 4 and a.is_contiguous() and x.is_contiguous() and x.shape[0] == n * a.shape[0]
+            and a.shape[2:] == x.shape[2:] and (a.shape[2] * a.shape[3]) % 8 == 0 and a.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+            and a.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.dtype in (torch.float32, torch.bfloat16, torch.float16))
+
+
+def cat_bcast_fwd(a, x, n, out_dtype):
+    """cat([a.repeat(n, 1, 1, 1), x], dim=1) in out_dtype: a [B, Ca, H, W], x [n B, Cb, H, W] -> [n B, Ca + Cb, H, W], one pass."""
+    require_cuda(a, x)
+    B, Ca = a.shape[0], a.shape[1]
+    Cb, HW = x.shape[1], x.shape[2] * x.shape[3]
+    out = torch.empty((n * B, Ca + Cb) + tuple(x.shape[2:]), dtype=out_dtype, device=x.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_cat_bcast_fwd(a.data_ptr(), dtype_code(a), x.data_ptr(), dtype_code(x), out.data_ptr(), dtype_code(out), B, n, Ca, Cb, HW,
+                                               stream_ptr()), 'vs_cat_bcast_fwd')
+    _pe(e0, 'vs_cat_bcast', nbytes=float(x.numel() * x.element_size() + out.numel() * out.element_size()))
+    return out
+
+
+def cat_bcast_bwd(dout, B, n, Ca, a_dtype, x_dtype, need_a=True, need_x=True):
+    """(da [B, Ca, H, W] = sum over the n frames of dout[:, :Ca], dx [n B, Cb, H, W] = dout[:, Ca:]) in one pass over dout."""
+    require_cuda(dout)
+    dout = dout.contiguous()
+    C, H, W = dout.shape[1], dout.shape[2], dout.shape[3]
+    Cb = C - Ca
+    da = torch.empty((B, Ca, H, W), dtype=a_dtype, device=dout.device) if need_a else None
+    dx = torch.empty((n * B, Cb, H, W), dtype=x_dtype, device=dout.device) if need_x else None
+    e0 = _pb()
+    check(_lib.load_library().vs_cat_bcast_bwd(dout.data_ptr(), dtype_code(dout), _ptr(da), code_of(a_dtype), _ptr(dx), code_of(x_dtype), B, n, Ca, Cb, H * W,
+                                               stream_ptr()), 'vs_cat_bcast_bwd')
+    _pe(e0, 'vs_cat_bcast', nbytes=float(dout.numel() * dout.element_size() * 2))
+    return da, dx
+
+
 def _code_loss_tables(pairs):
     import ctypes
     n = len(pairs)

@@ -179,3 +179,29 @@ def test_conv_losses_fused_equal_torch_assembly(skipco, average, spatial):
         assert x.grad is not None and x.grad.dtype == r.dtype
         tol = 1e-5 if r.dtype == torch.float32 else 8e-3
         assert ((x.grad.float() - r.float()).abs().max() <= tol * r.float().abs().max() + 1e-12), (tuple(x.shape), r.dtype)
+
+
+@pytest.mark.parametrize('a_dtype,x_dtype,out_dtype', [(torch.float32, torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16, torch.bfloat16),
+                                                       (torch.float16, torch.float32, torch.float16)])
+def test_cat_bcast_equals_repeat_and_cat(a_dtype, x_dtype, out_dtype):
+    """functional.cat_bcast (decoder inputs of a batched rollout, conv.py:228, 388-394): cat([a.repeat(n, 1, 1, 1), x], 1) in one pass, its
+    gradients (d a = sum over the frames, d x = the other channels) in one pass -- bit for bit against torch in fp32, to the rounding of the
+    sum in 16 bits."""
+    from spatiotemporal_variable_separation_amd import functional as VF
+    torch.manual_seed(1)
+    B, n, Ca, Cb, H, W = 3, 5, 7, 6, 8, 16
+    a = torch.randn(B, Ca, H, W, device='cuda').to(a_dtype).requires_grad_(True)
+    x = torch.randn(n * B, Cb, H, W, device='cuda').to(x_dtype).requires_grad_(True)
+    g = torch.randn(n * B, Ca + Cb, H, W, device='cuda').to(out_dtype)
+    want = torch.cat([a.repeat(n, 1, 1, 1).to(out_dtype), x.to(out_dtype)], dim=1)
+    want.backward(g)
+    ga, gx = a.grad.clone(), x.grad.clone()
+    a.grad = x.grad = None
+    got = VF.cat_bcast(a, x, n, out_dtype)
+    assert isinstance(got.grad_fn, torch.autograd.function.BackwardCFunction) and torch.equal(got, want)
+    got.backward(g)
+    torch.cuda.synchronize()
+    assert x.grad.dtype == gx.dtype and torch.equal(x.grad, gx)
+    assert a.grad.dtype == ga.dtype
+    tol = 0.0 if a_dtype == torch.float32 else 8e-3
+    assert (a.grad.float() - ga.float()).abs().max().item() <= tol * ga.float().abs().max().item() + (1e-6 if tol == 0.0 else 0.0)
