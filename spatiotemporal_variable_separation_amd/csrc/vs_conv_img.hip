@@ -1551,12 +1551,15 @@ extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout)
     return (4 / wgrad_band_mw(Cout)) * wgrad_band_ksplit(B, Cin, H, W, Cout);
 }
 
-// K4 form: two 32-channel tiles of a plane per workgroup against one staged dz tile (planes hold K >= 64 channels, a multiple of 64)
-constexpr int WGRAD_K4_CTW = 2;
+// K4 form: two 32-channel tiles of a plane per workgroup against one staged dz tile -- four where a plane holds a multiple of 128 channels
+// (VS_WGRAD_K4_CTW4=0: always two)
+static int wgrad_k4_ctw(int Cin) {
+    static const int allow4 = getenv("VS_WGRAD_K4_CTW4") ? atoi(getenv("VS_WGRAD_K4_CTW4")) : 1;
+    return (allow4 && (Cin >> 2) % 128 == 0) ? 4 : 2;
+}
 
-template <int W, int MW, int K4 = 0>
-static void launch_wgrad_band(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
-    constexpr int CTW = K4 ? WGRAD_K4_CTW : 1;
+template <int W, int MW, int K4, int CTW>
+static void launch_wgrad_band_ctw(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
     const size_t lds = (size_t)(3 * 32 * wgrad_cpitch<W>() + 32 * MW * 264) * 2;
     auto kb = wgrad3_band_kernel<VS_BF16, W, MW, K4, CTW>;
     auto kh = wgrad3_band_kernel<VS_F16, W, MW, K4, CTW>;
@@ -1574,6 +1577,16 @@ static void launch_wgrad_band(int compute, const WgradPieces& pieces, float* sla
         hipLaunchKernelGGL(kh, grid, dim3(256), lds, stream, pieces, slabs, B, Cin, H, Cout, ctiles, ksplit);
 }
 
+template <int W, int MW, int K4 = 0>
+static void launch_wgrad_band(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
+    if constexpr (K4) {
+        if (wgrad_k4_ctw(Cin) == 4) launch_wgrad_band_ctw<W, MW, K4, 4>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
+        else launch_wgrad_band_ctw<W, MW, K4, 2>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
+    } else {
+        launch_wgrad_band_ctw<W, MW, K4, 1>(compute, pieces, slabs, B, Cin, H, Cout, ksplit, stream);
+    }
+}
+
 template <int W, int K4 = 0>
 static void launch_wgrad_band_w(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int Cout, int ksplit, hipStream_t stream) {
     const int mw = wgrad_band_mw(Cout);
@@ -1584,7 +1597,7 @@ static void launch_wgrad_band_w(int compute, const WgradPieces& pieces, float* s
 
 template <int K4 = 0>
 static int wgrad_band_go(int compute, const WgradPieces& pieces, float* slabs, int B, int Cin, int H, int W, int Cout, hipStream_t stream) {
-    const int ks = wgrad_band_ksplit(B, Cin, H, W, Cout, K4 ? WGRAD_K4_CTW : 1);
+    const int ks = wgrad_band_ksplit(B, Cin, H, W, Cout, K4 ? wgrad_k4_ctw(Cin) : 1);
     if (W == 64) launch_wgrad_band_w<64, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     else if (W == 32) launch_wgrad_band_w<32, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
     else if (W == 16) launch_wgrad_band_w<16, K4>(compute, pieces, slabs, B, Cin, H, Cout, ks, stream);
@@ -1636,7 +1649,7 @@ extern "C" int vs_conv_k4s2_band(int compute, const void* planes, const void* w_
 
 // slabs vs_conv_k4s2_wgrad_band writes (the skip form shares the batch among fewer, heavier workgroups than vs_conv3_wgrad_band on the same planes)
 extern "C" int vs_conv_k4s2_wgrad_band_slabs(int B, int K, int H, int W, int M) {
-    return (4 / wgrad_band_mw(M)) * wgrad_band_ksplit(B, 4 * K, H, W, M, vs_conv_k4s2_skip_form(K) ? WGRAD_K4_CTW : 1);
+    return (4 / wgrad_band_mw(M)) * wgrad_band_ksplit(B, 4 * K, H, W, M, vs_conv_k4s2_skip_form(K) ? wgrad_k4_ctw(4 * K) : 1);
 }
 
 extern "C" int vs_conv_k4s2_wgrad_band(int compute, const void* planes, const void* small, float* slabs, int B, int K, int H, int W, int M, void* stream) {
