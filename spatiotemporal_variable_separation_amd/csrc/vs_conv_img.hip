@@ -1551,10 +1551,11 @@ extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout)
     return (4 / wgrad_band_mw(Cout)) * wgrad_band_ksplit(B, Cin, H, W, Cout);
 }
 
-// K4 form: two 32-channel tiles of a plane per workgroup against one staged dz tile -- four where a plane holds a multiple of 128 channels
-// (VS_WGRAD_K4_CTW4=0: always two)
+// K4 form: two 32-channel tiles of a plane per workgroup against one staged dz tile.  Four (VS_WGRAD_K4_CTW4=1, where a plane holds a multiple of
+// 128 channels) is built and measured SLOWER: half as many tiles means twice the batch shares to fill the chip, i.e. twice the slabs, and the
+// fourth stage of an item no longer hides its loads -- Moving-MNIST 6.45 (two) vs 6.71 ms (four).
 static int wgrad_k4_ctw(int Cin) {
-    static const int allow4 = getenv("VS_WGRAD_K4_CTW4") ? atoi(getenv("VS_WGRAD_K4_CTW4")) : 1;
+    static const int allow4 = getenv("VS_WGRAD_K4_CTW4") ? atoi(getenv("VS_WGRAD_K4_CTW4")) : 0;
     return (allow4 && (Cin >> 2) % 128 == 0) ? 4 : 2;
 }
 
