@@ -46,9 +46,16 @@ GROUPS = [
     ('vs_bn_small', r'^vs_bn_fwd_small|^vs_bn_bwd_small', r'bn_fwd_small|bn_bwd_small', 'hbm'),
     # first / last layers (1..8 channels on the image side): one VALU pass over the many-channel map, no column matrix
     ('vs_conv_thin', r'^vs_conv_thin:', r'thin_\w+_kernel', 'hbm'),
-    ('vs_bn', r'^vs_bn_stats|^vs_bn_act_fwd|^vs_bn_act_bwd|^vs_chan_sum', r'bn_stats_kernel|bn_act_fwd_kernel|bn_bwd_reduce|bn_bwd_apply|bn_running|bn_from_sums|chan_sum', 'hbm'),
+    ('vs_bn', r'^vs_bn_stats|^vs_bn_act_fwd|^vs_bn_act_bwd|^vs_chan_sum|^vs_bn_fwd_slab',
+     r'bn_stats_kernel|bn_act_fwd_kernel|bn_bwd_reduce|bn_bwd_apply|bn_running|bn_from_sums|chan_sum|group_sum2_kernel|bn_fwd_slab|bn_bwd_slab|bn_from_parts', 'hbm'),
+    # resampling / joins around the convolutions (VGG pooling and nearest upsampling, the decoder's code broadcast + skip join, stand-alone activations)
+    ('vs_resample+join', r'^vs_upsample|^vs_maxpool|^vs_cat_bcast|^vs_act_', r'upsample_\w+_kernel|maxpool_\w+_kernel|cat_bcast_\w+_kernel|act_fwd_kernel|act_bwd_kernel|'
+     r'space_to_depth2', 'hbm'),
+    # operand upkeep inside the recording: 16-bit / packed weight copies after the update, accumulator clears, dtype casts, strided copies
+    ('vs_operand_upkeep', r'^vs_pack|^vs_zero|^vs_cast|^vs_copy2d', r'tap_pack_kernel|pack_weight_kernel|pack_multi_kernel|conv3_img16_pack|vs_zero_kernel|cast_kernel|'
+     r'copy2d_\w*kernel|step_increment_kernel', 'hbm'),
     ('vs_adam_multi', r'^vs_adam_multi', r'adam_multi_kernel', 'hbm'),
-    ('vs_train_losses', r'^vs_train_losses|^vs_frames_sse', r'train_losses_\w+_kernel|frames_sse', 'hbm'),
+    ('vs_train_losses', r'^vs_train_losses|^vs_frames_sse', r'train_losses_\w+_kernel|frames_sse|code_losses_\w+_kernel', 'hbm'),
     ('vs_colsum_multi', r'^vs_colsum_multi', r'colsum_multi_kernel', 'hbm'),
     ('vs_mix_codes', r'^vs_mix_codes', r'mix_codes_\w+_kernel', 'hbm'),
     ('at::native (torch elementwise / cat / reduce)', r'^$', r'^void at::native|^at::native|__amd_rocclr', 'hbm'),
