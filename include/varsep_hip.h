@@ -612,6 +612,14 @@ int vs_bn_train_fwd_small_slabs(const float* slabs, int nslabs, const float* bia
 int vs_bn_act_bwd_small_ex(const void* dy_a, int dy_a_dtype, const float* dy_b, const float* slabs, int nslabs, const void* z, int z_dtype,
                            const float* mean, const float* invstd, const float* gamma, const float* beta, int act, float* dgamma,
                            float* dbeta, int accumulate, void* dx, int dx_dtype, int B, int C, int64_t HW, void* stream);
+/* Round 4: training-mode BatchNorm2d (+ activation) forward with every (call group, channel) slab read ONCE (reference conv.py:41-60): slabs of
+ * 8 193 .. 131 072 16-bit elements live in the registers of a 1024-thread workgroup between the statistics and the apply phase (vs_bn_stats +
+ * vs_bn_act_fwd read the tensor twice).  mean / invstd [groups][C]; running estimates folded in call order (groups > 1: var_scratch [groups][C]).
+ * The backward counterpart (x and dy resident, slabs up to 65 536 elements) is taken by vs_bn_act_bwd / _gsum by itself.  VS_BN_SLAB=0: never. */
+int vs_bn_train_fwd_slab_supported(int x_dtype, int Bg, int C, int64_t HW);
+int vs_bn_train_fwd_slab(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int act, float* mean, float* invstd,
+                         float* var_scratch, float* running_mean, float* running_var, float momentum, float eps, int B, int C, int64_t HW, int groups,
+                         void* stream);
 int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream);
 int vs_bn_act_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* invstd, const float* gamma,

@@ -198,6 +198,8 @@ SIGNATURES = {
     'vs_conv_transpose2d_dgrad': (_i32, [_i32, _vp, _vp, _vp, _i32] + [_i32] * 9 + [_vp, _sz, _i32, _vp]),
     'vs_conv_transpose2d_wgrad': (_i32, [_i32, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _sz, _vp]),
     'vs_bn_stats': (_i32, [_vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp]),
+    'vs_bn_train_fwd_slab_supported': (_i32, [_i32, _i32, _i32, _i64]),
+    'vs_bn_train_fwd_slab': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _i32, _i32, _i64, _i32, _vp]),
     'vs_bn_act_fwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     'vs_bn_act_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     'vs_bn_act_bwd_gsum': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp]),

@@ -749,6 +749,166 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const void* x, int xd
     }
 }
 
+// ---- BatchNorm of LARGE slabs with the slab resident in registers (round 4) -------------------------------------------------------------
+// vs_bn_stats + vs_bn_act_fwd read the pre-BatchNorm tensor twice (statistics, then apply) and the backward pair reads dy and x twice each:
+// HBM passes, 14-17 % of the Moving-MNIST / TaxiBJ steps.  One (call group, channel) slab of the batched decoder / encoder calls is 1.6 K ..
+// 131 K 16-bit elements: a 1024-thread workgroup holds it in registers as packed 16-byte vectors (<= 16 per thread), so the tensor is read ONCE
+// -- statistics in two passes over the registers (mean, then centred squares: the arithmetic of bn_fwd_small_kernel), apply from the registers.
+// Backward: x and dy resident (<= 8 + 8 vectors: slabs up to 65 536 elements).  grid = (C, call groups); running estimates of several call
+// groups are folded in call order by bn_running_kernel from mean / the unbiased variances.  ACT: VS_ACT_NONE / VS_ACT_LEAKY compile-time
+// (anything else goes through the run-time switch, ACT = -1).
+template <int ACT>
+__device__ __forceinline__ float slab_act(float v, int act) {
+    if constexpr (ACT == VS_ACT_NONE) return v;
+    else if constexpr (ACT == VS_ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
+    else return vs_act(v, act);
+}
+template <int ACT>
+__device__ __forceinline__ float slab_act_grad(float pre, int act) {
+    if constexpr (ACT == VS_ACT_NONE) return 1.f;
+    else if constexpr (ACT == VS_ACT_LEAKY) return pre > 0.f ? 1.f : 0.2f;
+    else return act_grad_from_pre(pre, act);
+}
+
+// element j of a packed 16-byte vector as fp32 (XD: VS_BF16 / VS_F16 compile-time)
+template <int XD>
+__device__ __forceinline__ float slab_get(const u32x4& v, int j) {
+    const unsigned w = v[j >> 1];
+    if constexpr (XD == VS_BF16) return __uint_as_float((j & 1) ? (w & 0xffff0000u) : (w << 16));
+    else return vs_h2f((unsigned short)((j & 1) ? (w >> 16) : (w & 0xffffu)), VS_F16);
+}
+// the resident vectors must stay PACKED between the phases: without this fence the compiler keeps the fp32 conversions of phase one alive for
+// the later phases (8 registers per vector instead of 4) and spills
+template <int NV>
+__device__ __forceinline__ void slab_fence(u32x4 (&v)[NV]) {
+#pragma unroll
+    for (int r = 0; r < NV; ++r) asm volatile("" : "+v"(v[r]));
+}
+
+template <int NV, int ACT, int XD>
+__global__ __launch_bounds__(1024) void bn_fwd_slab_kernel(const unsigned short* __restrict__ x, void* __restrict__ y, int yd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* mean,
+                                                           float* invstd, float* ubvar, float* rmean, float* rvar, float momentum, float eps, int Bg, int C,
+                                                           int HW) {
+    __shared__ double red[16];
+    const int c = blockIdx.x, grp = blockIdx.y;
+    // a plane is HW / 8 vectors, a power of two <= 1024: the workgroup covers 1024 / per maps per round, a thread's vectors are `bstep` maps apart
+    const int per = HW >> 3, bstep = 1024 / per;
+    const int bt0 = threadIdx.x / per;
+    const int64_t n = (int64_t)Bg * HW;
+    const int64_t off0 = (((int64_t)grp * Bg + bt0) * C + c) * (int64_t)HW + ((threadIdx.x - bt0 * per) << 3);
+    const int64_t rstride = (int64_t)bstep * C * HW;
+    u32x4 xv[NV];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        xv[r] = u32x4{0u, 0u, 0u, 0u};
+        if (bt0 + r * bstep < Bg) xv[r] = *reinterpret_cast<const u32x4*>(x + off0 + r * rstride);
+    }
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += slab_get<XD>(xv[r], j);          // (absent vectors are zeros)
+    }
+    slab_fence<NV>(xv);
+    const double mu_d = block_sum((double)a, red) / (double)n;
+    const float mu = (float)mu_d;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        if (bt0 + r * bstep < Bg) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = slab_get<XD>(xv[r], j) - mu; q += d * d; }
+        }
+    }
+    slab_fence<NV>(xv);
+    double ss = block_sum((double)q, red);
+    ss -= (double)n * (mu_d - (double)mu) * (mu_d - (double)mu);          // (the rounding of the mean: as bn_fwd_small_kernel)
+    if (ss < 0.0) ss = 0.0;
+    const double var = ss / (double)n;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        mean[grp * C + c] = mu;
+        invstd[grp * C + c] = is;
+        const double ub = n > 1 ? ss / (double)(n - 1) : var;
+        if (ubvar) {
+            ubvar[grp * C + c] = (float)ub;
+        } else if (rmean) {
+            rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * (double)mu);
+            rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * (double)(float)ub);
+        }
+    }
+    const float g = gamma[c], bt = beta[c];
+    const float sc = is * g, sh = bt - mu * is * g;
+    (void)sh;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        if (bt0 + r * bstep < Bg) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = slab_act<ACT>((slab_get<XD>(xv[r], j) - mu) * sc + bt, act);
+            st_vec(y, yd, off0 + r * rstride, o, 8);
+        }
+    }
+}
+
+template <int NV, int ACT, int XD>
+__global__ __launch_bounds__(1024) void bn_bwd_slab_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dz,
+                                                           float* sum_dz_xhat, void* __restrict__ dx, int dxd, int Bg, int C, int HW) {
+    __shared__ double red[16];
+    const int c = blockIdx.x, grp = blockIdx.y;
+    const int per = HW >> 3, bstep = 1024 / per;                           // (the thread -> vector map of bn_fwd_slab_kernel)
+    const int bt0 = threadIdx.x / per;
+    const int64_t off0 = (((int64_t)grp * Bg + bt0) * C + c) * (int64_t)HW + ((threadIdx.x - bt0 * per) << 3);
+    const int64_t rstride = (int64_t)bstep * C * HW;
+    const float mu = mean[grp * C + c], is = invstd[grp * C + c], g = gamma[c], bt = beta[c];
+    u32x4 xv[NV], gv[NV];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        xv[r] = u32x4{0u, 0u, 0u, 0u};
+        gv[r] = u32x4{0u, 0u, 0u, 0u};
+        if (bt0 + r * bstep < Bg) {
+            xv[r] = *reinterpret_cast<const u32x4*>(x + off0 + r * rstride);
+            gv[r] = *reinterpret_cast<const u32x4*>(dy + off0 + r * rstride);
+        }
+    }
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        asm volatile("" : "+v"(xv[r]), "+v"(gv[r]), "+v"(a1), "+v"(a2));   // (one vector pair at a time: the scheduler would otherwise convert them all up front and spill)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                                      // (absent vectors: dy = 0 contributes nothing)
+            const float xh = (slab_get<XD>(xv[r], j) - mu) * is;
+            const float dz = slab_get<XD>(gv[r], j) * slab_act_grad<ACT>(xh * g + bt, act);
+            a1 += dz;
+            a2 += dz * xh;
+        }
+    }
+    slab_fence<NV>(xv);
+    slab_fence<NV>(gv);
+    const double t1 = block_sum((double)a1, red);
+    const double t2 = block_sum((double)a2, red);
+    if (threadIdx.x == 0) { sum_dz[grp * C + c] = (float)t1; sum_dz_xhat[grp * C + c] = (float)t2; }
+    const float inv_n = 1.f / (float)((int64_t)Bg * HW);
+    const float k1 = (float)t1 * inv_n, k2 = (float)t2 * inv_n;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        asm volatile("" : "+v"(xv[r]), "+v"(gv[r]) : : "memory");
+        if (bt0 + r * bstep < Bg) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (slab_get<XD>(xv[r], j) - mu) * is;
+                const float dz = slab_get<XD>(gv[r], j) * slab_act_grad<ACT>(xh * g + bt, act);
+                o[j] = g * is * (dz - k1 - xh * k2);
+            }
+            st_vec(dx, dxd, off0 + r * rstride, o, 8);
+        }
+    }
+}
+
 // per-channel sum; blockIdx.y splits the (batch x pixel) extent so that few-channel tensors (the 1-channel frames of the
 // last decoder layer) still fill the chip; partial sums meet in one float atomic per workgroup
 __global__ __launch_bounds__(256) void chan_sum_kernel(const void* x, int xd, int B, int C, int64_t HW, float* out) {
@@ -1044,6 +1204,59 @@ extern "C" int vs_bn_train_fwd_small_slabs(const float* slabs, int nslabs, const
     return VS_OK;
 }
 
+// One (call group, channel) slab of 8 193 .. 131 072 16-bit elements: read once, held in the registers of a 1024-thread workgroup
+extern "C" int vs_bn_train_fwd_slab_supported(int x_dtype, int Bg, int C, int64_t HW) {
+    static const int slab_mode = getenv("VS_BN_SLAB") ? atoi(getenv("VS_BN_SLAB")) : 1;
+    const int64_t n = (int64_t)Bg * HW;
+    return slab_mode && vs_is16(x_dtype) && Bg > 0 && C > 0 && HW >= 8 && HW <= 8192 && (HW & (HW - 1)) == 0 && n > 8192 && n <= 131072;
+}
+
+// Training-mode BatchNorm2d (+ activation) forward of `groups` reference calls stacked along the batch axis, every (call, channel) slab read
+// ONCE: mean / invstd [groups][C]; running estimates updated (groups > 1: in call order by a second small launch from var_scratch [groups][C]).
+extern "C" int vs_bn_train_fwd_slab(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta, int act, float* mean,
+                                    float* invstd, float* var_scratch, float* running_mean, float* running_var, float momentum, float eps, int B, int C,
+                                    int64_t HW, int groups, void* stream) {
+    VS_CHECK_ARG(x && y && gamma && beta && mean && invstd && vs_dtype_ok(y_dtype) && groups >= 1 && B > 0 && B % groups == 0, "vs_bn_train_fwd_slab: bad argument");
+    VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && (!running_mean || groups == 1 || var_scratch),
+                 "vs_bn_train_fwd_slab: running_mean / running_var come together; several call groups need var_scratch");
+    const int Bg = B / groups;
+    if (!vs_bn_train_fwd_slab_supported(x_dtype, Bg, C, HW) || ((uintptr_t)x | (uintptr_t)y) % 16 != 0)
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_bn_train_fwd_slab: tensor not served (vs_bn_stats + vs_bn_act_fwd)");
+    const int64_t nvec = (int64_t)Bg * HW / 8;
+    const dim3 grid(C, groups);
+    float* ub = (groups > 1 && running_mean) ? var_scratch : nullptr;
+    float* rm = groups == 1 ? running_mean : nullptr;
+    float* rv = groups == 1 ? running_var : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+#define VS_BN_SLAB(NV, AV)                                                                                                              \
+    do {                                                                                                                                  \
+        if (x_dtype == VS_BF16)                                                                                                           \
+            hipLaunchKernelGGL((bn_fwd_slab_kernel<NV, AV, VS_BF16>), grid, dim3(1024), 0, st, (const unsigned short*)x, y, y_dtype, gamma, beta, act, mean, \
+                               invstd, ub, rm, rv, momentum, eps, Bg, C, (int)HW);                                                        \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((bn_fwd_slab_kernel<NV, AV, VS_F16>), grid, dim3(1024), 0, st, (const unsigned short*)x, y, y_dtype, gamma, beta, act, mean,  \
+                               invstd, ub, rm, rv, momentum, eps, Bg, C, (int)HW);                                                        \
+    } while (0)
+#define VS_BN_SLAB_NV(AV)                      \
+    do {                                       \
+        if (nvec <= 2048) VS_BN_SLAB(2, AV);   \
+        else if (nvec <= 4096) VS_BN_SLAB(4, AV);  \
+        else if (nvec <= 8192) VS_BN_SLAB(8, AV);  \
+        else VS_BN_SLAB(16, AV);               \
+    } while (0)
+    if (act == VS_ACT_LEAKY) VS_BN_SLAB_NV(VS_ACT_LEAKY);
+    else if (act == VS_ACT_NONE) VS_BN_SLAB_NV(VS_ACT_NONE);
+    else VS_BN_SLAB_NV(-1);
+#undef VS_BN_SLAB_NV
+#undef VS_BN_SLAB
+    VS_CHECK_LAUNCH("vs_bn_train_fwd_slab");
+    if (ub) {
+        hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, var_scratch, groups, C, running_mean, running_var, momentum);
+        VS_CHECK_LAUNCH("vs_bn_train_fwd_slab running update");
+    }
+    return VS_OK;
+}
+
 extern "C" int vs_bn_act_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, int act, int B, int C, int64_t HW, int groups, void* stream) {
     VS_CHECK_ARG(x && y && mean && invstd && gamma && beta && B > 0 && C > 0 && HW > 0 && groups >= 1 && B % groups == 0, "vs_bn_act_fwd: bad argument");
@@ -1117,6 +1330,43 @@ extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, i
             if (dbeta_sum) {
                 hipLaunchKernelGGL(group_sum2_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dbeta, dgamma, groups, C, dbeta_sum,
                                    dgamma_sum);
+                VS_CHECK_LAUNCH("vs_bn_act_bwd (group sums)");
+            }
+            return VS_OK;
+        }
+    }
+    {
+        // slabs of 8 193 .. 65 536 16-bit elements: x and dy resident in the registers of a 1024-thread workgroup, both read ONCE (bn_bwd_slab_kernel)
+        static const int slab_mode = getenv("VS_BN_SLAB") ? atoi(getenv("VS_BN_SLAB")) : 1;
+        const int64_t nslab = (int64_t)(B / groups) * HW;
+        if (slab_mode && training && vec == 1 && vs_is16(x_dtype) && x_dtype == dy_dtype && nslab > 8192 && nslab <= 65536 && HW <= 8192 && (HW & (HW - 1)) == 0 &&
+            ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0) {
+            const int64_t nvec = nslab / 8;
+            const dim3 grid(C, groups);
+            hipStream_t st = (hipStream_t)stream;
+#define VS_BN_SLAB(NV, AV)                                                                                                              \
+            do {                                                                                                                          \
+                if (x_dtype == VS_BF16)                                                                                                   \
+                    hipLaunchKernelGGL((bn_bwd_slab_kernel<NV, AV, VS_BF16>), grid, dim3(1024), 0, st, (const unsigned short*)dy, (const unsigned short*)x, mean, \
+                                       invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, (int)HW);                    \
+                else                                                                                                                      \
+                    hipLaunchKernelGGL((bn_bwd_slab_kernel<NV, AV, VS_F16>), grid, dim3(1024), 0, st, (const unsigned short*)dy, (const unsigned short*)x, mean,  \
+                                       invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, (int)HW);                    \
+            } while (0)
+#define VS_BN_SLAB_NV(AV)                          \
+            do {                                   \
+                if (nvec <= 2048) VS_BN_SLAB(2, AV);   \
+                else if (nvec <= 4096) VS_BN_SLAB(4, AV);  \
+                else VS_BN_SLAB(8, AV);            \
+            } while (0)
+            if (act == VS_ACT_LEAKY) VS_BN_SLAB_NV(VS_ACT_LEAKY);
+            else if (act == VS_ACT_NONE) VS_BN_SLAB_NV(VS_ACT_NONE);
+            else VS_BN_SLAB_NV(-1);
+#undef VS_BN_SLAB_NV
+#undef VS_BN_SLAB
+            VS_CHECK_LAUNCH("vs_bn_act_bwd (resident slabs)");
+            if (dbeta_sum) {
+                hipLaunchKernelGGL(group_sum2_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, st, dbeta, dgamma, groups, C, dbeta_sum, dgamma_sum);
                 VS_CHECK_LAUNCH("vs_bn_act_bwd (group sums)");
             }
             return VS_OK;

@@ -1315,6 +1315,9 @@ def _bn_apply(z, training, rmean, rvar, momentum, eps, groups, gamma, beta, act,
     """BatchNorm (+ activation) of a convolution output z on the two-launch path: (y, mean, invstd).  Training with tracked running estimates:
     the fold of the running estimates rides in the apply launch (VS_BN_RUNNING_FUSED=0: the separate bn_running launch)."""
     if training:
+        if ops.bn_slab_supported(z, groups):
+            # (a call's channel slab fits one workgroup's registers: statistics and apply from ONE read of z)
+            return ops.bn_train_fwd_slab(z, gamma.detach(), beta.detach(), act, out_dt, rmean, rvar, momentum, eps, groups=groups)
         if rmean is not None and os.environ.get('VS_BN_RUNNING_FUSED', '1') == '1':
             mean, invstd, ub = ops.bn_stats_ub(z, eps, groups=groups)
             y = ops.bn_act_fwd(z, mean, invstd, gamma.detach(), beta.detach(), act, out_dt, groups=groups, running=(ub, rmean, rvar, momentum))

@@ -1187,6 +1187,29 @@ def bn_train_fwd_small(x, gamma, beta, act, out_dtype, running_mean=None, runnin
     return y, mean, invstd
 
 
+def bn_slab_supported(x, groups=1):
+    """A (call group, channel) slab of `x` fits the registers of one workgroup (`bn_train_fwd_slab`: the tensor is read once)."""
+    B, C = x.shape[0], x.shape[1]
+    return (B % groups == 0 and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and bool(_lib.load_library().vs_bn_train_fwd_slab_supported(dtype_code(x), B // groups, C, x.numel() // (B * C))))
+
+
+def bn_train_fwd_slab(x, gamma, beta, act, out_dtype, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, groups=1):
+    """Training-mode BatchNorm + activation of `groups` calls stacked along the batch axis, every (call, channel) slab read ONCE (held in
+    registers between the statistics and the apply phase).  Returns (y, mean [groups, C], invstd [groups, C])."""
+    require_cuda(x)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    stats = torch.empty((3, groups, C), dtype=torch.float32, device=x.device)
+    e0 = _pb()
+    check(_lib.load_library().vs_bn_train_fwd_slab(x.data_ptr(), dtype_code(x), y.data_ptr(), dtype_code(y), gamma.data_ptr(), beta.data_ptr(), ACT[act],
+                                                   stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                                   float(momentum), float(eps), B, C, HW, groups, stream_ptr()), 'vs_bn_train_fwd_slab')
+    _pe(e0, 'vs_bn_fwd_slab', nbytes=float(x.numel() * (x.element_size() + y.element_size())))
+    return y, stats[0], stats[1]
+
+
 def bn_train_fwd_small_slabs(slabs, bias, z_dtype, gamma, beta, act, out_dtype, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
                              skip=None, want16=False):
     """`bn_train_fwd_small` on the split slabs [S, B, C, H, W] (fp32) of `conv3_img16`: the slab sum, the conv bias, the 16-bit rounding of

@@ -371,6 +371,53 @@ def test_batchnorm_small_slab_one_launch_paths(act, dtype, shape):
     assert rel(rmc, bn.running_mean) < 1e-5 and rel(rvc, bn.running_var) < 1e-5
 
 
+@pytest.mark.parametrize('act', ['leaky_relu', 'none', 'relu'])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape,groups', [((16, 24, 32, 32), 1), ((128, 8, 32, 32), 1), ((96, 6, 16, 16), 2), ((33, 5, 32, 32), 3), ((8, 9, 64, 64), 2),
+                                          ((40, 3, 16, 64), 1), ((63, 4, 32, 32), 1)])
+def test_batchnorm_register_resident_slabs(act, dtype, shape, groups):
+    """vs_bn_train_fwd_slab (a call's channel slab of 8 193 .. 131 072 16-bit elements read ONCE and held in registers: statistics, running
+    update, affine + activation) and the resident backward vs_bn_act_bwd takes for slabs up to 65 536 elements, per call group against torch's
+    BatchNorm2d in fp64 on the same (rounded) inputs; forward also against vs_bn_stats + vs_bn_act_fwd, the launches it replaces."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, C, H, W = shape
+    Bg = B // groups
+    x = (_rand(shape, 31) * 2 + 0.3).to(dtype)
+    gamma, beta = 1 + _rand((C,), 32, 0.3), _rand((C,), 33, 0.2)
+    dy = _rand(shape, 34).to(dtype)
+    rm, rv = _rand((C,), 35, 0.1), 1 + _rand((C,), 36, 0.2)
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    acts = {'leaky_relu': lambda t: F.leaky_relu(t, 0.2), 'relu': torch.relu, 'none': lambda t: t}
+    x64 = x.double().requires_grad_(True)
+    y64 = torch.cat([acts[act](bn(x64[g * Bg:(g + 1) * Bg])) for g in range(groups)])          # (one reference call per group, in order)
+    y64.backward(dy.double())
+    xc, dyc = x.cuda(), dy.cuda()
+    assert ops.bn_slab_supported(xc, groups), shape
+    rmc, rvc = rm.clone().cuda(), rv.clone().cuda()
+    y, mean, invstd = ops.bn_train_fwd_slab(xc, gamma.cuda(), beta.cuda(), act, torch.float32, rmc, rvc, 0.1, 1e-5, groups=groups)
+    assert mean.shape == (groups, C) and invstd.shape == (groups, C)
+
+    def rel(a, b):
+        return ((a.cpu().double() - b.cpu().double()).norm() / (b.cpu().double().norm() + 1e-30)).item()
+    assert rel(y, y64.detach()) < 2e-6
+    assert rel(rmc, bn.running_mean) < 2e-6 and rel(rvc, bn.running_var) < 2e-6
+    rm2, rv2 = rm.clone().cuda(), rv.clone().cuda()
+    m2, i2 = ops.bn_stats(xc, rm2, rv2, 0.1, 1e-5, groups=groups)
+    assert rel(mean, m2) < 1e-6 and rel(invstd, i2) < 1e-6 and rel(rmc, rm2) < 1e-6 and rel(rvc, rv2) < 1e-6
+    y16 = ops.bn_train_fwd_slab(xc, gamma.cuda(), beta.cuda(), act, dtype, None, None, 0.1, 1e-5, groups=groups)[0]
+    y16_2 = ops.bn_act_fwd(xc, m2, i2, gamma.cuda(), beta.cuda(), act, dtype, groups=groups)
+    assert rel(y16, y64.detach()) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+    assert (y16.float() - y16_2.float()).abs().max().item() <= 2e-2 * y16_2.float().abs().max().item()      # (an ulp where the statistics differ in their last bit)
+    # backward (slabs <= 65 536 elements run resident; the larger ones on the general kernels -- the same numbers either way)
+    dx, dg, db = ops.bn_act_bwd(dyc, xc, mean, invstd, gamma.cuda(), beta.cuda(), act, True, torch.float32, groups=groups)
+    assert rel(dx, x64.grad) < 2e-5
+    assert rel(dg, bn.weight.grad) < 2e-5 and rel(db, bn.bias.grad) < 2e-5
+    dx16 = ops.bn_act_bwd(dyc, xc, mean, invstd, gamma.cuda(), beta.cuda(), act, True, dtype, groups=groups)[0]
+    assert rel(dx16, x64.grad) < (6e-3 if dtype == torch.bfloat16 else 8e-4)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('transposed,geom', [(False, (8, 64, 16, 512, 3, 1, 1)), (False, (4, 24, 16, 40, 4, 2, 1)), (True, (6, 32, 8, 16, 4, 2, 1))])
 def test_conv_wgrad_accumulates_into_an_existing_gradient(dtype, transposed, geom):
