@@ -38,8 +38,13 @@ int launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, in
     constexpr size_t smem = (TileGeom<CT, LA, BM, BK>::ELEMS + TileGeom<CT, LB, BN, BK>::ELEMS) * sizeof(T);
     const int batch = epi.splits_per_batch > 0 ? plan.batch : 1;
     dim3 grid((unsigned)vs_cdiv(N, BN), (unsigned)vs_cdiv(M, BM), (unsigned)(plan.splits * batch));
+    // XCD runs (Epi::xcd_runs) from 64 workgroups upwards: PMC on the WaveEq decoder layers (3328 x 1200 x 1200, 988 tiles of 64 x 64) showed
+    // 77 MB fetched per launch for 11 MB of operands -- each of the eight L2s pulled the whole of A and B.  VS_GEMM_XCD=0: the plain map.
+    static const int xcd_mode = getenv("VS_GEMM_XCD") ? atoi(getenv("VS_GEMM_XCD")) : 1;
+    Epi e = epi;
+    e.xcd_runs = xcd_mode && (int64_t)grid.x * grid.y * grid.z >= 64;
     hipLaunchKernelGGL((gemm_kernel<CT, Dense<CT, LA>, Dense<CT, LB>, BM, BN, BK>), grid, dim3(256), smem, stream, a, b, M, N,
-                       K, (int)plan.k_tiles_per_split, epi, slabs);
+                       K, (int)plan.k_tiles_per_split, e, slabs);
     VS_CHECK_LAUNCH("vs_gemm");
     return VS_OK;
 }

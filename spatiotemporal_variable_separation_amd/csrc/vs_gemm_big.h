@@ -118,11 +118,7 @@ __device__ __forceinline__ u32x4 big_frag(const unsigned short* tile, int row0, 
     }
 }
 
-// XCD-aware, bijective block -> tile index (blocks b and b + 8 share an XCD under round-robin dispatch: speed only)
-__device__ __forceinline__ unsigned big_tile_of(unsigned b, unsigned nwg) {
-    const unsigned xcd = b & 7u, q = nwg >> 3, r = nwg & 7u;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
+// (big_tile_of, the XCD-aware block -> tile index: vs_gemm_core.h)
 
 // four consecutive columns n..n+3 of row m; vector I/O when the row-major addresses allow it
 // the Adam update of four consecutive parameters (row m, columns n..n+3) with the accumulators as their gradient

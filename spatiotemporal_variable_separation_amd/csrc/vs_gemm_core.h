@@ -45,7 +45,16 @@ struct Epi {
     float* adam_m; float* adam_v; unsigned short* adam_shadow; int adam_shadow_dtype;
     const int* adam_step; int adam_skipped;
     double adam_lr, adam_beta1, adam_beta2; float adam_eps;
+    // workgroup -> tile map: 1 = the workgroups of one XCD (b, b + 8, ... under round-robin dispatch) take a contiguous run of the
+    // (split, tile row, tile column) order, so an XCD's L2 holds a few A row panels and one K chunk instead of a share of everything
+    int xcd_runs;
 };
+
+// XCD-aware, bijective block -> tile index (blocks b and b + 8 share an XCD under round-robin dispatch: speed only)
+__device__ __forceinline__ unsigned big_tile_of(unsigned b, unsigned nwg) {
+    const unsigned xcd = b & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
 
 __device__ __forceinline__ Epi epi_for_batch(const Epi& e, int64_t batch) {
     Epi r = e;
@@ -227,14 +236,22 @@ __device__ __forceinline__ f32x4 frag_f32(const float* tile, int row0, int kk, i
 template <int CT, class OpA, class OpB, int BM, int BN, int BK, bool NCHW = false>
 __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int64_t N, int64_t K,
                                                    int k_tiles_per_split, Epi epi_in, float* slabs) {
-    int zsplit = blockIdx.z;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (epi_in.xcd_runs) {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned t = big_tile_of(bx + gx * (by + gy * bz), gx * gy * gridDim.z);
+        bz = t / (gx * gy);
+        by = (t - bz * gx * gy) / gx;
+        bx = t - (bz * gy + by) * gx;
+    }
+    int zsplit = bz;
     if (epi_in.splits_per_batch > 0) {                  // batched: z = batch * splits + split
-        const int batch = blockIdx.z / epi_in.splits_per_batch;
-        zsplit = blockIdx.z - batch * epi_in.splits_per_batch;
+        const int batch = bz / epi_in.splits_per_batch;
+        zsplit = bz - batch * epi_in.splits_per_batch;
         A.shift(batch * epi_in.batch_a);
         B.shift(batch * epi_in.batch_b);
     }
-    const Epi epi = epi_for_batch(epi_in, epi_in.splits_per_batch > 0 ? blockIdx.z / epi_in.splits_per_batch : 0);
+    const Epi epi = epi_for_batch(epi_in, epi_in.splits_per_batch > 0 ? bz / epi_in.splits_per_batch : 0);
     typedef typename CTraits<CT>::T T;
     typedef TileGeom<CT, OpA::layout, BM, BK> GA;
     typedef TileGeom<CT, OpB::layout, BN, BK> GB;
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
     const int64_t kt_total = (K + BK - 1) / BK;
     const int64_t kt_begin = (int64_t)zsplit * k_tiles_per_split;
     int64_t kt_end = kt_begin + k_tiles_per_split;
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
             for (int v = 0; v < 16; ++v) {
                 const int64_t m = m0 + wm + 32 * i + (v & 3) + 8 * (v >> 2) + rh;
                 if (m >= M) continue;
-                if (slabs) slabs[((int64_t)blockIdx.z * M + m) * N + n] = acc[i][j][v];
+                if (slabs) slabs[((int64_t)bz * M + m) * N + n] = acc[i][j][v];
                 else if constexpr (NCHW) epi_store_nchw(epi, m, col_base, acc[i][j][v]);
                 else epi_store(epi, m, n, acc[i][j][v]);
             }

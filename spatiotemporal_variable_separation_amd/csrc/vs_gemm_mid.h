@@ -92,11 +92,20 @@ struct MidOperand {
 template <int CT, int LA, int LB, bool NCHW, int ST, bool ADAM>
 __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
                                                           int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs, int64_t a_chan_hw) {
-    int zsplit = blockIdx.z;
+    // XCD runs over (split, tile): the workgroups of one XCD share K chunks, so a chunk of A and of B is fetched into ONE L2
+    unsigned tile, bz = blockIdx.z;
+    if (epi_in.xcd_runs) {
+        const unsigned t = big_tile_of(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x * gridDim.z);
+        bz = t / gridDim.x;
+        tile = t - bz * gridDim.x;
+    } else {
+        tile = big_tile_of(blockIdx.x, gridDim.x);
+    }
+    int zsplit = bz;
     int batch = 0;
     if (epi_in.splits_per_batch > 0) {
-        batch = blockIdx.z / epi_in.splits_per_batch;
-        zsplit = blockIdx.z - batch * epi_in.splits_per_batch;
+        batch = bz / epi_in.splits_per_batch;
+        zsplit = bz - batch * epi_in.splits_per_batch;
         Ap += batch * epi_in.batch_a;
         Bp += batch * epi_in.batch_b;
     }
@@ -106,7 +115,6 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = wave >> 1, wc = wave & 1;
-    const unsigned tile = big_tile_of(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(tile / (unsigned)tiles_n) * 128, n0 = (int64_t)(tile % (unsigned)tiles_n) * 128;
     const int64_t kt_total = (K + BIG_BK - 1) / BIG_BK;
     const int64_t kt_begin = (int64_t)zsplit * k_tiles_per_split;
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
     // ---- epilogue: accumulators -> LDS (row-major 64 x 64 fp32 per wave) -> coalesced row stores ----
     float* stg = reinterpret_cast<float*>(smem) + wave * (64 * 64);          // 16 KiB per wave, the whole 64 KiB ring
     const int cj = lane & 31, rh = 4 * (lane >> 5);
-    float* slab_base = slabs ? slabs + (int64_t)blockIdx.z * M * N : nullptr;
+    float* slab_base = slabs ? slabs + (int64_t)bz * M * N : nullptr;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -247,6 +255,12 @@ int mid_launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M
     } else {
         const int tiles_m = (int)vs_cdiv(M, 128), tiles_n = (int)vs_cdiv(N, 128);
         dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)(splits * batch));
+        // several splits: the XCD runs go over (split, tile) -- the 256 x 1200 x 20480 encoder layer (20 tiles x 22 splits) fetched 147 MB for
+        // 60 MB of operands with the splits of one K chunk spread over all eight L2s.  VS_GEMM_XCD=0: runs over the tiles of each split only.
+        static const int xcd_mode = getenv("VS_GEMM_XCD") ? atoi(getenv("VS_GEMM_XCD")) : 1;
+        Epi e_runs = epi;
+        e_runs.xcd_runs = xcd_mode && grid.z > 1;
+        const Epi& epi_l = e_runs;
         auto go = [&](auto kfn, int st_, bool& attr_set) -> int {
             const int lds = st_ * MID_TILE_BYTES;
             if (!attr_set) {                           // above the 64 KiB default limit of dynamic LDS
@@ -255,7 +269,7 @@ int mid_launch(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M
                 attr_set = true;
             }
             hipLaunchKernelGGL(kfn, grid, dim3(256), lds, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K,
-                               (int)k_tiles_per_split, tiles_n, epi, slabs, a_chan_hw);
+                               (int)k_tiles_per_split, tiles_n, epi_l, slabs, a_chan_hw);
             return VS_OK;
         };
         static bool set5 = false, set10 = false, set_adam = false;
