@@ -146,6 +146,34 @@ def test_pool_upsample(dtype):
     assert ((dxu.cpu().double() - x64b.grad).norm() / x64b.grad.norm()).item() < 1e-6
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(3, 5, 16, 16), (2, 7, 32, 64), (5, 3, 4, 48), (1, 2, 64, 32)])
+def test_pool_upsample_16_byte_forms(dtype, shape):
+    """The 16-byte kernels vs_maxpool2_* / vs_upsample2_* take for 16-bit tensors whose small-map rows are whole 16-byte pieces (the VGG
+    encoders / decoders, conv.py:127-171, 296-314): forward results equal torch's on the same values bit for bit, the pooling gradient too
+    (ties included: the first maximum in scan order wins), the upsampling gradient is the fp32 sum of four rounded once."""
+    from spatiotemporal_variable_separation_amd import ops
+    B, C, H, W = shape
+    x = _rand(shape, 41).to(dtype)
+    x[0, 0, :2, :4] = 0.5                                        # a window of equal values: the gradient goes to its first pixel
+    x64 = x.double().requires_grad_(True)
+    y64 = F.max_pool2d(x64, 2, 2)
+    dy = _rand(tuple(y64.shape), 42).to(dtype)
+    y64.backward(dy.double())
+    y = ops.maxpool2_fwd(x.cuda())
+    assert y.dtype == dtype and torch.equal(y.cpu().double(), y64.detach())
+    dx = ops.maxpool2_bwd(x.cuda(), dy.cuda())
+    assert dx.dtype == dtype and torch.equal(dx.cpu().double(), x64.grad)
+    xs = x[:, :, :H // 2, :W // 2].contiguous()                  # (small map with rows of W / 2 >= 8 pixels)
+    u = ops.upsample2_fwd(xs.cuda())
+    assert u.dtype == dtype and torch.equal(u.cpu(), F.interpolate(xs.float(), scale_factor=2, mode='nearest').to(dtype))
+    du = _rand(tuple(u.shape), 43).to(dtype)
+    dxu = ops.upsample2_bwd(du.cuda(), dtype)
+    d = du.float()
+    want = (((d[:, :, 0::2, 0::2] + d[:, :, 0::2, 1::2]) + d[:, :, 1::2, 0::2]) + d[:, :, 1::2, 1::2]).to(dtype)
+    assert dxu.dtype == dtype and torch.equal(dxu.cpu(), want)
+
+
 def test_grouped_batchnorm_equals_sequential_calls():
     """groups = G on a stacked batch == G separate BatchNorm calls (statistics, outputs, gradients, running stats)."""
     from spatiotemporal_variable_separation_amd import ops
