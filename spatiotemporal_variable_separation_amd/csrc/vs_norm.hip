@@ -909,6 +909,109 @@ __global__ __launch_bounds__(1024) void bn_bwd_slab_kernel(const unsigned short*
     }
 }
 
+// Slabs of 65 537 .. 131 072 elements (the 32 x 32 maps of a 100-128 sample call: the widest BatchNorm layers of the Moving-MNIST and TaxiBJ
+// networks): x stays packed in registers (<= 16 vectors), the first NL vectors of dy go global -> LDS by LDS-DMA (144 KB, no register pass) and
+// stay there, the remaining ones are read again in the apply phase (from L2 / the Infinity Cache: a workgroup's tail is <= 112 KB).  Traffic
+// 3 + (NV - NL) / NV tensor passes instead of 5 (bn_bwd_reduce_kernel + bn_bwd_apply_kernel).
+__device__ __attribute__((aligned(16))) const uint32_t bn_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int NV, int NL, int ACT, int XD>
+__global__ __launch_bounds__(1024) void bn_bwd_slab_lds_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dz,
+                                                               float* sum_dz_xhat, void* __restrict__ dx, int dxd, int Bg, int C, int HW) {
+    extern __shared__ __attribute__((aligned(16))) char gl_raw[];            // dy vectors [NL][1024] x 16 bytes (the ONLY dynamic LDS object)
+    __shared__ double red[16];
+    u32x4* gl = reinterpret_cast<u32x4*>(gl_raw);
+    const int c = blockIdx.x, grp = blockIdx.y;
+    const int per = HW >> 3, bstep = 1024 / per;                           // (the thread -> vector map of bn_fwd_slab_kernel)
+    const int bt0 = threadIdx.x / per;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t off0 = (((int64_t)grp * Bg + bt0) * C + c) * (int64_t)HW + ((threadIdx.x - bt0 * per) << 3);
+    const int64_t rstride = (int64_t)bstep * C * HW;
+    const float mu = mean[grp * C + c], is = invstd[grp * C + c], g = gamma[c], bt = beta[c];
+    // dy vectors 0 .. NL-1: global -> LDS, lane-linear (a thread later reads exactly the 16 bytes its own lane's DMA wrote)
+#pragma unroll
+    for (int r = 0; r < NL; ++r) {
+        const void* src = (bt0 + r * bstep < Bg) ? (const void*)(dy + off0 + r * rstride) : (const void*)bn_zero16;
+        const uint32_t dst = (uint32_t)(uintptr_t)(gl_raw + ((size_t)r * 1024 + wave * 64) * 16);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
+    }
+    u32x4 xv[NV], gt[NV - NL];
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        xv[r] = u32x4{0u, 0u, 0u, 0u};
+        if (bt0 + r * bstep < Bg) xv[r] = *reinterpret_cast<const u32x4*>(x + off0 + r * rstride);
+    }
+#pragma unroll
+    for (int r = NL; r < NV; ++r) {
+        gt[r - NL] = u32x4{0u, 0u, 0u, 0u};
+        if (bt0 + r * bstep < Bg) gt[r - NL] = *reinterpret_cast<const u32x4*>(dy + off0 + r * rstride);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // (the DMA is counted with the loads)
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        u32x4 gv;
+        if (r < NL) gv = gl[r * 1024 + threadIdx.x];
+        else gv = gt[r < NL ? 0 : r - NL];
+        asm volatile("" : "+v"(xv[r]), "+v"(gv), "+v"(a1), "+v"(a2));       // (one vector pair at a time, see bn_bwd_slab_kernel)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (slab_get<XD>(xv[r], j) - mu) * is;
+            const float dz = slab_get<XD>(gv, j) * slab_act_grad<ACT>(xh * g + bt, act);
+            a1 += dz;
+            a2 += dz * xh;
+        }
+    }
+    slab_fence<NV>(xv);
+    const double t1 = block_sum((double)a1, red);
+    const double t2 = block_sum((double)a2, red);
+    if (threadIdx.x == 0) { sum_dz[grp * C + c] = (float)t1; sum_dz_xhat[grp * C + c] = (float)t2; }
+    const float inv_n = 1.f / (float)((int64_t)Bg * HW);
+    const float k1 = (float)t1 * inv_n, k2 = (float)t2 * inv_n;
+    // the tail of dy again (its registers were given up after the sums)
+#pragma unroll
+    for (int r = NL; r < NV; ++r) {
+        gt[r - NL] = u32x4{0u, 0u, 0u, 0u};
+        if (bt0 + r * bstep < Bg) gt[r - NL] = *reinterpret_cast<const u32x4*>(dy + off0 + r * rstride);
+    }
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+        u32x4 gv;
+        if (r < NL) gv = gl[r * 1024 + threadIdx.x];
+        else gv = gt[r < NL ? 0 : r - NL];
+        asm volatile("" : "+v"(xv[r]), "+v"(gv) : : "memory");
+        if (bt0 + r * bstep < Bg) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (slab_get<XD>(xv[r], j) - mu) * is;
+                const float dz = slab_get<XD>(gv, j) * slab_act_grad<ACT>(xh * g + bt, act);
+                o[j] = g * is * (dz - k1 - xh * k2);
+            }
+            st_vec(dx, dxd, off0 + r * rstride, o, 8);
+        }
+    }
+}
+
+template <int NV, int ACT, int XD>
+int launch_bn_bwd_slab_lds(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, int act, float* s1, float* s2, void* dx, int dxd, int Bg, int C, int HW) {
+    constexpr int NL = 9;
+    auto kfn = bn_bwd_slab_lds_kernel<NV, NL, ACT, XD>;
+    constexpr int lds = NL * 1024 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {                                    // above the 64 KiB default limit of dynamic LDS
+        if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return vs_fail(VS_ERR_LAUNCH, "cannot raise the dynamic LDS limit to %d bytes", lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(1024), lds, st, (const unsigned short*)dy, (const unsigned short*)x, mean, invstd, gamma, beta, act, s1, s2, dx, dxd,
+                       Bg, C, HW);
+    return VS_OK;
+}
+
 // per-channel sum; blockIdx.y splits the (batch x pixel) extent so that few-channel tensors (the 1-channel frames of the
 // last decoder layer) still fill the chip; partial sums meet in one float atomic per workgroup
 __global__ __launch_bounds__(256) void chan_sum_kernel(const void* x, int xd, int B, int C, int64_t HW, float* out) {
@@ -1484,6 +1587,41 @@ extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, i
 #undef VS_BN_SLAB_NV
 #undef VS_BN_SLAB
             VS_CHECK_LAUNCH("vs_bn_act_bwd (resident slabs)");
+            if (dbeta_sum) {
+                hipLaunchKernelGGL(group_sum2_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, st, dbeta, dgamma, groups, C, dbeta_sum, dgamma_sum);
+                VS_CHECK_LAUNCH("vs_bn_act_bwd (group sums)");
+            }
+            return VS_OK;
+        }
+    }
+    {
+        // slabs of 65 537 .. 131 072 elements: x in registers, dy in LDS + a re-read tail (bn_bwd_slab_lds_kernel).  VS_BN_SLAB=2: not these.
+        static const int slab_mode = getenv("VS_BN_SLAB") ? atoi(getenv("VS_BN_SLAB")) : 1;
+        const int64_t nslab = (int64_t)(B / groups) * HW;
+        if (slab_mode == 1 && training && vec == 1 && vs_is16(x_dtype) && x_dtype == dy_dtype && nslab > 65536 && nslab <= 131072 && HW <= 8192 &&
+            (HW & (HW - 1)) == 0 && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0) {
+            const int64_t nvec = nslab / 8;
+            const dim3 grid(C, groups);
+            hipStream_t st = (hipStream_t)stream;
+            int rc;
+#define VS_BN_SLAB(NV, AV)                                                                                                                            \
+            rc = x_dtype == VS_BF16 ? launch_bn_bwd_slab_lds<NV, AV, VS_BF16>(grid, st, dy, x, mean, invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype,   \
+                                                                              B / groups, C, (int)HW)                                                  \
+                                    : launch_bn_bwd_slab_lds<NV, AV, VS_F16>(grid, st, dy, x, mean, invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype,    \
+                                                                             B / groups, C, (int)HW)
+#define VS_BN_SLAB_NV(AV)                              \
+            do {                                       \
+                if (nvec <= 12288) VS_BN_SLAB(12, AV); \
+                else if (nvec <= 14336) VS_BN_SLAB(14, AV); \
+                else VS_BN_SLAB(16, AV);               \
+            } while (0)
+            if (act == VS_ACT_LEAKY) VS_BN_SLAB_NV(VS_ACT_LEAKY);
+            else if (act == VS_ACT_NONE) VS_BN_SLAB_NV(VS_ACT_NONE);
+            else VS_BN_SLAB_NV(-1);
+#undef VS_BN_SLAB_NV
+#undef VS_BN_SLAB
+            if (rc != VS_OK) return rc;
+            VS_CHECK_LAUNCH("vs_bn_act_bwd (resident slabs, LDS)");
             if (dbeta_sum) {
                 hipLaunchKernelGGL(group_sum2_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, st, dbeta, dgamma, groups, C, dbeta_sum, dgamma_sum);
                 VS_CHECK_LAUNCH("vs_bn_act_bwd (group sums)");
