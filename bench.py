@@ -336,7 +336,8 @@ def run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=N
     prof = ops.profile_collect() if events_on else {}
     err = ops.rollout_exchange_error(dev)
     if err:
-        raise RuntimeError('the rollout kernels reported an inter-workgroup exchange time-out (code %d): results are invalid' % err)
+        raise RuntimeError('the rollout kernels reported an inter-workgroup exchange time-out (code %d): results are invalid '
+                           '(VS_ROLLOUT_XCD_LOCAL=0 selects the placement-independent agent-scope exchange)' % err)
     final_loss = float(loss.item())
     n_all = sum(p.numel() for p in net.parameters())
     n_fused = sum(p.numel() for p in getattr(opt, '_fused', []))

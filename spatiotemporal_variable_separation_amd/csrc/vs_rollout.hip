@@ -634,7 +634,17 @@ constexpr int SP = 72;            // LDS row pitch of the hidden-slice operand (
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __forceinline__ u64 gload(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void gstore(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// XL = false: agent-scope store (sc1: written through to the fabric, visible to every XCD).  XL = true: the ring of a slab lives on ONE XCD
+// (slab = blockIdx % nslabs with nslabs % 8 == 0 under the round-robin dispatch over the 8 XCDs), so a granule only has to reach that XCD's
+// L2, where the consumers' sc1 loads find it: a plain store.  Measured (tools/probes/xcd_pingpong.hip): 210 ns per hop against 385 ns for
+// sc1 / sc1 -- and NOT visible from another XCD until the line is evicted.  The dispatcher's round robin may start a launch on any XCD (blocks
+// are NOT pinned to XCD blockIdx % 8), but blocks 8 apart meet on one XCD; should that ever not hold, a consumer keeps polling an old epoch
+// and runs into the spin limit (the sticky error flag) -- a granule carries its epoch, so a stale line can never pass for the new value.
+template <bool XL>
+__device__ __forceinline__ void gstore(u64* p, u64 v) {
+    if constexpr (XL) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Two adjacent granules per load.  A relaxed agent-scope 8-byte atomic load is `global_load_dwordx2 ... sc1`; the exchange is
 // bound by the per-CU load issue rate, and a 16-byte `global_load_dwordx4 ... sc1` moves two granules per lane and issue slot
@@ -724,7 +734,7 @@ __device__ __forceinline__ void store_tile_masks(unsigned* dst, const u64* bal) 
 // next layer's weight fragments are loaded with).  Layer a -> layer b therefore never touches LDS: wave w computes the
 // feature tiles T = 4 j + w of layer a and contracts exactly those features in layer b (K split over the 4 waves, all 64
 // output features of the part); the four K-partials meet in LDS (16 KB, one barrier), wave w finishes output tile w.
-template <int KH, bool FWD, int CT>
+template <int KH, bool FWD, int CT, bool XL = false>
 __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_pitch /* words per row of m1/m2 */, long long* dbg) {
     typedef typename RT<CT>::T T;
     constexpr int H = 32 * KH, P = KH / 2, NJ = KH / 2, NKB = NJ / 2 > 0 ? NJ / 2 : 1;
@@ -885,7 +895,7 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
         if (part == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                gstore(slot(epoch_out, P) + er * 32 + ec + i, ((u64)epoch_out << 32) | (u64)__float_as_uint(xv[i]));
+                gstore<XL>(slot(epoch_out, P) + er * 32 + ec + i, ((u64)epoch_out << 32) | (u64)__float_as_uint(xv[i]));
                 if (erow && ec + i < C) {
                     if (FWD) {
                         ((T*)p.xin_save)[(sbase + er) * C + ec + i] = (T)xv[i];
@@ -999,7 +1009,7 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
             acc = mma<CT>(*reinterpret_cast<const u32x4*>(arow + 32), wc[1], acc);
             u64* dst = slot(epoch_out, part) + 16 * w + c;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gstore(dst + (4 * g + r) * 32, ((u64)epoch_out << 32) | (u64)__float_as_uint(acc[r]));
+            for (int r = 0; r < 4; ++r) gstore<XL>(dst + (4 * g + r) * 32, ((u64)epoch_out << 32) | (u64)__float_as_uint(acc[r]));
         }
         WS_STAMP(7);
         // the next block-step of this workgroup overwrites xa / ah2 / pb only after its receive, i.e. after the other blocks of
@@ -1058,20 +1068,30 @@ int launch_ws(int compute, bool fwd, const RollParams& p, int mask_pitch, size_t
     if (!dbg_buf && hipMalloc(&dbg_buf, 8 * 8 * 4096) != hipSuccess) dbg_buf = nullptr;
     dbg = Q <= 4096 ? dbg_buf : nullptr;
 #endif
-#define VS_WS_LAUNCH(KH)                                                                                              \
+    // rings on one XCD each (see wsr::gstore): 8, 16, ... slabs.  VS_ROLLOUT_XCD_LOCAL=0: agent-scope stores always.
+    const char* xl_env = getenv("VS_ROLLOUT_XCD_LOCAL");                      // (read per call: tests switch it)
+    const int xl_mode = xl_env ? atoi(xl_env) : 1;
+    const bool xl = xl_mode && nslabs % 8 == 0;
+#define VS_WS_LAUNCH_X(KH, XLV)                                                                                       \
     do {                                                                                                              \
         if (compute == VS_BF16) {                                                                                     \
-            if (fwd) hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, true, VS_BF16>), grid, block, 0, stream, p, mask_pitch, dbg);  \
-            else hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, false, VS_BF16>), grid, block, 0, stream, p, mask_pitch, dbg);     \
+            if (fwd) hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, true, VS_BF16, XLV>), grid, block, 0, stream, p, mask_pitch, dbg);  \
+            else hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, false, VS_BF16, XLV>), grid, block, 0, stream, p, mask_pitch, dbg);     \
         } else {                                                                                                      \
-            if (fwd) hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, true, VS_F16>), grid, block, 0, stream, p, mask_pitch, dbg);   \
-            else hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, false, VS_F16>), grid, block, 0, stream, p, mask_pitch, dbg);      \
+            if (fwd) hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, true, VS_F16, XLV>), grid, block, 0, stream, p, mask_pitch, dbg);   \
+            else hipLaunchKernelGGL((wsr::rollout_ws_kernel<KH, false, VS_F16, XLV>), grid, block, 0, stream, p, mask_pitch, dbg);      \
         }                                                                                                             \
+    } while (0)
+#define VS_WS_LAUNCH(KH)                    \
+    do {                                    \
+        if (xl) VS_WS_LAUNCH_X(KH, true);   \
+        else VS_WS_LAUNCH_X(KH, false);     \
     } while (0)
     if (p.H == 512) VS_WS_LAUNCH(16);
     else if (p.H == 256) VS_WS_LAUNCH(8);
     else VS_WS_LAUNCH(4);
 #undef VS_WS_LAUNCH
+#undef VS_WS_LAUNCH_X
     VS_CHECK_LAUNCH("vs_mlp_rollout (weight-stationary)");
 #ifdef VS_WS_TIMING
     if (dbg) {          // debug build only: phase timestamps of (slab 0, part 0) of every block, 10 ns ticks

@@ -713,7 +713,8 @@ def check_rollout_exchange(device):
     err = ops.rollout_exchange_error(device)
     if err:
         raise VarsepHipError('rollout kernel: inter-workgroup exchange timed out (code %d) -- the integrator results of at least one '
-                             'step since the last check are invalid; not continuing' % err)
+                             'step since the last check are invalid; not continuing.  (With 8 / 16 row slabs the exchange relies on the '
+                             'workgroups of a slab sharing an XCD; VS_ROLLOUT_XCD_LOCAL=0 selects the placement-independent agent-scope exchange.)' % err)
 
 
 def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb_ae, lamb_s, lamb_t, lamb_pred,

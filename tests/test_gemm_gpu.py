@@ -150,6 +150,38 @@ def test_fused_rollout_equals_stepwise(precision, dims):
         assert rel(gf, p.grad) < tol * 5, (gf.shape,)
 
 
+@pytest.mark.parametrize('dims', [(128, 32, 512, 3, 25), (256, 32, 256, 2, 6), (128, 20, 128, 1, 9)])
+def test_rollout_ring_on_one_xcd_equals_agent_scope_exchange(dims, monkeypatch):
+    """The weight-stationary rollout with 8 / 16 slabs keeps every slab's ring of workgroups on one XCD and publishes its exchange granules with
+    plain stores (they meet the consumers' sc1 loads in that XCD's L2; VS_ROLLOUT_XCD_LOCAL=0: agent-scope stores through the fabric).  Same
+    arithmetic: codes, residuals and every gradient bit for bit, and no exchange time-out."""
+    from spatiotemporal_variable_separation_amd import functional as VF, ops
+    from spatiotemporal_variable_separation_amd.networks.resnet import MLPResnet
+    from oracle.detdata import det_uniform
+    B, C, H, nb, n = dims
+    torch.manual_seed(0)
+    net = MLPResnet(C, nb, H).cuda()
+    x0 = (det_uniform((B, C), 7) - 0.5).cuda()
+    g = (det_uniform((B, n, C), 8) - 0.5).cuda()
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('VS_ROLLOUT_XCD_LOCAL', mode)
+        with VF.precision('bf16'):
+            net.zero_grad()
+            xa = x0.clone().requires_grad_(True)
+            codes, res = net.rollout(xa, n)
+            (codes * g).sum().backward()
+        torch.cuda.synchronize()
+        assert ops.rollout_exchange_error(x0.device) == 0
+        out[mode] = [codes.detach().clone(), xa.grad.clone()] + [r.detach().clone() for step in res for r in step] + [p.grad.clone() for p in net.parameters()]
+    assert len(out['1']) == len(out['0'])
+    for a, b in zip(out['1'], out['0']):
+        if a.dim() == 1:                        # bias gradients: column sums finished with fp32 atomics (order varies from run to run)
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
+        else:
+            assert torch.equal(a, b)
+
+
 def test_colsum_multi_shapes_and_dtypes():
     """All bias gradients of a chain in one launch: vector path (8-column units), ragged columns, odd row counts, views."""
     from spatiotemporal_variable_separation_amd import ops
