@@ -48,6 +48,7 @@ struct RollParams {
                                  // reads and clears it -- ops.rollout_exchange_error / train.check_rollout_exchange)
     size_t xtotal;               // workspace bytes (all but the last 16 are zero-filled before every launch)
     unsigned spin_limit;         // rounds a wait may take before it gives up (VS_ROLLOUT_SPIN_LIMIT, default 2^22)
+    int nap;                     // weight-stationary form: s_sleep units (64 clocks) between seeing the producer's input and polling its partials
     // backward
     const float* g;              // [B, n, C] gradient wrt every t_code
     float* dx0;                  // [B, C]
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
                 if (++spins > p.spin_limit) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_s_sleep(WS_NAP);
+            for (int z = 0; z < p.nap; ++z) __builtin_amdgcn_s_sleep(1);
             u32x4 v[P + 1];
             const u64* addr[P + 1];
 #pragma unroll
@@ -1164,6 +1165,7 @@ int setup_exchange(RollParams& p, int compute, void* workspace, size_t workspace
 // weight-stationary form: same decision in both directions (the sign-bit layout differs from the slab form)
 bool setup_ws(RollParams& p, int compute, void* workspace, size_t workspace_bytes, int* mask_pitch) {
     p.spin_limit = spin_limit_from_env();
+    { const char* e = getenv("VS_ROLLOUT_NAP"); p.nap = e ? atoi(e) : WS_NAP; if (p.nap < 0 || p.nap > 64) p.nap = WS_NAP; }
     if (!wsr::usable(compute, p.B, p.C, p.H, p.nb) || p.n < 2) return false;
     if (!workspace || workspace_bytes < wsr::exchange_bytes(p.B, p.H) + 16) return false;
     p.xbuf = (u64*)workspace;
