@@ -466,8 +466,10 @@ int vs_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, 
  *   m1_save / m2_save [nb, n-1, Bp, P, 32] uint32, Bp = B rounded up to 16, P = vs_mlp_rollout_parts(...): ReLU sign
  *             bits of h1 / h2, opaque to the caller (written by _fwd, read by _bwd of the same sizes), so the backward
  *             kernel reads a few words per step instead of the activations
- *   workspace: exchange area of vs_mlp_rollout_workspace_bytes(...) bytes (zeroed by the call; its last 16 bytes hold a
- *             timeout flag).  bf16, C <= 32, H in {128, 256, 512}, ceil(B/16) * n_blocks * H/64 <= 224: weight-stationary
+ *   workspace: exchange area of vs_mlp_rollout_workspace_bytes(...) bytes, ZERO-FILLED ONCE by the caller when it creates it and then
+ *             left to the library (the weight-stationary form numbers its launches through per-slab epoch words inside it and
+ *             never clears it; the slab form clears it itself; an all-zero area is always a valid state); its last 16 bytes hold a
+ *             timeout flag.  bf16, C <= 32, H in {128, 256, 512}, ceil(B/16) * n_blocks * H/64 <= 224: weight-stationary
  *             pipelined form -- one workgroup per (16-row slab, block, 64-column part) keeps its weight fragments in
  *             registers for the whole rollout and hands [16, C] partials to the workgroups of the next block through
  *             the exchange area.  Otherwise the slab form:  When the hidden size

@@ -49,6 +49,7 @@ struct RollParams {
     size_t xtotal;               // workspace bytes (all but the last 16 are zero-filled before every launch)
     unsigned spin_limit;         // rounds a wait may take before it gives up (VS_ROLLOUT_SPIN_LIMIT, default 2^22)
     int nap;                     // weight-stationary form: s_sleep units (64 clocks) between seeing the producer's input and polling its partials
+    unsigned* ebase;             // weight-stationary form: per-slab epoch base words (even; advanced by the slab's last workgroup of every launch)
     // backward
     const float* g;              // [B, n, C] gradient wrt every t_code
     float* dx0;                  // [B, C]
@@ -799,6 +800,10 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
     }
     __syncthreads();
 
+    // Epochs of this launch = ebase + block-step index: the slab's base word is even, was left by the previous launch (forward, backward,
+    // or the previous replay) above every tag that launch used, and is advanced again below -- so the exchange area never has to be
+    // cleared between launches (a 5 us fill launch in front of each of the two integrator kernels of a step).
+    const unsigned ebase = p.ebase[slab];
     u64* const xbase = p.xbuf;
     auto slot = [&](unsigned epoch, int who) -> u64* {
         return xbase + ((((int64_t)(epoch & 1u) * nslabs + slab) * (P + 1) + who) << 9);
@@ -836,7 +841,7 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
                 xv[i] = v;
             }
         } else {
-            const unsigned epoch = (unsigned)q;
+            const unsigned epoch = ebase + (unsigned)q;
             unsigned spins = 0;
             // Phase 1: cheap wait (one 8-byte load per thread and round) for the producer's block INPUT, which part 0 publishes a
             // whole block-step of compute before the partials.  Phase 2: the partials are now ~1 us away -- after a fixed nap
@@ -884,10 +889,12 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
                         else p.dx0[(int64_t)(row0 + er) * C + ec + i] = xv[i];
                     }
                 }
+                // the slab's last block-step: every workgroup of its ring has long read the base; the next launch starts above this one's tags
+                if (tid == 0) p.ebase[slab] = ebase + (((unsigned)q + 2u) & ~1u);
             }
             break;
         }
-        const unsigned epoch_out = (unsigned)q + 1u;
+        const unsigned epoch_out = ebase + (unsigned)q + 1u;
         *reinterpret_cast<unsigned*>(xa + er * XP + ec) = pk_bf16<CT>(xv[0], xv[1]);
         WS_STAMP(2);
         lds_barrier();
@@ -1038,6 +1045,8 @@ inline size_t exchange_bytes(int B, int H) {
     const int nslabs = (B + 15) / 16, P = H / 64;
     return (size_t)2 * nslabs * (P + 1) * 512 * sizeof(u64);
 }
+// + the per-slab epoch base words behind the granules (padded to whole 16-byte units)
+inline size_t base_words_bytes(int B) { return (size_t)((((B + 15) / 16) * 4 + 15) / 16) * 16; }
 
 }  // namespace wsr
 
@@ -1058,7 +1067,10 @@ int pick_parts(int compute, int B, int C, int H) {
 }
 
 int launch_ws(int compute, bool fwd, const RollParams& p, int mask_pitch, size_t workspace_bytes, hipStream_t stream) {
-    if (vs_zero_async(p.xbuf, p.xtotal - 16, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: zero fill failed");
+    // No fill: the workspace is zero when the caller creates it (the contract of vs_mlp_rollout_workspace_bytes) and every launch tags its
+    // granules above the previous launch's (RollParams::ebase).  VS_ROLLOUT_ZERO=1: clear it anyway (all-zero is always a valid state).
+    static const int zero_mode = getenv("VS_ROLLOUT_ZERO") ? atoi(getenv("VS_ROLLOUT_ZERO")) : 0;
+    if (zero_mode && vs_zero_async(p.xbuf, p.xtotal - 16, stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_mlp_rollout: zero fill failed");
     (void)workspace_bytes;
     const int nslabs = (p.B + 15) / 16, P = p.H / 64;
     dim3 grid((unsigned)(nslabs * p.nb * P)), block(wsr::WT);
@@ -1167,8 +1179,9 @@ bool setup_ws(RollParams& p, int compute, void* workspace, size_t workspace_byte
     p.spin_limit = spin_limit_from_env();
     { const char* e = getenv("VS_ROLLOUT_NAP"); p.nap = e ? atoi(e) : WS_NAP; if (p.nap < 0 || p.nap > 64) p.nap = WS_NAP; }
     if (!wsr::usable(compute, p.B, p.C, p.H, p.nb) || p.n < 2) return false;
-    if (!workspace || workspace_bytes < wsr::exchange_bytes(p.B, p.H) + 16) return false;
+    if (!workspace || workspace_bytes < wsr::exchange_bytes(p.B, p.H) + wsr::base_words_bytes(p.B) + 16) return false;
     p.xbuf = (u64*)workspace;
+    p.ebase = (unsigned*)((char*)workspace + wsr::exchange_bytes(p.B, p.H));
     p.xtotal = workspace_bytes & ~(size_t)15;
     p.xerr = (unsigned*)((char*)workspace + p.xtotal - 16);
     *mask_pitch = pick_parts(compute, p.B, p.C, p.H) * 32;
@@ -1183,7 +1196,7 @@ extern "C" size_t vs_mlp_rollout_workspace_bytes(int compute, int B, int C, int 
     const int P = pick_parts(compute, B, C, H);
     size_t need = P > 1 ? (size_t)2 * ((B + 15) / 16) * P * 16 * round_up(C, 4) * sizeof(u64) + 16 : 0;
     if (vs_is16(compute) && C <= 32 && (H == 128 || H == 256 || H == 512)) {       // weight-stationary form (any n_blocks)
-        const size_t ws = wsr::exchange_bytes(B, H) + 16;
+        const size_t ws = wsr::exchange_bytes(B, H) + wsr::base_words_bytes(B) + 16;
         if (ws > need) need = ws;
     }
     return need;

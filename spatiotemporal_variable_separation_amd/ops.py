@@ -270,17 +270,17 @@ def transpose_cast(src, dtype, out=None):
 _roll_ws = {}
 
 
-def _rollout_workspace(nbytes, device):
-    """Exchange area of the multi-workgroup rollout (one per device, grow-only; zeroed by every call of the library)."""
+def _rollout_workspace(nbytes, device, geometry):
+    """Exchange area of the multi-workgroup rollout: one per device AND geometry (compute type, B, C, H), zero-filled here once and then left to
+    the library -- the weight-stationary form keeps per-slab epoch words in it and never clears it (include/varsep_hip.h), so an area is
+    never shared between layouts."""
     if not nbytes:
         return None
-    buf = _roll_ws.get(device.index)
-    if buf is None or buf.numel() < nbytes:
-        if buf is not None:
-            buf._vs_rollout_ws = True
-            _retired.append(buf)
+    key = (device.index,) + tuple(geometry)
+    buf = _roll_ws.get(key)
+    if buf is None or buf.numel() != nbytes:
         buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-        _roll_ws[device.index] = buf
+        _roll_ws[key] = buf
     return buf
 
 
@@ -290,8 +290,8 @@ def rollout_exchange_error(device, reset=True):
     device = torch.device(device) if not isinstance(device, torch.device) else device
     index = device.index if device.index is not None else torch.cuda.current_device()
     err = 0
-    for buf in [_roll_ws.get(index)] + [b for b in _retired if b.device.index == index and getattr(b, '_vs_rollout_ws', False)]:
-        if buf is None:
+    for key, buf in list(_roll_ws.items()):
+        if key[0] != index:
             continue
         word = buf[buf.numel() // 16 * 16 - 16:buf.numel() // 16 * 16 - 12].view(torch.int32)
         err |= int(word.item())
@@ -371,7 +371,7 @@ def mlp_rollout_fwd(x0, weights, biases, n_steps, H, want_residuals=True):
     Bp = (B + 15) // 16 * 16                 # sign-bit arrays: rows padded to whole 16-row slabs
     m1 = torch.empty((nb, steps, Bp, parts, 32), dtype=torch.int32, device=dev)
     m2 = torch.empty((nb, steps, Bp, parts, 32), dtype=torch.int32, device=dev)
-    xws = _rollout_workspace(lib.vs_mlp_rollout_workspace_bytes(code, B, C, H), dev)
+    xws = _rollout_workspace(lib.vs_mlp_rollout_workspace_bytes(code, B, C, H), dev, (code, B, C, H))
     wa, ba = _ptr_array(weights), _ptr_array(biases)
     e0 = _pb()
     check(_lib.load_library().vs_mlp_rollout_fwd(dtype_code(weights[0]), B, C, H, nb, n_steps, x0.data_ptr(),
@@ -400,7 +400,7 @@ def mlp_rollout_bwd(grad_t_codes, weights_t, h1, h2, m1, m2, n_steps):
     dh1 = torch.empty((nb, steps, B, H), dtype=cdt, device=dev)
     wa = _ptr_array(weights_t)
     lib = _lib.load_library()
-    xws = _rollout_workspace(lib.vs_mlp_rollout_workspace_bytes(dtype_code(weights_t[0]), B, C, H), dev)
+    xws = _rollout_workspace(lib.vs_mlp_rollout_workspace_bytes(dtype_code(weights_t[0]), B, C, H), dev, (dtype_code(weights_t[0]), B, C, H))
     e0 = _pb()
     check(_lib.load_library().vs_mlp_rollout_bwd(dtype_code(weights_t[0]), B, C, H, nb, n_steps, grad_t_codes.data_ptr(),
                                                  ctypes.cast(wa, ctypes.c_void_p), h1.data_ptr(), h2.data_ptr(),
