@@ -182,6 +182,38 @@ def test_rollout_ring_on_one_xcd_equals_agent_scope_exchange(dims, monkeypatch):
             assert torch.equal(a, b)
 
 
+def test_rollout_launches_share_an_exchange_area_that_is_never_cleared():
+    """The weight-stationary rollout never clears its exchange area: every launch tags its granules above the previous launch's (per-slab epoch
+    words inside the workspace, one workspace per geometry).  Forty forward + backward launches of one geometry interleaved with launches of
+    two other geometries: every repetition reproduces the first bit for bit and no wait times out."""
+    from spatiotemporal_variable_separation_amd import functional as VF, ops
+    from spatiotemporal_variable_separation_amd.networks.resnet import MLPResnet
+    from oracle.detdata import det_uniform
+    nets, data = {}, {}
+    for dims in [(128, 32, 512, 3, 9), (16, 32, 512, 3, 2), (48, 32, 256, 2, 5)]:
+        B, C, H, nb, n = dims
+        torch.manual_seed(3)
+        nets[dims] = MLPResnet(C, nb, H).cuda()
+        data[dims] = ((det_uniform((B, C), 7) - 0.5).cuda(), (det_uniform((B, n, C), 8) - 0.5).cuda())
+
+    def run(dims):
+        x0, g = data[dims]
+        with VF.precision('bf16'):
+            xa = x0.clone().requires_grad_(True)
+            codes, _ = nets[dims].rollout(xa, dims[4])
+            (codes * g).sum().backward()
+        nets[dims].zero_grad()
+        return codes.detach().clone(), xa.grad.clone()
+    first = {d: run(d) for d in nets}
+    order = list(nets)
+    for i in range(40):
+        d = order[0] if i % 4 else order[1 + (i // 4) % 2]
+        c, dx = run(d)
+        assert torch.equal(c, first[d][0]) and torch.equal(dx, first[d][1]), (i, d)
+    torch.cuda.synchronize()
+    assert ops.rollout_exchange_error('cuda') == 0
+
+
 def test_colsum_multi_shapes_and_dtypes():
     """All bias gradients of a chain in one launch: vector path (8-column units), ragged columns, odd row counts, views."""
     from spatiotemporal_variable_separation_amd import ops
