@@ -129,7 +129,13 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     def spatial_codes():
         if isinstance(sep_net.Es, ConstantS):
             return sep_net.Es(full_data[:, :nt_cond]), sep_net.Es(full_data[:, -nt_cond:])
-        s_both = sep_net.Es.mlp(torch.cat([window(nt_cond), window(T)], dim=0))
+        if on_device:
+            # [first window; last window] in the compute type by ONE kernel (like E_t's input below) instead of a concatenation + a cast
+            x_es = torch.empty((2 * B, nt_cond * D), dtype=VF.compute_dtype(), device=flat.device)
+            ops.copy2d_pair(flat, B, nt_cond * D, T * D, x_es, nt_cond * D, None, 0, 0, (T - nt_cond) * D)
+        else:
+            x_es = torch.cat([window(nt_cond), window(T)], dim=0)
+        s_both = sep_net.Es.mlp(x_es)
         return s_both.view(2, B, -1).unbind(0)       # unbind: its gradient is ONE stack kernel (two slices: fill+copy each, then add)
 
     if (VF.side_streams_enabled() and torch.is_grad_enabled() and VF.compute_dtype() != torch.float32
