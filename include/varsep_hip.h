@@ -279,6 +279,10 @@ int vs_conv3_img16_bn_bwd(int compute, const void* dz_next, const void* w_packed
                           int B, int Cin, int Cout, void* stream);
 int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,
                 void* stream);
+/* Round 4: vs_slab_sum with a SECOND fp32 addend (the gradient of a ConvResBlock output that reaches the block along two paths -- the next
+ * block-step and the stacked codes the decoder reads, resnet.py:66-70 / model.py:76-86 -- joins the skip gradient without an add launch). */
+int vs_slab_sum2(const float* slabs, int nslabs, const float* bias, const float* addend, const float* addend2, void* out, int out_dtype, int B, int C,
+                 int64_t HW, void* stream);
 int vs_bn_stats_from_sums(const double* sums, int groups, int C, int64_t n_per_group, float* mean, float* invstd, float* var_scratch,
                           float* running_mean, float* running_var, float momentum, float eps, void* stream);
 

@@ -178,6 +178,7 @@ SIGNATURES = {
     'vs_conv3_wgrad_band_finish': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     'vs_slab_sum_grouped': (_i32, [_vp, _i32, _i32, _vp, _i64, _vp]),
     'vs_slab_sum': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
+    'vs_slab_sum2': (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp]),
     'vs_conv3_img16_bn_workspace_bytes': (ctypes.c_size_t, []),
     'vs_conv3_img16_bn_supported': (_i32, [_i32, _i32, _i32, _i32]),
     'vs_conv3_img16_bn_form_supported': (_i32, [_i32, _i32, _i32, _i32]),

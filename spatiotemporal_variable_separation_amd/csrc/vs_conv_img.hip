@@ -1120,7 +1120,8 @@ __global__ __launch_bounds__(256) void conv3_img16_pack_multi_kernel(ImgPackJobs
 }
 
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslabs, int64_t total, const float* __restrict__ bias,
-                                                       const float* __restrict__ addend, int C, int HW, void* __restrict__ out, int od) {
+                                                       const float* __restrict__ addend, const float* __restrict__ addend2, int C, int HW,
+                                                       void* __restrict__ out, int od) {
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
         f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
 #pragma unroll 4
@@ -1134,6 +1135,10 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
         }
         if (addend) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(addend + i);
+            s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+        }
+        if (addend2) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(addend2 + i);
             s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
         }
         if (od == VS_F32) *reinterpret_cast<f32x4*>((float*)out + i) = s;
@@ -1374,16 +1379,22 @@ extern "C" int vs_conv3_img16_bn_bwd(int compute, const void* dz_next, const voi
 }
 
 // out[b][c][p] = sum_s slabs[s][b][c][p] (+ bias[c]) (+ addend[b][c][p], fp32) in out_dtype; HW a multiple of 4
-extern "C" int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,
-                           void* stream) {
+extern "C" int vs_slab_sum2(const float* slabs, int nslabs, const float* bias, const float* addend, const float* addend2, void* out, int out_dtype, int B,
+                            int C, int64_t HW, void* stream) {
     VS_CHECK_ARG(slabs && out && nslabs >= 1 && B > 0 && C > 0 && HW > 0 && HW % 4 == 0 && vs_dtype_ok(out_dtype), "vs_slab_sum: bad argument");
-    VS_CHECK_ARG(((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)addend) % 16 == 0, "vs_slab_sum: operands must be 16-byte aligned");
+    VS_CHECK_ARG(((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)addend | (uintptr_t)addend2) % 16 == 0, "vs_slab_sum: operands must be 16-byte aligned");
     const int64_t total = (int64_t)B * C * HW;
     int64_t blocks = vs_cdiv(total, 1024);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, total, bias, addend, C, (int)HW, out, out_dtype);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, total, bias, addend, addend2, C, (int)HW, out,
+                       out_dtype);
     VS_CHECK_LAUNCH("vs_slab_sum");
     return VS_OK;
+}
+
+extern "C" int vs_slab_sum(const float* slabs, int nslabs, const float* bias, const float* addend, void* out, int out_dtype, int B, int C, int64_t HW,
+                           void* stream) {
+    return vs_slab_sum2(slabs, nslabs, bias, addend, nullptr, out, out_dtype, B, C, HW, stream);
 }
 
 // ---- row-band form: many maps, W in {16, 32, 64} with H a multiple of 256 / W, or 8 x 8 / 4 x 4 maps; Cin a multiple of 64; y in any type, bias added --

@@ -1173,7 +1173,7 @@ class ConvResBlockFn(torch.autograd.Function):
     over the calls of the step as in `ConvBlock`.
 
     apply(x, x16 or None, w1, b1, g1, be1, w2, ..., be3, cfg) with cfg = ((rmean, rvar, momentum, eps, act) x 3); returns
-    (x + r fp32, its 16-bit copy (not differentiable), r fp32)."""
+    (x + r fp32, its 16-bit copy (not differentiable), r fp32, x + r once more: the same storage as a second autograd output)."""
 
     @staticmethod
     def forward(ctx, x, x16, *rest):
@@ -1211,15 +1211,23 @@ class ConvResBlockFn(torch.autograd.Function):
         ctx.x_needs_grad = x.requires_grad
         ctx.mark_non_differentiable(xnew16)
         ctx.set_materialize_grads(False)          # an unused output arrives as None, not as a tensor of zeros
-        return xnew, xnew16, y
+        # The block output a SECOND time (same storage): a code of the rollout is read by the next block-step AND by the stack of codes the
+        # decoder gets (model.py:76-86).  Handed out as two outputs, their gradients arrive separately and join inside the launches below
+        # (two upstream operands of the BatchNorm backward, two addends of the skip gradient) -- as ONE output autograd adds them first, one
+        # launch per predicted frame (39 of the 41 ATen adds of an SST step).
+        return xnew, xnew16, y, xnew.view_as(xnew)
 
     @staticmethod
-    def backward(ctx, g_new, _g16, g_res):
+    def backward(ctx, g_new, _g16, g_res, g_alias=None):
         prm, cdt, saved = ctx.prm, ctx.cdt, ctx.saved_tensors
+        if g_new is None and g_alias is not None:
+            g_new, g_alias = g_alias, None
         if g_new is None and g_res is None:
             return (None,) * 15
+        if g_alias is not None and g_res is not None:
+            g_new, g_alias = g_new + g_alias, None      # (three upstream gradients: the residuals are read too -- not a training path)
         dy_a = g_res if g_res is not None else g_new
-        dy_b = g_new if g_res is not None else None
+        dy_b = g_new if g_res is not None else g_alias
         dy_a = dy_a.contiguous()
         if dy_b is not None:
             dy_b = dy_b.contiguous().float()
@@ -1258,7 +1266,8 @@ class ConvResBlockFn(torch.autograd.Function):
         slabs = ops.conv3_img16(dz_up, packed_img_weight(prm[0], cdt, True), prm[0].shape[1], role='dgrad') if ctx.x_needs_grad else None
         dx = None
         if ctx.x_needs_grad:
-            dx = ops.slab_sum(slabs, None, torch.float32, addend=g_new.contiguous().float() if g_new is not None else None)
+            dx = ops.slab_sum(slabs, None, torch.float32, addend=g_new.contiguous().float() if g_new is not None else None,
+                              addend2=g_alias.contiguous().float() if g_alias is not None else None)
         return (dx, None) + tuple(grads) + (None,)
 
 

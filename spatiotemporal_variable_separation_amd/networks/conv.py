@@ -357,10 +357,13 @@ class ConvResBlock(nn.Module):
                         args += [c.weight, c.bias, bn.weight, bn.bias]
                         cfg.append((bn.running_mean, bn.running_var, bn.momentum, bn.eps, act))
                     prev = getattr(x, '_vs16', None)
-                    xnew, x16, residual = VF.ConvResBlockFn.apply(x, prev[0] if prev is not None and prev[1] == x._version else None, *args,
-                                                                  tuple(cfg))
+                    xnew, x16, residual, alias = VF.ConvResBlockFn.apply(x, prev[0] if prev is not None and prev[1] == x._version else None, *args,
+                                                                         tuple(cfg))
                     # the next block's convolution operand (same values, already in the compute type), valid while xnew is not written to
                     xnew._vs16 = (x16, xnew._version)
+                    # the same output as a second autograd output: what a caller that ALSO keeps the code (model._roll stacks it for the decoder)
+                    # should keep, so that the two gradients join inside the block's backward launches instead of in an add launch
+                    xnew._vs_alias = alias
                     return xnew, residual
         residual = run_layers(self.conv, x, final_fp32=True)
         skip = x if isinstance(self.up, nn.Identity) else run_layers(self.up, x, final_fp32=True)

@@ -1,4 +1,6 @@
 """Model orchestrator (reference: networks/model.py:20-89)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -63,6 +65,7 @@ class SeparableNetwork(nn.Module):
         codes, residuals = [t_code], []
         while len(codes) < n_forecast:
             t_code, res = self.t_resnet(t_code)
-            codes.append(t_code)
+            # (a fused ConvResBlock hands its output out twice: the recurrence goes on with one, the list keeps the other -- functional.ConvResBlockFn)
+            codes.append(getattr(t_code, '_vs_alias', t_code) if os.environ.get('VARSEP_RESBLOCK_ALIAS', '1') == '1' else t_code)
             residuals.append(res)
         return codes, residuals

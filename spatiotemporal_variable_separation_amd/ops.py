@@ -1053,17 +1053,19 @@ def conv3_band(x, w_packed, bias, Cout, out_dtype, role='fwd', bn_sums=None, gro
     return y
 
 
-def slab_sum(slabs, bias, out_dtype, addend=None):
-    """sum over the leading (split) axis of fp32 slabs [S, B, C, H, W] (+ bias[c]) (+ addend, fp32 [B, C, H, W]) -> [B, C, H, W] in
+def slab_sum(slabs, bias, out_dtype, addend=None, addend2=None):
+    """sum over the leading (split) axis of fp32 slabs [S, B, C, H, W] (+ bias[c]) (+ addend (+ addend2), fp32 [B, C, H, W]) -> [B, C, H, W] in
     out_dtype, one launch."""
     require_cuda(slabs)
     S, B, C = slabs.shape[0], slabs.shape[1], slabs.shape[2]
     HW = slabs.numel() // (S * B * C)
-    if addend is not None:
-        assert addend.dtype == torch.float32 and addend.is_contiguous() and addend.numel() == B * C * HW
+    if addend is None and addend2 is not None:
+        addend, addend2 = addend2, None
+    for a in (addend, addend2):
+        assert a is None or (a.dtype == torch.float32 and a.is_contiguous() and a.numel() == B * C * HW)
     out = torch.empty(slabs.shape[1:], dtype=out_dtype, device=slabs.device)
-    check(_lib.load_library().vs_slab_sum(slabs.data_ptr(), S, _ptr(bias), _ptr(addend), out.data_ptr(), dtype_code(out), B, C, HW, stream_ptr()),
-          'vs_slab_sum')
+    check(_lib.load_library().vs_slab_sum2(slabs.data_ptr(), S, _ptr(bias), _ptr(addend), _ptr(addend2), out.data_ptr(), dtype_code(out), B, C, HW,
+                                           stream_ptr()), 'vs_slab_sum')
     return out
 
 

@@ -650,6 +650,50 @@ def test_fused_conv_res_block_equals_layer_by_layer(precision, mode, monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_conv_res_block_output_kept_and_passed_on_joins_its_gradients_in_the_block(precision):
+    """A rollout keeps every code AND feeds it to the next block-step (model.py:76-86).  The fused ConvResBlock hands its output out twice
+    (`_vs_alias`): with the kept copy taken from the alias, the two gradients reach the block separately and join inside its backward launches
+    (second upstream operand of the BatchNorm backward, second addend of the skip gradient); with the same tensor used twice autograd adds them
+    first.  Same forward bits; gradients equal up to the order of two fp32 additions."""
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.conv import ConvResnet
+    with VF.precision(precision):
+        torch.manual_seed(6)
+        net = ConvResnet(64, n_blocks=1, nf=64).cuda().train()
+        x0 = _rand((8, 64, 16, 16), 91).cuda()
+        gs = [_rand((8, 64, 16, 16), 92 + i).cuda() for i in range(3)]
+        res = []
+        for use_alias in (True, False):
+            net.zero_grad()
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.reset_running_stats()
+            x = x0.clone().requires_grad_(True)
+            kept, cur = [], x
+            for _ in range(3):
+                cur, _ = net(cur)
+                assert hasattr(cur, '_vs_alias')
+                kept.append(cur._vs_alias if use_alias else cur)
+            sum((k * g).sum() for k, g in zip(kept, gs)).backward()
+            torch.cuda.synchronize()
+            res.append(([k.detach().clone() for k in kept], x.grad.clone(), [p.grad.clone() for p in net.parameters()]))
+        (k1, dx1, p1), (k2, dx2, p2) = res
+        for a, b in zip(k1, k2):
+            assert torch.equal(a, b)
+
+        def rel(a, b):
+            return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+        tol = 2e-2 if precision == 'bf16' else 3e-3                  # (an fp32 sum in another order re-rounds 16-bit dz values downstream)
+        assert rel(dx1, dx2) < tol
+        for a, b in zip(p1, p2):
+            if b.abs().max().item() == 0:
+                assert a.abs().max().item() == 0
+            else:
+                assert rel(a, b) < tol
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('geom', [
     (2, 64, 64, 64, 64),      # one phase, W = 64 (the two column tiles of a wave are the halves of one row)
