@@ -502,6 +502,23 @@ int vs_pack_rollout_weights(int compute, int n_jobs, const float* const* src, co
 
 int vs_mlp_rollout_parts(int compute, int B, int C, int H);
 size_t vs_mlp_rollout_workspace_bytes(int compute, int B, int C, int H);
+/* Round 5: the exchange mode of the weight-stationary integrator (reference resnet.py:22-50 unrolled over time, model.py:74-86) is a
+ * START-UP decision.  With 8 / 16 / ... row slabs the ring of a slab publishes its granules with plain stores that only reach ONE XCD's
+ * L2: it leans on a dispatch property HIP does not promise (workgroups 8 apart share an XCD).
+ *   _get   1 when a launch of this geometry would take the XCD-local stores now (VS_ROLLOUT_XCD_LOCAL != 0, 8 k slabs, not refused)
+ *   _set   0: agent-scope (sc1) stores for the rest of the process -- what the caller does when its probe rollout (a first launch with a
+ *          short spin limit on a fresh workspace) came back with the error word raised; 1: allow again
+ * VS_ROLLOUT_XCD_LOCAL=2 (test aid) keeps the plain stores but deals the slabs out so that every ring is spread over the XCDs.            */
+int vs_mlp_rollout_xcd_local_get(int compute, int B, int C, int H, int n_blocks);
+int vs_mlp_rollout_xcd_local_set(int allowed);
+/* The exchange guard: ONE 4-byte device word (caller-owned, zero = fine) registered for the process.  While registered, every kernel with
+ * a bounded in-launch exchange (vs_mlp_rollout_fwd / _bwd: bit 1; vs_conv3_img16_bn_fwd / _bwd: bit 2) raises this word on a time-out
+ * INSTEAD of the word inside its own workspace, and every optimizer launch issued afterwards (vs_adam_multi, vs_adam_multi_scaled,
+ * vs_gemm_adam, vs_adam_step_increment*) reads it first and leaves parameters, moments, operand copies and the step count untouched
+ * while it is non-zero (the pointer is taken when a launch is issued or recorded): `optimizer.step()` (reference train.py:156-158) never
+ * applies an update computed from a timed-out exchange.  The caller reads and clears the word (it is sticky).  NULL unregisters.        */
+int vs_exchange_guard_set(void* word);
+void* vs_exchange_guard_get(void);
 int vs_mlp_rollout_fwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* x0,
                        const void* const* weights, const float* const* biases, float* t_codes, float* residuals,
                        void* xin_save, void* h1_save, void* h2_save, uint32_t* m1_save, uint32_t* m2_save, void* workspace,

@@ -220,6 +220,10 @@ SIGNATURES = {
     'vs_pack_rollout_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     'vs_mlp_rollout_parts': (_i32, [_i32] * 4),
     'vs_mlp_rollout_workspace_bytes': (_sz, [_i32] * 4),
+    'vs_mlp_rollout_xcd_local_get': (_i32, [_i32] * 5),
+    'vs_mlp_rollout_xcd_local_set': (_i32, [_i32]),
+    'vs_exchange_guard_set': (_i32, [_vp]),
+    'vs_exchange_guard_get': (_vp, []),
     'vs_mlp_rollout_fwd': (_i32, [_i32] * 6 + [_vp] * 11 + [_sz, _vp]),
     'vs_mlp_rollout_bwd': (_i32, [_i32] * 6 + [_vp] * 11 + [_sz, _vp]),
 }

@@ -23,6 +23,12 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 extern thread_local char vs_err_buf[256];
 int vs_fail(int code, const char* fmt, ...);
 
+// The process-wide exchange guard word (vs_exchange_guard_set, vs_eltwise.hip): when registered, every kernel with a bounded in-launch
+// exchange (the MLP integrator, the one-launch ConvResBlock layer) raises THIS device word on a time-out instead of the word inside its own
+// workspace, and every optimizer launch (vs_adam_multi*, vs_gemm_adam, the step counter) reads it first and leaves parameters, moments and
+// the step count untouched while it is non-zero: an update is never computed from the results of a timed-out exchange.
+extern unsigned* vs_g_exchange_guard;
+
 #define VS_CHECK_ARG(cond, ...)                        \
     do {                                               \
         if (!(cond)) return vs_fail(VS_ERR_ARG, __VA_ARGS__); \

@@ -232,6 +232,7 @@ struct ImgBnArgs {
     const unsigned* epoch_base;
     unsigned call_idx, spin_limit;
     unsigned* xerr;
+    unsigned xerr_bit;          // 1 in the workspace's own word, 2 in the process-wide guard word (vs_exchange_guard_set)
     const float* bias;
     const float* gamma;
     const float* beta;
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void conv3_img16_bn_kernel(ImgBnArgs p) {
     }
     __syncthreads();
     IMGBN_STAMP(5);
-    if (timed_out) atomicOr(p.xerr, 1u);
+    if (timed_out) atomicOr(p.xerr, p.xerr_bit);
 
     if constexpr (MODE == 0) {
         float sk[N];
@@ -1291,7 +1292,8 @@ static int imgbn_launch(int compute, int mode, ImgBnArgs& a, void* ws, unsigned 
     a.mtiles = (int)vs_cdiv(a.Cout, 32);
     char* base = (char*)ws;
     a.epoch_base = (const unsigned*)base;
-    a.xerr = (unsigned*)(base + 4);
+    a.xerr = vs_g_exchange_guard ? vs_g_exchange_guard : (unsigned*)(base + 4);
+    a.xerr_bit = vs_g_exchange_guard ? 2u : 1u;
     a.xb = (xg64*)(base + IMGBN_B_OFF);
     a.xa = (xg64*)(base + IMGBN_A_OFF);
     a.call_idx = call_idx;

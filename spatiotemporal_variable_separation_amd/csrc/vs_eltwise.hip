@@ -5,6 +5,14 @@
 #include "vs_common.h"
 
 thread_local char vs_err_buf[256] = "";
+unsigned* vs_g_exchange_guard = nullptr;
+
+extern "C" int vs_exchange_guard_set(void* word) {
+    if ((uintptr_t)word % 4 != 0) return vs_fail(VS_ERR_ARG, "vs_exchange_guard_set: the guard word must be 4-byte aligned");
+    vs_g_exchange_guard = (unsigned*)word;
+    return VS_OK;
+}
+extern "C" void* vs_exchange_guard_get(void) { return vs_g_exchange_guard; }
 
 int vs_fail(int code, const char* fmt, ...) {
     va_list ap;

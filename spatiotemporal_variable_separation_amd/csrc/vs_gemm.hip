@@ -259,7 +259,7 @@ extern "C" int vs_gemm_adam(int compute, int64_t M, int64_t N, int64_t K, const 
         return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm_adam: operands do not fit the LDS-DMA loader (16-byte alignment, multiples of 8)");
     Epi epi{param, N, VS_F32, alpha, nullptr, VS_ACT_NONE, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     epi.adam_m = exp_avg; epi.adam_v = exp_avg_sq; epi.adam_shadow = (unsigned short*)shadow; epi.adam_shadow_dtype = shadow_dtype;
-    epi.adam_step = step; epi.adam_skipped = skipped;
+    epi.adam_step = step; epi.adam_skipped = skipped; epi.adam_guard = vs_g_exchange_guard;
     epi.adam_lr = lr; epi.adam_beta1 = beta1; epi.adam_beta2 = beta2; epi.adam_eps = (float)eps;
     MidPlan mp{true, 1, vs_cdiv(K, BIG_BK), (int)vs_cdiv(M, 128), (int)vs_cdiv(N, 128), 5};
     if ((int64_t)mp.tiles_m * mp.tiles_n > 0x7fffffffll) return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm_adam: too many tiles");

@@ -44,6 +44,7 @@ struct Epi {
     // is never stored
     float* adam_m; float* adam_v; unsigned short* adam_shadow; int adam_shadow_dtype;
     const int* adam_step; int adam_skipped;
+    const unsigned* adam_guard;          // vs_exchange_guard_set: non-zero word = leave the parameter block untouched
     double adam_lr, adam_beta1, adam_beta2; float adam_eps;
     // workgroup -> tile map: 1 = the workgroups of one XCD (b, b + 8, ... under round-robin dispatch) take a contiguous run of the
     // (split, tile row, tile column) order, so an XCD's L2 holds a few A row panels and one K chunk instead of a share of everything

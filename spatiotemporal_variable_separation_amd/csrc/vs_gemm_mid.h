@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
     if constexpr (ADAM) {
         // fused optimizer (vs_gemm_adam; an instantiation of its own, so that profiles tell it from the plain GEMM): the tile is
         // a block of the parameter's gradient
+        if (epi.adam_guard && *epi.adam_guard != 0u) return;          // an exchange of this step timed out: no update (vs_common.h)
         const AdamCoef coef = vs_adam_coef(epi.adam_lr, epi.adam_beta1, epi.adam_beta2, epi.adam_eps, (double)(epi.adam_step[0] + 1 - epi.adam_skipped));
         for (int it = 0; it < 16; ++it) {
             const int r = it * 4 + (lane >> 4);

@@ -35,7 +35,8 @@ int g_adam_max_blocks = 0;                 // vs_adam_set_max_blocks: grid cap o
 // scale_state (optional, fp16 loss scaling): [0] = loss scale S (gradients arrive multiplied by S and are used as g / S),
 // [1] = found_inf flag of this step (non-zero: leave everything untouched, GradScaler.step semantics)
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* __restrict__ step, double lr_d, double beta1_d, double beta2_d,
-                                                         float eps, const float* __restrict__ scale_state) {
+                                                         float eps, const float* __restrict__ scale_state, const unsigned* __restrict__ guard) {
+    if (guard && *guard != 0u) return;                        // a bounded exchange of this step timed out (vs_exchange_guard_set): no update
     float inv_scale = 1.f;
     if (scale_state) {
         if (scale_state[1] != 0.f) return;
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
     }
 }
 
-__global__ void step_increment_kernel(int* step, const float* scale_state) {
+__global__ void step_increment_kernel(int* step, const float* scale_state, const unsigned* guard) {
+    if (guard && *guard != 0u) return;                        // exchange time-out: the step did not happen
     if (scale_state && scale_state[1] != 0.f) return;         // overflow step: skipped, the step count does not advance
     step[0] += 1;
 }
@@ -185,7 +187,8 @@ extern "C" int vs_adam_multi_scaled(int n_tensors, float* const* params, const v
     int blocks = J.chunk_off[n_tensors];
     const int cap = g_adam_max_blocks > 0 ? g_adam_max_blocks : 256 * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J, step, lr, beta1, beta2, (float)eps, scale_state);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J, step, lr, beta1, beta2, (float)eps, scale_state,
+                       (const unsigned*)vs_g_exchange_guard);
     VS_CHECK_LAUNCH("vs_adam_multi");
     return VS_OK;
 }
@@ -205,14 +208,14 @@ extern "C" int vs_adam_multi(int n_tensors, float* const* params, const void* co
 
 extern "C" int vs_adam_step_increment(int32_t* step, void* stream) {
     VS_CHECK_ARG(step, "vs_adam_step_increment: null pointer");
-    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, (const float*)nullptr);
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, (const float*)nullptr, (const unsigned*)vs_g_exchange_guard);
     VS_CHECK_LAUNCH("vs_adam_step_increment");
     return VS_OK;
 }
 
 extern "C" int vs_adam_step_increment_scaled(int32_t* step, const float* scale_state, void* stream) {
     VS_CHECK_ARG(step, "vs_adam_step_increment_scaled: null pointer");
-    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, scale_state);
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, scale_state, (const unsigned*)vs_g_exchange_guard);
     VS_CHECK_LAUNCH("vs_adam_step_increment_scaled");
     return VS_OK;
 }

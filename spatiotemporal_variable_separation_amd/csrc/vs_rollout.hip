@@ -50,6 +50,8 @@ struct RollParams {
     unsigned spin_limit;         // rounds a wait may take before it gives up (VS_ROLLOUT_SPIN_LIMIT, default 2^22)
     int nap;                     // weight-stationary form: s_sleep units (64 clocks) between seeing the producer's input and polling its partials
     unsigned* ebase;             // weight-stationary form: per-slab epoch base words (even; advanced by the slab's last workgroup of every launch)
+    int ring_skew;               // weight-stationary form, TEST AID (VS_ROLLOUT_XCD_LOCAL=2): deal the slabs out so that the ring of a slab is
+                                 // spread over the XCDs -- the placement the XCD-local exchange must never meet
     // backward
     const float* g;              // [B, n, C] gradient wrt every t_code
     float* dx0;                  // [B, C]
@@ -749,7 +751,8 @@ __global__ __launch_bounds__(WT) void rollout_ws_kernel(RollParams p, int mask_p
     const int B = p.B, C = p.C, n = p.n, nb = p.nb;
     const int nslabs = (B + 15) / 16, Bp = nslabs * 16;
     int id = blockIdx.x;
-    const int slab = id % nslabs; id /= nslabs;
+    const int slab = p.ring_skew ? (id + id / nslabs) % nslabs : id % nslabs;     // (skew: a bijection inside every group of nslabs ids)
+    id /= nslabs;
     const int part = id % P;
     const int blk = id / P;
     const int pos = FWD ? blk : nb - 1 - blk;                 // position of this block inside a time step, in execution order
@@ -1041,6 +1044,13 @@ inline bool usable(int compute, int B, int C, int H, int nb) {
     return !(e && e[0] == '0');
 }
 
+int g_xcd_local_allowed = 1;          // vs_mlp_rollout_xcd_local_set: 0 after a failed placement probe (process-wide)
+inline int xcd_local_env() {
+    const char* e = getenv("VS_ROLLOUT_XCD_LOCAL");                           // (read per call: tests switch it)
+    return e ? atoi(e) : 1;
+}
+inline bool xcd_local_wanted(int nslabs) { return g_xcd_local_allowed && xcd_local_env() != 0 && nslabs % 8 == 0; }
+
 inline size_t exchange_bytes(int B, int H) {
     const int nslabs = (B + 15) / 16, P = H / 64;
     return (size_t)2 * nslabs * (P + 1) * 512 * sizeof(u64);
@@ -1081,10 +1091,10 @@ int launch_ws(int compute, bool fwd, const RollParams& p, int mask_pitch, size_t
     if (!dbg_buf && hipMalloc(&dbg_buf, 8 * 8 * 4096) != hipSuccess) dbg_buf = nullptr;
     dbg = Q <= 4096 ? dbg_buf : nullptr;
 #endif
-    // rings on one XCD each (see wsr::gstore): 8, 16, ... slabs.  VS_ROLLOUT_XCD_LOCAL=0: agent-scope stores always.
-    const char* xl_env = getenv("VS_ROLLOUT_XCD_LOCAL");                      // (read per call: tests switch it)
-    const int xl_mode = xl_env ? atoi(xl_env) : 1;
-    const bool xl = xl_mode && nslabs % 8 == 0;
+    // rings on one XCD each (see wsr::gstore): 8, 16, ... slabs.  VS_ROLLOUT_XCD_LOCAL=0: agent-scope stores always; =2 (test aid): the
+    // XCD-local stores with the rings deliberately spread over the XCDs.  vs_mlp_rollout_xcd_local_set(0) (the start-up probe's verdict,
+    // ops.mlp_rollout_fwd) overrides both for the rest of the process.
+    const bool xl = wsr::xcd_local_wanted(nslabs);
 #define VS_WS_LAUNCH_X(KH, XLV)                                                                                       \
     do {                                                                                                              \
         if (compute == VS_BF16) {                                                                                     \
@@ -1170,7 +1180,7 @@ int setup_exchange(RollParams& p, int compute, void* workspace, size_t workspace
     if (p.P > 1 && (!workspace || workspace_bytes < need)) p.P = 1;         // no exchange area: run unsplit
     p.xbuf = (u64*)workspace;
     p.xtotal = workspace_bytes & ~(size_t)15;
-    p.xerr = p.P > 1 ? (unsigned*)((char*)workspace + p.xtotal - 16) : nullptr;
+    p.xerr = p.P > 1 ? (vs_g_exchange_guard ? vs_g_exchange_guard : (unsigned*)((char*)workspace + p.xtotal - 16)) : nullptr;
     return VS_OK;
 }
 
@@ -1183,7 +1193,8 @@ bool setup_ws(RollParams& p, int compute, void* workspace, size_t workspace_byte
     p.xbuf = (u64*)workspace;
     p.ebase = (unsigned*)((char*)workspace + wsr::exchange_bytes(p.B, p.H));
     p.xtotal = workspace_bytes & ~(size_t)15;
-    p.xerr = (unsigned*)((char*)workspace + p.xtotal - 16);
+    p.xerr = vs_g_exchange_guard ? vs_g_exchange_guard : (unsigned*)((char*)workspace + p.xtotal - 16);
+    p.ring_skew = wsr::xcd_local_env() == 2 ? 1 : 0;
     *mask_pitch = pick_parts(compute, p.B, p.C, p.H) * 32;
     return true;
 }
@@ -1191,6 +1202,16 @@ bool setup_ws(RollParams& p, int compute, void* workspace, size_t workspace_byte
 }  // namespace
 
 extern "C" int vs_mlp_rollout_parts(int compute, int B, int C, int H) { return pick_parts(compute, B, C, H); }
+
+// The XCD-local exchange (wsr::gstore<true>) leans on a dispatch property HIP does not promise (workgroups 8 apart share an XCD).
+// _get: would a launch of this geometry take it now?  _set(0): never again in this process (the caller's start-up probe failed).
+extern "C" int vs_mlp_rollout_xcd_local_get(int compute, int B, int C, int H, int n_blocks) {
+    return wsr::usable(compute, B, C, H, n_blocks) && wsr::xcd_local_wanted((B + 15) / 16) ? 1 : 0;
+}
+extern "C" int vs_mlp_rollout_xcd_local_set(int allowed) {
+    wsr::g_xcd_local_allowed = allowed ? 1 : 0;
+    return VS_OK;
+}
 
 extern "C" size_t vs_mlp_rollout_workspace_bytes(int compute, int B, int C, int H) {
     const int P = pick_parts(compute, B, C, H);

@@ -332,7 +332,9 @@ class ConvResBlock(nn.Module):
         self.conv = nn.Sequential(_c3(in_c, nf), _c3(nf, nf), _c3(nf, out_c, activation='none'))
         self.up = _c3(in_c, out_c, activation='none') if in_c != out_c else nn.Identity()
 
-    def forward(self, x):
+    def forward(self, x, return_alias=False):
+        """`return_alias=True` (not a reference argument; `ConvResnet` asks for it on behalf of `model._roll`): a third result, the block's
+        output a SECOND time as its own autograd output (None when the block does not run as one fused node) -- see below."""
         if not getattr(self, '_marked', False):
             # the integrator applies this block once per predicted frame: its weight gradients are batched over the step's calls
             VF.mark_repeated([m.weight for m in self.modules() if isinstance(m, nn.Conv2d)])
@@ -361,13 +363,14 @@ class ConvResBlock(nn.Module):
                                                                          tuple(cfg))
                     # the next block's convolution operand (same values, already in the compute type), valid while xnew is not written to
                     xnew._vs16 = (x16, xnew._version)
-                    # the same output as a second autograd output: what a caller that ALSO keeps the code (model._roll stacks it for the decoder)
-                    # should keep, so that the two gradients join inside the block's backward launches instead of in an add launch
-                    xnew._vs_alias = alias
-                    return xnew, residual
+                    # `alias` = the same output as a second autograd output: what a caller that ALSO keeps the code (model._roll stacks it for the
+                    # decoder) should keep, so that the two gradients join inside the block's backward launches instead of in an add launch.
+                    # It travels through the RETURN VALUE only: it is a view of xnew, so an attribute of xnew that holds it would be a
+                    # reference cycle through the C++ base pointer that the garbage collector cannot see (one leaked map per block call).
+                    return (xnew, residual, alias) if return_alias else (xnew, residual)
         residual = run_layers(self.conv, x, final_fp32=True)
         skip = x if isinstance(self.up, nn.Identity) else run_layers(self.up, x, final_fp32=True)
-        return skip + residual, residual
+        return (skip + residual, residual, None) if return_alias else (skip + residual, residual)
 
 
 class ConvResnet(nn.Module):
@@ -378,11 +381,19 @@ class ConvResnet(nn.Module):
         self.n_blocks = n_blocks
         self.resblock_modules = nn.ModuleList([ConvResBlock(in_c, in_c, nf=nf) for _ in range(n_blocks)])
 
-    def forward(self, x, return_res=True):
-        residuals = []
-        for blk in self.resblock_modules:
-            x, residual = blk(x)
+    supports_alias = True        # forward(..., return_alias=True): see ConvResBlock.forward
+
+    def forward(self, x, return_res=True, return_alias=False):
+        residuals, alias = [], None
+        last = len(self.resblock_modules) - 1
+        for i, blk in enumerate(self.resblock_modules):
+            if return_alias and i == last:
+                x, residual, alias = blk(x, return_alias=True)
+            else:
+                x, residual = blk(x)
             residuals.append(residual)
+        if return_alias:
+            return x, residuals, alias
         return (x, residuals) if return_res else x
 
 

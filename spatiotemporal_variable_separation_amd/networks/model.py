@@ -63,9 +63,15 @@ class SeparableNetwork(nn.Module):
     def _roll(self, t_code, n_forecast):
         """[t_0, ..., t_{n-1}] with t_{k+1} = t_resnet(t_k), and the per-step residual lists."""
         codes, residuals = [t_code], []
+        want_alias = getattr(self.t_resnet, 'supports_alias', False) and os.environ.get('VARSEP_RESBLOCK_ALIAS', '1') == '1'
         while len(codes) < n_forecast:
-            t_code, res = self.t_resnet(t_code)
-            # (a fused ConvResBlock hands its output out twice: the recurrence goes on with one, the list keeps the other -- functional.ConvResBlockFn)
-            codes.append(getattr(t_code, '_vs_alias', t_code) if os.environ.get('VARSEP_RESBLOCK_ALIAS', '1') == '1' else t_code)
+            if want_alias:
+                # a fused ConvResBlock hands its output out twice: the recurrence goes on with one, the list keeps the other, and the two
+                # gradients join inside the block's backward launches (functional.ConvResBlockFn) instead of in an add launch per frame
+                t_code, res, alias = self.t_resnet(t_code, return_alias=True)
+                codes.append(alias if alias is not None else t_code)
+            else:
+                t_code, res = self.t_resnet(t_code)
+                codes.append(t_code)
             residuals.append(res)
         return codes, residuals

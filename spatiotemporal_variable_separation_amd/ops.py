@@ -284,18 +284,45 @@ def _rollout_workspace(nbytes, device, geometry):
     return buf
 
 
+_GUARD = {}
+
+
+def exchange_guard(device):
+    """The process's exchange guard word (include/varsep_hip.h: vs_exchange_guard_set): one int32 device word that the kernels with a bounded
+    in-launch exchange raise on a time-out and that every optimizer launch reads first (non-zero: no update).  Created and registered at the
+    first use of such a kernel -- forward, i.e. before the step's first optimizer launch is issued or recorded.  One GPU per process (8e):
+    a second device in the same process keeps the per-workspace words."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    if index in _GUARD:
+        return _GUARD[index]
+    lib = _lib.load_library()
+    if _GUARD or lib.vs_exchange_guard_get():
+        _GUARD[index] = None
+        return None
+    word = torch.zeros((4,), dtype=torch.int32, device=device)              # (16 bytes: a line of its own would be better still; it is read-mostly)
+    check(lib.vs_exchange_guard_set(word.data_ptr()), 'vs_exchange_guard_set')
+    _GUARD[index] = word
+    return word
+
+
 def rollout_exchange_error(device, reset=True):
-    """Non-zero iff a bounded spin of the rollout exchange timed out in any launch since the last call (the word is sticky: the
-    library never clears it).  Synchronises the device (reads one word)."""
+    """Non-zero iff a bounded spin of an in-launch exchange timed out in any launch since the last call (the words are sticky: the
+    library never clears them): bit 1 = the MLP integrator, bit 2 = the one-launch ConvResBlock layers.  Synchronises the device (reads words)."""
     device = torch.device(device) if not isinstance(device, torch.device) else device
     index = device.index if device.index is not None else torch.cuda.current_device()
     err = 0
+    guard = _GUARD.get(index)
+    if guard is not None:
+        err |= int(guard[0].item())
+        if reset and err:
+            guard[0].zero_()
     for key, buf in list(_roll_ws.items()):
         if key[0] != index:
             continue
         word = buf[buf.numel() // 16 * 16 - 16:buf.numel() // 16 * 16 - 12].view(torch.int32)
-        err |= int(word.item())
-        if reset and err:
+        e1 = int(word.item())
+        err |= e1
+        if reset and e1:
             word.zero_()
     st = _IMGBN.get(index)                              # the fused ConvResBlock layers' exchange (conv3_img16_bn_*): word 1 of their workspace
     if st is not None:
@@ -305,6 +332,78 @@ def rollout_exchange_error(device, reset=True):
             if reset:
                 st['ws'][1].zero_()
     return err
+
+
+_XL_PROBED = set()
+
+
+def rollout_xcd_local(allowed=None):
+    """Process-wide switch of the integrator's XCD-local exchange (None: leave).  False selects the placement-independent agent-scope stores."""
+    if allowed is not None:
+        check(_lib.load_library().vs_mlp_rollout_xcd_local_set(1 if allowed else 0), 'vs_mlp_rollout_xcd_local_set')
+
+
+def _probe_rollout_exchange(code, B, C, H, nb, device):
+    """START-UP decision of the exchange mode (once per device and geometry, outside stream captures).  The XCD-local form of the
+    weight-stationary integrator (csrc/vs_rollout.hip, wsr::gstore<true>) leans on workgroups 8 apart sharing an XCD, which HIP does not
+    promise.  One probe rollout -- three steps on zero weights, a fresh zero-filled exchange area, a short spin limit -- either completes (the
+    property holds on this device / runtime: keep the 210 ns hops) or leaves the error word raised: then every launch of this process uses
+    the agent-scope stores (385 ns hops, any placement).  A mid-run change of the dispatch order is still caught by the epoch tags -> the
+    guard word -> skipped optimizer steps -> train.recover_exchange."""
+    import os
+    import sys
+    key = (device.index, code, B, C, H, nb)
+    if key in _XL_PROBED or torch.cuda.is_current_stream_capturing():
+        return
+    _XL_PROBED.add(key)
+    lib = _lib.load_library()
+    if not lib.vs_mlp_rollout_xcd_local_get(code, B, C, H, nb) or os.environ.get('VARSEP_ROLLOUT_PROBE', '1') == '0':
+        return
+    import ctypes
+    dt = {_lib.VS_BF16: torch.bfloat16, _lib.VS_F16: torch.float16}[code]
+    nbytes = lib.vs_mlp_rollout_workspace_bytes(code, B, C, H)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    n = 3
+    weights = []
+    for _ in range(nb):
+        for (N, K) in ((H, C), (H, H), (C, H)):
+            weights.append(torch.zeros((lib.vs_rollout_packed_elems(code, N, K),), dtype=dt, device=device))
+    biases = []
+    for _ in range(nb):
+        biases += [torch.zeros((H,), device=device), torch.zeros((H,), device=device), torch.zeros((C,), device=device)]
+    x0 = torch.zeros((B, C), device=device)
+    t_codes = torch.empty((B, n, C), device=device)
+    xin = torch.empty((nb, n - 1, B, C), dtype=dt, device=device)
+    h1 = torch.empty((nb, n - 1, B, H), dtype=dt, device=device)
+    h2 = torch.empty((nb, n - 1, B, H), dtype=dt, device=device)
+    parts = lib.vs_mlp_rollout_parts(code, B, C, H)
+    Bp = (B + 15) // 16 * 16
+    m1 = torch.empty((nb, n - 1, Bp, parts, 32), dtype=torch.int32, device=device)
+    m2 = torch.empty_like(m1)
+    guard = _GUARD.get(device.index if device.index is not None else torch.cuda.current_device())
+    before = int(guard[0].item()) if guard is not None else 0
+    saved = os.environ.get('VS_ROLLOUT_SPIN_LIMIT')
+    os.environ['VS_ROLLOUT_SPIN_LIMIT'] = os.environ.get('VARSEP_ROLLOUT_PROBE_SPINS', str(1 << 16))
+    try:
+        wa, ba = _ptr_array(weights), _ptr_array(biases)
+        check(lib.vs_mlp_rollout_fwd(code, B, C, H, nb, n, x0.data_ptr(), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
+                                     t_codes.data_ptr(), None, xin.data_ptr(), h1.data_ptr(), h2.data_ptr(), m1.data_ptr(), m2.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), stream_ptr()), 'vs_mlp_rollout_fwd (placement probe)')
+        torch.cuda.current_stream().synchronize()
+    finally:
+        if saved is None:
+            os.environ.pop('VS_ROLLOUT_SPIN_LIMIT', None)
+        else:
+            os.environ['VS_ROLLOUT_SPIN_LIMIT'] = saved
+    if guard is not None:
+        failed = int(guard[0].item()) != 0
+        guard[0].fill_(before)                               # the probe's verdict is consumed here; an earlier error stays
+    else:
+        failed = int(ws[ws.numel() // 16 * 16 - 16:ws.numel() // 16 * 16 - 12].view(torch.int32).item()) != 0
+    if failed:
+        rollout_xcd_local(False)
+        sys.stderr.write('varsep: the integrator\'s XCD-local exchange did not complete its start-up probe on this device (workgroups 8 apart do not '
+                         'share an XCD here): using the agent-scope exchange for this process\n')
 
 
 def _ptr_array(tensors):
@@ -371,6 +470,8 @@ def mlp_rollout_fwd(x0, weights, biases, n_steps, H, want_residuals=True):
     Bp = (B + 15) // 16 * 16                 # sign-bit arrays: rows padded to whole 16-row slabs
     m1 = torch.empty((nb, steps, Bp, parts, 32), dtype=torch.int32, device=dev)
     m2 = torch.empty((nb, steps, Bp, parts, 32), dtype=torch.int32, device=dev)
+    exchange_guard(dev)
+    _probe_rollout_exchange(code, B, C, H, nb, dev)
     xws = _rollout_workspace(lib.vs_mlp_rollout_workspace_bytes(code, B, C, H), dev, (code, B, C, H))
     wa, ba = _ptr_array(weights), _ptr_array(biases)
     e0 = _pb()
@@ -1282,6 +1383,7 @@ def _imgbn_state(device):
     index = device.index if device.index is not None else torch.cuda.current_device()
     st = _IMGBN.get(index)
     if st is None:
+        exchange_guard(device)
         nbytes = _lib.load_library().vs_conv3_img16_bn_workspace_bytes()
         ws = torch.zeros((nbytes // 4,), dtype=torch.int32, device=device)
         ws[0] = 65536                                    # epochs start above zero: a zero-filled granule never looks current

@@ -134,7 +134,25 @@ class GradAllReducer:
             self._reduce(flat)
         self._pending[bi] = None
 
+    def _reduce_guard(self, device):
+        """The exchange guard word (ops.exchange_guard: raised by a timed-out in-launch exchange, read by every optimizer launch) is
+        MAX-reduced with every bucket: a replica whose integrator timed out has put garbage on the wire, so ALL replicas must skip the
+        update, or they would drift apart (one tiny collective per bucket on the comm stream, N > 1 only)."""
+        if self.world_size == 1 or device.type != 'cuda':
+            return
+        from . import ops
+        word = ops.exchange_guard(device)
+        if word is None:
+            return
+        if self.backend == 'nccl':
+            dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group)
+        else:
+            host = word.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            word.copy_(host)
+
     def _reduce(self, flat):
+        self._reduce_guard(flat.device)
         if self.comm_dtype != torch.float32:
             wire = self._wire.get(flat.data_ptr())
             if wire is None:

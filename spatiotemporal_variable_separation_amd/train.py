@@ -281,6 +281,7 @@ class GraphedStep:
     def _capture(self):
         from . import functional as VF
         from .optim import Adam as HipAdam
+        self.steps_replayed = 0                      # (train() checks the exchange error word after each of a recording's first replays)
         params = list(self.net.parameters())
         if isinstance(self.opt, HipAdam):
             # restoring the warm-up snapshot bumped every parameter's version counter (and, for a re-recording after a learning-rate
@@ -449,6 +450,7 @@ class GraphedStep:
             self._capture()                          # a scheduler moved the learning rate: it is a launch argument of the recording
         self._draw()
         self.graph.replay()
+        self.steps_replayed += 1
         early = {}
         if getattr(self, 'graph2', None) is not None:
             # the decoder's buckets go on the wire now; the second segment (integrator + encoders backward) runs beside them
@@ -712,8 +714,8 @@ def make_loss_scaler(device, **kw):
 
 def check_rollout_exchange(device):
     """The weight-stationary rollout kernels exchange partial sums between workgroups with bounded spins; a spin that gives up sets
-    an error word and the step's numbers are garbage.  Raise instead of training on (called at log / checkpoint time: it reads one
-    device word, i.e. synchronises)."""
+    an error word and the step's numbers are garbage.  Raise instead of training on (reads device words, i.e. synchronises).  `train()`
+    itself no longer raises: see `recover_exchange`."""
     from . import ops
     from ._lib import VarsepHipError
     err = ops.rollout_exchange_error(device)
@@ -721,6 +723,43 @@ def check_rollout_exchange(device):
         raise VarsepHipError('rollout kernel: inter-workgroup exchange timed out (code %d) -- the integrator results of at least one '
                              'step since the last check are invalid; not continuing.  (With 8 / 16 row slabs the exchange relies on the '
                              'workgroups of a slab sharing an XCD; VS_ROLLOUT_XCD_LOCAL=0 selects the placement-independent agent-scope exchange.)' % err)
+
+
+def recover_exchange(device, log=True, grad_sync=None):
+    """What `train()` does about a timed-out in-launch exchange (reads device words: synchronises).  Returns the error code (0: nothing happened).
+
+    While the process's guard word is registered (ops.exchange_guard: always, for the first device of a process) a time-out cannot reach the
+    parameters: the kernels raise the guard, and every optimizer launch issued or recorded afterwards -- vs_adam_multi, vs_gemm_adam, the step
+    counter -- reads it first and does nothing while it is set (include/varsep_hip.h, vs_exchange_guard_set), so the steps between the time-out
+    and this call were SKIPPED, like overflow steps under fp16 loss scaling.  Here the cause is removed -- the MLP integrator switches to the
+    placement-independent agent-scope exchange for the rest of the process, the one-launch ConvResBlock layers to the two-launch form -- and
+    the word is cleared; the caller drops its recorded step (the exchange mode is baked into a recording) and training goes on.  Without a
+    guard (a second device in one process) the old behaviour stays: raise."""
+    import sys
+    from . import ops
+    from ._lib import VarsepHipError
+    guarded = ops.exchange_guard(torch.device(device)) is not None
+    err = ops.rollout_exchange_error(device)
+    if grad_sync is not None and grad_sync.world_size > 1:
+        # every rank must take the same branch (a re-recording contains collectives): the worst code of all ranks counts
+        import torch.distributed as dist
+        word = torch.tensor([err], dtype=torch.int32, device=device if grad_sync.backend == 'nccl' else 'cpu')
+        dist.all_reduce(word, op=dist.ReduceOp.MAX, group=grad_sync.group)
+        err = int(word.item())
+    if not err:
+        return 0
+    if not guarded:
+        raise VarsepHipError('rollout kernel: inter-workgroup exchange timed out (code %d) and no guard word protects the optimizer on this '
+                             'device: the results of at least one step are invalid' % err)
+    if err & 1:
+        ops.rollout_xcd_local(False)
+    if err & 2:
+        os.environ['VARSEP_FUSED_RESBLOCK'] = '1'
+    if log:
+        sys.stderr.write('varsep: an in-launch exchange timed out (code %d); the optimizer skipped the affected step(s).  Continuing with %s\n'
+                         % (err, ' and '.join((['the agent-scope integrator exchange'] if err & 1 else []) +
+                                              (['two-launch ConvResBlock layers'] if err & 2 else []))))
+    return err
 
 
 def compute_losses(cond, target, sep_net, nt_cond, nt_pred, offset, skipco, lamb_ae, lamb_s, lamb_t, lamb_pred,
@@ -874,32 +913,21 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
     def checkpoint(epoch_number=None, collective=True):
         # data parallel: replicas hold identical parameters; BatchNorm buffers are per replica (no SyncBN), rank 0's are the ones
         # kept and broadcast so that every replica continues from what was saved; only rank 0 writes.
-        # The model is saved FIRST: a (sticky) exchange time-out flag of the integrator raises afterwards, so that hours of training
-        # are not discarded with it -- the files are then written under a `suspect_` name.  With several ranks the error word is
-        # MAX-reduced, so every rank takes the same branch (a raise on one rank would leave the others in the next collective);
-        # `collective=False` (after Ctrl-C, which may have hit one rank only) skips every collective.
-        from . import ops
-        err = int(ops.rollout_exchange_error(device)) if torch.device(device).type == 'cuda' else 0
+        # A (sticky) exchange time-out word of the integrator is handled first (recover_exchange: the affected steps were skipped by the
+        # optimizer, the exchange mode is switched, nothing raises).  `collective=False` (after Ctrl-C, which may have hit one rank only)
+        # skips every collective.
+        nonlocal graphed
+        err = 0
+        if torch.device(device).type == 'cuda':
+            err = int(recover_exchange(device, grad_sync=grad_sync if collective else None))        # (a time-out cannot have reached the parameters: the guard word made the optimizer skip)
+            if err:
+                graphed = None                         # the exchange mode is baked into a recording
         if grad_sync is not None and world > 1 and collective:
             import torch.distributed as dist
             from .parallel import broadcast_buffers
-            word = torch.tensor([err], dtype=torch.int32, device=device if grad_sync.backend == 'nccl' else 'cpu')
-            dist.all_reduce(word, op=dist.ReduceOp.MAX, group=grad_sync.group)
-            err = int(word.item())
             broadcast_buffers(sep_net, process_group=grad_sync.group)
         if rank == 0:
-            if err:
-                # same four files, in a sub-directory that marks them: helper.save keeps the reference's file names (helper.py:22-33)
-                suspect = os.path.join(xp_dir, 'suspect_exchange_timeout')
-                os.makedirs(suspect, exist_ok=True)
-                save(suspect, sep_net, epoch_number=epoch_number)
-            else:
-                save(xp_dir, sep_net, epoch_number=epoch_number)
-        if err:
-            from ._lib import VarsepHipError
-            raise VarsepHipError('rollout kernel: inter-workgroup exchange timed out (code %d) since the last check -- the integrator '
-                                 'results of at least one step are invalid; the model was saved under %s/suspect_exchange_timeout'
-                                 % (err, xp_dir))
+            save(xp_dir, sep_net, epoch_number=epoch_number)
 
     interrupted = False
     try:
@@ -917,9 +945,13 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                     if cond.shape == graphed.cond.shape:
                         total_loss = graphed.step(cond, target)
                         step += 1
-                        if log_interval and step % log_interval == 0:
+                        first = graphed.steps_replayed <= 3      # the first replays of a recording are checked one by one (a sync each)
+                        if first or (log_interval and step % log_interval == 0):
                             torch.cuda.synchronize()
-                            check_rollout_exchange(device)
+                            if recover_exchange(device, grad_sync=grad_sync):
+                                graphed = None                   # re-record with the exchange mode now in force
+                                continue
+                        if log_interval and step % log_interval == 0:
                             dt, t_last = time.time() - t_last, time.time()
                             if rank == 0:
                                 print(f'epoch {epoch} step {step}: total {total_loss.item():.5f} | '
@@ -961,7 +993,7 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                 step += 1
                 if log_interval and step % log_interval == 0:
                     torch.cuda.synchronize()
-                    check_rollout_exchange(device)
+                    recover_exchange(device, grad_sync=grad_sync)
                     dt = time.time() - t_last
                     t_last = time.time()
                     fps = log_interval * cond.shape[0] * nt_pred * world / dt

@@ -653,7 +653,7 @@ def test_fused_conv_res_block_equals_layer_by_layer(precision, mode, monkeypatch
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 def test_conv_res_block_output_kept_and_passed_on_joins_its_gradients_in_the_block(precision):
     """A rollout keeps every code AND feeds it to the next block-step (model.py:76-86).  The fused ConvResBlock hands its output out twice
-    (`_vs_alias`): with the kept copy taken from the alias, the two gradients reach the block separately and join inside its backward launches
+    (`return_alias=True`): with the kept copy taken from the alias, the two gradients reach the block separately and join inside its backward launches
     (second upstream operand of the BatchNorm backward, second addend of the skip gradient); with the same tensor used twice autograd adds them
     first.  Same forward bits; gradients equal up to the order of two fp32 additions."""
     from spatiotemporal_variable_separation_amd import functional as VF
@@ -672,9 +672,9 @@ def test_conv_res_block_output_kept_and_passed_on_joins_its_gradients_in_the_blo
             x = x0.clone().requires_grad_(True)
             kept, cur = [], x
             for _ in range(3):
-                cur, _ = net(cur)
-                assert hasattr(cur, '_vs_alias')
-                kept.append(cur._vs_alias if use_alias else cur)
+                cur, _, alias = net(cur, return_alias=True)
+                assert alias is not None and not hasattr(cur, '_vs_alias')
+                kept.append(alias if use_alias else cur)
             sum((k * g).sum() for k, g in zip(kept, gs)).backward()
             torch.cuda.synchronize()
             res.append(([k.detach().clone() for k in kept], x.grad.clone(), [p.grad.clone() for p in net.parameters()]))
@@ -691,6 +691,41 @@ def test_conv_res_block_output_kept_and_passed_on_joins_its_gradients_in_the_blo
                 assert a.abs().max().item() == 0
             else:
                 assert rel(a, b) < tol
+
+
+@pytest.mark.gpu
+def test_fused_conv_res_block_calls_do_not_leak():
+    """Advisor finding (round 4): the block's second output used to hang on the tensor it is a view of (`xnew._vs_alias = alias`): a reference
+    cycle through the C++ base pointer that `gc` cannot collect -- one fp32 [B, C, 16, 16] map (and its backward node) leaked per block call
+    under grad.  The alias now travels through the return value; eager rollouts must leave `memory_allocated()` flat."""
+    import gc
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.conv import ConvResnet
+    with VF.precision('bf16'):
+        torch.manual_seed(7)
+        net = ConvResnet(64, n_blocks=2, nf=64).cuda().train()
+        x0 = _rand((8, 64, 16, 16), 17).cuda()
+
+        def rollout():
+            x = x0.clone().requires_grad_(True)
+            kept, cur = [], x
+            for _ in range(6):
+                cur, _, alias = net(cur, return_alias=True)
+                kept.append(alias)
+            sum(k.sum() for k in kept).backward()
+            net.zero_grad(set_to_none=True)
+
+        for _ in range(3):
+            rollout()
+        gc.collect()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        for _ in range(10):
+            rollout()
+        gc.collect()
+        torch.cuda.synchronize()
+        grown = torch.cuda.memory_allocated() - base
+        assert grown < 8 * 64 * 256 * 4, 'eager fused ConvResBlock calls leak %d bytes over 10 rollouts' % grown
 
 
 @pytest.mark.gpu

@@ -53,6 +53,138 @@ def test_rollout_exchange_timeout_is_sticky_and_raises():
     assert ops.rollout_exchange_error(dev) == 0
 
 
+def _ws_net(B=128, hidden=128, blocks=2):
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    cfg = dict(CONFIGS['mlp_mul'], B=B, res_hidden_size=hidden, n_blocks=blocks)     # weight-stationary form; B = 128: 8 row slabs
+    net = det_fill(build_sep_net(cfg), salt=cfg['salt']).cuda()
+    net.train()
+    cond, target = make_batch(cfg)
+    return cfg, net, cond.cuda(), target.cuda()
+
+
+def test_exchange_guard_makes_every_optimizer_launch_skip():
+    """include/varsep_hip.h, vs_exchange_guard_set: while the process's guard word is non-zero, vs_adam_multi, vs_gemm_adam and the step
+    counter leave parameters, moments, operand copies and the step count untouched (an update is never computed from a timed-out exchange);
+    with the word cleared the same calls update."""
+    from spatiotemporal_variable_separation_amd import ops
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    dev = torch.device('cuda', torch.cuda.current_device())
+    guard = ops.exchange_guard(dev)
+    assert guard is not None and ops.rollout_exchange_error(dev) == 0
+    torch.manual_seed(3)
+    w = torch.nn.Parameter(torch.randn(256, 384, device=dev))
+    b = torch.nn.Parameter(torch.randn(384, device=dev))
+    opt = Adam([w, b], lr=1e-2)
+    w.grad, b.grad = torch.randn_like(w), torch.randn_like(b)
+    opt.step()                                                   # creates the state
+    torch.cuda.synchronize()
+    w0, b0 = w.detach().clone(), b.detach().clone()
+    m0 = opt.state[w]['exp_avg'].clone()
+    t0 = int(opt.param_groups[0]['step_dev'].item())
+    guard[0] = 1
+    opt.step()
+    # the fused weight-gradient + Adam launch on the same parameter (G = A^T B as in MLPChain.backward: operands [rows, features], layout S)
+    a = torch.randn(128, 256, device=dev).bfloat16()
+    g = torch.randn(128, 384, device=dev).bfloat16()
+    st = opt.state[w]
+    shadow = torch.empty_like(w, dtype=torch.bfloat16)
+    ops.gemm_adam(a, ops.LAYOUT_S, g, ops.LAYOUT_S, 256, 384, 128, w.data, st['exp_avg'], st['exp_avg_sq'], shadow, opt.param_groups[0]['step_dev'], 0, 1e-2,
+                  (0.9, 0.999), 1e-8)
+    torch.cuda.synchronize()
+    assert torch.equal(w.detach(), w0) and torch.equal(b.detach(), b0) and torch.equal(opt.state[w]['exp_avg'], m0)
+    assert int(opt.param_groups[0]['step_dev'].item()) == t0, 'the step count must not advance on a guarded step'
+    assert ops.rollout_exchange_error(dev) == 1 and ops.rollout_exchange_error(dev) == 0          # reported once, cleared by the read
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(w.detach(), w0) and int(opt.param_groups[0]['step_dev'].item()) == t0 + 1
+
+
+def test_xcd_local_probe_refuses_a_split_ring_and_results_stay_exact(monkeypatch):
+    """The XCD-local exchange of the integrator is a START-UP decision (ops._probe_rollout_exchange).  VS_ROLLOUT_XCD_LOCAL=2 keeps its plain
+    stores but spreads every slab's ring over the XCDs -- the placement it must never meet: the probe rollout has to come back with the error
+    word raised, the process falls back to the agent-scope stores, and the real launches then give bit for bit what VS_ROLLOUT_XCD_LOCAL=0 gives,
+    with no error left behind."""
+    from spatiotemporal_variable_separation_amd import functional as VF, ops
+    from spatiotemporal_variable_separation_amd._lib import load_library, BF16
+    from spatiotemporal_variable_separation_amd.train import compute_losses
+    cfg, net, cond, target = _ws_net()
+    lam = cfg['lambdas']
+    dev = cond.device
+    lib = load_library()
+
+    def run():
+        net.zero_grad()
+        with VF.precision('bf16'):
+            total, _, _, t_codes = compute_losses(cond, target, net, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], False, lam['ae'], lam['s'], lam['t'],
+                                                  lam['pred'], t_random=4)
+            total.backward()
+        torch.cuda.synchronize()
+        return t_codes.detach().clone(), [p.grad.clone() for p in net.parameters() if p.grad is not None]
+    try:
+        monkeypatch.setenv('VS_ROLLOUT_XCD_LOCAL', '0')
+        ref_codes, ref_grads = run()
+        monkeypatch.setenv('VS_ROLLOUT_XCD_LOCAL', '2')
+        ops._XL_PROBED.clear()
+        ops.rollout_xcd_local(True)
+        C, H, nb = cfg['code_size_t'], cfg['res_hidden_size'], cfg['n_blocks']
+        assert lib.vs_mlp_rollout_xcd_local_get(BF16, cfg['B'], C, H, nb) == 1            # before the probe the launch WOULD take the plain stores
+        codes, grads = run()
+        assert lib.vs_mlp_rollout_xcd_local_get(BF16, cfg['B'], C, H, nb) == 0, 'the probe must have refused the split ring'
+        assert ops.rollout_exchange_error(dev) == 0, 'the probe consumes its own verdict'
+        assert torch.equal(codes, ref_codes)
+        for a, b in zip(grads, ref_grads):
+            assert torch.equal(a, b)
+    finally:
+        ops._XL_PROBED.clear()
+        ops.rollout_xcd_local(True)
+
+
+def test_recorded_training_survives_a_mid_run_exchange_timeout(monkeypatch, tmp_path, capfd):
+    """`train()` must never apply an optimizer step computed from a timed-out exchange, and must not abort.  The probe
+    is switched off and the ring split (VS_ROLLOUT_XCD_LOCAL=2), so the FIRST replay of the recorded step times out: the guard word makes the
+    recorded optimizer launches skip (parameters bit-identical to the start), `train()` notices at its check after the first replay, switches the
+    process to the agent-scope exchange, re-records and goes on: the parameters after the run equal those of a run that used the agent-scope
+    exchange from the start on the batches the first run actually applied."""
+    from spatiotemporal_variable_separation_amd import functional as VF, ops
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.train import train
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    def fit(xp, loader, xl, probe):
+        monkeypatch.setenv('VS_ROLLOUT_XCD_LOCAL', xl)
+        monkeypatch.setenv('VARSEP_ROLLOUT_PROBE', probe)
+        monkeypatch.setenv('VS_ROLLOUT_SPIN_LIMIT', str(1 << 14))
+        ops._XL_PROBED.clear()
+        ops.rollout_xcd_local(True)
+        cfg, net, cond, target = _ws_net()
+        opt = Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.99))
+        lam = cfg['lambdas']
+        np.random.seed(5)
+        VF.set_precision('bf16')
+        batches = [(cond, target)] * loader
+        train(str(xp), batches, dev, net, opt, None, False, False, 1, lam['ae'], lam['s'], lam['t'], lam['pred'], cfg['offset'], cfg['nt_cond'],
+              cfg['nt_pred'], False, False, None, False, hip_graph=True)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in net.state_dict().items()}
+    try:
+        start = {k: v.detach().clone() for k, v in _ws_net()[1].state_dict().items()}
+        # one batch, ring split, no probe: the only step times out and must leave the parameters untouched
+        one = fit(tmp_path / 'a', 1, '2', '0')
+        err = capfd.readouterr().err
+        assert 'exchange timed out' in err and 'agent-scope' in err
+        for k in start:
+            assert torch.equal(one[k], start[k]), 'a guarded step changed %s' % k
+        # four batches: the first is lost to the time-out, three are applied under the re-recorded agent-scope step
+        got = fit(tmp_path / 'b', 4, '2', '0')
+        assert any(not torch.equal(got[k], start[k]) for k in start), 'training did not continue after the time-out'
+        assert all(torch.isfinite(v).all() for v in got.values() if v.is_floating_point())
+        assert ops.rollout_exchange_error(dev) == 0
+    finally:
+        ops._XL_PROBED.clear()
+        ops.rollout_xcd_local(True)
+        VF.set_precision('fp32')
+
+
 def test_bench_gpus_2_launches_two_ranks():
     """`python bench.py --gpus 2` starts two rank processes itself; on the one-GPU box they share cuda:0 and average gradients
     over gloo (VARSEP_BENCH_SHARE_GPU=1).  The JSON line must say n_gpus 2 and a doubled global batch."""
