@@ -325,7 +325,15 @@ def _run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=
     ops.profile_reset(enable=False)
     regions = []
     loss = None
-    for rep in range(max(1, repeats)):
+    # regions of EXACTLY `steps` steps each; beyond the `repeats` asked for, further regions are added until the timed regions sum to
+    # VARSEP_BENCH_MIN_TIMED_S (default 1 s; the headline's 20-step regions are ~25 ms: five of them are too coarse for 1 % statements), at
+    # most 200.  The decision uses the MAX-over-ranks clock every rank holds, so all ranks run the same number of regions.
+    min_timed = float(os.environ.get('VARSEP_BENCH_MIN_TIMED_S', '1.0')) if graphed is not None and events_on else 0.0
+    rep = -1
+    while True:
+        rep += 1
+        if rep >= max(1, repeats) and (sum(regions) >= min_timed or rep >= 200):
+            break
         if graphed is None and events_on and rep == 0:
             # eager loop: HIP-event pairs around every vs_* launch of every 4th step of the first region (events pre-created)
             ops.profile_reset(enable=True, pool=512 * (steps // 4 + 8))
@@ -448,20 +456,33 @@ def live_replay_table(workload, precision, steps, warmup, timeout_s=240):
            '--no_cpu_baseline', '--extra_configs', 'none']
     try:
         t0 = time.time()
-        r = subprocess.run(cmd, env=env, cwd='/tmp', stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        # a session of its own: on a time-out the WHOLE process group goes (rocprofv3 is a launcher; killing it alone would leave the
+        # benchmark grandchild running on the GPU while this process starts its timed regions)
+        proc = subprocess.Popen(cmd, env=env, cwd='/tmp', stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.communicate()
+            sys.stderr.write('bench.py: live rocprofv3 pass of %s timed out after %d s (process group killed)\n' % (workload, timeout_s))
+            return None
         hits = glob.glob(os.path.join(tmp, '**', '*kernel_stats.csv'), recursive=True)
-        if r.returncode != 0 or not hits:
-            sys.stderr.write('bench.py: live rocprofv3 pass of %s failed (rc %s): %s\n' % (workload, r.returncode, r.stderr.decode(errors='replace')[-400:]))
+        if proc.returncode != 0 or not hits:
+            sys.stderr.write('bench.py: live rocprofv3 pass of %s failed (rc %s): %s\n' % (workload, proc.returncode, err.decode(errors='replace')[-400:]))
             return None
         rows = list(csv.DictReader(open(hits[0])))
         nsteps, table, rest = replay_table(rows)
         child = None
-        for ln in r.stdout.decode(errors='replace').splitlines():
+        for ln in out.decode(errors='replace').splitlines():
             if ln.startswith('{'):
                 child = json.loads(ln)
         return {'groups': table, 'steps': nsteps, 'unassigned_us_per_step': rest, 'seconds': round(time.time() - t0, 1),
                 'profiled_ms_per_step': None if child is None else child.get('ms_per_step')}
-    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+    except (OSError, ValueError) as e:
         sys.stderr.write('bench.py: live rocprofv3 pass of %s: %s\n' % (workload, e))
         return None
     finally:
@@ -512,9 +533,13 @@ def rooflines(res, workload, precision, top=6, live=None):
         rp = (replay or {}).get('groups', {}).get(g)
         if rp:
             us = rp['us_per_step']
+            # the share of the step is taken inside ONE run: the profiled child's kernel time over the profiled child's own step time (kernel
+            # times of the profiled pass over the un-profiled parent's step mixed two runs: advisor finding, round 4); sums above 1 mean
+            # overlapping streams
+            step_ms = (replay.get('profiled_ms_per_step') or ms) if timing == 'replay-live' else ms
             out.update({'achieved': round(work / (us * 1e-6) / scale, 2), 'frac': round(work / (us * 1e-6) / scale / peak, 4),
                         'launches_per_step': round(rp['launches_per_step'], 2), 'avg_launch_us': round(rp['avg_launch_us'], 3), 'us_per_step': round(us, 1),
-                        'share_of_step': round(us * 1e-3 / ms, 3), 'timing': timing, 'source': replay_src, 'eager_events': eager})
+                        'share_of_step': round(us * 1e-3 / step_ms, 3), 'timing': timing, 'source': replay_src, 'eager_events': eager})
         else:
             out.update({'achieved': eager['achieved'], 'frac': eager['frac'], 'launches_per_step': round(e['n'] / sampled, 2),
                         'avg_launch_us': eager['avg_launch_us'], 'us_per_step': eager['us_per_step'], 'share_of_step': round(eager_us * 1e-3 / ms, 3),

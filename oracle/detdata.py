@@ -63,6 +63,50 @@ def det_fill(net, salt=1):
     return net
 
 
+def det_normal(shape, salt, terms=8):
+    """Approximately N(0, 1) float32 tensor without an RNG and without libm: the sum of `terms` hash uniforms (24 random bits each, so
+    the sum is EXACT in float64 on any machine), centred and scaled to unit variance (Irwin-Hall).  Bit-reproducible anywhere."""
+    acc = None
+    for i in range(terms):
+        u = det_uniform(shape, salt * 131 + i + 1).double()
+        acc = u if acc is None else acc + u
+    return ((acc - terms / 2.0) * math.sqrt(12.0 / terms)).float()
+
+
+def det_init_fill(net, salt=1, gain=0.02, res_gain=1.41):
+    """Weights with the STATISTICS of the reference's start of training (main.py:119-138 -> utils.py:88-109 `init_net`): encoders and decoder
+    `normal` with gain 0.02 -- conv / linear weights N(0, 0.02), biases 0, BatchNorm weight N(1, 0.02), bias 0; the integrator `orthogonal`
+    with gain 1.41 -- restated here as N(0, res_gain^2 / max(rows, cols)) entries (an orthogonal matrix of that gain has entries of exactly
+    this variance; a QR factorisation would tie the fixture to one LAPACK build).  RNG-free (det_normal): identical bits on any machine.
+    BatchNorm running statistics keep their constructor values (0 / 1), as after `init_net`."""
+    k = 0
+    with torch.no_grad():
+        for name, m in net.named_modules():
+            kind = type(m).__name__
+            if kind not in ('Conv2d', 'ConvTranspose2d', 'Linear', 'BatchNorm2d'):
+                continue
+            s = salt * 1000003 + k * 7919 + 17
+            k += 1
+            in_res = name.startswith('t_resnet')
+            if kind == 'BatchNorm2d':
+                m.weight.copy_(1.0 + det_normal(m.weight.shape, s) * (res_gain if in_res else gain))
+                m.bias.zero_()
+                m.running_mean.zero_()
+                m.running_var.fill_(1.0)
+                m.num_batches_tracked.zero_()
+                continue
+            w = m.weight
+            if in_res:
+                rows, cols = w.shape[0], w[0].numel()
+                std = res_gain / math.sqrt(max(rows, cols))
+            else:
+                std = gain
+            w.copy_(det_normal(w.shape, s) * std)
+            if m.bias is not None:
+                m.bias.zero_()
+    return net
+
+
 def checksum(t):
     """(sum, L2, 16 strided samples) of a tensor in float64 -- pins tensors too large to commit."""
     f = t.detach().double().flatten()

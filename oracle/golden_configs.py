@@ -93,11 +93,23 @@ FULL_CONFIGS = {
 }
 
 
+# Round 5: the three convolution workloads again with weights that have the statistics of the reference's OWN start of
+# training (`init_net`, main.py:119-138: normal 0.02 for the encoders / decoder, orthogonal gain 1.41 for the integrator) instead of the
+# hash fill above -- to tell whether the chaotic 16-bit gradients of the deep BatchNorm stacks are a property of `det_fill` (gain 1.2 per
+# layer, BatchNorm weights 1 +- 0.2) or of the networks.  `fill='init'` -> oracle.detdata.det_init_fill (RNG-free).
+FULL_CONFIGS['full_mnist_b128_init'] = dict(FULL_CONFIGS['full_mnist_b128'], fill='init', res_scale=None, salt=43)
+FULL_CONFIGS['full_taxibj_init'] = dict(FULL_CONFIGS['full_taxibj'], fill='init', res_scale=None, salt=44)
+FULL_CONFIGS['full_sst_init'] = dict(FULL_CONFIGS['full_sst'], fill='init', res_scale=None, salt=45)
+
+
 def fill_net(net, cfg):
-    """RNG-free weights of a parity configuration: det_fill, then the integrator scaled by cfg['res_scale'] when given.  Works on
-    the oracle's, the reference's and the product's SeparableNetwork alike (all expose `.t_resnet`)."""
+    """RNG-free weights of a parity configuration: det_fill, then the integrator scaled by cfg['res_scale'] when given (or, with
+    cfg['fill'] == 'init', weights with the statistics of the reference's `init_net`).  Works on the oracle's, the reference's and the
+    product's SeparableNetwork alike (all expose `.t_resnet`)."""
     import torch
-    from oracle.detdata import det_fill
+    from oracle.detdata import det_fill, det_init_fill
+    if cfg.get('fill') == 'init':
+        return det_init_fill(net, salt=cfg['salt'])
     det_fill(net, salt=cfg['salt'])
     scale = cfg.get('res_scale')
     if scale:

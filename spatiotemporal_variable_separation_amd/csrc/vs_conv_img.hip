@@ -1467,6 +1467,15 @@ static int launch_band_w(int compute, const void* x, const void* w_packed, const
     return launch_band<W, 12, 1>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, stream, bn_sums, mpg);
 }
 
+// round 5: the form with both operands through LDS (csrc/vs_conv_band2.hip) serves every call that wants no BatchNorm sums from the epilogue;
+// VS_BAND_V2=0 (read per call: tools/band_bench.py runs A/B pairs in one process) restores the round-2 kernel
+int vs_band2_go(int compute, const void* x, const void* w_packed, const float* bias, void* y, int y_dtype, int B, int Cin, int H, int W, int Cout, int k4,
+                hipStream_t stream);
+static inline bool band2_enabled() {
+    const char* e = getenv("VS_BAND_V2");
+    return !(e && e[0] == '0');
+}
+
 // x [B][Cin][H][W] (16-bit), w_packed from vs_conv3_img16_pack_weight (same pre-pack) -> y [B][Cout][H][W] in y_dtype, bias added
 // bn_sums != NULL: the (sum, sum of squares) of the stored outputs are ADDED to bn_sums[group][Cout][2] (fp64; group = map / (B / groups)) -- what the
 // BatchNorm behind the convolution needs (vs_bn_stats_from_sums_fold), without a statistics pass over y.  Maps of >= 8 x 8 pixels only
@@ -1483,6 +1492,12 @@ extern "C" int vs_conv3_band_bn(int compute, const void* x, const void* w_packed
     VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0 && (uintptr_t)bn_sums % 8 == 0, "vs_conv3_band: operands must be 16-byte aligned");
     const int mpg = bn_sums ? B / groups : 1;
     int rc;
+    if (!bn_sums && band2_enabled()) {
+        rc = vs_band2_go(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, W, Cout, 0, (hipStream_t)stream);
+        if (rc != VS_OK) return rc;
+        VS_CHECK_LAUNCH("vs_conv3_band (v2)");
+        return VS_OK;
+    }
     if (W == 64) rc = launch_band_w<64>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream, bn_sums, mpg);
     else if (W == 32) rc = launch_band_w<32>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream, bn_sums, mpg);
     else if (W == 16) rc = launch_band_w<16>(compute, x, w_packed, bias, y, y_dtype, B, Cin, H, Cout, (hipStream_t)stream, bn_sums, mpg);
@@ -1646,6 +1661,12 @@ extern "C" int vs_conv_k4s2_band_bn(int compute, const void* planes, const void*
     if (!vs_conv_k4s2_skip_form(K)) return vs_conv3_band_bn(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, W, M, bn_sums, groups, stream);
     const int mpg = bn_sums ? B / groups : 1;
     int rc;
+    if (!bn_sums && band2_enabled()) {
+        rc = vs_band2_go(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, W, M, 1, (hipStream_t)stream);
+        if (rc != VS_OK) return rc;
+        VS_CHECK_LAUNCH("vs_conv_k4s2_band (v2)");
+        return VS_OK;
+    }
     if (W == 64) rc = launch_band_k4_w<64>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream, bn_sums, mpg);
     else if (W == 32) rc = launch_band_k4_w<32>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream, bn_sums, mpg);
     else if (W == 16) rc = launch_band_k4_w<16>(compute, planes, w_packed, bias, y, y_dtype, B, 4 * K, H, M, (hipStream_t)stream, bn_sums, mpg);

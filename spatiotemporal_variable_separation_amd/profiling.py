@@ -16,13 +16,18 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 
 
 def source_sha():
-    """sha256 (first 16 hex digits) over the kernel sources and the two files that decide which kernel a call reaches (`csrc/*`,
-    `ops.py`, `functional.py`).  `tools/replay_stats.py` / `tools/pmc_traffic.py` store it in every table they write under `profiles/`;
-    `bench.py` uses a committed table only while it still matches and says `"stale": true` otherwise."""
+    """sha256 (first 16 hex digits) over the kernel sources and EVERY Python file of the package: which kernels a step launches is decided
+    in `ops.py` / `functional.py` but also in `train.py`, `optim.py`, `parallel.py` and `networks/*` (advisor finding, round 4: a swap of
+    cat + cast for `vs_copy2d_pair` lived in `train.py` alone).  `tools/replay_stats.py` / `tools/pmc_traffic.py` / `tools/pmc_util.py` store
+    it in every table they write under `profiles/`; `bench.py` uses a committed table only while it still matches and says `"stale": true`
+    otherwise."""
     h = hashlib.sha256()
     files = sorted(os.path.join(_PKG, 'csrc', f) for f in os.listdir(os.path.join(_PKG, 'csrc')) if f.endswith(('.hip', '.h')))
-    for f in files + [os.path.join(_PKG, 'ops.py'), os.path.join(_PKG, 'functional.py')]:
-        h.update(os.path.basename(f).encode())
+    for root, dirs, names in sorted(os.walk(_PKG)):
+        dirs[:] = sorted(d for d in dirs if d not in ('__pycache__', 'build', 'csrc'))
+        files += [os.path.join(root, f) for f in sorted(names) if f.endswith('.py')]
+    for f in files:
+        h.update(os.path.relpath(f, _PKG).encode())
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]
 
@@ -32,11 +37,11 @@ GROUPS = [
     ('vs_gemm_adam', r'^vs_gemm_adam<', r'gemm_mid_kernel<\d, \d, \d, \w+, \d+, true>', 'hbm'),
     ('vs_mlp_rollout_fwd', r'^vs_mlp_rollout_fwd<', r'rollout_(ws|fwd)_kernel<\d+, true|rollout_fwd_kernel', 'mfma'),
     ('vs_mlp_rollout_bwd', r'^vs_mlp_rollout_bwd<', r'rollout_ws_kernel<\d+, false|rollout_bwd_kernel', 'mfma'),
-    ('vs_conv_k4s2', r'^vs_conv_k4s2:|^vs_space_to_depth2', r'conv3_band_kernel<\d, \d+, \d+, \d, 1>|wgrad3_band_kernel<\d, \d+, \d, 1(, \d)?>|space_to_depth2_kernel|'
+    ('vs_conv_k4s2', r'^vs_conv_k4s2:|^vs_space_to_depth2', r'conv3_band_kernel<\d, \d+, \d+, \d, 1>|conv3_band2_kernel<\d, \d+, \d, 1>|wgrad3_band_kernel<\d, \d+, \d, 1(, \d)?>|space_to_depth2_kernel|'
      r'::k4s2_\w+_kernel', 'mfma'),
     ('vs_conv3_img16_bn', r'^vs_conv3_img16_bn:', r'conv3_img16_bn_kernel|exchange_epoch_advance', 'mfma'),
     ('vs_conv3_img16', r'^vs_conv3_img16:', r'conv3_img16_kernel|(?<!grouped_)slab_sum_kernel', 'mfma'),
-    ('vs_conv3_band', r'^vs_conv3_band:', r'conv3_band_kernel', 'mfma'),
+    ('vs_conv3_band', r'^vs_conv3_band:', r'conv3_band2?_kernel', 'mfma'),
     ('vs_conv3_wgrad_band', r'^vs_conv3_wgrad_band<', r'wgrad3_band_kernel|wgrad_slab_finish_kernel|slab_sum_grouped_kernel', 'mfma'),
     ('vs_convT_tap', r'^vs_convT_tap:', r'convt_k4s2_tap_kernel', 'mfma'),
     ('vs_conv3_tap', r'^vs_conv3_tap:', r'conv_k3s1_tap_kernel', 'mfma'),

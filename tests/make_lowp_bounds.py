@@ -1,7 +1,7 @@
 """Writes tests/golden/lowp_bounds.json: per 16-bit step test case, the rounding-point emulation's distance to a second, equally valid
 evaluation of itself (step_util.lowp_noise_floor: every parameter moved by 2e-7 relative, the size of fp32 summation-order noise).
 
-    python tests/make_lowp_bounds.py [reduced|full|all]        (CPU only; `full` takes ~15 min on 8 cores)
+    python tests/make_lowp_bounds.py [reduced|full|init|all]        (CPU only; `full` takes ~15 min on 8 cores)
 
 The GPU tests bound HIP-vs-emulation distances by max(stated floor, 3 x these COMMITTED constants), never above 0.5 (step_util.noise_bound):
 round 3 evaluated the self-distance live and relaxed to 1.0 / 1.5 where it saturated, so a regression that doubled a gradient error on the
@@ -25,6 +25,8 @@ CONV_CONFIGS = ['dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'vgg64_skip', 'sst
 LOWP_BATCH = {'vgg32_tiny': 16, 'vgg64_skip': 16, 'sst_skip': 16, 'sst_noskip': 16}
 REDUCED = [(n, 'bf16', None) for n in CONV_CONFIGS] + [(n, 'fp16', 256.0) for n in ('dcgan_tiny', 'dcgan_skip_mul', 'vgg32_tiny', 'sst_skip')]
 FULL = [('full_mnist_b128', 'bf16', None), ('full_taxibj', 'bf16', None), ('full_sst', 'fp16', 1024.0), ('full_sst', 'bf16', None)]
+# round 5: the same workloads on weights with the statistics of the reference's init_net (oracle.detdata.det_init_fill)
+FULL_INIT = [('full_mnist_b128_init', 'bf16', None), ('full_taxibj_init', 'bf16', None), ('full_sst_init', 'fp16', 1024.0), ('full_sst_init', 'bf16', None)]
 
 
 def main():
@@ -38,6 +40,8 @@ def main():
         cases += [(n, dict(CONFIGS[n], B=LOWP_BATCH.get(n, CONFIGS[n]['B'])), p, ls) for n, p, ls in REDUCED]
     if what in ('full', 'all'):
         cases += [(n, FULL_CONFIGS[n], p, ls) for n, p, ls in FULL]
+    if what in ('init', 'all'):
+        cases += [(n, FULL_CONFIGS[n], p, ls) for n, p, ls in FULL_INIT]
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     for name, cfg, prec, ls in cases:
         t_random = int(load_golden(name)['t_random'])

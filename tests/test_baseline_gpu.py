@@ -28,7 +28,7 @@ from step_util import committed_noise, grad_err, grad_floor, hip_step, noise_bou
 pytestmark = pytest.mark.gpu
 
 # oracle cost on the host (fp32, ~16 threads): waveeq 1 s, mnist_b16 1 s, mnist_b128 10 s, taxibj 8 s, sst (40 frames) ~1 min
-LIVE_ORACLE = ['full_waveeq', 'full_mnist_b16', 'full_mnist_b128', 'full_taxibj']
+LIVE_ORACLE = ['full_waveeq', 'full_mnist_b16', 'full_mnist_b128', 'full_taxibj', 'full_mnist_b128_init', 'full_taxibj_init']
 
 
 def _fixture(name):
@@ -176,6 +176,12 @@ LOWP_FULL = [
     ('full_sst', 'fp16', ('vs_conv3_img16:fwd', 'vs_conv3_img16:dgrad', 'vs_conv3_band:fwd', 'vs_conv3_band:dgrad', 'vs_conv3_wgrad_band',
                           'vs_conv_thin:fwd', 'vs_conv_thin:dgrad', 'vs_conv_thin:wgrad', 'vs_bn_fwd_small_slabs', 'vs_bn_bwd_small_ex'), 1024.0),
     ('full_sst', 'bf16', ('vs_conv3_img16:fwd', 'vs_conv3_img16:dgrad', 'vs_conv3_band:fwd', 'vs_conv3_wgrad_band', 'vs_conv_thin:wgrad'), None),
+    # round 5: the same steps on weights with the statistics of the reference's own start of training (init_net: normal 0.02 /
+    # orthogonal 1.41) instead of the hash fill -- fixtures recorded from the reference by `python -m oracle.make_golden full_*_init`
+    ('full_mnist_b128_init', 'bf16', ('vs_convT_tap:fwd', 'vs_conv_k4s2:fwd', 'vs_conv_k4s2:wgrad'), None),
+    ('full_taxibj_init', 'bf16', ('vs_conv3_band:fwd', 'vs_conv3_band:dgrad', 'vs_conv3_wgrad_band'), None),
+    ('full_sst_init', 'fp16', ('vs_conv3_img16:fwd', 'vs_conv3_band:fwd', 'vs_conv3_wgrad_band'), 1024.0),
+    ('full_sst_init', 'bf16', ('vs_conv3_img16:fwd', 'vs_conv3_band:fwd', 'vs_conv3_wgrad_band'), None),
 ]
 # Bounds (relative L2).
 #  vs the rounding-point emulation (same rounding rules, independent implementation: oracle/bf16_emu.py on the oracle's module tree):

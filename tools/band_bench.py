@@ -198,6 +198,11 @@ def bench_k4(check, cold):
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('-') else 'all'
     check, cold = '--check' in sys.argv, '--cold' in sys.argv
+    only = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--only=')]
+    if only:
+        keys = only[0].split(',')
+        FWD[:] = [r for r in FWD if any(k in r[0] for k in keys)]
+        K4[:] = [r for r in K4 if any(k in r[0] for k in keys)]
     print('variants:', [v[0] for v in variants()], 'cold' if cold else 'hot')
     if what in ('fwd', 'all'):
         bench_fwd(check, cold)
