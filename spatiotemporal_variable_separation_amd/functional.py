@@ -256,6 +256,11 @@ def tail_fused_updates():
     return os.environ.get('VARSEP_ADAM_UNDER_FUSED', '1') == '1'
 
 
+def tail_split():
+    """VARSEP_TAIL_SPLIT=1 (round 5): see MLPChain.backward -- the last chain's fused first-layer update on lane 0, beside its own small gradients."""
+    return os.environ.get('VARSEP_TAIL_SPLIT', '0') == '1'
+
+
 def _lane_marker(lane):
     def fn():
         ev = torch.cuda.Event()
@@ -550,6 +555,8 @@ def join_side_streams(partial=False):
     release_deferred()  # (a step without the integrator's backward never reached the release point)
     late, _SIDE['late'] = _SIDE['late'], []
     for fn, inputs, outs, lane, producer in late:
+        if tail_split() and N_LANES > 1:
+            lane = N_LANES - 1                # (lane 0 carries the last chain's 640 MB update: the late gradients would queue behind it)
         ws = _lane_stream(lane)
         ws.wait_stream(producer)
         with torch.cuda.stream(ws):
@@ -800,8 +807,14 @@ class MLPChain(torch.autograd.Function):
             run_deferred(lambda views=views: ops.colsum_multi(dzs, outs=views, zero_flat=flat), *dzs, outs=flat, lane=lane)
         if tail_job is not None:
             tail_job[0]._vs_tail = True
-            run_deferred(_lane_marker(lane), outs=(), lane=lane)
-            run_deferred(tail_job[0], *tail_job[1], outs=(), lane=lane, late=_late_fused(0))
+            tl = lane
+            if tail_split() and lane == N_LANES - 1 and N_LANES > 1 and not deferred_held():
+                # the LAST chain of backward (E_t in the batched MLP step: lane N_LANES - 1): its small weight gradients and bias sums (~90 us of
+                # 10 us launches on `lane`) run BESIDE its 640 MB first-layer update instead of in front of it -- the update goes to lane 0, whose
+                # work (the decoder's weight gradients) is long done; the integrator's late weight gradients move to `lane` (join_side_streams)
+                tl = 0
+            run_deferred(_lane_marker(tl), outs=(), lane=tl)
+            run_deferred(tail_job[0], *tail_job[1], outs=(), lane=tl, late=_late_fused(0))
         return (dx, None, None, None) + tuple(grads)
 
 

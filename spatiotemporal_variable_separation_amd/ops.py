@@ -360,7 +360,7 @@ def _probe_rollout_exchange(code, B, C, H, nb, device):
     if not lib.vs_mlp_rollout_xcd_local_get(code, B, C, H, nb) or os.environ.get('VARSEP_ROLLOUT_PROBE', '1') == '0':
         return
     import ctypes
-    dt = {_lib.VS_BF16: torch.bfloat16, _lib.VS_F16: torch.float16}[code]
+    dt = {BF16: torch.bfloat16, F16: torch.float16}[code]
     nbytes = lib.vs_mlp_rollout_workspace_bytes(code, B, C, H)
     ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
     n = 3
