@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libvarsep_hip.so')
 SOURCES = ['vs_gemm.hip', 'vs_eltwise.hip', 'vs_conv.hip', 'vs_rollout.hip', 'vs_norm.hip', 'vs_optim.hip', 'vs_data.hip', 'vs_conv_tap.hip', 'vs_metrics.hip', 'vs_conv_img.hip', 'vs_conv_k4s2.hip',
-           'vs_conv_thin.hip', 'vs_conv_band2.hip']
+           'vs_conv_thin.hip', 'vs_conv_band2.hip', 'vs_conv_wgrad2.hip']
 
 F32, BF16, F16 = 0, 1, 2
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}

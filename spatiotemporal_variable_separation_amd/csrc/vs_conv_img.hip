@@ -1575,7 +1575,18 @@ static int wgrad_band_ksplit(int B, int Cin, int H, int W, int Cout, int ctw = 1
     return (int)(ks < 1 ? 1 : ks);
 }
 
+// round 5: the form with both operands staged by LDS-DMA and the column shift taken in registers (csrc/vs_conv_wgrad2.hip); VS_WGRAD_V2=0
+// (read per call: the slab query and the launch must see the same value) restores the round-2 kernel.  The k4 s2 family keeps the round-2 kernel.
+int vs_wgrad2_slabs(int B, int Cin, int H, int W, int Cout);
+int vs_wgrad2_go(int compute, int npieces, const void* const* x, const void* const* dz, int maps_per_piece, float* slabs, int B, int Cin, int H, int W, int Cout,
+                 hipStream_t stream);
+static inline bool wgrad2_enabled() {
+    const char* e = getenv("VS_WGRAD_V2");
+    return !(e && e[0] == '0');
+}
+
 extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout) {
+    if (wgrad2_enabled()) return vs_wgrad2_slabs(B, Cin, H, W, Cout);
     return (4 / wgrad_band_mw(Cout)) * wgrad_band_ksplit(B, Cin, H, W, Cout);
 }
 
@@ -1640,6 +1651,12 @@ extern "C" int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, f
     VS_CHECK_ARG(x && dz && slabs, "vs_conv3_wgrad_band: bad argument");
     VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_wgrad_band: unsupported geometry (query vs_conv3_wgrad_band_supported)");
     VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)dz | (uintptr_t)slabs) % 16 == 0, "vs_conv3_wgrad_band: operands must be 16-byte aligned");
+    if (wgrad2_enabled()) {
+        const int rc = vs_wgrad2_go(compute, 1, &x, &dz, B, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
+        if (rc != VS_OK) return rc;
+        VS_CHECK_LAUNCH("vs_conv3_wgrad_band (v2)");
+        return VS_OK;
+    }
     WgradPieces pieces = {};
     pieces.x[0] = (const unsigned short*)x;
     pieces.dz[0] = (const unsigned short*)dz;
@@ -1708,6 +1725,15 @@ extern "C" int vs_conv3_wgrad_band_pieces(int compute, int npieces, const void* 
     VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_wgrad_band_pieces: unsupported geometry");
     VS_CHECK_ARG(W != 8 || npieces == 1 || maps_per_piece % 4 == 0, "vs_conv3_wgrad_band_pieces: 8 x 8 maps go four at a time: maps_per_piece must be a multiple of 4");
     VS_CHECK_ARG(W != 4 || npieces == 1 || maps_per_piece % 16 == 0, "vs_conv3_wgrad_band_pieces: 4 x 4 maps go sixteen at a time: maps_per_piece must be a multiple of 16");
+    if (wgrad2_enabled()) {
+        for (int i = 0; i < npieces; ++i)
+            VS_CHECK_ARG(x[i] && dz[i] && ((uintptr_t)x[i] | (uintptr_t)dz[i]) % 16 == 0, "vs_conv3_wgrad_band_pieces: every piece must be a 16-byte aligned tensor");
+        VS_CHECK_ARG((uintptr_t)slabs % 16 == 0, "vs_conv3_wgrad_band_pieces: slabs must be 16-byte aligned");
+        const int rc = vs_wgrad2_go(compute, npieces, x, dz, maps_per_piece, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
+        if (rc != VS_OK) return rc;
+        VS_CHECK_LAUNCH("vs_conv3_wgrad_band_pieces (v2)");
+        return VS_OK;
+    }
     WgradPieces pieces = {};
     for (int i = 0; i < npieces; ++i) {
         VS_CHECK_ARG(x[i] && dz[i] && ((uintptr_t)x[i] | (uintptr_t)dz[i]) % 16 == 0, "vs_conv3_wgrad_band_pieces: every piece must be a 16-byte aligned tensor");
