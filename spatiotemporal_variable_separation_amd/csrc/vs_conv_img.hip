@@ -177,7 +177,7 @@ __device__ __forceinline__ void img16_tile(const unsigned short* __restrict__ X,
 // 72 KiB of LDS each) that cover each other's staging and epilogue -- taken when that doubles the number of resident workgroups.
 template <int CT, int AHEAD, int MINB>
 __global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned short* __restrict__ X, const u32x4* __restrict__ Wp, float* __restrict__ slabs,
-                                                          int B, int Cin, int Cout, int cs, int splits, int mtiles) {
+                                                          int B, int Cin, int Cout, int cs, int splits, int mtiles, int wide_store) {
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];          // [cs][18][16]
     int id = blockIdx.x;
     const int split = id % splits;
@@ -190,6 +190,27 @@ __global__ __launch_bounds__(256, MINB) void conv3_img16_kernel(const unsigned s
 
     // ---- fp32 slab of this split ----------------------------------------------------------------------------------------------------
     float* out = slabs + (((int64_t)split * B + b) * Cout) * 256;
+    if (wide_store) {
+        // round 5: the accumulator holds ONE pixel per lane, so a store instruction from there moves two 128-byte runs (32 of them per wave).
+        // The tile is transposed through the image's LDS (nobody reads it any more behind the barrier): wave-private [32 channels][64 px],
+        // read back 4 pixels per lane: 8 store instructions of 1 KiB per wave.
+        __syncthreads();
+        float* of = reinterpret_cast<float*>(xs) + wave * (32 * 64);
+        const int chb = 4 * (lane >> 5), l31 = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) of[(chb + (v & 3) + 8 * (v >> 2)) * 64 + j * 32 + l31] = o[j][v];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // (a wave reads back only what it wrote itself)
+#pragma unroll
+        for (int rd = 0; rd < 8; ++rd) {
+            const int c = rd * 64 + lane, chl = c >> 4, px = (c & 15) * 4;
+            const int m = mt * 32 + chl;
+            const f32x4 val = *reinterpret_cast<const f32x4*>(of + chl * 64 + px);
+            if (m < Cout) *reinterpret_cast<f32x4*>(out + (int64_t)m * 256 + wave * 64 + px) = val;
+        }
+        return;
+    }
     const int mrow = mt * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1246,10 +1267,12 @@ extern "C" int vs_conv3_img16(int compute, const void* x, const void* w_packed, 
             return vs_fail(VS_ERR_LAUNCH, "vs_conv3_img16: cannot raise the dynamic LDS limit");
         attr_set[pair] = true;
     }
+    const char* wse = getenv("VS_IMG16_WIDE_STORE");                              // (read per call: A/B in one process; the LDS image holds >= 32 KiB: cs >= 64)
+    const int wide = !(wse && wse[0] == '0') && lds >= (size_t)32 * 1024;
     if (compute == VS_BF16)
-        hipLaunchKernelGGL(kb, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)x, (const u32x4*)w_packed, slabs, B, Cin, Cout, cs, splits, mtiles);
+        hipLaunchKernelGGL(kb, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)x, (const u32x4*)w_packed, slabs, B, Cin, Cout, cs, splits, mtiles, wide);
     else
-        hipLaunchKernelGGL(kh, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)x, (const u32x4*)w_packed, slabs, B, Cin, Cout, cs, splits, mtiles);
+        hipLaunchKernelGGL(kh, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)x, (const u32x4*)w_packed, slabs, B, Cin, Cout, cs, splits, mtiles, wide);
     VS_CHECK_LAUNCH("vs_conv3_img16");
     return VS_OK;
 }
@@ -1579,10 +1602,17 @@ static int wgrad_band_ksplit(int B, int Cin, int H, int W, int Cout, int ctw = 1
 // (read per call: the slab query and the launch must see the same value) restores the round-2 kernel.  The k4 s2 family keeps the round-2 kernel.
 int vs_wgrad2_slabs(int B, int Cin, int H, int W, int Cout);
 int vs_wgrad2_go(int compute, int npieces, const void* const* x, const void* const* dz, int maps_per_piece, float* slabs, int B, int Cin, int H, int W, int Cout,
-                 hipStream_t stream);
+                 int k4, hipStream_t stream);
 static inline bool wgrad2_enabled() {
     const char* e = getenv("VS_WGRAD_V2");
     return !(e && e[0] == '0');
+}
+// the k4 s2 family: built and correct (tools/band_bench.py k4 --check), but a plane's 2 x 2 taps leave four MFMAs per k-step against the same
+// staged tiles -- the launch is bound by the LDS-DMA (52 KiB per 1 150 cycles) and loses to the round-2 kernel, which walks two channel tiles
+// per staged dz tile: 256 -> 349 us, 192 -> 263 us on the Moving-MNIST decoder layers, the step 6.11 -> 6.32 ms.  Opt-in: VS_WGRAD_V2_K4=1.
+static inline bool wgrad2_k4_enabled() {
+    const char* e = getenv("VS_WGRAD_V2_K4");
+    return wgrad2_enabled() && e && e[0] == '1';
 }
 
 extern "C" int vs_conv3_wgrad_band_slabs(int B, int Cin, int H, int W, int Cout) {
@@ -1652,7 +1682,7 @@ extern "C" int vs_conv3_wgrad_band(int compute, const void* x, const void* dz, f
     VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, Cin, H, W, Cout), "vs_conv3_wgrad_band: unsupported geometry (query vs_conv3_wgrad_band_supported)");
     VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)dz | (uintptr_t)slabs) % 16 == 0, "vs_conv3_wgrad_band: operands must be 16-byte aligned");
     if (wgrad2_enabled()) {
-        const int rc = vs_wgrad2_go(compute, 1, &x, &dz, B, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
+        const int rc = vs_wgrad2_go(compute, 1, &x, &dz, B, slabs, B, Cin, H, W, Cout, 0, (hipStream_t)stream);
         if (rc != VS_OK) return rc;
         VS_CHECK_LAUNCH("vs_conv3_wgrad_band (v2)");
         return VS_OK;
@@ -1701,6 +1731,7 @@ extern "C" int vs_conv_k4s2_band(int compute, const void* planes, const void* w_
 
 // slabs vs_conv_k4s2_wgrad_band writes (the skip form shares the batch among fewer, heavier workgroups than vs_conv3_wgrad_band on the same planes)
 extern "C" int vs_conv_k4s2_wgrad_band_slabs(int B, int K, int H, int W, int M) {
+    if (wgrad2_k4_enabled() && vs_conv_k4s2_skip_form(K)) return vs_wgrad2_slabs(B, 4 * K, H, W, M);
     return (4 / wgrad_band_mw(M)) * wgrad_band_ksplit(B, 4 * K, H, W, M, vs_conv_k4s2_skip_form(K) ? wgrad_k4_ctw(4 * K) : 1);
 }
 
@@ -1708,6 +1739,12 @@ extern "C" int vs_conv_k4s2_wgrad_band(int compute, const void* planes, const vo
     VS_CHECK_ARG(planes && small && slabs, "vs_conv_k4s2_wgrad_band: bad argument");
     VS_CHECK_ARG(vs_conv3_wgrad_band_supported(compute, B, 4 * K, H, W, M), "vs_conv_k4s2_wgrad_band: unsupported geometry");
     VS_CHECK_ARG(((uintptr_t)planes | (uintptr_t)small | (uintptr_t)slabs) % 16 == 0, "vs_conv_k4s2_wgrad_band: operands must be 16-byte aligned");
+    if (wgrad2_k4_enabled() && vs_conv_k4s2_skip_form(K)) {
+        const int rc = vs_wgrad2_go(compute, 1, &planes, &small, B, slabs, B, 4 * K, H, W, M, 1, (hipStream_t)stream);
+        if (rc != VS_OK) return rc;
+        VS_CHECK_LAUNCH("vs_conv_k4s2_wgrad_band (v2)");
+        return VS_OK;
+    }
     WgradPieces pieces = {};
     pieces.x[0] = (const unsigned short*)planes;
     pieces.dz[0] = (const unsigned short*)small;
@@ -1729,7 +1766,7 @@ extern "C" int vs_conv3_wgrad_band_pieces(int compute, int npieces, const void* 
         for (int i = 0; i < npieces; ++i)
             VS_CHECK_ARG(x[i] && dz[i] && ((uintptr_t)x[i] | (uintptr_t)dz[i]) % 16 == 0, "vs_conv3_wgrad_band_pieces: every piece must be a 16-byte aligned tensor");
         VS_CHECK_ARG((uintptr_t)slabs % 16 == 0, "vs_conv3_wgrad_band_pieces: slabs must be 16-byte aligned");
-        const int rc = vs_wgrad2_go(compute, npieces, x, dz, maps_per_piece, slabs, B, Cin, H, W, Cout, (hipStream_t)stream);
+        const int rc = vs_wgrad2_go(compute, npieces, x, dz, maps_per_piece, slabs, B, Cin, H, W, Cout, 0, (hipStream_t)stream);
         if (rc != VS_OK) return rc;
         VS_CHECK_LAUNCH("vs_conv3_wgrad_band_pieces (v2)");
         return VS_OK;

@@ -52,10 +52,13 @@ __device__ __forceinline__ void wg2_dma(uint32_t lds_dst, const void* sbase, uin
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 
-template <int CT, int W>
+// K4 = 1: the k4 s2 p1 family on parity planes (csrc/vs_conv_k4s2.hip): Cin = 4 K plane channels, K a multiple of 32, so the 32 channels of a workgroup
+// lie in ONE plane, which sees 2 x 2 of the 3 x 3 taps: four MFMAs per k-step, four slab positions written (vs_conv_k4s2_wgrad_finish reads no others)
+template <int CT, int W, int K4>
 __global__ __launch_bounds__(512, 2) void wgrad2_band_kernel(Wg2Pieces pieces, float* __restrict__ slabs, int B, int Cin, int H, int Cout, int ctiles, int ksplit) {
     typedef Wg2Geo<W> G;
     constexpr int ROWB = W * 2;
+    constexpr int NKY = K4 ? 2 : 3, NT = K4 ? 4 : 9;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];         // [2][x tile | dz tile]
     int id = blockIdx.x;
     const int ks = id % ksplit;
@@ -154,9 +157,12 @@ __global__ __launch_bounds__(512, 2) void wgrad2_band_kernel(Wg2Pieces pieces, f
         }
     };
 
-    f32x16 acc[9];
+    // K4: first tap row / column this plane sees (odd planes: {0, 1}, even planes: {1, 2}); wave-uniform
+    const int plane = K4 ? (ct * 32) / (Cin >> 2) : 0;
+    const int ky_lo = K4 ? ((plane >> 1) ? 0 : 1) : 0, kx_lo = K4 ? ((plane & 1) ? 0 : 1) : 0;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
@@ -183,7 +189,8 @@ __global__ __launch_bounds__(512, 2) void wgrad2_band_kernel(Wg2Pieces pieces, f
             }
             const u32x4 af = *reinterpret_cast<const u32x4*>(zs + (msub * 32 + rl) * (G::ZPP * 16) + (p0 + 8 * h) * 2);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int kyi = 0; kyi < NKY; ++kyi) {
+                const int ky = ky_lo + kyi;
                 u32x4 own;
                 unsigned lft = 0, rgt = 0;                                        // dwords holding the pixel before / after the lane's eight
                 if constexpr (G::HALO) {
@@ -230,9 +237,19 @@ __global__ __launch_bounds__(512, 2) void wgrad2_band_kernel(Wg2Pieces pieces, f
                     fr[0] = m01; fr[1] = m12; fr[2] = m23;
                     fr[3] = __builtin_amdgcn_alignbyte(rgt, own[3], 2);            // (.. pixel 7 : pixel after): rgt's LOW half
                 }
-                acc[ky * 3 + 0] = mfma16_32<CT>(af, fl, acc[ky * 3 + 0]);
-                acc[ky * 3 + 1] = mfma16_32<CT>(af, own, acc[ky * 3 + 1]);
-                acc[ky * 3 + 2] = mfma16_32<CT>(af, fr, acc[ky * 3 + 2]);
+                if constexpr (K4) {
+                    if (kx_lo == 0) {                                              // column taps {0, 1}: x[col - 1], x[col]
+                        acc[kyi * 2 + 0] = mfma16_32<CT>(af, fl, acc[kyi * 2 + 0]);
+                        acc[kyi * 2 + 1] = mfma16_32<CT>(af, own, acc[kyi * 2 + 1]);
+                    } else {                                                       // column taps {1, 2}: x[col], x[col + 1]
+                        acc[kyi * 2 + 0] = mfma16_32<CT>(af, own, acc[kyi * 2 + 0]);
+                        acc[kyi * 2 + 1] = mfma16_32<CT>(af, fr, acc[kyi * 2 + 1]);
+                    }
+                } else {
+                    acc[ky * 3 + 0] = mfma16_32<CT>(af, fl, acc[ky * 3 + 0]);
+                    acc[ky * 3 + 1] = mfma16_32<CT>(af, own, acc[ky * 3 + 1]);
+                    acc[ky * 3 + 2] = mfma16_32<CT>(af, fr, acc[ky * 3 + 2]);
+                }
             }
         }
         // the next item has landed (this wave's share; behind the barrier everybody's) and nobody reads this stage any more
@@ -246,7 +263,8 @@ __global__ __launch_bounds__(512, 2) void wgrad2_band_kernel(Wg2Pieces pieces, f
     float* out = slabs + (int64_t)ks * ((int64_t)Cout * Cin * 9);
     const int c = ct * 32 + rl;
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
+    for (int tp = 0; tp < NT; ++tp) {
+        const int t3 = K4 ? (ky_lo + (tp >> 1)) * 3 + kx_lo + (tp & 1) : tp;        // slab position [tap of the 3 x 3 form][m][c]
         if (kpart != 0) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) red[(wave * 16 + v) * 64 + lane] = acc[tp][v];
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_band_kernel(Wg2Pieces pieces, f
 #pragma unroll
                 for (int k = 1; k < 4; ++k) s += red[((k * 2 + msub) * 16 + v) * 64 + lane];          // fixed order: reproducible
                 const int m = mt * 64 + msub * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                if (m < Cout && c < Cin) out[((int64_t)tp * Cout + m) * Cin + c] = s;
+                if (m < Cout && c < Cin) out[((int64_t)t3 * Cout + m) * Cin + c] = s;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -282,13 +300,13 @@ int wg2_ksplit(int B, int Cin, int H, int W, int Cout) {
     return (int)(ks < 1 ? 1 : ks);
 }
 
-template <int W>
+template <int W, int K4>
 int wg2_launch(int compute, const Wg2Pieces& pieces, float* slabs, int B, int Cin, int H, int Cout, hipStream_t stream) {
     typedef Wg2Geo<W> G;
     constexpr size_t lds = (size_t)2 * G::STAGE;
     static_assert(lds <= 160 * 1024 && lds >= 32 * 1024, "two stages fit the CU; the final reduction needs 32 KiB");
-    auto kb = wgrad2_band_kernel<VS_BF16, W>;
-    auto kh = wgrad2_band_kernel<VS_F16, W>;
+    auto kb = wgrad2_band_kernel<VS_BF16, W, K4>;
+    auto kh = wgrad2_band_kernel<VS_F16, W, K4>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
@@ -312,8 +330,9 @@ int wg2_launch(int compute, const Wg2Pieces& pieces, float* slabs, int B, int Ci
 int vs_wgrad2_slabs(int B, int Cin, int H, int W, int Cout) { return wg2_ksplit(B, Cin, H, W, Cout); }
 
 // x / dz: up to 64 equal pieces of `maps_per_piece` maps each (vs_conv3_wgrad_band_pieces); slabs [vs_wgrad2_slabs][9][Cout][Cin] fp32
+// k4 != 0: x = parity planes [B][Cin = 4 K][H][W] (K a multiple of 32), dz = the small map; slabs as above (four of nine positions written)
 int vs_wgrad2_go(int compute, int npieces, const void* const* x, const void* const* dz, int maps_per_piece, float* slabs, int B, int Cin, int H, int W, int Cout,
-                 hipStream_t stream) {
+                 int k4, hipStream_t stream) {
     if (npieces < 1 || npieces > WG2_MAX_PIECES) return vs_fail(VS_ERR_UNSUPPORTED, "vs_conv3_wgrad_band (v2): %d pieces", npieces);
     Wg2Pieces p = {};
     for (int i = 0; i < npieces; ++i) {
@@ -321,12 +340,14 @@ int vs_wgrad2_go(int compute, int npieces, const void* const* x, const void* con
         p.dz[i] = (const unsigned short*)dz[i];
     }
     p.maps_per_piece = maps_per_piece;
+#define VS_WG2_CASE(WV) \
+    case WV: return k4 ? wg2_launch<WV, 1>(compute, p, slabs, B, Cin, H, Cout, stream) : wg2_launch<WV, 0>(compute, p, slabs, B, Cin, H, Cout, stream);
     switch (W) {
-        case 64: return wg2_launch<64>(compute, p, slabs, B, Cin, H, Cout, stream);
-        case 32: return wg2_launch<32>(compute, p, slabs, B, Cin, H, Cout, stream);
-        case 16: return wg2_launch<16>(compute, p, slabs, B, Cin, H, Cout, stream);
-        case 8: return wg2_launch<8>(compute, p, slabs, B, Cin, H, Cout, stream);
-        case 4: return wg2_launch<4>(compute, p, slabs, B, Cin, H, Cout, stream);
+        VS_WG2_CASE(64)
+        VS_WG2_CASE(32)
+        VS_WG2_CASE(16)
+        VS_WG2_CASE(8)
+        VS_WG2_CASE(4)
         default: return vs_fail(VS_ERR_UNSUPPORTED, "vs_conv3_wgrad_band (v2): map width %d", W);
     }
 }

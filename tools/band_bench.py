@@ -188,6 +188,15 @@ def bench_k4(check, cold):
                     y = ops.conv_k4s2_gather(pr, ops.conv_k4s2_pack_weight(w, dt), bias, M, torch.float32)
                 e = rel_err(y, ref)
                 assert e < 2e-5, (name, vname, e)
+            if h >= 8:
+                sr = small[:nb].contiguous()
+                wz = torch.zeros((M, K, 4, 4), dtype=torch.float64, device='cuda', requires_grad=True)
+                torch.nn.functional.conv2d(big.double(), wz, None, stride=2, padding=1).backward(sr.double())
+                for vname, kv in variants():
+                    with Env(kv):
+                        dw = ops.conv_k4s2_wgrad(sr, pr, (M, K, 4, 4))
+                    e = rel_err(dw, wz.grad)
+                    assert e < 2e-5, (name, 'wgrad', vname, e)
         r = time_variants(fns)
         print(f'{name:38s} {fl / 1e9:7.1f} GF  gather ' + '  '.join(f'{k}: {m:7.1f} ({lo:7.1f}) us {fl / m / 1e6:6.0f} TF/s' for k, (m, lo) in r.items()))
         if fw:
