@@ -39,6 +39,24 @@ def _headers():
     return sorted(glob.glob(os.path.join(_CSRC, '*.h'))) + [os.path.join(_HERE, '..', 'include', 'varsep_hip.h')]
 
 
+def _deps(src, _seen=None):
+    """`src` and the project headers it includes, transitively (quoted includes, resolved in csrc/ and include/): a header edit recompiles
+    only the sources that see it."""
+    import re
+    seen = _seen if _seen is not None else set()
+    if src in seen or not os.path.exists(src):
+        return seen
+    seen.add(src)
+    with open(src, errors='replace') as f:
+        for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', f.read(), flags=re.M):
+            for d in (os.path.dirname(src), _CSRC, os.path.join(_HERE, '..', 'include')):
+                cand = os.path.normpath(os.path.join(d, name))
+                if os.path.exists(cand):
+                    _deps(cand, seen)
+                    break
+    return seen
+
+
 def library_is_stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -57,8 +75,7 @@ def build_library(force=False, verbose=False):
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + '.o')
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
-                [os.path.getmtime(src)] + [os.path.getmtime(h) for h in _headers()]):
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in _deps(src)):
             return obj
         cmd = [hipcc] + flags + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

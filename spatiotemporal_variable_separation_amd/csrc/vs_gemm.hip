@@ -166,6 +166,35 @@ int launch_layout(int la, int lb, const void* A, int64_t lda, const void* B, int
     return launch_tile<CT, LS, LS>(A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
 }
 
+// ---- split-K arrival counters -------------------------------------------------------------------------------------------------
+// One word per output tile of a split launch, zero between launches (the last workgroup to arrive clears it).  The words come from a static
+// pool in device memory (no allocation behind the ABI), dealt out round robin: two launches share a word only if more than SK_POOL words
+// were taken between them AND they are in flight at the same time; a recorded graph keeps the ranges it was captured with.
+constexpr unsigned SK_POOL = 1u << 20;
+}  // namespace
+__device__ unsigned vs_sk_pool[1u << 20];         // (external linkage: hipGetSymbolAddress does not find a symbol of an unnamed namespace)
+namespace {
+
+// `tile_slab_bytes`: what the last workgroup of a tile has to read back (splits x tile x 4 B).  It reads at ~16-64 KB per us (one workgroup,
+// dependent on the loads it keeps in flight), the reduce launch at TB/s: the fix-up pays for small tiles x few splits only (measured in the
+// WaveEq step: 256 x 1200 x 20480 in 22 splits of 128 x 128 tiles, 1.4 MB per tile: 41 -> 115 us; 64 x 64 tiles x 4 splits: even or ahead).
+// With the threshold the WaveEq step is still 15-25 us SLOWER (1.284 / 1.286 / 1.299 vs 1.268 / 1.268 / 1.275 ms, three interleaved pairs: the
+// 64 x 64 kernel's slabs leave as 4-byte sc1 stores, one fabric write each), so the fix-up is OPT-IN: VS_GEMM_SPLITK_FUSED: 0 = never (default),
+// 1 = up to SK_FUSED_MAX_BYTES per tile, 2 = always.
+constexpr int64_t SK_FUSED_MAX_BYTES = 96 << 10;
+unsigned* sk_take(int64_t words, int64_t tile_slab_bytes) {
+    static unsigned* base = nullptr;
+    static unsigned next = 0;
+    const char* env = getenv("VS_GEMM_SPLITK_FUSED");              // read per call: tests switch it
+    const int fused = env ? atoi(env) : 0;
+    if (!fused || words <= 0 || words > SK_POOL / 4 || (fused == 1 && tile_slab_bytes > SK_FUSED_MAX_BYTES)) return nullptr;
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(vs_sk_pool)) != hipSuccess) { base = nullptr; return nullptr; }
+    if (next + words > SK_POOL) next = 0;
+    unsigned* p = base + next;
+    next += (unsigned)words;
+    return p;
+}
+
 }  // namespace
 
 extern "C" size_t vs_gemm_batched_workspace_bytes(int batch, int64_t M, int64_t N, int64_t K) {
@@ -218,6 +247,13 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
         if (!workspace || workspace_bytes < need)
             return vs_fail(VS_ERR_WORKSPACE, "vs_gemm_batched: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         slabs = (float*)workspace;
+        // one counter per (problem, tile) of the kernel that runs: 128-wide tiles on the ring kernel, plan.bm x plan.bn otherwise
+        if (!bp.use && (mp.use || !(plan.bm == 128 && plan.bn == 128))) {      // (the 128x128 LDS-DMA tile never splits in practice: no fix-up there)
+            if (need < (1ull << 31)) epi.sk_counters = sk_take(batch * (mp.use ? (int64_t)mp.tiles_m * mp.tiles_n : vs_cdiv(M, plan.bm) * vs_cdiv(N, plan.bn)),
+                                                             (int64_t)plan.splits * (mp.use ? 128 * 128 : plan.bm * plan.bn) * 4);
+            epi.sk_splits = plan.splits;
+            epi.sk_bytes = (int64_t)need;
+        }
     }
     int rc;
     if (bp.use)
@@ -231,7 +267,7 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
              : compute == VS_F16 ? launch_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
                                  : launch_layout<VS_F32>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     if (rc != VS_OK) return rc;
-    if (slabs) {
+    if (slabs && !epi.sk_counters) {
         int64_t blocks = vs_cdiv(M * N, 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, stream, slabs, plan.splits, M, N, epi);
@@ -260,6 +296,8 @@ extern "C" int vs_gemm_adam(int compute, int64_t M, int64_t N, int64_t K, const 
     Epi epi{param, N, VS_F32, alpha, nullptr, VS_ACT_NONE, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     epi.adam_m = exp_avg; epi.adam_v = exp_avg_sq; epi.adam_shadow = (unsigned short*)shadow; epi.adam_shadow_dtype = shadow_dtype;
     epi.adam_step = step; epi.adam_skipped = skipped; epi.adam_guard = vs_g_exchange_guard;
+    static const int adam_pipe = getenv("VS_ADAM_PIPE") ? atoi(getenv("VS_ADAM_PIPE")) : 1;
+    epi.adam_pipe = adam_pipe;
     epi.adam_lr = lr; epi.adam_beta1 = beta1; epi.adam_beta2 = beta2; epi.adam_eps = (float)eps;
     MidPlan mp{true, 1, vs_cdiv(K, BIG_BK), (int)vs_cdiv(M, 128), (int)vs_cdiv(N, 128), 5};
     if ((int64_t)mp.tiles_m * mp.tiles_n > 0x7fffffffll) return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm_adam: too many tiles");
@@ -316,6 +354,12 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
         if (!workspace || workspace_bytes < need)
             return vs_fail(VS_ERR_WORKSPACE, "vs_gemm: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         slabs = (float*)workspace;
+        if (!bp.use && (mp.use || !(plan.bm == 128 && plan.bn == 128))) {
+            if (need < (1ull << 31)) epi.sk_counters = sk_take(mp.use ? (int64_t)mp.tiles_m * mp.tiles_n : vs_cdiv(M, plan.bm) * vs_cdiv(N, plan.bn),
+                                                             (int64_t)plan.splits * (mp.use ? 128 * 128 : plan.bm * plan.bn) * 4);
+            epi.sk_splits = plan.splits;
+            epi.sk_bytes = (int64_t)need;
+        }
     }
     int rc;
     if (bp.use)
@@ -329,7 +373,7 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
              : compute == VS_F16 ? launch_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream)
                                  : launch_layout<VS_F32>(layout_a, layout_b, A, lda, B, ldb, M, N, K, plan, epi, slabs, stream);
     if (rc != VS_OK) return rc;
-    if (slabs) {
+    if (slabs && !epi.sk_counters) {
         int64_t blocks = vs_cdiv(M * N, 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, plan.splits, M, N, epi);

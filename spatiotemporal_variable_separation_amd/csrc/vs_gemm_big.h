@@ -155,8 +155,18 @@ __device__ __forceinline__ void big_adam4(const Epi& e, const AdamCoef& c, int64
 }
 
 template <bool NCHW>
-__device__ __forceinline__ void big_store4(const Epi& e, int64_t m, int64_t n, int64_t N, const f32x4& v, float* slab_row) {
+__device__ __forceinline__ void big_store4(const Epi& e, int64_t m, int64_t n, int64_t N, const f32x4& v, float* slab_row, const float* through = nullptr,
+                                           int64_t through_bytes = 0) {
     if (slab_row) {                                               // split-K partial: raw fp32, reduced (with the epilogue) later
+        if (through) {                                            // ... by the last workgroup of this launch: written through (sk_store)
+            const auto rs = sk_rsrc(through, through_bytes);      // `through` = start of the whole slab area
+            const int64_t e = (slab_row + n) - through;
+            if (n + 3 < N && ((uintptr_t)(slab_row + n) & 15) == 0) sk_store4(rs, e, v);
+            else
+                for (int t = 0; t < 4; ++t)
+                    if (n + t < N) sk_store(rs, e + t, v[t]);
+            return;
+        }
         if (n + 3 < N && ((uintptr_t)(slab_row + n) & 15) == 0) *reinterpret_cast<f32x4*>(slab_row + n) = v;
         else
             for (int t = 0; t < 4; ++t)

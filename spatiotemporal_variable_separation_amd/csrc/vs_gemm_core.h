@@ -49,6 +49,10 @@ struct Epi {
     // workgroup -> tile map: 1 = the workgroups of one XCD (b, b + 8, ... under round-robin dispatch) take a contiguous run of the
     // (split, tile row, tile column) order, so an XCD's L2 holds a few A row panels and one K chunk instead of a share of everything
     int xcd_runs;
+    // split-K finished inside the launch (vs_gemm / vs_gemm_batched): every split stores its fp32 slab, bumps its tile's counter and the LAST
+    // workgroup to arrive adds the slabs in split order (bitwise what splitk_reduce_kernel computes), applies the epilogue and clears the counter
+    unsigned* sk_counters; int sk_splits; int64_t sk_bytes;      // sk_bytes: size of the whole slab area (< 2 GiB)
+    int adam_pipe;                       // fused optimizer: state of four row pieces requested ahead (VS_ADAM_PIPE=0: one piece at a time)
 };
 
 // XCD-aware, bijective block -> tile index (blocks b and b + 8 share an XCD under round-robin dispatch: speed only)
@@ -61,6 +65,44 @@ __device__ __forceinline__ Epi epi_for_batch(const Epi& e, int64_t batch) {
     Epi r = e;
     if (batch) r.C = (char*)e.C + batch * e.batch_c * vs_esize(e.c_dtype);
     return r;
+}
+
+// ---- split-K finished inside the launch ---------------------------------------------------------------------------------------
+// No fences: an agent-scope fence is a write-back + invalidate of the XCD's whole L2 (measured in the WaveEq step: the split launches 4x
+// slower and the integrator's XCD-local exchange, which lives in L2, 1.7x).  Instead the slabs are written THROUGH to the fabric (sc1
+// stores = relaxed agent-scope stores), a workgroup waits for its own stores (vmcnt 0), then bumps the tile's counter (relaxed agent-scope
+// atomic), and the last workgroup to arrive reads every slab with sc1 loads, which do not hit in a stale line of its own L2.
+// The slab area of one launch is < 2 GiB (the host falls back to the reduce launch otherwise): one buffer descriptor, 32-bit byte offsets,
+// aux = 16 = sc1 on every access (compiler-tracked loads and stores of 4 and 16 bytes).
+typedef __attribute__((address_space(8))) void* sk_rsrc_t;
+__device__ __forceinline__ auto sk_rsrc(const float* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+template <class R> __device__ __forceinline__ void sk_store(R r, int64_t elem, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(elem * 4), 0, 16);
+}
+template <class R> __device__ __forceinline__ void sk_store4(R r, int64_t elem, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(elem * 4), 0, 16);
+}
+template <class R> __device__ __forceinline__ float sk_load(R r, int64_t elem) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(elem * 4), 0, 16));
+}
+template <class R> __device__ __forceinline__ f32x4 sk_load4(R r, int64_t elem) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(elem * 4), 0, 16));
+}
+// Arrival of one split of output tile `tile_id` (all threads of the workgroup call it after their slab stores): true for the workgroup
+// that arrives last.  `lds_word`: any LDS word nobody reads or writes any more (the kernels' only LDS object is their dynamic tile area).
+__device__ __forceinline__ bool sk_arrive_last(const Epi& e, unsigned tile_id, volatile unsigned* lds_word) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my slab stores have reached the fabric
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicAdd(e.sk_counters + tile_id, 1u);
+        const unsigned last = old == (unsigned)(e.sk_splits - 1);
+        if (last) atomicExch(e.sk_counters + tile_id, 0u);      // everybody has arrived: the counter is ready for the next launch
+        *lds_word = last;
+    }
+    __syncthreads();
+    return *lds_word != 0u;
 }
 
 // row-major form: element (m, n) at C[m*ldc + n], bias per column
@@ -371,11 +413,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(OpA A, OpB B, int64_t M, int6
             for (int v = 0; v < 16; ++v) {
                 const int64_t m = m0 + wm + 32 * i + (v & 3) + 8 * (v >> 2) + rh;
                 if (m >= M) continue;
-                if (slabs) slabs[((int64_t)bz * M + m) * N + n] = acc[i][j][v];
+                if (slabs) {
+                    if (epi_in.sk_counters) sk_store(sk_rsrc(slabs, epi_in.sk_bytes), ((int64_t)bz * M + m) * N + n, acc[i][j][v]);
+                    else slabs[((int64_t)bz * M + m) * N + n] = acc[i][j][v];
+                }
                 else if constexpr (NCHW) epi_store_nchw(epi, m, col_base, acc[i][j][v]);
                 else epi_store(epi, m, n, acc[i][j][v]);
             }
         }
+    if (slabs && epi_in.sk_counters) {
+        const int splits = epi_in.sk_splits;
+        const unsigned pb = (unsigned)(bz / (unsigned)splits);                 // problem of a batched launch (0 otherwise)
+        if (!sk_arrive_last(epi_in, (pb * gridDim.y + by) * gridDim.x + bx, reinterpret_cast<volatile unsigned*>(smem))) return;
+        const int64_t total = M * N;
+        const auto rs = sk_rsrc(slabs, epi_in.sk_bytes);
+        const int64_t first = (int64_t)pb * splits * total;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int64_t n = n0 + wn + 32 * j + cj;
+                if (n >= N) continue;
+                int64_t col_base = 0;
+                if constexpr (NCHW) col_base = nchw_col_base(epi, n);
+#pragma unroll 4
+                for (int v = 0; v < 16; ++v) {
+                    const int64_t m = m0 + wm + 32 * i + (v & 3) + 8 * (v >> 2) + rh;
+                    if (m >= M) continue;
+                    const int64_t q = first + m * N + n;
+                    float sum = 0.f;
+#pragma unroll 4
+                    for (int s = 0; s < splits; ++s) sum += sk_load(rs, q + (int64_t)s * total);        // split order: reproducible
+                    if constexpr (NCHW) epi_store_nchw(epi, m, col_base, sum);
+                    else epi_store(epi, m, n, sum);
+                }
+            }
+    }
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int splits, int64_t M, int64_t N, Epi epi_in) {

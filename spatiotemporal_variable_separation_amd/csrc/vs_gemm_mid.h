@@ -230,6 +230,61 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
         // a block of the parameter's gradient
         if (epi.adam_guard && *epi.adam_guard != 0u) return;          // an exchange of this step timed out: no update (vs_common.h)
         const AdamCoef coef = vs_adam_coef(epi.adam_lr, epi.adam_beta1, epi.adam_beta2, epi.adam_eps, (double)(epi.adam_step[0] + 1 - epi.adam_skipped));
+        // The update is a pure HBM stream (24 B in, 26 B out per parameter) and a lane's 16 row pieces are independent: the state of FOUR
+        // pieces (12 x 16 B per lane) is requested before the previous four are updated and stored, so a wave keeps 12 KiB of reads in
+        // flight instead of 3 (one piece at a time ran the 640 MB launches of the WaveEq encoders at 3.3 TB/s: latency x bytes in flight).
+        // (whole tiles only -- no per-row branch: a branch around a request makes the compiler wait for EVERY outstanding load, vmcnt(0),
+        // at the next use, which serialises the groups again)
+        if (epi.adam_pipe && m0 + 128 <= M && nn + 3 < N && ((epi.ldc | nn) & 3) == 0 &&
+            (((uintptr_t)epi.C | (uintptr_t)epi.adam_m | (uintptr_t)epi.adam_v) & 15) == 0 && (!epi.adam_shadow || ((uintptr_t)epi.adam_shadow & 7) == 0)) {
+            constexpr int G = 4;
+            f32x4 p[2][G], mm[2][G], vv[2][G];
+            const int64_t idx0 = (m0 + wr * 64 + (lane >> 4)) * epi.ldc + nn;           // row piece (g, t) lies (g * G + t) * 4 rows further
+            const int64_t rstep = 4 * epi.ldc;
+            const float* __restrict__ Pp = (const float*)epi.C + idx0;
+            const float* __restrict__ Mp = epi.adam_m + idx0;
+            const float* __restrict__ Vp = epi.adam_v + idx0;
+            const int sdt = epi.adam_shadow_dtype;
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                p[0][t] = *reinterpret_cast<const f32x4*>(Pp + t * rstep);
+                mm[0][t] = *reinterpret_cast<const f32x4*>(Mp + t * rstep);
+                vv[0][t] = *reinterpret_cast<const f32x4*>(Vp + t * rstep);
+            }
+#pragma unroll
+            for (int g = 0; g < 16 / G; ++g) {
+                if (g + 1 < 16 / G) {
+#pragma unroll
+                    for (int t = 0; t < G; ++t) {
+                        const int64_t o = ((g + 1) * G + t) * rstep;
+                        p[(g + 1) & 1][t] = *reinterpret_cast<const f32x4*>(Pp + o);
+                        mm[(g + 1) & 1][t] = *reinterpret_cast<const f32x4*>(Mp + o);
+                        vv[(g + 1) & 1][t] = *reinterpret_cast<const f32x4*>(Vp + o);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < G; ++t) {
+                    const int r = (g * G + t) * 4 + (lane >> 4);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(stg + r * 64 + (lane & 15) * 4);
+                    f32x4 pe = p[g & 1][t], me = mm[g & 1][t], ve = vv[g & 1][t];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = pe[e], b = me[e], c = ve[e];
+                        vs_adam_elem(coef, g4[e] * epi.alpha, a, b, c);
+                        pe[e] = a; me[e] = b; ve[e] = c;
+                    }
+                    const int64_t idx = idx0 + (g * G + t) * rstep;
+                    *reinterpret_cast<f32x4*>((float*)epi.C + idx) = pe;
+                    *reinterpret_cast<f32x4*>(epi.adam_m + idx) = me;
+                    *reinterpret_cast<f32x4*>(epi.adam_v + idx) = ve;
+                    if (epi.adam_shadow) {
+                        const u16x4 h = {vs_f2h(pe[0], sdt), vs_f2h(pe[1], sdt), vs_f2h(pe[2], sdt), vs_f2h(pe[3], sdt)};
+                        *reinterpret_cast<u16x4*>(epi.adam_shadow + idx) = h;
+                    }
+                }
+            }
+            return;
+        }
         for (int it = 0; it < 16; ++it) {
             const int r = it * 4 + (lane >> 4);
             const int64_t m = m0 + wr * 64 + r;
@@ -242,7 +297,31 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
         const int r = it * 4 + (lane >> 4);
         const int64_t m = m0 + wr * 64 + r;
         const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + r * 64 + (lane & 15) * 4);
-        if (m < M && nn < N) big_store4<NCHW>(epi, m, nn, N, v4, slab_base ? slab_base + m * N : nullptr);
+        if (m < M && nn < N) big_store4<NCHW>(epi, m, nn, N, v4, slab_base ? slab_base + m * N : nullptr, epi_in.sk_counters ? slabs : nullptr, epi_in.sk_bytes);
+    }
+    if (slab_base && epi_in.sk_counters) {
+        // split-K finished in the launch: the last workgroup of this tile to arrive adds the slabs (split order) and applies the epilogue
+        const int splits = epi_in.sk_splits;
+        if (!sk_arrive_last(epi_in, (unsigned)batch * gridDim.x + tile, reinterpret_cast<volatile unsigned*>(smem))) return;
+        const int64_t total = M * N;
+        const auto rs = sk_rsrc(slabs, epi_in.sk_bytes);
+        const int64_t first = (int64_t)batch * splits * total;
+        const bool vec = nn + 3 < N && (((uintptr_t)slabs | (uintptr_t)(total * 4)) & 15) == 0 && (N & 3) == 0;
+        for (int it = 0; it < 16; ++it) {
+            const int64_t m = m0 + wr * 64 + it * 4 + (lane >> 4);
+            if (m >= M || nn >= N) continue;
+            const int64_t q = first + m * N + nn;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            if (vec) {
+#pragma unroll 8
+                for (int s = 0; s < splits; ++s) sum += sk_load4(rs, q + (int64_t)s * total);
+            } else {
+                for (int s = 0; s < splits; ++s)
+                    for (int t = 0; t < 4; ++t)
+                        if (nn + t < N) sum[t] += sk_load(rs, q + (int64_t)s * total + t);
+            }
+            big_store4<NCHW>(epi, m, nn, N, sum, nullptr);
+        }
     }
 }
 

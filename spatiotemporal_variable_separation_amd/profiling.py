@@ -37,12 +37,12 @@ GROUPS = [
     ('vs_gemm_adam', r'^vs_gemm_adam<', r'gemm_mid_kernel<\d, \d, \d, \w+, \d+, true>', 'hbm'),
     ('vs_mlp_rollout_fwd', r'^vs_mlp_rollout_fwd<', r'rollout_(ws|fwd)_kernel<\d+, true|rollout_fwd_kernel', 'mfma'),
     ('vs_mlp_rollout_bwd', r'^vs_mlp_rollout_bwd<', r'rollout_ws_kernel<\d+, false|rollout_bwd_kernel', 'mfma'),
-    ('vs_conv_k4s2', r'^vs_conv_k4s2:|^vs_space_to_depth2', r'conv3_band_kernel<\d, \d+, \d+, \d, 1>|conv3_band2_kernel<\d, \d+, \d, 1>|wgrad3_band_kernel<\d, \d+, \d, 1(, \d)?>|space_to_depth2_kernel|'
+    ('vs_conv_k4s2', r'^vs_conv_k4s2:|^vs_space_to_depth2', r'conv3_band_kernel<\d, \d+, \d+, \d, 1>|conv3_band2_kernel<\d, \d+, \d, 1, \d+>|wgrad3_band_kernel<\d, \d+, \d, 1(, \d)?>|wgrad2_band_kernel<\d, \d+, 1>|space_to_depth2_kernel|'
      r'::k4s2_\w+_kernel', 'mfma'),
     ('vs_conv3_img16_bn', r'^vs_conv3_img16_bn:', r'conv3_img16_bn_kernel|exchange_epoch_advance', 'mfma'),
     ('vs_conv3_img16', r'^vs_conv3_img16:', r'conv3_img16_kernel|(?<!grouped_)slab_sum_kernel', 'mfma'),
     ('vs_conv3_band', r'^vs_conv3_band:', r'conv3_band2?_kernel', 'mfma'),
-    ('vs_conv3_wgrad_band', r'^vs_conv3_wgrad_band<', r'wgrad3_band_kernel|wgrad_slab_finish_kernel|slab_sum_grouped_kernel', 'mfma'),
+    ('vs_conv3_wgrad_band', r'^vs_conv3_wgrad_band<', r'wgrad3_band_kernel|wgrad2_band_kernel|wgrad_slab_finish_kernel|slab_sum_grouped_kernel', 'mfma'),
     ('vs_convT_tap', r'^vs_convT_tap:', r'convt_k4s2_tap_kernel', 'mfma'),
     ('vs_conv3_tap', r'^vs_conv3_tap:', r'conv_k3s1_tap_kernel', 'mfma'),
     # dense GEMMs and the convolutions that run as (gather +) GEMM (+ split-K reduce): one pool of GEMM kernels serves them all

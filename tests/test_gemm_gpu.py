@@ -369,3 +369,71 @@ def test_gemm_mid_tile_all_layouts(dtype, la, lb, shape, mode):
     assert err < 2e-6, f'{dtype} layouts ({la},{lb}) shape {shape}: rel err {err:.3e}'
     err16 = ((out16.cpu().double() - ref).norm() / ref.norm()).item()
     assert err16 < (6e-3 if dtype == torch.bfloat16 else 8e-4), f'{dtype} 16-bit output ({la},{lb}) {shape}: {err16:.3e}'
+
+
+SPLITK_SHAPES = [(256, 1200, 20480), (256, 1200, 1200), (256, 32, 1200), (1200, 1200, 3328), (64, 1200, 3328), (128, 96, 20480), (3328, 32, 1200),
+                 (100, 70, 4104)]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('la,lb', [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize('shape', SPLITK_SHAPES)
+def test_splitk_finished_in_launch_is_bit_equal(dtype, la, lb, shape):
+    """Split-K finished by the last workgroup of a tile (arrival counters, slabs added in split order) == the slab-reduce launch, bit for bit,
+    with the whole epilogue (bias, activation, 16-bit output), and the counters come back to zero (40 launches back to back)."""
+    import os
+    from spatiotemporal_variable_separation_amd import ops
+    from oracle.detdata import det_uniform
+    M, N, K = shape
+    _, a = _operand(M, K, la, dtype, 23)
+    _, b = _operand(N, K, lb, dtype, 29)
+    bias = ((det_uniform((N,), 31) - 0.5) * 0.5).cuda()
+    os.environ['VS_GEMM_SPLITK_FUSED'] = '0'
+    try:
+        ref = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='leaky_relu')
+        ref16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=torch.bfloat16)
+    finally:
+        del os.environ['VS_GEMM_SPLITK_FUSED']
+    for mode in ('1', '2'):                    # 1: the default (small tiles x few splits only), 2: every split launch
+        os.environ['VS_GEMM_SPLITK_FUSED'] = mode
+        try:
+            for _ in range(10):
+                out = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='leaky_relu')
+                out16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=torch.bfloat16)
+        finally:
+            del os.environ['VS_GEMM_SPLITK_FUSED']
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref) and torch.equal(out16, ref16), mode
+
+
+def test_splitk_finished_in_launch_batched_and_concurrent():
+    """Batched split launches (the integrator's weight gradients) and two split launches in flight on two streams at once."""
+    import os
+    from spatiotemporal_variable_separation_amd import ops
+    nb, M, N, K = 6, 512, 64, 2304
+    _, a = _operand(nb * M, K, 0, torch.bfloat16, 37)
+    _, b = _operand(nb * N, K, 0, torch.bfloat16, 41)
+    a3, b3 = a.view(nb, M, K), b.view(nb, N, K)
+    os.environ['VS_GEMM_SPLITK_FUSED'] = '0'
+    try:
+        ref = ops.gemm_batched(a3, 0, b3, 0, M, N, K)
+    finally:
+        del os.environ['VS_GEMM_SPLITK_FUSED']
+    os.environ['VS_GEMM_SPLITK_FUSED'] = '2'
+    try:
+        out = ops.gemm_batched(a3, 0, b3, 0, M, N, K)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        _, x = _operand(256, 20480, 0, torch.bfloat16, 43)
+        _, w = _operand(1200, 20480, 0, torch.bfloat16, 47)
+        one = ops.gemm(x, 0, w, 0, 256, 1200, 20480)
+        torch.cuda.synchronize()
+        outs = []
+        for i in range(8):
+            with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+                outs.append(ops.gemm(x, 0, w, 0, 256, 1200, 20480))
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, one) for o in outs)
+    finally:
+        del os.environ['VS_GEMM_SPLITK_FUSED']
