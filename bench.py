@@ -269,8 +269,11 @@ def _run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=
     # conv families: the decoder's gradients (complete first in backward) in leading buckets of their own -- the recorded step is split
     # there and their all-reduce travels beside the integrator's / encoders' backward kernels (train.GraphedStep.segmented)
     early = None if _is_mlp(net) else list(net.decoder.parameters())
+    from spatiotemporal_variable_separation_amd.train import rollout_weight_stacks, shard_optimizer_default
+    use_graph_planned = (not args.no_graph) and os.environ.get('VARSEP_BENCH_GRAPH_ALL', '1') == '1'
+    shard = bool(direct) and use_graph_planned and precision == 'bf16' and shard_optimizer_default()
     sync = GradAllReducer(net.parameters(), force=(rk.world == 1), comm_dtype=torch.bfloat16 if comm_bf16 else torch.float32,
-                          lowp_direct=direct, early=early) if rk.ddp else None
+                          lowp_direct=direct, early=early, shard_direct=shard, stacked=rollout_weight_stacks(net)) if rk.ddp else None
     use_graph = (not args.no_graph) and os.environ.get('VARSEP_BENCH_GRAPH_ALL', '1') == '1'
     opt = Adam(net.parameters(), lr=4e-4, betas=(0.9, 0.99))
     cond, target = synthetic_batch(cfg['data'], cfg['batch'], cfg['nt_cond'], cfg['nt_pred'], device=dev, seed=1234 + rk.rank)

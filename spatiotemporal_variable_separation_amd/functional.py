@@ -619,6 +619,14 @@ def shadow(p, dtype):
     return ent[1]
 
 
+def adopt_shadow(p, buf):
+    """Make `buf` (a 16-bit tensor of p's shape, e.g. a view into the sharded optimizer's arena: parallel.GradAllReducer) THE operand copy
+    of `p`: filled from the current fp32 value now, rewritten in place by the optimizer launches and the arena's all-gather afterwards."""
+    assert buf.shape == p.shape and buf.dtype in (torch.bfloat16, torch.float16) and buf.is_contiguous()
+    ops.cast(p.detach(), buf.dtype, out=buf)
+    _shadow[id(p)] = (_ver(p), buf, _wref(_shadow, id(p), p))
+
+
 def shadow_buffer_for_update(p):
     """The live bf16 operand copy of `p`, if one exists: the optimizer kernel rewrites it in the pass that updates `p`."""
     ent = _shadow.get(id(p))
@@ -857,6 +865,23 @@ def prepack_weights(requests, dtype):
             _packed[key] = (_ver(p), buf, _wref(_packed, key, p))
 
 
+def _stacked_grad_outputs(params, nb):
+    """([nb, H, C], [nb, H, H], [nb, C, H] fp32 views over the registered gradient destinations of the integrator's weights, [bias views in
+    (block, layer) order]) when every parameter has a destination and the blocks' weights of each layer lie back to back; None otherwise."""
+    outs = [grad_output(p) for p in params]
+    if any(o is None or o.dtype != torch.float32 for o in outs):
+        return None
+    stacks = []
+    for l in range(3):
+        ws = [outs[6 * b + 2 * l] for b in range(nb)]
+        n = ws[0].numel()
+        if any(w.data_ptr() != ws[0].data_ptr() + 4 * n * b or w.shape != ws[0].shape for b, w in enumerate(ws)):
+            return None
+        stacks.append(ws[0].as_strided((nb,) + tuple(ws[0].shape), (n,) + tuple(ws[0].stride())))
+    bias = [outs[6 * b + 2 * l + 1] for b in range(nb) for l in range(3)]
+    return stacks[0], stacks[1], stacks[2], bias
+
+
 class MLPRollout(torch.autograd.Function):
     """All n-1 integrator steps x n_blocks residual MLP blocks in one persistent kernel per direction.
 
@@ -928,6 +953,17 @@ class MLPRollout(torch.autograd.Function):
                 grads += [dW1[b], dbs[3 * b], dW2[b], dbs[3 * b + 1], dW3[b], dbs[3 * b + 2]]
             return grads
         if _GRAD_OUT:
+            stacked = _stacked_grad_outputs(params, nb)
+            if stacked is not None:
+                # the reducer laid the blocks' weights of one layer back to back (GradAllReducer(stacked=...)) and zeroes the bucket's tail at
+                # the start of the step: the three batched launches write [blocks, ., .] IN the bucket, the bias sums add into their views --
+                # autograd is handed nothing (no 18 `+=` launches of 4 us each at the end of backward: 86 us of the WaveEq step under a reducer)
+                w1, w2, w3, bias_out = stacked
+                if _SIDE['on'] and os.environ.get('VARSEP_ROLLOUT_WGRAD_LATE', '1') == '1':
+                    run_late(lambda: weight_grads(w1, w2, w3, bias_out, None), dr, dh2, dh1, xin, h1, h2, outs=(w1, w2, w3), lane=next_lane())
+                else:
+                    weight_grads(w1, w2, w3, bias_out, None)
+                return (dx0, None) + (None,) * len(params)
             # with gradient destinations registered these gradients still go through autograd's `+=` into the bucket views, which
             # runs on THIS node's stream: compute them here, not on a gradient stream
             grads = weight_grads()

@@ -124,10 +124,14 @@ def main(argv=None):
     if world > 1:
         broadcast_module_state(sep_net)
         lowp = getattr(args, 'grad_comm', 'fp32') == 'bf16'
-        from .train import _mlp_family, chain_weight_parameters
+        from .train import _mlp_family, chain_weight_parameters, rollout_weight_stacks, shard_optimizer_default
+        direct = chain_weight_parameters(sep_net) if (lowp and not getattr(args, 'no_hip_graph', False)) else None
+        # MLP family, bf16 wire, recorded step: reduce-scatter + Adam on this rank's slice + all-gather of the operand copies
+        # (parallel.GradAllReducer, "Sharded optimizer"); GraphedStep falls back to the all-reduce when the precision mode does not allow it
         grad_sync = GradAllReducer(sep_net.parameters(), comm_dtype=torch.bfloat16 if lowp else torch.float32,
                                    early=None if _mlp_family(sep_net) else list(decoder.parameters()),
-                                   lowp_direct=chain_weight_parameters(sep_net) if (lowp and not getattr(args, 'no_hip_graph', False)) else None)
+                                   lowp_direct=direct, shard_direct=bool(direct) and shard_optimizer_default(),
+                                   stacked=rollout_weight_stacks(sep_net))
 
     # same constructor call as the reference (main.py:133); the update runs as one multi-tensor HIP launch (optim.py)
     from .optim import Adam

@@ -214,6 +214,55 @@ class Adam(torch.optim.Optimizer):
                 self._update(gi, group, live)
 
     @torch.no_grad()
+    def step_ranges(self, ranges):
+        """The Adam update of ELEMENT RANGES [(parameter, lo, hi)] -- this rank's slice of the parameters under a sharded optimizer
+        (parallel.GradAllReducer(shard_direct=True)): fp32 master, both moments and the 16-bit operand copy of elements lo..hi-1, gradient
+        from the bf16 wire image (functional.lowp_gradient).  Same kernel and arithmetic as step_subset; the step counter is not advanced
+        (finish_step).  lo / hi are multiples of 8 (16-byte vector accesses on every operand)."""
+        from . import functional as VF
+        lib = _lib.load_library()
+        if not ranges:
+            return
+        group = self.param_groups[0]
+        self._init_group(0, group)
+        stream = torch.cuda.current_stream(ranges[0][0].device).cuda_stream
+        lr, (b1, b2), eps = group['lr'], group['betas'], group['eps']
+        written = []
+        for i in range(0, len(ranges), 64):
+            chunk = ranges[i:i + 64]
+            n = len(chunk)
+            P, G, M_, V, S, NUM, SK, GD = [], [], [], [], [], [], [], []
+            sdt = _lib.BF16
+            for p, lo, hi in chunk:
+                g = VF.lowp_gradient(p)
+                if g is None:
+                    g = p.grad
+                if g is None or not (0 <= lo < hi <= p.numel()):
+                    raise VarsepHipError('step_ranges: a range needs a gradient and 0 <= lo < hi <= numel')
+                st = self.state[p]
+                sh = VF.shadow_buffer_for_update(p)
+                P.append(p.data_ptr() + 4 * lo); M_.append(st['exp_avg'].data_ptr() + 4 * lo); V.append(st['exp_avg_sq'].data_ptr() + 4 * lo)
+                G.append(g.data_ptr() + g.element_size() * lo)
+                GD.append(_lib.BF16 if g.dtype == torch.bfloat16 else _lib.F32)
+                S.append(None if sh is None else sh.data_ptr() + 2 * lo)
+                if sh is not None:
+                    sdt = _lib.code_of(sh.dtype)
+                    written.append(p)
+                NUM.append(hi - lo); SK.append(st.get('skipped', 0))
+            VP, I64, I32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+            tab = (VP(*P), VP(*G), VP(*M_), VP(*V), VP(*S), I64(*NUM), I32(*SK), I32(*GD))
+            self._tables[('ranges', id(chunk[0][0]), chunk[0][1], n)] = (None, tab)          # keep the tables alive (recorded launches copy them at launch)
+            rc = lib.vs_adam_multi_scaled(n, ctypes.cast(tab[0], ctypes.c_void_p), ctypes.cast(tab[1], ctypes.c_void_p),
+                                          ctypes.cast(tab[7], ctypes.c_void_p), ctypes.cast(tab[2], ctypes.c_void_p),
+                                          ctypes.cast(tab[3], ctypes.c_void_p), ctypes.cast(tab[4], ctypes.c_void_p), sdt,
+                                          ctypes.cast(tab[5], ctypes.c_void_p), ctypes.cast(tab[6], ctypes.c_void_p),
+                                          group['step_dev'].data_ptr(), lr, b1, b2, eps, None, stream)
+            _lib.check(rc, 'vs_adam_multi (ranges)')
+        for p in {id(p): p for p, _, _ in ranges}.values():
+            torch.autograd.graph.increment_version(p)
+        VF.shadows_written(written)
+
+    @torch.no_grad()
     def finish_step(self):
         lib = _lib.load_library()
         for gi, group in enumerate(self.param_groups):

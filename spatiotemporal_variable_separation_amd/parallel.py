@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 class GradAllReducer:
     def __init__(self, params, bucket_bytes=64 << 20, process_group=None, overlap=True, force=False, comm_dtype=torch.float32,
-                 lowp_direct=None, early=None):
+                 lowp_direct=None, early=None, shard_direct=False, stacked=None, shard_tail_dtype=torch.float32):
         self.params = [p for p in params if p.requires_grad]
         # `early`: parameters whose gradients are complete long before the end of backward (the decoder's: it is the first thing backward
         # finishes).  They get leading buckets of their own (`early_buckets`), so that their all-reduce can start -- from the hook of the last
@@ -45,6 +45,20 @@ class GradAllReducer:
         self.lowp_views = {}          # id(param) -> bf16 view of the wire buffer
         self._tail = {}               # flat.data_ptr() -> first element of the not-direct region
         self.direct_lowp = False
+        # shard_direct (bf16 wire + lowp_direct, recorded step only -- train.GraphedStep): the direct parameters' gradients are
+        # REDUCE-SCATTERED instead of all-reduced, every rank runs Adam on ITS 1/N slice of their fp32 masters / moments and rewrites its slice
+        # of their 16-bit operand copies, which live in one flat arena per bucket and are ALL-GATHERED afterwards (see "Sharded optimizer"
+        # below).  Wire bytes as the all-reduce (RS + AG of 2 B per parameter), optimizer traffic and time 1/N of the replicated update.
+        self.shard = bool(shard_direct) and bool(self._direct_ids)
+        # the small tail (biases, integrator) of a sharded bucket is summed in fp32 by default; torch.bfloat16 rounds it before and after
+        # the sum like the replicated bf16-wire path does -- then the sharded step is BIT-identical to the replicated one (the GPU tests use it)
+        self.shard_tail_dtype = shard_tail_dtype
+        self.masters_dirty = False       # fp32 masters / moments of the direct parameters are current in the own slice only
+        self._head = {}                  # bucket index -> (padded head length, [(param, offset)])
+        self._arena = {}                 # bucket index -> flat 16-bit arena of the direct parameters' operand copies
+        # stacked: lists of same-shaped parameters whose gradients must lie back to back in a bucket, in the given order, so that ONE batched
+        # launch can write all of them (the integrator's per-layer weights: functional.MLPRollout.backward writes [blocks, H, C] in place)
+        self._stacked = [list(g) for g in (stacked or [])]
         self._build(bucket_bytes)
         self._comm_stream = None
         self._held = set()               # buckets that hooks must not launch (hold_params)
@@ -69,19 +83,42 @@ class GradAllReducer:
     def _finish_bucket(self, plist, early=False):
         if early:
             self.early_buckets.append(len(self.buckets))
-        plist = [p for p in plist if id(p) in self._direct_ids] + [p for p in plist if id(p) not in self._direct_ids]
-        total = sum(p.numel() for p in plist)
+        direct = [p for p in plist if id(p) in self._direct_ids]
+        rest = [p for p in plist if id(p) not in self._direct_ids]
+        # stacked groups whose members are all in this bucket: moved to the front of the not-direct region, members adjacent and in order
+        in_rest = {id(p) for p in rest}
+        front = []
+        for g in self._stacked:
+            if g and all(id(p) in in_rest for p in g):
+                front += g
+        taken = {id(p) for p in front}
+        rest = front + [p for p in rest if id(p) not in taken]
+        plist = direct + rest
+        # the direct (head) region is padded so that it splits into world_size slices of whole 128-byte lines (reduce-scatter / all-gather)
+        head = sum(p.numel() for p in direct)
+        if self.shard and head:
+            q = self.world_size * 64
+            head = (head + q - 1) // q * q
+        total = head + sum(p.numel() for p in rest) if (self.shard and direct) else sum(p.numel() for p in plist)
         flat = torch.zeros(total, dtype=torch.float32, device=plist[0].device)
         wire = torch.zeros(total, dtype=self.comm_dtype, device=plist[0].device) if self._direct_ids else None
         off = 0
         self._tail[flat.data_ptr()] = total
+        heads = []
         for p in plist:
+            if id(p) not in self._direct_ids and self._tail[flat.data_ptr()] == total:
+                if self.shard and direct:
+                    off = head
+                self._tail[flat.data_ptr()] = off
             p.grad = flat[off:off + p.numel()].view_as(p)
             if id(p) in self._direct_ids:
                 self.lowp_views[id(p)] = wire[off:off + p.numel()].view_as(p)
-            elif self._tail[flat.data_ptr()] == total:
-                self._tail[flat.data_ptr()] = off
+                heads.append((p, off))
             off += p.numel()
+        if self.shard and direct:
+            if self._tail[flat.data_ptr()] == total:
+                self._tail[flat.data_ptr()] = head if rest else total
+            self._head[len(self.buckets)] = (head, heads)
         if wire is not None:
             self._wire[flat.data_ptr()] = wire
         self.buckets.append((flat, list(plist)))
@@ -153,6 +190,8 @@ class GradAllReducer:
 
     def _reduce(self, flat):
         self._reduce_guard(flat.device)
+        if self.shard and self.direct_lowp:
+            return self._reduce_sharded(flat)
         if self.comm_dtype != torch.float32:
             wire = self._wire.get(flat.data_ptr())
             if wire is None:
@@ -225,6 +264,134 @@ class GradAllReducer:
         ev = torch.cuda.Event()
         ev.record(self._comm_stream)
         return ev
+
+    # ---- Sharded optimizer (MLP family, bf16 wire, recorded step) -----------------------------------------------------------------
+    # No reference counterpart (the reference is single-GPU).  Per bucket and step:
+    #   backward     : the chains' weight-gradient GEMMs round their result once into the bf16 wire buffer (head region, as before); the loss
+    #                  gradient is seeded with 1 / world_size (train.GraphedStep), so SUMS over ranks are averages -- no AVG pre-multiply pass
+    #   reduce-scatter (SUM, in place): rank r receives the summed slice r of the head; the small tail (biases, integrator) is all-reduced
+    #   Adam         : optim.Adam.step_ranges on the element ranges of the direct parameters inside slice r (fp32 master, exp_avg, exp_avg_sq:
+    #                  1/N of the replicated update's 26 B per parameter) + the replicated update of the tail
+    #   all-gather   : the 16-bit operand copies (what forward / backward read) live in one arena per bucket; every rank contributes slice r
+    # fp32 masters and moments of the direct parameters are current in the OWN slice only (`masters_dirty`): `sync_masters()` before anything
+    # reads them (checkpoint, an eager step, evaluation in fp32).
+    def _slice(self, bi):
+        head, _ = self._head[bi]
+        n = head // self.world_size
+        return self.rank * n, (self.rank + 1) * n
+
+    def _reduce_sharded(self, flat):
+        bi = next(i for i, (f, _) in enumerate(self.buckets) if f.data_ptr() == flat.data_ptr())
+        wire = self._wire[flat.data_ptr()]
+        t0 = self._tail.get(flat.data_ptr(), flat.numel())
+        head = self._head.get(bi, (0, []))[0]
+        if head:
+            lo, hi = self._slice(bi)
+            if self.backend == 'nccl':
+                dist.reduce_scatter_tensor(wire[lo:hi], wire[:head], op=dist.ReduceOp.SUM, group=self.group)      # in place
+            else:                                          # gloo (tests): no reduce-scatter / bf16 arithmetic there
+                host = wire[:head].float().cpu()
+                if self.world_size > 1:
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                mine = host[lo:hi].to(self.comm_dtype)
+                wire[:head].fill_(float('nan'))            # what a reduce-scatter leaves elsewhere is undefined: nobody may read it
+                wire[lo:hi].copy_(mine)
+        if t0 < flat.numel():                              # tail: small fp32 gradients, summed in fp32 (seeded with 1 / world_size)
+            tail = flat[t0:]
+            lowp = self.shard_tail_dtype != torch.float32
+            if lowp:
+                tail.copy_(tail.to(self.shard_tail_dtype).float())
+            if self.backend == 'nccl':
+                dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+            elif self.world_size > 1:
+                host = tail.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                tail.copy_(host)
+            if lowp:
+                tail.copy_(tail.to(self.shard_tail_dtype).float())
+
+    def shard_ranges(self, bi):
+        """[(parameter, lo, hi)]: the element ranges of bucket `bi`'s direct parameters that lie in this rank's slice."""
+        if bi not in self._head:
+            return []
+        lo, hi = self._slice(bi)
+        out = []
+        for p, off in self._head[bi][1]:
+            a, b = max(lo, off), min(hi, off + p.numel())
+            if a < b:
+                out.append((p, a - off, b - off))
+        return out
+
+    def tail_params(self, bi):
+        return [p for p in self.buckets[bi][1] if id(p) not in self._direct_ids]
+
+    def adopt_operand_copies(self, dtype, register=None):
+        """Move the direct parameters' 16-bit operand copies into one flat arena per bucket (same layout as the head of the wire buffer).
+        `register(parameter, view)`: what makes the view THE operand copy (default functional.adopt_shadow; the CPU tests pass their own)."""
+        if register is None:
+            from . import functional as VF
+            register = VF.adopt_shadow
+        for bi, (head, heads) in self._head.items():
+            arena = self._arena.get(bi)
+            if arena is None or arena.dtype != dtype:
+                arena = self._arena[bi] = torch.zeros(head, dtype=dtype, device=heads[0][0].device)
+            for p, off in heads:
+                register(p, arena[off:off + p.numel()].view_as(p))
+
+    def gather_operand_copies(self, bi):
+        """All-gather the arena of bucket `bi` on the comm stream, behind the current stream (the Adam launch that wrote this rank's slice)."""
+        arena = self._arena.get(bi)
+        if arena is None:
+            return
+        lo, hi = self._slice(bi)
+        if arena.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=arena.device)
+            self._comm_stream.wait_stream(torch.cuda.current_stream(arena.device))
+            ctx = torch.cuda.stream(self._comm_stream)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            if self.backend == 'nccl':
+                dist.all_gather_into_tensor(arena, arena[lo:hi], group=self.group)                  # in place
+            elif self.world_size > 1:
+                mine = arena[lo:hi].view(torch.int32).cpu()          # (gloo moves no 16-bit types; a slice is a whole number of 128-byte lines)
+                parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+                dist.all_gather(parts, mine, group=self.group)
+                arena.view(torch.int32).copy_(torch.cat(parts))
+
+    def wait_comm(self):
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def sync_masters(self, optimizer):
+        """Every rank receives the other ranks' slices of the direct parameters' fp32 masters and Adam moments (checkpoint, eager step)."""
+        if not self.shard or not self.masters_dirty:
+            return
+        self.wait_comm()
+        for bi, (head, heads) in self._head.items():
+            lo, hi = self._slice(bi)
+            tensors = [[p.data for p, _ in heads]]
+            for key in ('exp_avg', 'exp_avg_sq'):
+                if all(key in optimizer.state.get(p, {}) for p, _ in heads):
+                    tensors.append([optimizer.state[p][key] for p, _ in heads])
+            for group in tensors:
+                full = torch.zeros(head, dtype=torch.float32, device=heads[0][0].device)
+                for (p, off), t in zip(heads, group):
+                    a, b = max(lo, off), min(hi, off + p.numel())
+                    if a < b:
+                        full[a:b] = t.reshape(-1)[a - off:b - off]
+                if self.world_size > 1:
+                    if self.backend == 'nccl':
+                        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+                    else:
+                        host = full.cpu()
+                        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                        full.copy_(host)
+                    for (p, off), t in zip(heads, group):
+                        t.reshape(-1).copy_(full[off:off + p.numel()])
+        self.masters_dirty = False
 
     def payload_bytes(self):
         return sum(flat.numel() * 4 for flat, _ in self.buckets)

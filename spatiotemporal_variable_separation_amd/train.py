@@ -250,6 +250,17 @@ class GraphedStep:
             from . import functional as VF
             grad_sync.direct_lowp = True
             VF.set_lowp_gradients({p: grad_sync.lowp_views[id(p)] for p in grad_sync.params if id(p) in grad_sync.lowp_views})
+        # sharded optimizer (parallel.GradAllReducer(shard_direct=True)): reduce-scatter of the chains' bf16 wire gradients, Adam on this rank's
+        # slice, all-gather of the 16-bit operand copies.  Needs the wire shortcut above, a 16-bit compute type (the copies ARE the weights
+        # forward / backward read) and no loss scaling; sums instead of averages: the loss gradient is seeded with 1 / world_size
+        from . import functional as VF
+        self.sharded = bool(grad_sync is not None and getattr(grad_sync, 'shard', False) and getattr(grad_sync, 'direct_lowp', False)
+                            and scaler is None and hasattr(optimizer, 'step_ranges') and VF.compute_dtype() != torch.float32)
+        if grad_sync is not None and getattr(grad_sync, 'shard', False) and not self.sharded:
+            grad_sync.shard = False                  # (fp32 / fp16-with-scaler / foreign optimizer: the all-reduce path)
+        if self.sharded:
+            grad_sync.adopt_operand_copies(VF.compute_dtype())
+            self._one = torch.full((), 1.0 / grad_sync.world_size, dtype=torch.float32, device=cond.device)
         enable_fused_update(optimizer, sep_net, grad_sync, scaler)
         enable_update_in_backward(optimizer, sep_net, grad_sync, scaler=scaler)
         self.args = (nt_cond, nt_pred, offset) + tuple(lambdas) + (average_tloss,)
@@ -283,6 +294,8 @@ class GraphedStep:
         from .optim import Adam as HipAdam
         self.steps_replayed = 0                      # (train() checks the exchange error word after each of a recording's first replays)
         params = list(self.net.parameters())
+        if getattr(self, 'sharded', False):
+            self.sync.sync_masters(self.opt)         # the operand copies are re-derived from the fp32 masters below: they must be complete
         if isinstance(self.opt, HipAdam):
             # restoring the warm-up snapshot bumped every parameter's version counter (and, for a re-recording after a learning-rate
             # change, the replays since the last recording moved the replay epoch): bring the 16-bit operand copies up to date NOW, or
@@ -333,13 +346,19 @@ class GraphedStep:
             finally:
                 VF.bn_counts_flushed_in_capture(False)
             self._reduce()
-            if self.scaler is None and hasattr(self.opt, 'step_subset') and os.environ.get('VARSEP_ADAM_PER_BUCKET', '1') == '1':
+            if self.sharded or (self.scaler is None and hasattr(self.opt, 'step_subset') and os.environ.get('VARSEP_ADAM_PER_BUCKET', '1') == '1'):
                 # one Adam recording per all-reduce bucket: the update of bucket i runs while buckets i+1.. are still on the wire
                 self.graph_opt = []
-                for _, plist in grad_sync.buckets:
+                for bi, (_, plist) in enumerate(grad_sync.buckets):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
-                        self.opt.step_subset(plist)
+                        if self.sharded:
+                            self.opt.step_ranges(grad_sync.shard_ranges(bi))       # this rank's slice of the chains' weights
+                            tail = grad_sync.tail_params(bi)
+                            if tail:
+                                self.opt.step_subset(tail)                         # biases, integrator: replicated
+                        else:
+                            self.opt.step_subset(plist)
                     self.graph_opt.append(g)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
@@ -353,6 +372,18 @@ class GraphedStep:
     def _opt_step(self):
         from . import functional as VF
         pending, self._pending_join = getattr(self, '_pending_join', None), None
+        if getattr(self, 'sharded', False):
+            # (warm-up steps: the recorded form is one graph per bucket, see _capture)
+            for bi in range(len(self.sync.buckets)):
+                self.opt.step_ranges(self.sync.shard_ranges(bi))
+                tail = self.sync.tail_params(bi)
+                if tail:
+                    self.opt.step_subset(tail)
+                self.sync.gather_operand_copies(bi)
+            self.opt.finish_step()
+            self.sync.wait_comm()
+            self.sync.masters_dirty = True
+            return
         if self.scaler is not None:
             self.scaler.step(self.opt)               # finite check, unscale inside the update, skip on overflow, scale update
         elif pending:
@@ -459,11 +490,16 @@ class GraphedStep:
         if isinstance(self.graph_opt, list):
             events = [early[bi] if bi in early else self.sync.reduce_bucket(bi) for bi in range(len(self.sync.buckets))]
             main = torch.cuda.current_stream()
-            for ev, g in zip(events, self.graph_opt):
+            for bi, (ev, g) in enumerate(zip(events, self.graph_opt)):
                 if ev is not None:
                     main.wait_event(ev)
                 g.replay()
+                if self.sharded:
+                    self.sync.gather_operand_copies(bi)  # comm stream, beside the next bucket's update
             self.graph_opt[-1].replay()              # step counter
+            if self.sharded:
+                self.sync.wait_comm()                    # the next step's forward reads the gathered copies
+                self.sync.masters_dirty = True
         elif self.graph_opt is not None:
             for bi in range(len(self.sync.buckets)):
                 if bi not in early:
@@ -550,6 +586,22 @@ def chain_weight_parameters(sep_net):
         if mlp is not None:
             out += [lin.weight for lin in mlp.linears()]
     return out
+
+
+def rollout_weight_stacks(sep_net):
+    """[[W1 of every block], [W2 ...], [W3 ...]] of an MLP-family integrator: the groups GradAllReducer(stacked=...) lays back to back so
+    that functional.MLPRollout.backward writes each layer's batched weight gradient straight into the bucket."""
+    if not _mlp_family(sep_net):
+        return []
+    per_block = [[lin.weight for lin in blk.mlp.linears()] for blk in sep_net.t_resnet.blocks]
+    if not per_block or any(len(ws) != 3 for ws in per_block):
+        return []
+    return [[ws[l] for ws in per_block] for l in range(3)]
+
+
+def shard_optimizer_default():
+    """VARSEP_SHARD_OPT (default 1): MLP family under a bf16-wire reducer -> reduce-scatter + sharded Adam + all-gather of the operand copies."""
+    return os.environ.get('VARSEP_SHARD_OPT', '1') == '1'
 
 
 def enable_update_in_backward(optimizer, sep_net, grad_sync=None, force=False, scaler=None):
@@ -922,6 +974,8 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
             err = int(recover_exchange(device, grad_sync=grad_sync if collective else None))        # (a time-out cannot have reached the parameters: the guard word made the optimizer skip)
             if err:
                 graphed = None                         # the exchange mode is baked into a recording
+        if grad_sync is not None and collective and getattr(grad_sync, 'masters_dirty', False):
+            grad_sync.sync_masters(optimizer)          # sharded optimizer: every rank's slice of the fp32 masters / moments to every rank
         if grad_sync is not None and world > 1 and collective:
             import torch.distributed as dist
             from .parallel import broadcast_buffers
@@ -961,6 +1015,8 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                 # gradients of THIS step go through autograd into the fp32 buckets: switch the wire shortcut off for its duration,
                 # or the reducer would skip them and Adam would read the previous step's bf16 images
                 lowp_saved = None
+                if grad_sync is not None and getattr(grad_sync, 'masters_dirty', False):
+                    grad_sync.sync_masters(optimizer)    # the eager step below is the replicated update: it needs complete masters / moments
                 if grad_sync is not None and getattr(grad_sync, 'direct_lowp', False):
                     lowp_saved = dict(VF._LOWP_GRAD)
                     grad_sync.direct_lowp = False
