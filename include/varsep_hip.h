@@ -364,6 +364,20 @@ int vs_train_losses_fwd_grad(const float* frames, const float* full, const int32
                              const float* grad_total, float* ds_old, float* ds_new, float* dt0, int frames_act, void* dz, int dz_dtype,
                              void* stream);
 
+/* The decoder's last Linear layer with the frame losses in its epilogue -- replaces, in the recorded MLP-family step, the pair
+ * [last vs_gemm of MLPDecoder.forward (networks/mlp_encdec.py:43-50) ; vs_train_losses_fwd_grad (train.py:85-86, 117-149)]:
+ *   frames[r = (b, g), :] = act(A[r, :] W^T + bias) is compared with full[b, target(g), :] while in registers and never stored;
+ *   dz [M, N] (dz_dtype) = grad_total * k_g * (frames - target) * act'(frames), ds_old / ds_new / dt0 and out[0..8] as
+ *   vs_train_losses_fwd_grad (out holds 16 + 2 * 4096 floats; the frame sums are added from one pair per workgroup, in order).
+ * A [M = B * G, K] and W [N, K] 16-bit row-major (K contiguous), bias fp32 [N] or NULL, N % 4 == 0, target frames resolved on the
+ * device from t_random_dev (frame 0 <-> t - ae_shift, frame g <-> first_forecast + g - 1).  VS_ERR_UNSUPPORTED when the problem does
+ * not run on the 256 x 256 tile kernel: store the frames with vs_gemm and call vs_train_losses_fwd_grad.                          */
+int vs_gemm_frame_loss(int compute, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
+                       const float* bias, int act, const float* full, const int32_t* t_random_dev, int ae_shift, int first_forecast,
+                       int G, int T, const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
+                       int average_tloss, const float* lambdas, const float* grad_total, void* dz, int dz_dtype, float* ds_old,
+                       float* ds_new, float* dt0, float* out, void* stream);
+
 /* Adam update of up to 64 fp32 tensors in one launch (reference: train.py:156-158 `optimizer.step()` on
  * torch.optim.Adam(lr, betas): weight_decay 0, amsgrad off; same operation order as torch's single-tensor path:
  *   m += (1-b1)(g-m); v = b2 v + (1-b2) g g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = step[0] + 1).

@@ -126,6 +126,8 @@ SIGNATURES = {
     'vs_train_losses_fwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     'vs_train_losses_fwd_grad': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp,
                                         _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
+    'vs_gemm_frame_loss': (_i32, [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i64,
+                                  _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'vs_train_losses_bwd': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _i32, _vp, _i32, _vp]),
     'vs_convt_tap_supported': (_i32, [_i32] * 7),

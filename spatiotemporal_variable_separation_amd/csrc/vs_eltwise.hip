@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void frames_sse_bwd_kernel(const float* frames
 
 }  // namespace
 
+#include "vs_loss.h"
 // ---- all four training losses in one pass (train.py:117-149) -------------------------------------------------------------
 //   total = l_ae * mse(frame 0) + l_s * mean((s_old - s_new)^2) + l_pred * mse(frames 1..) + l_t * t_reg
 //   t_reg = 0.5 * mean_b sum_c t0^2   (average_tloss: 0.5 * mean_{b,c} t0^2)
@@ -256,38 +257,11 @@ __global__ __launch_bounds__(256) void frames_sse_bwd_kernel(const float* frames
 // otherwise MFMA/HBM work.  Forward: a zero fill, ONE pass (frame rows walked by all workgroups, the two small code terms by
 // workgroup 0) and a 1-thread launch assembling the scalars; backward: ONE kernel writing every gradient.
 namespace {
-struct LossArgs {
-    const float* frames; const float* full; const int* idx;
-    const int* t_dev; int ae_shift, first_forecast;           // idx == NULL: frame 0 <-> full[:, t_dev[0] - ae_shift], frame g <-> first_forecast + g - 1
-    int64_t rows, D; int G, T;
-    const float* s_old; const float* s_new; int64_t n_s;      // spatial codes (n_s = 0: no spatial term)
-    const float* t0; int64_t Bt, Ct;                           // initial temporal code [Bt, Ct]
-    float l_ae, l_s, l_pred, l_t;
-    float inv_ae, inv_pred, inv_s, inv_t;                      // 1/N of each mean
-};
-
-__device__ __forceinline__ int loss_target_frame(const LossArgs& a, int g) {
-    if (a.idx) return a.idx[g];
-    return g == 0 ? a.t_dev[0] - a.ae_shift : a.first_forecast + g - 1;
-}
-
-__device__ __forceinline__ float block_sum_256(float v, float* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-}
-
 // out: [0..3] raw sums (SSE frame 0, SSE frames 1.., sum (s_old - s_new)^2, sum t0^2), [4] total, [5] ae, [6] zero, [7] pred,
 //      [8] t_reg
 // GRAD: the same pass also writes the gradients of `total` for an upstream gradient *g that is known when the forward runs (a
 // recorded step passes its resident 1.0 / loss scale): dz = k (y - target) act'(y) in the compute dtype for the producing chain and
 // the three small code gradients -- the frames and targets are read ONCE per step instead of twice (D % 4 == 0).
-constexpr int VS_LOSS_MAX_PARTIALS = 4096;          // vs_train_losses_fwd_grad: `out` holds 16 + 2 * 4096 floats
-struct LossGrads { const float* g; void* dz; int dz_dtype; int act; float* ds_old; float* ds_new; float* dt0; };
-
 template <bool GRAD>
 __global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float* out, LossGrads gr) {
     __shared__ float red[4];
@@ -375,25 +349,6 @@ __global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float
     }
 }
 
-// A device-scope release fence per workgroup (the "last ticket assembles" pattern) costs more than this whole kernel on
-// gfx950 (each fence writes back the XCD's L2: +45 us at 1024 workgroups), so the scalars are assembled by a 1-thread launch.
-// (partials > 0: the frame sums arrive as that many per-workgroup pairs at out[16 ..])
-__global__ __launch_bounds__(256) void train_losses_finalize_kernel(LossArgs a, float* out, int partials) {
-    if (partials > 0) {
-        __shared__ float red[4];
-        float s0 = 0.f, s1 = 0.f;
-        for (int i = threadIdx.x; i < partials; i += 256) { s0 += out[16 + 2 * i]; s1 += out[17 + 2 * i]; }
-        s0 = block_sum_256(s0, red);
-        s1 = block_sum_256(s1, red);
-        if (threadIdx.x == 0) { out[0] = s0; out[1] = s1; }
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    const float ae = out[0] * a.inv_ae, pred = out[1] * a.inv_pred, zero = out[2] * a.inv_s, treg = 0.5f * out[3] * a.inv_t;
-    out[5] = ae; out[6] = zero; out[7] = pred; out[8] = treg;
-    out[4] = a.l_ae * ae + a.l_s * zero + a.l_pred * pred + a.l_t * treg;          // same association as train.py:146-149
-}
-
 // gradients of `total` times the upstream scalar *g: dframes, ds_old (= -ds_new), dt0
 // dz != NULL: the frames are the output y of an activation (the decoder's last one) and the kernel writes the gradient of its
 // INPUT, k * (y - target) * act'(y), in dz's dtype -- what ops.act_bwd would compute from dframes in a second pass
@@ -446,22 +401,6 @@ __global__ __launch_bounds__(256) void train_losses_bwd_kernel(LossArgs a, const
         for (int64_t i = a.D & ~(int64_t)3; i < a.D; ++i) o[i] = k * (f[i] - t[i]);
 }
 
-int fill_loss_args(LossArgs& a, const float* frames, const float* full, const int32_t* idx, const int32_t* t_dev, int ae_shift, int first_forecast,
-                   int64_t B, int G, int T, int64_t D, const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
-                   int average_tloss, const float* lambdas) {
-    a.t_dev = t_dev; a.ae_shift = ae_shift; a.first_forecast = first_forecast;
-    VS_CHECK_ARG(frames && full && (idx || t_dev) && t0 && lambdas && B > 0 && G >= 1 && T > 0 && D > 0 && Bt > 0 && Ct > 0 && n_s >= 0,
-                 "vs_train_losses: bad argument");
-    VS_CHECK_ARG(n_s == 0 || (s_old && s_new), "vs_train_losses: spatial codes missing");
-    a.frames = frames; a.full = full; a.idx = idx; a.rows = B * G; a.D = D; a.G = G; a.T = T;
-    a.s_old = s_old; a.s_new = s_new; a.n_s = n_s; a.t0 = t0; a.Bt = Bt; a.Ct = Ct;
-    a.l_ae = lambdas[0]; a.l_s = lambdas[1]; a.l_t = lambdas[2]; a.l_pred = lambdas[3];
-    a.inv_ae = (float)(1.0 / ((double)B * D));
-    a.inv_pred = (float)(1.0 / ((double)B * (G > 1 ? G - 1 : 1) * D));
-    a.inv_s = n_s > 0 ? (float)(1.0 / (double)n_s) : 0.f;
-    a.inv_t = (float)(1.0 / (average_tloss ? (double)Bt * Ct : (double)Bt));
-    return VS_OK;
-}
 }  // namespace
 
 extern "C" int vs_train_losses_fwd(const float* frames, const float* full, const int32_t* idx, const int32_t* t_random_dev, int ae_shift,
@@ -472,7 +411,7 @@ extern "C" int vs_train_losses_fwd(const float* frames, const float* full, const
     int rc = fill_loss_args(a, frames, full, idx, t_random_dev, ae_shift, first_forecast, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss,
                             lambdas);
     if (rc != VS_OK) return rc;
-    VS_CHECK_ARG(out, "vs_train_losses_fwd: null output");
+    VS_CHECK_ARG(out && frames, "vs_train_losses_fwd: null pointer");
     if (vs_zero_async(out, 10 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_train_losses_fwd: zero fill failed");
     int64_t wgs = B * G;
     if (wgs > 1024) wgs = 1024;
@@ -494,7 +433,7 @@ extern "C" int vs_train_losses_fwd_grad(const float* frames, const float* full, 
     int rc = fill_loss_args(a, frames, full, idx, t_random_dev, ae_shift, first_forecast, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss,
                             lambdas);
     if (rc != VS_OK) return rc;
-    VS_CHECK_ARG(out && grad_total && dz && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_fwd_grad: null pointer");
+    VS_CHECK_ARG(frames && out && grad_total && dz && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_fwd_grad: null pointer");
     VS_CHECK_ARG(vs_dtype_ok(dz_dtype) && frames_act >= VS_ACT_NONE && frames_act <= VS_ACT_ELU && D % 4 == 0,
                  "vs_train_losses_fwd_grad: needs a valid dz dtype / activation and D %% 4 == 0");
     if (vs_zero_async(out, 10 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_train_losses_fwd_grad: zero fill failed");
@@ -516,7 +455,7 @@ extern "C" int vs_train_losses_bwd(const float* frames, const float* full, const
     int rc = fill_loss_args(a, frames, full, idx, t_random_dev, ae_shift, first_forecast, B, G, T, D, s_old, s_new, n_s, t0, Bt, Ct, average_tloss,
                             lambdas);
     if (rc != VS_OK) return rc;
-    VS_CHECK_ARG(grad_total && (dframes || dz) && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_bwd: null pointer");
+    VS_CHECK_ARG(frames && grad_total && (dframes || dz) && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_bwd: null pointer");
     VS_CHECK_ARG(!dz || (vs_dtype_ok(dz_dtype) && frames_act >= VS_ACT_NONE && frames_act <= VS_ACT_ELU && D % 4 == 0),
                  "vs_train_losses_bwd: dz needs a valid dtype / activation and D %% 4 == 0");
     unsigned gx = (unsigned)((D / 4 + 255) / 256);

@@ -23,6 +23,7 @@
 #include "vs_gemm_glds.h"
 #include "vs_gemm_big.h"
 #include "vs_gemm_mid.h"
+#include "vs_loss.h"
 
 namespace {
 
@@ -66,13 +67,13 @@ int launch_glds(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t 
     return VS_OK;
 }
 
-template <int CT, int LA, int LB>
+template <int CT, int LA, int LB, bool LOSS = false>
 int launch_big(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const BigPlan& bp, int batch, const Epi& epi,
                float* slabs, hipStream_t stream) {
     if constexpr (CT == VS_F32) {
         return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm: the 256x256 tile is a 16-bit kernel");
     } else {
-        auto kfn = gemm_big_kernel<CT, LA, LB, false>;
+        auto kfn = gemm_big_kernel<CT, LA, LB, false, LOSS>;
         static bool attr_set = false;                  // 128 KiB of dynamic LDS: above the 64 KiB default limit
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_BIG_STAGES * BIG_TILE_BYTES) != hipSuccess)
@@ -305,6 +306,45 @@ extern "C" int vs_gemm_adam(int compute, int64_t M, int64_t N, int64_t K, const 
                               : launch_mid_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, mp, 1, epi, nullptr, stream);
 }
 
+// The decoder's last Linear layer with the frame losses in its epilogue (recorded MLP-family step): frames = act(A W^T + bias) is row
+// r = (b, g) of the decoded stack [B, G, N = D] (reference: networks/mlp_encdec.py:43-50 + train.py:85-86, 139); instead of storing the
+// 54 MB of fp32 frames and reading them back with the targets (vs_train_losses_fwd_grad), the 256 x 256 tile kernel compares its result
+// with full[b, target(g)] while it is in registers: squared errors into one partial-sum pair per workgroup, k (y - target) act'(y) into
+// `dz`.  A one-workgroup launch then adds the partials, computes the two code terms and their gradients and assembles `out` (layout of
+// vs_train_losses_fwd_grad: [4] total, [5] ae, [6] zero-order, [7] pred, [8] t_reg).  VS_ERR_UNSUPPORTED when the problem does not run on
+// the 256 x 256 tile (the caller stores the frames and calls vs_train_losses_fwd_grad instead).
+extern "C" int vs_gemm_frame_loss(int compute, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
+                                  const float* bias, int act, const float* full, const int32_t* t_random_dev, int ae_shift, int first_forecast,
+                                  int G, int T, const float* s_old, const float* s_new, int64_t n_s, const float* t0, int64_t Bt, int64_t Ct,
+                                  int average_tloss, const float* lambdas, const float* grad_total, void* dz, int dz_dtype, float* ds_old,
+                                  float* ds_new, float* dt0, float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VS_CHECK_ARG(compute == VS_BF16 || compute == VS_F16, "vs_gemm_frame_loss: 16-bit compute types only (%d)", compute);
+    VS_CHECK_ARG(M > 0 && M < (1ll << 31) && N > 0 && K > 0 && G >= 1 && M % G == 0 && N % 4 == 0, "vs_gemm_frame_loss: bad sizes (rows = B * G, N %% 4 == 0)");
+    VS_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0, "vs_gemm_frame_loss: the bias must be 16-byte aligned");
+    VS_CHECK_ARG(A && W && full && t_random_dev && grad_total && dz && dt0 && out && (n_s == 0 || (ds_old && ds_new)), "vs_gemm_frame_loss: null pointer");
+    VS_CHECK_ARG(lda >= K && ldw >= K, "vs_gemm_frame_loss: leading dimension too small");
+    VS_CHECK_ARG(vs_dtype_ok(dz_dtype) && act >= VS_ACT_NONE && act <= VS_ACT_ELU, "vs_gemm_frame_loss: bad dz dtype / activation");
+    LossArgs a;
+    int rc = fill_loss_args(a, nullptr, full, nullptr, t_random_dev, ae_shift, first_forecast, M / G, G, T, N, s_old, s_new, n_s, t0, Bt, Ct,
+                            average_tloss, lambdas);
+    if (rc != VS_OK) return rc;
+    const BigPlan bp = big_plan_for(compute, M, N, K, 1, A, lda, LR, W, ldw, LR, 0, 0);
+    if (!bp.use || bp.splits != 1 || (int64_t)bp.tiles_m * bp.tiles_n > VS_LOSS_MAX_PARTIALS)
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm_frame_loss: the problem does not run on the 256x256 tile kernel");
+    Epi epi{nullptr, N, VS_F32, 1.f, bias, act, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    epi.fl_full = full; epi.fl_tdev = t_random_dev; epi.fl_ae_shift = ae_shift; epi.fl_first = first_forecast; epi.fl_G = G; epi.fl_T = T;
+    epi.fl_up = grad_total; epi.fl_l_ae = a.l_ae; epi.fl_l_pred = a.l_pred; epi.fl_inv_ae = a.inv_ae; epi.fl_inv_pred = a.inv_pred;
+    epi.fl_dz = dz; epi.fl_dz_dtype = dz_dtype; epi.fl_partials = out + 16;
+    rc = compute == VS_BF16 ? launch_big<VS_BF16, LR, LR, true>(A, lda, W, ldw, M, N, K, bp, 1, epi, nullptr, stream)
+                            : launch_big<VS_F16, LR, LR, true>(A, lda, W, ldw, M, N, K, bp, 1, epi, nullptr, stream);
+    if (rc != VS_OK) return rc;
+    LossGrads gr{grad_total, dz, dz_dtype, act, ds_old, ds_new, dt0};
+    hipLaunchKernelGGL(frame_loss_finish_kernel, dim3(1), dim3(256), 0, stream, a, out, bp.tiles_m * bp.tiles_n, gr);
+    VS_CHECK_LAUNCH("vs_gemm_frame_loss");
+    return VS_OK;
+}
+
 extern "C" size_t vs_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     size_t worst = 0;
@@ -342,7 +382,7 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
     VS_CHECK_ARG(!mask || ldmask >= N, "vs_gemm: ldmask too small");
     VS_CHECK_ARG(act >= VS_ACT_NONE && act <= VS_ACT_ELU, "vs_gemm: bad activation");
     Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    Plan plan = make_plan(compute, M, N, K);
+    Plan plan = make_plan(compute, M, N, K, 1, layout_a == LR && layout_b == LR);
     const BigPlan bp = big_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);
     MidPlan mp{false, 1, 0, 0, 0, 5};
     if (!bp.use) mp = mid_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);

@@ -30,6 +30,7 @@
 //     so the A row panel of a run stays in that XCD's L2.
 //   * split-K and the slab reduction are those of gemm_kernel.
 #pragma once
+#include <type_traits>
 #include "vs_gemm_glds.h"
 
 namespace {
@@ -214,6 +215,35 @@ __device__ __forceinline__ void big_store4(const Epi& e, int64_t m, int64_t n, i
     }
 }
 
+// frame-loss epilogue (Epi::fl_*): address of the target of frame row m, columns n.. (m < M, n + 3 < N)
+__device__ __forceinline__ const float* big_loss_target(const Epi& e, int64_t m, int64_t n, int64_t N, int t_rand, int& g_out) {
+    const unsigned b = (unsigned)m / (unsigned)e.fl_G;                 // (rows < 2^31: the host checks; a 64-bit division is ~190 instructions)
+    const int g = (int)((unsigned)m - b * (unsigned)e.fl_G);
+    const int frame = g == 0 ? t_rand - e.fl_ae_shift : e.fl_first + g - 1;
+    g_out = g;
+    return e.fl_full + ((int64_t)b * e.fl_T + frame) * N + n;
+}
+// ... and what is done with four consecutive columns of the result once their targets `t` have arrived
+__device__ __forceinline__ void big_loss4(const Epi& e, int64_t m, int64_t n, int64_t N, int g, const f32x4& v, const f32x4& t, const f32x4& bias4, float up,
+                                          float& s0, float& s1) {
+    const float k = g == 0 ? up * e.fl_l_ae * 2.f * e.fl_inv_ae : up * e.fl_l_pred * 2.f * e.fl_inv_pred;      // (as train_losses_fwd_kernel)
+    float rr[4], s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x = vs_act(v[j] * e.alpha + bias4[j], e.act);
+        const float d = x - t[j];
+        s += d * d;
+        rr[j] = (k * d) * vs_act_grad_from_out(x, e.act);
+    }
+    if (g == 0) s0 += s; else s1 += s;
+    const int64_t o = m * N + n;
+    if (e.fl_dz_dtype == VS_F32) *reinterpret_cast<f32x4*>((float*)e.fl_dz + o) = f32x4{rr[0], rr[1], rr[2], rr[3]};
+    else {
+        const u16x4 w = {vs_f2h(rr[0], e.fl_dz_dtype), vs_f2h(rr[1], e.fl_dz_dtype), vs_f2h(rr[2], e.fl_dz_dtype), vs_f2h(rr[3], e.fl_dz_dtype)};
+        *reinterpret_cast<u16x4*>((unsigned short*)e.fl_dz + o) = w;
+    }
+}
+
 // Instruction order inside one K tile ("block") of the main loop is pinned in the source (sched_barrier(0) fences between the
 // groups): an MFMA holds the SIMD's issue port for 8 of its 32 cycles, so the 12 fragment reads, the 4 DMA requests and their
 // address arithmetic of a block are dealt out one or two per MFMA instead of ahead of them.  (All waves in step and everything
@@ -222,7 +252,9 @@ __device__ __forceinline__ void big_store4(const Epi& e, int64_t m, int64_t n, i
 // sched_group_barrier, clumps the reads behind the MFMAs.)
 #define VS_FENCE __builtin_amdgcn_sched_barrier(0)
 
-template <int CT, int LA, int LB, bool NCHW>
+// LOSS: the frame-loss epilogue (Epi::fl_*, vs_gemm_frame_loss) -- an instantiation of its own: its registers must not cost the GEMM its
+// spill-free allocation (236 VGPRs)
+template <int CT, int LA, int LB, bool NCHW, bool LOSS = false>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
                                                        int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs) {
     int zsplit = blockIdx.z;
@@ -359,8 +391,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap,
     float* stg = reinterpret_cast<float*>(smem) + wave * (64 * 64);          // 16 KiB per wave, 128 KiB in all
     const int cj = lane & 31, rh = 4 * (lane >> 5);
     float* slab_base = slabs ? slabs + (int64_t)blockIdx.z * M * N : nullptr;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    float fl_s0 = 0.f, fl_s1 = 0.f;
+    float fl_up = 0.f;
+    int fl_t = 0;
+    if constexpr (LOSS) { fl_up = epi.fl_up[0]; fl_t = epi.fl_tdev[0]; }
+    // (the two passes as calls with a COMPILE-TIME pass number: an index of `acc` the compiler cannot resolve would move all 128
+    // accumulators to scratch memory -- seen with the frame-loss variant's inner lambda inside an unrolled `for`)
+    auto epilogue_pass = [&](auto pass_c) {
+        constexpr int pass = decltype(pass_c)::value;
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -370,13 +408,62 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const unsigned short* Ap,
                     stg[(32 * ii + (v & 3) + 8 * (v >> 2) + rh) * 64 + 32 * j + cj] = acc[2 * pass + ii][j][v];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // own writes only: a wave reads back what it wrote itself
         const int64_t nn = n0 + wc * 64 + (lane & 15) * 4;
-        for (int it = 0; it < 16; ++it) {
-            const int r = it * 4 + (lane >> 4);
-            const int64_t m = m0 + wr * 128 + 64 * pass + r;
-            const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + r * 64 + (lane & 15) * 4);
-            if (m < M && nn < N) big_store4<NCHW>(epi, m, nn, N, v4, slab_base ? slab_base + m * N : nullptr);
+        if constexpr (LOSS) {
+            // frame losses: a row piece needs 16 bytes of its TARGET frame from HBM; the requests of four pieces are in flight while the previous
+            // four are worked off (one piece at a time the epilogue waited ~1 us per piece: +25 us on the WaveEq step).  Rows / columns past
+            // the end read a clamped (valid) address -- no branch around a request (see gemm_mid_kernel's optimizer epilogue) -- and are skipped.
+            f32x4 tg[2][4];
+            int gg[2][4];
+            const int64_t nn_c = nn + 3 < N ? nn : N - 4;
+            // (a lane's four columns are the same for all its row pieces: the bias is loaded ONCE -- a load inside the loop is waited for
+            // with vmcnt(0), i.e. together with every target request in flight)
+            const f32x4 bias4 = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + nn_c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            auto request = [&](int buf, int q) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    int64_t m = m0 + wr * 128 + 64 * pass + (q * 4 + t) * 4 + (lane >> 4);
+                    if (m > M - 1) m = M - 1;
+                    tg[buf][t] = *reinterpret_cast<const f32x4*>(big_loss_target(epi, m, nn_c, N, fl_t, gg[buf][t]));
+                }
+            };
+            request(0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q + 1 < 4) request((q + 1) & 1, q + 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r = (q * 4 + t) * 4 + (lane >> 4);
+                    const int64_t m = m0 + wr * 128 + 64 * pass + r;
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + r * 64 + (lane & 15) * 4);
+                    if (m < M && nn + 3 < N) big_loss4(epi, m, nn, N, gg[q & 1][t], v4, tg[q & 1][t], bias4, fl_up, fl_s0, fl_s1);
+                }
+            }
+        } else {
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 4 + (lane >> 4);
+                const int64_t m = m0 + wr * 128 + 64 * pass + r;
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + r * 64 + (lane & 15) * 4);
+                if (m < M && nn < N) big_store4<NCHW>(epi, m, nn, N, v4, slab_base ? slab_base + m * N : nullptr);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next pass overwrites the area
+    };
+    epilogue_pass(std::integral_constant<int, 0>{});
+    epilogue_pass(std::integral_constant<int, 1>{});
+    if constexpr (LOSS) {
+        // the workgroup's two partial sums: lanes -> waves (shuffles) -> LDS (the staging area is idle after the barrier) -> one pair per tile
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { fl_s0 += __shfl_down(fl_s0, o, 64); fl_s1 += __shfl_down(fl_s1, o, 64); }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) { red[2 * wave] = fl_s0; red[2 * wave + 1] = fl_s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int w = 0; w < 8; ++w) { a0 += red[2 * w]; a1 += red[2 * w + 1]; }
+            epi.fl_partials[2 * blockIdx.x] = a0;
+            epi.fl_partials[2 * blockIdx.x + 1] = a1;
+        }
     }
 }
 

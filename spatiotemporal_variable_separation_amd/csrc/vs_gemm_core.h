@@ -52,6 +52,12 @@ struct Epi {
     // split-K finished inside the launch (vs_gemm / vs_gemm_batched): every split stores its fp32 slab, bumps its tile's counter and the LAST
     // workgroup to arrive adds the slabs in split order (bitwise what splitk_reduce_kernel computes), applies the epilogue and clears the counter
     unsigned* sk_counters; int sk_splits; int64_t sk_bytes;      // sk_bytes: size of the whole slab area (< 2 GiB)
+    // frame losses in the epilogue (vs_gemm_frame_loss, 256x256 tile kernel only): the result act(alpha * acc + bias) is row r = (b, g) of the
+    // decoded frame stack [B, G, N]; it is compared with full[b, target(g)] (fp32 [B, T, N]) and NOT stored: the squared errors go to two
+    // per-workgroup partial sums (frame 0 | frames 1..: fl_partials[2 * workgroup ..]) and k * (y - target) * act'(y) to fl_dz in fl_dz_dtype
+    const float* fl_full; const int* fl_tdev; int fl_ae_shift, fl_first, fl_G, fl_T;
+    const float* fl_up; float fl_l_ae, fl_l_pred, fl_inv_ae, fl_inv_pred;        // k = *fl_up * l * 2 * (1 / count), in this order
+    void* fl_dz; int fl_dz_dtype; float* fl_partials;
     int adam_pipe;                       // fused optimizer: state of four row pieces requested ahead (VS_ADAM_PIPE=0: one piece at a time)
 };
 
@@ -468,7 +474,7 @@ struct Plan { int bm, bn, splits; int64_t k_tiles_per_split; int batch = 1; };
 
 template <int CT> constexpr int bk_of() { return CT != VS_F32 ? 64 : 16; }
 
-Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1) {
+Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1, bool forward_layout = false) {
     const int bk = compute != VS_F32 ? 64 : 16;
     Plan p;
     // Tile choice (measured on the config-2 shapes, tools/gemm_bench.py): the kernel keeps ~3 workgroups (12 waves) per CU
@@ -481,7 +487,11 @@ Plan make_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch = 1) 
     // not (WaveEq B=128, whole recorded step: 1.51 -> 1.43 ms; 3328x1200 outputs are 494 tiles of 128x64 but 988 of 64x64, and
     // the 256x1200 encoder outputs 38 against 76): the launches overlap with the gradient branches, where more and lighter
     // workgroups fill the CUs the neighbours leave.  VS_GEMM_T64_BELOW moves the threshold (0 = the round-1 rule).
-    static const int64_t t64_below = getenv("VS_GEMM_T64_BELOW") ? atoll(getenv("VS_GEMM_T64_BELOW")) : 600;
+    static const int64_t t64_below_any = getenv("VS_GEMM_T64_BELOW") ? atoll(getenv("VS_GEMM_T64_BELOW")) : 600;
+    // R x R operands = a Linear layer's FORWARD launch: nothing runs beside the decoder's forward chain (the gradient branches that made the
+    // light tiles win exist in backward only), so the threshold may differ there (VS_GEMM_T64_BELOW_RR)
+    static const int64_t t64_below_rr = getenv("VS_GEMM_T64_BELOW_RR") ? atoll(getenv("VS_GEMM_T64_BELOW_RR")) : t64_below_any;
+    const int64_t t64_below = forward_layout ? t64_below_rr : t64_below_any;
     if (const char* f = getenv("VS_GEMM_TILE")) {                       // debugging aid: force a tile ("128x128", "128x64", "64x64")
         p.bm = atoi(f); const char* x = strchr(f, 'x'); p.bn = x ? atoi(x + 1) : p.bm;
     } else if (K <= 512 && t128 >= 256) { p.bm = 64; p.bn = 64; }      // short K: prologue/epilogue bound, many small tiles win

@@ -16,7 +16,7 @@ import weakref
 import torch
 
 from . import ops
-from ._lib import LAYOUT_R as R, LAYOUT_S as S, require_cuda
+from ._lib import LAYOUT_R as R, LAYOUT_S as S, VarsepHipError, require_cuda
 
 _STATE = {'precision': 'fp32'}
 
@@ -221,6 +221,10 @@ def promise_loss_gradient(t):
     (`total.backward(t)`): TrainLosses then writes its gradients in the forward pass (one read of the frame stack per step instead of
     two).  The value is read on the device when the forward kernel runs; a backward call with any other tensor recomputes."""
     _STATE['promised_loss_grad'] = t
+
+
+def promised_loss_gradient():
+    return _STATE.get('promised_loss_grad')
 
 
 def compute_dtype():
@@ -684,18 +688,25 @@ class GradHandoff:
     gradient of the frame stack in HBM).  Autograd still wants an fp32 gradient for the output, so the consumer returns a
     zero placeholder (a 0-stride view of one resident zero, no kernel) and leaves the real tensor here; if other consumers
     add gradients of their own, the chain sees a non-placeholder `dy` and adds its activation gradient on top."""
-    __slots__ = ('act', 'cdt', 'dz')
+    __slots__ = ('act', 'cdt', 'dz', 'fuse', 'fused')
     _zero = {}
 
     def __init__(self):
         self.act, self.cdt, self.dz = None, None, None
+        # fuse: what the chain's LAST GEMM needs to evaluate the frame losses in its epilogue (train._compute_losses_mlp_batched sets it for
+        # the recorded step): dict(full, idx, G, s_old, s_new, t0, lambdas, average, up); fused: the results (out, dz, ds_old, ds_new, dt0)
+        self.fuse, self.fused = None, None
 
     @classmethod
     def placeholder(cls, like):
-        z = cls._zero.get(like.device)
+        return cls.zeros(like.shape, like.device)
+
+    @classmethod
+    def zeros(cls, shape, device):
+        z = cls._zero.get(device)
         if z is None:
-            z = cls._zero[like.device] = torch.zeros((), dtype=torch.float32, device=like.device)
-        return z.expand(like.shape)
+            z = cls._zero[device] = torch.zeros((), dtype=torch.float32, device=device)
+        return z.expand(tuple(shape))
 
     @staticmethod
     def is_placeholder(t):
@@ -723,6 +734,17 @@ class MLPChain(torch.autograd.Function):
             W, b = params[2 * l], params[2 * l + 1]
             N, K = W.shape
             last = l == n_layers - 1
+            if last and handoff is not None and handoff.fuse is not None and cdt != torch.float32:
+                # the frames are consumed by the fused losses only (recorded step): compare them with their targets in the GEMM's
+                # epilogue instead of storing 4 B per element and reading them back (ops.gemm_frame_loss)
+                f = handoff.fuse
+                res = ops.gemm_frame_loss(h, shadow(W, cdt), b.detach() if b is not None else None, acts[l], f['full'], f['idx'], f['G'],
+                                          f['s_old'], f['s_new'], f['t0'], f['lambdas'], f['average'], f['up'], cdt)
+                if res is not None:
+                    handoff.fused = res
+                    h = GradHandoff.zeros((M, N), h.device)          # (no frames exist: a 0-stride view of one resident zero)
+                    saved.append(h.new_zeros(()))
+                    continue
             h = ops.gemm(h, R, shadow(W, cdt), R, M, N, K, bias=b.detach() if b is not None else None, act=acts[l],
                          out_dtype=torch.float32 if last else cdt)
             saved.append(h)
@@ -733,7 +755,7 @@ class MLPChain(torch.autograd.Function):
         ctx.x_needs_grad = x.requires_grad
         ctx.params = params
         ctx.save_for_backward(*saved)
-        return saved[-1]
+        return h
 
     @staticmethod
     def backward(ctx, dy):
@@ -746,6 +768,9 @@ class MLPChain(torch.autograd.Function):
         if handed is not None and GradHandoff.is_placeholder(dy):
             dz = handed                                  # the consumer already applied act'(y) and the cast
         else:
+            if saved[L].dim() == 0:
+                raise VarsepHipError('the frames of this chain were never stored (losses evaluated in the GEMM epilogue): their only '
+                                     'consumer may be the fused loss')
             dy = dy.contiguous()
             if acts[L - 1] not in ('none', None):
                 dz = ops.act_bwd(dy, saved[L], acts[L - 1], out_dtype=cdt)
@@ -1813,7 +1838,12 @@ class TrainLosses(torch.autograd.Function):
         idx_arg = idx if ctx.window is None else (idx,) + ctx.window
         ctx.early = None
         up = _STATE.get('promised_loss_grad')
-        if (up is not None and handoff is not None and handoff.act not in ('none', None) and frames.shape[-1] % 4 == 0 and ctx.needs_input_grad[0]
+        if handoff is not None and handoff.fused is not None:
+            # the chain's last GEMM evaluated the frame losses in its epilogue (no frames exist): take its results
+            (out, dz, ds_old, ds_new, dt0), handoff.fused = handoff.fused, None
+            up = handoff.fuse['up']
+            ctx.early = (up.data_ptr(), up._version, dz.view(frames.shape), ds_old, ds_new, dt0)
+        elif (up is not None and handoff is not None and handoff.act not in ('none', None) and frames.shape[-1] % 4 == 0 and ctx.needs_input_grad[0]
                 and up.device == frames.device):
             # the caller has promised the tensor it will pass to backward (a recorded step: its resident 1.0 / loss scale): the
             # gradients are written by the same pass that sums the losses; backward hands them out if the promise was kept

@@ -102,7 +102,7 @@ def _mlp_family(sep_net):
 
 
 def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset, lamb_ae, lamb_s, lamb_t, lamb_pred,
-                                average_tloss, t_random, full_data=None):
+                                average_tloss, t_random, full_data=None, frames_unused=False):
     """Same arithmetic as the generic path below, with the calls that share weights batched along the row axis:
     E_s on [first window; last window], E_t on [random window; conditioning window], D on [the auto-encoding row
     block; every rollout step].  The MLP family has no BatchNorm, so stacking rows is exact; it halves the number of
@@ -171,21 +171,29 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
         s_old, s_new = spatial_codes()
         t_codes, _ = sep_net.t_resnet.rollout(t0, n)
     handoff = VF.GradHandoff() if os.environ.get('VARSEP_LOSS_HANDOFF', '1') == '1' else None
-    frames = sep_net.decoder.decode_rollout(s_old, t_rand, t_codes, handoff=handoff)                      # [B, 1+n, ...]
-    forecasts = frames[:, 1:]
-
     # both frame losses in one fused pass: frame 0 vs full[:, t_random - offset], frame g vs full[:, fo + g - 1]
     fo = nt_cond if offset == 0 else 0
+    # t_codes[:, 0] IS t0 (the rollout copies its input there), so the regulariser reads the encoder output directly
+    no_s = isinstance(sep_net.Es, ConstantS)
+    s_old_f = None if no_s else s_old.reshape(B, -1).float().contiguous()
+    s_new_f = None if no_s else s_new.reshape(B, -1).float().contiguous()
+    t0_f = t0.reshape(B, -1).float().contiguous()
+    flat_c = flat.contiguous()
+    up = VF.promised_loss_gradient()
+    if (frames_unused and handoff is not None and on_device and up is not None and torch.is_grad_enabled()
+            and VF.compute_dtype() != torch.float32 and os.environ.get('VARSEP_FUSE_FRAME_LOSS', '0') == '1'):
+        # recorded step (nobody reads the frames): the decoder's last GEMM compares them with their targets in its epilogue and
+        # writes the gradient of its pre-activation; neither the fp32 frame stack nor a loss pass over it exists (functional.MLPChain)
+        handoff.fuse = dict(full=flat_c, idx=(t_random, offset, fo), G=1 + n, s_old=s_old_f, s_new=s_new_f, t0=t0_f,
+                            lambdas=(lamb_ae, lamb_s, lamb_t, lamb_pred), average=average_tloss, up=up)
+    frames = sep_net.decoder.decode_rollout(s_old, t_rand, t_codes, handoff=handoff)                      # [B, 1+n, ...]
+    forecasts = None if (handoff is not None and handoff.fused is not None) else frames[:, 1:]
     if on_device:
         idx = (t_random, offset, fo)                 # resolved inside the loss kernels: no index tensor to build per step
     else:
         idx = _frame_index(int(t_random) - offset, fo, n, frames.device, T + 1)
-    # t_codes[:, 0] IS t0 (the rollout copies its input there), so the regulariser reads the encoder output directly
-    no_s = isinstance(sep_net.Es, ConstantS)
     total_loss, ae_loss_value, spatial_ode_loss, forecast_loss, t_reg = VF.TrainLosses.apply(
-        frames.reshape(B, 1 + n, -1), flat.contiguous(), idx, None if no_s else s_old.reshape(B, -1).float().contiguous(),
-        None if no_s else s_new.reshape(B, -1).float().contiguous(), t0.reshape(B, -1).float().contiguous(),
-        (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss, handoff)
+        frames.reshape(B, 1 + n, -1), flat_c, idx, s_old_f, s_new_f, t0_f, (lamb_ae, lamb_s, lamb_t, lamb_pred), average_tloss, handoff)
     terms = {'ae': ae_loss_value, 'zero': spatial_ode_loss, 'pred': forecast_loss, 't_reg': t_reg}
     if VF.side_streams_enabled() and os.environ.get('VARSEP_HOLD_WGRADS', '1') == '1':
         # backward: collect the decoder's and E_s's weight gradients and launch them under the integrator's backward kernel
@@ -449,7 +457,7 @@ class GraphedStep:
         try:
             if self.mlp:
                 total, _, _, _ = _compute_losses_mlp_batched(self.cond, self.target, self.net, nt_cond, nt_pred, offset, l_ae, l_s, l_t,
-                                                             l_pred, avg, self.t_dev, full_data=self.full)
+                                                             l_pred, avg, self.t_dev, full_data=self.full, frames_unused=True)
             else:                                    # conv families: the reference's call structure with a device-side window
                 total, _, _, _ = compute_losses(self.cond, self.target, self.net, nt_cond, nt_pred, offset, self.skipco, l_ae, l_s,
                                                 l_t, l_pred, avg, t_random=self.t_dev)

@@ -306,3 +306,40 @@ def test_full_size_lowp_step_matches_emulation_and_reference(name, precision, fa
     print(name, precision, {k: '%.1e' % v for k, v in worst.items()}, 'worst gradient / bound at', kw, 'largest gradient distances to the emulation:',
           [(k, '%.1e' % v) for k, v in top], '| committed emulation self-distance', {k: '%.1e' % v for k, v in noise.items() if not k.startswith('loss')})
     assert not fails, '\n'.join(fails)
+
+
+def test_full_size_taxibj_fp32_step_through_the_band_kernels(monkeypatch):
+    """VARSEP_FP32_SPLIT=1: every Conv2d k3 s1 p1 of the fp32 step -- forward, input gradient, weight gradient -- runs as six launches of
+    the 16-bit ROW-BAND kernels bench.py times (x and w in three bf16 pieces each, the six leading products, fp32 accumulation and output:
+    ops._conv3_split) instead of the column-matrix GEMM route.  The step must meet the SAME bars against the fixture recorded from the
+    reference's own train() as the fp32 step does (1e-3 on losses / forecasts / codes, 1e-2 on the conv family's gradients): the kernels of
+    the benched path reproduce the reference's numbers, not only their own emulation's."""
+    monkeypatch.setenv('VARSEP_FP32_SPLIT', '1')
+    name = 'full_taxibj'
+    cfg = FULL_CONFIGS[name]
+    gold = _fixture(name)
+    o_net0 = fill_net(cpu_ref.build_sep_net(cfg), cfg)
+    h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, int(gold['t_random']), o_net0, 'fp32', profile=True)
+    ran = set(h_net.kernel_families)
+    for fam in ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>'):
+        assert any(k.startswith(fam) for k in ran), f'{fam} did not run; ran {sorted(ran)}'
+    tol = 1e-3
+    assert abs(h_total.item() - float(gold['total'])) <= tol * abs(float(gold['total'])), (h_total.item(), float(gold['total']))
+    for k, v in h_terms.items():
+        ref = float(gold['loss:' + k])
+        assert abs(v.item() - ref) <= tol * max(abs(ref), 1e-6), f'loss {k}: {v.item()} vs {ref}'
+    worst = {'forecasts': check_tensor(gold, 'forecasts', h_fore, tol), 't_codes': check_tensor(gold, 't_codes', h_tc, tol)}
+    total_norm = np.sqrt(sum(float(gold[k][1]) ** 2 if k.startswith('cs:grad:') else float((gold[k].astype(np.float64) ** 2).sum())
+                             for k in gold if k.startswith('cs:grad:') or k.startswith('grad:')))
+    gw = 0.0
+    for k, p in h_net.named_parameters():
+        if p.grad is None:
+            continue
+        key = 'grad:' + k
+        ref_norm = float(gold['cs:' + key][1]) if 'cs:' + key in gold else float(np.linalg.norm(gold[key].astype(np.float64)))
+        if ref_norm < 1e-4 * total_norm:
+            assert p.grad.double().norm().item() <= 2e-4 * total_norm, f'{key}: should be ~0 on the scale of the whole gradient'
+            continue
+        gw = max(gw, check_tensor(gold, key, p.grad, 1e-2))
+    worst['grad'] = gw
+    print(name, 'HIP fp32 through the band kernels vs reference fixture:', {k: '%.1e' % v for k, v in worst.items()})
