@@ -676,6 +676,35 @@ def _conv3_split(x, w, bias, flip, role):
     return y
 
 
+def _k4s2_split_gather(big, w, bias, role):
+    """fp32 k4 s2 p1 gather (Conv2d forward on x / ConvTranspose2d input gradient on dy; w [M, K, 4, 4]) through six launches of the 16-bit
+    parity-plane row-band kernel."""
+    M = w.shape[0]
+    bs = _split16(big)
+    if not conv_k4s2_gather_supported(bs[0], M):
+        return None
+    planes = [space_to_depth2(b) for b in bs]
+    ws = [conv_k4s2_pack_weight(p.float().contiguous(), torch.bfloat16) for p in _split16(w)]
+    y = None
+    for i, j in _SPLIT_TERMS:
+        t = conv_k4s2_gather(planes[i], ws[j], bias if y is None else None, M, torch.float32, role=role)
+        y = t if y is None else y.add_(t)
+    return y
+
+
+def _k4s2_split_wgrad(small, big, w_shape, into, out):
+    M = w_shape[0]
+    bs = _split16(big)
+    if not conv_k4s2_supported(bs[0], M):
+        return None
+    planes = [space_to_depth2(b) for b in bs]
+    ss = _split16(small)
+    dw = None
+    for i, j in _SPLIT_TERMS:
+        dw = conv_k4s2_wgrad(ss[j], planes[i], w_shape, into=into if dw is None else dw, out=out if dw is None else None)
+    return dw
+
+
 def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     """x [B,Cin,H,W], w Conv2d [Cout,Cin,k,k] / ConvTranspose2d [Cin,Cout,k,k] in the same (compute) dtype.
     The transposed form consumes `w_packed` (conv_pack_weight); it is built on the fly from `w` when not given."""
@@ -684,6 +713,11 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     if (x.dtype == torch.float32 and out_dtype == torch.float32 and not transposed and tuple(w.shape[2:]) == (3, 3) and stride == 1 and pad == 1
             and fp32_split_enabled()):
         y = _conv3_split(x, w, bias, False, 'fwd')
+        if y is not None:
+            return y
+    if (x.dtype == torch.float32 and out_dtype == torch.float32 and not transposed and tuple(w.shape[2:]) == (4, 4) and stride == 2 and pad == 1
+            and fp32_split_enabled()):
+        y = _k4s2_split_gather(x, w, bias, 'fwd')
         if y is not None:
             return y
     if transposed:
@@ -731,6 +765,11 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     if (dy.dtype == torch.float32 and out_dtype == torch.float32 and not transposed and tuple(w.shape[2:]) == (3, 3) and stride == 1 and pad == 1
             and fp32_split_enabled()):
         dx = _conv3_split(dy, w, None, True, 'dgrad')
+        if dx is not None:
+            return dx
+    if (dy.dtype == torch.float32 and out_dtype == torch.float32 and transposed and tuple(w.shape[2:]) == (4, 4) and stride == 2 and pad == 1
+            and fp32_split_enabled()):
+        dx = _k4s2_split_gather(dy, w, None, 'dgrad')
         if dx is not None:
             return dx
     if not transposed:
@@ -844,6 +883,11 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
             dw = None
             for i, j in _SPLIT_TERMS:
                 dw = conv_wgrad(ds[j], xs[i], w_shape, stride, pad, transposed, into=into if dw is None else dw, out=out if dw is None else None)
+            return dw
+    if x.dtype == torch.float32 and tuple(w_shape[2:]) == (4, 4) and stride == 2 and pad == 1 and fp32_split_enabled():
+        # k4 s2 p1: the LARGE map (x of a Conv2d, dy of a ConvTranspose2d) on its parity planes, the small one as it is
+        dw = _k4s2_split_wgrad(x, dy, w_shape, into, out) if transposed else _k4s2_split_wgrad(dy, x, w_shape, into, out)
+        if dw is not None:
             return dw
     if _convt_1x1(x.shape, k, stride, pad, transposed):
         # dW[ci][j] (+)= sum_b x[b][ci] dy[b][j]

@@ -308,20 +308,28 @@ def test_full_size_lowp_step_matches_emulation_and_reference(name, precision, fa
     assert not fails, '\n'.join(fails)
 
 
-def test_full_size_taxibj_fp32_step_through_the_band_kernels(monkeypatch):
-    """VARSEP_FP32_SPLIT=1: every Conv2d k3 s1 p1 of the fp32 step -- forward, input gradient, weight gradient -- runs as six launches of
-    the 16-bit ROW-BAND kernels bench.py times (x and w in three bf16 pieces each, the six leading products, fp32 accumulation and output:
-    ops._conv3_split) instead of the column-matrix GEMM route.  The step must meet the SAME bars against the fixture recorded from the
-    reference's own train() as the fp32 step does (1e-3 on losses / forecasts / codes, 1e-2 on the conv family's gradients): the kernels of
-    the benched path reproduce the reference's numbers, not only their own emulation's."""
+SPLIT_FULL = [
+    ('full_taxibj', ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>')),
+    ('full_sst', ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>')),
+    ('full_mnist_b16', ('vs_conv_k4s2:fwd<bf16>', 'vs_conv_k4s2:dgrad<bf16>', 'vs_conv_k4s2:wgrad<bf16>')),
+]
+
+
+@pytest.mark.parametrize('name,families', SPLIT_FULL, ids=[n for n, _ in SPLIT_FULL])
+def test_full_size_fp32_step_through_the_16bit_kernels(name, families, monkeypatch):
+    """VARSEP_FP32_SPLIT=1: every Conv2d k3 s1 p1 of the fp32 step -- forward, input gradient, weight gradient -- and the gather-type
+    operations of the k4 s2 p1 family run as six launches of the 16-bit ROW-BAND kernels bench.py times (x and w in three bf16 pieces each,
+    the six leading products, fp32 accumulation and output: ops._conv3_split / _k4s2_split_*) instead of the column-matrix GEMM route.
+    The step must meet the SAME bars against the fixture recorded from the reference's own train() as the fp32 step does (1e-3 on losses /
+    forecasts / codes, 1e-2 on the conv family's gradients): the kernels of the benched path reproduce the reference's numbers, not only
+    their own emulation's -- a factor-2 error in any of their gradients cannot hide behind a 16-bit bound here."""
     monkeypatch.setenv('VARSEP_FP32_SPLIT', '1')
-    name = 'full_taxibj'
     cfg = FULL_CONFIGS[name]
     gold = _fixture(name)
     o_net0 = fill_net(cpu_ref.build_sep_net(cfg), cfg)
     h_net, h_total, h_terms, h_fore, h_tc = hip_step(cfg, int(gold['t_random']), o_net0, 'fp32', profile=True)
     ran = set(h_net.kernel_families)
-    for fam in ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>'):
+    for fam in families:
         assert any(k.startswith(fam) for k in ran), f'{fam} did not run; ran {sorted(ran)}'
     tol = 1e-3
     assert abs(h_total.item() - float(gold['total'])) <= tol * abs(float(gold['total'])), (h_total.item(), float(gold['total']))
@@ -342,4 +350,4 @@ def test_full_size_taxibj_fp32_step_through_the_band_kernels(monkeypatch):
             continue
         gw = max(gw, check_tensor(gold, key, p.grad, 1e-2))
     worst['grad'] = gw
-    print(name, 'HIP fp32 through the band kernels vs reference fixture:', {k: '%.1e' % v for k, v in worst.items()})
+    print(name, 'HIP fp32 through the 16-bit kernels vs reference fixture:', {k: '%.1e' % v for k, v in worst.items()})
