@@ -1162,8 +1162,41 @@ def _fold_param_grads(pairs):
             what.append(g)
             out[i] = None
     if into:
-        torch._foreach_add_(into, what)
+        if _CONV_GRAD_OUT and torch.cuda.is_current_stream_capturing() and os.environ.get('VARSEP_BATCH_SMALL_ADDS', '1') == '1':
+            # recorded step under a reducer: EVERY contribution (the first included) is an add into a bucket view -- 44 multi-tensor launches
+            # of ~5 us per TaxiBJ step against 11 without a reducer.  Nothing reads the buckets before the backward call returns (no hooks
+            # fire in a recording; train.GraphedStep reduces after the replay), so the adds of the whole pass are issued as ONE multi-tensor
+            # launch by an engine callback at its end (per segment of a two-segment recording).  Eager steps keep the immediate adds: there
+            # the reducer's hooks may put a bucket on the wire as soon as autograd has visited its last parameter.
+            _PENDING_ADDS['into'] += into
+            _PENDING_ADDS['what'] += what
+            if not _PENDING_ADDS['queued']:
+                torch.autograd.Variable._execution_engine.queue_callback(flush_pending_adds)
+                _PENDING_ADDS['queued'] = True
+        else:
+            torch._foreach_add_(into, what)
     return out
+
+
+_PENDING_ADDS = {'into': [], 'what': [], 'queued': False}
+
+
+def flush_pending_adds():
+    into, what = _PENDING_ADDS['into'], _PENDING_ADDS['what']
+    _PENDING_ADDS.update(into=[], what=[], queued=False)
+    # a parameter that is applied several times per step (E_s on two windows, the decoder on the auto-encoding pair and the rollout, the SST
+    # integrator once per frame) appears several times: one multi-tensor launch may hold a destination only ONCE (its entries are processed
+    # concurrently), so the k-th contributions of all destinations form launch k
+    rounds, seen = [], {}
+    for dst, g in zip(into, what):
+        k = seen.get(dst.data_ptr(), 0)
+        seen[dst.data_ptr()] = k + 1
+        if k == len(rounds):
+            rounds.append(([], []))
+        rounds[k][0].append(dst)
+        rounds[k][1].append(g)
+    for dsts, gs in rounds:
+        torch._foreach_add_(dsts, gs)
 
 
 _packed_img = {}

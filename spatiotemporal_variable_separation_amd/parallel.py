@@ -53,6 +53,10 @@ class GradAllReducer:
         # the small tail (biases, integrator) of a sharded bucket is summed in fp32 by default; torch.bfloat16 rounds it before and after
         # the sum like the replicated bf16-wire path does -- then the sharded step is BIT-identical to the replicated one (the GPU tests use it)
         self.shard_tail_dtype = shard_tail_dtype
+        # presummed: the caller seeds its loss gradient with 1 / world_size (train.GraphedStep), so gradients only have to be SUMMED: same
+        # arithmetic as ReduceOp.AVG (RCCL pre-multiplies by 1 / N and sums; exact for N a power of two), but no pre-multiply kernel -- and at
+        # world size 1 (the forced N > 1 path) an in-place sum is no launch at all, where AVG runs a 32-workgroup copy at 0.25 TB/s
+        self.presummed = False
         self.masters_dirty = False       # fp32 masters / moments of the direct parameters are current in the own slice only
         self._head = {}                  # bucket index -> (padded head length, [(param, offset)])
         self._arena = {}                 # bucket index -> flat 16-bit arena of the direct parameters' operand copies
@@ -202,25 +206,27 @@ class GradAllReducer:
             src, dst = (flat[t0:], wire[t0:]) if t0 else (flat, wire)
             if src.numel():
                 dst.copy_(src)                                 # fp32 -> bf16 (round to nearest even)
+            div = 1 if self.presummed else self.world_size
             if self.backend == 'nccl':
-                dist.all_reduce(wire, op=dist.ReduceOp.AVG, group=self.group)
+                dist.all_reduce(wire, op=dist.ReduceOp.SUM if self.presummed else dist.ReduceOp.AVG, group=self.group)
             else:                                              # gloo (tests): no bf16 reduction there -- sum the bf16 values in fp32
                 host = wire.float().cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                wire.copy_((host / self.world_size).to(self.comm_dtype))
+                wire.copy_((host / div).to(self.comm_dtype))
             if src.numel():
                 src.copy_(dst)
             return
+        div = 1 if self.presummed else self.world_size
         if self.backend == 'nccl':
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM if self.presummed else dist.ReduceOp.AVG, group=self.group)
         elif flat.is_cuda:
             # gloo with device buckets (tests: several ranks sharing one GPU): staged through host memory
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-            flat.copy_(host.div_(self.world_size))
+            flat.copy_(host.div_(div))
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.div_(self.world_size)
+            flat.div_(div)
 
     def all_reduce(self):
         """Average gradients over ranks; returns when the current stream may consume them."""

@@ -268,6 +268,11 @@ class GraphedStep:
             grad_sync.shard = False                  # (fp32 / fp16-with-scaler / foreign optimizer: the all-reduce path)
         if self.sharded:
             grad_sync.adopt_operand_copies(VF.compute_dtype())
+        # under a reducer the recorded step seeds its loss gradient with 1 / world_size and the collectives SUM (GradAllReducer.presummed);
+        # with loss scaling the scale tensor is the seed, so that path keeps ReduceOp.AVG.  VARSEP_DDP_PRESUM=0: averages as before
+        self.presum = bool(grad_sync is not None and hasattr(grad_sync, 'presummed')
+                           and (self.sharded or (scaler is None and os.environ.get('VARSEP_DDP_PRESUM', '1') == '1')))
+        if self.presum:
             self._one = torch.full((), 1.0 / grad_sync.world_size, dtype=torch.float32, device=cond.device)
         enable_fused_update(optimizer, sep_net, grad_sync, scaler)
         enable_update_in_backward(optimizer, sep_net, grad_sync, scaler=scaler)
@@ -411,7 +416,11 @@ class GraphedStep:
 
     def _reduce(self):
         if self.sync is not None:
-            self.sync.reduce_all()
+            was, self.sync.presummed = self.sync.presummed, getattr(self, 'presum', False)
+            try:
+                self.sync.reduce_all()
+            finally:
+                self.sync.presummed = was
 
     def _fwd_bwd(self, segment=None):
         """Losses + backward.  `segment` (conv family under a reducer with early buckets): 1 = forward and the part of backward that ends at
@@ -490,6 +499,15 @@ class GraphedStep:
         self._draw()
         self.graph.replay()
         self.steps_replayed += 1
+        if self.sync is not None:
+            was_presummed, self.sync.presummed = self.sync.presummed, getattr(self, 'presum', False)
+        try:
+            return self._finish_step()
+        finally:
+            if self.sync is not None:
+                self.sync.presummed = was_presummed
+
+    def _finish_step(self):
         early = {}
         if getattr(self, 'graph2', None) is not None:
             # the decoder's buckets go on the wire now; the second segment (integrator + encoders backward) runs beside them

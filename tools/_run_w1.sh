@@ -1,10 +1,9 @@
 export VARSEP_BENCH_LIVE_PROFILE=0
-out=gpurun_out/r05w9.txt
+out=gpurun_out/r05w12.txt
 : > $out
-b() { python3 bench.py --config waveeq --extra_configs none --no_cpu_baseline --steps 20 2>>gpurun_out/r05w9.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['ms_per_step'], 'ms')" >> $out; }
-for i in 1 2 3; do
-b "base          "
-VS_GEMM_T64_BELOW_RR=400 b "fwd 128x64    "
-VS_GEMM_T64_BELOW=400 b "all 128x64    "
-VS_GEMM_MID=0 b "no mid        "
+python3 -m pytest tests/test_ddp_gpu.py -m gpu -q -x -k "conv_family or segments" 2>&1 | grep -E "^E  |passed|failed" | head -8 >> $out
+b() { python3 bench.py --config $2 --extra_configs none --no_cpu_baseline --steps 20 2>>gpurun_out/r05w12.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', '$2', d['ms_per_step'], 'ms')" >> $out; }
+for cfg in taxibj sst; do
+VARSEP_BENCH_FORCE_DIST=1 VARSEP_BATCH_SMALL_ADDS=0 b "dist1 adds per block" $cfg
+VARSEP_BENCH_FORCE_DIST=1 b "dist1 adds batched  " $cfg
 done
