@@ -245,7 +245,7 @@ def test_gemm_frame_loss_equals_gemm_then_fused_losses(dtype, act, B, G, N, K, o
 
 def test_recorded_waveeq_step_with_the_losses_in_the_gemm_epilogue(monkeypatch):
     """BASELINE configs[1] (WaveEq MLP, B = 128, bf16), recorded step: with the frame losses evaluated in the epilogue of the decoder's last
-    GEMM (default) the parameters after three steps equal (to the run-to-run noise of the float-atomic bias sums) those of the step that stores the frames and runs the loss pass, and the
+    GEMM (default) the parameters after one step equal (to the run-to-run noise of the float-atomic bias sums) those of the step that stores the frames and runs the loss pass, and the
     reported losses agree to the order of the sums."""
     import numpy as np
     from spatiotemporal_variable_separation_amd import functional as VF
@@ -268,7 +268,7 @@ def test_recorded_waveeq_step_with_the_losses_in_the_gemm_epilogue(monkeypatch):
             lam = cfg['lambdas']
             gs = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], (lam['ae'], lam['s'], lam['t'], lam['pred']),
                              warmup=1)
-            losses = [gs.step().item() for _ in range(3)]
+            losses = [gs.step().item() for _ in range(1)]
             torch.cuda.synchronize()
             results[mode] = (losses, {k: v.detach().clone() for k, v in net.state_dict().items()})
             del gs, opt, net
@@ -277,8 +277,8 @@ def test_recorded_waveeq_step_with_the_losses_in_the_gemm_epilogue(monkeypatch):
     (la, pa), (lb, pb) = results['1'], results['0']
     assert np.allclose(la, lb, rtol=1e-5), (la, lb)
     for k in pa:
-        # (the step itself is not bit-reproducible: float-atomic bias sums, and Adam's first steps turn a last-bit difference of a near-zero
-        # gradient into up to 2 lr on that element; the gradient of the pre-activation IS bit-equal -- see the op test above.)  All but a few
-        # elements agree to 2e-5, none is further apart than three learning rates
+        # ONE step: the loss it reports and the parameters it leaves.  The step is not bit-reproducible (float-atomic bias sums), and Adam's first
+        # step is lr * sign(g): a last-bit difference of a noise-level gradient flips an element by 2 lr.  The gradient of the pre-activation itself
+        # IS bit-equal (op test above); here: all but a few elements agree to 1e-6, none is further apart than 2.5 learning rates
         d = (pa[k] - pb[k]).abs()
-        assert float((d > 2e-5).float().mean()) <= 1e-4 and float(d.max()) <= 3 * 4e-4, f'{k}: max diff {d.max().item():.3e}'
+        assert float((d > 1e-6).float().mean()) <= 1e-3 and float(d.max()) <= 2.5 * 4e-4, f'{k}: {float((d > 1e-6).float().mean()):.2e} of the elements differ, max {d.max().item():.3e}'
