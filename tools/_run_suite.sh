@@ -1,1 +1,2 @@
-python3 -m pytest tests/test_baseline_gpu.py -m gpu -q -s -k "through_the_16bit" 2>&1 | grep -E "^E  |passed|failed|HIP fp32" | head -20 > gpurun_out/r05x3.txt
+mkdir -p gpurun_out/r05
+python3 -m pytest tests/ -m gpu -q 2>&1 | tail -6 > gpurun_out/r05/r05_gpu_tests.txt
