@@ -197,3 +197,40 @@ def test_sharded_optimizer_machinery_equals_replicated_update(tmp_path):
     # some direct parameter of each rank was stale outside the rank's slice before the masters were completed
     assert any(not torch.equal(s0['before'][k], s0['state'][k]) for k in s0['before'])
     assert any(not torch.equal(s1['before'][k], s1['state'][k]) for k in s1['before'])
+
+
+def _presum_worker(rank, world, port, presum, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from spatiotemporal_variable_separation_amd.parallel import GradAllReducer, broadcast_module_state
+    torch.set_num_threads(1)
+    cfg = dict(CONFIGS['mlp_mul'], B=8)
+    cond, target = make_batch(cfg)
+    net = det_fill(cpu_ref.build_sep_net(cfg), salt=cfg['salt'] + rank)
+    broadcast_module_state(net)
+    sync = GradAllReducer(net.parameters(), bucket_bytes=16 << 10, overlap=False)
+    sync.presummed = presum
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    part = slice(rank * 4, rank * 4 + 4)
+    for step in range(2):
+        sync.zero_grad()
+        _losses(net, cond[part], target[part], cfg, 5 + step).backward(torch.tensor(1.0 / world if presum else 1.0))
+        sync.all_reduce()
+        opt.step()
+    torch.save({k: v.clone() for k, v in net.state_dict().items()}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_sums_of_gradients_seeded_with_one_over_n_equal_averages(tmp_path):
+    """GradAllReducer.presummed (what a recorded data-parallel step uses): the loss gradient seeded with 1 / N and the buckets SUMMED is the
+    averaged-gradient step bit for bit at N = 2 (halving is exact), replicas identical."""
+    a, b = tmp_path / 'sum', tmp_path / 'avg'
+    a.mkdir(), b.mkdir()
+    mp.spawn(_presum_worker, args=(2, _free_port(), True, str(a)), nprocs=2, join=True)
+    mp.spawn(_presum_worker, args=(2, _free_port(), False, str(b)), nprocs=2, join=True)
+    s0, s1 = torch.load(os.path.join(a, 'rank0.pt')), torch.load(os.path.join(a, 'rank1.pt'))
+    r0 = torch.load(os.path.join(b, 'rank0.pt'))
+    for k, v in r0.items():
+        assert torch.equal(s0[k], v), f'{k}: summed 1 / N-seeded gradients != averaged gradients'
+        assert torch.equal(s0[k], s1[k]), f'replicas diverged at {k}'
