@@ -160,6 +160,11 @@ size_t vs_convt_tap_packed_elems(int Cin, int Cout);
 int vs_convt_tap_pack_weight(int compute, const float* w, int Cin, int Cout, void* dst, void* stream);
 int vs_convt_k4s2_tap_fwd(int compute, const void* x, const void* w_tap, const float* bias, void* y, double* bn_sums, int B, int Cin, int H,
                           int W, int Cout, int groups, void* stream);
+/* vs_convt_k4s2_tap_fwd with an fp32 output tensor (no BatchNorm sums): the fp32 parity mode (VARSEP_FP32_SPLIT) assembles the fp32 transposed
+ * convolution -- ConvTranspose2d k4 s2 p1 forward, conv.py:260-263, and the input gradient of Conv2d k4 s2 p1, conv.py:119-122 -- from six launches
+ * on bf16 pieces of its operands.                                                                                                     */
+int vs_convt_k4s2_tap_fwd_f32(int compute, const void* x, const void* w_tap, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                              void* stream);
 /* Conv2d k3 s1 p1 the same way (reference: every 3x3 block of EncoderSST / DecoderSST(_Skip) conv.py:323-426, ConvResBlock
  * resnet.py:53-88, VGG64Encoder / VGG64Decoder conv.py:127-171, 267-320) on 4x4 / 8x8 / 16x16 maps: tile rows = 9 taps x 28
  * channels, out[m][y][x] = sum_t G_t[m][y+ky-1][x+kx-1] in the epilogue.  The input gradient is the same kernel on dz with the

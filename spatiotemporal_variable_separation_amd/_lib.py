@@ -134,6 +134,7 @@ SIGNATURES = {
     'vs_convt_tap_packed_elems': (_sz, [_i32, _i32]),
     'vs_convt_tap_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _vp, _vp]),
     'vs_convt_k4s2_tap_fwd': (_i32, [_i32, _vp, _vp, _vp, _vp, _vp] + [_i32] * 6 + [_vp]),
+    'vs_convt_k4s2_tap_fwd_f32': (_i32, [_i32, _vp, _vp, _vp, _vp] + [_i32] * 5 + [_vp]),
     'vs_conv_k3_tap_supported': (_i32, [_i32] * 7),
     'vs_conv_k3_tap_packed_elems': (_sz, [_i32, _i32]),
     'vs_conv_k3_tap_pack_weight': (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),

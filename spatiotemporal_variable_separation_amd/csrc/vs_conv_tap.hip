@@ -127,7 +127,7 @@ __device__ __forceinline__ void tap_bn_accumulate(double* sums, float s1, float 
 
 template <int CT>
 __global__ __launch_bounds__(512) void convt_k4s2_tap_kernel(const unsigned short* X, const unsigned short* At, const float* bias, unsigned short* Y,
-                                                             double* sums, int B, int Cin, int H, int W, int Cout, int Bg, int tiles_m, int diag) {
+                                                             double* sums, int B, int Cin, int H, int W, int Cout, int Bg, int tiles_m, int diag, int y_f32) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // ring: 4 x [A0 | A1 | B0 | B1] x 8 KiB; then the fp32 staging area
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 2, wc = wave & 3;
@@ -203,14 +203,23 @@ __global__ __launch_bounds__(512) void convt_k4s2_tap_kernel(const unsigned shor
                     z[6] += k1[3] + k3[2];  z[7] += k2[3] + right;
                 }
                 if (m < Cout && b < B) {
-                    u16x8 o;
+                    if (y_f32) {
+                        // fp32 output (vs_convt_k4s2_tap_fwd_f32: the fp32 parity mode assembles an fp32 convolution from bf16 pieces, ops._tap_split)
+                        float* yo = reinterpret_cast<float*>(Y) + (b * Cout + m) * OHW + oy * OW + ox0;
+                        *reinterpret_cast<f32x4*>(yo) = f32x4{z[0], z[1], z[2], z[3]};
+                        *reinterpret_cast<f32x4*>(yo + 4) = f32x4{z[4], z[5], z[6], z[7]};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        o[e] = vs_f2h(z[e], CT);
-                        const float zr = vs_h2f(o[e], CT);                       // statistics of the STORED values, like vs_bn_stats
-                        s1 += zr; s2 += zr * zr;
+                        for (int e = 0; e < 8; ++e) { s1 += z[e]; s2 += z[e] * z[e]; }
+                    } else {
+                        u16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            o[e] = vs_f2h(z[e], CT);
+                            const float zr = vs_h2f(o[e], CT);                       // statistics of the STORED values, like vs_bn_stats
+                            s1 += zr; s2 += zr * zr;
+                        }
+                        *reinterpret_cast<u16x8*>(Y + (b * Cout + m) * OHW + oy * OW + ox0) = o;
                     }
-                    *reinterpret_cast<u16x8*>(Y + (b * Cout + m) * OHW + oy * OW + ox0) = o;
                 }
             }
             // the tile's samples belong to ONE call group (Bg % S == 0 is checked on the host)
@@ -514,8 +523,9 @@ extern "C" int vs_convt_tap_pack_weight(int compute, const float* w, int Cin, in
     return VS_OK;
 }
 
-extern "C" int vs_convt_k4s2_tap_fwd(int compute, const void* x, const void* w_tap, const float* bias, void* y, double* bn_sums, int B, int Cin, int H,
-                                     int W, int Cout, int groups, void* stream) {
+namespace {
+int convt_tap_go(int compute, const void* x, const void* w_tap, const float* bias, void* y, int y_f32, double* bn_sums, int B, int Cin, int H,
+                 int W, int Cout, int groups, void* stream) {
     VS_CHECK_ARG(x && w_tap && y, "vs_convt_k4s2_tap_fwd: null pointer");
     VS_CHECK_ARG(vs_convt_tap_supported(compute, B, Cin, H, W, Cout, groups), "vs_convt_k4s2_tap_fwd: unsupported geometry (query vs_convt_tap_supported)");
     VS_CHECK_ARG(((uintptr_t)x | (uintptr_t)w_tap | (uintptr_t)y) % 16 == 0, "vs_convt_k4s2_tap_fwd: operands must be 16-byte aligned");
@@ -540,12 +550,25 @@ extern "C" int vs_convt_k4s2_tap_fwd(int compute, const void* x, const void* w_t
     const int diag = denv ? atoi(denv) : 0;
     if (compute == VS_BF16)
         hipLaunchKernelGGL(kb, grid, dim3(512), BIG_STAGES * BIG_TILE_BYTES, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)w_tap, bias,
-                           (unsigned short*)y, bn_sums, B, Cin, H, W, Cout, B / groups, tiles_m, diag);
+                           (unsigned short*)y, bn_sums, B, Cin, H, W, Cout, B / groups, tiles_m, diag, y_f32);
     else
         hipLaunchKernelGGL(kh, grid, dim3(512), BIG_STAGES * BIG_TILE_BYTES, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)w_tap, bias,
-                           (unsigned short*)y, bn_sums, B, Cin, H, W, Cout, B / groups, tiles_m, diag);
+                           (unsigned short*)y, bn_sums, B, Cin, H, W, Cout, B / groups, tiles_m, diag, y_f32);
     VS_CHECK_LAUNCH("vs_convt_k4s2_tap_fwd");
     return VS_OK;
+}
+}  // namespace
+
+extern "C" int vs_convt_k4s2_tap_fwd(int compute, const void* x, const void* w_tap, const float* bias, void* y, double* bn_sums, int B, int Cin, int H,
+                                     int W, int Cout, int groups, void* stream) {
+    return convt_tap_go(compute, x, w_tap, bias, y, 0, bn_sums, B, Cin, H, W, Cout, groups, stream);
+}
+
+// The same launch with an fp32 output tensor y [B, Cout, 2H, 2W] (no BatchNorm sums): used by the fp32 parity mode that assembles an fp32
+// transposed convolution from bf16 pieces of its operands (bilinearity; reference layers conv.py:260-263 and the input gradient of :119-122).
+extern "C" int vs_convt_k4s2_tap_fwd_f32(int compute, const void* x, const void* w_tap, const float* bias, float* y, int B, int Cin, int H, int W,
+                                         int Cout, void* stream) {
+    return convt_tap_go(compute, x, w_tap, bias, y, 1, nullptr, B, Cin, H, W, Cout, 1, stream);
 }
 
 

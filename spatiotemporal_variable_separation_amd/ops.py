@@ -692,6 +692,27 @@ def _k4s2_split_gather(big, w, bias, role):
     return y
 
 
+def _tap_split(x, w, bias, role):
+    """fp32 k4 s2 p1 SCATTER (ConvTranspose2d forward of x with w [Cin, Cout, 4, 4]; the input gradient of a Conv2d k4 s2 p1 is the same operation
+    on dy with its weight read as [in = Cout, out = Cin]) through six launches of the 16-bit tap kernel with fp32 output."""
+    Cout = w.shape[1]
+    xs = _split16(x)
+    if not convt_tap_supported(xs[0], Cout, 1):
+        return None
+    ws = [convt_tap_pack_weight(p.float().contiguous(), torch.bfloat16) for p in _split16(w)]
+    B, Cin, H, W = x.shape
+    lib = _lib.load_library()
+    y = None
+    for i, j in _SPLIT_TERMS:
+        t = torch.empty((B, Cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        e0 = _pb()
+        check(lib.vs_convt_k4s2_tap_fwd_f32(_lib.BF16, xs[i].data_ptr(), ws[j].data_ptr(), _ptr(bias) if y is None else None, t.data_ptr(), B, Cin, H, W, Cout,
+                                            stream_ptr()), 'vs_convt_k4s2_tap_fwd_f32')
+        _pe(e0, 'vs_convT_tap:%s<bf16>' % role, flops=2.0 * B * H * W * Cin * Cout * 16, nbytes=float(xs[i].numel() * 2 + t.numel() * 4))
+        y = t if y is None else y.add_(t)
+    return y
+
+
 def _k4s2_split_wgrad(small, big, w_shape, into, out):
     M = w_shape[0]
     bs = _split16(big)
@@ -718,6 +739,11 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
     if (x.dtype == torch.float32 and out_dtype == torch.float32 and not transposed and tuple(w.shape[2:]) == (4, 4) and stride == 2 and pad == 1
             and fp32_split_enabled()):
         y = _k4s2_split_gather(x, w, bias, 'fwd')
+        if y is not None:
+            return y
+    if (x.dtype == torch.float32 and out_dtype == torch.float32 and transposed and tuple(w.shape[2:]) == (4, 4) and stride == 2 and pad == 1
+            and fp32_split_enabled()):
+        y = _tap_split(x, w, bias, 'fwd')
         if y is not None:
             return y
     if transposed:
@@ -770,6 +796,11 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
     if (dy.dtype == torch.float32 and out_dtype == torch.float32 and transposed and tuple(w.shape[2:]) == (4, 4) and stride == 2 and pad == 1
             and fp32_split_enabled()):
         dx = _k4s2_split_gather(dy, w, None, 'dgrad')
+        if dx is not None:
+            return dx
+    if (dy.dtype == torch.float32 and out_dtype == torch.float32 and not transposed and tuple(w.shape[2:]) == (4, 4) and stride == 2 and pad == 1
+            and fp32_split_enabled()):
+        dx = _tap_split(dy, w, None, 'dgrad')        # w [Cout, Cin, 4, 4] read as a ConvTranspose2d weight [in = Cout, out = Cin]
         if dx is not None:
             return dx
     if not transposed:
