@@ -666,12 +666,16 @@ def _conv3_split(x, w, bias, flip, role):
     """fp32 Conv2d k3 s1 p1 (flip: its input gradient, w [Cout, Cin, 3, 3] applied transposed) through six bf16 row-band launches."""
     Cout = w.shape[1] if flip else w.shape[0]
     xs = _split16(x)
-    if not conv3_band_supported(xs[0], Cout):
+    few = conv3_img16_supported(xs[0], Cout)         # the SST integrator's few 16 x 16 maps: the few-maps kernel (same weight pre-pack)
+    if not few and not conv3_band_supported(xs[0], Cout):
         return None
     ws = [conv3_img16_pack_weight(p.float().contiguous(), torch.bfloat16, flip) for p in _split16(w)]
     y = None
     for i, j in _SPLIT_TERMS:
-        t = conv3_band(xs[i], ws[j], bias if y is None else None, Cout, torch.float32, role=role)
+        if few:
+            t = slab_sum(conv3_img16(xs[i], ws[j], Cout, role=role), bias if y is None else None, torch.float32)
+        else:
+            t = conv3_band(xs[i], ws[j], bias if y is None else None, Cout, torch.float32, role=role)
         y = t if y is None else y.add_(t)
     return y
 

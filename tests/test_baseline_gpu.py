@@ -310,7 +310,7 @@ def test_full_size_lowp_step_matches_emulation_and_reference(name, precision, fa
 
 SPLIT_FULL = [
     ('full_taxibj', ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>')),
-    ('full_sst', ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>')),
+    ('full_sst', ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>', 'vs_conv3_img16:fwd<bf16>', 'vs_conv3_img16:dgrad<bf16>')),
     ('full_mnist_b16', ('vs_conv_k4s2:fwd<bf16>', 'vs_conv_k4s2:dgrad<bf16>', 'vs_conv_k4s2:wgrad<bf16>', 'vs_convT_tap:fwd<bf16>', 'vs_convT_tap:dgrad<bf16>')),
 ]
 
