@@ -750,6 +750,21 @@ def conv_fwd(x, w, bias, stride, pad, transposed, out_dtype, w_packed=None):
         y = _tap_split(x, w, bias, 'fwd')
         if y is not None:
             return y
+    if x.dtype == torch.float32 and out_dtype == torch.float32 and w.shape[2] == w.shape[3] and fp32_split_enabled():
+        # the thin-channel edge layers (first encoder / last decoder convolution): the same six products on the VALU kernels
+        B_, Cin_, H_, W_ = x.shape
+        k_ = w.shape[2]
+        Cout_ = w.shape[1] if transposed else w.shape[0]
+        OH_, OW_ = _conv_out_hw(H_, W_, k_, stride, pad, transposed)
+        thin = _thin_plan('fwd', BF16, B_, Cin_, H_, W_, Cout_, OH_, OW_, k_, stride, pad, transposed)
+        if thin is not None:
+            xs, ws, y = _split16(x), _split16(w), None
+            for i, j in _SPLIT_TERMS:
+                b_ = bias if y is None else None
+                t = (conv_thin_expand(xs[i], ws[j], b_, (B_, Cout_, OH_, OW_), torch.float32, k_, stride, *thin[5:]) if thin[0] == 'expand'
+                     else conv_thin_reduce(xs[i], ws[j], b_, Cout_, torch.float32, k_, stride, *thin[5:]))
+                y = t if y is None else y.add_(t)
+            return y
     if transposed:
         if w_packed is None:
             w_packed = conv_pack_weight(w.float().contiguous(), x.dtype, stride, pad)
@@ -806,6 +821,17 @@ def conv_dgrad(dy, w, x_shape, stride, pad, transposed, out_dtype, w_packed=None
             and fp32_split_enabled()):
         dx = _tap_split(dy, w, None, 'dgrad')        # w [Cout, Cin, 4, 4] read as a ConvTranspose2d weight [in = Cout, out = Cin]
         if dx is not None:
+            return dx
+    if dy.dtype == torch.float32 and out_dtype == torch.float32 and w.shape[2] == w.shape[3] and fp32_split_enabled():
+        B_, Cin_, H_, W_ = x_shape
+        k_ = w.shape[2]
+        Cout_ = w.shape[1] if transposed else w.shape[0]
+        thin = _thin_plan('dgrad', BF16, B_, Cin_, H_, W_, Cout_, dy.shape[2], dy.shape[3], k_, stride, pad, transposed)
+        if thin is not None:
+            ds, ws, dx = _split16(dy), _split16(w), None
+            for i, j in _SPLIT_TERMS:
+                t = conv_thin_expand(ds[i], ws[j], None, (B_, Cin_, H_, W_), torch.float32, k_, stride, *thin[5:], role='dgrad')
+                dx = t if dx is None else dx.add_(t)
             return dx
     if not transposed:
         if w_packed is None:
@@ -923,6 +949,14 @@ def conv_wgrad(dy, x, w_shape, stride, pad, transposed, into=None, out=None):
         # k4 s2 p1: the LARGE map (x of a Conv2d, dy of a ConvTranspose2d) on its parity planes, the small one as it is
         dw = _k4s2_split_wgrad(x, dy, w_shape, into, out) if transposed else _k4s2_split_wgrad(dy, x, w_shape, into, out)
         if dw is not None:
+            return dw
+    if x.dtype == torch.float32 and w_shape[2] == w_shape[3] and fp32_split_enabled():
+        thin = _thin_plan('wgrad', BF16, B, Cin, H, W, Cout, OH, OW, k, stride, pad, transposed)
+        if thin is not None:
+            big, small = (dy, x) if thin[0] == 'wgrad_big_dy' else (x, dy)
+            bs, ss, dw = _split16(big), _split16(small), None
+            for i, j in _SPLIT_TERMS:
+                dw = conv_thin_wgrad(bs[i], ss[j], w_shape, k, stride, *thin[5:], into=into if dw is None else dw, out=out if dw is None else None)
             return dw
     if _convt_1x1(x.shape, k, stride, pad, transposed):
         # dW[ci][j] (+)= sum_b x[b][ci] dy[b][j]

@@ -309,9 +309,12 @@ def test_full_size_lowp_step_matches_emulation_and_reference(name, precision, fa
 
 
 SPLIT_FULL = [
-    ('full_taxibj', ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>')),
-    ('full_sst', ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>', 'vs_conv3_img16:fwd<bf16>', 'vs_conv3_img16:dgrad<bf16>')),
-    ('full_mnist_b16', ('vs_conv_k4s2:fwd<bf16>', 'vs_conv_k4s2:dgrad<bf16>', 'vs_conv_k4s2:wgrad<bf16>', 'vs_convT_tap:fwd<bf16>', 'vs_convT_tap:dgrad<bf16>')),
+    ('full_taxibj', ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>', 'vs_conv_thin:fwd<bf16>', 'vs_conv_thin:dgrad<bf16>',
+                     'vs_conv_thin:wgrad<bf16>')),
+    ('full_sst', ('vs_conv3_band:fwd<bf16>', 'vs_conv3_band:dgrad<bf16>', 'vs_conv3_wgrad_band<bf16>', 'vs_conv3_img16:fwd<bf16>', 'vs_conv3_img16:dgrad<bf16>',
+                  'vs_conv_thin:fwd<bf16>', 'vs_conv_thin:wgrad<bf16>')),
+    ('full_mnist_b16', ('vs_conv_k4s2:fwd<bf16>', 'vs_conv_k4s2:dgrad<bf16>', 'vs_conv_k4s2:wgrad<bf16>', 'vs_convT_tap:fwd<bf16>', 'vs_convT_tap:dgrad<bf16>',
+                        'vs_conv_thin:fwd<bf16>', 'vs_conv_thin:wgrad<bf16>')),
 ]
 
 
@@ -331,6 +334,8 @@ def test_full_size_fp32_step_through_the_16bit_kernels(name, families, monkeypat
     ran = set(h_net.kernel_families)
     for fam in families:
         assert any(k.startswith(fam) for k in ran), f'{fam} did not run; ran {sorted(ran)}'
+    cols = sorted(k for k in ran if k.startswith(('vs_conv_cols:', 'vs_convT_cols:')))
+    assert not cols, f'{name}: column-matrix routes ran in the split mode: {cols}'
     tol = 1e-3
     assert abs(h_total.item() - float(gold['total'])) <= tol * abs(float(gold['total'])), (h_total.item(), float(gold['total']))
     for k, v in h_terms.items():
