@@ -563,10 +563,14 @@ def rooflines(res, workload, precision, top=6, live=None):
         return out
     roofs = [roof_of(g, e) for g, e in groups.items()]
     roofs.sort(key=lambda r: -r['us_per_step'])
+    if replay:
+        # kernel launches of one replayed step, all groups (the recording's kernel nodes): into the dominant group's
+        # object so that the line and bench_detail.json carry it
+        roofs[0]['kernel_launches_per_step'] = round(sum(g_['launches_per_step'] for g_ in replay.get('groups', {}).values()), 1)
     return roofs[0], roofs[1:top]
 
 
-_ROOF_KEYS = ('kernel', 'bound', 'peak', 'unit', 'achieved', 'frac', 'us_per_step', 'launches_per_step', 'avg_launch_us', 'share_of_step',
+_ROOF_KEYS = ('kernel', 'bound', 'peak', 'unit', 'achieved', 'frac', 'us_per_step', 'launches_per_step', 'kernel_launches_per_step', 'avg_launch_us', 'share_of_step',
               'traffic', 'traffic_per_step', 'algorithmic_bytes_per_step', 'algorithmic_per_step', 'timing', 'source', 'stale', 'traffic_stale')
 
 

@@ -1,1 +1,2 @@
-python3 -m pytest tests/test_baseline_gpu.py -m gpu -q -s -k "through_the_16bit" 2>&1 | grep -E "^E  |passed|failed|HIP fp32" | head -12 > gpurun_out/r05w20.txt
+mkdir -p gpurun_out/r05
+python3 bench.py > gpurun_out/r05/r05_bench_default.json 2> gpurun_out/r05/bench_default.err
