@@ -166,3 +166,25 @@ def test_profile_tables_are_tied_to_the_sources():
     from spatiotemporal_variable_separation_amd.profiling import source_sha
     a = source_sha()
     assert len(a) == 16 and a == source_sha()
+
+
+def test_fp32_split_pieces_reconstruct_the_value_and_six_products_the_convolution():
+    """ops._split16 / _SPLIT_TERMS (VARSEP_FP32_SPLIT, the route that runs fp32 steps on the 16-bit convolution kernels): three bf16 pieces
+    carry an fp32 value exactly, and the six leading piece products of a bilinear map -- each evaluated like the kernels do: bf16 operands,
+    exact products, fp32 accumulation -- reproduce the fp32 result to fp32 rounding (two pieces / three products would leave 2^-16)."""
+    import torch
+    import torch.nn.functional as F
+    from spatiotemporal_variable_separation_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((4, 24, 12, 12), generator=g) * torch.logspace(-3, 2, 24).view(1, 24, 1, 1)
+    w = torch.randn((16, 24, 3, 3), generator=g) * 0.05
+    xs, ws = ops._split16(x), ops._split16(w)
+    assert all(p.dtype == torch.bfloat16 for p in xs + ws)
+    assert torch.equal(xs[0].float() + xs[1].float() + xs[2].float(), x)
+    assert torch.equal(ws[0].float() + ws[1].float() + ws[2].float(), w)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    six = sum(F.conv2d(xs[i].double(), ws[j].double(), padding=1) for i, j in ops._SPLIT_TERMS)       # products of bf16 values are exact
+    three = sum(F.conv2d(xs[i].double(), ws[j].double(), padding=1) for i, j in ((0, 0), (0, 1), (1, 0)))
+    e6 = ((six - ref).norm() / ref.norm()).item()
+    e3 = ((three - ref).norm() / ref.norm()).item()
+    assert e6 < 2e-7 and e3 > 20 * e6, (e6, e3)
