@@ -60,6 +60,7 @@ class GradAllReducer:
         self.masters_dirty = False       # fp32 masters / moments of the direct parameters are current in the own slice only
         self._head = {}                  # bucket index -> (padded head length, [(param, offset)])
         self._arena = {}                 # bucket index -> flat 16-bit arena of the direct parameters' operand copies
+        self._rs_tmp, self._ag_tmp = {}, {}   # N > 1: receive / send buffers of one slice per bucket
         # stacked: lists of same-shaped parameters whose gradients must lie back to back in a bucket, in the given order, so that ONE batched
         # launch can write all of them (the integrator's per-layer weights: functional.MLPRollout.backward writes [blocks, H, C] in place)
         self._stacked = [list(g) for g in (stacked or [])]
@@ -294,7 +295,16 @@ class GradAllReducer:
         if head:
             lo, hi = self._slice(bi)
             if self.backend == 'nccl':
-                dist.reduce_scatter_tensor(wire[lo:hi], wire[:head], op=dist.ReduceOp.SUM, group=self.group)      # in place
+                if self.world_size == 1:
+                    dist.reduce_scatter_tensor(wire[lo:hi], wire[:head], op=dist.ReduceOp.SUM, group=self.group)  # in place: no launch at all
+                else:
+                    # N > 1: the slice is received in a buffer of its own (1 / N of the head) and copied into place -- no aliasing of a
+                    # collective's input and output, which is RCCL-legal at exactly this offset but has never run here on more than one rank
+                    tmp = self._rs_tmp.get(bi)
+                    if tmp is None:
+                        tmp = self._rs_tmp[bi] = torch.empty(hi - lo, dtype=wire.dtype, device=wire.device)
+                    dist.reduce_scatter_tensor(tmp, wire[:head], op=dist.ReduceOp.SUM, group=self.group)
+                    wire[lo:hi].copy_(tmp)
             else:                                          # gloo (tests): no reduce-scatter / bf16 arithmetic there
                 host = wire[:head].float().cpu()
                 if self.world_size > 1:
@@ -360,7 +370,14 @@ class GradAllReducer:
             ctx = contextlib.nullcontext()
         with ctx:
             if self.backend == 'nccl':
-                dist.all_gather_into_tensor(arena, arena[lo:hi], group=self.group)                  # in place
+                if self.world_size == 1:
+                    dist.all_gather_into_tensor(arena, arena[lo:hi], group=self.group)              # in place
+                else:
+                    tmp = self._ag_tmp.get(bi)                                                      # (as above: the contribution from a copy of the slice)
+                    if tmp is None:
+                        tmp = self._ag_tmp[bi] = torch.empty(hi - lo, dtype=arena.dtype, device=arena.device)
+                    tmp.copy_(arena[lo:hi])
+                    dist.all_gather_into_tensor(arena, tmp, group=self.group)
             elif self.world_size > 1:
                 mine = arena[lo:hi].view(torch.int32).cpu()          # (gloo moves no 16-bit types; a slice is a whole number of 128-byte lines)
                 parts = [torch.empty_like(mine) for _ in range(self.world_size)]
