@@ -1,0 +1,490 @@
+// vs_gemm_p8.h -- 256 x (128 NI) output tile, 8 waves in two staggered groups, K in steps of 64 through two LDS-DMA buffers with counted
+// waits: the 16-bit GEMM main loop of the "8 phases per two K tiles" class (cdna_hip_programming.md section 5, T2-T5) for the
+// Linear layers of the MLP family (reference: networks/mlp.py:24-41, mlp_encdec.py:43-50).
+//
+// Geometry (NI = 2: 256 x 256; NI = 1: 256 x 128):
+//   * 512 threads = 8 waves as 2 (M) x 4 (N); wave (wr, wc) owns the contiguous 128 x (32 NI) block of C at rows wr*128, columns wc*32*NI,
+//     as 2 x 2 quadrants Q(i, j) of 64 x (16 NI): 4 x NI accumulators of v_mfma_f32_16x16x32 each (NI = 2: 128 registers).
+//   * one K tile (64 deep) in LDS = four half-tile images  HA0 | HA1 | HB0 | HB1.  HAi holds, for every wave row wr, the 64 rows of
+//     quadrant row i (LDS row wr*64 + x  <->  tile row wr*128 + i*64 + x); HBj the 16 NI columns of quadrant column j of every wave column
+//     (LDS row wc*16NI + y  <->  tile column wc*32NI + j*16NI + y).  So a phase that multiplies Q(i, j) reads exactly HAi and HBj, every
+//     image is read in ONE phase by all waves, and can be re-requested two phases later.  Two K-tile buffers: 2 x 64 KiB (NI = 2).
+//   * images are filled by global_load_lds_dwordx4 (1 KiB per wave instruction, no VGPRs), so they are lane-linear; the bank swizzle sits on
+//     the SOURCE address and on the read address (the same involution):
+//       R operand (reduction index contiguous): [rows / 8][8 rows][8 pieces of 8 k], piece s of row r in slot s ^ ((r >> 1) & 7): a wave
+//         instruction fetches 8 whole 128-byte lines, and the 16 lanes of every ds_read_b128 group land on the 16 different 16-byte
+//         slots of the 256-byte bank row (conflict-free; the plain [128][64] image of the guide's template is 4-way);
+//       S operand (output index contiguous): [64 k][rows] with 32-byte pieces (16 rows) of k-row k in slot p ^ ((k & 3) | ((k >> 3) & 1) << 2),
+//         read with ds_read_b64_tr_b16 (the 8 k-rows of a 32-lane half sit in 8 different 32-byte slots).
+//   * schedule of one K tile u (buffer u & 1), four phases, each [LDS reads + one half-tile request | barrier | 8 NI MFMAs | barrier]:
+//         phase 1: read HB0, HA0;  request HA1 of tile u+1;  multiply Q(0,0)
+//         phase 2: read HB1;       request HB0 of tile u+2;  multiply Q(0,1)
+//         phase 3: read HA1;       request HA0 of tile u+2;  multiply Q(1,1)
+//         phase 4: --              request HB1 of tile u+2;  s_waitcnt vmcnt(three requests);  multiply Q(1,0)
+//     waves 4-7 run one barrier behind waves 0-3 (one extra s_barrier up front), so on every SIMD one wave multiplies while its partner
+//     reads and requests.  The wait of phase 4 leaves the three youngest half-tile requests in flight across the barriers and retires
+//     tile u+1, which is read from the next phase on (one barrier after every wave's wait).  An image is re-requested two phases after
+//     the phase that read it -- HB0 one phase after, its reads being retired by a counted lgkmcnt BEFORE the reading phase's barrier.
+//   * operands are multiplied swapped (the B fragment is the MFMA's first operand): a lane then holds four CONSECUTIVE columns of one row
+//     of C, and the epilogue stores 16-byte vectors straight from the accumulators (no LDS pass).
+#pragma once
+#include <type_traits>
+#include "vs_gemm_big.h"
+
+namespace {
+
+constexpr int P8_BK = 64;
+
+template <int CT>
+__device__ __forceinline__ f32x4 mfma16x32(const u32x4& a, const u32x4& b, const f32x4& c) {
+    if constexpr (CT == VS_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ const char* p8_uniform64(const char* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi << 32) | lo));
+}
+
+// LDS row -> tile row / column of half-tile image h; RUN = consecutive indices a wave owns per quadrant (A: 64, B: 16 NI).
+// A: 2 wave rows x 64 = 128 LDS rows; B: 4 wave columns x 16 NI = 64 NI LDS rows
+__device__ __forceinline__ constexpr int p8_tile_index(int lds_row, int h, int run) { return (lds_row / run) * (2 * run) + h * run + (lds_row % run); }
+
+// One operand's loader.  ROWS = LDS rows of a half-tile image (128 or 64), RUN as above.  Requests per thread and half-tile: ROWS / 64.
+template <int LAYOUT, int ROWS, int RUN>
+struct P8Operand {
+    static constexpr int NJ = ROWS / 64;                 // 1 KiB pieces per wave and half-tile
+    static constexpr int HALF_BYTES = ROWS * P8_BK * 2;
+    const char* base[2];                                 // UNIFORM [h]: first element of the next K tile of half h (each half advances alone)
+    uint32_t voff[2][NJ];                                // [h][j]: this lane's byte offset from base[h]
+    int kofs[NJ];                                        // k of this lane's piece inside a K tile
+    int64_t step;
+
+    __device__ __forceinline__ void prepare(const unsigned short* p, int64_t ld, int64_t rows, int64_t i0, int64_t k_begin, int wave) {
+        const int i = (int)(threadIdx.x & 63);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (LAYOUT == LR) {
+                    const int r = 8 * wave + (i >> 3) + 64 * j;                      // LDS row of this lane's piece
+                    const int s = (i & 7) ^ ((r >> 1) & 7);                          // the 8-k piece that lives in slot i & 7 of that row
+                    int64_t g = i0 + p8_tile_index(r, h, RUN);
+                    if (g > rows - 1) g = rows - 1;                                  // clamped rows land in output rows never stored
+                    kofs[j] = 8 * s;
+                    voff[h][j] = (uint32_t)(((g - i0) * ld + 8 * s) * 2);
+                } else {
+                    const int kr = 4 * wave + 32 * j + (i >> 4);                     // k-row of this lane's piece
+                    const int f = (kr & 3) | (((kr >> 3) & 1) << 2);
+                    const int nl = ((((i & 15) >> 1) ^ f) << 4) + (i & 1) * 8;       // LDS column (output index) of the piece: ROWS == 128 only
+                    int64_t g = i0 + p8_tile_index(nl, h, RUN);
+                    if (g > rows - 8) g = rows - 8;                                  // rows % 8 == 0: a piece is inside or outside as a whole
+                    kofs[j] = kr;
+                    voff[h][j] = (uint32_t)((kr * ld + (g - i0)) * 2);
+                }
+            }
+        // base and step are wave-uniform by construction; the 64-bit multiplies above are VALU work, so say it: an "s" operand of the request
+        // below must be an SGPR pair (hipcc puts a VGPR pair into the instruction text otherwise: "invalid operand")
+        const char* b0 = LAYOUT == LR ? reinterpret_cast<const char*>(p + i0 * ld + k_begin) : reinterpret_cast<const char*>(p + k_begin * ld + i0);
+        base[0] = base[1] = p8_uniform64(b0);
+        step = (int64_t)p8_uniform64(reinterpret_cast<const char*>((uintptr_t)(LAYOUT == LR ? (int64_t)P8_BK * 2 : (int64_t)P8_BK * ld * 2)));
+    }
+    // request half `h` of K tile `kt` into the image at byte OFF of the LDS area (`wbase` = LDS address of the area + wave * 1024, uniform);
+    // CHECKED: the tile may be partial or past the end of the split (zeros then: k past K meets valid rows of the other operand).
+    // M0 = LDS address of this wave's piece, written in the same statement that uses it.
+    template <bool CHECKED, int OFF>
+    __device__ __forceinline__ void stage(int h, uint32_t wbase, int64_t kt, int64_t kt_end, int64_t K) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (!CHECKED) {
+                if (j == 0)
+                    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(wbase), "v"(voff[h][0]), "s"(base[h]), "n"(OFF) : "memory", "m0", "scc");
+                else
+                    asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(wbase), "v"(voff[h][NJ - 1]), "s"(base[h]), "n"(OFF + 8192) : "memory", "m0", "scc");
+            } else {
+                const void* g = (kt < kt_end && kt * P8_BK + kofs[j] < K) ? (const void*)(base[h] + voff[h][j]) : (const void*)vs_glds_zero;
+                if (j == 0)
+                    asm volatile("s_add_u32 m0, %0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(wbase), "v"(g), "n"(OFF) : "memory", "m0", "scc");
+                else
+                    asm volatile("s_add_u32 m0, %0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(wbase), "v"(g), "n"(OFF + 8192) : "memory", "m0", "scc");
+            }
+        }
+        base[h] += step;
+    }
+};
+
+// ---- fragment reads ---------------------------------------------------------------------------------------------------------------
+// A fragment = 8 elements of k-step ks (0 / 1) for output index R0 + (lane & 15), R0 a multiple of 16.  The lane-dependent part of its
+// LDS address is kept in a few base registers per K-tile buffer (NB per operand), everything else is an immediate offset below 64 KiB
+// (buffer 1 starts 64 KiB in: folded into the address by the compiler, every read of it would want a register of its own).
+//   R image: base[ks]   = lane part with the k-step's slot permutation;      + image + R0 * 128
+//   S image: base[rep]  = lane part with fragment repeat rep's slot (4 wr + mi, or 2 wc + ni) permuted in;   + image + ks * 8192 (+ 1024)
+typedef __attribute__((address_space(3))) const u32x4 p8_lds_u32x4;
+typedef __attribute__((address_space(3))) vs_i16x4 p8_lds_i16x4;
+
+template <int LAYOUT, int REPS>
+struct P8Reader {
+    static constexpr int NB = LAYOUT == LR ? 2 : REPS;
+    uint32_t base[2][NB];                                             // [buffer][...]: LDS byte addresses
+
+    // `area`: LDS address of the operand's first image in buffer 0; `tile_bytes`: distance of buffer 1; `first_rep`: 4 wr (A) / NI wc (B) = R0 / 16 of repeat 0
+    __device__ __forceinline__ void prepare(uint32_t area, int tile_bytes, int first_rep, int rows, int lane) {
+#pragma unroll
+        for (int P = 0; P < 2; ++P)
+#pragma unroll
+            for (int x = 0; x < NB; ++x) {
+                uint32_t a;
+                if (LAYOUT == LR) {
+                    const int r = lane & 15;
+                    a = area + P * tile_bytes + first_rep * 2048 + (r >> 3) * 1024 + (r & 7) * 128 + ((((lane >> 4) + 4 * x) ^ (r >> 1)) << 4);
+                } else {
+                    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+                    const int f = q | ((g & 1) << 2);
+                    a = area + P * tile_bytes + (8 * g + q) * (rows * 2) + (((first_rep + x) ^ f) << 5) + 8 * pp;
+                }
+                asm volatile("" : "+v"(a));                            // opaque: keeps 64 KiB out of the immediate offsets
+                base[P][x] = a;
+            }
+    }
+    // repeat `rep` (0 .. REPS-1), k-step ks, of the image `img_off` bytes into the operand's area; P, rep, ks, img_off compile-time after unrolling
+    __device__ __forceinline__ u32x4 frag(int P, int img_off, int rep, int ks, int rows) const {
+        if (LAYOUT == LR) {
+            return *reinterpret_cast<p8_lds_u32x4*>(base[P][ks] + img_off + rep * 2048);
+        } else {
+            const uint32_t a = base[P][rep] + img_off + ks * 32 * (rows * 2);
+            const vs_i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<p8_lds_i16x4*>(a));
+            const vs_i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<p8_lds_i16x4*>(a + 4 * (rows * 2)));
+            typedef __attribute__((ext_vector_type(8))) short i16x8;
+            return __builtin_bit_cast(u32x4, (i16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    }
+};
+
+#define P8_FENCE __builtin_amdgcn_sched_barrier(0)
+#define P8_BAR()                                \
+    do {                                        \
+        asm volatile("s_barrier" ::: "memory"); \
+        P8_FENCE;                               \
+    } while (0)
+
+template <int CT, int LA, int LB, int NI, bool NCHW, bool LOSS = false>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
+                                                      int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs) {
+    constexpr int BN = 128 * NI;
+    constexpr int RUN_B = 16 * NI, ROWS_B = 64 * NI;
+    typedef P8Operand<LA, 128, 64> OpA;
+    typedef P8Operand<LB, ROWS_B, RUN_B> OpB;
+    static_assert(LB == LR || NI == 2, "an S image of B is 128 columns wide");
+    constexpr int HA = OpA::HALF_BYTES, HB = OpB::HALF_BYTES;
+    constexpr int TILE = 2 * HA + 2 * HB;                             // one K tile: HA0 | HA1 | HB0 | HB1
+    constexpr int WAIT = OpB::NJ * 2 + OpA::NJ;                       // requests of HB0, HA0, HB1: what the phase-4 wait leaves in flight
+
+    int zsplit = blockIdx.z;
+    int batch = 0;
+    if (epi_in.splits_per_batch > 0) {
+        batch = blockIdx.z / epi_in.splits_per_batch;
+        zsplit = blockIdx.z - batch * epi_in.splits_per_batch;
+        Ap += batch * epi_in.batch_a;
+        Bp += batch * epi_in.batch_b;
+    }
+    const Epi epi = epi_for_batch(epi_in, batch);
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // the ONLY LDS object: 2 x TILE
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned tile = big_tile_of(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(tile / (unsigned)tiles_n) * 256, n0 = (int64_t)(tile % (unsigned)tiles_n) * BN;
+    const int64_t kt_total = (K + P8_BK - 1) / P8_BK;
+    const int64_t kt_begin = (int64_t)zsplit * k_tiles_per_split;
+    int64_t kt_end = kt_begin + k_tiles_per_split;
+    if (kt_end > kt_total) kt_end = kt_total;
+    int64_t kt_full = K / P8_BK;                                     // tiles [kt_begin, kt_full) are full and live
+    if (kt_full > kt_end) kt_full = kt_end;
+
+    f32x4 acc[2][2][4][NI];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[i][j][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t wbase = (uint32_t)(uintptr_t)smem + (uint32_t)wave * 1024u;      // LDS address of this wave's 1 KiB piece of image 0
+    OpA ga;
+    OpB gb;
+    ga.prepare(Ap, lda, M, m0, kt_begin * P8_BK, wave);
+    gb.prepare(Bp, ldb, N, n0, kt_begin * P8_BK, wave);
+
+    u32x4 fa[4][2], fb0[NI][2], fb1[NI][2];                           // [repeat][k-step]
+    P8Reader<LA, 4> ra;
+    P8Reader<LB, NI> rb;
+    ra.prepare((uint32_t)(uintptr_t)smem, TILE, 4 * wr, 128, lane);
+    rb.prepare((uint32_t)(uintptr_t)smem + 2 * HA, TILE, NI * wc, ROWS_B, lane);
+    auto rd_a = [&](int P, int i) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[mi][ks] = ra.frag(P, i * HA, mi, ks, 128);
+    };
+    auto rd_b = [&](u32x4(&fb)[NI][2], int P, int j) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[ni][ks] = rb.frag(P, j * HB, ni, ks, ROWS_B);
+    };
+    auto mm = [&](auto ic, auto jc, const u32x4(&fb)[NI][2]) {
+        constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[i][j][mi][ni] = mfma16x32<CT>(fb[ni][ks], fa[mi][ks], acc[i][j][mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        P8_FENCE;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    constexpr int LGKM_B0 = (LA == LR ? 8 : 15);                      // reads of HA0 that may still be out when HB0's are done (4-bit counter)
+
+    // one K tile `u` out of buffer P (see the schedule in the header)
+    auto k_tile = [&](auto pc, auto chk, int64_t u) {
+        constexpr int P = decltype(pc)::value;
+        constexpr bool CHK = decltype(chk)::value;
+        constexpr int CUR = P * TILE, NXT = (P ^ 1) * TILE;
+        // phase 1
+        rd_b(fb0, P, 0);
+        P8_FENCE;
+        rd_a(P, 0);
+        P8_FENCE;
+        ga.template stage<CHK, NXT + HA>(1, wbase, u + 1, kt_end, K);
+        // HB0 is re-requested in phase 2: its reads (issued first) are retired here, ahead of this phase's barrier
+        if constexpr (LGKM_B0 == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+        P8_BAR();
+        mm(I0{}, I0{}, fb0);
+        P8_BAR();
+        // phase 2
+        rd_b(fb1, P, 1);
+        P8_FENCE;
+        gb.template stage<CHK, CUR + 2 * HA>(0, wbase, u + 2, kt_end, K);
+        P8_BAR();
+        mm(I0{}, I1{}, fb1);
+        P8_BAR();
+        // phase 3
+        rd_a(P, 1);
+        P8_FENCE;
+        ga.template stage<CHK, CUR>(0, wbase, u + 2, kt_end, K);
+        P8_BAR();
+        mm(I1{}, I1{}, fb1);
+        P8_BAR();
+        // phase 4
+        gb.template stage<CHK, CUR + 2 * HA + HB>(1, wbase, u + 2, kt_end, K);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
+        P8_BAR();
+        mm(I1{}, I0{}, fb0);
+        P8_BAR();
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+
+    // prologue: tile 0 whole, HB0 | HA0 | HB1 of tile 1 (HA1 of tile 1 is phase 1's request)
+    {
+        ga.template stage<true, 0>(0, wbase, kt_begin, kt_end, K);
+        ga.template stage<true, HA>(1, wbase, kt_begin, kt_end, K);
+        gb.template stage<true, 2 * HA>(0, wbase, kt_begin, kt_end, K);
+        gb.template stage<true, 2 * HA + HB>(1, wbase, kt_begin, kt_end, K);
+        gb.template stage<true, TILE + 2 * HA>(0, wbase, kt_begin + 1, kt_end, K);
+        ga.template stage<true, TILE>(0, wbase, kt_begin + 1, kt_end, K);
+        gb.template stage<true, TILE + 2 * HA + HB>(1, wbase, kt_begin + 1, kt_end, K);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT) : "memory");
+        P8_BAR();
+        if (wr == 1) P8_BAR();                                        // waves 4-7 run one barrier behind
+    }
+    int64_t u = kt_begin;
+    // main loop: pairs of K tiles whose requests (tiles u+1 .. u+3) are full and live
+    while (u + 3 < kt_full) {
+        k_tile(I0{}, F{}, u);
+        k_tile(I1{}, F{}, u + 1);
+        u += 2;
+    }
+    while (u < kt_end) {
+        k_tile(I0{}, T{}, u);
+        if (++u >= kt_end) break;
+        k_tile(I1{}, T{}, u);
+        ++u;
+    }
+    if (wr == 0) P8_BAR();                                            // (the barrier waves 4-7 took up front)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // zero-source requests past the end must not outlive the workgroup's LDS
+
+    // ---- epilogue: a lane holds C[m][n .. n+3] per accumulator ----
+    float* slab_base = slabs ? slabs + (int64_t)blockIdx.z * M * N : nullptr;
+    const int64_t mw = m0 + wr * 128 + (lane & 15), nw = n0 + wc * (2 * RUN_B) + (lane >> 4) * 4;
+    if constexpr (LOSS) {
+        // frame losses (vs_gemm_frame_loss): compare with the target frames instead of storing; partial sums per workgroup
+        float fl_s0 = 0.f, fl_s1 = 0.f;
+        const float fl_up = epi.fl_up[0];
+        const int fl_t = epi.fl_tdev[0];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int64_t n = nw + j * RUN_B + ni * 16;
+                const int64_t n_c = n + 3 < N ? n : N - 4;
+                const f32x4 bias4 = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n_c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 tg[4];
+                    int gg[4];
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        int64_t m = mw + i * 64 + mi * 16;
+                        if (m > M - 1) m = M - 1;
+                        tg[mi] = *reinterpret_cast<const f32x4*>(big_loss_target(epi, m, n_c, N, fl_t, gg[mi]));
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const int64_t m = mw + i * 64 + mi * 16;
+                        if (m < M && n + 3 < N) big_loss4(epi, m, n, N, gg[mi], acc[i][j][mi][ni], tg[mi], bias4, fl_up, fl_s0, fl_s1);
+                    }
+                }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { fl_s0 += __shfl_down(fl_s0, o, 64); fl_s1 += __shfl_down(fl_s1, o, 64); }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        if (lane == 0) { red[2 * wave] = fl_s0; red[2 * wave + 1] = fl_s1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int w = 0; w < 8; ++w) { a0 += red[2 * w]; a1 += red[2 * w + 1]; }
+            epi.fl_partials[2 * blockIdx.x] = a0;
+            epi.fl_partials[2 * blockIdx.x + 1] = a1;
+        }
+    } else {
+        // The stores that matter (Linear forward: bias + none / relu / leaky; input gradient: activation mask of the layer below) are
+        // straight-line code with the activation as a compile-time constant, accumulators in registers.  Everything else (sigmoid / tanh / elu,
+        // accumulate, NCHW scatter, odd alignments) takes the general store in a run-time loop: compact code, accumulators through scratch
+        // memory once (32 unrolled copies of the general store were 30 000 instructions per instantiation).
+        const bool mask_ok = !epi.mask || ((epi.mask_act == VS_ACT_RELU || epi.mask_act == VS_ACT_LEAKY) && (epi.ldmask & 3) == 0 && ((uintptr_t)epi.mask & 15) == 0);
+        const bool fast = !NCHW && mask_ok && !epi.accumulate && !epi.adam_m && (epi.ldc & 3) == 0 && (N & 3) == 0 && ((uintptr_t)epi.C & 15) == 0 &&
+                          (!epi.bias || ((uintptr_t)epi.bias & 15) == 0) && (epi.act == VS_ACT_NONE || epi.act == VS_ACT_RELU || epi.act == VS_ACT_LEAKY);
+        if (slab_base && (N & 3) == 0) {
+            // split-K partial: raw fp32, reduced (with the epilogue) by splitk_reduce_kernel
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const int64_t m = mw + i * 64 + mi * 16, n = nw + j * RUN_B + ni * 16;
+                            if (m < M && n < N) *reinterpret_cast<f32x4*>(slab_base + m * N + n) = acc[i][j][mi][ni];
+                        }
+        } else if (fast && !slab_base) {
+            const float mask_slope = epi.mask_act == VS_ACT_LEAKY ? 0.2f : 0.f;
+            auto store_all = [&](auto actc, auto wide) {
+                constexpr int ACT = decltype(actc)::value;
+                constexpr bool F32OUT = decltype(wide)::value;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int64_t n = nw + j * RUN_B + ni * 16;
+                        const int64_t n_c = n < N ? n : 0;
+                        const f32x4 bias4 = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n_c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int mi = 0; mi < 4; ++mi) {
+                                const int64_t m = mw + i * 64 + mi * 16;
+                                if (!(m < M && n < N)) continue;
+                                f32x4 r;
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) r[t] = vs_act(acc[i][j][mi][ni][t] * epi.alpha + bias4[t], ACT);
+                                if (epi.mask) {
+                                    f32x4 y;
+                                    if (epi.mask_dtype == VS_F32) y = *reinterpret_cast<const f32x4*>((const float*)epi.mask + m * epi.ldmask + n);
+                                    else {
+                                        const u16x4 yb = *reinterpret_cast<const u16x4*>((const unsigned short*)epi.mask + m * epi.ldmask + n);
+#pragma unroll
+                                        for (int t = 0; t < 4; ++t) y[t] = vs_h2f(yb[t], epi.mask_dtype);
+                                    }
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) r[t] *= y[t] > 0.f ? 1.f : mask_slope;
+                                }
+                                if constexpr (F32OUT) {
+                                    *reinterpret_cast<f32x4*>((float*)epi.C + m * epi.ldc + n) = r;
+                                } else {
+                                    const u16x4 hv = {vs_f2h(r[0], epi.c_dtype), vs_f2h(r[1], epi.c_dtype), vs_f2h(r[2], epi.c_dtype), vs_f2h(r[3], epi.c_dtype)};
+                                    *reinterpret_cast<u16x4*>((unsigned short*)epi.C + m * epi.ldc + n) = hv;
+                                }
+                            }
+                    }
+            };
+            auto by_type = [&](auto actc) {
+                if (epi.c_dtype == VS_F32) store_all(actc, std::true_type{});
+                else store_all(actc, std::false_type{});
+            };
+            if (epi.act == VS_ACT_RELU) by_type(std::integral_constant<int, VS_ACT_RELU>{});
+            else if (epi.act == VS_ACT_LEAKY) by_type(std::integral_constant<int, VS_ACT_LEAKY>{});
+            else by_type(std::integral_constant<int, VS_ACT_NONE>{});
+        } else {
+            // accumulators -> LDS (idle now; compile-time indices) -> a run-time loop over them: a lane reads back what it wrote itself
+            P8_BAR();                                                  // every wave's requests have landed (vmcnt(0) above): the buffers are free
+            f32x4* const stg = reinterpret_cast<f32x4*>(smem) + wave * (8 * NI * 64) + lane;
+            auto pass = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) stg[((j * 4 + mi) * NI + ni) * 64] = acc[i][j][mi][ni];
+#pragma unroll 1
+                for (int q = 0; q < 8 * NI; ++q) {
+                    const int ni = q % NI, mi = (q / NI) & 3, j = q / (4 * NI);
+                    const int64_t m = mw + i * 64 + mi * 16, n = nw + j * RUN_B + ni * 16;
+                    const f32x4 v = stg[q * 64];
+                    if (m < M && n < N) big_store4<NCHW>(epi, m, n, N, v, slab_base ? slab_base + m * N : nullptr);
+                }
+            };
+            pass(I0{});
+            pass(I1{});
+        }
+    }
+}
+
+// ---- when to take it ---------------------------------------------------------------------------------------------------------
+// One workgroup per CU (128 / 96 KiB of LDS).  VS_GEMM_P8: 0 = never, 1 = by plan (default), 2 = whenever the operands allow (tests).
+struct P8Plan { bool use; int ni; int splits; int64_t k_tiles_per_split; int tiles_m, tiles_n; };
+
+inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch, int lb) {
+    P8Plan p{false, 2, 1, vs_cdiv(K, P8_BK), (int)vs_cdiv(M, 256), (int)vs_cdiv(N, 256)};
+    const char* env = getenv("VS_GEMM_P8");                       // read per call: tests switch it
+    const int mode = env ? atoi(env) : 1;
+    if (compute == VS_F32 || mode == 0) return p;
+    const char* env_ni = getenv("VS_GEMM_P8_NI");
+    const int force_ni = env_ni ? atoi(env_ni) : 0;
+    auto fill_of = [&](int bn) { return (double)M * (double)N / ((double)vs_cdiv(M, 256) * 256.0 * (double)vs_cdiv(N, bn) * (double)bn); };
+    if (mode == 2) {
+        p.ni = (force_ni == 1 && lb == LR) ? 1 : 2;
+        p.tiles_n = (int)vs_cdiv(N, 128 * p.ni);
+        p.use = (int64_t)p.tiles_m * p.tiles_n * batch <= 65535;
+        return p;
+    }
+    if (M < 512 || N < 512 || p.k_tiles_per_split < 6) return p;
+    const int64_t t256 = (int64_t)p.tiles_m * p.tiles_n * batch;
+    if (t256 >= 160 && fill_of(256) >= 0.8) { p.use = true; return p; }
+    return p;
+}
+
+}  // namespace
