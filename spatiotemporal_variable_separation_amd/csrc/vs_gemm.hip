@@ -23,6 +23,7 @@
 #include "vs_gemm_glds.h"
 #include "vs_gemm_big.h"
 #include "vs_gemm_mid.h"
+#include "vs_gemm_p8.h"
 #include "vs_loss.h"
 
 namespace {
@@ -95,6 +96,50 @@ int launch_big_layout(int la, int lb, const void* A, int64_t lda, const void* B,
     if (la == LR && lb == LS) return launch_big<CT, LR, LS>(A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
     if (la == LS && lb == LR) return launch_big<CT, LS, LR>(A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
     return launch_big<CT, LS, LS>(A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
+}
+
+// the 256 x 256 / 256 x 128 tile with two staggered wave groups (vs_gemm_p8.h)
+template <int CT, int LA, int LB, int NI, bool LOSS = false>
+int launch_p8(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const P8Plan& pp, int batch, const Epi& epi, float* slabs,
+              hipStream_t stream) {
+    if constexpr (CT == VS_F32 || (NI == 1 && LB != LR)) {
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm: the staggered 256-row tile is a 16-bit kernel (256 x 128: B with the reduction index contiguous)");
+    } else {
+        auto kfn = gemm_p8_kernel<CT, LA, LB, NI, false, LOSS>;
+        constexpr int lds = 2 * (2 * 128 * P8_BK * 2 + 2 * 64 * NI * P8_BK * 2);
+        static bool attr_set = false;                  // 96 / 128 KiB of dynamic LDS: above the 64 KiB default limit
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return vs_fail(VS_ERR_LAUNCH, "vs_gemm: cannot raise the dynamic LDS limit to %d bytes", lds);
+            attr_set = true;
+        }
+        dim3 grid((unsigned)(pp.tiles_m * pp.tiles_n), 1, (unsigned)(pp.splits * batch));
+        hipLaunchKernelGGL(kfn, grid, dim3(512), lds, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, (int)pp.k_tiles_per_split,
+                           pp.tiles_n, epi, slabs);
+        VS_CHECK_LAUNCH("vs_gemm (staggered 256-row tile)");
+        return VS_OK;
+    }
+}
+
+template <int CT>
+int launch_p8_layout(int la, int lb, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const P8Plan& pp, int batch,
+                     const Epi& epi, float* slabs, hipStream_t stream) {
+    if (pp.ni == 1) {
+        if (la == LR) return launch_p8<CT, LR, LR, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        return launch_p8<CT, LS, LR, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+    }
+    if (la == LR && lb == LR) return launch_p8<CT, LR, LR, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+    if (la == LR && lb == LS) return launch_p8<CT, LR, LS, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+    if (la == LS && lb == LR) return launch_p8<CT, LS, LR, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+    return launch_p8<CT, LS, LS, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+}
+
+inline P8Plan p8_plan_for(int compute, int64_t M, int64_t N, int64_t K, int64_t batch, const void* A, int64_t lda, int la, const void* B, int64_t ldb, int lb,
+                          int64_t stride_a, int64_t stride_b) {
+    P8Plan pp = make_p8_plan(compute, M, N, K, batch, lb);
+    if (pp.use && !(glds_operand_ok(A, lda, la, M, K, stride_a) && glds_operand_ok(B, ldb, lb, N, K, stride_b))) pp.use = false;
+    if (pp.use && (lda >= (1ll << 22) || ldb >= (1ll << 22))) pp.use = false;       // 32-bit lane offsets inside a tile
+    return pp;
 }
 
 template <int CT, int LA, int LB>
@@ -236,9 +281,12 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
     VS_CHECK_ARG(lda >= (layout_a == LR ? K : M) && ldb >= (layout_b == LR ? K : N) && ldc >= N, "vs_gemm_batched: leading dimension too small");
     Plan plan = make_plan(compute, M, N, K, batch);
     plan.batch = batch;
-    const BigPlan bp = big_plan_for(compute, M, N, K, batch, A, lda, layout_a, B, ldb, layout_b, stride_a, stride_b);
+    const P8Plan pp = p8_plan_for(compute, M, N, K, batch, A, lda, layout_a, B, ldb, layout_b, stride_a, stride_b);
+    BigPlan bp = big_plan_for(compute, M, N, K, batch, A, lda, layout_a, B, ldb, layout_b, stride_a, stride_b);
+    if (pp.use) bp.use = false;
     MidPlan mp{false, 1, 0, 0, 0, 5};
-    if (!bp.use) mp = mid_plan_for(compute, M, N, K, batch, A, lda, layout_a, B, ldb, layout_b, stride_a, stride_b);
+    if (!bp.use && !pp.use) mp = mid_plan_for(compute, M, N, K, batch, A, lda, layout_a, B, ldb, layout_b, stride_a, stride_b);
+    if (pp.use) { plan.splits = pp.splits; plan.k_tiles_per_split = pp.k_tiles_per_split; }
     if (bp.use) { plan.splits = bp.splits; plan.k_tiles_per_split = bp.k_tiles_per_split; }
     if (mp.use) { plan.splits = mp.splits; plan.k_tiles_per_split = mp.k_tiles_per_split; }
     Epi epi{C, ldc, c_dtype, alpha, nullptr, VS_ACT_NONE, nullptr, 0, 0, 0, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0, plan.splits, stride_a, stride_b, stride_c};
@@ -249,7 +297,7 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
             return vs_fail(VS_ERR_WORKSPACE, "vs_gemm_batched: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         slabs = (float*)workspace;
         // one counter per (problem, tile) of the kernel that runs: 128-wide tiles on the ring kernel, plan.bm x plan.bn otherwise
-        if (!bp.use && (mp.use || !(plan.bm == 128 && plan.bn == 128))) {      // (the 128x128 LDS-DMA tile never splits in practice: no fix-up there)
+        if (!bp.use && !pp.use && (mp.use || !(plan.bm == 128 && plan.bn == 128))) {      // (the 128x128 LDS-DMA tile never splits in practice: no fix-up there)
             if (need < (1ull << 31)) epi.sk_counters = sk_take(batch * (mp.use ? (int64_t)mp.tiles_m * mp.tiles_n : vs_cdiv(M, plan.bm) * vs_cdiv(N, plan.bn)),
                                                              (int64_t)plan.splits * (mp.use ? 128 * 128 : plan.bm * plan.bn) * 4);
             epi.sk_splits = plan.splits;
@@ -257,7 +305,10 @@ extern "C" int vs_gemm_batched(int compute, int batch, int64_t M, int64_t N, int
         }
     }
     int rc;
-    if (bp.use)
+    if (pp.use)
+        rc = compute == VS_BF16 ? launch_p8_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream)
+                                : launch_p8_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+    else if (bp.use)
         rc = compute == VS_BF16 ? launch_big_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream)
                                 : launch_big_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, batch, epi, slabs, stream);
     else if (mp.use)
@@ -329,18 +380,24 @@ extern "C" int vs_gemm_frame_loss(int compute, int64_t M, int64_t N, int64_t K, 
     int rc = fill_loss_args(a, nullptr, full, nullptr, t_random_dev, ae_shift, first_forecast, M / G, G, T, N, s_old, s_new, n_s, t0, Bt, Ct,
                             average_tloss, lambdas);
     if (rc != VS_OK) return rc;
+    const P8Plan pp = p8_plan_for(compute, M, N, K, 1, A, lda, LR, W, ldw, LR, 0, 0);
+    const bool p8 = pp.use && pp.ni == 2 && pp.splits == 1 && (int64_t)pp.tiles_m * pp.tiles_n <= VS_LOSS_MAX_PARTIALS;
     const BigPlan bp = big_plan_for(compute, M, N, K, 1, A, lda, LR, W, ldw, LR, 0, 0);
-    if (!bp.use || bp.splits != 1 || (int64_t)bp.tiles_m * bp.tiles_n > VS_LOSS_MAX_PARTIALS)
-        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm_frame_loss: the problem does not run on the 256x256 tile kernel");
+    if (!p8 && (!bp.use || bp.splits != 1 || (int64_t)bp.tiles_m * bp.tiles_n > VS_LOSS_MAX_PARTIALS))
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm_frame_loss: the problem does not run on the 256x256 tile kernels");
     Epi epi{nullptr, N, VS_F32, 1.f, bias, act, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     epi.fl_full = full; epi.fl_tdev = t_random_dev; epi.fl_ae_shift = ae_shift; epi.fl_first = first_forecast; epi.fl_G = G; epi.fl_T = T;
     epi.fl_up = grad_total; epi.fl_l_ae = a.l_ae; epi.fl_l_pred = a.l_pred; epi.fl_inv_ae = a.inv_ae; epi.fl_inv_pred = a.inv_pred;
     epi.fl_dz = dz; epi.fl_dz_dtype = dz_dtype; epi.fl_partials = out + 16;
-    rc = compute == VS_BF16 ? launch_big<VS_BF16, LR, LR, true>(A, lda, W, ldw, M, N, K, bp, 1, epi, nullptr, stream)
-                            : launch_big<VS_F16, LR, LR, true>(A, lda, W, ldw, M, N, K, bp, 1, epi, nullptr, stream);
+    if (p8)
+        rc = compute == VS_BF16 ? launch_p8<VS_BF16, LR, LR, 2, true>(A, lda, W, ldw, M, N, K, pp, 1, epi, nullptr, stream)
+                                : launch_p8<VS_F16, LR, LR, 2, true>(A, lda, W, ldw, M, N, K, pp, 1, epi, nullptr, stream);
+    else
+        rc = compute == VS_BF16 ? launch_big<VS_BF16, LR, LR, true>(A, lda, W, ldw, M, N, K, bp, 1, epi, nullptr, stream)
+                                : launch_big<VS_F16, LR, LR, true>(A, lda, W, ldw, M, N, K, bp, 1, epi, nullptr, stream);
     if (rc != VS_OK) return rc;
     LossGrads gr{grad_total, dz, dz_dtype, act, ds_old, ds_new, dt0};
-    hipLaunchKernelGGL(frame_loss_finish_kernel, dim3(1), dim3(256), 0, stream, a, out, bp.tiles_m * bp.tiles_n, gr);
+    hipLaunchKernelGGL(frame_loss_finish_kernel, dim3(1), dim3(256), 0, stream, a, out, p8 ? pp.tiles_m * pp.tiles_n : bp.tiles_m * bp.tiles_n, gr);
     VS_CHECK_LAUNCH("vs_gemm_frame_loss");
     return VS_OK;
 }
@@ -383,9 +440,12 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
     VS_CHECK_ARG(act >= VS_ACT_NONE && act <= VS_ACT_ELU, "vs_gemm: bad activation");
     Epi epi{C, ldc, c_dtype, alpha, bias, act, mask, ldmask, mask_dtype, mask_act, accumulate, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     Plan plan = make_plan(compute, M, N, K, 1, layout_a == LR && layout_b == LR);
-    const BigPlan bp = big_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);
+    const P8Plan pp = p8_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);
+    BigPlan bp = big_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);
+    if (pp.use) bp.use = false;
     MidPlan mp{false, 1, 0, 0, 0, 5};
-    if (!bp.use) mp = mid_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);
+    if (!bp.use && !pp.use) mp = mid_plan_for(compute, M, N, K, 1, A, lda, layout_a, B, ldb, layout_b, 0, 0);
+    if (pp.use) { plan.splits = pp.splits; plan.k_tiles_per_split = pp.k_tiles_per_split; }
     if (bp.use) { plan.splits = bp.splits; plan.k_tiles_per_split = bp.k_tiles_per_split; }
     if (mp.use) { plan.splits = mp.splits; plan.k_tiles_per_split = mp.k_tiles_per_split; }
     float* slabs = nullptr;
@@ -394,7 +454,7 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
         if (!workspace || workspace_bytes < need)
             return vs_fail(VS_ERR_WORKSPACE, "vs_gemm: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
         slabs = (float*)workspace;
-        if (!bp.use && (mp.use || !(plan.bm == 128 && plan.bn == 128))) {
+        if (!bp.use && !pp.use && (mp.use || !(plan.bm == 128 && plan.bn == 128))) {
             if (need < (1ull << 31)) epi.sk_counters = sk_take(mp.use ? (int64_t)mp.tiles_m * mp.tiles_n : vs_cdiv(M, plan.bm) * vs_cdiv(N, plan.bn),
                                                              (int64_t)plan.splits * (mp.use ? 128 * 128 : plan.bm * plan.bn) * 4);
             epi.sk_splits = plan.splits;
@@ -402,7 +462,10 @@ extern "C" int vs_gemm(int compute, int64_t M, int64_t N, int64_t K, const void*
         }
     }
     int rc;
-    if (bp.use)
+    if (pp.use)
+        rc = compute == VS_BF16 ? launch_p8_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, pp, 1, epi, slabs, stream)
+                                : launch_p8_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, pp, 1, epi, slabs, stream);
+    else if (bp.use)
         rc = compute == VS_BF16 ? launch_big_layout<VS_BF16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, 1, epi, slabs, stream)
                                 : launch_big_layout<VS_F16>(layout_a, layout_b, A, lda, B, ldb, M, N, K, bp, 1, epi, slabs, stream);
     else if (mp.use)

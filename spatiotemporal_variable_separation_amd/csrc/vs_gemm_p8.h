@@ -484,6 +484,13 @@ inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t
     if (M < 512 || N < 512 || p.k_tiles_per_split < 6) return p;
     const int64_t t256 = (int64_t)p.tiles_m * p.tiles_n * batch;
     if (t256 >= 160 && fill_of(256) >= 0.8) { p.use = true; return p; }
+    // 256 x 128 where the 256-wide tiles leave most CUs idle (decoder layers of the WaveEq model, 3328 x 1200: 65 -> 130 tiles): VS_GEMM_P8_NI=1
+    const int64_t t128 = (int64_t)p.tiles_m * vs_cdiv(N, 128) * batch;
+    if (force_ni == 1 && lb == LR && t128 >= 96 && t128 <= 256 && fill_of(128) >= 0.85 && p.k_tiles_per_split >= 8) {
+        p.ni = 1;
+        p.tiles_n = (int)vs_cdiv(N, 128);
+        p.use = true;
+    }
     return p;
 }
 

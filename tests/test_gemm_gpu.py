@@ -322,11 +322,13 @@ def test_gemm_big_tile_all_layouts(dtype, la, lb, shape):
     from oracle.detdata import det_uniform
     bias = ((det_uniform((N,), 9) - 0.5) * 0.5).cuda()
     os.environ['VS_GEMM_BIG'] = '2'                  # take the 256x256 tile whatever the plan would say (it is read per call)
+    os.environ['VS_GEMM_P8'] = '0'                   # (the staggered tile has tests of its own below)
     try:
         out = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='relu')
         out16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=dtype)
     finally:
         del os.environ['VS_GEMM_BIG']
+        del os.environ['VS_GEMM_P8']
     torch.cuda.synchronize()
     ref = a64 @ b64.t()
     refa = torch.relu(ref + bias.cpu().double())
@@ -356,12 +358,14 @@ def test_gemm_mid_tile_all_layouts(dtype, la, lb, shape, mode):
     bias = ((det_uniform((N,), 19) - 0.5) * 0.5).cuda()
     os.environ['VS_GEMM_MID'] = mode
     os.environ['VS_GEMM_BIG'] = '0'
+    os.environ['VS_GEMM_P8'] = '0'
     try:
         out = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='relu')
         out16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=dtype)
     finally:
         del os.environ['VS_GEMM_MID']
         del os.environ['VS_GEMM_BIG']
+        del os.environ['VS_GEMM_P8']
     torch.cuda.synchronize()
     ref = a64 @ b64.t()
     refa = torch.relu(ref + bias.cpu().double())
@@ -437,3 +441,105 @@ def test_splitk_finished_in_launch_batched_and_concurrent():
         assert all(torch.equal(o, one) for o in outs)
     finally:
         del os.environ['VS_GEMM_SPLITK_FUSED']
+
+
+# ---- the staggered 256 x 256 / 256 x 128 tile (vs_gemm_p8.h): two wave groups half a phase apart, two 64-deep LDS-DMA buffers, counted waits ----
+P8_SHAPES = [(3328, 4096, 1200), (3328, 1200, 4096), (4096, 1200, 3328), (3328, 1200, 1200), (256, 256, 64), (264, 520, 136),
+             (1000, 1016, 520), (520, 2048, 776)]
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('la,lb,ni', [(0, 0, '2'), (0, 1, '2'), (1, 0, '2'), (1, 1, '2'), (0, 0, '1'), (1, 0, '1')])
+@pytest.mark.parametrize('shape', P8_SHAPES)
+def test_gemm_p8_tile_all_layouts(dtype, la, lb, ni, shape):
+    """Every operand layout and both tile widths of the staggered tile, forced (VS_GEMM_P8=2): one K tile only, row / column / K tails (the
+    partial K tile reads zeros), the straight-line epilogues (bias + relu to fp32, 16-bit output, leaky mask) and the general one (sigmoid;
+    accumulate), against fp64 on the same rounded operands."""
+    from spatiotemporal_variable_separation_amd import ops
+    from oracle.detdata import det_uniform
+    M, N, K = shape
+    a64, a = _operand(M, K, la, dtype, 23)
+    b64, b = _operand(N, K, lb, dtype, 25)
+    bias = ((det_uniform((N,), 29) - 0.5) * 0.5).cuda()
+    mask = (det_uniform((M, N), 31) - 0.3).to(dtype)
+    prev = det_uniform((M, N), 33)
+    acc = prev.clone().cuda()
+    with _Env(VS_GEMM_P8='2', VS_GEMM_P8_NI=ni):
+        out = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='relu')
+        out16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=dtype)
+        outm = ops.gemm(a, la, b, lb, M, N, K, alpha=0.5, mask=mask.cuda(), mask_act='leaky_relu')
+        outs = ops.gemm(a, la, b, lb, M, N, K, alpha=0.05, bias=bias, act='sigmoid')
+        ops.gemm(a, la, b, lb, M, N, K, out=acc, accumulate=True)
+    torch.cuda.synchronize()
+    ref = a64 @ b64.t()
+
+    def rel(x, r):
+        return ((x.cpu().double() - r).norm() / r.norm()).item()
+    assert rel(out, torch.relu(ref + bias.cpu().double())) < 2e-6, f'{dtype} ({la},{lb}) ni {ni} {shape}: bias + relu'
+    assert rel(out16, ref) < (6e-3 if dtype == torch.bfloat16 else 8e-4), f'{dtype} ({la},{lb}) ni {ni} {shape}: 16-bit output'
+    assert rel(outm, 0.5 * ref * torch.where(mask.double() > 0, 1.0, 0.2)) < 2e-6, f'{dtype} ({la},{lb}) ni {ni} {shape}: leaky mask'
+    assert rel(outs, torch.sigmoid(0.05 * ref + bias.cpu().double())) < 2e-6, f'{dtype} ({la},{lb}) ni {ni} {shape}: sigmoid'
+    assert rel(acc, prev.double() + ref) < 2e-6, f'{dtype} ({la},{lb}) ni {ni} {shape}: accumulate'
+
+
+@pytest.mark.parametrize('ni', ['2', '1'])
+def test_gemm_p8_integer_exact_and_repeatable(ni):
+    """Small-integer operands (every product and sum exact in fp32): the staggered tile must reproduce the fp64 contraction BIT FOR BIT, on
+    every one of 40 back-to-back launches beside a bandwidth-hungry kernel on another stream (a fragment read that overtakes its LDS-DMA or
+    a request that overtakes the last read of its image shows up as rare wrong tiles, not as a tolerance miss)."""
+    from spatiotemporal_variable_separation_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K, la, lb) in [(1000, 1016, 1224, 0, 0), (776, 520, 3336, 1, 0)] + ([(1016, 776, 1224, 0, 1), (520, 1000, 2056, 1, 1)] if ni == '2' else []):
+        a = torch.randint(-2, 3, (M, K), generator=g).float()
+        b = torch.randint(-2, 3, (N, K), generator=g).float()
+        ref = a @ b.t()
+        aa = a.to(torch.bfloat16).cuda()
+        bb = b.to(torch.bfloat16).cuda()
+        aa = aa if la == 0 else aa.t().contiguous()
+        bb = bb if lb == 0 else bb.t().contiguous()
+        noise = torch.empty(64 << 20, device='cuda')
+        side = torch.cuda.Stream()
+        with _Env(VS_GEMM_P8='2', VS_GEMM_P8_NI=ni):
+            for it in range(40):
+                if it % 3 == 0:
+                    with torch.cuda.stream(side):
+                        noise.add_(1.0)
+                out = ops.gemm(aa, la, bb, lb, M, N, K)
+                assert torch.equal(out.cpu(), ref), f'ni {ni} ({la},{lb}) {M}x{N}x{K} launch {it}: max diff {(out.cpu() - ref).abs().max()}'
+        torch.cuda.synchronize()
+
+
+def test_gemm_p8_default_plan_takes_the_decoder_layer():
+    """Without any switch the last decoder layer of the WaveEq model (3328 x 4096 x 1200) runs on the staggered tile: same numbers as with the
+    tile forced, and as the fp64 contraction."""
+    from spatiotemporal_variable_separation_amd import ops
+    M, N, K = 3328, 4096, 1200
+    a64, a = _operand(M, K, 0, torch.bfloat16, 43)
+    b64, b = _operand(N, K, 0, torch.bfloat16, 45)
+    out = ops.gemm(a, 0, b, 0, M, N, K)
+    with _Env(VS_GEMM_P8='2'):
+        forced = ops.gemm(a, 0, b, 0, M, N, K)
+    with _Env(VS_GEMM_P8='0'):
+        old = ops.gemm(a, 0, b, 0, M, N, K)
+    ref = a64 @ b64.t()
+    assert torch.equal(out, forced)
+    assert ((out.cpu().double() - ref).norm() / ref.norm()).item() < 2e-6
+    assert ((old.cpu().double() - ref).norm() / ref.norm()).item() < 2e-6
