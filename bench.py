@@ -563,6 +563,21 @@ def rooflines(res, workload, precision, top=6, live=None):
         return out
     roofs = [roof_of(g, e) for g, e in groups.items()]
     roofs.sort(key=lambda r: -r['us_per_step'])
+    # BOTH roofs of the dominant group and of the whole step: which one is nearer.  Bytes: the PMC traffic table when
+    # one exists for these sources, the algorithmic bytes otherwise (`bytes_from`); step-level sums run over every group.
+    top_g = roofs[0]
+    grp_bytes = top_g.get('traffic_per_step') if (top_g.get('traffic_per_step') and not top_g.get('traffic_stale')) else top_g['algorithmic_bytes_per_step']
+    tot_flops = sum(e['flops'] for e in groups.values()) / sampled
+    tot_alg_bytes = sum(e['bytes'] for e in groups.values()) / sampled
+    tot_traffic = sum(t_['bytes_per_step'] for t_ in (traffic or {}).get('groups', {}).values()) if (traffic and traffic_fresh) else None
+    step_s = ms * 1e-3
+    both = {'group_mfma': round(sum(e['flops'] for g_, e in groups.items() if g_ == top_g['kernel']) / sampled / (top_g['us_per_step'] * 1e-6) / 1e12 / peak_mfma, 4),
+            'group_hbm': round(grp_bytes / (top_g['us_per_step'] * 1e-6) / 1e9 / 8000.0, 4),
+            'step_mfma': round(tot_flops / step_s / 1e12 / peak_mfma, 4),
+            'step_hbm': round((tot_traffic if tot_traffic else tot_alg_bytes) / step_s / 1e9 / 8000.0, 4),
+            'bytes_from': 'pmc' if tot_traffic else 'algorithmic'}
+    both['nearer_roof'] = 'hbm' if both['step_hbm'] > both['step_mfma'] else 'mfma'
+    top_g['both_bounds'] = both
     if replay:
         # kernel launches of one replayed step, all groups (the recording's kernel nodes): into the dominant group's
         # object so that the line and bench_detail.json carry it
@@ -571,7 +586,7 @@ def rooflines(res, workload, precision, top=6, live=None):
 
 
 _ROOF_KEYS = ('kernel', 'bound', 'peak', 'unit', 'achieved', 'frac', 'us_per_step', 'launches_per_step', 'kernel_launches_per_step', 'avg_launch_us', 'share_of_step',
-              'traffic', 'traffic_per_step', 'algorithmic_bytes_per_step', 'algorithmic_per_step', 'timing', 'source', 'stale', 'traffic_stale')
+              'traffic', 'traffic_per_step', 'algorithmic_bytes_per_step', 'algorithmic_per_step', 'timing', 'source', 'stale', 'traffic_stale', 'both_bounds')
 
 
 def compact_line(full, limit=4000):

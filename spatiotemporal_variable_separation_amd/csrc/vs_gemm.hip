@@ -102,8 +102,8 @@ int launch_big_layout(int la, int lb, const void* A, int64_t lda, const void* B,
 template <int CT, int LA, int LB, int NI, bool LOSS = false>
 int launch_p8(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const P8Plan& pp, int batch, const Epi& epi, float* slabs,
               hipStream_t stream) {
-    if constexpr (CT == VS_F32 || (NI == 1 && LB != LR)) {
-        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm: the staggered 256-row tile is a 16-bit kernel (256 x 128: B with the reduction index contiguous)");
+    if constexpr (CT == VS_F32) {
+        return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm: the staggered 256-row tile is a 16-bit kernel");
     } else {
         auto kfn = gemm_p8_kernel<CT, LA, LB, NI, false, LOSS>;
         constexpr int lds = 2 * (2 * 128 * P8_BK * 2 + 2 * 64 * NI * P8_BK * 2);
@@ -125,8 +125,10 @@ template <int CT>
 int launch_p8_layout(int la, int lb, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const P8Plan& pp, int batch,
                      const Epi& epi, float* slabs, hipStream_t stream) {
     if (pp.ni == 1) {
-        if (la == LR) return launch_p8<CT, LR, LR, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
-        return launch_p8<CT, LS, LR, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        if (la == LR && lb == LR) return launch_p8<CT, LR, LR, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        if (la == LR && lb == LS) return launch_p8<CT, LR, LS, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        if (la == LS && lb == LR) return launch_p8<CT, LS, LR, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        return launch_p8<CT, LS, LS, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
     }
     if (la == LR && lb == LR) return launch_p8<CT, LR, LR, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
     if (la == LR && lb == LS) return launch_p8<CT, LR, LS, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);

@@ -49,6 +49,14 @@ __device__ __forceinline__ const char* p8_uniform64(const char* p) {
     return reinterpret_cast<const char*>((uintptr_t)(((uint64_t)hi << 32) | lo));
 }
 
+// S image: the 32-byte slot (16 output indices) p of k-row kr lives in slot p ^ key(kr); the 8 k-rows a 32-lane half of ds_read_b64_tr_b16
+// touches (kr = 8 g + q, g of two values, q = 0..3; the second read of a fragment: + 4) land on 8 different 32-byte pieces of the bank row
+template <int ROWS>
+__device__ __forceinline__ constexpr int p8_s_slot_key(int kr) {
+    return ROWS == 128 ? ((kr & 3) | (((kr >> 3) & 1) << 2))          // 256-byte k-rows: one k-row = one bank row, 8 slots
+                       : (((kr >> 1) & 1) | (((kr >> 3) & 1) << 1));  // 128-byte k-rows: two k-rows per bank row (kr & 1), 4 slots each
+}
+
 // LDS row -> tile row / column of half-tile image h; RUN = consecutive indices a wave owns per quadrant (A: 64, B: 16 NI).
 // A: 2 wave rows x 64 = 128 LDS rows; B: 4 wave columns x 16 NI = 64 NI LDS rows
 __device__ __forceinline__ constexpr int p8_tile_index(int lds_row, int h, int run) { return (lds_row / run) * (2 * run) + h * run + (lds_row % run); }
@@ -77,9 +85,11 @@ struct P8Operand {
                     kofs[j] = 8 * s;
                     voff[h][j] = (uint32_t)(((g - i0) * ld + 8 * s) * 2);
                 } else {
-                    const int kr = 4 * wave + 32 * j + (i >> 4);                     // k-row of this lane's piece
-                    const int f = (kr & 3) | (((kr >> 3) & 1) << 2);
-                    const int nl = ((((i & 15) >> 1) ^ f) << 4) + (i & 1) * 8;       // LDS column (output index) of the piece: ROWS == 128 only
+                    // k-row of this lane's piece and the LDS column (output index) of the 32-byte slot it fills: 256-byte k-rows (ROWS 128, 4 per
+                    // wave instruction) or 128-byte k-rows (ROWS 64, 8 per wave instruction)
+                    const int kr = ROWS == 128 ? 4 * wave + 32 * j + (i >> 4) : 8 * wave + (i >> 3);
+                    const int f = p8_s_slot_key<ROWS>(kr);
+                    const int nl = ROWS == 128 ? ((((i & 15) >> 1) ^ f) << 4) + (i & 1) * 8 : ((((i & 7) >> 1) ^ f) << 4) + (i & 1) * 8;
                     int64_t g = i0 + p8_tile_index(nl, h, RUN);
                     if (g > rows - 8) g = rows - 8;                                  // rows % 8 == 0: a piece is inside or outside as a whole
                     kofs[j] = kr;
@@ -121,7 +131,7 @@ struct P8Operand {
 // LDS address is kept in a few base registers per K-tile buffer (NB per operand), everything else is an immediate offset below 64 KiB
 // (buffer 1 starts 64 KiB in: folded into the address by the compiler, every read of it would want a register of its own).
 //   R image: base[ks]   = lane part with the k-step's slot permutation;      + image + R0 * 128
-//   S image: base[rep]  = lane part with fragment repeat rep's slot (4 wr + mi, or 2 wc + ni) permuted in;   + image + ks * 8192 (+ 1024)
+//   S image: base[rep]  = lane part with fragment repeat rep's slot (4 wr + mi, or NI wc + ni) permuted in;   + image + ks * 32 k-rows (+ 4 k-rows)
 typedef __attribute__((address_space(3))) const u32x4 p8_lds_u32x4;
 typedef __attribute__((address_space(3))) vs_i16x4 p8_lds_i16x4;
 
@@ -142,7 +152,7 @@ struct P8Reader {
                     a = area + P * tile_bytes + first_rep * 2048 + (r >> 3) * 1024 + (r & 7) * 128 + ((((lane >> 4) + 4 * x) ^ (r >> 1)) << 4);
                 } else {
                     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-                    const int f = q | ((g & 1) << 2);
+                    const int f = rows == 128 ? p8_s_slot_key<128>(8 * g + q) : p8_s_slot_key<64>(8 * g + q);
                     a = area + P * tile_bytes + (8 * g + q) * (rows * 2) + (((first_rep + x) ^ f) << 5) + 8 * pp;
                 }
                 asm volatile("" : "+v"(a));                            // opaque: keeps 64 KiB out of the immediate offsets
@@ -177,7 +187,6 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
     constexpr int RUN_B = 16 * NI, ROWS_B = 64 * NI;
     typedef P8Operand<LA, 128, 64> OpA;
     typedef P8Operand<LB, ROWS_B, RUN_B> OpB;
-    static_assert(LB == LR || NI == 2, "an S image of B is 128 columns wide");
     constexpr int HA = OpA::HALF_BYTES, HB = OpB::HALF_BYTES;
     constexpr int TILE = 2 * HA + 2 * HB;                             // one K tile: HA0 | HA1 | HB0 | HB1
     constexpr int WAIT = OpB::NJ * 2 + OpA::NJ;                       // requests of HB0, HA0, HB1: what the phase-4 wait leaves in flight
@@ -476,7 +485,7 @@ inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t
     const int force_ni = env_ni ? atoi(env_ni) : 0;
     auto fill_of = [&](int bn) { return (double)M * (double)N / ((double)vs_cdiv(M, 256) * 256.0 * (double)vs_cdiv(N, bn) * (double)bn); };
     if (mode == 2) {
-        p.ni = (force_ni == 1 && lb == LR) ? 1 : 2;
+        p.ni = force_ni == 1 ? 1 : 2;
         p.tiles_n = (int)vs_cdiv(N, 128 * p.ni);
         p.use = (int64_t)p.tiles_m * p.tiles_n * batch <= 65535;
         return p;
@@ -484,9 +493,10 @@ inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t
     if (M < 512 || N < 512 || p.k_tiles_per_split < 6) return p;
     const int64_t t256 = (int64_t)p.tiles_m * p.tiles_n * batch;
     if (t256 >= 160 && fill_of(256) >= 0.8) { p.use = true; return p; }
-    // 256 x 128 where the 256-wide tiles leave most CUs idle (decoder layers of the WaveEq model, 3328 x 1200: 65 -> 130 tiles): VS_GEMM_P8_NI=1
+    // 256 x 128 where the 256-wide tiles leave most CUs idle (decoder layers of the WaveEq model, 3328 x 1200: 65 -> 130 tiles; measured in the
+    // replayed WaveEq step against the 64 x 64 tile, two interleaved pairs: 1.2309 / 1.2380 vs 1.2424 / 1.2459 ms).  VS_GEMM_P8_NI=2: never.
     const int64_t t128 = (int64_t)p.tiles_m * vs_cdiv(N, 128) * batch;
-    if (force_ni == 1 && lb == LR && t128 >= 96 && t128 <= 256 && fill_of(128) >= 0.85 && p.k_tiles_per_split >= 8) {
+    if (force_ni != 2 && t128 >= 96 && t128 <= 256 && fill_of(128) >= 0.85 && p.k_tiles_per_split >= 8) {
         p.ni = 1;
         p.tiles_n = (int)vs_cdiv(N, 128);
         p.use = true;

@@ -46,7 +46,7 @@ GROUPS = [
     ('vs_convT_tap', r'^vs_convT_tap:', r'convt_k4s2_tap_kernel', 'mfma'),
     ('vs_conv3_tap', r'^vs_conv3_tap:', r'conv_k3s1_tap_kernel', 'mfma'),
     # dense GEMMs and the convolutions that run as (gather +) GEMM (+ split-K reduce): one pool of GEMM kernels serves them all
-    ('vs_gemm+cols', r'^vs_gemm<|^vs_conv_cols:|^vs_convT_cols:', r'gemm_kernel<|gemm_glds_kernel<|gemm_big_kernel<|gemm_mid_kernel<\d, \d, \d, \w+, \d+, false>|'
+    ('vs_gemm+cols', r'^vs_gemm<|^vs_conv_cols:|^vs_convT_cols:', r'gemm_kernel<|gemm_glds_kernel<|gemm_big_kernel<|gemm_p8_kernel<|gemm_mid_kernel<\d, \d, \d, \w+, \d+, false>|'
      r'splitk_reduce_kernel|im2col_|convt_k4s2_small_kernel|gather_small_s1_kernel|gather_rowdot_kernel', 'mfma'),
     ('vs_bn_small', r'^vs_bn_fwd_small|^vs_bn_bwd_small', r'bn_fwd_small|bn_bwd_small', 'hbm'),
     # first / last layers (1..8 channels on the image side): one VALU pass over the many-channel map, no column matrix

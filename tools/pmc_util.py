@@ -27,7 +27,7 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatiotemporal_variable_separation_amd.profiling import group_of_kernel, source_sha  # noqa: E402
 
-SPLIT_BY_GRID = re.compile(r'conv3_band_kernel|wgrad3_band_kernel|conv3_img16_kernel|convt_k4s2_tap_kernel|gemm_big_kernel|gemm_mid_kernel|gemm_kernel<')
+SPLIT_BY_GRID = re.compile(r'conv3_band_kernel|wgrad3_band_kernel|conv3_img16_kernel|convt_k4s2_tap_kernel|gemm_big_kernel|gemm_p8_kernel|gemm_mid_kernel|gemm_kernel<')
 
 
 def short(name):

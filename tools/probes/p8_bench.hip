@@ -60,7 +60,9 @@ int main(int argc, char** argv) {
         if (la == 1 && lb == 1) fn = launch<LS, LS, 2>;
     } else {
         if (la == 0 && lb == 0) fn = launch<LR, LR, 1>;
+        if (la == 0 && lb == 1) fn = launch<LR, LS, 1>;
         if (la == 1 && lb == 0) fn = launch<LS, LR, 1>;
+        if (la == 1 && lb == 1) fn = launch<LS, LS, 1>;
     }
     if (!fn) { fprintf(stderr, "unsupported layout / ni\n"); return 2; }
     const bool exact = !strcmp(mode, "int");
