@@ -538,6 +538,10 @@ int vs_mlp_rollout_xcd_local_set(int allowed);
  * applies an update computed from a timed-out exchange.  The caller reads and clears the word (it is sticky).  NULL unregisters.        */
 int vs_exchange_guard_set(void* word);
 void* vs_exchange_guard_get(void);
+/* Optional companion of the guard: a second caller-owned 4-byte device word that vs_adam_step_increment* bumps by one every time the guard
+ * made it skip a step (reference train.py:156-158: `optimizer.step()` did not happen), so that the host can report HOW MANY steps a sticky
+ * time-out cost between two reads.  NULL unregisters; the caller reads and clears it.                                                     */
+int vs_exchange_skip_counter_set(void* word);
 int vs_mlp_rollout_fwd(int compute, int B, int C, int H, int n_blocks, int n_steps, const float* x0,
                        const void* const* weights, const float* const* biases, float* t_codes, float* residuals,
                        void* xin_save, void* h1_save, void* h2_save, uint32_t* m1_save, uint32_t* m2_save, void* workspace,

@@ -244,6 +244,7 @@ SIGNATURES = {
     'vs_mlp_rollout_xcd_local_set': (_i32, [_i32]),
     'vs_exchange_guard_set': (_i32, [_vp]),
     'vs_exchange_guard_get': (_vp, []),
+    'vs_exchange_skip_counter_set': (_i32, [_vp]),
     'vs_mlp_rollout_fwd': (_i32, [_i32] * 6 + [_vp] * 11 + [_sz, _vp]),
     'vs_mlp_rollout_bwd': (_i32, [_i32] * 6 + [_vp] * 11 + [_sz, _vp]),
 }

@@ -28,6 +28,8 @@ int vs_fail(int code, const char* fmt, ...);
 // workspace, and every optimizer launch (vs_adam_multi*, vs_gemm_adam, the step counter) reads it first and leaves parameters, moments and
 // the step count untouched while it is non-zero: an update is never computed from the results of a timed-out exchange.
 extern unsigned* vs_g_exchange_guard;
+// optional companion (vs_exchange_skip_counter_set): bumped by the step-count kernel every time the guard made it skip a step
+extern unsigned* vs_g_exchange_skips;
 
 #define VS_CHECK_ARG(cond, ...)                        \
     do {                                               \

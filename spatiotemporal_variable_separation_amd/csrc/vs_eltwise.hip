@@ -13,6 +13,12 @@ extern "C" int vs_exchange_guard_set(void* word) {
     return VS_OK;
 }
 extern "C" void* vs_exchange_guard_get(void) { return vs_g_exchange_guard; }
+unsigned* vs_g_exchange_skips = nullptr;
+extern "C" int vs_exchange_skip_counter_set(void* word) {
+    if ((uintptr_t)word % 4 != 0) return vs_fail(VS_ERR_ARG, "vs_exchange_skip_counter_set: the counter must be 4-byte aligned");
+    vs_g_exchange_skips = (unsigned*)word;
+    return VS_OK;
+}
 
 int vs_fail(int code, const char* fmt, ...) {
     va_list ap;

@@ -101,8 +101,11 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs J, const int* 
     }
 }
 
-__global__ void step_increment_kernel(int* step, const float* scale_state, const unsigned* guard) {
-    if (guard && *guard != 0u) return;                        // exchange time-out: the step did not happen
+__global__ void step_increment_kernel(int* step, const float* scale_state, const unsigned* guard, unsigned* skips) {
+    if (guard && *guard != 0u) {                              // exchange time-out: the step did not happen -- counted, so that the host can say how many
+        if (skips) skips[0] += 1u;
+        return;
+    }
     if (scale_state && scale_state[1] != 0.f) return;         // overflow step: skipped, the step count does not advance
     step[0] += 1;
 }
@@ -208,14 +211,14 @@ extern "C" int vs_adam_multi(int n_tensors, float* const* params, const void* co
 
 extern "C" int vs_adam_step_increment(int32_t* step, void* stream) {
     VS_CHECK_ARG(step, "vs_adam_step_increment: null pointer");
-    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, (const float*)nullptr, (const unsigned*)vs_g_exchange_guard);
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, (const float*)nullptr, (const unsigned*)vs_g_exchange_guard, vs_g_exchange_skips);
     VS_CHECK_LAUNCH("vs_adam_step_increment");
     return VS_OK;
 }
 
 extern "C" int vs_adam_step_increment_scaled(int32_t* step, const float* scale_state, void* stream) {
     VS_CHECK_ARG(step, "vs_adam_step_increment_scaled: null pointer");
-    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, scale_state, (const unsigned*)vs_g_exchange_guard);
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, scale_state, (const unsigned*)vs_g_exchange_guard, vs_g_exchange_skips);
     VS_CHECK_LAUNCH("vs_adam_step_increment_scaled");
     return VS_OK;
 }

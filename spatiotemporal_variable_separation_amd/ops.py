@@ -301,8 +301,23 @@ def exchange_guard(device):
         return None
     word = torch.zeros((4,), dtype=torch.int32, device=device)              # (16 bytes: a line of its own would be better still; it is read-mostly)
     check(lib.vs_exchange_guard_set(word.data_ptr()), 'vs_exchange_guard_set')
+    check(lib.vs_exchange_skip_counter_set(word.data_ptr() + 4), 'vs_exchange_skip_counter_set')      # word[1]: steps the guard made the optimizer skip
     _GUARD[index] = word
     return word
+
+
+def exchange_skipped_steps(device, reset=True):
+    """How many optimisation steps the raised guard word has made the step-count kernel skip since the last call (0 without a guard).
+    Synchronises the device (reads a word)."""
+    device = torch.device(device) if not isinstance(device, torch.device) else device
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    guard = _GUARD.get(index)
+    if guard is None:
+        return 0
+    n = int(guard[1].item())
+    if reset and n:
+        guard[1].zero_()
+    return n
 
 
 def rollout_exchange_error(device, reset=True):

@@ -178,8 +178,9 @@ class GradAllReducer:
 
     def _reduce_guard(self, device):
         """The exchange guard word (ops.exchange_guard: raised by a timed-out in-launch exchange, read by every optimizer launch) is
-        MAX-reduced with every bucket: a replica whose integrator timed out has put garbage on the wire, so ALL replicas must skip the
-        update, or they would drift apart (one tiny collective per bucket on the comm stream, N > 1 only)."""
+        OR-reduced with every bucket: a replica whose integrator timed out has put garbage on the wire, so ALL replicas must skip the
+        update, or they would drift apart (one tiny collective per bucket on the comm stream, N > 1 only).  The word is a bit mask (bit 0:
+        MLP integrator, bit 1: one-launch ConvResBlock layer): OR keeps rank A's bit beside rank B's, MAX would drop the smaller one."""
         if self.world_size == 1 or device.type != 'cuda':
             return
         from . import ops
@@ -187,10 +188,10 @@ class GradAllReducer:
         if word is None:
             return
         if self.backend == 'nccl':
-            dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(word, op=dist.ReduceOp.BOR, group=self.group)
         else:
             host = word.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(host, op=dist.ReduceOp.BOR, group=self.group)
             word.copy_(host)
 
     def _reduce(self, flat):
@@ -415,6 +416,36 @@ class GradAllReducer:
                     for (p, off), t in zip(heads, group):
                         t.reshape(-1).copy_(full[off:off + p.numel()])
         self.masters_dirty = False
+
+    def fill_masters_from_arena(self):
+        """No collective possible (Ctrl-C reached one rank only: train.train's final checkpoint): complete the direct parameters' fp32 masters
+        OUTSIDE this rank's slice from the all-gathered 16-bit operand copies -- the current weights of every slice, rounded to the compute
+        type -- instead of leaving what the last sync_masters() put there (stale by every step since).  The own slice keeps its fp32 values;
+        the Adam moments outside the slice stay incomplete (`masters_dirty` stays set: a later sync_masters() completes both exactly).
+        Returns True when something was filled in."""
+        if not self.shard or not self.masters_dirty:
+            return False
+        self.wait_comm()
+        done = False
+        with torch.no_grad():
+            for bi, (head, heads) in self._head.items():
+                arena = self._arena.get(bi)
+                if arena is None:
+                    continue
+                lo, hi = self._slice(bi)
+                for p, off in heads:
+                    n = p.numel()
+                    flat = p.data.reshape(-1)
+                    a, b = min(max(lo, off), off + n), max(min(hi, off + n), off)       # own range [a, b) in bucket coordinates (empty: a >= b)
+                    if a >= b:
+                        flat.copy_(arena[off:off + n].float())
+                    else:
+                        if a > off:
+                            flat[:a - off].copy_(arena[off:a].float())
+                        if b < off + n:
+                            flat[b - off:].copy_(arena[b:off + n].float())
+                    done = True
+        return done
 
     def payload_bytes(self):
         return sum(flat.numel() * 4 for flat, _ in self.buckets)

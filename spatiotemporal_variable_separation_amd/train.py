@@ -817,12 +817,13 @@ def recover_exchange(device, log=True, grad_sync=None):
     from . import ops
     from ._lib import VarsepHipError
     guarded = ops.exchange_guard(torch.device(device)) is not None
+    skipped = ops.exchange_skipped_steps(device) if guarded else 0      # (read before the guard is cleared: counted by the step-count kernel)
     err = ops.rollout_exchange_error(device)
     if grad_sync is not None and grad_sync.world_size > 1:
-        # every rank must take the same branch (a re-recording contains collectives): the worst code of all ranks counts
+        # every rank must take the same branch (a re-recording contains collectives): the codes are bit masks, every rank's bits count
         import torch.distributed as dist
         word = torch.tensor([err], dtype=torch.int32, device=device if grad_sync.backend == 'nccl' else 'cpu')
-        dist.all_reduce(word, op=dist.ReduceOp.MAX, group=grad_sync.group)
+        dist.all_reduce(word, op=dist.ReduceOp.BOR, group=grad_sync.group)
         err = int(word.item())
     if not err:
         return 0
@@ -834,8 +835,11 @@ def recover_exchange(device, log=True, grad_sync=None):
     if err & 2:
         os.environ['VARSEP_FUSED_RESBLOCK'] = '1'
     if log:
-        sys.stderr.write('varsep: an in-launch exchange timed out (code %d); the optimizer skipped the affected step(s).  Continuing with %s\n'
-                         % (err, ' and '.join((['the agent-scope integrator exchange'] if err & 1 else []) +
+        # (the fused weight-gradient updates -- vs_gemm_adam -- issued in the SAME backward pass before the exchange timed out have been applied:
+        # that one step is partial (decoder updated, the rest not); every later step was skipped as a whole)
+        sys.stderr.write('varsep: an in-launch exchange timed out (code %d); the optimizer skipped %s (batches consumed, no update; the first of them '
+                         'may have updated the weights whose Adam step runs inside their weight-gradient GEMM).  Continuing with %s\n'
+                         % (err, ('%d step(s)' % skipped) if skipped else 'the affected step(s)', ' and '.join((['the agent-scope integrator exchange'] if err & 1 else []) +
                                               (['two-launch ConvResBlock layers'] if err & 2 else []))))
     return err
 
@@ -980,6 +984,7 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
 
     step, t_last = 0, time.time()
     graphed = None
+    GUARD_POLL = max(1, int(os.environ.get('VARSEP_GUARD_POLL', '50')))
     rank = grad_sync.rank if grad_sync is not None else 0
     world = grad_sync.world_size if grad_sync is not None else 1
     # folding repeated gradients (VF.fold_repeated_gradients) replaces ~1000 tiny add launches per SST step by one multi-tensor
@@ -1002,6 +1007,14 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                 graphed = None                         # the exchange mode is baked into a recording
         if grad_sync is not None and collective and getattr(grad_sync, 'masters_dirty', False):
             grad_sync.sync_masters(optimizer)          # sharded optimizer: every rank's slice of the fp32 masters / moments to every rank
+        elif grad_sync is not None and not collective and getattr(grad_sync, 'masters_dirty', False):
+            # Ctrl-C may have reached this rank only: no collective.  Outside its own slice this rank's fp32 masters are as old as the last
+            # sync_masters(); the all-gathered 16-bit operand copies are current everywhere -- save those (rounded to the compute type) rather
+            # than stale weights under the normal file name
+            if grad_sync.fill_masters_from_arena() and rank == 0:
+                import sys
+                sys.stderr.write('varsep: interrupted under the sharded optimizer: the saved weights outside rank 0\'s slice are the current '
+                                 '16-bit operand copies (rounded to the compute type), not the fp32 masters held by the other ranks\n')
         if grad_sync is not None and world > 1 and collective:
             import torch.distributed as dist
             from .parallel import broadcast_buffers
@@ -1026,7 +1039,9 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                         total_loss = graphed.step(cond, target)
                         step += 1
                         first = graphed.steps_replayed <= 3      # the first replays of a recording are checked one by one (a sync each)
-                        if first or (log_interval and step % log_interval == 0):
+                        # the guard is sticky: every step until it is read is skipped.  Read it with the log line, or every GUARD_POLL steps
+                        # when nothing is logged (one synchronisation per poll)
+                        if first or (log_interval and step % log_interval == 0) or (not log_interval and step % GUARD_POLL == 0):
                             torch.cuda.synchronize()
                             if recover_exchange(device, grad_sync=grad_sync):
                                 graphed = None                   # re-record with the exchange mode now in force
@@ -1073,9 +1088,14 @@ def train(xp_dir, train_loader, device, sep_net, optimizer, scheduler, use_apex_
                         VF._LOWP_GRAD.update(lowp_saved)
                 VF.flush_bn_call_counts()
                 step += 1
+                if not log_interval and step % GUARD_POLL == 0 and torch.device(device).type == 'cuda':
+                    torch.cuda.synchronize()
+                    if recover_exchange(device, grad_sync=grad_sync):
+                        graphed = None                   # a recording made earlier has the old exchange mode baked in
                 if log_interval and step % log_interval == 0:
                     torch.cuda.synchronize()
-                    recover_exchange(device, grad_sync=grad_sync)
+                    if recover_exchange(device, grad_sync=grad_sync):
+                        graphed = None                   # (as the graph branch and checkpoint() do)
                     dt = time.time() - t_last
                     t_last = time.time()
                     fps = log_interval * cond.shape[0] * nt_pred * world / dt

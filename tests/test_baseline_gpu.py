@@ -315,6 +315,9 @@ SPLIT_FULL = [
                   'vs_conv_thin:fwd<bf16>', 'vs_conv_thin:wgrad<bf16>')),
     ('full_mnist_b16', ('vs_conv_k4s2:fwd<bf16>', 'vs_conv_k4s2:dgrad<bf16>', 'vs_conv_k4s2:wgrad<bf16>', 'vs_convT_tap:fwd<bf16>', 'vs_convT_tap:dgrad<bf16>',
                         'vs_conv_thin:fwd<bf16>', 'vs_conv_thin:wgrad<bf16>')),
+    # round 6: BASELINE configs[2] at its own batch
+    ('full_mnist_b128', ('vs_conv_k4s2:fwd<bf16>', 'vs_conv_k4s2:dgrad<bf16>', 'vs_conv_k4s2:wgrad<bf16>', 'vs_convT_tap:fwd<bf16>', 'vs_convT_tap:dgrad<bf16>',
+                         'vs_conv_thin:fwd<bf16>', 'vs_conv_thin:wgrad<bf16>')),
 ]
 
 

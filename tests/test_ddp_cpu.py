@@ -166,11 +166,19 @@ def _shard_worker(rank, world, port, shard, out_dir):
                             copies[id(p)] = p.detach().to(torch.bfloat16)
         sync.masters_dirty = shard
         before = {id(p): p.detach().clone() for p in direct}
+        filled = {}
+        if shard and step == 1:
+            # the Ctrl-C path of train.train: no collective -- the masters outside the own slice come from the gathered copies
+            assert sync.fill_masters_from_arena() and sync.masters_dirty
+            filled = {id(p): p.detach().clone() for p in direct}
+            for p in direct:
+                p.data.copy_(before[id(p)])                  # (back to the stale state: sync_masters() below is checked on it)
         # (on the GPU the next forward pass reads the gathered 16-bit copies; the CPU oracle network reads the fp32 masters: complete them)
         sync.sync_masters(_Opt(state))
     names = {id(p): n for n, p in net.named_parameters()}
     before = {names[k]: v for k, v in before.items()}
-    torch.save({'state': {k: v.clone() for k, v in net.state_dict().items()}, 'before': before,
+    filled = {names[k]: v for k, v in filled.items()}
+    torch.save({'state': {k: v.clone() for k, v in net.state_dict().items()}, 'before': before, 'filled': filled,
                 'copies': {names[k]: v.float().clone() for k, v in copies.items()},
                 'm': {names[id(p)]: st['exp_avg'].clone() for p, st in state.items()}}, os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
@@ -197,6 +205,20 @@ def test_sharded_optimizer_machinery_equals_replicated_update(tmp_path):
     # some direct parameter of each rank was stale outside the rank's slice before the masters were completed
     assert any(not torch.equal(s0['before'][k], s0['state'][k]) for k in s0['before'])
     assert any(not torch.equal(s1['before'][k], s1['state'][k]) for k in s1['before'])
+    # an interrupted run (no collective at the final checkpoint): fill_masters_from_arena() leaves, on every rank, each direct weight equal to
+    # the true fp32 master inside the rank's slice and to its bf16 rounding outside -- never the stale value of the last sync
+    for s in (s0, s1):
+        assert s['filled'], 'the worker did not exercise the interrupted path'
+        n_exact = n_rounded = 0
+        for k, f in s['filled'].items():
+            true = s['state'][k]
+            exact = f == true
+            rounded = f == true.to(torch.bfloat16).float()
+            assert bool((exact | rounded).all()), f'{k}: filled masters are neither the fp32 master nor its bf16 rounding'
+            n_exact += int((exact & ~rounded).sum())
+            n_rounded += int((rounded & ~exact).sum())
+        assert n_exact > 0 and n_rounded > 0, 'own slice must stay fp32, the rest must come from the 16-bit copies'
+        assert any(not torch.equal(s['before'][k], s['filled'][k]) for k in s['filled'])
 
 
 def _presum_worker(rank, world, port, presum, out_dir):

@@ -1,0 +1,201 @@
+"""GPU: the RECORDED optimisation step -- train.GraphedStep, the launch structure bench.py times (side streams, weight gradients with the
+Adam update in their epilogue, folded gradients, one hipGraph) -- at BASELINE size against the reference's fixture, and over many steps.
+
+  (1) test_full_size_recorded_step_matches_reference_fixture: ONE replay on the fixture's weights, batch and t_random; the loss and the
+      parameters afterwards against what the reference's own train() step left (`after:*` checksums of tests/golden/full_*.npz), in fp32 at
+      the fp32 bars and in the 16-bit modes at the mode's bars; and against the EAGER HIP step of the same mode (compute_losses + backward +
+      optim.Adam, the path test_baseline_gpu.py checks element-wise), which the recording must reproduce up to summation order.
+  (2) test_recorded_training_tracks_fp32_oracle: N consecutive replays in a 16-bit mode; the loss before every step against the fp32 CPU
+      oracle's trajectory, bounded by max(floor, 3 x the rounding-point emulation's own distance from that trajectory) -- both trajectories
+      are committed constants (tests/golden/drift_trajectories.json, tests/make_drift_fixture.py).
+
+An Adam step moves every parameter by about +-lr whatever the size of its gradient, so post-step parameters are compared through the
+UPDATE: the change of the tensor's sum and of its 16 checksum samples (linear in the tensor, hence derivable from the fixture's checksums
+and the known initial weights), not through norms that a wrong update would barely move.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+from oracle.detdata import checksum
+from oracle.golden_configs import CONFIGS, FULL_CONFIGS, fill_net, make_batch
+from golden_util import load_golden
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _recorded(cfg, precision, t_values, steps, loss_scale=None, seed=None):
+    """GraphedStep as bench.py builds it, on the oracle's hash-filled weights and batch.  `t_values`: the t_random of every replay (a list) or
+    None = NumPy's global stream re-seeded with `seed` right before the first replay.  Returns (net, initial state dict, losses per step)."""
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.train import GraphedStep, make_loss_scaler
+    dev = torch.device('cuda', torch.cuda.current_device())
+    o_net = fill_net(cpu_ref.build_sep_net(cfg), cfg)
+    before = {k: v.clone() for k, v in o_net.state_dict().items()}
+    net = build_sep_net(cfg)
+    net.load_state_dict({k: v.clone() for k, v in before.items()}, strict=True)
+    net = net.to(dev)
+    net.train()
+    cond, target = make_batch(cfg)
+    cond, target = cond.to(dev), target.to(dev)
+    lam = cfg['lambdas']
+    lamb_t = 0 if cfg.get('no_s') else lam['t']
+    VF.set_precision(precision)
+    fold_was = VF.folding_repeated_gradients()
+    VF.fold_repeated_gradients(True)
+    scaler = make_loss_scaler(dev, init_scale=float(loss_scale), growth_interval=100000) if loss_scale else None
+    opt = Adam(net.parameters(), lr=cfg.get('lr', 4e-4), betas=(0.9, 0.99))
+    try:
+        g = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], (lam['ae'], lam['s'], lamb_t, lam['pred']),
+                        bool(cfg.get('average_tloss')), warmup=2, scaler=scaler)
+        losses = []
+        if t_values is None:
+            np.random.seed(seed)
+        for i in range(steps):
+            if t_values is not None:
+                # GraphedStep._draw fills the device-side window end from NumPy's stream: pin it to the fixture's value
+                real = np.random.randint
+                np.random.randint = lambda lo, hi=None, _v=int(t_values[i]): _v
+                try:
+                    loss = g.step()
+                finally:
+                    np.random.randint = real
+            else:
+                loss = g.step()
+            losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        from spatiotemporal_variable_separation_amd import ops
+        assert ops.rollout_exchange_error(dev) == 0, 'rollout exchange timed out'
+        if scaler is not None:
+            assert scaler.skipped_steps() == 0, 'loss scaling skipped a step: the trajectory is not the oracle\'s'
+    finally:
+        VF.fold_repeated_gradients(fold_was)
+        VF.set_precision('fp32')
+        if hasattr(opt, 'unfuse'):
+            opt.unfuse()
+    return net, before, losses, g
+
+
+def _eager_step(cfg, precision, t_random, loss_scale=None):
+    """The eager HIP step of the same mode + one optim.Adam step (what test_baseline_gpu.py checks element-wise against the oracle)."""
+    from step_util import hip_step
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    o_net0 = fill_net(cpu_ref.build_sep_net(cfg), cfg)
+    h_net, h_total, _, _, _ = hip_step(cfg, t_random, o_net0, precision, loss_scale=loss_scale, fold=True)
+    opt = Adam(h_net.parameters(), lr=cfg.get('lr', 4e-4), betas=(0.9, 0.99))
+    opt.step()
+    torch.cuda.synchronize()
+    return h_net, float(h_total.item())
+
+
+# (fixture, precision, loss bound vs the reference, share of update samples / elements that may differ (sign flips of near-zero gradients))
+RECORDED_FULL = [
+    ('full_waveeq', 'fp32', 1e-3, 0.02),
+    ('full_waveeq', 'bf16', 5e-2, 0.15),
+    ('full_taxibj', 'bf16', 5e-2, 0.30),
+    ('full_sst', 'bf16', 5e-2, 0.30),
+    ('full_mnist_b128', 'bf16', 5e-2, 0.30),
+]
+
+
+@pytest.mark.parametrize('name,precision,loss_tol,flip_share', RECORDED_FULL, ids=['%s-%s' % (n, p) for n, p, _, _ in RECORDED_FULL])
+def test_full_size_recorded_step_matches_reference_fixture(name, precision, loss_tol, flip_share):
+    cfg = FULL_CONFIGS[name]
+    gold = load_golden(name)
+    t_random = int(gold['t_random'])
+    lr = cfg.get('lr', 4e-4)
+    net, before, losses, g = _recorded(cfg, precision, [t_random], 1)
+    ref_total = float(gold['total'])
+    assert abs(losses[0] - ref_total) <= loss_tol * abs(ref_total), f'{name} {precision}: recorded loss {losses[0]} vs reference {ref_total}'
+    e_net, e_loss = _eager_step(cfg, precision, t_random)
+    # same mode, same kernels up to launch structure (fused Adam epilogue, folded gradients): the loss agrees to summation order
+    assert abs(losses[0] - e_loss) <= (2e-5 if precision == 'fp32' else 2e-3) * abs(e_loss), f'{name} {precision}: recorded {losses[0]} vs eager {e_loss}'
+    esd = e_net.state_dict()
+    total_norm = np.sqrt(sum(float(gold[k][1]) ** 2 if k.startswith('cs:grad:') else float((gold[k].astype(np.float64) ** 2).sum())
+                             for k in gold if k.startswith('cs:grad:') or k.startswith('grad:')))
+    n_smp = n_far_ref = 0
+    worst_sum = 0.0
+    far_eager = tot_eager = 0
+    moved = 0
+    for k, v in net.state_dict().items():
+        if k.endswith('num_batches_tracked'):
+            key = 'after:' + k
+            if key in gold:
+                assert int(v) == int(gold[key]), k
+            continue
+        v = v.detach().float().cpu()
+        b0 = before[k].float()
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            continue                                    # BatchNorm statistics: test_baseline_gpu.py (emulation, element-wise)
+        gk = 'cs:grad:' + k
+        g_norm = float(gold[gk][1]) if gk in gold else (float(np.linalg.norm(gold['grad:' + k].astype(np.float64))) if 'grad:' + k in gold else None)
+        if g_norm is not None and g_norm < 1e-4 * total_norm:
+            # a conv bias in front of a training-mode BatchNorm: exactly-zero gradient here, summation noise in the reference, and Adam
+            # turns that noise into +-lr steps there -- bounded (|update| <= lr), not compared (test_baseline_gpu.py does the same)
+            assert float((v - b0).abs().max()) <= 1.05 * lr + 1e-7, k
+            continue
+        ck = 'cs:after:' + k
+        if ck in gold:
+            ref_after, ref_before, got = gold[ck], checksum(b0), checksum(v)
+        else:
+            ref_after, ref_before, got = checksum(torch.from_numpy(gold['after:' + k])), checksum(b0), checksum(v)
+        n = v.numel()
+        # the update through the checksum's linear parts: sum and samples
+        d_ref, d_got = ref_after[2:] - ref_before[2:], got[2:] - ref_before[2:]
+        n_smp += len(d_ref)
+        n_far_ref += int((np.abs(d_got - d_ref) > 0.25 * lr).sum())
+        assert np.abs(d_got).max() <= 1.05 * lr + 1e-7 and np.abs(d_got - d_ref).max() <= 2.1 * lr, f'{k}: an update larger than lr (first Adam step) {d_got} vs {d_ref}'
+        s_ref, s_got = ref_after[0] - ref_before[0], got[0] - ref_before[0]
+        worst_sum = max(worst_sum, abs(s_got - s_ref) / (lr * n))
+        assert abs(s_got - s_ref) <= 2.0 * flip_share * lr * n + 4e-7 * max(abs(ref_after[0]), 1.0), f'{k}: sum of the update {s_got:.6g} vs reference {s_ref:.6g} (n {n})'
+        moved += int(np.abs(d_got).max() > 0.5 * lr)
+        # element-wise against the eager HIP step of the same mode
+        ev = esd[k].detach().float().cpu()
+        far_eager += int(((v - ev).abs() > 0.25 * lr).sum())
+        tot_eager += n
+    assert moved > 0, 'no parameter moved: the replay did not run the optimizer'
+    assert n_far_ref <= flip_share * n_smp, f'{name} {precision}: {n_far_ref} of {n_smp} update samples differ from the reference step'
+    eager_share = far_eager / max(tot_eager, 1)
+    assert eager_share <= (1e-3 if precision == 'fp32' else 0.05), f'{name} {precision}: {eager_share:.2%} of the parameters differ between the recorded and the eager step'
+    print(name, precision, 'recorded step: loss vs reference %.1e, update samples off %d/%d, worst sum-of-update distance %.3f lr n, elements off vs eager %.2e'
+          % (abs(losses[0] - ref_total) / abs(ref_total), n_far_ref, n_smp, worst_sum, eager_share))
+
+
+def _drift_cases():
+    path = os.path.join(HERE, 'golden', 'drift_trajectories.json')
+    if not os.path.exists(path):
+        return []
+    return [k for k in json.load(open(path)) if not k.startswith('_')]
+
+
+@pytest.mark.parametrize('case', _drift_cases())
+def test_recorded_training_tracks_fp32_oracle(case):
+    """N consecutive replays of the recorded 16-bit step against the committed fp32 oracle trajectory (same weights, batch, t_random stream,
+    Adam): the loss before every step within max(2 %, 3 x the emulation's own distance at that step) of the oracle's, and the final loss of
+    the run within max(2 %, 3 x the emulation's) as well -- a kernel whose gradients were wrong by a factor would walk away within a few steps."""
+    from make_drift_fixture import DRIFT_SEED
+    traj = json.load(open(os.path.join(HERE, 'golden', 'drift_trajectories.json')))[case]
+    name, b, precision, steps = case.split('|')
+    steps = int(steps)
+    base = FULL_CONFIGS[name] if name in FULL_CONFIGS else CONFIGS[name]
+    cfg = dict(base, B=int(b[1:]))
+    net, _, losses, g = _recorded(cfg, precision, None, steps, loss_scale=1024.0 if precision == 'fp16' else None, seed=DRIFT_SEED)
+    ref, emu = traj['fp32'], traj['emu']
+    assert len(losses) == len(ref) == steps
+    worst, at = 0.0, 0
+    for i, (h, r, e) in enumerate(zip(losses, ref, emu)):
+        bound = max(0.02, 3.0 * abs(e - r) / abs(r))
+        d = abs(h - r) / abs(r)
+        if d / bound > worst:
+            worst, at = d / bound, i
+        assert d <= bound, f'{case}: step {i}: recorded {precision} loss {h:.6g} vs fp32 oracle {r:.6g} ({d:.2e} > {bound:.2e}; emulation {e:.6g})'
+    assert ref[-1] < ref[0], 'the oracle run does not train'
+    assert losses[-1] < losses[0], f'{case}: the recorded run does not train: {losses[0]} -> {losses[-1]}'
+    print(case, 'loss %.5g -> %.5g (oracle %.5g -> %.5g, emulation -> %.5g); worst distance / bound %.2f at step %d' % (losses[0], losses[-1], ref[0], ref[-1], emu[-1], worst, at))

@@ -81,8 +81,10 @@ def test_exchange_guard_makes_every_optimizer_launch_skip():
     w0, b0 = w.detach().clone(), b.detach().clone()
     m0 = opt.state[w]['exp_avg'].clone()
     t0 = int(opt.param_groups[0]['step_dev'].item())
+    assert ops.exchange_skipped_steps(dev) == 0
     guard[0] = 1
     opt.step()
+    opt.step()                                                   # a second batch consumed while the (sticky) word is still up
     # the fused weight-gradient + Adam launch on the same parameter (G = A^T B as in MLPChain.backward: operands [rows, features], layout S)
     a = torch.randn(128, 256, device=dev).bfloat16()
     g = torch.randn(128, 384, device=dev).bfloat16()
@@ -93,6 +95,8 @@ def test_exchange_guard_makes_every_optimizer_launch_skip():
     torch.cuda.synchronize()
     assert torch.equal(w.detach(), w0) and torch.equal(b.detach(), b0) and torch.equal(opt.state[w]['exp_avg'], m0)
     assert int(opt.param_groups[0]['step_dev'].item()) == t0, 'the step count must not advance on a guarded step'
+    # the companion word (vs_exchange_skip_counter_set) says how many steps the guard cost: two optimizer steps were issued while it was up
+    assert ops.exchange_skipped_steps(dev, reset=False) == 2 and ops.exchange_skipped_steps(dev) == 2 and ops.exchange_skipped_steps(dev) == 0
     assert ops.rollout_exchange_error(dev) == 1 and ops.rollout_exchange_error(dev) == 0          # reported once, cleared by the read
     opt.step()
     torch.cuda.synchronize()
