@@ -264,6 +264,13 @@ extern "C" size_t vs_gemm_batched_workspace_bytes(int batch, int64_t M, int64_t 
             size_t b = (size_t)batch * mp.splits * (size_t)M * (size_t)N * sizeof(float);
             if (b > worst) worst = b;
         }
+        for (int lb = 0; lb < 2; ++lb) {
+            const P8Plan pp = make_p8_plan(c, M, N, K, batch, lb);
+            if (pp.use && pp.splits > 1) {
+                size_t b = (size_t)batch * pp.splits * (size_t)M * (size_t)N * sizeof(float);
+                if (b > worst) worst = b;
+            }
+        }
     }
     return worst;
 }
@@ -422,6 +429,13 @@ extern "C" size_t vs_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
         if (mp.use && mp.splits > 1) {
             size_t b = (size_t)mp.splits * (size_t)M * (size_t)N * sizeof(float);
             if (b > worst) worst = b;
+        }
+        for (int lb = 0; lb < 2; ++lb) {
+            const P8Plan pp = make_p8_plan(c, M, N, K, 1, lb);
+            if (pp.use && pp.splits > 1) {
+                size_t b = (size_t)pp.splits * (size_t)M * (size_t)N * sizeof(float);
+                if (b > worst) worst = b;
+            }
         }
     }
     return worst;

@@ -490,6 +490,25 @@ inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t
         p.use = (int64_t)p.tiles_m * p.tiles_n * batch <= 65535;
         return p;
     }
+    // One tile row, long K (the encoders' first layer, 256 x 1200 x 20480: the weight matrix is streamed once, HBM-bound): 256 x 128 tiles, K split
+    // over ~one round of CUs into fp32 slabs (reduced by splitk_reduce_kernel).  Measured against the 128 x 128 ring tile (20 tiles x 22 splits):
+    // alone, cold operands 43.5 -> 38.1 us; replayed WaveEq step, two interleaved pairs 1.2414 / 1.2337 -> 1.2114 / 1.2079 ms.  VS_GEMM_P8_SPLIT=0: off.
+    {
+        const char* env_sp = getenv("VS_GEMM_P8_SPLIT");
+        const int64_t kt = p.k_tiles_per_split, tn = vs_cdiv(N, 128);
+        if (!(env_sp && atoi(env_sp) == 0) && M > 128 && M <= 256 && N >= 512 && kt >= 64 && tn * batch <= 64 && (double)N / (tn * 128.0) >= 0.85) {
+            int64_t splits = 250 / (tn * batch);
+            if (splits > kt / 8) splits = kt / 8;
+            if (splits >= 2) {
+                p.ni = 1;
+                p.tiles_n = (int)tn;
+                p.k_tiles_per_split = vs_cdiv(kt, splits);
+                p.splits = (int)vs_cdiv(kt, p.k_tiles_per_split);
+                p.use = true;
+                return p;
+            }
+        }
+    }
     if (M < 512 || N < 512 || p.k_tiles_per_split < 6) return p;
     const int64_t t256 = (int64_t)p.tiles_m * p.tiles_n * batch;
     if (t256 >= 160 && fill_of(256) >= 0.8) { p.use = true; return p; }

@@ -96,12 +96,14 @@ def _eager_step(cfg, precision, t_random, loss_scale=None):
 
 
 # (fixture, precision, loss bound vs the reference, share of update samples / elements that may differ (sign flips of near-zero gradients))
+# measured (round 6, one MI355X): samples off 0 / 608 (waveeq fp32), 2 / 608 (waveeq bf16), 162 / 1650 (taxibj), 130 / 1746 (sst), 3 / 545 (mnist); loss vs
+# the reference 0 / 3.9e-4 / 6.8e-4 / 2.7e-5 / 8.9e-5; elements that differ from the eager step: none in any case
 RECORDED_FULL = [
-    ('full_waveeq', 'fp32', 1e-3, 0.02),
-    ('full_waveeq', 'bf16', 5e-2, 0.15),
-    ('full_taxibj', 'bf16', 5e-2, 0.30),
-    ('full_sst', 'bf16', 5e-2, 0.30),
-    ('full_mnist_b128', 'bf16', 5e-2, 0.30),
+    ('full_waveeq', 'fp32', 1e-3, 0.01),
+    ('full_waveeq', 'bf16', 5e-3, 0.03),
+    ('full_taxibj', 'bf16', 5e-3, 0.20),
+    ('full_sst', 'bf16', 5e-3, 0.15),
+    ('full_mnist_b128', 'bf16', 5e-3, 0.03),
 ]
 
 
