@@ -131,6 +131,7 @@ struct ColsumJobs {
     int64_t ld[CS_MAXJ], M[CS_MAXJ], N[CS_MAXJ];
     float* out[CS_MAXJ];
     int blk_off[CS_MAXJ + 1];
+    int direct;                          // one row block per column: plain stores (nothing to meet, so nothing to clear first)
 };
 
 // A workgroup reduces CS_ROWS rows of a 256-column block: 32 lanes x 8 consecutive columns (one 16-byte load per row for bf16,
@@ -195,7 +196,8 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumJobs J) {
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) t += part[q][col];
-        atomicAdd(J.out[j] + nc, t);
+        if (J.direct) J.out[j][nc] = t;
+        else atomicAdd(J.out[j] + nc, t);
     }
 }
 
@@ -351,7 +353,10 @@ __global__ __launch_bounds__(256) void train_losses_fwd_kernel(LossArgs a, float
         }
         ss = block_sum_256(ss, red);
         st = block_sum_256(st, red);
-        if (threadIdx.x == 0) { atomicAdd(out + 2, ss); atomicAdd(out + 3, st); }
+        if (threadIdx.x == 0) {
+            if constexpr (GRAD) { out[2] = ss; out[3] = st; }     // one writer, and the frame sums travel as per-workgroup partials: nothing to clear first
+            else { atomicAdd(out + 2, ss); atomicAdd(out + 3, st); }
+        }
     }
 }
 
@@ -442,7 +447,7 @@ extern "C" int vs_train_losses_fwd_grad(const float* frames, const float* full, 
     VS_CHECK_ARG(frames && out && grad_total && dz && dt0 && (n_s == 0 || (ds_old && ds_new)), "vs_train_losses_fwd_grad: null pointer");
     VS_CHECK_ARG(vs_dtype_ok(dz_dtype) && frames_act >= VS_ACT_NONE && frames_act <= VS_ACT_ELU && D % 4 == 0,
                  "vs_train_losses_fwd_grad: needs a valid dz dtype / activation and D %% 4 == 0");
-    if (vs_zero_async(out, 10 * sizeof(float), (hipStream_t)stream) != hipSuccess) return vs_fail(VS_ERR_LAUNCH, "vs_train_losses_fwd_grad: zero fill failed");
+    // (no clearing launch: out[0..8] are all written -- [2], [3] by workgroup 0, the rest by the finalize launch from the partials at out[16..])
     int64_t wgs = B * G;                                       // one row per workgroup: every load of the pass is issued at once
     if (wgs > VS_LOSS_MAX_PARTIALS) wgs = VS_LOSS_MAX_PARTIALS;
     LossGrads gr{grad_total, dz, dz_dtype, frames_act, ds_old, ds_new, dt0};
@@ -918,11 +923,24 @@ extern "C" int vs_colsum_multi(int n_jobs, const void* const* X, const int* x_dt
         J.blk_off[j + 1] = J.blk_off[j] + (int)vs_cdiv(N[j], CSM_COLS);
         if (M[j] > max_m) max_m = M[j];
     }
-    if (zero_base && zero_count > 0) {
+    dim3 grid((unsigned)J.blk_off[n_jobs], (unsigned)vs_cdiv(max_m, CS_ROWS));
+    // Every job within ONE row block (the encoders' bias gradients: 256 rows) and the outputs tiling exactly the area this call is asked to
+    // clear: each column sum has one writer, so it is stored instead of added and the clearing launch is not issued (one kernel boundary
+    // less on the critical path of the WaveEq step's tail).
+    J.direct = 0;
+    if (zero_base && zero_count > 0 && grid.y == 1) {
+        int64_t cols = 0;
+        bool inside = true;
+        for (int j = 0; j < n_jobs; ++j) {
+            cols += N[j];
+            if (out[j] < zero_base || out[j] + N[j] > zero_base + zero_count) inside = false;
+        }
+        J.direct = inside && cols == zero_count;
+    }
+    if (zero_base && zero_count > 0 && !J.direct) {
         if (vs_zero_async(zero_base, (size_t)zero_count * sizeof(float), (hipStream_t)stream) != hipSuccess)
             return vs_fail(VS_ERR_LAUNCH, "vs_colsum_multi: memset failed");
     }
-    dim3 grid((unsigned)J.blk_off[n_jobs], (unsigned)vs_cdiv(max_m, CS_ROWS));
     hipLaunchKernelGGL(colsum_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, J);
     VS_CHECK_LAUNCH("vs_colsum_multi");
     return VS_OK;

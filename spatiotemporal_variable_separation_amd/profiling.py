@@ -113,3 +113,28 @@ def replay_table(stats_rows, step_kernel='step_increment'):
     table = {g: {'us_per_step': e['ns'] / steps / 1e3, 'launches_per_step': e['calls'] / steps, 'avg_launch_us': e['ns'] / e['calls'] / 1e3}
              for g, e in out.items()}
     return steps, table, rest / steps / 1e3
+
+
+def hip_graph_counts(raw_graph, dot_path=None):
+    """{'nodes', 'kernel_nodes', 'edges', 'roots'} of a captured hipGraph_t (an integer handle: torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph());
+    `dot_path`: additionally hipGraphDebugDotPrint there.  Measurement only (train.GraphedStep.graph_stats, bench.py, tests)."""
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    g = ctypes.c_void_p(int(raw_graph))
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(g, None, ctypes.byref(n)) != 0:
+        return None
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    hip.hipGraphGetNodes(g, nodes, ctypes.byref(n))
+    kernels = 0
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+        kernels += int(t.value == 0)                      # hipGraphNodeTypeKernel
+    e = ctypes.c_size_t(0)
+    hip.hipGraphGetEdges(g, None, None, ctypes.byref(e))
+    r = ctypes.c_size_t(0)
+    hip.hipGraphGetRootNodes(g, None, ctypes.byref(r))
+    if dot_path:
+        hip.hipGraphDebugDotPrint(g, dot_path.encode(), ctypes.c_uint(0))
+    return {'nodes': int(n.value), 'kernel_nodes': kernels, 'edges': int(e.value), 'roots': int(r.value)}

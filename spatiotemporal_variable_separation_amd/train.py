@@ -326,6 +326,10 @@ class GraphedStep:
         self._draw()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
+        # VARSEP_GRAPH_STATS=1: keep the captured hipGraph_t so that graph_stats() can count its nodes and edges (VARSEP_GRAPH_DOT=<path>: and dump it)
+        self._keep = os.environ.get('VARSEP_GRAPH_STATS') == '1' or bool(os.environ.get('VARSEP_GRAPH_DOT'))
+        if self._keep:
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         if grad_sync is None:
             from . import functional as VF
             VF.bn_counts_flushed_in_capture(True)        # SST: ~200 per-call `num_batches_tracked += 1` launches become one
@@ -381,6 +385,15 @@ class GraphedStep:
                 self.graph_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_opt, capture_error_mode=_CAPTURE_MODE):
                     self._opt_step()
+
+    def graph_stats(self):
+        """Node and edge counts of the (first) recording -- {'nodes', 'kernel_nodes', 'edges', 'roots'} -- read from the captured hipGraph_t
+        (hipGraphGetNodes / hipGraphGetEdges / hipGraphNodeGetType); needs VARSEP_GRAPH_STATS=1 at capture time.  The host pays per node and
+        per dependency edge of a replay, the device per dependent kernel boundary."""
+        if not getattr(self, '_keep', False):
+            return None
+        from .profiling import hip_graph_counts
+        return hip_graph_counts(self.graph.raw_cuda_graph(), os.environ.get('VARSEP_GRAPH_DOT'))
 
     def _opt_step(self):
         from . import functional as VF
