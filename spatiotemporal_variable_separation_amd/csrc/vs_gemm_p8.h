@@ -341,30 +341,49 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
         float fl_s0 = 0.f, fl_s1 = 0.f;
         const float fl_up = epi.fl_up[0];
         const int fl_t = epi.fl_tdev[0];
+        // Sixteen target requests (one quadrant row: 2 x NI x 4 accumulators' worth) are in flight before the first is consumed: a lane's 16 bytes
+        // of a target frame come from HBM at ~2 us under load, and four at a time (the first form) left the epilogue waiting 8 times per wave
+        // (fused losses then LOST 40 us on the WaveEq step).  Rows / columns past the end read a clamped (valid) address and are skipped.
+        f32x4 bias4[2][NI];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int64_t n = nw + j * RUN_B + ni * 16;
                 const int64_t n_c = n + 3 < N ? n : N - 4;
-                const f32x4 bias4 = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n_c) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f32x4 tg[4];
-                    int gg[4];
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
-                        int64_t m = mw + i * 64 + mi * 16;
-                        if (m > M - 1) m = M - 1;
-                        tg[mi] = *reinterpret_cast<const f32x4*>(big_loss_target(epi, m, n_c, N, fl_t, gg[mi]));
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
-                        const int64_t m = mw + i * 64 + mi * 16;
-                        if (m < M && n + 3 < N) big_loss4(epi, m, n, N, gg[mi], acc[i][j][mi][ni], tg[mi], bias4, fl_up, fl_s0, fl_s1);
-                    }
-                }
+                bias4[j][ni] = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n_c) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        auto loss_rows = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            f32x4 tg[2][NI][4];
+            int gg[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                int64_t m = mw + i * 64 + mi * 16;
+                if (m > M - 1) m = M - 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int64_t n = nw + j * RUN_B + ni * 16;
+                        const int64_t n_c = n + 3 < N ? n : N - 4;
+                        tg[j][ni][mi] = *reinterpret_cast<const f32x4*>(big_loss_target(epi, m, n_c, N, fl_t, gg[mi]));
+                    }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int64_t m = mw + i * 64 + mi * 16;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int64_t n = nw + j * RUN_B + ni * 16;
+                        if (m < M && n + 3 < N) big_loss4(epi, m, n, N, gg[mi], acc[i][j][mi][ni], tg[j][ni][mi], bias4[j][ni], fl_up, fl_s0, fl_s1);
+                    }
+            }
+        };
+        loss_rows(I0{});
+        loss_rows(I1{});
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { fl_s0 += __shfl_down(fl_s0, o, 64); fl_s1 += __shfl_down(fl_s1, o, 64); }
         __syncthreads();
@@ -410,6 +429,22 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
                         const int64_t n = nw + j * RUN_B + ni * 16;
                         const int64_t n_c = n < N ? n : 0;
                         const f32x4 bias4 = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n_c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        // the mask values of the column's eight accumulators are requested TOGETHER, from clamped (always valid) addresses and ahead of
+                        // the bounds branches: a load behind each branch would be waited for one at a time (8 x ~1 us per column group)
+                        // (raw bits until they are used: a conversion next to the load would wait for it)
+                        f32x4 yf[2][4];
+                        u16x4 yh[2][4];
+                        if (epi.mask) {
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int mi = 0; mi < 4; ++mi) {
+                                    int64_t m = mw + i * 64 + mi * 16;
+                                    if (m > M - 1) m = M - 1;
+                                    if (epi.mask_dtype == VS_F32) yf[i][mi] = *reinterpret_cast<const f32x4*>((const float*)epi.mask + m * epi.ldmask + n_c);
+                                    else yh[i][mi] = *reinterpret_cast<const u16x4*>((const unsigned short*)epi.mask + m * epi.ldmask + n_c);
+                                }
+                        }
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -420,15 +455,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) r[t] = vs_act(acc[i][j][mi][ni][t] * epi.alpha + bias4[t], ACT);
                                 if (epi.mask) {
-                                    f32x4 y;
-                                    if (epi.mask_dtype == VS_F32) y = *reinterpret_cast<const f32x4*>((const float*)epi.mask + m * epi.ldmask + n);
-                                    else {
-                                        const u16x4 yb = *reinterpret_cast<const u16x4*>((const unsigned short*)epi.mask + m * epi.ldmask + n);
 #pragma unroll
-                                        for (int t = 0; t < 4; ++t) y[t] = vs_h2f(yb[t], epi.mask_dtype);
+                                    for (int t = 0; t < 4; ++t) {
+                                        const float yv = epi.mask_dtype == VS_F32 ? yf[i][mi][t] : vs_h2f(yh[i][mi][t], epi.mask_dtype);
+                                        r[t] *= yv > 0.f ? 1.f : mask_slope;
                                     }
-#pragma unroll
-                                    for (int t = 0; t < 4; ++t) r[t] *= y[t] > 0.f ? 1.f : mask_slope;
                                 }
                                 if constexpr (F32OUT) {
                                     *reinterpret_cast<f32x4*>((float*)epi.C + m * epi.ldc + n) = r;

@@ -181,7 +181,7 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     flat_c = flat.contiguous()
     up = VF.promised_loss_gradient()
     if (frames_unused and handoff is not None and on_device and up is not None and torch.is_grad_enabled()
-            and VF.compute_dtype() != torch.float32 and os.environ.get('VARSEP_FUSE_FRAME_LOSS', '0') == '1'):
+            and VF.compute_dtype() != torch.float32 and os.environ.get('VARSEP_FUSE_FRAME_LOSS', '1') == '1'):
         # recorded step (nobody reads the frames): the decoder's last GEMM compares them with their targets in its epilogue and
         # writes the gradient of its pre-activation; neither the fp32 frame stack nor a loss pass over it exists (functional.MLPChain)
         handoff.fuse = dict(full=flat_c, idx=(t_random, offset, fo), G=1 + n, s_old=s_old_f, s_new=s_new_f, t0=t0_f,
