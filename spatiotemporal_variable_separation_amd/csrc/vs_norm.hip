@@ -511,10 +511,45 @@ __global__ __launch_bounds__(256) void group_sum2_kernel(const float* a, const f
     }
 }
 
+
+// ---- per-call-group parameter gradients summed inside the launch that produces them ---------------------------------------------------
+// The one-launch backward kernels below run one workgroup per (channel, call group) and leave d beta / d gamma per group; the sums over the
+// groups (what the optimizer wants) used to be a launch of their own (group_sum2_kernel: 30 launches of ~4.8 us per TaxiBJ step, 29 per SST
+// step -- pure kernel-boundary cost).  Now the LAST workgroup of a channel to arrive adds the groups' values in group order (bit for bit what
+// group_sum2_kernel computes).  Hand-off: thread 0 stores its two partials write-through (relaxed agent-scope stores = sc1), drains them
+// (s_waitcnt vmcnt(0)) and bumps the channel's counter (relaxed agent-scope atomic); the workgroup whose add returns groups - 1 reads every
+// partial with agent-scope (sc1) loads, which do not hit a stale line of its own L1, writes the sums and clears the counter for the next
+// launch.  Placement-independent; the counters come from a static pool (no allocation behind the ABI), dealt out in rotation.
+struct BnGroupSums { int groups; float* out_a; float* out_b; unsigned* cnt; };
+constexpr unsigned BN_ARRIVE_POOL = 1u << 15;
+}  // namespace
+__device__ unsigned vs_bn_arrive_pool[1u << 15];  // (external linkage: hipGetSymbolAddress does not find a symbol of an unnamed namespace)
+namespace {
+
+__device__ __forceinline__ void bn_group_sums_arrive(const BnGroupSums& gs, float* a, float* b, int grp, int C, int c, float v1, float v2) {
+    // thread 0 of workgroup (c, grp); a / b: the per-group arrays [groups][C]
+    if (!gs.out_a) { a[grp * C + c] = v1; b[grp * C + c] = v2; return; }
+    if (gs.groups == 1) { a[c] = v1; b[c] = v2; gs.out_a[c] = v1; gs.out_b[c] = v2; return; }
+    __hip_atomic_store(a + grp * C + c, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(b + grp * C + c, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(gs.cnt + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)(gs.groups - 1)) {
+        float sa = 0.f, sb = 0.f;
+        for (int g = 0; g < gs.groups; ++g) {
+            sa += __hip_atomic_load(a + g * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sb += __hip_atomic_load(b + g * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        gs.out_a[c] = sa;
+        gs.out_b[c] = sb;
+        __hip_atomic_store(gs.cnt + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int NV>                    // 16-byte vectors per thread
 __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const void* dy, const void* x, int xd, const float* mean, const float* invstd,
                                                           const float* gamma, const float* beta, int act, float* sum_dz, float* sum_dz_xhat,
-                                                          void* dx, int dxd, int Bg, int C, int HW, int training) {
+                                                          void* dx, int dxd, int Bg, int C, int HW, int training, BnGroupSums gs) {
     __shared__ double red[16];
     const int c = blockIdx.x, grp = blockIdx.y;
     const int w = xd == VS_F32 ? 4 : 8;
@@ -545,7 +580,6 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const void* dy, const
     }
     const double t1 = block_sum((double)a1, red);
     const double t2 = block_sum((double)a2, red);
-    if (threadIdx.x == 0) { sum_dz[grp * C + c] = (float)t1; sum_dz_xhat[grp * C + c] = (float)t2; }
     const float inv_n = 1.f / (float)((int64_t)Bg * HW);
     const float k1 = (float)t1 * inv_n, k2 = (float)t2 * inv_n;
 #pragma unroll
@@ -560,6 +594,7 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const void* dy, const
             st_vec(dx, dxd, idx, o, w);
         }
     }
+    if (threadIdx.x == 0) bn_group_sums_arrive(gs, sum_dz, sum_dz_xhat, grp, C, c, (float)t1, (float)t2);      // (last: the drain waits for this thread's stores too)
 }
 
 // The same for the fused residual block (functional.ConvResBlockFn): training mode, one call group, z in a 16-bit type; the upstream
@@ -856,7 +891,7 @@ template <int NV, int ACT, int XD>
 __global__ __launch_bounds__(1024) void bn_bwd_slab_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dz,
-                                                           float* sum_dz_xhat, void* __restrict__ dx, int dxd, int Bg, int C, int HW) {
+                                                           float* sum_dz_xhat, void* __restrict__ dx, int dxd, int Bg, int C, int HW, BnGroupSums gs) {
     __shared__ double red[16];
     const int c = blockIdx.x, grp = blockIdx.y;
     const int per = HW >> 3, bstep = 1024 / per;                           // (the thread -> vector map of bn_fwd_slab_kernel)
@@ -890,7 +925,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_slab_kernel(const unsigned short*
     slab_fence<NV>(gv);
     const double t1 = block_sum((double)a1, red);
     const double t2 = block_sum((double)a2, red);
-    if (threadIdx.x == 0) { sum_dz[grp * C + c] = (float)t1; sum_dz_xhat[grp * C + c] = (float)t2; }
+    if (threadIdx.x == 0) bn_group_sums_arrive(gs, sum_dz, sum_dz_xhat, grp, C, c, (float)t1, (float)t2);
     const float inv_n = 1.f / (float)((int64_t)Bg * HW);
     const float k1 = (float)t1 * inv_n, k2 = (float)t2 * inv_n;
 #pragma unroll
@@ -919,7 +954,7 @@ template <int NV, int NL, int ACT, int XD>
 __global__ __launch_bounds__(1024) void bn_bwd_slab_lds_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* sum_dz,
-                                                               float* sum_dz_xhat, void* __restrict__ dx, int dxd, int Bg, int C, int HW) {
+                                                               float* sum_dz_xhat, void* __restrict__ dx, int dxd, int Bg, int C, int HW, BnGroupSums gs) {
     extern __shared__ __attribute__((aligned(16))) char gl_raw[];            // dy vectors [NL][1024] x 16 bytes (the ONLY dynamic LDS object)
     __shared__ double red[16];
     u32x4* gl = reinterpret_cast<u32x4*>(gl_raw);
@@ -967,7 +1002,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_slab_lds_kernel(const unsigned sh
     slab_fence<NV>(xv);
     const double t1 = block_sum((double)a1, red);
     const double t2 = block_sum((double)a2, red);
-    if (threadIdx.x == 0) { sum_dz[grp * C + c] = (float)t1; sum_dz_xhat[grp * C + c] = (float)t2; }
+    if (threadIdx.x == 0) bn_group_sums_arrive(gs, sum_dz, sum_dz_xhat, grp, C, c, (float)t1, (float)t2);
     const float inv_n = 1.f / (float)((int64_t)Bg * HW);
     const float k1 = (float)t1 * inv_n, k2 = (float)t2 * inv_n;
     // the tail of dy again (its registers were given up after the sums)
@@ -997,7 +1032,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_slab_lds_kernel(const unsigned sh
 
 template <int NV, int ACT, int XD>
 int launch_bn_bwd_slab_lds(dim3 grid, hipStream_t st, const void* dy, const void* x, const float* mean, const float* invstd, const float* gamma,
-                           const float* beta, int act, float* s1, float* s2, void* dx, int dxd, int Bg, int C, int HW) {
+                           const float* beta, int act, float* s1, float* s2, void* dx, int dxd, int Bg, int C, int HW, BnGroupSums gs) {
     constexpr int NL = 9;
     auto kfn = bn_bwd_slab_lds_kernel<NV, NL, ACT, XD>;
     constexpr int lds = NL * 1024 * 16;
@@ -1008,7 +1043,7 @@ int launch_bn_bwd_slab_lds(dim3 grid, hipStream_t st, const void* dy, const void
         attr_set = true;
     }
     hipLaunchKernelGGL(kfn, grid, dim3(1024), lds, st, (const unsigned short*)dy, (const unsigned short*)x, mean, invstd, gamma, beta, act, s1, s2, dx, dxd,
-                       Bg, C, HW);
+                       Bg, C, HW, gs);
     return VS_OK;
 }
 
@@ -1531,6 +1566,21 @@ extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, i
     if ((!vec || x_dtype != dy_dtype) && HW >= 8 && (int64_t)B * C * HW < ((int64_t)1 << 31) && ((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0)
         vec = 2;                                                         // ragged planes and / or mixed dtypes: unit-per-plane path
     (void)w_;
+    // the group sums inside the producing launch (bn_group_sums_arrive); VS_BN_GSUM_FUSED=0: the separate group_sum2_kernel launch
+    BnGroupSums gs{groups, nullptr, nullptr, nullptr};
+    {
+        const char* env = getenv("VS_BN_GSUM_FUSED");                 // read per call: tests switch it
+        if (dbeta_sum && !(env && atoi(env) == 0) && C <= 4096) {
+            static unsigned* pool = nullptr;
+            static unsigned next = 0;
+            if (!pool && hipGetSymbolAddress((void**)&pool, HIP_SYMBOL(vs_bn_arrive_pool)) != hipSuccess) pool = nullptr;
+            if (pool) {
+                if (next + (unsigned)C > BN_ARRIVE_POOL) next = 0;
+                gs.out_a = dbeta_sum; gs.out_b = dgamma_sum; gs.cnt = pool + next;
+                next += (unsigned)C;
+            }
+        }
+    }
     {
         // one launch for small slabs (see bn_bwd_small_kernel); enough workgroups to be worth it
         static const int small_mode = getenv("VS_BN_SMALL") ? atoi(getenv("VS_BN_SMALL")) : 1;
@@ -1542,14 +1592,14 @@ extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, i
             const dim3 grid(C, groups);
 #define VS_BN_SMALL(NV)                                                                                                              \
             hipLaunchKernelGGL(bn_bwd_small_kernel<NV>, grid, dim3(256), 0, (hipStream_t)stream, dy, x, x_dtype, mean, invstd, gamma, beta, act,  \
-                               dbeta, dgamma, dx, dx_dtype, B / groups, C, (int)HW, training)
+                               dbeta, dgamma, dx, dx_dtype, B / groups, C, (int)HW, training, gs)
             if (nvec <= 256) VS_BN_SMALL(1);
             else if (nvec <= 512) VS_BN_SMALL(2);
             else if (nvec <= 1024) VS_BN_SMALL(4);
             else VS_BN_SMALL(8);
 #undef VS_BN_SMALL
             VS_CHECK_LAUNCH("vs_bn_act_bwd (small slabs)");
-            if (dbeta_sum) {
+            if (dbeta_sum && !gs.out_a) {
                 hipLaunchKernelGGL(group_sum2_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dbeta, dgamma, groups, C, dbeta_sum,
                                    dgamma_sum);
                 VS_CHECK_LAUNCH("vs_bn_act_bwd (group sums)");
@@ -1570,10 +1620,10 @@ extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, i
             do {                                                                                                                          \
                 if (x_dtype == VS_BF16)                                                                                                   \
                     hipLaunchKernelGGL((bn_bwd_slab_kernel<NV, AV, VS_BF16>), grid, dim3(1024), 0, st, (const unsigned short*)dy, (const unsigned short*)x, mean, \
-                                       invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, (int)HW);                    \
+                                       invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, (int)HW, gs);                \
                 else                                                                                                                      \
                     hipLaunchKernelGGL((bn_bwd_slab_kernel<NV, AV, VS_F16>), grid, dim3(1024), 0, st, (const unsigned short*)dy, (const unsigned short*)x, mean,  \
-                                       invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, (int)HW);                    \
+                                       invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype, B / groups, C, (int)HW, gs);                \
             } while (0)
 #define VS_BN_SLAB_NV(AV)                          \
             do {                                   \
@@ -1587,7 +1637,7 @@ extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, i
 #undef VS_BN_SLAB_NV
 #undef VS_BN_SLAB
             VS_CHECK_LAUNCH("vs_bn_act_bwd (resident slabs)");
-            if (dbeta_sum) {
+            if (dbeta_sum && !gs.out_a) {
                 hipLaunchKernelGGL(group_sum2_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, st, dbeta, dgamma, groups, C, dbeta_sum, dgamma_sum);
                 VS_CHECK_LAUNCH("vs_bn_act_bwd (group sums)");
             }
@@ -1606,9 +1656,9 @@ extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, i
             int rc;
 #define VS_BN_SLAB(NV, AV)                                                                                                                            \
             rc = x_dtype == VS_BF16 ? launch_bn_bwd_slab_lds<NV, AV, VS_BF16>(grid, st, dy, x, mean, invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype,   \
-                                                                              B / groups, C, (int)HW)                                                  \
+                                                                              B / groups, C, (int)HW, gs)                                              \
                                     : launch_bn_bwd_slab_lds<NV, AV, VS_F16>(grid, st, dy, x, mean, invstd, gamma, beta, act, dbeta, dgamma, dx, dx_dtype,    \
-                                                                             B / groups, C, (int)HW)
+                                                                             B / groups, C, (int)HW, gs)
 #define VS_BN_SLAB_NV(AV)                              \
             do {                                       \
                 if (nvec <= 12288) VS_BN_SLAB(12, AV); \
@@ -1622,7 +1672,7 @@ extern "C" int vs_bn_act_bwd_gsum(const void* dy, int dy_dtype, const void* x, i
 #undef VS_BN_SLAB
             if (rc != VS_OK) return rc;
             VS_CHECK_LAUNCH("vs_bn_act_bwd (resident slabs, LDS)");
-            if (dbeta_sum) {
+            if (dbeta_sum && !gs.out_a) {
                 hipLaunchKernelGGL(group_sum2_kernel, dim3((unsigned)vs_cdiv(C, 256)), dim3(256), 0, st, dbeta, dgamma, groups, C, dbeta_sum, dgamma_sum);
                 VS_CHECK_LAUNCH("vs_bn_act_bwd (group sums)");
             }

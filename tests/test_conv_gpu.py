@@ -1128,3 +1128,33 @@ def test_conv_k4s2_gather_on_4x4_planes_matches_fp64(dtype, geom):
     y = ops.conv_k4s2_gather(planes, ops.conv_k4s2_pack_weight(w.float().cuda(), dtype), bias.cuda(), M, torch.float32)
     ref = F.conv2d(x.double(), w.double(), bias.double(), stride=2, padding=1)
     assert ((y.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(8, 96, 16, 16, 4), (32, 64, 16, 16, 2), (48, 128, 32, 32, 3), (200, 64, 32, 32, 2), (6, 520, 8, 8, 3)])
+def test_bn_group_sums_inside_the_backward_launch_equal_the_separate_launch(shape, monkeypatch):
+    """vs_bn_act_bwd_gsum: the sums of d gamma / d beta over the call groups are formed by the LAST workgroup of each channel to arrive inside
+    the one-launch backward kernels (small / resident / resident + LDS slabs: csrc/vs_norm.hip, bn_group_sums_arrive) instead of a launch of
+    their own.  Same group order, so BIT-equal to the separate launch (VS_BN_GSUM_FUSED=0), on every one of 30 back-to-back calls beside a
+    bandwidth-hungry kernel on another stream (a stale partial or a lost arrival would show as a wrong or missing sum)."""
+    from spatiotemporal_variable_separation_amd import ops
+    from oracle.detdata import det_uniform
+    B, C, H, W, G = shape
+    x = ((det_uniform((B, C, H, W), 71) - 0.5) * 2).to(torch.bfloat16).cuda()
+    dy = ((det_uniform((B, C, H, W), 73) - 0.5) * 2).to(torch.bfloat16).cuda()
+    gamma = (det_uniform((C,), 75) + 0.5).cuda()
+    beta = (det_uniform((C,), 77) - 0.5).cuda()
+    mean, invstd = ops.bn_stats(x, None, None, 0.1, 1e-5, groups=G)
+    monkeypatch.setenv('VS_BN_GSUM_FUSED', '0')
+    dx0, dg0, db0 = ops.bn_act_bwd(dy, x, mean, invstd, gamma, beta, 'leaky_relu', True, torch.bfloat16, groups=G)
+    torch.cuda.synchronize()
+    monkeypatch.setenv('VS_BN_GSUM_FUSED', '1')
+    noise = torch.empty(32 << 20, device='cuda')
+    side = torch.cuda.Stream()
+    for it in range(30):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                noise.add_(1.0)
+        dx1, dg1, db1 = ops.bn_act_bwd(dy, x, mean, invstd, gamma, beta, 'leaky_relu', True, torch.bfloat16, groups=G)
+        assert torch.equal(dg1, dg0) and torch.equal(db1, db0), f'{shape} call {it}: group sums differ: {(dg1 - dg0).abs().max().item()}'
+        assert torch.equal(dx1, dx0)
+    torch.cuda.synchronize()
