@@ -312,13 +312,19 @@ def _run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=
         return total
 
     graphed = None
+    graph_stats = None
     if use_graph:
         # the timed region replays the recorded step (train.GraphedStep: the same kernels, launched by hipGraphLaunch instead
         # of Python-issued launches); with N > 1 ranks: graph(losses + backward) -> bucket all-reduces -> graph(Adam)
+        os.environ.setdefault('VARSEP_GRAPH_STATS', '1')       # keep the captured hipGraph_t: node / edge counts of the recording go into the result
         graphed = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'],
                               (lam['ae'], lam['s'], lam['t'], lam['pred']), bool(cfg.get('average_tloss')),
                               warmup=max(1, min(warmup, 3)), grad_sync=sync, scaler=scaler)
         timed_step = graphed.step
+        try:
+            graph_stats = graphed.graph_stats()
+        except Exception:                                 # measurement only: never in the way of the timing
+            graph_stats = None
     else:
         timed_step = step
     for _ in range(warmup):
@@ -379,7 +385,7 @@ def _run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=
     out = {'cfg': cfg, 'ms': statistics.median(regions) / steps * 1e3, 'ms_all': [round(r / steps * 1e3, 4) for r in regions],
            'prof': prof, 'sampled': sampled, 'loss': final_loss, 'comm_bf16': comm_bf16, 'use_graph': use_graph,
            'scaler': None if scaler is None else scaler.describe(), 'optimizer': opt_text, 'precision': precision,
-           'full_size': batch is None and not rk.ddp}
+           'full_size': batch is None and not rk.ddp, 'graph': graph_stats}
     VF.fold_repeated_gradients(False)
     del graphed, net, opt, sync
     torch.cuda.empty_cache()
@@ -598,6 +604,8 @@ def compact_line(full, limit=4000):
     out['config'] = {k: cfg[k] for k in ('workload', 'global_batch', 'parallelism', 'grad_allreduce', 'launch', 'final_loss') if k in cfg}
     rf = full.get('roofline')
     out['roofline'] = None if rf is None else {k: rf[k] for k in _ROOF_KEYS if k in rf}
+    if full.get('graph'):
+        out['graph'] = full['graph']
     cb = full.get('cpu_baseline')
     if cb is not None:
         out['cpu_baseline'] = {k: cb[k] for k in ('value', 'unit', 'cores', 'ms_per_step', 'kind', 'sample', 'by_threads_ms_per_step') if k in cb}
@@ -710,7 +718,7 @@ def main():
             configs[name] = {'workload': workload_text(wname, c), 'ms_per_step': round(r['ms'], 4), 'n_gpus': rk.world,
                              'value': round(rk.world * c['batch'] * c['nt_pred'] / (r['ms'] * 1e-3), 1), 'unit': 'frames/s',
                              'steps': st, 'warmup': wu, 'ms_per_step_all': r['ms_all'], 'dtype': prec,
-                             'grad_allreduce': allreduce_text(rk, r), 'optimizer': r['optimizer'], 'final_loss': round(r['loss'], 5),
+                             'grad_allreduce': allreduce_text(rk, r), 'optimizer': r['optimizer'], 'final_loss': round(r['loss'], 5), 'graph': r.get('graph'),
                              'roofline': rf, 'roofline_others': oth}
             if r['scaler']:
                 configs[name]['loss_scaling'] = r['scaler']
@@ -732,6 +740,8 @@ def main():
                    'timing': 'median of %d regions of %d steps' % (len(res['ms_all']), args.steps),
                    'final_loss': round(res['loss'], 5)},
         'roofline': roof, 'roofline_others': others,
+        # nodes / kernel nodes / dependency edges / roots of the recorded step (train.GraphedStep.graph_stats): what one replay costs the host
+        'graph': res.get('graph'),
     }
     if res['scaler']:
         out['config']['loss_scaling'] = res['scaler']

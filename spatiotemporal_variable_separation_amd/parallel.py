@@ -295,24 +295,25 @@ class GradAllReducer:
         head = self._head.get(bi, (0, []))[0]
         if head:
             lo, hi = self._slice(bi)
-            if self.backend == 'nccl':
-                if self.world_size == 1:
-                    dist.reduce_scatter_tensor(wire[lo:hi], wire[:head], op=dist.ReduceOp.SUM, group=self.group)  # in place: no launch at all
-                else:
-                    # N > 1: the slice is received in a buffer of its own (1 / N of the head) and copied into place -- no aliasing of a
-                    # collective's input and output, which is RCCL-legal at exactly this offset but has never run here on more than one rank
-                    tmp = self._rs_tmp.get(bi)
-                    if tmp is None:
-                        tmp = self._rs_tmp[bi] = torch.empty(hi - lo, dtype=wire.dtype, device=wire.device)
+            if self.world_size == 1 and self.backend == 'nccl':
+                dist.reduce_scatter_tensor(wire[lo:hi], wire[:head], op=dist.ReduceOp.SUM, group=self.group)      # in place: no launch at all
+            elif self.world_size == 1:
+                pass                                       # gloo, one rank: the slice is the head and already holds the sums
+            else:
+                # N > 1, either backend: the slice is received in a buffer of its own (1 / N of the head) and copied into place -- no aliasing of
+                # a collective's input and output.  The buffer handling is shared, only the collective differs, so the two-rank gloo tests on
+                # device tensors (tests/test_ddp_gpu.py) run these lines although RCCL itself has never seen more than one rank here.
+                tmp = self._rs_tmp.get(bi)
+                if tmp is None:
+                    tmp = self._rs_tmp[bi] = torch.empty(hi - lo, dtype=wire.dtype, device=wire.device)
+                if self.backend == 'nccl':
                     dist.reduce_scatter_tensor(tmp, wire[:head], op=dist.ReduceOp.SUM, group=self.group)
-                    wire[lo:hi].copy_(tmp)
-            else:                                          # gloo (tests): no reduce-scatter / bf16 arithmetic there
-                host = wire[:head].float().cpu()
-                if self.world_size > 1:
+                else:                                      # gloo (tests): no reduce-scatter / 16-bit arithmetic there -- fp32 sums on the host
+                    host = wire[:head].float().cpu()
                     dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                mine = host[lo:hi].to(self.comm_dtype)
-                wire[:head].fill_(float('nan'))            # what a reduce-scatter leaves elsewhere is undefined: nobody may read it
-                wire[lo:hi].copy_(mine)
+                    tmp.copy_(host[lo:hi].to(self.comm_dtype))
+                    wire[:head].fill_(float('nan'))        # what a reduce-scatter leaves outside the slice is undefined: nobody may read it
+                wire[lo:hi].copy_(tmp)
         if t0 < flat.numel():                              # tail: small fp32 gradients, summed in fp32 (seeded with 1 / world_size)
             tail = flat[t0:]
             lowp = self.shard_tail_dtype != torch.float32
@@ -370,20 +371,22 @@ class GradAllReducer:
             import contextlib
             ctx = contextlib.nullcontext()
         with ctx:
-            if self.backend == 'nccl':
-                if self.world_size == 1:
+            if self.world_size == 1:
+                if self.backend == 'nccl':
                     dist.all_gather_into_tensor(arena, arena[lo:hi], group=self.group)              # in place
-                else:
-                    tmp = self._ag_tmp.get(bi)                                                      # (as above: the contribution from a copy of the slice)
-                    if tmp is None:
-                        tmp = self._ag_tmp[bi] = torch.empty(hi - lo, dtype=arena.dtype, device=arena.device)
-                    tmp.copy_(arena[lo:hi])
+            else:
+                tmp = self._ag_tmp.get(bi)                                                          # (as above: the contribution from a copy of the slice)
+                if tmp is None:
+                    tmp = self._ag_tmp[bi] = torch.empty(hi - lo, dtype=arena.dtype, device=arena.device)
+                tmp.copy_(arena[lo:hi])
+                if self.backend == 'nccl':
                     dist.all_gather_into_tensor(arena, tmp, group=self.group)
-            elif self.world_size > 1:
-                mine = arena[lo:hi].view(torch.int32).cpu()          # (gloo moves no 16-bit types; a slice is a whole number of 128-byte lines)
-                parts = [torch.empty_like(mine) for _ in range(self.world_size)]
-                dist.all_gather(parts, mine, group=self.group)
-                arena.view(torch.int32).copy_(torch.cat(parts))
+                else:
+                    arena.fill_(float('nan'))                        # (an all-gather defines every element: whatever survives this is a bug)
+                    mine = tmp.view(torch.int32).cpu()               # (gloo moves no 16-bit types; a slice is a whole number of 128-byte lines)
+                    parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+                    dist.all_gather(parts, mine, group=self.group)
+                    arena.view(torch.int32).copy_(torch.cat(parts))
 
     def wait_comm(self):
         if self._comm_stream is not None:

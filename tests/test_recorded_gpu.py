@@ -201,3 +201,20 @@ def test_recorded_training_tracks_fp32_oracle(case):
     assert ref[-1] < ref[0], 'the oracle run does not train'
     assert losses[-1] < losses[0], f'{case}: the recorded run does not train: {losses[0]} -> {losses[-1]}'
     print(case, 'loss %.5g -> %.5g (oracle %.5g -> %.5g, emulation -> %.5g); worst distance / bound %.2f at step %d' % (losses[0], losses[-1], ref[0], ref[-1], emu[-1], worst, at))
+
+
+def test_recorded_waveeq_step_stays_within_its_node_budget(monkeypatch):
+    """The replayed WaveEq step is a hipGraph of kernel nodes on up to eight streams; the host pays per node and per dependency edge of a
+    replay (~14 us per node: 1.02 ms of enqueue against 1.19 ms of device time, tools/host_vs_gpu.py), so the node count is a budget: round 5
+    recorded 84 kernels per step, round 6 records 73 (graph_stats() of the captured hipGraph_t).  A change that adds launches to the recorded
+    step has to show up here."""
+    monkeypatch.setenv('VARSEP_GRAPH_STATS', '1')
+    cfg = FULL_CONFIGS['full_waveeq']
+    gold = load_golden('full_waveeq')
+    net, before, losses, g = _recorded(cfg, 'bf16', [int(gold['t_random'])], 1)
+    st = g.graph_stats()
+    assert st is not None and st['roots'] == 1, st
+    assert st['kernel_nodes'] == st['nodes'], f'only kernel nodes are expected in the recording (no memset / memcpy nodes): {st}'
+    assert st['kernel_nodes'] <= 76, f'the recorded WaveEq step grew to {st["kernel_nodes"]} kernel nodes (budget 76): {st}'
+    assert st['edges'] <= 96, f'{st["edges"]} dependency edges (budget 96): {st}'
+    print('recorded WaveEq step:', st)
