@@ -99,14 +99,14 @@ int launch_big_layout(int la, int lb, const void* A, int64_t lda, const void* B,
 }
 
 // the 256 x 256 / 256 x 128 tile with two staggered wave groups (vs_gemm_p8.h)
-template <int CT, int LA, int LB, int NI, bool LOSS = false>
+template <int CT, int LA, int LB, int NI, bool LOSS = false, int MI = 4>
 int launch_p8(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const P8Plan& pp, int batch, const Epi& epi, float* slabs,
               hipStream_t stream) {
     if constexpr (CT == VS_F32) {
         return vs_fail(VS_ERR_UNSUPPORTED, "vs_gemm: the staggered 256-row tile is a 16-bit kernel");
     } else {
-        auto kfn = gemm_p8_kernel<CT, LA, LB, NI, false, LOSS>;
-        constexpr int lds = 2 * (2 * 128 * P8_BK * 2 + 2 * 64 * NI * P8_BK * 2);
+        auto kfn = gemm_p8_kernel<CT, LA, LB, NI, false, LOSS, MI>;
+        constexpr int lds = 2 * (2 * 32 * MI * P8_BK * 2 + 2 * 64 * NI * P8_BK * 2);
         static bool attr_set = false;                  // 96 / 128 KiB of dynamic LDS: above the 64 KiB default limit
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -124,6 +124,12 @@ int launch_p8(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M,
 template <int CT>
 int launch_p8_layout(int la, int lb, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const P8Plan& pp, int batch,
                      const Epi& epi, float* slabs, hipStream_t stream) {
+    if (pp.ni == 1 && pp.mi == 2) {
+        if (la == LR && lb == LR) return launch_p8<CT, LR, LR, 1, false, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        if (la == LR && lb == LS) return launch_p8<CT, LR, LS, 1, false, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        if (la == LS && lb == LR) return launch_p8<CT, LS, LR, 1, false, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        return launch_p8<CT, LS, LS, 1, false, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+    }
     if (pp.ni == 1) {
         if (la == LR && lb == LR) return launch_p8<CT, LR, LR, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
         if (la == LR && lb == LS) return launch_p8<CT, LR, LS, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);

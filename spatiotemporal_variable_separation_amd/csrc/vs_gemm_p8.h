@@ -180,12 +180,14 @@ struct P8Reader {
         P8_FENCE;                               \
     } while (0)
 
-template <int CT, int LA, int LB, int NI, bool NCHW, bool LOSS = false>
-__global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
+// MI: 16-row accumulator repeats per quadrant (4: 256 rows per tile; 2: 128 rows -- 64 KiB of LDS and <= 128 registers, two workgroups per CU)
+template <int CT, int LA, int LB, int NI, bool NCHW, bool LOSS = false, int MI = 4>
+__global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
                                                       int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs) {
-    constexpr int BN = 128 * NI;
+    constexpr int BN = 128 * NI, BM = 64 * MI;
+    constexpr int RUN_A = 16 * MI, ROWS_A = 32 * MI;
     constexpr int RUN_B = 16 * NI, ROWS_B = 64 * NI;
-    typedef P8Operand<LA, 128, 64> OpA;
+    typedef P8Operand<LA, ROWS_A, RUN_A> OpA;
     typedef P8Operand<LB, ROWS_B, RUN_B> OpB;
     constexpr int HA = OpA::HALF_BYTES, HB = OpB::HALF_BYTES;
     constexpr int TILE = 2 * HA + 2 * HB;                             // one K tile: HA0 | HA1 | HB0 | HB1
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = wave >> 2, wc = wave & 3;
     const unsigned tile = big_tile_of(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(tile / (unsigned)tiles_n) * 256, n0 = (int64_t)(tile % (unsigned)tiles_n) * BN;
+    const int64_t m0 = (int64_t)(tile / (unsigned)tiles_n) * BM, n0 = (int64_t)(tile % (unsigned)tiles_n) * BN;
     const int64_t kt_total = (K + P8_BK - 1) / P8_BK;
     const int64_t kt_begin = (int64_t)zsplit * k_tiles_per_split;
     int64_t kt_end = kt_begin + k_tiles_per_split;
@@ -214,13 +216,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
     int64_t kt_full = K / P8_BK;                                     // tiles [kt_begin, kt_full) are full and live
     if (kt_full > kt_end) kt_full = kt_end;
 
-    f32x4 acc[2][2][4][NI];
+    f32x4 acc[2][2][MI][NI];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[i][j][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -230,16 +232,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
     ga.prepare(Ap, lda, M, m0, kt_begin * P8_BK, wave);
     gb.prepare(Bp, ldb, N, n0, kt_begin * P8_BK, wave);
 
-    u32x4 fa[4][2], fb0[NI][2], fb1[NI][2];                           // [repeat][k-step]
-    P8Reader<LA, 4> ra;
+    u32x4 fa[MI][2], fb0[NI][2], fb1[NI][2];                           // [repeat][k-step]
+    P8Reader<LA, MI> ra;
     P8Reader<LB, NI> rb;
-    ra.prepare((uint32_t)(uintptr_t)smem, TILE, 4 * wr, 128, lane);
+    ra.prepare((uint32_t)(uintptr_t)smem, TILE, MI * wr, ROWS_A, lane);
     rb.prepare((uint32_t)(uintptr_t)smem + 2 * HA, TILE, NI * wc, ROWS_B, lane);
     auto rd_a = [&](int P, int i) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[mi][ks] = ra.frag(P, i * HA, mi, ks, 128);
+            for (int ks = 0; ks < 2; ++ks) fa[mi][ks] = ra.frag(P, i * HA, mi, ks, ROWS_A);
     };
     auto rd_b = [&](u32x4(&fb)[NI][2], int P, int j) {
 #pragma unroll
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[i][j][mi][ni] = mfma16x32<CT>(fb[ni][ks], fa[mi][ks], acc[i][j][mi][ni]);
         __builtin_amdgcn_s_setprio(0);
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    constexpr int LGKM_B0 = (LA == LR ? 8 : 15);                      // reads of HA0 that may still be out when HB0's are done (4-bit counter)
+    constexpr int LGKM_B0 = (LA == LR ? 2 * MI : (4 * MI > 15 ? 15 : 4 * MI));                      // reads of HA0 that may still be out when HB0's are done (4-bit counter)
 
     // one K tile `u` out of buffer P (see the schedule in the header)
     auto k_tile = [&](auto pc, auto chk, int64_t u) {
@@ -275,8 +277,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
         P8_FENCE;
         ga.template stage<CHK, NXT + HA>(1, wbase, u + 1, kt_end, K);
         // HB0 is re-requested in phase 2: its reads (issued first) are retired here, ahead of this phase's barrier
-        if constexpr (LGKM_B0 == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LGKM_B0) : "memory");
         P8_BAR();
         mm(I0{}, I0{}, fb0);
         P8_BAR();
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
 
     // ---- epilogue: a lane holds C[m][n .. n+3] per accumulator ----
     float* slab_base = slabs ? slabs + (int64_t)blockIdx.z * M * N : nullptr;
-    const int64_t mw = m0 + wr * 128 + (lane & 15), nw = n0 + wc * (2 * RUN_B) + (lane >> 4) * 4;
+    const int64_t mw = m0 + wr * (2 * RUN_A) + (lane & 15), nw = n0 + wc * (2 * RUN_B) + (lane >> 4) * 4;
     if constexpr (LOSS) {
         // frame losses (vs_gemm_frame_loss): compare with the target frames instead of storing; partial sums per workgroup
         float fl_s0 = 0.f, fl_s1 = 0.f;
@@ -355,11 +356,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
             }
         auto loss_rows = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            f32x4 tg[2][NI][4];
-            int gg[4];
+            f32x4 tg[2][NI][MI];
+            int gg[MI];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                int64_t m = mw + i * 64 + mi * 16;
+            for (int mi = 0; mi < MI; ++mi) {
+                int64_t m = mw + i * RUN_A + mi * 16;
                 if (m > M - 1) m = M - 1;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -371,8 +372,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
                     }
             }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int64_t m = mw + i * 64 + mi * 16;
+            for (int mi = 0; mi < MI; ++mi) {
+                const int64_t m = mw + i * RUN_A + mi * 16;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -409,12 +410,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) {
-                            const int64_t m = mw + i * 64 + mi * 16, n = nw + j * RUN_B + ni * 16;
+                            const int64_t m = mw + i * RUN_A + mi * 16, n = nw + j * RUN_B + ni * 16;
                             if (m < M && n < N) *reinterpret_cast<f32x4*>(slab_base + m * N + n) = acc[i][j][mi][ni];
                         }
         } else if (fast && !slab_base) {
@@ -432,14 +433,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
                         // the mask values of the column's eight accumulators are requested TOGETHER, from clamped (always valid) addresses and ahead of
                         // the bounds branches: a load behind each branch would be waited for one at a time (8 x ~1 us per column group)
                         // (raw bits until they are used: a conversion next to the load would wait for it)
-                        f32x4 yf[2][4];
-                        u16x4 yh[2][4];
+                        f32x4 yf[2][MI];
+                        u16x4 yh[2][MI];
                         if (epi.mask) {
 #pragma unroll
                             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                                for (int mi = 0; mi < 4; ++mi) {
-                                    int64_t m = mw + i * 64 + mi * 16;
+                                for (int mi = 0; mi < MI; ++mi) {
+                                    int64_t m = mw + i * RUN_A + mi * 16;
                                     if (m > M - 1) m = M - 1;
                                     if (epi.mask_dtype == VS_F32) yf[i][mi] = *reinterpret_cast<const f32x4*>((const float*)epi.mask + m * epi.ldmask + n_c);
                                     else yh[i][mi] = *reinterpret_cast<const u16x4*>((const unsigned short*)epi.mask + m * epi.ldmask + n_c);
@@ -448,8 +449,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int mi = 0; mi < 4; ++mi) {
-                                const int64_t m = mw + i * 64 + mi * 16;
+                            for (int mi = 0; mi < MI; ++mi) {
+                                const int64_t m = mw + i * RUN_A + mi * 16;
                                 if (!(m < M && n < N)) continue;
                                 f32x4 r;
 #pragma unroll
@@ -480,19 +481,19 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
         } else {
             // accumulators -> LDS (idle now; compile-time indices) -> a run-time loop over them: a lane reads back what it wrote itself
             P8_BAR();                                                  // every wave's requests have landed (vmcnt(0) above): the buffers are free
-            f32x4* const stg = reinterpret_cast<f32x4*>(smem) + wave * (8 * NI * 64) + lane;
+            f32x4* const stg = reinterpret_cast<f32x4*>(smem) + wave * (2 * MI * NI * 64) + lane;
             auto pass = [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) stg[((j * 4 + mi) * NI + ni) * 64] = acc[i][j][mi][ni];
+                        for (int ni = 0; ni < NI; ++ni) stg[((j * MI + mi) * NI + ni) * 64] = acc[i][j][mi][ni];
 #pragma unroll 1
-                for (int q = 0; q < 8 * NI; ++q) {
-                    const int ni = q % NI, mi = (q / NI) & 3, j = q / (4 * NI);
-                    const int64_t m = mw + i * 64 + mi * 16, n = nw + j * RUN_B + ni * 16;
+                for (int q = 0; q < 2 * MI * NI; ++q) {
+                    const int ni = q % NI, mi = (q / NI) % MI, j = q / (MI * NI);
+                    const int64_t m = mw + i * RUN_A + mi * 16, n = nw + j * RUN_B + ni * 16;
                     const f32x4 v = stg[q * 64];
                     if (m < M && n < N) big_store4<NCHW>(epi, m, n, N, v, slab_base ? slab_base + m * N : nullptr);
                 }
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const unsigned short* Ap, 
 
 // ---- when to take it ---------------------------------------------------------------------------------------------------------
 // One workgroup per CU (128 / 96 KiB of LDS).  VS_GEMM_P8: 0 = never, 1 = by plan (default), 2 = whenever the operands allow (tests).
-struct P8Plan { bool use; int ni; int splits; int64_t k_tiles_per_split; int tiles_m, tiles_n; };
+struct P8Plan { bool use; int ni; int splits; int64_t k_tiles_per_split; int tiles_m, tiles_n; int mi = 4; };
 
 inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t batch, int lb) {
     P8Plan p{false, 2, 1, vs_cdiv(K, P8_BK), (int)vs_cdiv(M, 256), (int)vs_cdiv(N, 256)};
@@ -515,8 +516,11 @@ inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t
     const char* env_ni = getenv("VS_GEMM_P8_NI");
     const int force_ni = env_ni ? atoi(env_ni) : 0;
     auto fill_of = [&](int bn) { return (double)M * (double)N / ((double)vs_cdiv(M, 256) * 256.0 * (double)vs_cdiv(N, bn) * (double)bn); };
+    const char* env_mi = getenv("VS_GEMM_P8_MI");
+    const int force_mi = env_mi ? atoi(env_mi) : 0;
     if (mode == 2) {
         p.ni = force_ni == 1 ? 1 : 2;
+        if (force_mi == 2 && p.ni == 1) { p.mi = 2; p.tiles_m = (int)vs_cdiv(M, 128); }
         p.tiles_n = (int)vs_cdiv(N, 128 * p.ni);
         p.use = (int64_t)p.tiles_m * p.tiles_n * batch <= 65535;
         return p;
@@ -545,6 +549,17 @@ inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t
     if (t256 >= 160 && fill_of(256) >= 0.8) { p.use = true; return p; }
     // 256 x 128 where the 256-wide tiles leave most CUs idle (decoder layers of the WaveEq model, 3328 x 1200: 65 -> 130 tiles; measured in the
     // replayed WaveEq step against the 64 x 64 tile, two interleaved pairs: 1.2309 / 1.2380 vs 1.2424 / 1.2459 ms).  VS_GEMM_P8_NI=2: never.
+    // 128 x 128 (MI = 2, two workgroups per CU) where that fills the chip once: 3328 x 1200 -> 260 workgroups on 512 slots.  VS_GEMM_P8_MI=4: never.
+    const int64_t t128sq = (int64_t)vs_cdiv(M, 128) * vs_cdiv(N, 128) * batch;
+    const double fill128sq = (double)M * (double)N / ((double)vs_cdiv(M, 128) * 128.0 * (double)vs_cdiv(N, 128) * 128.0);
+    if (force_ni != 2 && force_mi != 4 && force_mi == 2 && t128sq >= 200 && t128sq <= 512 && fill128sq >= 0.85 && p.k_tiles_per_split >= 8) {
+        p.ni = 1;
+        p.mi = 2;
+        p.tiles_m = (int)vs_cdiv(M, 128);
+        p.tiles_n = (int)vs_cdiv(N, 128);
+        p.use = true;
+        return p;
+    }
     const int64_t t128 = (int64_t)p.tiles_m * vs_cdiv(N, 128) * batch;
     if (force_ni != 2 && t128 >= 96 && t128 <= 256 && fill_of(128) >= 0.85 && p.k_tiles_per_split >= 8) {
         p.ni = 1;

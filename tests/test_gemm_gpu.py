@@ -467,10 +467,12 @@ class _Env:
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('la,lb,ni', [(0, 0, '2'), (0, 1, '2'), (1, 0, '2'), (1, 1, '2'), (0, 0, '1'), (1, 0, '1')])
+@pytest.mark.parametrize('la,lb,ni', [(0, 0, '2'), (0, 1, '2'), (1, 0, '2'), (1, 1, '2'), (0, 0, '1'), (1, 0, '1'), (0, 1, '1'), (1, 1, '1'),
+                                      (0, 0, '1m2'), (0, 1, '1m2'), (1, 0, '1m2'), (1, 1, '1m2')])
 @pytest.mark.parametrize('shape', P8_SHAPES)
 def test_gemm_p8_tile_all_layouts(dtype, la, lb, ni, shape):
-    """Every operand layout and both tile widths of the staggered tile, forced (VS_GEMM_P8=2): one K tile only, row / column / K tails (the
+    """Every operand layout and the three tile shapes of the staggered tile (256 x 256, 256 x 128, and '1m2' = 128 x 128 with two workgroups per
+    CU), forced (VS_GEMM_P8=2): one K tile only, row / column / K tails (the
     partial K tile reads zeros), the straight-line epilogues (bias + relu to fp32, 16-bit output, leaky mask) and the general one (sigmoid;
     accumulate), against fp64 on the same rounded operands."""
     from spatiotemporal_variable_separation_amd import ops
@@ -482,7 +484,7 @@ def test_gemm_p8_tile_all_layouts(dtype, la, lb, ni, shape):
     mask = (det_uniform((M, N), 31) - 0.3).to(dtype)
     prev = det_uniform((M, N), 33)
     acc = prev.clone().cuda()
-    with _Env(VS_GEMM_P8='2', VS_GEMM_P8_NI=ni):
+    with _Env(VS_GEMM_P8='2', VS_GEMM_P8_NI=ni[0], VS_GEMM_P8_MI='2' if ni.endswith('m2') else '4'):
         out = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='relu')
         out16 = ops.gemm(a, la, b, lb, M, N, K, out_dtype=dtype)
         outm = ops.gemm(a, la, b, lb, M, N, K, alpha=0.5, mask=mask.cuda(), mask_act='leaky_relu')
@@ -500,14 +502,14 @@ def test_gemm_p8_tile_all_layouts(dtype, la, lb, ni, shape):
     assert rel(acc, prev.double() + ref) < 2e-6, f'{dtype} ({la},{lb}) ni {ni} {shape}: accumulate'
 
 
-@pytest.mark.parametrize('ni', ['2', '1'])
+@pytest.mark.parametrize('ni', ['2', '1', '1m2'])
 def test_gemm_p8_integer_exact_and_repeatable(ni):
     """Small-integer operands (every product and sum exact in fp32): the staggered tile must reproduce the fp64 contraction BIT FOR BIT, on
     every one of 40 back-to-back launches beside a bandwidth-hungry kernel on another stream (a fragment read that overtakes its LDS-DMA or
     a request that overtakes the last read of its image shows up as rare wrong tiles, not as a tolerance miss)."""
     from spatiotemporal_variable_separation_amd import ops
     g = torch.Generator().manual_seed(5)
-    for (M, N, K, la, lb) in [(1000, 1016, 1224, 0, 0), (776, 520, 3336, 1, 0)] + ([(1016, 776, 1224, 0, 1), (520, 1000, 2056, 1, 1)] if ni == '2' else []):
+    for (M, N, K, la, lb) in [(1000, 1016, 1224, 0, 0), (776, 520, 3336, 1, 0)] + [(1016, 776, 1224, 0, 1), (520, 1000, 2056, 1, 1)]:
         a = torch.randint(-2, 3, (M, K), generator=g).float()
         b = torch.randint(-2, 3, (N, K), generator=g).float()
         ref = a @ b.t()
@@ -517,7 +519,7 @@ def test_gemm_p8_integer_exact_and_repeatable(ni):
         bb = bb if lb == 0 else bb.t().contiguous()
         noise = torch.empty(64 << 20, device='cuda')
         side = torch.cuda.Stream()
-        with _Env(VS_GEMM_P8='2', VS_GEMM_P8_NI=ni):
+        with _Env(VS_GEMM_P8='2', VS_GEMM_P8_NI=ni[0], VS_GEMM_P8_MI='2' if ni.endswith('m2') else '4'):
             for it in range(40):
                 if it % 3 == 0:
                     with torch.cuda.stream(side):

@@ -1,6 +1,6 @@
 // p8_bench.hip -- standalone correctness + timing harness of the 256 x (128 NI) "8 phases" GEMM tile (csrc/vs_gemm_p8.h).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/p8_bench.hip -o tools/probes/p8_bench
-//   p8_bench M N K la lb ni [mode]      la / lb: 0 = R, 1 = S; ni: 1 | 2 (256x128 | 256x256); mode: int = exact small-integer operands
+//   p8_bench M N K la lb ni [mode]      la / lb: 0 = R, 1 = S; ni: 1 | 2 | 12 (256x128 | 256x256 | 128x128); mode: int = exact small-integer operands
 //                                        (bit-exact against a naive kernel, repeated), rand = uniform [-1,1) operands (timing + tolerance),
 //                                        cold = rand with operand sets rotating through > 256 MB
 // Prints one line per run; exit code 1 on a mismatch.
@@ -32,15 +32,15 @@ __global__ void ref_kernel(const unsigned short* A, int64_t lda, int la, const u
     C[m * N + n] = s;
 }
 
-template <int LA, int LB, int NI>
+template <int LA, int LB, int NI, int MI = 4>
 static void launch(const unsigned short* A, int64_t lda, const unsigned short* B, int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    auto kfn = gemm_p8_kernel<VS_BF16, LA, LB, NI, false, false>;
-    constexpr int lds = 2 * (2 * 128 * 64 * 2 + 2 * 64 * NI * 64 * 2);
+    auto kfn = gemm_p8_kernel<VS_BF16, LA, LB, NI, false, false, MI>;
+    constexpr int lds = 2 * (2 * 32 * MI * 64 * 2 + 2 * 64 * NI * 64 * 2);
     static bool set = false;
     if (!set) { CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); set = true; }
     Epi epi{};
     epi.C = C; epi.ldc = N; epi.c_dtype = VS_F32; epi.alpha = 1.f;
-    const int tm = (int)((M + 255) / 256), tn = (int)((N + 128 * NI - 1) / (128 * NI));
+    const int tm = (int)((M + 64 * MI - 1) / (64 * MI)), tn = (int)((N + 128 * NI - 1) / (128 * NI));
     hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), lds, st, A, lda, B, ldb, M, N, K, (int)((K + 63) / 64), tn, epi, (float*)nullptr);
 }
 
@@ -58,6 +58,11 @@ int main(int argc, char** argv) {
         if (la == 0 && lb == 1) fn = launch<LR, LS, 2>;
         if (la == 1 && lb == 0) fn = launch<LS, LR, 2>;
         if (la == 1 && lb == 1) fn = launch<LS, LS, 2>;
+    } else if (ni == 12) {                        // 128 x 128 (MI = 2, NI = 1)
+        if (la == 0 && lb == 0) fn = launch<LR, LR, 1, 2>;
+        if (la == 0 && lb == 1) fn = launch<LR, LS, 1, 2>;
+        if (la == 1 && lb == 0) fn = launch<LS, LR, 1, 2>;
+        if (la == 1 && lb == 1) fn = launch<LS, LS, 1, 2>;
     } else {
         if (la == 0 && lb == 0) fn = launch<LR, LR, 1>;
         if (la == 0 && lb == 1) fn = launch<LR, LS, 1>;
