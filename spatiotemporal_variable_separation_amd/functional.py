@@ -781,6 +781,19 @@ class MLPChain(torch.autograd.Function):
         grads = [None] * (2 * L)
         dx = None
         lane = next_lane()                   # this chain's weight / bias gradients: one gradient stream, in order
+        tail_lane = lane
+        if (lane > 0 and deferred_held() and _late_mode() == '2' and tail_fused_updates() and L > 1 and params[0].requires_grad
+                and grad_output(params[0]) is None and fused_optimizer(params[0]) is not None and cdt != torch.float32
+                and os.environ.get('VARSEP_LATE_TAIL_ALONE', '0') == '1'):
+            # A chain whose fused first-layer update is HELD for the end of the integrator's backward kernel (E_s in the batched MLP step: 640 MB
+            # of HBM traffic that must not run beside that latency-bound kernel) keeps its lane for that update alone; its small weight gradients
+            # and bias sums ride on the previous chain's lane.  In the recording the update then depends on the chain's input gradient and on
+            # the integrator's kernel only -- not on its own small gradients, which sat behind the decoder's weight gradients on a shared
+            # hardware queue and started it ~180 us after the integrator's kernel had finished (timeline of round 6) -- so it runs in the
+            # HBM-idle window beside E_t's input-gradient chain instead of beside E_t's own 640 MB update.  MEASURED AND NOT THE DEFAULT
+            # (VARSEP_LATE_TAIL_ALONE=1 turns it on): 1.2521 / 1.2337 vs 1.2047 / 1.1930 ms -- E_t's input-gradient chain, the critical path
+            # after the integrator, loses more under the update's HBM traffic than the earlier start of the tail gives back.
+            lane = lane - 1
         bias_jobs = []                       # (slot, dz): all bias gradients of the chain in one launch at the end
         tail_job = None
         for l in range(L - 1, -1, -1):
@@ -840,8 +853,8 @@ class MLPChain(torch.autograd.Function):
             run_deferred(lambda views=views: ops.colsum_multi(dzs, outs=views, zero_flat=flat), *dzs, outs=flat, lane=lane)
         if tail_job is not None:
             tail_job[0]._vs_tail = True
-            tl = lane
-            if tail_split() and lane == N_LANES - 1 and N_LANES > 1 and not deferred_held():
+            tl = tail_lane
+            if tail_split() and tail_lane == N_LANES - 1 and N_LANES > 1 and not deferred_held():
                 # the LAST chain of backward (E_t in the batched MLP step: lane N_LANES - 1): its small weight gradients and bias sums (~90 us of
                 # 10 us launches on `lane`) run BESIDE its 640 MB first-layer update instead of in front of it -- the update goes to lane 0, whose
                 # work (the decoder's weight gradients) is long done; the integrator's late weight gradients move to `lane` (join_side_streams)
