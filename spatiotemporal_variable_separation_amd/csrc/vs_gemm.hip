@@ -363,7 +363,7 @@ extern "C" int vs_gemm_adam(int compute, int64_t M, int64_t N, int64_t K, const 
     Epi epi{param, N, VS_F32, alpha, nullptr, VS_ACT_NONE, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     epi.adam_m = exp_avg; epi.adam_v = exp_avg_sq; epi.adam_shadow = (unsigned short*)shadow; epi.adam_shadow_dtype = shadow_dtype;
     epi.adam_step = step; epi.adam_skipped = skipped; epi.adam_guard = vs_g_exchange_guard;
-    static const int adam_pipe = getenv("VS_ADAM_PIPE") ? atoi(getenv("VS_ADAM_PIPE")) : 1;
+    static const int adam_pipe = getenv("VS_ADAM_PIPE") ? atoi(getenv("VS_ADAM_PIPE")) : 1;      // 0: one row piece at a time; 1: four ahead; 3: + non-temporal state
     epi.adam_pipe = adam_pipe;
     epi.adam_lr = lr; epi.adam_beta1 = beta1; epi.adam_beta2 = beta2; epi.adam_eps = (float)eps;
     MidPlan mp{true, 1, vs_cdiv(K, BIG_BK), (int)vs_cdiv(M, 128), (int)vs_cdiv(N, 128), 5};

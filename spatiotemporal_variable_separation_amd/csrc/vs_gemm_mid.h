@@ -245,11 +245,16 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
             const float* __restrict__ Mp = epi.adam_m + idx0;
             const float* __restrict__ Vp = epi.adam_v + idx0;
             const int sdt = epi.adam_shadow_dtype;
+            // adam_pipe & 2: the fp32 master and the two moments are touched once per step -- non-temporal loads and stores (they do not displace
+            // what the step re-reads from the L2s / the Infinity Cache); the 16-bit copy, read by the next forward pass, keeps the default policy
+            const bool nt = (epi.adam_pipe & 2) != 0;
+            auto ld4 = [&](const float* q) { return nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)) : *reinterpret_cast<const f32x4*>(q); };
+            auto st4 = [&](float* q, const f32x4& v) { if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q)); else *reinterpret_cast<f32x4*>(q) = v; };
 #pragma unroll
             for (int t = 0; t < G; ++t) {
-                p[0][t] = *reinterpret_cast<const f32x4*>(Pp + t * rstep);
-                mm[0][t] = *reinterpret_cast<const f32x4*>(Mp + t * rstep);
-                vv[0][t] = *reinterpret_cast<const f32x4*>(Vp + t * rstep);
+                p[0][t] = ld4(Pp + t * rstep);
+                mm[0][t] = ld4(Mp + t * rstep);
+                vv[0][t] = ld4(Vp + t * rstep);
             }
 #pragma unroll
             for (int g = 0; g < 16 / G; ++g) {
@@ -257,9 +262,9 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
 #pragma unroll
                     for (int t = 0; t < G; ++t) {
                         const int64_t o = ((g + 1) * G + t) * rstep;
-                        p[(g + 1) & 1][t] = *reinterpret_cast<const f32x4*>(Pp + o);
-                        mm[(g + 1) & 1][t] = *reinterpret_cast<const f32x4*>(Mp + o);
-                        vv[(g + 1) & 1][t] = *reinterpret_cast<const f32x4*>(Vp + o);
+                        p[(g + 1) & 1][t] = ld4(Pp + o);
+                        mm[(g + 1) & 1][t] = ld4(Mp + o);
+                        vv[(g + 1) & 1][t] = ld4(Vp + o);
                     }
                 }
 #pragma unroll
@@ -274,9 +279,9 @@ __global__ __launch_bounds__(256) void gemm_mid_kernel(const unsigned short* Ap,
                         pe[e] = a; me[e] = b; ve[e] = c;
                     }
                     const int64_t idx = idx0 + (g * G + t) * rstep;
-                    *reinterpret_cast<f32x4*>((float*)epi.C + idx) = pe;
-                    *reinterpret_cast<f32x4*>(epi.adam_m + idx) = me;
-                    *reinterpret_cast<f32x4*>(epi.adam_v + idx) = ve;
+                    st4((float*)epi.C + idx, pe);
+                    st4(epi.adam_m + idx, me);
+                    st4(epi.adam_v + idx, ve);
                     if (epi.adam_shadow) {
                         const u16x4 h = {vs_f2h(pe[0], sdt), vs_f2h(pe[1], sdt), vs_f2h(pe[2], sdt), vs_f2h(pe[3], sdt)};
                         *reinterpret_cast<u16x4*>(epi.adam_shadow + idx) = h;
