@@ -55,7 +55,7 @@ __device__ __forceinline__ void wg2_dma(uint32_t lds_dst, const void* sbase, uin
 // K4 = 1: the k4 s2 p1 family on parity planes (csrc/vs_conv_k4s2.hip): Cin = 4 K plane channels, K a multiple of 32, so the 32 channels of a workgroup
 // lie in ONE plane, which sees 2 x 2 of the 3 x 3 taps: four MFMAs per k-step, four slab positions written (vs_conv_k4s2_wgrad_finish reads no others)
 template <int CT, int W, int K4>
-__global__ __launch_bounds__(512, 2) void wgrad2_band_kernel(Wg2Pieces pieces, float* __restrict__ slabs, int B, int Cin, int H, int Cout, int ctiles, int ksplit) {
+__global__ __launch_bounds__(512, 2) void wgrad2_band_kernel(Wg2Pieces pieces, float* __restrict__ slabs, int B, int Cin, int H, int Cout, int ctiles, int ksplit, int lds_neighbours) {
     typedef Wg2Geo<W> G;
     constexpr int ROWB = W * 2;
     constexpr int NKY = K4 ? 2 : 3, NT = K4 ? 4 : 9;
@@ -200,10 +200,27 @@ __global__ __launch_bounds__(512, 2) void wgrad2_band_kernel(Wg2Pieces pieces, f
                     if (yimg < 0 || yimg >= H) continue;                          // a row outside the image contributes nothing
                     const unsigned char* src = xs + rl * (G::PPCP * 16) + ((row + ky) * W + q) * 2;
                     own = *reinterpret_cast<const u32x4*>(src);
-                    // (unconditional loads, the select on the address and on the value: a conditional load makes the compiler wait for each one)
-                    const unsigned lv = *reinterpret_cast<const unsigned*>(src - (q > 0 ? 4 : 0)), rv = *reinterpret_cast<const unsigned*>(src + (q + 8 < W ? 16 : 0));
-                    lft = q > 0 ? lv : 0u;
-                    rgt = q + 8 < W ? rv : 0u;
+                    // The sixteen pixels of a k-step are split over the two lane halves (h): the pixel AFTER the lower half's eight is the upper half's
+                    // first, the pixel BEFORE the upper half's eight is the lower half's last -- one v_permlane32_swap instead of two LDS reads.  What
+                    // is left for LDS is the pixel outside the sixteen (one ds_read_b32 per lane; none at W = 16, where a k-step is a whole row): the
+                    // channel pitch is a multiple of 16 bytes, so a 4-byte read of 32 channels is 4-way bank-conflicted whatever the pad, and round 5's
+                    // counters had these reads at 46-52 % of the kernel's LDS cycles (profiles/r05_*_mfma_util.md).
+                    if (lds_neighbours) {                                        // VS_WGRAD2_NB=1: the round-5 form (both neighbours from LDS), kept for A/B runs
+                        const unsigned lv = *reinterpret_cast<const unsigned*>(src - (q > 0 ? 4 : 0)), rv = *reinterpret_cast<const unsigned*>(src + (q + 8 < W ? 16 : 0));
+                        lft = q > 0 ? lv : 0u;
+                        rgt = q + 8 < W ? rv : 0u;
+                    } else {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(own[0], own[3], false, false);
+                        unsigned outer = 0u;
+                        if constexpr (W > 16) {
+                            // (unconditional load, the select on the address and on the value: a conditional load makes the compiler wait for each one)
+                            const bool need = h ? (q + 8 < W) : (q > 0);
+                            const unsigned ov = *reinterpret_cast<const unsigned*>(src + (need ? (h ? 16 : -4) : 0));
+                            outer = need ? ov : 0u;
+                        }
+                        lft = h ? sw[0] : outer;                                 // upper half: the lower half's last dword (its HIGH half is the pixel before)
+                        rgt = h ? outer : sw[1];                                 // lower half: the upper half's first dword (its LOW half is the pixel after)
+                    }
                 } else if constexpr (W == 8) {
                     // a lane's eight pixels are one whole row of an 8 x 8 map: no column neighbours; the tap row may leave the map (per lane half)
                     const int mp = t / 4, r8 = 2 * (t % 4) + h + ky - 1;
@@ -317,10 +334,15 @@ int wg2_launch(int compute, const Wg2Pieces& pieces, float* slabs, int B, int Ci
     const int ks = wg2_ksplit(B, Cin, H, W, Cout);
     const int mtiles = (int)vs_cdiv(Cout, 64), ctiles = (int)vs_cdiv(Cin, 32);
     const dim3 grid((unsigned)((int64_t)mtiles * ctiles * ks));
+    // the column neighbours of a lane's eight pixels: from LDS (1) or from the other lane half by v_permlane32_swap (0).  Same-box A/B of
+    // round 6 (tools/band_bench.py wgrad, VS_BAND_BENCH_VARIANTS="VS_WGRAD2_NB=0,1"): the swap form wins 4-9 % at W = 16 (no LDS read left:
+    // 88.7 vs 93.3, 123.5 vs 135.3, 107.6 vs 113.7 us) and loses 2-5 % at W = 32 / 64 (one conflicted read still needed + the selects).
+    const char* env = getenv("VS_WGRAD2_NB");                     // read per call: A/B runs switch it
+    const int nb = env ? atoi(env) : (W > 16 ? 1 : 0);
     if (compute == VS_BF16)
-        hipLaunchKernelGGL(kb, grid, dim3(512), lds, stream, pieces, slabs, B, Cin, H, Cout, ctiles, ks);
+        hipLaunchKernelGGL(kb, grid, dim3(512), lds, stream, pieces, slabs, B, Cin, H, Cout, ctiles, ks, nb);
     else
-        hipLaunchKernelGGL(kh, grid, dim3(512), lds, stream, pieces, slabs, B, Cin, H, Cout, ctiles, ks);
+        hipLaunchKernelGGL(kh, grid, dim3(512), lds, stream, pieces, slabs, B, Cin, H, Cout, ctiles, ks, nb);
     return VS_OK;
 }
 

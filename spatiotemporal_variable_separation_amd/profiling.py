@@ -60,7 +60,7 @@ GROUPS = [
     ('vs_operand_upkeep', r'^vs_pack|^vs_zero|^vs_cast|^vs_copy2d', r'tap_pack_kernel|pack_weight_kernel|pack_multi_kernel|conv3_img16_pack|vs_zero_kernel|cast_kernel|'
      r'copy2d_\w*kernel|step_increment_kernel', 'hbm'),
     ('vs_adam_multi', r'^vs_adam_multi', r'adam_multi_kernel', 'hbm'),
-    ('vs_train_losses', r'^vs_train_losses|^vs_frames_sse', r'train_losses_\w+_kernel|frames_sse|code_losses_\w+_kernel', 'hbm'),
+    ('vs_train_losses', r'^vs_train_losses|^vs_frames_sse', r'train_losses_\w+_kernel|frames_sse|code_losses_\w+_kernel|frame_loss_finish_kernel', 'hbm'),
     ('vs_colsum_multi', r'^vs_colsum_multi', r'colsum_multi_kernel', 'hbm'),
     ('vs_mix_codes', r'^vs_mix_codes', r'mix_codes_\w+_kernel', 'hbm'),
     ('at::native (torch elementwise / cat / reduce)', r'^$', r'^void at::native|^at::native|__amd_rocclr', 'hbm'),
