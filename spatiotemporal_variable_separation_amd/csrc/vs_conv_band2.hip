@@ -71,8 +71,12 @@ __device__ __forceinline__ void b2_dma(uint32_t lds_dst, const void* sbase, uint
 template <int CT, int W, int WM, int K4, int KC>
 __global__ __launch_bounds__(256 * WM, 2) void conv3_band2_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ Wp,
                                                                  const float* __restrict__ bias, void* __restrict__ Y, int yd, int B, int Creal, int H, int Cout,
-                                                                 int mgroups, int bands, int ntiles, int chunks_total, int nph) {
+                                                                 int mgroups, int bands, int ntiles, int chunks_total, int nph, int stagger) {
     typedef B2Geo<W, KC> G;
+    // VS_BAND2_STAGGER=k (an experiment, default 0): the second half of the grid -- under round-robin placement the second workgroup of every CU -- starts
+    // k x 1024 cycles late, so that the two co-resident workgroups do not meet at the matrix pipe and at the LDS in lockstep
+    if (stagger > 0 && (int)blockIdx.x >= ((int)gridDim.x >> 1))
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
     constexpr int NTHR = 256 * WM;
     constexpr int NKY = K4 ? 2 : 3, NF = K4 ? 2 : 3, NT = NKY * NF;               // tap rows, tap columns (fragments per group), taps per chunk
     constexpr int NJ = 2;                                                          // 32-pixel column tiles per wave
@@ -467,12 +471,14 @@ int b2_launch(int compute, const void* x, const void* w_packed, const float* bia
     const dim3 grid((unsigned)(ntiles < slots ? ntiles : slots));
     const int chunks_total = (int)vs_cdiv(Cin, 64) * 4;                             // the pack holds whole 64-channel phases (zeros beyond Cin)
     const int nph = (int)vs_cdiv(Cin, KC);
+    const char* se = getenv("VS_BAND2_STAGGER");                                    // read per call: A/B runs switch it
+    const int stagger = (se && per_cu == 2) ? atoi(se) : 0;
     if (compute == VS_BF16)
         hipLaunchKernelGGL(kb, grid, dim3(256 * WM), lds, stream, (const unsigned short*)x, (const unsigned short*)w_packed, bias, y, y_dtype, B, Cin, H, Cout,
-                           mgroups, bands, (int)ntiles, chunks_total, nph);
+                           mgroups, bands, (int)ntiles, chunks_total, nph, stagger);
     else
         hipLaunchKernelGGL(kh, grid, dim3(256 * WM), lds, stream, (const unsigned short*)x, (const unsigned short*)w_packed, bias, y, y_dtype, B, Cin, H, Cout,
-                           mgroups, bands, (int)ntiles, chunks_total, nph);
+                           mgroups, bands, (int)ntiles, chunks_total, nph, stagger);
     return VS_OK;
 }
 
