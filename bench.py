@@ -79,6 +79,8 @@ def parse():
     p.add_argument('--horizon', type=int, default=95, help='--eval: predicted frames beyond the conditioning window (README.md:116: 95)')
     p.add_argument('--no_cpu_baseline', action='store_true')
     p.add_argument('--no_graph', action='store_true', help='issue every kernel from Python instead of replaying a hipGraph')
+    p.add_argument('--graph_stats', action='store_true', help='count the nodes / edges of the recorded step (keeps the captured hipGraph_t) and write '
+                   'them to gpurun_out/graph_stats.json')
     p.add_argument('--cpu_steps', type=int, default=None)
     p.add_argument('--extra_configs', default=None,
                    help='comma list of further workloads appended under "configs" (default at N=1 with the default workload: '
@@ -316,7 +318,9 @@ def _run_workload(name, args, rk, steps, warmup, repeats, batch=None, precision=
     if use_graph:
         # the timed region replays the recorded step (train.GraphedStep: the same kernels, launched by hipGraphLaunch instead
         # of Python-issued launches); with N > 1 ranks: graph(losses + backward) -> bucket all-reduces -> graph(Adam)
-        os.environ.setdefault('VARSEP_GRAPH_STATS', '1')       # keep the captured hipGraph_t: node / edge counts of the recording go into the result
+        # node / edge counts of the recording: only on request (`--graph_stats` sets VARSEP_GRAPH_STATS=1 for this process: the captured hipGraph_t
+        # is then kept, torch.cuda.CUDAGraph(keep_graph=True) -- a different capture path inside torch, so never in a default run); a default run
+        # quotes the committed table profiles/rNN_graph_stats.json while its source hash matches
         graphed = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'],
                               (lam['ae'], lam['s'], lam['t'], lam['pred']), bool(cfg.get('average_tloss')),
                               warmup=max(1, min(warmup, 3)), grad_sync=sync, scaler=scaler)
@@ -646,6 +650,8 @@ def workload_text(name, cfg):
 
 def main():
     args = parse()
+    if args.graph_stats:
+        os.environ['VARSEP_GRAPH_STATS'] = '1'
     if args.gpus > 1 and 'RANK' not in os.environ:
         spawn_ranks(args)                    # does not return
     # stdout carries exactly ONE line (the result JSON): libraries that print banners to the C-level stdout (RCCL prints its
@@ -743,6 +749,18 @@ def main():
         # nodes / kernel nodes / dependency edges / roots of the recorded step (train.GraphedStep.graph_stats): what one replay costs the host
         'graph': res.get('graph'),
     }
+    if out.get('graph') is None:
+        tab, src, fresh = _latest_profile(args.config, args.precision, 'graph')
+        if tab is not None and fresh:
+            out['graph'] = dict({k: tab[k] for k in ('nodes', 'kernel_nodes', 'edges', 'roots') if k in tab}, source=src)
+    elif args.graph_stats:
+        try:
+            from spatiotemporal_variable_separation_amd.profiling import source_sha as _sha
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'graph_stats_%s_%s.json' % (args.config, args.precision)), 'w') as f:
+                json.dump(dict(out['graph'], _source_sha=_sha(), _source='python bench.py --config %s --precision %s --graph_stats' % (args.config, args.precision)), f)
+        except OSError:
+            pass
     if res['scaler']:
         out['config']['loss_scaling'] = res['scaler']
     if configs is not None:

@@ -245,6 +245,33 @@ _SIDE = {'on': False, 'lanes': [], 'next_lane': 0, 'rollout': None, 'hold': Fals
 N_LANES = max(1, int(os.environ.get('VARSEP_WGRAD_LANES', '3')))
 
 
+_OWN_STREAMS = []
+
+
+def own_stream(device=None):
+    """A HIP stream of this package's own (hipStreamCreateWithPriority, non-blocking, default priority), wrapped as torch.cuda.ExternalStream and
+    never destroyed.  `torch.cuda.Stream()` hands out the next of 32 POOLED streams per device and priority: after 32 requests anywhere in
+    the process two Stream objects are the same HIP stream.  Two of the streams of a step being one stream (a gradient lane and the
+    optimizer's stream, say) makes `a.wait_stream(b)` a stream waiting for its own event, which inside a capture enters the stream into
+    its own list of joined streams and hipStreamEndCapture recurses until the stack ends (seen as a segmentation fault late in a long test
+    session, at a position that moved with the number of streams requested before).  Streams made here cannot coincide with each other
+    nor with any pooled stream."""
+    import ctypes
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    torch.cuda.init()
+    hip = ctypes.CDLL('libamdhip64.so')
+    handle = ctypes.c_void_p(0)
+    with torch.cuda.device(dev):
+        err = hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(0))        # 1 = hipStreamNonBlocking
+    if err != 0 or not handle.value:
+        raise RuntimeError('hipStreamCreateWithPriority failed (%d)' % err)
+    s = torch.cuda.ExternalStream(handle.value, device=dev)
+    _OWN_STREAMS.append(s)
+    return s
+
+
 def enable_side_streams(flag):
     _SIDE['on'] = bool(flag)
     _SIDE['next_lane'] = 0
@@ -295,13 +322,13 @@ def note_main_stream(stream):
 
 def _side_stream(name):
     if _SIDE[name] is None:
-        _SIDE[name] = torch.cuda.Stream()
+        _SIDE[name] = own_stream()
     return _SIDE[name]
 
 
 def _lane_stream(i):
     while len(_SIDE['lanes']) <= i:
-        _SIDE['lanes'].append(torch.cuda.Stream())
+        _SIDE['lanes'].append(own_stream())
     return _SIDE['lanes'][i]
 
 

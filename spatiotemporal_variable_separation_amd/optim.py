@@ -101,7 +101,7 @@ class Adam(torch.optim.Optimizer):
             return
         main = torch.cuda.current_stream(p.device)
         if self._stream is None:
-            self._stream = torch.cuda.Stream(device=p.device)
+            self._stream = VF.own_stream(p.device)
         self._stream.wait_stream(main)
         for s in VF.side_streams_in_use():             # deferred weight gradients are produced on their own stream
             self._stream.wait_stream(s)

@@ -168,7 +168,8 @@ class GradAllReducer:
         flat = self.buckets[bi][0]
         if flat.is_cuda:
             if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=flat.device)
+                from . import functional as VF
+                self._comm_stream = VF.own_stream(flat.device)
             self._comm_stream.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(self._comm_stream):
                 self._reduce(flat)
@@ -364,7 +365,8 @@ class GradAllReducer:
         lo, hi = self._slice(bi)
         if arena.is_cuda:
             if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=arena.device)
+                from . import functional as VF
+                self._comm_stream = VF.own_stream(arena.device)
             self._comm_stream.wait_stream(torch.cuda.current_stream(arena.device))
             ctx = torch.cuda.stream(self._comm_stream)
         else:

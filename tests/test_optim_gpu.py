@@ -182,6 +182,47 @@ def test_update_in_backward_equals_plain_step(graph):
         assert torch.allclose(a[k], b[k], rtol=2e-4, atol=2e-6), k
 
 
+def test_recording_with_side_streams_at_every_position_of_the_stream_pool():
+    """`torch.cuda.Stream()` hands out one of 32 pooled HIP streams in turn, so the 33rd request anywhere in the process is the first stream
+    again.  The streams of a recorded step (gradient lanes, the integrator's stream, the optimizer's stream) are made by
+    functional.own_stream() and cannot coincide with a pooled one nor with each other: the recording is repeated with the pool advanced by one
+    request each time, over more than a full turn (with pooled side streams one of these positions made the optimizer's stream wait for
+    itself inside the capture and hipStreamEndCapture never returned)."""
+    import numpy as np
+    from oracle.detdata import det_fill
+    from oracle.golden_configs import CONFIGS, make_batch
+    from spatiotemporal_variable_separation_amd import functional as VF
+    from spatiotemporal_variable_separation_amd.networks.factory import build_sep_net
+    from spatiotemporal_variable_separation_amd.optim import Adam
+    from spatiotemporal_variable_separation_amd.train import GraphedStep, enable_update_in_backward
+    order = [torch.cuda.Stream().cuda_stream for _ in range(32)]
+    pooled = set(order)
+    assert torch.cuda.Stream().cuda_stream == order[0]                        # the pool has come round
+
+    def advance_pool_to(k):
+        nxt = (order.index(torch.cuda.Stream().cuda_stream) + 1) % 32
+        for _ in range((k - nxt) % 32):
+            torch.cuda.Stream()
+    own = [VF.own_stream() for _ in range(3)]
+    handles = [s.cuda_stream for s in own] + [s.cuda_stream for s in VF._OWN_STREAMS]
+    assert len({s.cuda_stream for s in own}) == 3 and not (set(handles) & pooled)
+    cfg = CONFIGS['mlp_mul']
+    lam = cfg['lambdas']
+    cond, target = make_batch(cfg)
+    cond, target = cond.cuda(), target.cuda()
+    np.random.seed(5)
+    for turn in range(33):
+        net = det_fill(build_sep_net(cfg), salt=cfg['salt']).cuda().train()
+        opt = Adam(net.parameters(), lr=1e-3, betas=(0.9, 0.99))
+        enable_update_in_backward(opt, net, force=True)
+        advance_pool_to(turn % 32)
+        g = GraphedStep(net, opt, cond, target, cfg['nt_cond'], cfg['nt_pred'], cfg['offset'], (lam['ae'], lam['s'], lam['t'], lam['pred']), warmup=1)
+        g.step()
+        used = {s.cuda_stream for s in VF._SIDE['lanes']} | ({opt._stream.cuda_stream} if opt._stream is not None else set())
+        assert used and not (used & pooled), turn
+    torch.cuda.synchronize()
+
+
 def test_step_by_subsets_equals_one_step():
     """`step_subset()` over a partition of the parameters + `finish_step()` is `step()` (the data-parallel graph path updates
     one all-reduce bucket at a time while the next buckets are still on the wire)."""
