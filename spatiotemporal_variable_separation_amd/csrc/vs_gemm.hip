@@ -99,7 +99,7 @@ int launch_big_layout(int la, int lb, const void* A, int64_t lda, const void* B,
 }
 
 // the 256 x 256 / 256 x 128 tile with two staggered wave groups (vs_gemm_p8.h)
-template <int CT, int LA, int LB, int NI, bool LOSS = false, int MI = 4>
+template <int CT, int LA, int LB, int NI, int LOSS = 0, int MI = 4>
 int launch_p8(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const P8Plan& pp, int batch, const Epi& epi, float* slabs,
               hipStream_t stream) {
     if constexpr (CT == VS_F32) {
@@ -114,8 +114,11 @@ int launch_p8(const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M,
             attr_set = true;
         }
         dim3 grid((unsigned)(pp.tiles_m * pp.tiles_n), 1, (unsigned)(pp.splits * batch));
+        static const int plain = getenv("VS_GEMM_P8_QUICK") && atoi(getenv("VS_GEMM_P8_QUICK")) == 0;
+        Epi e = epi;
+        e.p8_plain = plain;
         hipLaunchKernelGGL(kfn, grid, dim3(512), lds, stream, (const unsigned short*)A, lda, (const unsigned short*)B, ldb, M, N, K, (int)pp.k_tiles_per_split,
-                           pp.tiles_n, epi, slabs);
+                           pp.tiles_n, e, slabs);
         VS_CHECK_LAUNCH("vs_gemm (staggered 256-row tile)");
         return VS_OK;
     }
@@ -125,10 +128,10 @@ template <int CT>
 int launch_p8_layout(int la, int lb, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const P8Plan& pp, int batch,
                      const Epi& epi, float* slabs, hipStream_t stream) {
     if (pp.ni == 1 && pp.mi == 2) {
-        if (la == LR && lb == LR) return launch_p8<CT, LR, LR, 1, false, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
-        if (la == LR && lb == LS) return launch_p8<CT, LR, LS, 1, false, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
-        if (la == LS && lb == LR) return launch_p8<CT, LS, LR, 1, false, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
-        return launch_p8<CT, LS, LS, 1, false, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        if (la == LR && lb == LR) return launch_p8<CT, LR, LR, 1, 0, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        if (la == LR && lb == LS) return launch_p8<CT, LR, LS, 1, 0, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        if (la == LS && lb == LR) return launch_p8<CT, LS, LR, 1, 0, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
+        return launch_p8<CT, LS, LS, 1, 0, 2>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
     }
     if (pp.ni == 1) {
         if (la == LR && lb == LR) return launch_p8<CT, LR, LR, 1>(A, lda, B, ldb, M, N, K, pp, batch, epi, slabs, stream);
@@ -404,9 +407,12 @@ extern "C" int vs_gemm_frame_loss(int compute, int64_t M, int64_t N, int64_t K, 
     epi.fl_full = full; epi.fl_tdev = t_random_dev; epi.fl_ae_shift = ae_shift; epi.fl_first = first_forecast; epi.fl_G = G; epi.fl_T = T;
     epi.fl_up = grad_total; epi.fl_l_ae = a.l_ae; epi.fl_l_pred = a.l_pred; epi.fl_inv_ae = a.inv_ae; epi.fl_inv_pred = a.inv_pred;
     epi.fl_dz = dz; epi.fl_dz_dtype = dz_dtype; epi.fl_partials = out + 16;
-    if (p8)
-        rc = compute == VS_BF16 ? launch_p8<VS_BF16, LR, LR, 2, true>(A, lda, W, ldw, M, N, K, pp, 1, epi, nullptr, stream)
-                                : launch_p8<VS_F16, LR, LR, 2, true>(A, lda, W, ldw, M, N, K, pp, 1, epi, nullptr, stream);
+    if (p8 && act == VS_ACT_SIGMOID)
+        rc = compute == VS_BF16 ? launch_p8<VS_BF16, LR, LR, 2, 2>(A, lda, W, ldw, M, N, K, pp, 1, epi, nullptr, stream)
+                                : launch_p8<VS_F16, LR, LR, 2, 2>(A, lda, W, ldw, M, N, K, pp, 1, epi, nullptr, stream);
+    else if (p8)
+        rc = compute == VS_BF16 ? launch_p8<VS_BF16, LR, LR, 2, 1>(A, lda, W, ldw, M, N, K, pp, 1, epi, nullptr, stream)
+                                : launch_p8<VS_F16, LR, LR, 2, 1>(A, lda, W, ldw, M, N, K, pp, 1, epi, nullptr, stream);
     else
         rc = compute == VS_BF16 ? launch_big<VS_BF16, LR, LR, true>(A, lda, W, ldw, M, N, K, bp, 1, epi, nullptr, stream)
                                 : launch_big<VS_F16, LR, LR, true>(A, lda, W, ldw, M, N, K, bp, 1, epi, nullptr, stream);

@@ -59,6 +59,7 @@ struct Epi {
     const float* fl_up; float fl_l_ae, fl_l_pred, fl_inv_ae, fl_inv_pred;        // k = *fl_up * l * 2 * (1 / count), in this order
     void* fl_dz; int fl_dz_dtype; float* fl_partials;
     int adam_pipe;                       // fused optimizer: state of four row pieces requested ahead (VS_ADAM_PIPE=0: one piece at a time)
+    int p8_plain;                        // VS_GEMM_P8_QUICK=0 (measurements): interior tiles of the staggered tile take the general stores too
 };
 
 // XCD-aware, bijective block -> tile index (blocks b and b + 8 share an XCD under round-robin dispatch: speed only)

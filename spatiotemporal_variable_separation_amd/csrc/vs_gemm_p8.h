@@ -34,6 +34,20 @@
 namespace {
 
 constexpr int P8_BK = 64;
+#ifndef P8_LOSS_DEPTH
+#define P8_LOSS_DEPTH 12       // target requests in flight per lane in the frame-loss epilogue (16: the sigmoid form spills 376 bytes per lane)
+#endif
+
+// tools/probes/p8_bench.hip -DP8_STAMPS: wall-clock stamps (100 MHz) of workgroup 0 at the seams of the kernel; nothing in the library build
+#ifdef P8_STAMPS
+__device__ long long p8_stamps[8];
+#define P8_STAMP(k) long long p8_t##k = wall_clock64()
+#define P8_STAMPS_OUT() do { if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) { p8_stamps[0] = p8_t0; p8_stamps[1] = p8_t1; p8_stamps[2] = p8_t2; \
+                                  p8_stamps[3] = p8_t3; p8_stamps[4] = p8_t4; p8_stamps[5] = wall_clock64(); } } while (0)
+#else
+#define P8_STAMP(k) do { } while (0)
+#define P8_STAMPS_OUT() do { } while (0)
+#endif
 
 template <int CT>
 __device__ __forceinline__ f32x4 mfma16x32(const u32x4& a, const u32x4& b, const f32x4& c) {
@@ -181,7 +195,9 @@ struct P8Reader {
     } while (0)
 
 // MI: 16-row accumulator repeats per quadrant (4: 256 rows per tile; 2: 128 rows -- 64 KiB of LDS and <= 128 registers, two workgroups per CU)
-template <int CT, int LA, int LB, int NI, bool NCHW, bool LOSS = false, int MI = 4>
+// LOSS: 0 = a GEMM; 1 / 2 = the frame-loss epilogue (vs_gemm_frame_loss) whose straight-line form on interior tiles is compiled for no activation /
+// for a sigmoid behind the last Linear (one form per instantiation: two in one kernel cost it its spill-free register allocation)
+template <int CT, int LA, int LB, int NI, bool NCHW, int LOSS = 0, int MI = 4>
 __global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const unsigned short* Ap, int64_t lda, const unsigned short* Bp, int64_t ldb, int64_t M, int64_t N,
                                                       int64_t K, int k_tiles_per_split, int tiles_n, Epi epi_in, float* slabs) {
     constexpr int BN = 128 * NI, BM = 64 * MI;
@@ -193,6 +209,7 @@ __global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const uns
     constexpr int TILE = 2 * HA + 2 * HB;                             // one K tile: HA0 | HA1 | HB0 | HB1
     constexpr int WAIT = OpB::NJ * 2 + OpA::NJ;                       // requests of HB0, HA0, HB1: what the phase-4 wait leaves in flight
 
+    P8_STAMP(0);
     int zsplit = blockIdx.z;
     int batch = 0;
     if (epi_in.splits_per_batch > 0) {
@@ -306,6 +323,7 @@ __global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const uns
     using F = std::false_type;
 
     // prologue: tile 0 whole, HB0 | HA0 | HB1 of tile 1 (HA1 of tile 1 is phase 1's request)
+    P8_STAMP(1);
     {
         ga.template stage<true, 0>(0, wbase, kt_begin, kt_end, K);
         ga.template stage<true, HA>(1, wbase, kt_begin, kt_end, K);
@@ -318,6 +336,7 @@ __global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const uns
         P8_BAR();
         if (wr == 1) P8_BAR();                                        // waves 4-7 run one barrier behind
     }
+    P8_STAMP(2);
     int64_t u = kt_begin;
     // main loop: pairs of K tiles whose requests (tiles u+1 .. u+3) are full and live
     while (u + 3 < kt_full) {
@@ -333,6 +352,7 @@ __global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const uns
     }
     if (wr == 0) P8_BAR();                                            // (the barrier waves 4-7 took up front)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // zero-source requests past the end must not outlive the workgroup's LDS
+    P8_STAMP(3);
 
     // ---- epilogue: a lane holds C[m][n .. n+3] per accumulator ----
     float* slab_base = slabs ? slabs + (int64_t)blockIdx.z * M * N : nullptr;
@@ -354,6 +374,53 @@ __global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const uns
                 const int64_t n_c = n + 3 < N ? n : N - 4;
                 bias4[j][ni] = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n_c) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        // A tile that lies inside the matrix with the common settings (no activation or a sigmoid behind the last Linear, gradient stored in the compute
+        // type) takes straight-line code: no branch per element (the run-time activation / dtype switches are ~100 scalar branches per four
+        // elements, ~36 us of a 64 us launch at 3328 x 4096 x 1200 by the stamps of tools/probes/p8_bench.hip), one rolling window of DEPTH
+        // target requests that is refilled as it is consumed (the hardware counter waits are the compiler's, exact in straight-line code), and
+        // the four stores of a row back to back (a full 128-byte line of the gradient).  Same arithmetic, same order of the partial sums.
+        const bool quick = !epi.p8_plain && (m0 + BM <= M) && (n0 + BN <= N) && epi.act == (LOSS == 2 ? VS_ACT_SIGMOID : VS_ACT_NONE) && epi.fl_dz_dtype == CT;
+        auto loss_quick = [&]() {
+            constexpr int ACT = LOSS == 2 ? VS_ACT_SIGMOID : VS_ACT_NONE;
+            constexpr int RQ = 2 * NI, ROWS = 2 * MI, Q = ROWS * RQ, DEPTH = P8_LOSS_DEPTH < Q ? P8_LOSS_DEPTH : Q;
+            const float k_ae = fl_up * epi.fl_l_ae * 2.f * epi.fl_inv_ae, k_pred = fl_up * epi.fl_l_pred * 2.f * epi.fl_inv_pred;
+            const float* tp[ROWS];
+            unsigned short* dp[ROWS];
+            int g_of[ROWS];
+            f32x4 tg[DEPTH];
+            auto request = [&](int q) {
+                const int r = q / RQ, c = q % RQ;
+                if (c == 0) {
+                    const int64_t m = mw + (r / MI) * RUN_A + (r % MI) * 16;
+                    tp[r] = big_loss_target(epi, m, nw, N, fl_t, g_of[r]);
+                    dp[r] = (unsigned short*)epi.fl_dz + m * N + nw;
+                }
+                tg[q % DEPTH] = *reinterpret_cast<const f32x4*>(tp[r] + (c / NI) * RUN_B + (c % NI) * 16);
+            };
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) request(q);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int r = q / RQ, c = q % RQ, i = r / MI, mi = r % MI, j = c / NI, ni = c % NI;
+                const float k = g_of[r] == 0 ? k_ae : k_pred;
+                const f32x4 t4 = tg[q % DEPTH];
+                float rr[4], sq = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float x = vs_act(acc[i][j][mi][ni][t] * epi.alpha + bias4[j][ni][t], ACT);
+                    const float d = x - t4[t];
+                    sq += d * d;
+                    rr[t] = (k * d) * vs_act_grad_from_out(x, ACT);
+                }
+                fl_s0 += g_of[r] == 0 ? sq : 0.f;
+                fl_s1 += g_of[r] == 0 ? 0.f : sq;
+                const u16x4 w = {vs_f2h(rr[0], CT), vs_f2h(rr[1], CT), vs_f2h(rr[2], CT), vs_f2h(rr[3], CT)};
+                *reinterpret_cast<u16x4*>(dp[r] + j * RUN_B + ni * 16) = w;
+                if (q + DEPTH < Q) request(q + DEPTH);
+                P8_FENCE;                                  // (left to itself the scheduler hoists requests and row set-ups until registers spill)
+            }
+        };
+        if (quick) loss_quick();
         auto loss_rows = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
             f32x4 tg[2][NI][MI];
@@ -383,8 +450,10 @@ __global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const uns
                     }
             }
         };
-        loss_rows(I0{});
-        loss_rows(I1{});
+        if (!quick) {
+            loss_rows(I0{});
+            loss_rows(I1{});
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { fl_s0 += __shfl_down(fl_s0, o, 64); fl_s1 += __shfl_down(fl_s1, o, 64); }
         __syncthreads();
@@ -405,7 +474,61 @@ __global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const uns
         const bool mask_ok = !epi.mask || ((epi.mask_act == VS_ACT_RELU || epi.mask_act == VS_ACT_LEAKY) && (epi.ldmask & 3) == 0 && ((uintptr_t)epi.mask & 15) == 0);
         const bool fast = !NCHW && mask_ok && !epi.accumulate && !epi.adam_m && (epi.ldc & 3) == 0 && (N & 3) == 0 && ((uintptr_t)epi.C & 15) == 0 &&
                           (!epi.bias || ((uintptr_t)epi.bias & 15) == 0) && (epi.act == VS_ACT_NONE || epi.act == VS_ACT_RELU || epi.act == VS_ACT_LEAKY);
-        if (slab_base && (N & 3) == 0) {
+        // Interior tiles of the stores of a training step -- Linear forward (bias, none / relu, 16-bit result) and input gradient (16-bit relu /
+        // leaky mask of the layer below) -- take straight-line code: the general fast form below waits for EVERY store to be acknowledged before
+        // the next one (its bounds branches leave the compiler a `s_waitcnt vmcnt(0)` in front of each: 32 x ~250 ns = 8 us of a 36 us launch
+        // at 3328 x 4096 x 1200, stamps of tools/probes/p8_bench.hip).  Here the mask bits come through a rolling window of DEPTH requests, the
+        // test `mask > 0` is made on the 16 bits themselves (positive, non-zero, not a NaN: what the float comparison says) and the stores of a
+        // row follow each other (full 128-byte lines).
+        const bool quick = !epi.p8_plain && fast && !slab_base && (m0 + BM <= M) && (n0 + BN <= N) && epi.c_dtype == CT && (epi.act == VS_ACT_NONE || epi.act == VS_ACT_RELU) &&
+                           (!epi.mask || epi.mask_dtype == VS_BF16 || epi.mask_dtype == VS_F16);
+        if (quick) {
+            auto store_quick = [&](auto actc) {
+                constexpr int ACT = decltype(actc)::value;
+                constexpr int RQ = 2 * NI, ROWS = 2 * MI, Q = ROWS * RQ, DEPTH = 16 < Q ? 16 : Q;
+                const bool has_mask = epi.mask != nullptr;
+                const float mask_slope = epi.mask_act == VS_ACT_LEAKY ? 0.2f : 0.f;
+                const int top = epi.mask_dtype == VS_F16 ? 0x7C00 : 0x7F80;          // +inf: the largest bit pattern that is "> 0"
+                f32x4 bias4[2][NI];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        bias4[j][ni] = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + nw + j * RUN_B + ni * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const unsigned short* yp[ROWS];
+                unsigned short* cp[ROWS];
+                u16x4 yh[DEPTH];
+                auto request = [&](int q) {
+                    const int r = q / RQ, c = q % RQ;
+                    if (c == 0) {
+                        const int64_t m = mw + (r / MI) * RUN_A + (r % MI) * 16;
+                        yp[r] = (const unsigned short*)epi.mask + m * epi.ldmask + nw;
+                        cp[r] = (unsigned short*)epi.C + m * epi.ldc + nw;
+                    }
+                    if (has_mask) yh[q % DEPTH] = *reinterpret_cast<const u16x4*>(yp[r] + (c / NI) * RUN_B + (c % NI) * 16);
+                    else yh[q % DEPTH] = u16x4{1, 1, 1, 1};
+                };
+#pragma unroll
+                for (int q = 0; q < DEPTH; ++q) request(q);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int r = q / RQ, c = q % RQ, i = r / MI, mi = r % MI, j = c / NI, ni = c % NI;
+                    const u16x4 y4 = yh[q % DEPTH];
+                    float rr[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float x = vs_act(acc[i][j][mi][ni][t] * epi.alpha + bias4[j][ni][t], ACT);
+                        const int yb = (int)(short)y4[t];
+                        rr[t] = x * ((yb > 0 && yb <= top) ? 1.f : mask_slope);
+                    }
+                    const u16x4 w = {vs_f2h(rr[0], CT), vs_f2h(rr[1], CT), vs_f2h(rr[2], CT), vs_f2h(rr[3], CT)};
+                    *reinterpret_cast<u16x4*>(cp[r] + j * RUN_B + ni * 16) = w;
+                    if (q + DEPTH < Q) request(q + DEPTH);
+                }
+            };
+            if (epi.act == VS_ACT_RELU) store_quick(std::integral_constant<int, VS_ACT_RELU>{});
+            else store_quick(std::integral_constant<int, VS_ACT_NONE>{});
+        } else if (slab_base && (N & 3) == 0) {
             // split-K partial: raw fp32, reduced (with the epilogue) by splitk_reduce_kernel
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -502,6 +625,11 @@ __global__ __launch_bounds__(512, MI == 4 ? 2 : 4) void gemm_p8_kernel(const uns
             pass(I1{});
         }
     }
+    P8_STAMP(4);
+#ifdef P8_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    P8_STAMPS_OUT();
 }
 
 // ---- when to take it ---------------------------------------------------------------------------------------------------------

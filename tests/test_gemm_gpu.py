@@ -490,8 +490,20 @@ def test_gemm_p8_tile_all_layouts(dtype, la, lb, ni, shape):
         outm = ops.gemm(a, la, b, lb, M, N, K, alpha=0.5, mask=mask.cuda(), mask_act='leaky_relu')
         outs = ops.gemm(a, la, b, lb, M, N, K, alpha=0.05, bias=bias, act='sigmoid')
         ops.gemm(a, la, b, lb, M, N, K, out=acc, accumulate=True)
+        # the stores of a training step (straight-line code on tiles inside the matrix): Linear forward = bias + relu to 16 bits; input gradient =
+        # 16-bit result under the 16-bit relu mask of the layer below, with every kind of "not > 0" planted in the first rows
+        outf = ops.gemm(a, la, b, lb, M, N, K, bias=bias, act='relu', out_dtype=dtype)
+        mask16 = mask.clone()
+        tiny = torch.finfo(dtype).smallest_normal / 4                      # a denormal: > 0
+        special = torch.tensor([0.0, -0.0, tiny, -tiny, float('inf'), -float('inf'), float('nan'), 1.0], dtype=torch.float32).to(dtype)
+        mask16[:4, :special.numel() * 8] = special.repeat(8)
+        outg = ops.gemm(a, la, b, lb, M, N, K, out_dtype=dtype, mask=mask16.cuda(), mask_act='relu')
     torch.cuda.synchronize()
     ref = a64 @ b64.t()
+    keep = mask16.float() > 0                                                # (NaN > 0 is False, a denormal is > 0)
+    assert keep[0, :8].tolist() == [False, False, True, False, True, False, False, True]
+    assert torch.equal(outg.cpu().float(), torch.where(keep, out16.cpu().float(), torch.zeros(()))), f'{dtype} ({la},{lb}) ni {ni} {shape}: 16-bit relu mask'
+    assert torch.equal(outf.cpu().float(), out.cpu().to(dtype).float()), f'{dtype} ({la},{lb}) ni {ni} {shape}: bias + relu to 16 bits'
 
     def rel(x, r):
         return ((x.cpu().double() - r).norm() / r.norm()).item()

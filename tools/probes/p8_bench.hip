@@ -12,6 +12,7 @@
 #include <vector>
 #include "../../spatiotemporal_variable_separation_amd/csrc/vs_gemm_p8.h"
 
+static int g_out16 = 0;
 thread_local char vs_err_buf[256];
 int vs_fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; }
 unsigned* vs_g_exchange_guard = nullptr;
@@ -34,13 +35,50 @@ __global__ void ref_kernel(const unsigned short* A, int64_t lda, int la, const u
 
 template <int LA, int LB, int NI, int MI = 4>
 static void launch(const unsigned short* A, int64_t lda, const unsigned short* B, int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, hipStream_t st) {
-    auto kfn = gemm_p8_kernel<VS_BF16, LA, LB, NI, false, false, MI>;
+    auto kfn = gemm_p8_kernel<VS_BF16, LA, LB, NI, false, 0, MI>;
     constexpr int lds = 2 * (2 * 32 * MI * 64 * 2 + 2 * 64 * NI * 64 * 2);
     static bool set = false;
     if (!set) { CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); set = true; }
     Epi epi{};
     epi.C = C; epi.ldc = N; epi.c_dtype = VS_F32; epi.alpha = 1.f;
+    if (g_out16) {                          // timing of the 16-bit stores (C is large enough for either); 2: with a 16-bit relu mask
+        epi.c_dtype = VS_BF16;
+        if (g_out16 == 2) {
+            static unsigned short* mask = nullptr;
+            if (!mask) { CK(hipMalloc(&mask, (size_t)M * N * 2)); CK(hipMemset(mask, 0x3f, (size_t)M * N * 2)); }
+            epi.mask = mask; epi.ldmask = N; epi.mask_dtype = VS_BF16; epi.mask_act = VS_ACT_RELU;
+        }
+    }
     const int tm = (int)((M + 64 * MI - 1) / (64 * MI)), tn = (int)((N + 128 * NI - 1) / (128 * NI));
+    hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), lds, st, A, lda, B, ldb, M, N, K, (int)((K + 63) / 64), tn, epi, (float*)nullptr);
+}
+
+// the frame-loss epilogue (vs_gemm_frame_loss) on a linear frame map: row m = (b, g) of [M / 26, 26, N] against target row m; nothing is checked
+// but the time (the library's tests hold its values)
+static void launch_loss(const unsigned short* A, int64_t lda, const unsigned short* B, int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    auto kfn = g_out16 == 3 ? gemm_p8_kernel<VS_BF16, LR, LR, 2, false, 2, 4> : gemm_p8_kernel<VS_BF16, LR, LR, 2, false, 1, 4>;
+    constexpr int lds = 2 * (2 * 32 * 4 * 64 * 2 + 2 * 64 * 2 * 64 * 2);
+    static int set = 0;
+    static float *target, *partials, *up;
+    static int* tdev;
+    static unsigned short* dz;
+    const int tm = (int)((M + 255) / 256), tn = (int)((N + 255) / 256);
+    if (!set) {
+        CK(hipFuncSetAttribute((const void*)gemm_p8_kernel<VS_BF16, LR, LR, 2, false, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipFuncSetAttribute((const void*)gemm_p8_kernel<VS_BF16, LR, LR, 2, false, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CK(hipMalloc(&target, (size_t)M * N * 4)); CK(hipMemset(target, 0, (size_t)M * N * 4));
+        CK(hipMalloc(&dz, (size_t)M * N * 2));
+        CK(hipMalloc(&partials, (size_t)tm * tn * 8));
+        CK(hipMalloc(&up, 4)); const float one = 1.f; CK(hipMemcpy(up, &one, 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&tdev, 4)); CK(hipMemset(tdev, 0, 4));
+        set = 1;
+    }
+    Epi epi{};
+    epi.C = C; epi.ldc = N; epi.c_dtype = VS_F32; epi.alpha = 1.f;
+    epi.fl_full = target; epi.fl_tdev = tdev; epi.fl_ae_shift = 0; epi.fl_first = 1; epi.fl_G = 26; epi.fl_T = 26;
+    epi.fl_up = up; epi.fl_l_ae = 1.f; epi.fl_l_pred = 1.f; epi.fl_inv_ae = 1.f; epi.fl_inv_pred = 1.f;
+    epi.fl_dz = dz; epi.fl_dz_dtype = VS_BF16; epi.fl_partials = partials;
+    if (g_out16 == 3) epi.act = VS_ACT_SIGMOID;
     hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), lds, st, A, lda, B, ldb, M, N, K, (int)((K + 63) / 64), tn, epi, (float*)nullptr);
 }
 
@@ -69,6 +107,12 @@ int main(int argc, char** argv) {
         if (la == 1 && lb == 0) fn = launch<LS, LR, 1>;
         if (la == 1 && lb == 1) fn = launch<LS, LS, 1>;
     }
+    if (!strcmp(mode, "h16")) g_out16 = 1;
+    if (!strcmp(mode, "h16m")) g_out16 = 2;
+    if (!strcmp(mode, "loss_sigmoid")) g_out16 = 3;
+    const bool loss = !strcmp(mode, "loss") || g_out16;          // (time only)
+    if (!strcmp(mode, "loss") || g_out16 == 3)          // ni = 2, R x R, M a multiple of 26: time only
+        fn = launch_loss;
     if (!fn) { fprintf(stderr, "unsupported layout / ni\n"); return 2; }
     const bool exact = !strcmp(mode, "int");
     const bool cold = !strcmp(mode, "cold");
@@ -111,12 +155,28 @@ int main(int argc, char** argv) {
             if (d > worst) worst = d;
             if (b && !bad++) first = i;
         }
+        if (loss) break;
         if (bad) {
             ++bad_runs;
             printf("MISMATCH run %d: %zu of %zu elements, first at (%zu, %zu): got %g want %g, worst |d| %g\n", c, bad, ec, first / N, first % N, hc[first], hr[first], worst);
             if (bad_runs >= 3) break;
         } else if (c == 0) printf("check ok (%s): worst |d| %g\n", exact ? "bit-exact integers" : "tolerance", worst);
     }
+#ifdef P8_STAMPS
+    {   // seams of workgroup 0, in us since its first instruction: prepare done | prologue landed | K loop done | epilogue issued | stores retired
+        for (int rep = 0; rep < 4; ++rep) {
+            if (rep == 0 || rep == 2)      // something else through the instruction caches first
+                hipLaunchKernelGGL(ref_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)std::min<int64_t>(M, 64)), dim3(256), 0, 0, dA[0], lda, la, dB[0], ldb, lb, dR, std::min<int64_t>(M, 64), N, K);
+            CK(hipDeviceSynchronize());
+            fn(dA[0], lda, dB[0], ldb, dC[0], M, N, K, 0);
+            CK(hipDeviceSynchronize());
+            long long st[8];
+            CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(p8_stamps), sizeof(st)));
+            printf("stamps%s: prepare %.2f  prologue %.2f  k-loop %.2f  epilogue-issue %.2f  stores-retired %.2f us\n", (rep == 0 || rep == 2) ? " (after another kernel)" : " (repeat)          ",
+                   (st[1] - st[0]) * 0.01, (st[2] - st[0]) * 0.01, (st[3] - st[0]) * 0.01, (st[4] - st[0]) * 0.01, (st[5] - st[0]) * 0.01);
+        }
+    }
+#endif
     // timing
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
