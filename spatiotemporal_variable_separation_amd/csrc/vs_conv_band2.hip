@@ -253,12 +253,22 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3_band2_kernel(const unsigned
         const bool has_next = tn < ntiles;
         Tile nxt = cur;
         if (has_next) nxt = decode(tn);
-        // the bias values this lane adds on the way out (16-bit output: pass (q4, sub) -> channel 8 q4 + CPP sub + (lane / 8), fetched now
-        float bpre[4 * (8 / CPP)];
+        // the bias values this lane adds on the way out, fetched now.  16-bit output: pass (q4, sub) -> channel 8 q4 + CPP sub + (lane & (8 CPP - 1)) / 8;
+        // fp32 output: read `rd` of pass (q4, sub) -> channel 8 q4 + CPP sub + 4 rd + lane / 16, i.e. slot 2 q4 + (sub | rd) of eight.
+        // (Fetched inside the epilogue's passes, or fetched here but waited for by an `asm volatile` s_waitcnt the compiler cannot see, every use
+        //  carried a compiler-made `s_waitcnt vmcnt(0)` that also drained the previous pass's stores: 15 acknowledged stores in a row per tile,
+        //  the 6 100-cycle epilogue of round 5's phase stamps.  The waits at the phase end and at the head of the epilogue are the BUILTIN, which
+        //  clears the compiler's scoreboard: with a value possibly still on its way and a conditional store in between, the only safe counted
+        //  wait is vmcnt(0).)
+        float bpre[8];
 #pragma unroll
-        for (int k = 0; k < 4 * (8 / CPP); ++k) {
-            const int m = (cur.mg * WM + wm) * 32 + (k / (8 / CPP)) * 8 + (k % (8 / CPP)) * CPP + ((lane & (CPP * 8 - 1)) >> 3);
-            bpre[k] = (bias && m < Cout) ? bias[m] : 0.f;
+        for (int k = 0; k < 8; ++k) {
+            const int mb = (cur.mg * WM + wm) * 32;
+            const int m16 = mb + (k / (8 / CPP)) * 8 + (k % (8 / CPP)) * CPP + ((lane & (CPP * 8 - 1)) >> 3);
+            const int m32 = mb + (k / 2) * 8 + (k % 2) * 4 + (lane >> 4);
+            const int m = yd != VS_F32 ? m16 : m32;
+            const bool used = yd != VS_F32 ? k < 4 * (8 / CPP) : true;
+            bpre[k] = (bias && used && m < Cout) ? bias[m] : 0.f;
         }
         f32x16 acc[3][NJ];
 #pragma unroll
@@ -329,7 +339,9 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3_band2_kernel(const unsigned
                 }
             }
             // the next stage has landed (this wave's share; behind the barrier everybody's) and nobody reads this stage any more
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0070);                                    // vmcnt(0) lgkmcnt(0), as an instruction the compiler accounts for
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();
             ++gp;
         }
@@ -343,6 +355,9 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3_band2_kernel(const unsigned
         // for a cross-lane result; a lane then reads 8 (fp32 output: 4) pixels of each plane, masks the positions no neighbour wrote (row
         // ends), adds in the order of the sums above, adds the bias (fetched at the start of the tile), converts and stores 16 bytes.
         {
+            // (nothing is outstanding here -- the last phase ended with the wait above -- but the compiler cannot know that the phase loop ran at
+            //  least once: said again where it dominates the passes, for its scoreboard)
+            __builtin_amdgcn_s_waitcnt(0x0070);
             const int mbase = (cur.mg * WM + wm) * 32;
             float* of = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + ((gp - 1) & 1) * STAGE * 2 + wave * (3 * CPP * 64 * 4));
 #pragma unroll
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(256 * WM, 2) void conv3_band2_kernel(const unsigned
                                   a2 = *reinterpret_cast<const f32x4*>(r0 + 2 * CPP * 64);
                             if (tpx % W == 0) a0[0] = 0.f;
                             if ((tpx + 4) % W == 0) a2[3] = 0.f;
-                            const float bv = (bias && m < Cout) ? bias[m] : 0.f;
+                            const float bv = bpre[q4 * 2 + (CPP == 8 ? rd : sub)];
                             const f32x4 o = a1 + a0 + a2 + bv;
                             if (live) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Y) + off) = o;
                         }

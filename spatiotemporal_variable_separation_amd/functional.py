@@ -239,7 +239,7 @@ def compute_dtype():
 #     E_s encoder, its backward overlaps the decoder/encoder weight gradients.
 # Only valid when every parameter receives ONE gradient per step (the batched MLP-family step) and without hook-driven
 # gradient all-reduce; `train._compute_losses_mlp_batched` / `GraphedStep` switch it on, everything else leaves it off.
-_SIDE = {'on': False, 'lanes': [], 'next_lane': 0, 'rollout': None, 'hold': False, 'held': [], 'hold_main': None, 'late': []}
+_SIDE = {'on': False, 'lanes': [], 'next_lane': 0, 'rollout': None, 'es': None, 'hold': False, 'held': [], 'hold_main': None, 'late': []}
 # Deferred gradient work is spread over a few streams ("lanes", one per Linear chain / integrator backward in turn): most of it
 # is GEMMs of 10-50 us that fill a fraction of the chip each, and one stream would run them one after the other.
 N_LANES = max(1, int(os.environ.get('VARSEP_WGRAD_LANES', '3')))
@@ -314,6 +314,27 @@ def side_streams_enabled():
     return _SIDE['on']
 
 
+class chain_forward_stream:
+    """While active, MLPChain.forward issues its launches on `stream` (and records what it hands to the caller and keeps for backward on the
+    caller's stream); the autograd node is still created under the caller's stream, so BACKWARD runs where it would have run anyway."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev, _SIDE['chain_stream'] = _SIDE.get('chain_stream'), self.stream
+
+    def __exit__(self, *exc):
+        _SIDE['chain_stream'] = self.prev
+
+
+def on_chain_forward_stream():
+    """Context: the stream of the active chain_forward_stream, or nothing."""
+    from contextlib import nullcontext
+    s = _SIDE.get('chain_stream')
+    return torch.cuda.stream(s) if s is not None else nullcontext()
+
+
 def note_main_stream(stream):
     """The stream the step runs on while part of it is on a side stream: tensors of the backward pass that are allocated wherever they are first
     needed but read by the optimizer afterwards (the pooled zero gradients) are recorded on it."""
@@ -384,7 +405,9 @@ def run_deferred(fn, *inputs, outs=None, lane=0, late=False):
         out = fn()
         return out if outs is None else outs
     if _SIDE['hold'] and outs is not None:
-        _SIDE['held'].append((fn, inputs, outs, ('late', lane) if late else lane))
+        # (with the stream the inputs are produced on: a chain whose backward runs on a stream of its own -- E_s, train.py -- is not covered by
+        #  the wait for the stream the hold was declared on)
+        _SIDE['held'].append((fn, inputs, outs, ('late', lane) if late else lane, torch.cuda.current_stream()))
         return outs
     main, ws = torch.cuda.current_stream(), _lane_stream(lane)
     ws.wait_stream(main)
@@ -417,8 +440,14 @@ def defer_call(fn, late=False):
     `late`: additionally behind the event recorded after the integrator's backward kernel (release_deferred(late_after=...))."""
     if not deferred_held():
         return False
-    _SIDE['held'].append((fn, (), (), 'all-late' if late else None))
+    _SIDE['held'].append((fn, (), (), 'all-late' if late else None, None))
     return True
+
+
+def _behind_producer(ws, producer, main, behind):
+    if producer is not None and producer != main and producer != ws and (ws, producer) not in behind:
+        ws.wait_stream(producer)
+        behind.add((ws, producer))
 
 
 def release_deferred(after=None, late_after=None):
@@ -430,7 +459,8 @@ def release_deferred(after=None, late_after=None):
         return
     main = _SIDE['hold_main'] if (was and _SIDE['hold_main'] is not None) else torch.cuda.current_stream()
     started = set()
-    for fn, inputs, outs, lane in held:
+    behind = set()                             # (gradient stream, producer stream) pairs already ordered
+    for fn, inputs, outs, lane, producer in held:
         if isinstance(lane, tuple):            # ('late', lane): behind the event `late_after` (recorded after the integrator's kernel)
             own = _late_mode() == '1'          # '1': a stream of its own; '2': the closure's own lane
             key = 'late' if own else lane[1]
@@ -440,6 +470,7 @@ def release_deferred(after=None, late_after=None):
                 if after is not None and not own:
                     ws.wait_event(after)
                 started.add(key)
+            _behind_producer(ws, producer, main, behind)
             if late_after is not None:
                 ws.wait_event(late_after)
             with torch.cuda.stream(ws):
@@ -464,6 +495,7 @@ def release_deferred(after=None, late_after=None):
                 if after is not None:
                     ws.wait_event(after)
                 started.add(lane)
+            _behind_producer(ws, producer, main, behind)
         with torch.cuda.stream(ws):
             fn()
         _queued_on_lane(fn, 0 if (lane is None or lane == 'all-late') else lane)
@@ -567,7 +599,7 @@ def fused_optimizer(prm):
 
 def side_streams_in_use():
     """Streams that deferred gradient work of the current step may still be running on."""
-    return (list(_SIDE['lanes']) + ([_SIDE['rollout']] if _SIDE['rollout'] is not None else [])) if _SIDE['on'] else []
+    return (list(_SIDE['lanes']) + [_SIDE[k] for k in ('rollout', 'es') if _SIDE[k] is not None]) if _SIDE['on'] else []
 
 
 def finish_join(pending):
@@ -605,8 +637,9 @@ def join_side_streams(partial=False):
         else:
             cur.wait_stream(ws)
     _SIDE['markers'] = {}
-    if _SIDE['rollout'] is not None:
-        cur.wait_stream(_SIDE['rollout'])
+    for k in ('rollout', 'es'):
+        if _SIDE[k] is not None:
+            cur.wait_stream(_SIDE[k])
     return pending
 
 
@@ -750,6 +783,19 @@ class MLPChain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x_lowp, acts, handoff, *params):
+        fs = _SIDE.get('chain_stream')
+        if fs is not None and fs != torch.cuda.current_stream():
+            caller = torch.cuda.current_stream()
+            _SIDE['chain_stream'] = None
+            try:
+                with torch.cuda.stream(fs):
+                    out = MLPChain.forward(ctx, x, x_lowp, acts, handoff, *params)
+            finally:
+                _SIDE['chain_stream'] = fs
+            for t in (out,) + tuple(ctx.to_save):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(caller)
+            return out
         require_cuda(x)
         cdt = compute_dtype()
         n_layers = len(params) // 2

@@ -123,18 +123,24 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
     if t_random is None:
         t_random = np.random.randint(nt_cond, T) if offset == 0 else np.random.randint(nt_cond, T + 1)
 
+    step_start = None
+    if (VF.side_streams_enabled() and flat.is_cuda and not isinstance(sep_net.Es, ConstantS) and os.environ.get('VARSEP_ES_EARLY', '0') in ('1', '2')):
+        step_start = torch.cuda.Event()
+        step_start.record()
+
     def window(end):
         return flat[:, end - nt_cond:end].reshape(B, -1)
 
     def spatial_codes():
         if isinstance(sep_net.Es, ConstantS):
             return sep_net.Es(full_data[:, :nt_cond]), sep_net.Es(full_data[:, -nt_cond:])
-        if on_device:
-            # [first window; last window] in the compute type by ONE kernel (like E_t's input below) instead of a concatenation + a cast
-            x_es = torch.empty((2 * B, nt_cond * D), dtype=VF.compute_dtype(), device=flat.device)
-            ops.copy2d_pair(flat, B, nt_cond * D, T * D, x_es, nt_cond * D, None, 0, 0, (T - nt_cond) * D)
-        else:
-            x_es = torch.cat([window(nt_cond), window(T)], dim=0)
+        with VF.on_chain_forward_stream():           # (the input is built where the chain's forward launches go: see `step_start` below)
+            if on_device:
+                # [first window; last window] in the compute type by ONE kernel (like E_t's input below) instead of a concatenation + a cast
+                x_es = torch.empty((2 * B, nt_cond * D), dtype=VF.compute_dtype(), device=flat.device)
+                ops.copy2d_pair(flat, B, nt_cond * D, T * D, x_es, nt_cond * D, None, 0, 0, (T - nt_cond) * D)
+            else:
+                x_es = torch.cat([window(nt_cond), window(T)], dim=0)
         s_both = sep_net.Es.mlp(x_es)
         return s_both.view(2, B, -1).unbind(0)       # unbind: its gradient is ONE stack kernel (two slices: fill+copy each, then add)
 
@@ -164,7 +170,24 @@ def _compute_losses_mlp_batched(cond, target, sep_net, nt_cond, nt_pred, offset,
         t0.record_stream(side)
         with torch.cuda.stream(side):
             t_codes, _ = sep_net.t_resnet.rollout(t0, n)
-        s_old, s_new = spatial_codes()
+        if step_start is not None:
+            # E_s on a stream of its own that depends on the START of the step only: in the replayed recording its first layer (a 250-workgroup
+            # GEMM that streams 49 MB of weights) runs beside E_t's small layers instead of under the integrator's kernel, whose 192 resident
+            # workgroups leave it 64 CUs (timeline of round 6: 84 us there against 28 us alone, and E_s's chain -- 200 us -- outlasted the
+            # integrator's 148).  Only the FORWARD launches move (functional.chain_forward_stream): the chain's autograd node is created under
+            # the main stream, so backward runs where it ran before -- a sixth concurrent branch in backward is the runtime's scheduling cliff
+            # (2.50 ms per step, measured with the whole chain, backward included, on the new stream).
+            # MEASURED AND NOT THE DEFAULT (VARSEP_ES_EARLY=1: a stream of its own, 2: the last gradient lane's stream, idle in forward), same box,
+            # alternating with the default: '1' 2.64 / 2.64 / 2.67 ms -- a sixth stream in the recording is the same cliff as six hardware queues
+            # (profiles/r06_queues.md) even though only three branches are ever concurrent in forward; '2' 1.178 / 1.174 / 1.175 against
+            # 1.147 / 1.152 / 1.164 -- E_s's first layer then competes with E_t's chain, which the integrator (the critical path) waits for.
+            es = VF._lane_stream(VF.N_LANES - 1) if os.environ.get('VARSEP_ES_EARLY', '0') == '2' else VF._side_stream('es')
+            es.wait_event(step_start)
+            with VF.chain_forward_stream(es):
+                s_old, s_new = spatial_codes()
+            main.wait_stream(es)
+        else:
+            s_old, s_new = spatial_codes()
         main.wait_stream(side)
         t_codes.record_stream(main)
     else:
