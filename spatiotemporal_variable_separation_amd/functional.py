@@ -816,7 +816,7 @@ class MLPChain(torch.autograd.Function):
                 if res is not None:
                     handoff.fused = res
                     h = GradHandoff.zeros((M, N), h.device)          # (no frames exist: a 0-stride view of one resident zero)
-                    saved.append(h.new_zeros(()))
+                    saved.append(GradHandoff.zeros((), h.device))    # (the resident zero: `new_zeros` is a fill launch per step)
                     continue
             h = ops.gemm(h, R, shadow(W, cdt), R, M, N, K, bias=b.detach() if b is not None else None, act=acts[l],
                          out_dtype=torch.float32 if last else cdt)
@@ -1019,12 +1019,23 @@ class MLPRollout(torch.autograd.Function):
         ctx.cdt, ctx.nb, ctx.n_steps, ctx.params = cdt, nb, n_steps, params
         ctx.save_for_backward(xin, h1, h2, m1, m2)
         ctx.mark_non_differentiable(residuals)
+        # VARSEP_ROLLOUT_GRES_FILL=0: no zero tensor for the gradient of the non-differentiable residuals (autograd launches a 1.2 MB fill for it
+        # on the integrator's stream, right in front of the backward kernel).  MEASURED AND NOT THE DEFAULT: without that node the replayed WaveEq
+        # step is 1.282 / 1.283 ms against 1.145 / 1.151 (same box, alternating).  It is not a race between the held weight-gradient GEMMs and
+        # the backward kernel for the CUs: holding the GEMMs back by one to three small launches behind `ready` leaves it at 1.29-1.30 ms.  The
+        # node changes where the runtime places the branches of the recording (the same kind of cliff as a sixth stream or six hardware
+        # queues, profiles/r06_queues.md), so it stays.
+        if os.environ.get('VARSEP_ROLLOUT_GRES_FILL', '1') == '0':
+            ctx.set_materialize_grads(False)
+        ctx.codes_shape = tuple(t_codes.shape)
         return t_codes, residuals
 
     @staticmethod
     def backward(ctx, g_codes, _g_res):
         xin, h1, h2, m1, m2 = ctx.saved_tensors
         cdt, nb, n_steps, params = ctx.cdt, ctx.nb, ctx.n_steps, ctx.params
+        if g_codes is None:
+            g_codes = torch.zeros(ctx.codes_shape, dtype=torch.float32, device=xin.device)
         wts = []
         for b in range(nb):
             W1, W2, W3 = params[6 * b], params[6 * b + 2], params[6 * b + 4]
@@ -2013,6 +2024,8 @@ class MixCodes(torch.autograd.Function):
         z, z_lowp = ops.mix_codes_fwd(s, t_rand, t_codes, mixing, lowp=None if cdt == torch.float32 else cdt)
         ctx.save_for_backward(s, t_rand, t_codes)
         ctx.mixing = mixing
+        # (no zero tensor for the gradient of the non-differentiable second output: autograd would launch a fill per step for it)
+        ctx.set_materialize_grads(False)
         if z_lowp is None:
             return z, None
         ctx.mark_non_differentiable(z_lowp)
@@ -2021,6 +2034,8 @@ class MixCodes(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, _unused=None):
         s, t_rand, t_codes = ctx.saved_tensors
+        if dz is None:
+            return None, None, None, None
         ds, dt_rand, dt_codes = ops.mix_codes_bwd(dz.float().contiguous(), s, t_rand, t_codes, ctx.mixing)
         return ds, dt_rand, dt_codes, None
 
