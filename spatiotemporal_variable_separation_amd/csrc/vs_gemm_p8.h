@@ -658,8 +658,11 @@ inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t
     // alone, cold operands 43.5 -> 38.1 us; replayed WaveEq step, two interleaved pairs 1.2414 / 1.2337 -> 1.2114 / 1.2079 ms.  VS_GEMM_P8_SPLIT=0: off.
     {
         const char* env_sp = getenv("VS_GEMM_P8_SPLIT");
-        const int64_t kt = p.k_tiles_per_split, tn = vs_cdiv(N, 128);
-        if (!(env_sp && atoi(env_sp) == 0) && M > 128 && M <= 256 && N >= 512 && kt >= 64 && tn * batch <= 64 && (double)N / (tn * 128.0) >= 0.85) {
+        // VS_GEMM_P8_SPLIT_NI=2: 256 x 256 tiles (the activation panel is read by half as many tile columns, twice the splits and slab bytes)
+        const char* env_sni = getenv("VS_GEMM_P8_SPLIT_NI");
+        const int sni = env_sni && atoi(env_sni) == 2 ? 2 : 1;
+        const int64_t kt = p.k_tiles_per_split, tn = vs_cdiv(N, 128 * sni);
+        if (!(env_sp && atoi(env_sp) == 0) && M > 128 && M <= 256 && N >= 512 && kt >= 64 && tn * batch <= 64 && (double)N / (tn * 128.0 * sni) >= 0.85) {
             // VS_GEMM_P8_SPLIT_MI=2: 128 x 128 tiles (100 registers per lane, two workgroups per CU: a workgroup fits beside a workgroup of the integrator's
             // forward kernel, under which E_s's first layer runs in the WaveEq step)
             const char* env_smi = getenv("VS_GEMM_P8_SPLIT_MI");
@@ -667,8 +670,8 @@ inline P8Plan make_p8_plan(int compute, int64_t M, int64_t N, int64_t K, int64_t
             int64_t splits = 250 / (tn * tm * batch);
             if (splits > kt / 8) splits = kt / 8;
             if (splits >= 2) {
-                p.ni = 1;
-                if (tm == 2) { p.mi = 2; p.tiles_m = (int)vs_cdiv(M, 128); }
+                p.ni = sni;
+                if (tm == 2 && sni == 1) { p.mi = 2; p.tiles_m = (int)vs_cdiv(M, 128); }
                 p.tiles_n = (int)tn;
                 p.k_tiles_per_split = vs_cdiv(kt, splits);
                 p.splits = (int)vs_cdiv(kt, p.k_tiles_per_split);
