@@ -205,8 +205,8 @@ def test_recorded_training_tracks_fp32_oracle(case):
 
 def test_recorded_waveeq_step_stays_within_its_node_budget(monkeypatch):
     """The replayed WaveEq step is a hipGraph of kernel nodes on up to eight streams; the host pays per node and per dependency edge of a
-    replay (~14 us per node: 1.02 ms of enqueue against 1.19 ms of device time, tools/host_vs_gpu.py), so the node count is a budget: round 5
-    recorded 84 kernels per step, round 6 records 73 (graph_stats() of the captured hipGraph_t).  A change that adds launches to the recorded
+    replay (~14 us per node: 0.96 ms of enqueue against 1.14 ms of device time, tools/host_vs_gpu.py), so the node count is a budget: round 5
+    recorded 84 kernels per step, round 6 records 69 with 84 edges (graph_stats() of the captured hipGraph_t).  A change that adds launches to the recorded
     step has to show up here."""
     monkeypatch.setenv('VARSEP_GRAPH_STATS', '1')
     cfg = FULL_CONFIGS['full_waveeq']
@@ -215,6 +215,6 @@ def test_recorded_waveeq_step_stays_within_its_node_budget(monkeypatch):
     st = g.graph_stats()
     assert st is not None and st['roots'] == 1, st
     assert st['kernel_nodes'] == st['nodes'], f'only kernel nodes are expected in the recording (no memset / memcpy nodes): {st}'
-    assert st['kernel_nodes'] <= 76, f'the recorded WaveEq step grew to {st["kernel_nodes"]} kernel nodes (budget 76): {st}'
-    assert st['edges'] <= 96, f'{st["edges"]} dependency edges (budget 96): {st}'
+    assert st['kernel_nodes'] <= 72, f'the recorded WaveEq step grew to {st["kernel_nodes"]} kernel nodes (budget 72): {st}'
+    assert st['edges'] <= 90, f'{st["edges"]} dependency edges (budget 90): {st}'
     print('recorded WaveEq step:', st)
