@@ -210,13 +210,17 @@ def test_cat_bcast_equals_repeat_and_cat(a_dtype, x_dtype, out_dtype):
 # ---- the frame losses in the epilogue of the decoder's last GEMM (vs_gemm_frame_loss) -----------------------------------------------------
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('act', ['sigmoid', 'none'])
-@pytest.mark.parametrize('B,G,N,K,offset', [(16, 6, 640, 128, 3), (7, 5, 520, 72, 0), (128, 2, 256, 64, 2)])
-def test_gemm_frame_loss_equals_gemm_then_fused_losses(dtype, act, B, G, N, K, offset, monkeypatch):
+@pytest.mark.parametrize('B,G,N,K,offset,tile', [(16, 6, 640, 128, 3, 'big'), (7, 5, 520, 72, 0, 'big'), (128, 2, 256, 64, 2, 'big'),
+                                                  (64, 8, 512, 128, 3, 'p8'), (70, 8, 776, 200, 0, 'p8'), (128, 6, 1024, 64, 2, 'p8')])
+def test_gemm_frame_loss_equals_gemm_then_fused_losses(dtype, act, B, G, N, K, offset, tile, monkeypatch):
     """ops.gemm_frame_loss == ops.gemm (fp32 frames) followed by ops.train_losses_fwd_grad: the gradient of the pre-activation and the
-    code gradients BIT-equal (same fp32 formula on the same values), the five scalars equal up to the order of the frame sums."""
+    code gradients BIT-equal (same fp32 formula on the same values), the five scalars equal up to the order of the frame sums.  `tile`: the
+    round-5 256 x 256 ring tile, or the staggered tile ('p8': tiles inside the matrix take its straight-line epilogue -- compiled for the
+    activations none / sigmoid --, tiles on the ragged edge the general one; 512 x 512 and 768 x 1024 are interior only)."""
     from spatiotemporal_variable_separation_amd import ops
     from oracle.detdata import det_uniform
     monkeypatch.setenv('VS_GEMM_BIG', '2')               # the 256x256 tile kernel whatever the size (the plan takes it at WaveEq size only)
+    monkeypatch.setenv('VS_GEMM_P8', '2' if tile == 'p8' else '0')
     T = G + 4
     h = ((det_uniform((B * G, K), 3) - 0.5) * 2).to(dtype).cuda()
     w = ((det_uniform((N, K), 5) - 0.5) * 0.2).to(dtype).cuda()
@@ -240,6 +244,7 @@ def test_gemm_frame_loss_equals_gemm_then_fused_losses(dtype, act, B, G, N, K, o
         assert torch.allclose(got[0][4:9], ref[0][4:9], rtol=2e-6, atol=0), (got[0][:9], ref[0][:9])
     # a problem the 256x256 tile does not take: the caller is told to use the two launches
     monkeypatch.setenv('VS_GEMM_BIG', '1')
+    monkeypatch.setenv('VS_GEMM_P8', '1')
     assert ops.gemm_frame_loss(h, w, bias, act, full, idx, G, s_old, s_new, t0, lam, False, up, dtype) is None
 
 
